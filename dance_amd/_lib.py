@@ -1,0 +1,71 @@
+"""ctypes binding of libdancehip.so (the C ABI declared in include/dance_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (``make -C dance_amd/csrc``).  There is no
+CPU fallback: if the shared object is missing, or no HIP device is visible when a kernel is requested,
+the call raises — a GPU box must never silently run something else.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdancehip.so")
+
+_lib = None
+
+
+class DanceHipError(RuntimeError):
+    """A libdancehip entry point returned a negative status."""
+
+
+def _declare(lib):
+    P = c_void_p  # every device pointer crosses the ABI as a raw address
+    i64, i32 = c_int64, c_int
+    sig = {
+        "dh_version": (c_int, []),
+        "dh_last_error_string": (c_char_p, []),
+        "dh_device_count": (c_int, []),
+        "dh_spmm_csr_f32": (c_int, [i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, i32, i32, P]),
+        "dh_csr_transpose_workspace_bytes": (c_size_t, [i64, i64, i64]),
+        "dh_csr_transpose": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
+        "dh_gemm_f32_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
+        "dh_gemm_f32": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
+        "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
+        "dh_colsum_f32_workspace_bytes": (c_size_t, [i64, i64]),
+        "dh_colsum_f32": (c_int, [i64, i64, P, i64, P, P, c_size_t, P]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return sig
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the library has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DanceHipError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(or `make -C dance_amd/csrc`) first; there is no CPU fallback")
+        lib = ctypes.CDLL(LIB_PATH)
+        lib._dh_signatures = _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    """Names this binding expects (used by the header/library consistency test)."""
+    return sorted(load()._dh_signatures)
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().dh_last_error_string().decode("utf-8", "replace")
+        raise DanceHipError(f"{what or 'libdancehip'} failed with status {status}: {msg}")
+
+
+def require_device():
+    """Raise unless a HIP device is visible (the product path never falls back to the CPU)."""
+    if load().dh_device_count() < 1:
+        raise DanceHipError("no HIP device visible: dance_amd kernels run on MI355X only (no CPU fallback)")

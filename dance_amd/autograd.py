@@ -1,0 +1,96 @@
+"""Autograd glue for the GCN layer op  out = act(A @ (X @ W) + b)  (SURVEY.md §0.3, §3.3).
+
+Forward and backward are sequences of libdancehip kernels on the current HIP stream:
+
+    forward : support = X W                 dh_gemm_f32            (MFMA f32)
+              out = act(A support + b)      dh_spmm_csr_f32        (HBM-bound gather, fused epilogue)
+    backward: G  = dY * (out > 0)           dh_relu_backward_f32   (only when act = relu)
+              dS = A^T G                    dh_spmm_csr_f32 on the cached transposed CSR
+              dW = X^T dS                   dh_gemm_f32 (trans_a, split-K)
+              dX = dS W^T                   dh_gemm_f32 (trans_b)  (only if X needs grad)
+              db = colsum(G)                dh_colsum_f32          (only with bias)
+
+This is the arithmetic torch autograd performs for the reference layers
+(dance/modules/single_modality/clustering/scdsc.py:496-501, dance/modules/spatial/spatial_domain/spagcn.py:357-363).
+"""
+from typing import Optional
+
+import torch
+
+from . import kernels
+from .graph import CSRGraph
+
+
+class _GCNLayerFn(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], graph: CSRGraph,
+                active: bool):
+        x = x.contiguous() if x.stride(-1) != 1 else x
+        w = weight.contiguous()
+        support = kernels.gemm(x, w)
+        out = kernels.spmm_csr(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, bias=bias,
+                               act=kernels.ACT_RELU if active else kernels.ACT_NONE)
+        ctx.graph, ctx.active, ctx.has_bias = graph, active, bias is not None
+        ctx.save_for_backward(x, w, out if active else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        x, w, out = ctx.saved_tensors
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dy = dy.contiguous() if dy.stride(-1) != 1 else dy
+        g = kernels.relu_backward(out, dy) if ctx.active else dy
+        dx = dw = db = None
+        if need_b:
+            db = kernels.colsum(g)
+        if need_x or need_w:
+            gt = ctx.graph.transpose()
+            ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols)
+            if need_w:
+                dw = kernels.gemm(x, ds, trans_a=True)
+            if need_x:
+                dx = kernels.gemm(ds, w, trans_b=True)
+        return dx, dw, db, None, None
+
+
+def gcn_layer(x: torch.Tensor, weight: torch.Tensor, graph: CSRGraph, bias: Optional[torch.Tensor] = None,
+              active: bool = False) -> torch.Tensor:
+    """act(A @ (x @ weight) + bias) with a hand-written HIP forward and backward."""
+    return _GCNLayerFn.apply(x, weight, bias, graph, active)
+
+
+class _DenseAdjLayerFn(torch.autograd.Function):
+    """Same op for a DENSE adjacency (SpaGCN passes a dense N x N FloatTensor, spagcn.py:497,359)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, adj):
+        x = x.contiguous() if x.stride(-1) != 1 else x
+        w = weight.contiguous()
+        adj = adj.contiguous() if adj.stride(-1) != 1 else adj
+        support = kernels.gemm(x, w)
+        out = kernels.gemm(adj, support)
+        if bias is not None:
+            out += bias  # broadcast add (torch elementwise on the same stream)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, adj)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, adj = ctx.saved_tensors
+        dy = dy.contiguous() if dy.stride(-1) != 1 else dy
+        dx = dw = db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = kernels.colsum(dy)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            ds = kernels.gemm(adj, dy, trans_a=True)
+            if ctx.needs_input_grad[1]:
+                dw = kernels.gemm(x, ds, trans_a=True)
+            if ctx.needs_input_grad[0]:
+                dx = kernels.gemm(ds, w, trans_b=True)
+        return dx, dw, db, None
+
+
+def dense_adj_layer(x, weight, adj, bias=None):
+    return _DenseAdjLayerFn.apply(x, weight, bias, adj)

@@ -1,0 +1,108 @@
+// Small streaming kernels of the layers' backward pass (HBM-bound, one touch per element).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// G = dY where Y > 0 else 0  (autograd of F.relu; threshold_backward semantics: Y <= 0 -> 0)
+template <bool VEC4>
+__global__ __launch_bounds__(256) void relu_backward_kernel(int64_t n_rows, int64_t width,
+                                                            const float* __restrict__ Y, int64_t ldy,
+                                                            const float* __restrict__ dY, int64_t lddy,
+                                                            float* __restrict__ G, int64_t ldg) {
+  if constexpr (VEC4) {
+    const int64_t wv = width / 4, total = n_rows * wv;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / wv, c = (i % wv) * 4;
+      const f32x4 y = *reinterpret_cast<const f32x4*>(Y + r * ldy + c);
+      const f32x4 d = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dY + r * lddy + c));
+      f32x4 g;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) g[k] = y[k] > 0.f ? d[k] : 0.f;
+      *reinterpret_cast<f32x4*>(G + r * ldg + c) = g;
+    }
+  } else {
+    const int64_t total = n_rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+      const int64_t r = i / width, c = i % width;
+      G[r * ldg + c] = Y[r * ldy + c] > 0.f ? dY[r * lddy + c] : 0.f;
+    }
+  }
+}
+
+// Column sums, pass 1: block b sums rows [b*rows_per_block, ...) for all columns -> partial[b][width]
+__global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n_rows, int64_t width,
+                                                             const float* __restrict__ X, int64_t ldx,
+                                                             int64_t rows_per_block,
+                                                             float* __restrict__ partial) {
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = min(n_rows, r0 + rows_per_block);
+  for (int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x; c < width; c += (int64_t)gridDim.y * 256) {
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + c];
+    partial[(int64_t)blockIdx.x * width + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(int64_t n_blocks, int64_t width,
+                                                           const float* __restrict__ partial,
+                                                           float* __restrict__ out) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= width) return;
+  float s = 0.f;
+  for (int64_t b = 0; b < n_blocks; ++b) s += partial[b * width + c];
+  out[c] = s;
+}
+
+constexpr int64_t kColsumRows = 512;
+
+}  // namespace
+
+extern "C" int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* Y, int64_t ldy,
+                                    const float* dY, int64_t lddy, float* G, int64_t ldg,
+                                    dh_stream_t stream) {
+  if (n_rows < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_relu_backward_f32: negative size");
+  if (n_rows == 0 || width == 0) return DH_OK;
+  if (!Y || !dY || !G) return dh::fail(DH_ERR_INVALID, "dh_relu_backward_f32: null pointer");
+  if (ldy < width || lddy < width || ldg < width)
+    return dh::fail(DH_ERR_INVALID, "dh_relu_backward_f32: leading dimension < width");
+  hipStream_t st = dh::as_stream(stream);
+  const bool vec = width % 4 == 0 && ldy % 4 == 0 && lddy % 4 == 0 && ldg % 4 == 0 &&
+                   dh::aligned16(Y) && dh::aligned16(dY) && dh::aligned16(G);
+  const int64_t work = vec ? n_rows * (width / 4) : n_rows * width;
+  const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 8192 ? dh::ceil_div(work, 256) : 8192);
+  if (vec)
+    hipLaunchKernelGGL(relu_backward_kernel<true>, dim3(grid), dim3(256), 0, st, n_rows, width, Y, ldy, dY, lddy, G, ldg);
+  else
+    hipLaunchKernelGGL(relu_backward_kernel<false>, dim3(grid), dim3(256), 0, st, n_rows, width, Y, ldy, dY, lddy, G, ldg);
+  return dh::check_launch("dh_relu_backward_f32");
+}
+
+extern "C" size_t dh_colsum_f32_workspace_bytes(int64_t n_rows, int64_t width) {
+  if (n_rows <= 0 || width <= 0) return 0;
+  return (size_t)dh::ceil_div(n_rows, kColsumRows) * (size_t)width * sizeof(float);
+}
+
+extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, float* out,
+                             void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  if (n_rows < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_colsum_f32: negative size");
+  if (width == 0) return DH_OK;
+  if (!out) return dh::fail(DH_ERR_INVALID, "dh_colsum_f32: null out");
+  hipStream_t st = dh::as_stream(stream);
+  if (n_rows == 0) {
+    if (hipMemsetAsync(out, 0, width * sizeof(float), st) != hipSuccess)
+      return dh::fail(DH_ERR_LAUNCH, "dh_colsum_f32: memset failed");
+    return DH_OK;
+  }
+  if (!X || ldx < width) return dh::fail(DH_ERR_INVALID, "dh_colsum_f32: bad X/ldx");
+  const size_t need = dh_colsum_f32_workspace_bytes(n_rows, width);
+  if (!workspace || workspace_bytes < need)
+    return dh::fail(DH_ERR_WORKSPACE, "dh_colsum_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+  const int64_t nb = dh::ceil_div(n_rows, kColsumRows);
+  float* partial = static_cast<float*>(workspace);
+  dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 256));
+  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
+  return dh::check_launch("dh_colsum_f32");
+}

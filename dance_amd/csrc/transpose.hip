@@ -1,0 +1,123 @@
+// Deterministic CSR transpose (CSR of A^T) for the backward SpMM.
+//
+// The backward pass of Y = A Z is dZ = A^T dY.  Instead of scattering with float atomics
+// (non-deterministic summation order), the transposed CSR is built once per graph and the
+// same gather SpMM kernel is reused.  Graph set-up, not the per-epoch hot loop:
+//   1. stable LSD radix sort of (key = column, value = nnz position) — rocPRIM device sort,
+//      the ROCm library primitive for exactly this; stable + input positions ascending makes
+//      every output row ordered by source row, i.e. bit-identical to scipy's tocsc();
+//   2. out_rowptr[j] = lower_bound(sorted columns, j)            (hand-written, one thread per j)
+//   3. out_col[p] = row owning nnz position perm[p] (upper_bound on rowptr), out_val gathered.
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void iota_kernel(int64_t n, int32_t* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    out[i] = (int32_t)i;
+}
+
+// out_rowptr[j] = number of sorted keys < j, j in [0, n_cols]
+__global__ __launch_bounds__(256) void rowptr_from_sorted_kernel(int64_t n_cols, int64_t nnz,
+                                                                 const int32_t* __restrict__ keys,
+                                                                 int32_t* __restrict__ out_rowptr) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j > n_cols) return;
+  int64_t lo = 0, hi = nnz;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (keys[mid] < (int32_t)j) lo = mid + 1; else hi = mid;
+  }
+  out_rowptr[j] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(256) void gather_transposed_kernel(int64_t n_rows, int64_t nnz,
+                                                                const int32_t* __restrict__ rowptr,
+                                                                const float* __restrict__ val,
+                                                                const int32_t* __restrict__ perm,
+                                                                int32_t* __restrict__ out_col,
+                                                                float* __restrict__ out_val) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * 256) {
+    const int32_t e = perm[p];
+    // row i with rowptr[i] <= e < rowptr[i+1]  (skips empty rows)
+    int64_t lo = 0, hi = n_rows;  // invariant: rowptr[lo] <= e, rowptr[hi] > e
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (rowptr[mid] <= e) lo = mid; else hi = mid;
+    }
+    out_col[p] = (int32_t)lo;
+    if (out_val) out_val[p] = val[e];
+  }
+}
+
+int end_bit_for(int64_t n_cols) {
+  int b = 1;
+  while (((int64_t)1 << b) < n_cols && b < 31) ++b;
+  return b;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t sort_temp_bytes(int64_t nnz, int64_t n_cols) {
+  size_t bytes = 0;
+  int32_t* dummy = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, dummy, dummy, dummy, dummy, (size_t)nnz, 0,
+                                           end_bit_for(n_cols), (hipStream_t)0);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return bytes;
+}
+
+}  // namespace
+
+extern "C" size_t dh_csr_transpose_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  (void)n_rows;
+  if (nnz <= 0) return 0;
+  return 2 * align256((size_t)nnz * sizeof(int32_t)) + align256(sort_temp_bytes(nnz, n_cols)) + 256;
+}
+
+extern "C" int dh_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, const int32_t* rowptr,
+                                const int32_t* col, const float* val, int32_t* out_rowptr,
+                                int32_t* out_col, float* out_val, int32_t* out_perm, void* workspace,
+                                size_t workspace_bytes, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0 || nnz < 0) return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: negative size");
+  if (!out_rowptr) return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: null out_rowptr");
+  if ((val == nullptr) != (out_val == nullptr))
+    return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: val and out_val must both be given or both NULL");
+  hipStream_t st = dh::as_stream(stream);
+  if (nnz == 0) {
+    if (hipMemsetAsync(out_rowptr, 0, (size_t)(n_cols + 1) * sizeof(int32_t), st) != hipSuccess)
+      return dh::fail(DH_ERR_LAUNCH, "dh_csr_transpose: memset failed");
+    return DH_OK;
+  }
+  if (!rowptr || !col || !out_col || !out_perm)
+    return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: null pointer");
+  const size_t need = dh_csr_transpose_workspace_bytes(n_rows, n_cols, nnz);
+  if (!workspace || workspace_bytes < need)
+    return dh::fail(DH_ERR_WORKSPACE, "dh_csr_transpose: workspace %zu < %zu bytes", workspace_bytes, need);
+
+  char* ws = static_cast<char*>(workspace);
+  ws = reinterpret_cast<char*>(align256(reinterpret_cast<size_t>(ws)));
+  int32_t* keys_sorted = reinterpret_cast<int32_t*>(ws);
+  ws += align256((size_t)nnz * sizeof(int32_t));
+  int32_t* positions = reinterpret_cast<int32_t*>(ws);
+  ws += align256((size_t)nnz * sizeof(int32_t));
+  size_t temp_bytes = sort_temp_bytes(nnz, n_cols);
+
+  const unsigned g = (unsigned)(dh::ceil_div(nnz, 256) < 8192 ? dh::ceil_div(nnz, 256) : 8192);
+  hipLaunchKernelGGL(iota_kernel, dim3(g), dim3(256), 0, st, nnz, positions);
+  hipError_t e = rocprim::radix_sort_pairs(ws, temp_bytes, col, keys_sorted, positions, out_perm, (size_t)nnz, 0,
+                                           end_bit_for(n_cols), st);
+  if (e != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_csr_transpose: radix sort: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(rowptr_from_sorted_kernel, dim3((unsigned)dh::ceil_div(n_cols + 1, 256)), dim3(256), 0, st,
+                     n_cols, nnz, keys_sorted, out_rowptr);
+  hipLaunchKernelGGL(gather_transposed_kernel, dim3(g), dim3(256), 0, st, n_rows, nnz, rowptr, val, out_perm,
+                     out_col, out_val);
+  return dh::check_launch("dh_csr_transpose");
+}

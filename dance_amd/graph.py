@@ -1,0 +1,107 @@
+"""Device-resident CSR adjacency for message passing (rows = destination nodes, columns = source nodes).
+
+The reference hands its GCN layers a ``torch.sparse`` COO tensor built from a scipy matrix
+(dance/transforms/preprocess.py:526-532, used at dance/modules/single_modality/clustering/scdsc.py:244) or a
+dense FloatTensor (dance/modules/spatial/spatial_domain/spagcn.py:497).  ``CSRGraph`` is what our kernels
+consume: int32 ``rowptr``/``col`` + f32 ``val`` in HBM, plus the lazily built CSR of the transpose used by
+the backward SpMM (deterministic gather instead of atomic scatter).
+"""
+import weakref
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import kernels
+
+
+class CSRGraph:
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], n_rows: int,
+                 n_cols: int, *, symmetric: bool = False):
+        if rowptr.dtype != torch.int32 or col.dtype != torch.int32:
+            raise TypeError("CSRGraph wants int32 rowptr/col")
+        if rowptr.numel() != n_rows + 1:
+            raise ValueError(f"rowptr has {rowptr.numel()} entries, expected {n_rows + 1}")
+        if val is not None and val.numel() != col.numel():
+            raise ValueError("val and col differ in length")
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self.n_rows, self.n_cols = int(n_rows), int(n_cols)
+        self.symmetric = bool(symmetric)  # value-symmetric square matrix: A^T == A, no transpose needed
+        self._t: Optional["CSRGraph"] = None
+
+    # ---- constructors --------------------------------------------------------------------------------------
+    @classmethod
+    def from_scipy(cls, mat, device="cuda", *, symmetric: bool = False) -> "CSRGraph":
+        """Host scipy sparse matrix -> device CSR (index order preserved after canonical CSR conversion)."""
+        import scipy.sparse as sp
+        csr = sp.csr_matrix(mat)
+        csr.sum_duplicates()
+        csr.sort_indices()
+        if csr.nnz >= 2**31:
+            raise ValueError("nnz >= 2^31 is not supported by the int32 CSR layout")
+        rowptr = torch.from_numpy(csr.indptr.astype(np.int32)).to(device)
+        col = torch.from_numpy(csr.indices.astype(np.int32)).to(device)
+        val = torch.from_numpy(csr.data.astype(np.float32)).to(device)
+        return cls(rowptr, col, val, csr.shape[0], csr.shape[1], symmetric=symmetric)
+
+    @classmethod
+    def from_torch_sparse(cls, adj: torch.Tensor, device=None) -> "CSRGraph":
+        """torch sparse COO/CSR tensor (what the reference layers receive) -> device CSR.
+
+        Duplicate COO entries are summed (``coalesce``), which is what ``torch.spmm`` computes.
+        """
+        if adj.layout == torch.sparse_coo:
+            adj = adj.coalesce().to_sparse_csr()
+        elif adj.layout != torch.sparse_csr:
+            raise TypeError(f"unsupported adjacency layout {adj.layout}")
+        device = device or (adj.device if adj.is_cuda else "cuda")
+        rowptr = adj.crow_indices().to(torch.int32).to(device)
+        col = adj.col_indices().to(torch.int32).to(device)
+        val = adj.values().to(torch.float32).to(device)
+        return cls(rowptr, col, val, adj.shape[0], adj.shape[1])
+
+    # ---- views ---------------------------------------------------------------------------------------------
+    @property
+    def nnz(self) -> int:
+        return int(self.col.numel())
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def transpose(self) -> "CSRGraph":
+        """CSR of A^T, built once on the device (dh_csr_transpose) and cached."""
+        if self.symmetric:
+            return self
+        if self._t is None:
+            rp, c, v, _ = kernels.csr_transpose(self.rowptr, self.col, self.val, self.n_rows, self.n_cols)
+            self._t = CSRGraph(rp, c, v, self.n_cols, self.n_rows)
+            self._t._t = self
+        return self._t
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        val = self.val.cpu().numpy() if self.val is not None else np.ones(self.nnz, dtype=np.float32)
+        return sp.csr_matrix((val, self.col.cpu().numpy(), self.rowptr.cpu().numpy()),
+                             shape=(self.n_rows, self.n_cols))
+
+
+_CACHE = weakref.WeakKeyDictionary()
+
+
+def as_graph(adj, device=None) -> CSRGraph:
+    """Accept what the reference layers accept (torch sparse tensor) or a ready CSRGraph.
+
+    Conversions are cached per adjacency object: the reference passes the same ``adj`` every epoch
+    (scdsc.py:257-288), so the CSR and its transpose are built once.
+    """
+    if isinstance(adj, CSRGraph):
+        return adj
+    if isinstance(adj, torch.Tensor) and adj.layout in (torch.sparse_coo, torch.sparse_csr):
+        g = _CACHE.get(adj)
+        if g is None:
+            g = CSRGraph.from_torch_sparse(adj, device)
+            _CACHE[adj] = g
+        return g
+    raise TypeError(f"cannot interpret {type(adj)} as a sparse adjacency")

@@ -1,0 +1,108 @@
+/*
+ * dance_hip.h — C ABI of libdancehip.so, the MI355X (gfx950) kernels behind DANCE's GNN
+ * message-passing hot path.
+ *
+ * The reference (OmicsML/dance) has no FFI of its own: on this path its Python layers drop
+ * straight into third-party native kernels (torch sparse / DGL / numba / scanpy / sklearn).
+ * Each entry point below names the reference call site whose native work it replaces
+ * (paths relative to the reference tree).  INTEGRATION.md shows the ctypes binding a DANCE
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless its name ends in _host; the library never owns
+ *    caller memory and allocates nothing persistent (workspaces are passed in, their sizes
+ *    come from the *_workspace_bytes queries);
+ *  - dense matrices are row-major with an explicit leading dimension in ELEMENTS;
+ *  - CSR graphs use int32 row pointers and int32 column indices (nnz < 2^31), rows = the
+ *    DESTINATION nodes of message passing, columns = the SOURCE nodes;
+ *  - every launcher takes the hipStream_t to enqueue on (as void*), is asynchronous and
+ *    returns 0 on success or a negative dh_status; dh_last_error_string() describes the last
+ *    failure on the calling thread.  Nothing throws across the ABI.
+ */
+#ifndef DANCE_HIP_H
+#define DANCE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dh_stream_t; /* hipStream_t */
+
+#if defined(DH_BUILDING)
+#define DH_API __attribute__((visibility("default")))
+#else
+#define DH_API
+#endif
+
+enum dh_status {
+  DH_OK = 0,
+  DH_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unsupported combo) */
+  DH_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch */
+  DH_ERR_WORKSPACE = -3, /* workspace too small */
+  DH_ERR_NO_DEVICE = -4  /* no gfx950 device visible */
+};
+
+enum dh_act { DH_ACT_NONE = 0, DH_ACT_RELU = 1 };
+enum dh_reduce { DH_REDUCE_SUM = 0, DH_REDUCE_MEAN = 1 };
+enum dh_metric { DH_METRIC_EUCLIDEAN = 0, DH_METRIC_PEARSON = 1, DH_METRIC_SPEARMAN = 2 };
+
+/* ---- library ---------------------------------------------------------------------------- */
+DH_API int dh_version(void);                     /* 10000*major + 100*minor + patch                 */
+DH_API const char* dh_last_error_string(void);   /* thread-local, never NULL                        */
+DH_API int dh_device_count(void);                /* number of visible HIP devices (0 on a CPU box)  */
+
+/* ---- K1/K2/K5: CSR SpMM with fused epilogue ------------------------------------------------
+ * Y[i,:] = act( rowscale[i] * reduce_{e in row i} ( val[e] * colscale[col[e]] * Z[col[e],:] ) + bias )
+ * Replaces torch.spmm(adj, support) at dance/modules/single_modality/clustering/scdsc.py:498 and
+ * dance/modules/spatial/spatial_domain/spagcn.py:359 (+bias :360-361, relu scdsc.py:499-500),
+ * its autograd transpose product (run on the transposed CSR), and DGL's
+ * update_all(u_mul_e, sum|mean) with the GraphConv degree norms at
+ * dance/modules/single_modality/clustering/graphsc.py:444-449,462-476.
+ * val / rowscale / colscale / bias may be NULL (= 1, 1, 1, 0).  reduce=MEAN divides by the row's
+ * edge count (0 for an empty row, DGL fn.mean semantics).                                      */
+DH_API int dh_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
+                    const int32_t* rowptr, const int32_t* col, const float* val,
+                    const float* rowscale, const float* colscale,
+                    const float* Z, int64_t ldz, float* Y, int64_t ldy,
+                    const float* bias, int act, int reduce, dh_stream_t stream);
+
+/* ---- K2: deterministic CSR transpose (CSR of A^T) ------------------------------------------
+ * out_perm[p] = index into the input nnz arrays of output entry p; output rows are ordered by
+ * input position, i.e. exactly a stable sort by column (what scipy's tocsc gives).
+ * val/out_val may both be NULL (pattern only).  workspace: dh_csr_transpose_workspace_bytes. */
+DH_API size_t dh_csr_transpose_workspace_bytes(int64_t n_rows, int64_t n_cols, int64_t nnz);
+DH_API int dh_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz,
+                     const int32_t* rowptr, const int32_t* col, const float* val,
+                     int32_t* out_rowptr, int32_t* out_col, float* out_val, int32_t* out_perm,
+                     void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* ---- K3: dense feature GEMM on the f32 matrix cores (v_mfma_f32_32x32x2_f32) ---------------
+ * C[M,N] (+)= op(A)[M,K] * op(B)[K,N]; exact f32 (one rounding per product, k-ordered chain).
+ * trans_a=0: A is [M,K] (lda>=K); trans_a=1: A is stored [K,M] (lda>=M).  Same for B.
+ * Replaces torch.mm(features, self.weight) (scdsc.py:497, spagcn.py:358) and its autograd
+ * products dW = X^T dZ (trans_a=1, split over K) and dX = dZ W^T (trans_b=1).
+ * accumulate != 0 adds into C.  workspace (split-K partial slabs): dh_gemm_f32_workspace_bytes;
+ * may be NULL when that query returns 0.                                                       */
+DH_API size_t dh_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b);
+DH_API int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
+                const float* A, int64_t lda, const float* B, int64_t ldb,
+                float* C, int64_t ldc, int accumulate,
+                void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* ---- elementwise / reductions used by the layers' backward ---------------------------------
+ * dh_relu_backward_f32: G = dY where Y > 0 else 0 (autograd of F.relu, scdsc.py:499-500).
+ * dh_colsum_f32: out[j] = sum_i X[i,j] (bias gradient of spagcn.py:360-361); deterministic
+ * two-pass reduction, workspace from dh_colsum_f32_workspace_bytes.                            */
+DH_API int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* Y, int64_t ldy,
+                         const float* dY, int64_t lddy, float* G, int64_t ldg, dh_stream_t stream);
+DH_API size_t dh_colsum_f32_workspace_bytes(int64_t n_rows, int64_t width);
+DH_API int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, float* out,
+                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DANCE_HIP_H */

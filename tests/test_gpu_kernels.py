@@ -1,0 +1,149 @@
+"""GPU: every libdancehip kernel of the GCN path, called through the C ABI, against CPU references
+(scipy / float64 numpy) on seeded inputs.  Integer outputs must be bit-exact; f32 within 1e-4 max-norm rel
+(SURVEY.md §8c); tolerances are written per test."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = 1e-4
+
+
+def _rand_csr(n_rows, n_cols, avg_deg, seed, long_row=None, empty_rows=()):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(avg_deg, n_rows)
+    if long_row is not None:
+        deg[long_row[0]] = long_row[1]
+    for r in empty_rows:
+        deg[r] = 0
+    deg = np.minimum(deg, n_cols)
+    indptr = np.zeros(n_rows + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum(deg)
+    indices = np.concatenate([np.sort(rng.choice(n_cols, d, replace=False)) for d in deg]) if indptr[-1] else np.zeros(0, int)
+    data = rng.uniform(0.1, 1.0, indptr[-1]).astype(np.float32)
+    return sp.csr_matrix((data, indices.astype(np.int32), indptr.astype(np.int32)), shape=(n_rows, n_cols))
+
+
+def _dev_csr(a, dev):
+    return (torch.from_numpy(a.indptr.astype(np.int32)).to(dev), torch.from_numpy(a.indices.astype(np.int32)).to(dev),
+            torch.from_numpy(a.data.astype(np.float32)).to(dev))
+
+
+@pytest.mark.parametrize("width", [512, 256, 128, 50, 33, 7, 1, 300, 1000])
+def test_spmm_widths(cuda_device, width):
+    from dance_amd import kernels
+    a = _rand_csr(777, 613, 9, seed=width, long_row=(5, 200), empty_rows=(0, 10, 776))
+    z = np.random.default_rng(1).standard_normal((613, width)).astype(np.float32)
+    rp, c, v = _dev_csr(a, cuda_device)
+    y = kernels.spmm_csr(rp, c, v, torch.from_numpy(z).to(cuda_device))
+    ref = (a.astype(np.float64) @ z.astype(np.float64))
+    assert rel_err(y.cpu().numpy(), ref) < F32_TOL
+    assert np.all(y.cpu().numpy()[[0, 10, 776]] == 0)  # empty rows -> exactly 0
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("width", [64, 50])
+def test_spmm_epilogue(cuda_device, reduce, width):
+    from dance_amd import kernels
+    rng = np.random.default_rng(11)
+    a = _rand_csr(300, 200, 6, seed=5, empty_rows=(3,))
+    z = rng.standard_normal((200, width)).astype(np.float32)
+    bias = rng.standard_normal(width).astype(np.float32)
+    rs = rng.uniform(0.5, 2, 300).astype(np.float32)
+    cs = rng.uniform(0.5, 2, 200).astype(np.float32)
+    rp, c, v = _dev_csr(a, cuda_device)
+    t = lambda x: torch.from_numpy(x).to(cuda_device)
+    y = kernels.spmm_csr(rp, c, v, t(z), rowscale=t(rs), colscale=t(cs), bias=t(bias), act=kernels.ACT_RELU,
+                         reduce=kernels.REDUCE_MEAN if reduce == "mean" else kernels.REDUCE_SUM)
+    agg = a.astype(np.float64) @ (cs[:, None].astype(np.float64) * z)
+    if reduce == "mean":
+        deg = np.diff(a.indptr)
+        agg = agg / np.maximum(deg, 1)[:, None]
+    ref = np.maximum(rs[:, None] * agg + bias, 0)
+    assert rel_err(y.cpu().numpy(), ref) < F32_TOL
+
+
+def test_spmm_unweighted_and_strided(cuda_device):
+    from dance_amd import kernels
+    a = _rand_csr(100, 100, 5, seed=2)
+    big = torch.randn(100, 96, device=cuda_device)
+    z = big[:, 16:80]  # row stride 96, width 64: leading dimension != width
+    rp, c, _ = _dev_csr(a, cuda_device)
+    y = kernels.spmm_csr(rp, c, None, z)
+    pattern = sp.csr_matrix((np.ones_like(a.data), a.indices, a.indptr), shape=a.shape)
+    assert rel_err(y.cpu().numpy(), pattern.astype(np.float64) @ z.cpu().numpy().astype(np.float64)) < F32_TOL
+
+
+@pytest.mark.parametrize("shape", [(300, 200, 9), (64, 5000, 3), (5000, 64, 40), (1, 1, 1), (10, 10, 0)])
+def test_csr_transpose_bit_exact(cuda_device, shape):
+    from dance_amd import kernels
+    n_rows, n_cols, deg = shape
+    a = _rand_csr(n_rows, n_cols, deg, seed=sum(shape)) if deg else sp.csr_matrix((n_rows, n_cols), dtype=np.float32)
+    rp, c, v = _dev_csr(a, cuda_device)
+    rpt, ct, vt, perm = kernels.csr_transpose(rp, c, v, n_rows, n_cols)
+    ref = a.tocsc()  # stable by column == CSR of A^T ordered by source row
+    assert np.array_equal(rpt.cpu().numpy(), ref.indptr.astype(np.int32))
+    assert np.array_equal(ct.cpu().numpy(), ref.indices.astype(np.int32))
+    assert np.array_equal(vt.cpu().numpy(), ref.data.astype(np.float32))
+    if a.nnz:
+        assert np.array_equal(a.data[perm.cpu().numpy()], ref.data)
+
+
+GEMM_SHAPES = [
+    (257, 130, 100, False, False), (128, 128, 32, False, False), (1000, 512, 2000, False, False),
+    (333, 50, 50, False, False),  # unaligned leading dimensions (SpaGCN 50->50)
+    (200, 64, 5000, True, False),  # dW-style, split-K
+    (2000, 512, 9000, True, False),
+    (77, 33, 4100, True, False),
+    (300, 200, 64, False, True),  # dX-style
+    (129, 50, 31, False, True), (65, 70, 129, True, True), (1, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", GEMM_SHAPES)
+def test_gemm_f32(cuda_device, M, N, K, ta, tb):
+    from dance_amd import kernels
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a = rng.standard_normal((K, M) if ta else (M, K)).astype(np.float32)
+    b = rng.standard_normal((N, K) if tb else (K, N)).astype(np.float32)
+    c = kernels.gemm(torch.from_numpy(a).to(cuda_device), torch.from_numpy(b).to(cuda_device), trans_a=ta, trans_b=tb)
+    ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    assert c.shape == ref.shape
+    assert rel_err(c.cpu().numpy(), ref) < 1e-5  # exact-f32 MFMA chain: f32 round-off only
+
+
+def test_gemm_transpose_detecting_and_accumulate(cuda_device):
+    # asymmetric operands (A = I-like selector, B[i][j] = i*1000 + j) catch swapped C rows/cols
+    from dance_amd import kernels
+    n = 160
+    a = torch.eye(n, device=cuda_device)
+    b = (torch.arange(n, device=cuda_device)[:, None] * 1000 + torch.arange(n, device=cuda_device)[None, :]).float()
+    c = kernels.gemm(a, b)
+    assert torch.equal(c, b)
+    c2 = kernels.gemm(a, b, out=c.clone(), accumulate=True)
+    assert torch.equal(c2, 2 * b)
+
+
+def test_relu_backward_and_colsum(cuda_device):
+    from dance_amd import kernels
+    for shape in [(1000, 512), (37, 50), (5, 3)]:
+        y = torch.randn(*shape, device=cuda_device)
+        y[y.abs() < 0.1] = 0  # exact zeros: gradient must be 0 there (threshold_backward)
+        dy = torch.randn(*shape, device=cuda_device)
+        g = kernels.relu_backward(y, dy)
+        assert torch.equal(g, torch.where(y > 0, dy, torch.zeros_like(dy)))
+        s = kernels.colsum(dy)
+        assert rel_err(s.cpu().numpy(), dy.cpu().numpy().astype(np.float64).sum(0)) < 1e-5
+
+
+def test_errors_are_loud(cuda_device):
+    from dance_amd import _lib, kernels
+    with pytest.raises(_lib.DanceHipError):
+        kernels.gemm(torch.zeros(4, 4), torch.zeros(4, 4))  # CPU tensors are refused, no fallback
+    lib = _lib.load()
+    assert lib.dh_spmm_csr_f32(4, 4, 4, None, None, None, None, None, None, 4, None, 4, None, 0, 0, None) < 0
+    assert b"null" in lib.dh_last_error_string()

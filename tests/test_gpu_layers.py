@@ -1,0 +1,75 @@
+"""GPU parity of the mirrored layer classes (dance_amd.modules...) against (i) golden vectors produced by the
+reference's own classes and (ii) the CPU oracle on larger seeded inputs; fp32 within 1e-4 max-norm relative."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import rel_err
+from oracle import layers as ol
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _adj(g):
+    n = g["x"].shape[0]
+    return sp.csr_matrix((g["adj_data"], g["adj_indices"], g["adj_indptr"]), shape=(n, n))
+
+
+@pytest.mark.parametrize("active,tag", [(True, "gnn_act"), (False, "gnn_lin")])
+@pytest.mark.parametrize("adj_kind", ["torch_coo", "csrgraph"])
+def test_gnnlayer_golden(cuda_device, golden_gcn, active, tag, adj_kind):
+    from dance_amd.graph import CSRGraph
+    from dance_amd.modules.single_modality.clustering.scdsc import GNNLayer
+    g = golden_gcn
+    layer = GNNLayer(g["x"].shape[1], g["w"].shape[1]).to(cuda_device)
+    layer.weight.data = torch.from_numpy(g["w"].copy()).to(cuda_device)
+    adj = ol.scipy_to_torch_coo(_adj(g)).to(cuda_device) if adj_kind == "torch_coo" else CSRGraph.from_scipy(_adj(g), cuda_device)
+    x = torch.from_numpy(g["x"].copy()).to(cuda_device).requires_grad_(True)
+    y = layer(x, adj, active=active)
+    y.backward(torch.from_numpy(g["dy"]).to(cuda_device))
+    assert rel_err(y.detach().cpu().numpy(), g[f"{tag}_out"]) < TOL
+    assert rel_err(layer.weight.grad.cpu().numpy(), g[f"{tag}_dW"]) < TOL
+    assert rel_err(x.grad.cpu().numpy(), g[f"{tag}_dX"]) < TOL
+
+
+@pytest.mark.parametrize("tag", ["gc_sparse", "gc_dense"])
+def test_graphconvolution_golden(cuda_device, golden_gcn, tag):
+    from dance_amd.modules.spatial.spatial_domain.spagcn import GraphConvolution
+    g = golden_gcn
+    layer = GraphConvolution(g["x"].shape[1], g["w"].shape[1]).to(cuda_device)
+    assert repr(layer) == f"GraphConvolution({g['x'].shape[1]} -> {g['w'].shape[1]})"
+    layer.weight.data = torch.from_numpy(g["w"].copy()).to(cuda_device)
+    layer.bias.data = torch.from_numpy(g["b"].copy()).to(cuda_device)
+    adj = (ol.scipy_to_torch_coo(_adj(g)) if tag == "gc_sparse" else torch.from_numpy(g["adj_dense"])).to(cuda_device)
+    x = torch.from_numpy(g["x"].copy()).to(cuda_device).requires_grad_(True)
+    y = layer(x, adj)
+    y.backward(torch.from_numpy(g["dy"]).to(cuda_device))
+    assert rel_err(y.detach().cpu().numpy(), g[f"{tag}_out"]) < TOL
+    assert rel_err(layer.weight.grad.cpu().numpy(), g[f"{tag}_dW"]) < TOL
+    assert rel_err(layer.bias.grad.cpu().numpy(), g[f"{tag}_db"]) < TOL
+    assert rel_err(x.grad.cpu().numpy(), g[f"{tag}_dX"]) < TOL
+
+
+@pytest.mark.parametrize("n,fin,fout,k", [(3000, 2000, 512, 15), (20000, 200, 50, 15), (5000, 50, 50, 6)])
+def test_gnnlayer_vs_oracle_medium(cuda_device, n, fin, fout, k):
+    """Seeded rand-k graph (SURVEY.md §8d 'rand-k15': k distinct random in-neighbours, values 1/k)."""
+    from dance_amd.graph import CSRGraph
+    from dance_amd.modules.single_modality.clustering.scdsc import GNNLayer
+    rng = np.random.default_rng(n + fin)
+    x = rng.standard_normal((n, fin)).astype(np.float32)
+    w = (rng.standard_normal((fin, fout)) / np.sqrt(fin)).astype(np.float32)
+    dy = rng.standard_normal((n, fout)).astype(np.float32)
+    cols = np.stack([rng.choice(n, k, replace=False) for _ in range(n)])
+    cols.sort(axis=1)
+    adj = sp.csr_matrix((np.full(n * k, 1.0 / k, np.float32), cols.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+    ref = ol.gcn_layer_fwd_bwd(x, adj, w, dy, active=True, x_requires_grad=True)
+    layer = GNNLayer(fin, fout).to(cuda_device)
+    layer.weight.data = torch.from_numpy(w).to(cuda_device)
+    xt = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
+    y = layer(xt, CSRGraph.from_scipy(adj, cuda_device))
+    y.backward(torch.from_numpy(dy).to(cuda_device))
+    assert rel_err(y.detach().cpu().numpy(), ref["out"]) < TOL
+    assert rel_err(layer.weight.grad.cpu().numpy(), ref["dW"]) < TOL
+    assert rel_err(xt.grad.cpu().numpy(), ref["dX"]) < TOL
