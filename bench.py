@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: cells/sec through one GCN layer forward+backward (scDSC GNNLayer semantics,
+2000 genes -> 512, fp32) on a synthetic 1M-cell x 2k-gene k=15 graph (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = relu(A (X W)) forward, then backward from a fixed random dY producing dW (X is a non-grad leaf, as
+in the reference: scdsc.py:247,286-288).  With N > 1 the 1M cells are sharded by destination range
+(dance_amd/sharding.py): strong scaling, RCCL all-gather of the transformed features / output gradients and an
+all-reduce of dW inside the timed region.  Inputs are generated on the device and resident in HBM before
+the timed region; graph set-up (CSR transpose) is outside it, as graph construction is in the reference.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_CELLS, N_GENES, N_HIDDEN, K_NEIGH = 1_000_000, 2000, 512, 15
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+PEAK_MFMA_F32_TFLOPS = 157.3  # dense f32-input MFMA peak
+
+
+def synth_features(n_rows, n_genes, device, seed):
+    """Sparse-ish log-normalised expression, standardised per gene and clipped, made on device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = torch.empty((n_rows, n_genes), dtype=torch.float32, device=device)
+    step = 125_000
+    for lo in range(0, n_rows, step):
+        hi = min(n_rows, lo + step)
+        u = torch.rand((hi - lo, n_genes), device=device, generator=g)
+        lam = torch.rand((hi - lo, n_genes), device=device, generator=g)
+        counts = torch.where(u < 0.10, torch.floor(lam * lam * 20.0) + 1.0, torch.zeros_like(u))
+        x = torch.log1p(counts)
+        out[lo:hi] = ((x - 0.16) / 0.55).clamp_(max=10.0)
+    return out
+
+
+def synth_rand_graph(n, k, device, seed):
+    """'rand-k15' (SURVEY.md §8d): k uniformly random in-neighbours per row, sorted, value 1/k; same on all ranks."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    col = torch.randint(0, n, (n, k), device=device, generator=g, dtype=torch.int64).sort(dim=1).values
+    rowptr = torch.arange(0, n * k + 1, k, device=device, dtype=torch.int32)
+    val = torch.full((n * k,), 1.0 / k, dtype=torch.float32, device=device)
+    return rowptr, col.to(torch.int32).reshape(-1).contiguous(), val
+
+
+def cpu_baseline(sample_cells, min_seconds=10.0, max_iters=5):
+    """The reference's CPU path for the same layer — oracle.layers.GNNLayer (torch-CPU mm + spmm + autograd,
+    a port of scdsc.py:475-501) — timed on this host's cores on a bounded sample of the workload."""
+    import numpy as np
+    from oracle import layers as ol
+    torch.manual_seed(0)
+    n = sample_cells
+    x = torch.randn(n, N_GENES)
+    layer = ol.GNNLayer(N_GENES, N_HIDDEN)
+    col = torch.randint(0, n, (n, K_NEIGH)).sort(dim=1).values.reshape(-1)
+    row = torch.arange(n).repeat_interleave(K_NEIGH)
+    adj = torch.sparse_coo_tensor(torch.stack([row, col]), torch.full((n * K_NEIGH,), 1.0 / K_NEIGH), (n, n))
+    dy = torch.randn(n, N_HIDDEN)
+
+    def step():
+        layer.weight.grad = None
+        layer(x, adj).backward(dy)
+
+    step()  # warm-up (includes torch's COO coalesce bookkeeping on first use)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < max_iters and (time.perf_counter() - t_all < min_seconds or len(times) < 2):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": n / med, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} cells x {N_GENES} genes -> {N_HIDDEN}, rand k={K_NEIGH} graph, fp32, fwd+bwd, "
+                      f"median of {len(times)} iterations ({med * 1e3:.0f} ms each), torch-CPU "
+                      f"oracle.layers.GNNLayer",
+            "host_cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cells", type=int, default=N_CELLS, help="total cells (default: the BASELINE config)")
+    ap.add_argument("--cpu-sample-cells", type=int, default=100_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from dance_amd import _lib, kernels, sharding
+    from dance_amd.graph import CSRGraph
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    _lib.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    n = args.cells
+    # ---- inputs resident in HBM before the timed region ---------------------------------------------------
+    rowptr, col, val = synth_rand_graph(n, K_NEIGH, dev, seed=1)
+    graph = CSRGraph(rowptr, col, val, n, n)
+    sg = sharding.ShardedGCNGraph.from_global_csr(graph)  # world == 1: the whole graph
+    lo, hi = sg.ranges[sg.rank]
+    n_local = hi - lo
+    del graph, rowptr, col, val
+    x = synth_features(n_local, N_GENES, dev, seed=100 + rank)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    bound = (6.0 / (N_GENES + N_HIDDEN))**0.5  # xavier_uniform, same W on every rank
+    w = ((torch.rand((N_GENES, N_HIDDEN), device=dev, generator=gen) * 2 - 1) * bound).requires_grad_(True)
+    dy = torch.randn((n_local, N_HIDDEN), device=dev, generator=torch.Generator(device=dev).manual_seed(3 + rank))
+    torch.cuda.synchronize()
+
+    def step():
+        w.grad = None
+        y = sharding.sharded_gcn_layer(x, w, sg, None, True)
+        y.backward(dy)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    with kernels.KernelTimer() as timer:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        ksum = timer.summary()
+        nnz_local = int(sg.a.col.numel())
+        nnz_t_local = int(sg.at.col.numel())
+        gemm_flops = 2.0 * n_local * N_GENES * N_HIDDEN
+
+        def spmm_bytes(nnz, rows):  # B_gather of SURVEY.md §8d: indices+values, row pointers, gathered rows, output
+            return nnz * 8.0 + 4.0 * (rows + 1) + nnz * N_HIDDEN * 4.0 + rows * N_HIDDEN * 4.0
+
+        kernels_out = {}
+        for name, (launches, ms) in sorted(ksum.items()):
+            e = {"launches": launches, "avg_ms": round(ms, 4)}
+            if name.startswith("gemm_f32"):
+                e.update(bound="mfma", achieved=round(gemm_flops / ms / 1e9, 2), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s")
+            elif name.startswith("spmm_csr_f32"):
+                b = spmm_bytes(nnz_local if "fwd" in name else nnz_t_local, n_local)
+                e.update(bound="hbm", achieved=round(b / ms / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s")
+            elif name.startswith("relu_backward"):
+                e.update(bound="hbm", achieved=round(3.0 * n_local * N_HIDDEN * 4 / ms / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s")
+            if "achieved" in e:
+                e["frac"] = round(e["achieved"] / e["peak"], 4)
+            kernels_out[name] = e
+        dominant = max((k for k in kernels_out if "achieved" in kernels_out[k]), key=lambda k: kernels_out[k]["avg_ms"] * kernels_out[k]["launches"])
+        d = kernels_out[dominant]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes/launch, see profiles/README.md
+        if os.path.exists(tpath) and n == N_CELLS and world == 1:
+            traffic = json.load(open(tpath)).get(dominant)
+        roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic}
+        out = {
+            "metric": "cells/sec per GCN fwd+bwd, 1M cells x 2k genes k=15",
+            "value": n / (elapsed / args.steps), "unit": "cells/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"GCN layer (scDSC GNNLayer) fwd+bwd, {n} cells x {N_GENES} genes -> {N_HIDDEN}, "
+                                   f"rand-k{K_NEIGH} graph (nnz={K_NEIGH * n}), fp32",
+                       "cells": n, "genes": N_GENES, "hidden": N_HIDDEN, "k": K_NEIGH,
+                       "parallelism": f"dst-range x{world}" if world > 1 else "single GPU"},
+            "roofline": roofline, "kernels": kernels_out,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_cells)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,7 +30,7 @@ class _GCNLayerFn(torch.autograd.Function):
         w = weight.contiguous()
         support = kernels.gemm(x, w)
         out = kernels.spmm_csr(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, bias=bias,
-                               act=kernels.ACT_RELU if active else kernels.ACT_NONE)
+                               act=kernels.ACT_RELU if active else kernels.ACT_NONE, tag="spmm_csr_f32[fwd]")
         ctx.graph, ctx.active, ctx.has_bias = graph, active, bias is not None
         ctx.save_for_backward(x, w, out if active else None)
         return out
@@ -46,7 +46,7 @@ class _GCNLayerFn(torch.autograd.Function):
             db = kernels.colsum(g)
         if need_x or need_w:
             gt = ctx.graph.transpose()
-            ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols)
+            ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols, tag="spmm_csr_f32[bwd]")
             if need_w:
                 dw = kernels.gemm(x, ds, trans_a=True)
             if need_x:

@@ -1,0 +1,48 @@
+"""Oracle-backed compute namespace (torch-CPU / scipy) with the signature of ``dance_amd.kernels`` — TEST ONLY.
+
+Injected into ``dance_amd.sharding.sharded_gcn_layer(ops=...)`` so that the partition + collective logic can be
+exercised under gloo on a CPU box.  The product never selects this by itself."""
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+ACT_NONE, ACT_RELU = 0, 1
+REDUCE_SUM, REDUCE_MEAN = 0, 1
+
+
+def gemm(A, B, *, trans_a=False, trans_b=False, out=None, accumulate=False, tag=None):
+    r = torch.mm(A.t() if trans_a else A, B.t() if trans_b else B)
+    if out is not None:
+        out.copy_(out + r if accumulate else r)
+        return out
+    return r
+
+
+def spmm_csr(rowptr, col, val, Z, *, n_cols=None, rowscale=None, colscale=None, bias=None, act=ACT_NONE,
+             reduce=REDUCE_SUM, out=None, tag=None):
+    n_rows = rowptr.numel() - 1
+    n_cols = Z.shape[0] if n_cols is None else n_cols
+    v = np.ones(col.numel(), np.float32) if val is None else val.numpy()
+    a = sp.csr_matrix((v, col.numpy(), rowptr.numpy()), shape=(n_rows, n_cols))
+    z = Z.numpy()
+    if colscale is not None:
+        z = z * colscale.numpy()[:, None]
+    y = a @ z
+    if reduce == REDUCE_MEAN:
+        deg = np.diff(rowptr.numpy())
+        y = y / np.maximum(deg, 1)[:, None]
+    if rowscale is not None:
+        y = y * rowscale.numpy()[:, None]
+    if bias is not None:
+        y = y + bias.detach().numpy()
+    if act == ACT_RELU:
+        y = np.maximum(y, 0)
+    return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+
+
+def relu_backward(Y, dY):
+    return torch.where(Y > 0, dY, torch.zeros_like(dY))
+
+
+def colsum(X):
+    return X.sum(0)

@@ -70,6 +70,18 @@ def test_gnnlayer_vs_oracle_medium(cuda_device, n, fin, fout, k):
     xt = torch.from_numpy(x).to(cuda_device).requires_grad_(True)
     y = layer(xt, CSRGraph.from_scipy(adj, cuda_device))
     y.backward(torch.from_numpy(dy).to(cuda_device))
-    assert rel_err(y.detach().cpu().numpy(), ref["out"]) < TOL
-    assert rel_err(layer.weight.grad.cpu().numpy(), ref["dW"]) < TOL
-    assert rel_err(xt.grad.cpu().numpy(), ref["dX"]) < TOL
+    y_hip = y.detach().cpu().numpy()
+    assert rel_err(y_hip, ref["out"]) < TOL
+    # ReLU is not differentiable at 0: an output that is +-1e-8 flips its mask under fp32 re-association and
+    # moves dW by one whole dy entry.  Such flips are legal only where the oracle's pre-activation is ~0 ...
+    flips = (y_hip > 0) != (ref["out"] > 0)
+    scale = np.abs(ref["out"]).max()
+    assert flips.sum() <= 8 and np.all(np.abs(ref["out"][flips]) + np.abs(y_hip[flips]) < 1e-5 * scale)
+    # ... and the gradients must match the oracle arithmetic evaluated (in float64) with the HIP mask.
+    g = np.where(y_hip > 0, dy, 0).astype(np.float64)
+    ds = adj.T.astype(np.float64) @ g
+    assert rel_err(layer.weight.grad.cpu().numpy(), x.astype(np.float64).T @ ds) < TOL
+    assert rel_err(xt.grad.cpu().numpy(), ds @ w.astype(np.float64).T) < TOL
+    if not flips.any():
+        assert rel_err(layer.weight.grad.cpu().numpy(), ref["dW"]) < TOL
+        assert rel_err(xt.grad.cpu().numpy(), ref["dX"]) < TOL

@@ -1,0 +1,97 @@
+"""CPU, world_size 2 (gloo): the destination-range sharded GCN layer reproduces the single-process oracle.
+Compute is injected from tests/cpu_ops.py (oracle-backed); what is under test is the partitioning, the
+all-gather row placement, the transposed shard and the gradient all-reduce of dance_amd/sharding.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import rel_err
+from oracle import layers as ol
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(n, fin, fout, k, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, fin)).astype(np.float32)
+    w = (rng.standard_normal((fin, fout)) / np.sqrt(fin)).astype(np.float32)
+    b = rng.standard_normal(fout).astype(np.float32)
+    dy = rng.standard_normal((n, fout)).astype(np.float32)
+    adj = sp.random(n, n, density=k / n, random_state=seed, format="csr", dtype=np.float32)
+    adj.data = rng.uniform(0.1, 1, adj.nnz).astype(np.float32)
+    adj.sort_indices()
+    return x, w, b, dy, adj
+
+
+def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_ops
+    from dance_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, w, b, dy, adj = _problem(n, fin, fout, k, seed)
+        at = adj.T.tocsr()
+        at.sort_indices()
+        ranges, _ = sharding.row_ranges(n, world)
+        lo, hi = ranges[rank]
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
+        a_sh = sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), lo, hi, n)
+        at_sh = sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), lo, hi, n)
+        sg = sharding.ShardedGCNGraph(a_sh, at_sh, n)
+        xl = torch.from_numpy(x[lo:hi].copy()).requires_grad_(True)
+        wt = torch.from_numpy(w.copy()).requires_grad_(True)
+        bt = torch.from_numpy(b.copy()).requires_grad_(True) if use_bias else None
+        y = sharding.sharded_gcn_layer(xl, wt, sg, bt, active, ops=cpu_ops)
+        y.backward(torch.from_numpy(dy[lo:hi].copy()))
+        q.put((rank, lo, hi, y.detach().numpy(), wt.grad.numpy(), xl.grad.numpy(), None if bt is None else bt.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,use_bias,active", [(2, 101, False, True), (2, 64, True, False), (3, 50, True, True)])
+def test_sharded_layer_matches_oracle(world, n, use_bias, active):
+    fin, fout, k, seed = 12, 7, 5, 17 + n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, fin, fout, k, seed, use_bias, active, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, w, b, dy, adj = _problem(n, fin, fout, k, seed)
+    ref = ol.gcn_layer_fwd_bwd(x, adj, w, dy, bias=b if use_bias else None, active=active, x_requires_grad=True)
+    results.sort(key=lambda r: r[0])
+    y = np.concatenate([r[3] for r in results])
+    dx = np.concatenate([r[5] for r in results])
+    assert y.shape == ref["out"].shape
+    assert rel_err(y, ref["out"]) < 1e-5
+    assert rel_err(dx, ref["dX"]) < 1e-5
+    for r in results:  # all-reduced gradients are identical on every rank
+        assert rel_err(r[4], ref["dW"]) < 1e-5
+        if use_bias:
+            assert rel_err(r[6], ref["db"]) < 1e-5
+
+
+def test_row_ranges_cover_everything():
+    from dance_amd.sharding import row_ranges
+    for n in (0, 1, 7, 8, 9, 1_000_000):
+        for world in (1, 2, 3, 8):
+            ranges, chunk = row_ranges(n, world)
+            assert ranges[0][0] == 0 and ranges[-1][1] == n and len(ranges) == world
+            assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+            assert all(hi - lo <= chunk for lo, hi in ranges)
