@@ -33,6 +33,19 @@ def _declare(lib):
         "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
         "dh_colsum_f32_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_colsum_f32": (c_int, [i64, i64, P, i64, P, P, c_size_t, P]),
+        "dh_pairwise_distance_f32": (c_int, [i64, i64, P, i64, P, i64, i32, P]),
+        "dh_rank_rows_f32": (c_int, [i64, i64, P, i64, P, i64, P]),
+        "dh_knn_bruteforce_f32": (c_int, [i64, i64, P, i64, i64, i64, i32, P, P, P]),
+        "dh_umap_membership_f32": (c_int, [i64, i32, P, P, P, P, P, P, c_size_t, P]),
+        "dh_knn_row_nnz": (c_int, [i64, i32, P, P, P, P]),
+        "dh_knn_graph_to_csr": (c_int, [i64, i32, P, P, P, P, P, P]),
+        "dh_csr_union_count": (c_int, [i64, P, P, P, P, P, P]),
+        "dh_csr_fuzzy_union_fill": (c_int, [i64, P, P, P, P, P, P, P, P, P, P]),
+        "dh_exclusive_scan_i32_workspace_bytes": (c_size_t, [i64]),
+        "dh_exclusive_scan_i32": (c_int, [i64, P, P, P, c_size_t, P]),
+        "dh_csr_row_normalize_f32": (c_int, [i64, P, P, P, P]),
+        "dh_sage_aggregate_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, P, i64, P, i64, P]),
+        "dh_sage_alpha_grad_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

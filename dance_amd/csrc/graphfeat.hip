@@ -1,0 +1,101 @@
+// Cell-gene graph kernels: edge normalisation of CellFeatureGraph and the
+// alpha gradient of AdaptiveSAGE.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// One wavefront per row: val[e] <- deg * val[e] / sum(val[row])  (cell_feature_graph.py:62-68).
+// Row sums are accumulated in f64 (rows of gene nodes can hold ~1e6 edges) and rounded to f32 once.
+__global__ __launch_bounds__(256) void row_normalize_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr,
+                                                            const float* __restrict__ val, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int s = rowptr[row], t = rowptr[row + 1];
+  if (t == s) return;
+  double acc = 0.0;
+  for (int e = s + lane; e < t; e += 64) acc += (double)val[e];
+  const float sum = (float)wave_sum(acc);
+  const float deg = (float)(t - s);
+  for (int e = s + lane; e < t; e += 64) out[e] = __fdiv_rn(__fmul_rn(deg, val[e]), sum);
+}
+
+// dalpha[idx(e)] += w_e * <H[u], dneigh[v]> / deg(v); one wavefront per destination row.
+__global__ __launch_bounds__(256) void sage_alpha_grad_kernel(int64_t n_dst, int64_t width, int n_genes,
+                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                              const float* __restrict__ w, const int32_t* __restrict__ src_id,
+                                                              const int32_t* __restrict__ dst_id, const float* __restrict__ H,
+                                                              int64_t ldh, const float* __restrict__ dneigh, int64_t ldn,
+                                                              float* __restrict__ dalpha) {
+  __shared__ float self_bins[2];
+  if (threadIdx.x < 2) self_bins[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row < n_dst) {
+    const int s = rowptr[row], t = rowptr[row + 1];
+    const int did = dst_id[row];
+    const float inv_deg = t > s ? 1.f / (float)(t - s) : 0.f;
+    const float* g = dneigh + row * ldn;
+    for (int e = s; e < t; ++e) {
+      const int c = col[e];
+      const float* h = H + (int64_t)c * ldh;
+      float dot = 0.f;
+      for (int64_t j = lane; j < width; j += 64) dot = fmaf(h[j], g[j], dot);
+      dot = wave_sum(dot);
+      if (lane == 0) {
+        const int sid = src_id[c];
+        int idx = n_genes + 1;
+        if (sid >= 0 && did < 0) idx = sid;
+        if (did >= 0 && sid < 0) idx = did;
+        if (did >= 0 && sid >= 0) idx = n_genes;
+        const float v = w[e] * dot * inv_deg;
+        if (idx >= n_genes) atomicAdd(&self_bins[idx - n_genes], v);  // per-block pre-reduction of the two hot bins
+        else atomicAdd(&dalpha[idx], v);
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 && self_bins[threadIdx.x] != 0.f) atomicAdd(&dalpha[n_genes + threadIdx.x], self_bins[threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" int dh_csr_row_normalize_f32(int64_t n_rows, const int32_t* rowptr, const float* val, float* out_val,
+                                        dh_stream_t stream) {
+  if (n_rows < 0) return dh::fail(DH_ERR_INVALID, "dh_csr_row_normalize_f32: negative size");
+  if (n_rows == 0) return DH_OK;
+  if (!rowptr || !val || !out_val) return dh::fail(DH_ERR_INVALID, "dh_csr_row_normalize_f32: null pointer");
+  hipLaunchKernelGGL(row_normalize_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream),
+                     n_rows, rowptr, val, out_val);
+  return dh::check_launch("dh_csr_row_normalize_f32");
+}
+
+extern "C" int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
+                                      const int32_t* rowptr, const int32_t* col, const float* w,
+                                      const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* H,
+                                      int64_t ldh, const float* dneigh, int64_t ldn, float* dalpha,
+                                      dh_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || width < 0 || n_genes < 0) return dh::fail(DH_ERR_INVALID, "dh_sage_alpha_grad_f32: negative size");
+  if (!dalpha) return dh::fail(DH_ERR_INVALID, "dh_sage_alpha_grad_f32: null dalpha");
+  hipStream_t st = dh::as_stream(stream);
+  if (hipMemsetAsync(dalpha, 0, (size_t)(n_genes + 2) * sizeof(float), st) != hipSuccess)
+    return dh::fail(DH_ERR_LAUNCH, "dh_sage_alpha_grad_f32: memset failed");
+  if (n_dst == 0 || width == 0) return DH_OK;
+  if (!rowptr || !col || !w || !src_cell_id || !dst_cell_id || !H || !dneigh)
+    return dh::fail(DH_ERR_INVALID, "dh_sage_alpha_grad_f32: null pointer");
+  hipLaunchKernelGGL(sage_alpha_grad_kernel, dim3((unsigned)dh::ceil_div(n_dst, 4)), dim3(256), 0, st, n_dst, width,
+                     (int)n_genes, rowptr, col, w, src_cell_id, dst_cell_id, H, ldh, dneigh, ldn, dalpha);
+  return dh::check_launch("dh_sage_alpha_grad_f32");
+}

@@ -54,14 +54,31 @@ __device__ __forceinline__ float bcast_f(float v, int k) {
   return __int_as_float(bcast_i<G>(__float_as_int(v), k));
 }
 
+// AdaptiveSAGE per-edge factor (dance/models/nn/gnn.py:72-82): alpha[idx(e)] with idx chosen from the
+// "cell_id" of the edge's source and destination node; folded into the edge weight on the fly.
+struct SageScale {
+  const int32_t* src_id;  // [n_src] cell_id of source nodes (>= 0 for genes, -1 for cells)
+  const int32_t* dst_id;  // [n_dst]
+  const float* alpha;     // [n_genes + 2]
+  int n_genes;
+};
+
+__device__ __forceinline__ float sage_alpha(const SageScale& sg, int sid, int did) {
+  int idx = sg.n_genes + 1;                      // cell self loop (default)
+  if (sid >= 0 && did < 0) idx = sid;            // gene -> cell
+  if (did >= 0 && sid < 0) idx = did;            // cell -> gene
+  if (did >= 0 && sid >= 0) idx = sg.n_genes;    // gene self loop
+  return sg.alpha[idx];
+}
+
 // G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart).
-template <int G, int VEC, int NACC>
+template <int G, int VEC, int NACC, bool SAGE>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int64_t n_rows, int64_t width, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ rowscale, const float* __restrict__ colscale,
     const float* __restrict__ Z, int64_t ldz, float* __restrict__ Y, int64_t ldy,
-    const float* __restrict__ bias, int act, int reduce) {
+    const float* __restrict__ bias, int act, int reduce, SageScale sage) {
   using V = typename VecT<VEC>::type;
   constexpr int ROWS_PER_BLOCK = 256 / G;
   const int g = threadIdx.x % G;
@@ -88,6 +105,7 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
       c = col[e];
       w = val ? val[e] : 1.f;
       if (colscale) w *= colscale[c];
+      if constexpr (SAGE) w *= sage_alpha(sage, sage.src_id[c], sage.dst_id[row]);
     }
     const int cnt = min(G, t - base);
     int k = 0;
@@ -130,18 +148,19 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
   }
 }
 
-template <int VEC>
+template <int VEC, bool SAGE>
 int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32_t* col,
                const float* val, const float* rowscale, const float* colscale, const float* Z,
                int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, int reduce,
-               hipStream_t st) {
+               SageScale sage, hipStream_t st) {
   const int64_t vecs = dh::ceil_div(width, VEC);
 #define DH_SPMM_LAUNCH(G, NACC)                                                                  \
   do {                                                                                           \
     dim3 grid((unsigned)dh::ceil_div(n_rows, 256 / G),                                           \
               (unsigned)dh::ceil_div(vecs, (int64_t)G * NACC));                                  \
-    hipLaunchKernelGGL((spmm_csr_kernel<G, VEC, NACC>), grid, dim3(256), 0, st, n_rows, width,   \
-                       rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce); \
+    hipLaunchKernelGGL((spmm_csr_kernel<G, VEC, NACC, SAGE>), grid, dim3(256), 0, st, n_rows,    \
+                       width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act,   \
+                       reduce, sage);                                                            \
   } while (0)
   if (vecs > 64) DH_SPMM_LAUNCH(64, 2);
   else if (vecs > 32) DH_SPMM_LAUNCH(64, 1);
@@ -149,7 +168,20 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
   else if (vecs > 8) DH_SPMM_LAUNCH(16, 1);
   else DH_SPMM_LAUNCH(8, 1);
 #undef DH_SPMM_LAUNCH
-  return dh::check_launch("dh_spmm_csr_f32");
+  return dh::check_launch(SAGE ? "dh_sage_aggregate_f32" : "dh_spmm_csr_f32");
+}
+
+template <bool SAGE>
+int dispatch(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
+             const float* rowscale, const float* colscale, const float* Z, int64_t ldz, float* Y,
+             int64_t ldy, const float* bias, int act, int reduce, SageScale sage, hipStream_t st) {
+  const bool a16 = dh::aligned16(Z) && dh::aligned16(Y) && (!bias || dh::aligned16(bias));
+  const bool a8 = ((uintptr_t)Z % 8 == 0) && ((uintptr_t)Y % 8 == 0) && (!bias || (uintptr_t)bias % 8 == 0);
+  if (a16 && width % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0)
+    return launch_vec<4, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, st);
+  if (a8 && width % 2 == 0 && ldz % 2 == 0 && ldy % 2 == 0)
+    return launch_vec<2, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, st);
+  return launch_vec<1, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, st);
 }
 
 }  // namespace
@@ -166,12 +198,20 @@ extern "C" int dh_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
   if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad act %d", act);
   if (reduce != DH_REDUCE_SUM && reduce != DH_REDUCE_MEAN) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad reduce %d", reduce);
   if (n_rows >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: n_rows >= 2^31");
-  hipStream_t st = dh::as_stream(stream);
-  const bool a16 = dh::aligned16(Z) && dh::aligned16(Y) && (!bias || dh::aligned16(bias));
-  const bool a8 = ((uintptr_t)Z % 8 == 0) && ((uintptr_t)Y % 8 == 0) && (!bias || (uintptr_t)bias % 8 == 0);
-  if (a16 && width % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0)
-    return launch_vec<4>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, st);
-  if (a8 && width % 2 == 0 && ldz % 2 == 0 && ldy % 2 == 0)
-    return launch_vec<2>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, st);
-  return launch_vec<1>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, st);
+  return dispatch<false>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce,
+                         SageScale{nullptr, nullptr, nullptr, 0}, dh::as_stream(stream));
+}
+
+extern "C" int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
+                                     const int32_t* rowptr, const int32_t* col, const float* w,
+                                     const int32_t* src_cell_id, const int32_t* dst_cell_id,
+                                     const float* alpha, const float* H, int64_t ldh, float* neigh,
+                                     int64_t ldn, dh_stream_t stream) {
+  if (n_dst < 0 || n_src < 0 || width < 0 || n_genes < 0) return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: negative size");
+  if (n_dst == 0 || width == 0) return DH_OK;
+  if (!rowptr || !H || !neigh || !src_cell_id || !dst_cell_id || !alpha)
+    return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: null pointer");
+  if (ldh < width || ldn < width) return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: leading dimension < width");
+  return dispatch<true>(n_dst, width, rowptr, col, w, nullptr, nullptr, H, ldh, neigh, ldn, nullptr, DH_ACT_NONE,
+                        DH_REDUCE_MEAN, SageScale{src_cell_id, dst_cell_id, alpha, (int)n_genes}, dh::as_stream(stream));
 }

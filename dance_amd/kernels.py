@@ -164,3 +164,114 @@ def colsum(X: torch.Tensor) -> torch.Tensor:
     _call("colsum_f32", lib.dh_colsum_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
           out.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
     return out
+
+
+# ---- graph builders ----------------------------------------------------------------------------------------
+def pairwise_distance(X: torch.Tensor, metric: int = METRIC_EUCLIDEAN) -> torch.Tensor:
+    """Dense [n, n] f32 distance matrix (dh_pairwise_distance_f32); spearman ranks the rows on the device first."""
+    lib = _lib_ready()
+    n, d = X.shape
+    if metric == METRIC_SPEARMAN:
+        ranked = torch.empty((n, d), dtype=torch.float32, device=X.device)
+        _call("rank_rows_f32", lib.dh_rank_rows_f32, n, d, _dev(X, torch.float32, "X", 2), _ld(X), ranked.data_ptr(),
+              _ld(ranked), _stream())
+        X = ranked
+    out = torch.empty((n, n), dtype=torch.float32, device=X.device)
+    _call("pairwise_distance_f32", lib.dh_pairwise_distance_f32, n, d, _dev(X, torch.float32, "X", 2), _ld(X),
+          out.data_ptr(), _ld(out), metric, _stream())
+    return out
+
+
+def knn(X: torch.Tensor, k: int, q_begin: int = 0, q_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact kNN (self included), ordered by (distance, index); returns (idx int32 [nq,k], dist f32 [nq,k])."""
+    lib = _lib_ready()
+    n, d = X.shape
+    q_end = n if q_end is None else q_end
+    nq = q_end - q_begin
+    idx = torch.empty((nq, k), dtype=torch.int32, device=X.device)
+    dist = torch.empty((nq, k), dtype=torch.float32, device=X.device)
+    _call("knn_bruteforce_f32", lib.dh_knn_bruteforce_f32, n, d, _dev(X, torch.float32, "X", 2), _ld(X), q_begin,
+          q_end, k, idx.data_ptr(), dist.data_ptr(), _stream())
+    return idx, dist
+
+
+def exclusive_scan(counts: torch.Tensor) -> torch.Tensor:
+    """int32 counts[n] -> int32 rowptr[n+1]."""
+    lib = _lib_ready()
+    n = counts.numel()
+    out = torch.empty(n + 1, dtype=torch.int32, device=counts.device)
+    ws_bytes = lib.dh_exclusive_scan_i32_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=counts.device)
+    _call("exclusive_scan_i32", lib.dh_exclusive_scan_i32, n, _dev(counts, torch.int32, "counts", 1), out.data_ptr(),
+          ws.data_ptr(), ws_bytes, _stream())
+    return out
+
+
+def umap_connectivities(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
+    """kNN list -> symmetric fuzzy-simplicial-set CSR (rowptr, col, val) + (sigma, rho); see umap.hip."""
+    lib = _lib_ready()
+    n, k = knn_idx.shape
+    dev = knn_idx.device
+    w = torch.empty((n, k), dtype=torch.float32, device=dev)
+    sigma = torch.empty(n, dtype=torch.float32, device=dev)
+    rho = torch.empty(n, dtype=torch.float32, device=dev)
+    ws = torch.empty(8, dtype=torch.uint8, device=dev)
+    ip, dp = _dev(knn_idx, torch.int32, "knn_idx", 2), _dev(knn_dist, torch.float32, "knn_dist", 2)
+    if not (knn_idx.is_contiguous() and knn_dist.is_contiguous()):
+        raise ValueError("knn_idx / knn_dist must be contiguous [n, k]")
+    _call("umap_membership_f32", lib.dh_umap_membership_f32, n, k, ip, dp, w.data_ptr(), sigma.data_ptr(),
+          rho.data_ptr(), ws.data_ptr(), 8, _stream())
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    _call("knn_row_nnz", lib.dh_knn_row_nnz, n, k, ip, w.data_ptr(), counts.data_ptr(), _stream())
+    rp_w = exclusive_scan(counts)
+    nnz_w = int(rp_w[-1])
+    col_w = torch.empty(nnz_w, dtype=torch.int32, device=dev)
+    val_w = torch.empty(nnz_w, dtype=torch.float32, device=dev)
+    _call("knn_graph_to_csr", lib.dh_knn_graph_to_csr, n, k, ip, w.data_ptr(), rp_w.data_ptr(), col_w.data_ptr(),
+          val_w.data_ptr(), _stream())
+    rp_t, col_t, val_t, _ = csr_transpose(rp_w, col_w, val_w, n, n)
+    _call("csr_union_count", lib.dh_csr_union_count, n, rp_w.data_ptr(), col_w.data_ptr(), rp_t.data_ptr(),
+          col_t.data_ptr(), counts.data_ptr(), _stream())
+    rp = exclusive_scan(counts)
+    nnz = int(rp[-1])
+    col = torch.empty(nnz, dtype=torch.int32, device=dev)
+    val = torch.empty(nnz, dtype=torch.float32, device=dev)
+    _call("csr_fuzzy_union_fill", lib.dh_csr_fuzzy_union_fill, n, rp_w.data_ptr(), col_w.data_ptr(), val_w.data_ptr(),
+          rp_t.data_ptr(), col_t.data_ptr(), val_t.data_ptr(), rp.data_ptr(), col.data_ptr(), val.data_ptr(), _stream())
+    return (rp, col, val), (sigma, rho)
+
+
+def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
+    """out[e] = deg(row) * val[e] / sum(val[row])."""
+    lib = _lib_ready()
+    out = torch.empty_like(val)
+    _call("csr_row_normalize_f32", lib.dh_csr_row_normalize_f32, rowptr.numel() - 1,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(val, torch.float32, "val", 1), out.data_ptr(), _stream())
+    return out
+
+
+# ---- AdaptiveSAGE ------------------------------------------------------------------------------------------
+def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H) -> torch.Tensor:
+    """neigh[v] = mean_e alpha[idx(e)] * w_e * H[src(e)] (dh_sage_aggregate_f32)."""
+    lib = _lib_ready()
+    n_dst, n_src, width = rowptr.numel() - 1, H.shape[0], H.shape[1]
+    out = torch.empty((n_dst, width), dtype=torch.float32, device=H.device)
+    _call("sage_aggregate_f32", lib.dh_sage_aggregate_f32, n_dst, n_src, width, alpha.numel() - 2,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
+          _dev(src_cell_id, torch.int32, "src_cell_id", 1), _dev(dst_cell_id, torch.int32, "dst_cell_id", 1),
+          _dev(alpha.reshape(-1), torch.float32, "alpha", 1), _dev(H, torch.float32, "H", 2), _ld(H), out.data_ptr(),
+          _ld(out), _stream())
+    return out
+
+
+def sage_alpha_grad(rowptr, col, w, src_cell_id, dst_cell_id, n_genes, H, dneigh) -> torch.Tensor:
+    """dalpha[idx(e)] += w_e <H[src(e)], dneigh[dst(e)]> / deg(dst(e)) (dh_sage_alpha_grad_f32)."""
+    lib = _lib_ready()
+    n_dst, n_src, width = rowptr.numel() - 1, H.shape[0], H.shape[1]
+    out = torch.empty(n_genes + 2, dtype=torch.float32, device=H.device)
+    _call("sage_alpha_grad_f32", lib.dh_sage_alpha_grad_f32, n_dst, n_src, width, n_genes,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
+          _dev(src_cell_id, torch.int32, "src_cell_id", 1), _dev(dst_cell_id, torch.int32, "dst_cell_id", 1),
+          _dev(H, torch.float32, "H", 2), _ld(H), _dev(dneigh, torch.float32, "dneigh", 2), _ld(dneigh),
+          out.data_ptr(), _stream())
+    return out

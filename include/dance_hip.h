@@ -102,6 +102,86 @@ DH_API size_t dh_colsum_f32_workspace_bytes(int64_t n_rows, int64_t width);
 DH_API int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, float* out,
                   void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* ---- K9/A14: dense pairwise distance ------------------------------------------------------
+ * out[i,j] = dist(x_i, x_j), f32 [n,n].  Replaces the numba kernel pairwise_distance at
+ * dance/utils/matrix.py:164-180 (euclidean :100-105: f32 differences and squares, accumulated in
+ * double in index order, sqrt in double, rounded to f32 once; pearson :108-116, evaluated in
+ * double; spearman :119-157 = pearson on mean-ranked rows: rank with dh_rank_rows_f32 first and
+ * pass DH_METRIC_SPEARMAN).  Used by SpaGCNGraph / SpaGCNGraph2D
+ * (dance/transforms/graph/spatial_graph.py:60,75).                                             */
+DH_API int dh_pairwise_distance_f32(int64_t n, int64_t d, const float* X, int64_t ldx,
+                             float* out, int64_t ldo, int metric, dh_stream_t stream);
+/* out[r,c] = mean rank (ties averaged) of X[r,c] within row r (matrix.py:119-140).             */
+DH_API int dh_rank_rows_f32(int64_t n, int64_t d, const float* X, int64_t ldx, float* out, int64_t ldo,
+                     dh_stream_t stream);
+
+/* ---- K8: exact brute-force kNN ------------------------------------------------------------
+ * For each query row q in [q_begin, q_end) the k nearest rows of X (the query itself included,
+ * as sklearn / scanpy do), ordered by (d2, index): ties go to the lower index.
+ * d2 = sum_t rn(rn(x_t - y_t)^2), every op a separate f32 round-to-nearest, terms added in
+ * feature order (no |x|^2 - 2xy expansion), so index lists are reproducible bit for bit;
+ * out_dist = sqrt(d2).  Fewer than k points: remaining slots get index -1, distance +inf.
+ * Replaces sklearn NearestNeighbors.kneighbors at dance/transforms/graph/heteronet_graph.py:36-37,
+ * dance/transforms/graph/spatial_graph.py:147-149 and the kNN stage of sc.pp.neighbors
+ * (dance/transforms/graph/neighbor_graph.py:52).  out_idx/out_dist are [(q_end-q_begin), k].    */
+DH_API int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx,
+                          int64_t q_begin, int64_t q_end, int k,
+                          int32_t* out_idx, float* out_dist, dh_stream_t stream);
+
+/* ---- K8: UMAP fuzzy-simplicial-set connectivities on a kNN list ------------------------------
+ * What sc.pp.neighbors(method="umap") computes after its kNN search (neighbor_graph.py:52-55;
+ * umap-learn smooth_knn_dist / compute_membership_strengths, local_connectivity = 1,
+ * bandwidth = 1, 64 bisection steps, set_op_mix_ratio = 1).
+ * dh_umap_membership_f32: rho_i = first positive distance, sigma_i by bisection (in double) so that
+ *   sum_{j>=1} exp(-max(0,d_ij-rho_i)/sigma_i) = log2(k); w_ij = exp(-(d_ij-rho_i)/sigma_i), 1 where
+ *   d_ij <= rho_i, 0 for the self slot / missing slots.  out_w is [n,k]; workspace >= 8 bytes.
+ * dh_knn_row_nnz + dh_knn_graph_to_csr: drop w == 0 slots, sort each row by column -> CSR of W.
+ * dh_csr_union_count + dh_csr_fuzzy_union_fill: sorted merge of W and W^T rows with
+ *   v = (a + b) - a*b in f32 (W + W^T - W o W^T).  Row pointers come from dh_exclusive_scan_i32. */
+DH_API int dh_umap_membership_f32(int64_t n, int k, const int32_t* knn_idx, const float* knn_dist,
+                           float* out_w, float* out_sigma, float* out_rho,
+                           void* workspace, size_t workspace_bytes, dh_stream_t stream);
+DH_API int dh_knn_row_nnz(int64_t n, int k, const int32_t* knn_idx, const float* w, int32_t* out_counts,
+                   dh_stream_t stream);
+DH_API int dh_knn_graph_to_csr(int64_t n, int k, const int32_t* knn_idx, const float* w,
+                        const int32_t* rowptr, int32_t* out_col, float* out_val, dh_stream_t stream);
+DH_API int dh_csr_union_count(int64_t n_rows, const int32_t* rowptr_a, const int32_t* col_a,
+                       const int32_t* rowptr_b, const int32_t* col_b, int32_t* out_counts,
+                       dh_stream_t stream);
+DH_API int dh_csr_fuzzy_union_fill(int64_t n_rows, const int32_t* rowptr_a, const int32_t* col_a,
+                            const float* val_a, const int32_t* rowptr_b, const int32_t* col_b,
+                            const float* val_b, const int32_t* out_rowptr, int32_t* out_col,
+                            float* out_val, dh_stream_t stream);
+/* out[0] = 0, out[i+1] = in[0] + ... + in[i]  (out has n+1 entries).                            */
+DH_API size_t dh_exclusive_scan_i32_workspace_bytes(int64_t n);
+DH_API int dh_exclusive_scan_i32(int64_t n, const int32_t* in, int32_t* out, void* workspace,
+                          size_t workspace_bytes, dh_stream_t stream);
+
+/* ---- K10: CellFeatureGraph edge normalisation ----------------------------------------------
+ * For every CSR row: out_val[e] = deg * val[e] / sum(val[row]) — the in-degree rescale of
+ * dance/transforms/graph/cell_feature_graph.py:62-68 in one pass instead of a Python loop over
+ * every node (row sums accumulated in double, rounded to f32 once).                            */
+DH_API int dh_csr_row_normalize_f32(int64_t n_rows, const int32_t* rowptr, const float* val,
+                             float* out_val, dh_stream_t stream);
+
+/* ---- K4/K7: AdaptiveSAGE message + mean aggregation -----------------------------------------
+ * neigh[v,:] = mean_{e=(u->v)} alpha[idx(e)] * w_e * H[u,:], idx(e) chosen from the src/dst
+ * "cell_id" arrays exactly as dance/models/nn/gnn.py:72-76 (gene->cell: src id; cell->gene:
+ * dst id; gene self loop: G; cell self loop: G+1); mean over in-edges, 0 for an isolated node
+ * (DGL fn.mean, gnn.py:90).  CSR rows = dst nodes of the block, columns = src nodes.
+ * dh_sage_alpha_grad_f32: dalpha[idx(e)] += w_e * <H[u], dneigh[v]> / deg(v)  (K7; zeroed first;
+ * float atomics: summation order, hence the last bits, is not reproducible).                   */
+DH_API int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
+                          const int32_t* rowptr, const int32_t* col, const float* w,
+                          const int32_t* src_cell_id, const int32_t* dst_cell_id,
+                          const float* alpha, const float* H, int64_t ldh,
+                          float* neigh, int64_t ldn, dh_stream_t stream);
+DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
+                           const int32_t* rowptr, const int32_t* col, const float* w,
+                           const int32_t* src_cell_id, const int32_t* dst_cell_id,
+                           const float* H, int64_t ldh, const float* dneigh, int64_t ldn,
+                           float* dalpha, dh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

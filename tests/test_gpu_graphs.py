@@ -1,0 +1,143 @@
+"""GPU: graph-builder and AdaptiveSAGE kernels through the C ABI vs the CPU oracle.
+Indices (kNN lists, CSR structure) must be bit-exact; distances/weights to the tolerances written below."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import GOLDEN, rel_err
+from oracle import graphs as og
+from oracle import matrix as om
+from oracle import sage as osg
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype else t).to(dev)
+
+
+# ---- A14 pairwise_distance -----------------------------------------------------------------------------------
+def test_pairwise_reference_known_answers(cuda_device):
+    """The reference's own golden test (tests/utils/test_matrix.py:32-65) run against the HIP kernel."""
+    from dance_amd import kernels
+    ka = json.load(open(os.path.join(GOLDEN, "matrix_known_answers.json")))
+    mat = _t(np.array(ka["mat"], dtype=np.float32), cuda_device)
+    for metric, name in enumerate(("euclidean", "pearson", "spearman")):
+        res = kernels.pairwise_distance(mat, metric).cpu().numpy()
+        assert np.allclose(np.array(ka[name]), res), name
+
+
+@pytest.mark.parametrize("n,d", [(1, 3), (65, 3), (200, 2), (130, 50), (300, 1)])
+def test_pairwise_euclidean_bit_exact_vs_oracle(cuda_device, n, d):
+    from dance_amd import kernels
+    x = np.random.default_rng(n + d).standard_normal((n, d)).astype(np.float32) * 100
+    res = kernels.pairwise_distance(_t(x, cuda_device), 0).cpu().numpy()
+    ref = om.pairwise_distance(x, 0)
+    assert np.array_equal(res, ref)  # same f32 terms, same f64 accumulation order, one rounding
+    assert np.all(np.diag(res) == 0) and np.array_equal(res, res.T)
+
+
+@pytest.mark.parametrize("metric", [1, 2])
+def test_pairwise_correlation_vs_float64(cuda_device, metric):
+    from dance_amd import kernels
+    x = np.random.default_rng(metric).standard_normal((90, 12)).astype(np.float32)
+    res = kernels.pairwise_distance(_t(x, cuda_device), metric).cpu().numpy()
+    assert np.abs(res - om.pairwise_distance_f64(x, metric)).max() < 1e-5  # reference test tolerance is np.allclose
+
+
+# ---- K8 exact kNN --------------------------------------------------------------------------------------------
+KNN_CASES = [(1000, 10, 15), (777, 3, 6), (500, 50, 15), (400, 64, 5), (300, 100, 10), (260, 2000, 15),
+             (600, 16, 40), (10, 5, 15), (257, 33, 1)]
+
+
+@pytest.mark.parametrize("n,d,k", KNN_CASES)
+def test_knn_bit_exact(cuda_device, n, d, k):
+    from dance_amd import kernels
+    x = np.random.default_rng(n * 3 + d).standard_normal((n, d)).astype(np.float32)
+    idx, dist = kernels.knn(_t(x, cuda_device), k)
+    ref_idx, ref_dist = og.knn_exact(x, k)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(dist.cpu().numpy(), ref_dist)  # same f32 op sequence + correctly rounded sqrt
+
+
+def test_knn_ties_and_query_range(cuda_device):
+    from dance_amd import kernels
+    x = np.zeros((300, 4), dtype=np.float32)
+    x[100:] = 1  # massive ties: order must be by index
+    idx, dist = kernels.knn(_t(x, cuda_device), 7, 90, 110)
+    ref_idx, ref_dist = og.knn_exact(x, 7)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx[90:110])
+    assert np.array_equal(dist.cpu().numpy(), ref_dist[90:110])
+
+
+# ---- A11 UMAP connectivities ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,k", [(1500, 10, 15), (600, 50, 15), (300, 3, 6), (400, 20, 50)])
+def test_neighbor_graph_connectivities(cuda_device, n, d, k):
+    from dance_amd import kernels
+    rng = np.random.default_rng(k + n)
+    centers = rng.standard_normal((8, d)) * 3
+    x = (centers[rng.integers(0, 8, n)] + rng.standard_normal((n, d))).astype(np.float32)
+    idx, dist = kernels.knn(_t(x, cuda_device), k)
+    (rp, col, val), (sigma, rho) = kernels.umap_connectivities(idx, dist)
+    ref_idx, ref_dist = og.knn_exact(x, k)
+    ref, ref_sigma, ref_rho = og.fuzzy_simplicial_set(ref_idx, ref_dist, k)
+    assert np.array_equal(rho.cpu().numpy(), ref_rho)
+    assert rel_err(sigma.cpu().numpy(), ref_sigma) < 1e-5
+    assert np.array_equal(rp.cpu().numpy(), ref.indptr.astype(np.int32))  # bit-exact graph structure
+    assert np.array_equal(col.cpu().numpy(), ref.indices.astype(np.int32))
+    assert np.allclose(val.cpu().numpy(), ref.data, rtol=2e-5, atol=1e-7)
+
+
+def test_exclusive_scan(cuda_device):
+    from dance_amd import kernels
+    for n in (1, 5, 1000, 100_003):
+        c = np.random.default_rng(n).integers(0, 50, n).astype(np.int32)
+        out = kernels.exclusive_scan(_t(c, cuda_device)).cpu().numpy()
+        assert np.array_equal(out, np.concatenate(([0], np.cumsum(c))).astype(np.int32))
+
+
+# ---- A1 edge normalisation, A3 AdaptiveSAGE ------------------------------------------------------------------
+def test_csr_row_normalize(cuda_device):
+    from dance_amd import kernels
+    a = sp.random(500, 300, density=0.05, random_state=0, format="csr", dtype=np.float32)
+    a.data = np.random.default_rng(0).uniform(0.1, 5, a.nnz).astype(np.float32)
+    out = kernels.csr_row_normalize(_t(a.indptr.astype(np.int32), cuda_device), _t(a.data, cuda_device)).cpu().numpy()
+    deg = np.diff(a.indptr)
+    sums = np.asarray(a.sum(1)).ravel()
+    row = np.repeat(np.arange(500), deg)
+    ref = deg[row] * a.data.astype(np.float64) / sums[row]
+    assert rel_err(out, ref) < 1e-6
+
+
+def _cellgene_block(n_cells, n_genes, density, seed):
+    rng = np.random.default_rng(seed)
+    feat = (rng.random((n_cells, n_genes)) < density) * rng.uniform(0.5, 3, (n_cells, n_genes))
+    g = og.cell_feature_graph(feat.astype(np.float32), normalize_edges=True)
+    n = n_cells + n_genes
+    order = np.lexsort((np.arange(g["src"].size), g["dst"]))  # CSR by dst, reference edge order within a row
+    rowptr = np.concatenate(([0], np.cumsum(np.bincount(g["dst"], minlength=n)))).astype(np.int32)
+    return g, n, rowptr, g["src"][order].astype(np.int32), g["weight"][order]
+
+
+@pytest.mark.parametrize("width", [400, 200, 50, 33])
+def test_sage_aggregate_and_alpha_grad(cuda_device, width):
+    from dance_amd import kernels
+    g, n, rowptr, col, w = _cellgene_block(120, 60, 0.15, seed=width)
+    rng = np.random.default_rng(width)
+    h = rng.standard_normal((n, width)).astype(np.float32)
+    alpha = rng.uniform(0.5, 1.5, 60 + 2).astype(np.float32)
+    cid = g["cell_id"]
+    neigh = kernels.sage_aggregate(_t(rowptr, cuda_device), _t(col, cuda_device), _t(w, cuda_device), _t(cid, cuda_device),
+                                   _t(cid, cuda_device), _t(alpha, cuda_device), _t(h, cuda_device))
+    ref = osg.sage_neigh(g["src"], g["dst"], g["weight"], cid, cid, alpha, h, n)
+    assert rel_err(neigh.cpu().numpy(), ref) < 1e-5
+    dn = rng.standard_normal((n, width)).astype(np.float32)
+    da = kernels.sage_alpha_grad(_t(rowptr, cuda_device), _t(col, cuda_device), _t(w, cuda_device), _t(cid, cuda_device),
+                                 _t(cid, cuda_device), 60, _t(h, cuda_device), _t(dn, cuda_device))
+    ref_da = osg.sage_alpha_grad(g["src"], g["dst"], g["weight"], cid, cid, 60, h, dn)
+    assert rel_err(da.cpu().numpy(), ref_da) < 1e-4
