@@ -71,7 +71,7 @@ class _DenseAdjLayerFn(torch.autograd.Function):
         support = kernels.gemm(x, w)
         out = kernels.gemm(adj, support)
         if bias is not None:
-            out += bias  # broadcast add (torch elementwise on the same stream)
+            kernels.bias_act_(out, bias)
         ctx.has_bias = bias is not None
         ctx.save_for_backward(x, w, adj)
         return out
@@ -94,3 +94,38 @@ class _DenseAdjLayerFn(torch.autograd.Function):
 
 def dense_adj_layer(x, weight, adj, bias=None):
     return _DenseAdjLayerFn.apply(x, weight, bias, adj)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b (torch.nn.Linear semantics) on the f32 matrix cores."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        w = weight.contiguous()
+        y = kernels.gemm(x, w, trans_b=True)
+        if bias is not None:
+            kernels.bias_act_(y, bias)
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = kernels.gemm(dy, w) if ctx.needs_input_grad[0] else None
+        dw = kernels.gemm(dy, x, trans_a=True) if ctx.needs_input_grad[1] else None
+        db = kernels.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    return _LinearFn.apply(x, weight, bias)
+
+
+class HipLinear(torch.nn.Linear):
+    """``nn.Linear`` (same parameters / state_dict) whose forward and backward run on dh_gemm_f32."""
+
+    def forward(self, input):
+        return linear(input, self.weight, self.bias)

@@ -1,0 +1,227 @@
+"""Stand-in for the ``DGLGraph`` objects that cross the scDeepSort / graph-sc API.
+
+DGL cannot be installed on ROCm here, and the reference's ``fit(graph, ...)`` / ``predict(graph)`` signatures take a
+DGLGraph.  ``CellGeneGraph`` exposes the subset of that surface the hot-path call sites use (``ndata``/``edata``
+frames, ``number_of_nodes``, ``in_degrees``, ``out_degrees``, ``edges``, ``in_edges``, ``subgraph``, ``to``) on top of
+a device-resident CSR keyed by destination node; ``NeighborSampler`` / ``DataLoader`` reproduce the full-fan-out
+in-neighbour blocks of ``dgl.dataloading.NeighborSampler([-1]*L)`` (scdeepsort.py:183,233-236; graphsc.py:181-183).
+
+Edge order: ``eid`` maps every CSR slot to the edge's id in the graph's edge list (for the transform output this is
+the reference's order, cell_feature_graph.py:43-69), so ``edges()`` / ``edata`` come back in that order.
+"""
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+
+class _Frame(dict):
+    """ndata / edata: name -> tensor."""
+
+
+class CellGeneGraph:
+
+    def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, eid: Optional[torch.Tensor],
+                 n_nodes: int, ndata: Optional[Dict[str, torch.Tensor]] = None):
+        self.rowptr, self.col, self.val = rowptr, col, val  # int32, int32 (src ids), f32 — CSR by destination
+        self.eid = eid  # int32 edge id of every CSR slot (None: slot order is the edge order)
+        self._n_nodes = int(n_nodes)
+        self.ndata = _Frame(ndata or {})
+        self._edge_cache = None
+
+    # ---- DGLGraph surface ----------------------------------------------------------------------------------
+    def number_of_nodes(self) -> int:
+        return self._n_nodes
+
+    num_nodes = number_of_nodes
+
+    def number_of_edges(self) -> int:
+        return int(self.col.numel())
+
+    num_edges = number_of_edges
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+    def nodes(self) -> torch.Tensor:
+        return torch.arange(self._n_nodes, device=self.device)
+
+    def in_degrees(self) -> torch.Tensor:
+        return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+
+    def out_degrees(self) -> torch.Tensor:
+        return torch.bincount(self.col.to(torch.int64), minlength=self._n_nodes)
+
+    def _dst_of_slots(self) -> torch.Tensor:
+        deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+        return torch.repeat_interleave(torch.arange(self._n_nodes, device=self.device), deg)
+
+    def _edge_lists(self):
+        """(src, dst, weight) in edge-id order."""
+        if self._edge_cache is None:
+            src, dst, w = self.col.to(torch.int64), self._dst_of_slots(), self.val
+            if self.eid is not None:
+                order = torch.argsort(self.eid.to(torch.int64))
+                src, dst, w = src[order], dst[order], w[order]
+            self._edge_cache = (src, dst, w)
+        return self._edge_cache
+
+    def edges(self):
+        src, dst, _ = self._edge_lists()
+        return src, dst
+
+    @property
+    def edata(self) -> Dict[str, torch.Tensor]:
+        return _Frame(weight=self._edge_lists()[2][:, None])
+
+    def in_edges(self, v: int, form: str = "uv"):
+        s, t = int(self.rowptr[v]), int(self.rowptr[v + 1])
+        src = self.col[s:t].to(torch.int64)
+        dst = torch.full_like(src, v)
+        ids = (self.eid[s:t] if self.eid is not None else torch.arange(s, t, device=self.device)).to(torch.int64)
+        return (src, dst, ids) if form == "all" else (src, dst)
+
+    def to(self, device) -> "CellGeneGraph":
+        if torch.device(device) == self.device:
+            return self
+        g = CellGeneGraph(self.rowptr.to(device), self.col.to(device), self.val.to(device),
+                          None if self.eid is None else self.eid.to(device), self._n_nodes,
+                          {k: v.to(device) for k, v in self.ndata.items()})
+        return g
+
+    def local_scope(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def subgraph(self, nodes) -> "CellGeneGraph":
+        """Induced subgraph; node i of the result is ``nodes[i]`` and edges keep their relative order
+        (``dgl.DGLGraph.subgraph``, examples/single_modality/cell_type_annotation/scdeepsort.py:65-66)."""
+        dev = self.device
+        nodes = torch.as_tensor(nodes, dtype=torch.int64, device=dev)
+        lut = torch.full((self._n_nodes, ), -1, dtype=torch.int64, device=dev)
+        lut[nodes] = torch.arange(nodes.numel(), device=dev)
+        dst = self._dst_of_slots()
+        src = self.col.to(torch.int64)
+        keep = (lut[src] >= 0) & (lut[dst] >= 0)
+        new_src, new_dst = lut[src[keep]], lut[dst[keep]]
+        old_eid = (self.eid.to(torch.int64) if self.eid is not None else torch.arange(src.numel(), device=dev))[keep]
+        val = self.val[keep]
+        # CSR by new destination, slots inside a row ordered by original edge id; new edge ids = rank of old ids
+        order = torch.argsort(new_dst * (int(old_eid.max()) + 1 if old_eid.numel() else 1) + old_eid)
+        new_src, new_dst, val, old_eid = new_src[order], new_dst[order], val[order], old_eid[order]
+        rank = torch.empty_like(old_eid)
+        rank[torch.argsort(old_eid)] = torch.arange(old_eid.numel(), device=dev)
+        rowptr = torch.zeros(nodes.numel() + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(new_dst, minlength=nodes.numel()), 0)
+        g = CellGeneGraph(rowptr.to(torch.int32), new_src.to(torch.int32), val.contiguous(), rank.to(torch.int32),
+                          nodes.numel(), {k: v[nodes] for k, v in self.ndata.items()})
+        g.ndata["_ID"] = nodes
+        return g
+
+
+class Block:
+    """Bipartite message-flow block: ``num_dst`` destination nodes (= the first ``num_dst`` source nodes) with all
+    their in-edges; CSR rows are destinations, columns index ``srcdata`` rows."""
+
+    def __init__(self, rowptr, col, val, num_src: int, num_dst: int, src_ids: torch.Tensor, parent: CellGeneGraph):
+        self.rowptr, self.col, self.val = rowptr, col, val
+        self._num_src, self._num_dst = int(num_src), int(num_dst)
+        self.srcdata = _Frame({k: v[src_ids] for k, v in parent.ndata.items()})
+        self.srcdata["_ID"] = src_ids
+        self.dstdata = _Frame({k: v[:num_dst] for k, v in self.srcdata.items()})
+        self.edata = _Frame(weight=val[:, None])
+
+    def number_of_dst_nodes(self) -> int:
+        return self._num_dst
+
+    num_dst_nodes = number_of_dst_nodes
+
+    def number_of_src_nodes(self) -> int:
+        return self._num_src
+
+    num_src_nodes = number_of_src_nodes
+
+    def number_of_edges(self) -> int:
+        return int(self.col.numel())
+
+    def in_degrees(self) -> torch.Tensor:
+        return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
+
+    def out_degrees(self) -> torch.Tensor:
+        return torch.bincount(self.col.to(torch.int64), minlength=self._num_src)
+
+    def to(self, device) -> "Block":
+        return self  # blocks are created on the graph's device
+
+    def local_scope(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def dstnodes(self):
+        return torch.arange(self._num_dst, device=self.rowptr.device)
+
+
+def _full_in_block(g: CellGeneGraph, seeds: torch.Tensor) -> Block:
+    """All in-edges of ``seeds``; source nodes = seeds first, then the remaining in-neighbours (ascending id)."""
+    dev = g.device
+    seeds = seeds.to(dev).to(torch.int64)
+    rp = g.rowptr.to(torch.int64)
+    start, deg = rp[seeds], rp[seeds + 1] - rp[seeds]
+    brp = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
+    brp[1:] = torch.cumsum(deg, 0)
+    total = int(brp[-1])
+    pos = torch.repeat_interleave(start - brp[:-1], deg) + torch.arange(total, device=dev)
+    gcol = g.col[pos].to(torch.int64)
+    is_seed = torch.zeros(g.number_of_nodes(), dtype=torch.bool, device=dev)
+    is_seed[seeds] = True
+    others = torch.unique(gcol[~is_seed[gcol]])  # sorted
+    src_ids = torch.cat((seeds, others))
+    lut = torch.empty(g.number_of_nodes(), dtype=torch.int64, device=dev)
+    lut[src_ids] = torch.arange(src_ids.numel(), device=dev)
+    return Block(brp.to(torch.int32), lut[gcol].to(torch.int32), g.val[pos].contiguous(), src_ids.numel(),
+                 seeds.numel(), src_ids, g)
+
+
+class NeighborSampler:
+    """``dgl.dataloading.NeighborSampler(fanouts, edge_dir="in")`` restricted to full fan-out (every entry -1),
+    which is all the reference uses (scdeepsort.py:183, graphsc.py:181 MultiLayerFullNeighborSampler)."""
+
+    def __init__(self, fanouts: Sequence[int], edge_dir: str = "in"):
+        if any(f != -1 for f in fanouts) or edge_dir != "in":
+            raise NotImplementedError("only full in-neighbour sampling ([-1]*L, edge_dir='in') is used by the hot path")
+        self.num_layers = len(fanouts)
+
+    def sample(self, g: CellGeneGraph, seeds: torch.Tensor):
+        blocks: List[Block] = []
+        out_nodes = seeds
+        for _ in range(self.num_layers):
+            blk = _full_in_block(g, seeds)
+            blocks.insert(0, blk)
+            seeds = blk.srcdata["_ID"]
+        return seeds, out_nodes, blocks
+
+
+def MultiLayerFullNeighborSampler(num_layers: int):
+    return NeighborSampler([-1] * num_layers)
+
+
+class DataLoader:
+    """Mini-batch iterator yielding ``(input_nodes, output_nodes, blocks)`` like ``dgl.dataloading.DataLoader``."""
+
+    def __init__(self, graph: CellGeneGraph, indices, sampler: NeighborSampler, batch_size: int = 1,
+                 shuffle: bool = False, drop_last: bool = False, generator: Optional[torch.Generator] = None, **_ignored):
+        self.graph, self.sampler = graph, sampler
+        self.indices = torch.as_tensor(indices, dtype=torch.int64)
+        self.batch_size, self.shuffle, self.drop_last, self.generator = batch_size, shuffle, drop_last, generator
+
+    def __len__(self):
+        n = self.indices.numel()
+        return n // self.batch_size if self.drop_last else -(-n // self.batch_size)
+
+    def __iter__(self):
+        idx = self.indices
+        if self.shuffle:
+            idx = idx[torch.randperm(idx.numel(), generator=self.generator)]
+        for i in range(len(self)):
+            seeds = idx[i * self.batch_size:(i + 1) * self.batch_size]
+            yield self.sampler.sample(self.graph, seeds.to(self.graph.device))

@@ -106,3 +106,29 @@ extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int6
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
   return dh::check_launch("dh_colsum_f32");
 }
+
+// X[i,:] = act(X[i,:] + bias) in place — epilogue of the dense layers (nn.Linear bias, GraphConvolution bias on a
+// dense adjacency).
+namespace {
+__global__ __launch_bounds__(256) void bias_act_kernel(int64_t n_rows, int64_t width, float* __restrict__ X, int64_t ldx,
+                                                       const float* __restrict__ bias, int act) {
+  const int64_t total = n_rows * width;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / width, c = i % width;
+    float v = X[r * ldx + c] + (bias ? bias[c] : 0.f);
+    X[r * ldx + c] = act == DH_ACT_RELU ? fmaxf(v, 0.f) : v;
+  }
+}
+}  // namespace
+
+extern "C" int dh_bias_act_f32(int64_t n_rows, int64_t width, float* X, int64_t ldx, const float* bias, int act,
+                               dh_stream_t stream) {
+  if (n_rows < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_bias_act_f32: negative size");
+  if (n_rows == 0 || width == 0) return DH_OK;
+  if (!X || ldx < width) return dh::fail(DH_ERR_INVALID, "dh_bias_act_f32: bad X/ldx");
+  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_bias_act_f32: bad act %d", act);
+  const int64_t work = n_rows * width;
+  const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 8192 ? dh::ceil_div(work, 256) : 8192);
+  hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), n_rows, width, X, ldx, bias, act);
+  return dh::check_launch("dh_bias_act_f32");
+}

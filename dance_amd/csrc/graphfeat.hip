@@ -99,3 +99,72 @@ extern "C" int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t widt
                      (int)n_genes, rowptr, col, w, src_cell_id, dst_cell_id, H, ldh, dneigh, ldn, dalpha);
   return dh::check_launch("dh_sage_alpha_grad_f32");
 }
+
+// ---- CellFeatureGraph assembly (cell_feature_graph.py:38-69) in CSR-by-destination form ------------------------
+// Nodes: genes [0,G), cells [G,G+N).  Row of gene g = its cell->gene in-edges (reference edge id = position of the
+// entry in row-major nonzero order of X) followed by its self loop; row of cell c = its gene->cell in-edges
+// (edge id nnz + position) followed by its self loop (edge ids 2nnz + node).  `eid` keeps the reference's edge
+// order recoverable bit-exactly.
+namespace {
+__global__ __launch_bounds__(256) void cellgene_assemble_kernel(
+    int64_t n_cells, int64_t n_genes, int64_t nnz, const int32_t* __restrict__ rowptr_x, const int32_t* __restrict__ col_x,
+    const float* __restrict__ val_x, const int32_t* __restrict__ rowptr_t, const int32_t* __restrict__ col_t,
+    const float* __restrict__ val_t, const int32_t* __restrict__ perm_t, int32_t* __restrict__ rowptr,
+    int32_t* __restrict__ col, float* __restrict__ val, int32_t* __restrict__ eid) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_nodes = n_genes + n_cells;
+  if (row > n_nodes) return;
+  if (row == n_nodes) {
+    if (lane == 0) rowptr[row] = (int32_t)(2 * nnz + n_nodes);
+    return;
+  }
+  if (row < n_genes) {
+    const int s = rowptr_t[row], t = rowptr_t[row + 1];
+    const int64_t base = (int64_t)s + row;
+    if (lane == 0) rowptr[row] = (int32_t)base;
+    for (int e = s + lane; e < t; e += 64) {
+      col[base + (e - s)] = (int32_t)(n_genes + col_t[e]);
+      val[base + (e - s)] = val_t[e];
+      eid[base + (e - s)] = perm_t[e];
+    }
+    if (lane == 0) {
+      col[base + (t - s)] = (int32_t)row;
+      val[base + (t - s)] = 1.f;
+      eid[base + (t - s)] = (int32_t)(2 * nnz + row);
+    }
+  } else {
+    const int64_t c = row - n_genes;
+    const int s = rowptr_x[c], t = rowptr_x[c + 1];
+    const int64_t base = nnz + n_genes + (int64_t)s + c;
+    if (lane == 0) rowptr[row] = (int32_t)base;
+    for (int e = s + lane; e < t; e += 64) {
+      col[base + (e - s)] = col_x[e];
+      val[base + (e - s)] = val_x[e];
+      eid[base + (e - s)] = (int32_t)(nnz + e);
+    }
+    if (lane == 0) {
+      col[base + (t - s)] = (int32_t)row;
+      val[base + (t - s)] = 1.f;
+      eid[base + (t - s)] = (int32_t)(2 * nnz + row);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t nnz, const int32_t* rowptr_x,
+                                          const int32_t* col_x, const float* val_x, const int32_t* rowptr_t,
+                                          const int32_t* col_t, const float* val_t, const int32_t* perm_t,
+                                          int32_t* out_rowptr, int32_t* out_col, float* out_val, int32_t* out_eid,
+                                          dh_stream_t stream) {
+  if (n_cells < 0 || n_genes < 0 || nnz < 0) return dh::fail(DH_ERR_INVALID, "dh_cellgene_graph_assemble: negative size");
+  if (2 * nnz + n_cells + n_genes >= ((int64_t)1 << 31))
+    return dh::fail(DH_ERR_INVALID, "dh_cellgene_graph_assemble: edge count exceeds int32 CSR");
+  if (!rowptr_x || !rowptr_t || !out_rowptr || !out_col || !out_val || !out_eid)
+    return dh::fail(DH_ERR_INVALID, "dh_cellgene_graph_assemble: null pointer");
+  const int64_t rows = n_cells + n_genes + 1;
+  hipLaunchKernelGGL(cellgene_assemble_kernel, dim3((unsigned)dh::ceil_div(rows, 4)), dim3(256), 0, dh::as_stream(stream),
+                     n_cells, n_genes, nnz, rowptr_x, col_x, val_x, rowptr_t, col_t, val_t, perm_t, out_rowptr, out_col,
+                     out_val, out_eid);
+  return dh::check_launch("dh_cellgene_graph_assemble");
+}

@@ -1,0 +1,251 @@
+"""Minimal stand-ins for the objects every DANCE transform / method receives.
+
+``anndata`` is not installable in this environment, so ``AnnDataLite`` provides the attribute surface the hot
+path touches (``X, obs, var, obsm, varm, obsp, varp, layers, uns``) and ``Data`` mirrors the accessor API of
+dance/data/base.py (splits :114-184, config :203-271, ``get_feature`` :415-475, ``get_x/get_y/get_train_data``
+:845-888).  A real ``anndata.AnnData`` can be wrapped by ``Data`` just as well — only attribute access is used.
+"""
+import warnings
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+
+class AnnDataLite:
+    """Attribute container with AnnData's channel names (no views, no backing file)."""
+
+    def __init__(self, X, obs=None, var=None, *, obsm=None, varm=None, obsp=None, varp=None, layers=None, uns=None):
+        import pandas as pd
+        self.X = X
+        n_obs, n_var = X.shape
+        self.obs = obs if obs is not None else pd.DataFrame(index=[str(i) for i in range(n_obs)])
+        self.var = var if var is not None else pd.DataFrame(index=[str(i) for i in range(n_var)])
+        self.obsm, self.varm = dict(obsm or {}), dict(varm or {})
+        self.obsp, self.varp = dict(obsp or {}), dict(varp or {})
+        self.layers, self.uns = dict(layers or {}), dict(uns or {})
+
+    @property
+    def shape(self):
+        return self.X.shape
+
+    @property
+    def n_obs(self):
+        return self.X.shape[0]
+
+    @property
+    def n_vars(self):
+        return self.X.shape[1]
+
+    def __repr__(self):
+        return (f"AnnDataLite object with n_obs x n_vars = {self.n_obs} x {self.n_vars}\n"
+                f"    obsm: {list(self.obsm)}\n    varm: {list(self.varm)}\n    obsp: {list(self.obsp)}\n"
+                f"    uns: {list(self.uns)}")
+
+
+def _ensure_iter(x):
+    return x if isinstance(x, (list, tuple)) else [x]
+
+
+class Data:
+    _FEATURE_CONFIGS: List[str] = ["feature_mod", "feature_channel", "feature_channel_type"]
+    _LABEL_CONFIGS: List[str] = ["label_mod", "label_channel", "label_channel_type"]
+    _DATA_CHANNELS: List[str] = ["obs", "var", "obsm", "varm", "obsp", "varp", "layers", "uns"]
+
+    def __init__(self, data, train_size: Optional[int] = None, val_size: int = 0, test_size: int = -1,
+                 split_index_range_dict: Optional[Dict[str, Tuple[int, int]]] = None,
+                 full_split_name: Optional[str] = None):
+        self._data = data
+        self._split_idx_dict: Dict[str, Sequence[int]] = {}
+        if split_index_range_dict is not None and full_split_name is not None:
+            raise ValueError("Only one of split_index_range_dict, full_split_name can be specified, but not both")
+        if split_index_range_dict is not None:
+            for name, rng in split_index_range_dict.items():
+                if not isinstance(rng, tuple) or len(rng) != 2 or any(not isinstance(i, int) for i in rng):
+                    raise TypeError(f"The split index range must be a two-tuple of int, got {rng!r} for key {name!r}")
+                if rng[1] - rng[0] > 0:
+                    self._split_idx_dict[name] = list(range(*rng))
+        elif full_split_name is not None:
+            self._split_idx_dict[full_split_name] = list(range(self.shape[0]))
+        else:
+            self._setup_splits_default(train_size, val_size, test_size)
+        if "dance_config" not in self._data.uns:
+            self._data.uns["dance_config"] = dict()
+
+    def _setup_splits_default(self, train_size, val_size, test_size):
+        if train_size is None:
+            return
+        if isinstance(train_size, str) and train_size.lower() == "all":
+            train_size, val_size, test_size = -1, 0, 0
+        elif any(not isinstance(i, (int, np.integer)) for i in (train_size, val_size, test_size)):
+            raise TypeError("Split sizes must be of type int")
+        sizes = np.array((train_size, val_size, test_size))
+        if (sizes == -1).sum() > 1:
+            raise ValueError("Only one split can be specified as -1")
+        n = self.num_cells
+        for name, size in zip(("train", "val", "test"), sizes):
+            if size < -1:
+                raise ValueError(f"{name} must be integer no less than -1, got {size!r}")
+            if size > n:
+                raise ValueError(f"{name}={size:,} exceeds total number of samples {n:,}")
+        if (tot := sizes.clip(0).sum()) > n:
+            raise ValueError(f"Total size {tot:,} exceeds total number of samples {n:,}")
+        sizes[sizes == -1] = n - sizes.clip(0).sum()
+        edges = np.concatenate(([0], sizes.cumsum()))
+        for i, name in enumerate(("train", "val", "test")):
+            if edges[i + 1] - edges[i] > 0:
+                self._split_idx_dict[name] = list(range(edges[i], edges[i + 1]))
+
+    # ---- basic views ---------------------------------------------------------------------------------------
+    @property
+    def data(self):
+        return self._data
+
+    @property
+    def shape(self):
+        return self._data.shape
+
+    @property
+    def num_cells(self) -> int:
+        return self._data.shape[0]
+
+    @property
+    def num_features(self) -> int:
+        return self._data.shape[1]
+
+    @property
+    def config(self) -> Dict[str, Any]:
+        return self._data.uns["dance_config"]
+
+    def __getattr__(self, name):  # pass X / obs / obsm ... through, like the reference does with setattr
+        if name in Data._DATA_CHANNELS + ["X"]:
+            return getattr(self._data, name)
+        raise AttributeError(name)
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} object that wraps (.data):\n{self.data}"
+
+    # ---- config --------------------------------------------------------------------------------------------
+    def set_config(self, *, overwrite: bool = False, **kwargs):
+        self.set_config_from_dict(kwargs, overwrite=overwrite)
+
+    def set_config_from_dict(self, config_dict: Dict[str, Any], *, overwrite: bool = False):
+        known = set(self._FEATURE_CONFIGS + self._LABEL_CONFIGS)
+        if unknown := set(config_dict).difference(known):
+            raise KeyError(f"Unknown config option(s): {unknown}, available options are: {known}")
+        for group in (self._FEATURE_CONFIGS, self._LABEL_CONFIGS):
+            vals = [v for k, v in config_dict.items() if k in group and v is not None]
+            if len(set(map(type, vals))) > 1:
+                raise TypeError(f"Found mixed types: {set(map(type, vals))}. Input configs must be either all str or all lists.")
+            if vals and not isinstance(vals[0], str) and len(set(map(len, vals))) > 1:
+                raise ValueError("Found mixed sizes lists. Input configs must be of same length.")
+        for key, val in config_dict.items():
+            if key not in self.config or self.config[key] == val:
+                self.config[key] = val
+            elif overwrite:
+                self.config[key] = val
+            else:
+                raise KeyError(f"Config {key!r} exit with value {self.config[key]!r} but trying to set to a different "
+                               f"value {val!r}. If you want to overwrite the config, please specify `overwrite=True`")
+
+    # ---- splits --------------------------------------------------------------------------------------------
+    def get_split_idx(self, split_name: str, error_on_miss: bool = False):
+        if split_name is None:
+            return list(range(self.shape[0]))
+        if split_name in self._split_idx_dict:
+            return self._split_idx_dict[split_name]
+        if error_on_miss:
+            raise KeyError(f"Unknown split {split_name!r}. Please set the split inddices via set_split_idx first.")
+        return None
+
+    def set_split_idx(self, split_name: str, split_idx: Sequence[int]):
+        self._split_idx_dict[split_name] = split_idx
+
+    @property
+    def train_idx(self):
+        return self.get_split_idx("train", error_on_miss=False)
+
+    @property
+    def val_idx(self):
+        return self.get_split_idx("val", error_on_miss=False)
+
+    @property
+    def test_idx(self):
+        return self.get_split_idx("test", error_on_miss=False)
+
+    # ---- features ------------------------------------------------------------------------------------------
+    def _get_feature(self, channel, channel_type, mod):
+        if mod is not None:
+            raise AttributeError("`mod` needs a MuData object, which this container does not model")
+        data = self._data
+        if channel_type == "X":
+            return data.X
+        if channel_type == "raw_X":
+            return data.raw.X
+        if channel_type in ("obs", "var"):
+            return getattr(data, channel_type)[channel]
+        channel_type = channel_type or "obsm"
+        if channel_type not in self._DATA_CHANNELS:
+            raise ValueError(f"Unknown channel type {channel_type!r}. Available options are {self._DATA_CHANNELS}")
+        if channel is None:
+            warnings.warn("The `None` option for channel is deprecated; use channel_type='X'", DeprecationWarning, stacklevel=3)
+            return data.X
+        return getattr(data, channel_type)[channel]
+
+    def get_feature(self, *, split_name: Optional[str] = None, return_type: str = "numpy",
+                    channel: Optional[str] = None, channel_type: Optional[str] = "obsm", mod: Optional[str] = None):
+        feature = self._get_feature(channel, channel_type, mod)
+        channel_type = channel_type or "obsm"
+        if return_type == "default":
+            if split_name is not None:
+                raise ValueError(f"split_name is not supported when return_type is 'default', got {split_name=!r}")
+            return feature
+        if return_type == "sparse":
+            if isinstance(feature, np.ndarray):
+                feature = sp.csr_matrix(feature)
+            elif not sp.issparse(feature):
+                raise ValueError(f"Feature is not sparse, got {type(feature)}")
+        elif hasattr(feature, "toarray"):
+            feature = feature.toarray()
+        elif hasattr(feature, "to_numpy"):
+            feature = feature.to_numpy()
+        if split_name is not None:
+            if channel_type in ["X", "raw_X", "obs", "obsm", "obsp", "layers"]:
+                idx = [i for i in self.get_split_idx(split_name, error_on_miss=True) if i < feature.shape[0]]
+                feature = feature[idx][:, idx] if channel_type == "obsp" else feature[idx]
+        if return_type == "torch":
+            feature = torch.from_numpy(feature)
+        elif return_type not in ["numpy", "sparse"]:
+            raise ValueError(f"Unknown return_type {return_type!r}")
+        return feature
+
+    def _get(self, config_keys, *, split_name=None, return_type="numpy", **kwargs):
+        info = list(map(self.config.get, config_keys))
+        if all(i is None for i in info):
+            mods = channels = channel_types = [None]
+        else:
+            mods, channels, channel_types = map(_ensure_iter, info)
+            n = max(len(mods), len(channels), len(channel_types))
+            mods, channels, channel_types = (list(v) * n if len(v) == 1 and v[0] is None else v for v in (mods, channels, channel_types))
+        out = [self.get_feature(split_name=split_name, return_type=return_type, mod=m, channel=c, channel_type=t, **kwargs)
+               for m, c, t in zip(mods, channels, channel_types)]
+        return out[0] if len(out) == 1 else out
+
+    def get_x(self, split_name=None, return_type="numpy", **kwargs):
+        return self._get(self._FEATURE_CONFIGS, split_name=split_name, return_type=return_type, **kwargs)
+
+    def get_y(self, split_name=None, return_type="numpy", **kwargs):
+        return self._get(self._LABEL_CONFIGS, split_name=split_name, return_type=return_type, **kwargs)
+
+    def get_data(self, split_name=None, return_type="numpy", x_kwargs=dict(), y_kwargs=dict()):
+        return self.get_x(split_name, return_type, **x_kwargs), self.get_y(split_name, return_type, **y_kwargs)
+
+    def get_train_data(self, return_type="numpy", x_kwargs=dict(), y_kwargs=dict()):
+        return self.get_data("train", return_type, x_kwargs, y_kwargs)
+
+    def get_val_data(self, return_type="numpy", x_kwargs=dict(), y_kwargs=dict()):
+        return self.get_data("val", return_type, x_kwargs, y_kwargs)
+
+    def get_test_data(self, return_type="numpy", x_kwargs=dict(), y_kwargs=dict()):
+        return self.get_data("test", return_type, x_kwargs, y_kwargs)

@@ -155,6 +155,14 @@ def relu_backward(Y: torch.Tensor, dY: torch.Tensor) -> torch.Tensor:
     return G
 
 
+def bias_act_(X: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE) -> torch.Tensor:
+    """In place: X = act(X + bias)."""
+    lib = _lib_ready()
+    _call("bias_act_f32", lib.dh_bias_act_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          _dev(bias, torch.float32, "bias", 1), act, _stream())
+    return X
+
+
 def colsum(X: torch.Tensor) -> torch.Tensor:
     """out[j] = sum_i X[i, j] (deterministic two-pass)."""
     lib = _lib_ready()
@@ -275,3 +283,22 @@ def sage_alpha_grad(rowptr, col, w, src_cell_id, dst_cell_id, n_genes, H, dneigh
           _dev(H, torch.float32, "H", 2), _ld(H), _dev(dneigh, torch.float32, "dneigh", 2), _ld(dneigh),
           out.data_ptr(), _stream())
     return out
+
+
+def cellgene_graph_assemble(rowptr_x, col_x, val_x, rowptr_t, col_t, val_t, perm_t, n_cells: int, n_genes: int):
+    """CSR-by-destination CellFeatureGraph (+ reference edge ids) from X and X^T; see dh_cellgene_graph_assemble."""
+    lib = _lib_ready()
+    nnz = col_x.numel()
+    dev = rowptr_x.device
+    n_nodes, n_edges = n_cells + n_genes, 2 * nnz + n_cells + n_genes
+    rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(n_edges, dtype=torch.int32, device=dev)
+    val = torch.empty(n_edges, dtype=torch.float32, device=dev)
+    eid = torch.empty(n_edges, dtype=torch.int32, device=dev)
+    _call("cellgene_graph_assemble", lib.dh_cellgene_graph_assemble, n_cells, n_genes, nnz,
+          _dev(rowptr_x, torch.int32, "rowptr_x", 1), _dev(col_x, torch.int32, "col_x", 1),
+          _dev(val_x, torch.float32, "val_x", 1), _dev(rowptr_t, torch.int32, "rowptr_t", 1),
+          _dev(col_t, torch.int32, "col_t", 1), _dev(val_t, torch.float32, "val_t", 1),
+          _dev(perm_t, torch.int32, "perm_t", 1), rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), eid.data_ptr(),
+          _stream())
+    return rowptr, col, val, eid

@@ -1,0 +1,183 @@
+"""scDeepSort on MI355X — drop-in for dance/modules/single_modality/cell_type_annotation/scdeepsort.py:26-349
+(``GNN`` :26-88, ``ScDeepSort`` :91-349): same constructor / fit / predict / predict_proba / score signatures and
+``state_dict`` keys (``alpha``, ``layers.{i}.alpha``, ``layers.{i}.layers.1.weight|bias``, ``linear.weight|bias``).
+
+The training loop is the reference's (full-fan-out in-neighbour blocks of ``batch_size`` cells, Adam, summed CE);
+the per-row ``.item()`` loop of ``evaluate`` (:278-283) is replaced by the equivalent vectorised device ops.
+"""
+import time
+from copy import deepcopy
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from ....autograd import HipLinear
+from ....cellgraph import DataLoader, NeighborSampler
+from ....nn import AdaptiveSAGE
+from ....transforms import Compose, SetConfig
+from ....transforms.graph import PCACellFeatureGraph
+from ...base import BaseClassificationMethod
+
+
+class GNN(nn.Module):
+
+    def __init__(self, dim_in: int, dim_out: int, dim_hid: int, n_layers: int, gene_num: int, activation=None, norm=None,
+                 dropout: float = 0.):
+        super().__init__()
+        self.n_layers = n_layers
+        self.gene_num = gene_num
+        # [gene_num] is alpha of gene-gene self loop, [gene_num+1] is alpha of cell-cell self loop, the rest are betas
+        self.alpha = nn.Parameter(torch.tensor([1] * (self.gene_num + 2), dtype=torch.float32).unsqueeze(-1))
+        dropout_layer = nn.Dropout(p=dropout) if dropout > 0 else nn.Identity()
+        act_layer = activation or nn.Identity()
+        norm_layer = norm or nn.Identity()
+        self.layers = nn.ModuleList()
+        for i in range(n_layers):
+            self.layers.append(AdaptiveSAGE(dim_in if i == 0 else dim_hid, dim_hid, self.alpha, dropout_layer, act_layer, norm_layer))
+        self.linear = HipLinear(dim_hid, dim_out)
+        nn.init.xavier_uniform_(self.linear.weight, gain=nn.init.calculate_gain("relu"))
+
+    def forward(self, blocks, x):
+        assert len(blocks) == len(self.layers), f"Inonsistent layer info: {len(blocks)=} vs {len(self.layers)=}"
+        for block, layer in zip(blocks, self.layers):
+            x = layer(block, x)
+        return self.linear(x)
+
+
+class ScDeepSort(BaseClassificationMethod):
+
+    def __init__(self, dim_in: int, dim_hid: int, num_layers: int, species: str, tissue: str, *, dropout: int = 0,
+                 batch_size: int = 500, device: str = "cuda", save_root=None, verbose: bool = True):
+        self.dense_dim = dim_in
+        self.hidden_dim = dim_hid
+        self.n_layers = num_layers
+        self.dropout = dropout
+        self.species = species
+        self.tissue = tissue
+        self.batch_size = batch_size
+        self.device = device
+        self.verbose = verbose
+        self.postfix = time.strftime("%d_%m_%Y") + "_" + time.strftime("%H:%M:%S")
+        self.prj_path = Path(save_root).resolve() if save_root else Path().resolve()
+        self.save_path = (self.prj_path / "saved_models" / "single_modality" / "cell_type_annotation" / "pretrained" /
+                          self.species / "models")
+        if not self.save_path.exists():
+            self.save_path.mkdir(parents=True)
+
+    @staticmethod
+    def preprocessing_pipeline(n_components: int = 400, log_level="INFO"):
+        return Compose(
+            PCACellFeatureGraph(n_components=n_components, split_name="train"),
+            SetConfig({"label_channel": "cell_type"}),
+            log_level=log_level,
+        )
+
+    def _print(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def fit(self, graph, labels: torch.Tensor, epochs: int = 300, lr: float = 1e-3, weight_decay: float = 0,
+            val_ratio: float = 0.2):
+        gene_mask = graph.ndata["cell_id"] != -1
+        cell_mask = graph.ndata["cell_id"] == -1
+        num_genes = int(gene_mask.sum())
+        num_cells = int(cell_mask.sum())
+        labels = torch.as_tensor(labels)
+        self.num_labels = labels.max().item() + 1
+
+        perm = torch.randperm(num_cells) + num_genes
+        num_val = int(num_cells * val_ratio)
+        val_idx = perm[:num_val].to(self.device)
+        train_idx = perm[num_val:].to(self.device)
+
+        full_labels = -torch.ones(num_genes + num_cells, dtype=torch.long)
+        full_labels[-num_cells:] = labels.cpu()
+        graph = graph.to(self.device)
+        graph.ndata["label"] = full_labels.to(self.device)
+
+        self.model = GNN(self.dense_dim, self.num_labels, self.hidden_dim, self.n_layers, num_genes, activation=nn.ReLU(),
+                         dropout=self.dropout).to(self.device)
+        self.sampler = NeighborSampler(fanouts=[-1] * self.n_layers, edge_dir="in")
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
+        self.loss_fn = nn.CrossEntropyLoss(reduction="sum")
+
+        self._print(f"Train Number: {len(train_idx)}, Val Number: {len(val_idx)}")
+        max_val_acc, _train_acc, _epoch = 0, 0, 0
+        final_val_correct_num = final_val_unsure_num = 0
+        best_state_dict = None
+        for epoch in range(epochs):
+            loss = self.cal_loss(graph, train_idx)
+            train_acc = self.evaluate(graph, train_idx)[-1]
+            val_correct, val_unsure, val_acc = self.evaluate(graph, val_idx) if len(val_idx) else (0, 0, 0.0)
+            if max_val_acc <= val_acc:
+                final_val_correct_num, final_val_unsure_num = val_correct, val_unsure
+                _train_acc, _epoch, max_val_acc = train_acc, epoch, val_acc
+                self.save_model()
+                best_state_dict = deepcopy(self.model.state_dict())
+            self._print(f">>>>Epoch {epoch:04d}: Train Acc {train_acc:.4f}, Loss {loss / len(train_idx):.4f}, "
+                        f"Val correct {val_correct}, Val unsure {val_unsure}, Val Acc {val_acc:.4f}")
+        if best_state_dict is not None:
+            self.model.load_state_dict(best_state_dict)
+        self._print(f"---{self.species} {self.tissue} Best val result:---")
+        self._print(f"Epoch {_epoch:04d}, Train Acc {_train_acc:.4f}, Val Correct Num {final_val_correct_num}, "
+                    f"Val Total Num {len(val_idx)}, Val Unsure Num {final_val_unsure_num}")
+
+    def cal_loss(self, graph, idx: torch.Tensor):
+        self.model.train()
+        total_loss = total_size = 0
+        dataloader = DataLoader(graph=graph, indices=idx.cpu(), sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
+        for _, _, blocks in dataloader:
+            input_features = blocks[0].srcdata["features"]
+            output_labels = blocks[-1].dstdata["label"]
+            output_predictions = self.model(blocks, input_features)
+            loss = self.loss_fn(output_predictions, output_labels)
+            self.optimizer.zero_grad()
+            loss.backward()
+            self.optimizer.step()
+            total_size += (size := blocks[-1].num_dst_nodes())
+            total_loss += loss.item() * size
+        return total_loss / total_size
+
+    @torch.no_grad()
+    def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0):
+        self.model.eval()
+        total_correct = total_unsure = 0
+        dataloader = DataLoader(graph=graph, indices=idx.cpu(), sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
+        for _, _, blocks in dataloader:
+            input_features = blocks[0].srcdata["features"]
+            output_labels = blocks[-1].dstdata["label"]
+            pred = self.model(blocks, input_features)
+            unsure = pred.max(1).values < unsure_rate / self.num_labels  # :280-281 (on raw logits, as written)
+            total_unsure += int(unsure.sum())
+            total_correct += int(((pred.argmax(1) == output_labels) & ~unsure).sum())
+        return total_correct, total_unsure, total_correct / len(idx)
+
+    def save_model(self):
+        state = {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict()}
+        torch.save(state, self.save_path / f"{self.species}-{self.tissue}.pt")
+
+    def load_model(self):
+        filename = f"{self.species}-{self.tissue}.pt"
+        model_path = self.prj_path / "pretrained" / self.species / "models" / filename
+        state = torch.load(model_path, map_location=self.device)
+        self.model.load_state_dict(state["model"])
+
+    @torch.no_grad()
+    def predict_proba(self, graph):
+        self.model.eval()
+        cell_mask = (graph.ndata["cell_id"] == -1).cpu()
+        idx = torch.where(cell_mask)[0]
+        graph = graph.to(self.device)
+        logits = torch.zeros(graph.number_of_nodes(), self.num_labels)
+        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size)
+        for _, output_nodes, blocks in dataloader:
+            input_features = blocks[0].srcdata["features"]
+            logits[output_nodes.cpu()] = self.model(blocks, input_features).detach().cpu()
+        return nn.functional.softmax(logits[cell_mask], dim=-1).numpy()
+
+    def predict(self, graph, unsure_rate: float = 2.0, return_unsure: bool = False):
+        pred_prob = self.predict_proba(graph)
+        pred = pred_prob.argmax(1)
+        unsure = pred_prob.max(1) < unsure_rate / self.num_labels
+        return (pred, unsure) if return_unsure else pred

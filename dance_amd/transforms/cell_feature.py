@@ -1,0 +1,69 @@
+"""Cell / gene PCA features feeding the graph builders (dance/transforms/cell_feature.py:19-75,146-194).
+Host-side scikit-learn, as in the reference (GPU PCA is a later row)."""
+import numpy as np
+from sklearn.decomposition import PCA
+
+from ..registry import register_preprocessor
+from ..utils.matrix import normalize
+from .base import BaseTransform
+
+
+@register_preprocessor("feature", "cell")
+class WeightedFeaturePCA(BaseTransform):
+    """Gene PCA on the (train-split) expression matrix; cell feature = row-normalised X @ gene features."""
+
+    _DISPLAY_ATTRS = ("n_components", "split_name", "feat_norm_mode", "feat_norm_axis")
+
+    def __init__(self, n_components=400, split_name=None, feat_norm_mode=None, feat_norm_axis=0, save_info=False, **kwargs):
+        super().__init__(**kwargs)
+        self.n_components = n_components
+        self.split_name = split_name
+        self.feat_norm_mode = feat_norm_mode
+        self.feat_norm_axis = feat_norm_axis
+        self.save_info = save_info
+
+    def __call__(self, data):
+        feat = data.get_x(self.split_name)  # cells x genes
+        if self.feat_norm_mode is not None:
+            feat = normalize(feat, mode=self.feat_norm_mode, axis=self.feat_norm_axis)
+        if self.n_components > min(feat.shape):
+            self.logger.warning(f"n_components={self.n_components} must be between 0 and "
+                                f"min(n_samples, n_features)={min(feat.shape)} with svd_solver='full'")
+            self.n_components = min(feat.shape)
+        gene_pca = PCA(n_components=self.n_components)
+        gene_feat = gene_pca.fit_transform(feat.T)  # genes x components
+        x = data.get_x()
+        cell_feat = normalize(x, mode="normalize", axis=1) @ gene_feat
+        data.data.obsm[self.out] = cell_feat.astype(np.float32)
+        data.data.varm[self.out] = gene_feat.astype(np.float32)
+        if self.save_info:
+            data.data.uns["pca_components"] = gene_pca.components_
+            data.data.uns["pca_mean"] = gene_pca.mean_
+            data.data.uns["pca_explained_variance"] = gene_pca.explained_variance_
+            data.data.uns["pca_explained_variance_ratio"] = gene_pca.explained_variance_ratio_
+        return data
+
+
+@register_preprocessor("feature", "cell")
+class CellPCA(BaseTransform):
+    """PCA of the cell feature matrix -> obsm[out]."""
+
+    _DISPLAY_ATTRS = ("n_components", )
+
+    def __init__(self, n_components=400, *, channel=None, mod=None, save_info=False, svd_solver="auto", **kwargs):
+        super().__init__(**kwargs)
+        self.n_components = n_components
+        self.channel = channel
+        self.save_info = save_info
+        self.svd_solver = svd_solver
+
+    def __call__(self, data):
+        feat = data.get_feature(return_type="numpy", channel=self.channel, channel_type="obsm" if self.channel else "X")
+        if self.n_components > min(feat.shape):
+            self.n_components = min(feat.shape)
+        pca = PCA(n_components=self.n_components, svd_solver=self.svd_solver)
+        data.data.obsm[self.out] = pca.fit_transform(feat)
+        if self.save_info:
+            data.data.uns["pca_components"] = pca.components_
+            data.data.uns["pca_mean"] = pca.mean_
+        return data

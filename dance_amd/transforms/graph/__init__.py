@@ -1,0 +1,7 @@
+from .cell_feature_graph import CellFeatureGraph, PCACellFeatureGraph
+from .heteronet_graph import HeteronetGraph
+from .neighbor_graph import NeighborGraph
+from .spatial_graph import SpaGCNGraph, SpaGCNGraph2D, StagateGraph
+
+__all__ = ["CellFeatureGraph", "PCACellFeatureGraph", "HeteronetGraph", "NeighborGraph", "SpaGCNGraph",
+           "SpaGCNGraph2D", "StagateGraph"]

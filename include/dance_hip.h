@@ -98,6 +98,10 @@ DH_API int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b
  * two-pass reduction, workspace from dh_colsum_f32_workspace_bytes.                            */
 DH_API int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* Y, int64_t ldy,
                          const float* dY, int64_t lddy, float* G, int64_t ldg, dh_stream_t stream);
+/* X[i,:] = act(X[i,:] + bias) in place: bias of nn.Linear in AdaptiveSAGE (dance/models/nn/gnn.py:56)
+ * and of GraphConvolution on a dense adjacency (spagcn.py:360-361).  bias may be NULL.            */
+DH_API int dh_bias_act_f32(int64_t n_rows, int64_t width, float* X, int64_t ldx, const float* bias, int act,
+                    dh_stream_t stream);
 DH_API size_t dh_colsum_f32_workspace_bytes(int64_t n_rows, int64_t width);
 DH_API int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, float* out,
                   void* workspace, size_t workspace_bytes, dh_stream_t stream);
@@ -163,6 +167,20 @@ DH_API int dh_exclusive_scan_i32(int64_t n, const int32_t* in, int32_t* out, voi
  * every node (row sums accumulated in double, rounded to f32 once).                            */
 DH_API int dh_csr_row_normalize_f32(int64_t n_rows, const int32_t* rowptr, const float* val,
                              float* out_val, dh_stream_t stream);
+
+/* Assemble the CellFeatureGraph of dance/transforms/graph/cell_feature_graph.py:38-69 as a CSR by
+ * destination node from the expression matrix X (CSR, N cells x G genes) and its transpose
+ * (dh_csr_transpose; perm_t = its out_perm).  Nodes: genes [0,G), cells [G,G+N).  Row of gene g: its
+ * cell->gene in-edges then its self loop; row of cell c: its gene->cell in-edges then its self loop
+ * (weight 1, :69).  out_eid[p] = the edge's id in the reference's edge order (cell->gene edges in
+ * row-major nonzero order, then gene->cell, then self loops), so that order is recoverable exactly.
+ * val_x / val_t are the (optionally dh_csr_row_normalize'd, :62-68) weights of X and X^T.
+ * Outputs: out_rowptr [G+N+1], out_col/out_val/out_eid [2 nnz + G + N].                         */
+DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t nnz,
+                               const int32_t* rowptr_x, const int32_t* col_x, const float* val_x,
+                               const int32_t* rowptr_t, const int32_t* col_t, const float* val_t,
+                               const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
+                               float* out_val, int32_t* out_eid, dh_stream_t stream);
 
 /* ---- K4/K7: AdaptiveSAGE message + mean aggregation -----------------------------------------
  * neigh[v,:] = mean_{e=(u->v)} alpha[idx(e)] * w_e * H[u,:], idx(e) chosen from the src/dst

@@ -1,0 +1,82 @@
+"""CPU: the host-side mirror keeps the reference's operator API — reprs pinned by the reference's
+tests/transforms/test_basics.py:5-30, constructor signatures of SURVEY.md §8b.1, registry scopes, Data accessors."""
+import inspect
+
+import numpy as np
+import pytest
+
+from dance_amd.data import AnnDataLite, Data
+from dance_amd.registry import REGISTRY, resolve_from_registry
+from dance_amd.transforms import CellPCA, Compose, SetConfig, WeightedFeaturePCA
+from dance_amd.transforms.graph import (CellFeatureGraph, HeteronetGraph, NeighborGraph, PCACellFeatureGraph, SpaGCNGraph,
+                                        SpaGCNGraph2D, StagateGraph)
+
+
+def test_reprs_match_reference_test_basics():
+    assert repr(CellPCA(n_components=100)) == "CellPCA(n_components=100)"
+    assert repr(WeightedFeaturePCA(n_components=100, split_name="train")) == (
+        "WeightedFeaturePCA(n_components=100, split_name='train', feat_norm_mode=None, feat_norm_axis=0)")
+    t = NeighborGraph(n_neighbors=10, n_pcs=None, knn=True, random_state=0, method="umap", metric="euclidean")
+    assert repr(t) == ("NeighborGraph(n_neighbors=10, n_pcs=None, knn=True, random_state=0, method='umap', "
+                       "metric='euclidean')")
+    assert repr(PCACellFeatureGraph(n_components=100, split_name="train")) == "PCACellFeatureGraph(n_components=100, split_name='train')"
+    assert repr(SpaGCNGraph(alpha=1, beta=2)) == "SpaGCNGraph(alpha=1, beta=2)"
+    assert len(t.hexdigest()) == 32 and t.out == "NeighborGraph"
+
+
+def test_constructor_signatures():
+    def params(cls):
+        return {k: v.default for k, v in inspect.signature(cls.__init__).parameters.items() if k not in ("self", "kwargs", "device")}
+
+    assert params(NeighborGraph) == dict(n_neighbors=15, n_pcs=None, knn=True, random_state=0, method="umap",
+                                         metric="euclidean", channel="CellPCA")
+    p = params(CellFeatureGraph)
+    assert p["gene_feature_channel"] is None and p["mod"] is None and p["normalize_edges"] is True
+    assert params(PCACellFeatureGraph) == dict(n_components=400, split_name=None, normalize_edges=True, feat_norm_mode=None,
+                                               feat_norm_axis=0, mod=None, log_level="WARNING")
+    assert params(HeteronetGraph) == dict(knn_num=5, distance_metrics="l2", random_state=0, channel=None, channel_type="X",
+                                          ignore_first=False)
+    assert params(StagateGraph) == dict(model_name="radius", radius=1, n_neighbors=5, channel="spatial_pixel", channel_type="obsm")
+    assert params(SpaGCNGraph2D) == dict(channel="spatial_pixel")
+    with pytest.raises(ValueError):
+        StagateGraph("bogus")  # spatial_graph.py:135-136
+
+
+def test_registry_scopes():
+    for name in ("CellFeatureGraph", "PCACellFeatureGraph", "NeighborGraph", "HeteronetGraph"):
+        assert resolve_from_registry(name, "preprocessor.graph.cell").__name__ == name
+    for name in ("SpaGCNGraph", "SpaGCNGraph2D", "StagateGraph"):
+        assert resolve_from_registry(name, "preprocessor.graph.spatial").__name__ == name
+    with pytest.raises(KeyError):
+        resolve_from_registry("Nope", "preprocessor.graph.cell")
+    assert not REGISTRY.is_leaf_node("preprocessor.graph")
+
+
+def test_data_container():
+    x = np.arange(20, dtype=np.float32).reshape(5, 4)
+    d = Data(AnnDataLite(x, obsm={"emb": x[:, :2]}), train_size=3, val_size=0, test_size=-1)
+    assert d.train_idx == [0, 1, 2] and d.test_idx == [3, 4] and d.val_idx is None
+    assert d.num_cells == 5 and d.num_features == 4
+    d.set_config(feature_channel="emb", feature_channel_type="obsm")
+    assert d.get_x("train").shape == (3, 2)
+    assert d.get_feature(channel_type="X", return_type="sparse").nnz == 19
+    assert d.get_feature(channel="emb", return_type="torch").shape == (5, 2)
+    with pytest.raises(KeyError):
+        d.set_config(bogus=1)
+    with pytest.raises(KeyError):
+        d.set_config(feature_channel="other")
+    d.set_config(feature_channel="other", overwrite=True)
+    Compose(SetConfig({"feature_channel": "emb", "feature_channel_type": "obsm"}))(d)
+    assert d.config["feature_channel"] == "emb"
+    with pytest.raises(ValueError):
+        Data(AnnDataLite(x), train_size=9)
+
+
+def test_weighted_feature_pca_shapes():
+    rng = np.random.default_rng(0)
+    x = rng.poisson(1.0, (40, 30)).astype(np.float32)
+    d = Data(AnnDataLite(x), train_size=30)
+    d.set_config(feature_channel=None, feature_channel_type="X")
+    WeightedFeaturePCA(n_components=8, split_name="train")(d)
+    assert d.data.obsm["WeightedFeaturePCA"].shape == (40, 8) and d.data.varm["WeightedFeaturePCA"].shape == (30, 8)
+    assert d.data.obsm["WeightedFeaturePCA"].dtype == np.float32
