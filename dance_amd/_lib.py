@@ -6,7 +6,7 @@ the call raises — a GPU box must never silently run something else.
 """
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdancehip.so")
@@ -32,6 +32,7 @@ def _declare(lib):
         "dh_gemm_f32": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
         "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
         "dh_bias_act_f32": (c_int, [i64, i64, P, i64, P, i32, P]),
+        "dh_gaussian_kernel_f32": (c_int, [i64, i64, P, i64, c_double, P, i64, P, P]),
         "dh_colsum_f32_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_colsum_f32": (c_int, [i64, i64, P, i64, P, P, c_size_t, P]),
         "dh_pairwise_distance_f32": (c_int, [i64, i64, P, i64, P, i64, i32, P]),

@@ -22,16 +22,19 @@ from .graph import CSRGraph
 
 
 class _GCNLayerFn(torch.autograd.Function):
+    """out = act(rowscale * reduce_e(val_e * colscale[src] * (x W)[src]) + bias); scales / mean are optional."""
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], graph: CSRGraph,
-                active: bool):
+                active: bool, rowscale: Optional[torch.Tensor], colscale: Optional[torch.Tensor], reduce: int):
         x = x.contiguous() if x.stride(-1) != 1 else x
         w = weight.contiguous()
         support = kernels.gemm(x, w)
         out = kernels.spmm_csr(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, bias=bias,
+                               rowscale=rowscale, colscale=colscale, reduce=reduce,
                                act=kernels.ACT_RELU if active else kernels.ACT_NONE, tag="spmm_csr_f32[fwd]")
         ctx.graph, ctx.active, ctx.has_bias = graph, active, bias is not None
+        ctx.rowscale, ctx.colscale, ctx.reduce = rowscale, colscale, reduce
         ctx.save_for_backward(x, w, out if active else None)
         return out
 
@@ -46,18 +49,25 @@ class _GCNLayerFn(torch.autograd.Function):
             db = kernels.colsum(g)
         if need_x or need_w:
             gt = ctx.graph.transpose()
-            ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols, tag="spmm_csr_f32[bwd]")
+            # d(x W)[u] = colscale[u] * sum_{e: u -> v} val_e * m[v] * g[v],  m = rowscale (/ in-degree for mean)
+            m = ctx.rowscale
+            if ctx.reduce == kernels.REDUCE_MEAN:
+                deg = (ctx.graph.rowptr[1:] - ctx.graph.rowptr[:-1]).to(torch.float32).clamp(min=1)
+                m = (1.0 / deg) if m is None else m / deg
+            ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols, rowscale=ctx.colscale, colscale=m,
+                                  tag="spmm_csr_f32[bwd]")
             if need_w:
                 dw = kernels.gemm(x, ds, trans_a=True)
             if need_x:
                 dx = kernels.gemm(ds, w, trans_b=True)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def gcn_layer(x: torch.Tensor, weight: torch.Tensor, graph: CSRGraph, bias: Optional[torch.Tensor] = None,
-              active: bool = False) -> torch.Tensor:
-    """act(A @ (x @ weight) + bias) with a hand-written HIP forward and backward."""
-    return _GCNLayerFn.apply(x, weight, bias, graph, active)
+              active: bool = False, *, rowscale: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None,
+              reduce: int = kernels.REDUCE_SUM) -> torch.Tensor:
+    """act(rowscale * reduce(A diag(colscale) (x @ weight)) + bias) with a hand-written HIP forward and backward."""
+    return _GCNLayerFn.apply(x, weight, bias, graph, active, rowscale, colscale, reduce)
 
 
 class _DenseAdjLayerFn(torch.autograd.Function):

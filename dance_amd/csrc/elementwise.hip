@@ -132,3 +132,41 @@ extern "C" int dh_bias_act_f32(int64_t n_rows, int64_t width, float* X, int64_t 
   hipLaunchKernelGGL(bias_act_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), n_rows, width, X, ldx, bias, act);
   return dh::check_launch("dh_bias_act_f32");
 }
+
+// SpaGCN's Gaussian kernel (spagcn.py:249-251,807-809): e = exp(-(d*d) / (2 l^2)) in f32 like numpy evaluates it
+// (f32 square, f32 negate, divide by the f32-rounded scalar 2 l^2, expf).  Optionally writes e and/or per-row sums
+// (f64 accumulation, one wavefront per row): calculate_p needs only the sums, so search_l's bisection streams the
+// N^2 distances once per step and writes N floats.
+namespace {
+__global__ __launch_bounds__(256) void gaussian_kernel_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ D,
+                                                              int64_t ldd, float denom, float* __restrict__ out, int64_t ldo,
+                                                              float* __restrict__ rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* d = D + row * ldd;
+  double acc = 0.0;
+  for (int64_t c = lane; c < n_cols; c += 64) {
+    const float v = d[c];
+    const float e = expf(__fdiv_rn(-(v * v), denom));
+    if (out) out[row * ldo + c] = e;
+    acc += (double)e;
+  }
+  if (rowsum) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) rowsum[row] = (float)acc;
+  }
+}
+}  // namespace
+
+extern "C" int dh_gaussian_kernel_f32(int64_t n_rows, int64_t n_cols, const float* D, int64_t ldd, double l, float* out,
+                                      int64_t ldo, float* rowsum, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_gaussian_kernel_f32: negative size");
+  if (n_rows == 0 || n_cols == 0) return DH_OK;
+  if (!D || ldd < n_cols || (out && ldo < n_cols)) return dh::fail(DH_ERR_INVALID, "dh_gaussian_kernel_f32: bad pointer / leading dimension");
+  if (!(l > 0)) return dh::fail(DH_ERR_INVALID, "dh_gaussian_kernel_f32: l must be positive");
+  hipLaunchKernelGGL(gaussian_kernel_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream),
+                     n_rows, n_cols, D, ldd, (float)(2.0 * (l * l)), out, ldo, rowsum);
+  return dh::check_launch("dh_gaussian_kernel_f32");
+}

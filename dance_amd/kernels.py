@@ -163,6 +163,17 @@ def bias_act_(X: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE
     return X
 
 
+def gaussian_kernel(D: torch.Tensor, l: float, *, want_out: bool = True, want_rowsum: bool = False):
+    """exp(-D^2 / (2 l^2)) of a dense [n, m] matrix; returns (out | None, rowsum | None)."""
+    lib = _lib_ready()
+    n, m = D.shape
+    out = torch.empty((n, m), dtype=torch.float32, device=D.device) if want_out else None
+    rs = torch.empty(n, dtype=torch.float32, device=D.device) if want_rowsum else None
+    _call("gaussian_kernel_f32", lib.dh_gaussian_kernel_f32, n, m, _dev(D, torch.float32, "D", 2), _ld(D), float(l),
+          None if out is None else out.data_ptr(), m, None if rs is None else rs.data_ptr(), _stream())
+    return out, rs
+
+
 def colsum(X: torch.Tensor) -> torch.Tensor:
     """out[j] = sum_i X[i, j] (deterministic two-pass)."""
     lib = _lib_ready()

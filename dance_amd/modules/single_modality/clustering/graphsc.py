@@ -1,0 +1,209 @@
+"""graph-sc on MI355X — drop-in for dance/modules/single_modality/clustering/graphsc.py:34-484
+(``GraphSC`` :34-271, ``GCNAE`` :274-383, ``InnerProductDecoder`` :386-411, ``WeightedGraphConv`` :414-484).
+
+``WeightedGraphConv`` is DGL's GraphConv(norm="both") with edge weights: the out-degree^-1/2 source scaling, the
+weighted sum/mean aggregation, the in-degree^-1/2 scaling, bias and ReLU are ONE fused CSR SpMM launch
+(dh_spmm_csr_f32 with colscale / rowscale / bias / act) after the MFMA GEMM; degrees are those of the block, as in
+the reference (:444-449,:467-476).
+"""
+from typing import Any, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import kernels
+from ....autograd import HipLinear, gcn_layer, linear
+from ....cellgraph import DataLoader, MultiLayerFullNeighborSampler
+from ....graph import CSRGraph
+from ....transforms import Compose, SetConfig
+from ....transforms.graph import PCACellFeatureGraph
+from ...base import BaseClusteringMethod
+
+
+class WeightedGraphConv(nn.Module):
+    """Adaptation of the dgl GraphConv model to use edge weights (parameters ``weight`` [in, out], ``bias`` [out])."""
+
+    def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None, allow_zero_in_degree=False):
+        super().__init__()
+        if norm not in ("none", "both", "right", "left"):
+            raise ValueError(f'Invalid norm value. Must be either "none", "both", "right" or "left". But got "{norm}".')
+        self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
+        self._allow_zero_in_degree = allow_zero_in_degree
+        self.weight = nn.Parameter(torch.empty(in_feats, out_feats)) if weight else None
+        self.bias = nn.Parameter(torch.empty(out_feats)) if bias else None
+        self.reset_parameters()
+        self._activation = activation
+
+    def reset_parameters(self):
+        if self.weight is not None:
+            nn.init.xavier_uniform_(self.weight)
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+    def forward(self, graph, feat, weight=None, agg="sum"):
+        in_deg = graph.in_degrees()
+        if not self._allow_zero_in_degree and bool((in_deg == 0).any()):
+            raise RuntimeError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                               "Adding self-loop on the input graph will resolve the issue.")
+        if weight is not None and self.weight is not None:
+            raise RuntimeError("External weight is provided while at the same time the module has defined its own "
+                               "weight parameter. Please create the module with flag weight=False.")
+        weight = self.weight if weight is None else weight
+        colscale = rowscale = None
+        if self._norm == "both":
+            colscale = graph.out_degrees().float().clamp(min=1).pow(-0.5)  # :444-449
+            rowscale = in_deg.float().clamp(min=1).pow(-0.5)  # :467-471
+        elif self._norm == "right":
+            rowscale = 1.0 / in_deg.float().clamp(min=1)
+        elif self._norm == "left":
+            colscale = 1.0 / graph.out_degrees().float().clamp(min=1)
+        relu = self._activation in (F.relu, torch.relu) or isinstance(self._activation, nn.ReLU)
+        g = CSRGraph(graph.rowptr, graph.col, graph.val, graph.number_of_dst_nodes(), graph.number_of_src_nodes())
+        rst = gcn_layer(feat, weight, g, self.bias, relu, rowscale=rowscale, colscale=colscale,
+                        reduce=kernels.REDUCE_MEAN if agg == "mean" else kernels.REDUCE_SUM)
+        if self._activation is not None and not relu:
+            rst = self._activation(rst)
+        return rst
+
+
+class InnerProductDecoder(nn.Module):
+
+    def __init__(self, activation=torch.sigmoid, dropout=0.1):
+        super().__init__()
+        self.dropout = dropout
+        self.activation = activation
+
+    def forward(self, z):
+        z = F.dropout(z, self.dropout)  # training=True always, as in the reference (:409)
+        return self.activation(linear(z, z))  # z z^T on the matrix cores
+
+
+class GCNAE(nn.Module):
+
+    def __init__(self, *, agg: str, activation: str, in_feats: int, n_hidden: int, hidden_dim: int, hidden_1: int,
+                 hidden_2: int, dropout: float, n_layers: int, hidden_relu: bool, hidden_bn: bool):
+        super().__init__()
+        self.agg = agg
+        activation = {"gelu": F.gelu, "prelu": F.prelu, "relu": F.relu, "leaky_relu": F.leaky_relu}.get(activation, activation)
+        hidden = None if n_hidden == 0 else [hidden_1] if n_hidden == 1 else [hidden_1, hidden_2]
+        self.dropout = nn.Dropout(p=dropout) if dropout != 0 else None
+        self.layer1 = WeightedGraphConv(in_feats=in_feats, out_feats=hidden_dim, activation=activation)
+        if n_layers == 2:
+            self.layer2 = WeightedGraphConv(in_feats=hidden_dim, out_feats=hidden_dim, activation=activation)
+        self.decoder = InnerProductDecoder(activation=lambda x: x)
+        self.hidden = hidden
+        if hidden is not None:
+            enc = []
+            for i, s in enumerate(hidden):
+                enc.append(HipLinear(hidden_dim if i == 0 else hidden[i - 1], hidden[i]))
+                if hidden_bn and i != len(hidden):
+                    enc.append(nn.BatchNorm1d(hidden[i]))
+                if hidden_relu and i != len(hidden):
+                    enc.append(nn.ReLU())
+            self.encoder = nn.Sequential(*enc)
+
+    def forward(self, blocks, features):
+        x = blocks[0].srcdata["features"]
+        for i in range(len(blocks)):
+            if self.dropout is not None:
+                x = self.dropout(x)
+            x = (self.layer1 if i == 0 else self.layer2)(blocks[i], x, agg=self.agg)
+        if self.hidden is not None:
+            x = self.encoder(x)
+        return self.decoder(x), x
+
+
+def block_dst_adjacency(block) -> torch.Tensor:
+    """``g.adjacency_matrix().to_dense()[dst][:, dst]`` of the reference (:208-209): B x B, entry [u, v] = 1 for an
+    edge u -> v between two destination nodes of the block."""
+    b = block.number_of_dst_nodes()
+    rows = torch.repeat_interleave(torch.arange(b, device=block.rowptr.device), block.in_degrees())
+    cols = block.col.to(torch.int64)
+    keep = cols < b
+    adj = torch.zeros((b, b), dtype=torch.float32, device=block.rowptr.device)
+    adj.index_put_((cols[keep], rows[keep]), torch.ones(int(keep.sum()), device=adj.device), accumulate=True)
+    return adj
+
+
+class GraphSC(BaseClusteringMethod):
+
+    def __init__(self, agg: str = "sum", activation: str = "relu", in_feats: int = 50, n_hidden: int = 1, hidden_dim: int = 200,
+                 hidden_1: int = 300, hidden_2: int = 0, dropout: float = 0.1, n_layers: int = 1, hidden_relu: bool = False,
+                 hidden_bn: bool = False, n_clusters: int = 10, cluster_method: str = "kmeans", num_workers: int = 1,
+                 device: str = "auto"):
+        super().__init__()
+        self.n_layers = n_layers
+        self.n_clusters = n_clusters
+        self.cluster_method = cluster_method
+        self.num_workers = num_workers
+        self.device = "cuda" if device == "auto" else device
+        self.model = GCNAE(agg=agg, activation=activation, in_feats=in_feats, n_hidden=n_hidden, hidden_dim=hidden_dim,
+                           hidden_1=hidden_1, hidden_2=hidden_2, dropout=dropout, n_layers=n_layers, hidden_relu=hidden_relu,
+                           hidden_bn=hidden_bn).to(self.device)
+
+    @staticmethod
+    def preprocessing_pipeline(n_top_genes: int = 3000, normalize_weights: str = "log_per_cell", n_components: int = 50,
+                               normalize_edges: bool = False, log_level="INFO"):
+        """Graph part of the reference pipeline (:134-146).  The scanpy gene filtering / HVG / normalisation steps
+        (:111-131) are CPU count-matrix preprocessing outside the hot path: feed a matrix that
+        already went through them."""
+        if normalize_weights not in ("log_per_cell", "per_cell", "none"):
+            raise ValueError(f"Unknown normalization option {normalize_weights!r}."
+                             "Available options are: 'none', 'log_per_cell', 'per_cell'")
+        return Compose(
+            PCACellFeatureGraph(n_components=n_components, normalize_edges=normalize_edges, feat_norm_mode="standardize"),
+            SetConfig({"feature_channel": "CellFeatureGraph", "feature_channel_type": "uns", "label_channel": "Group"}),
+            log_level=log_level,
+        )
+
+    def fit(self, g, y: Optional[Any] = None, *, epochs: int = 100, lr: float = 1e-5, batch_size: int = 128,
+            show_epoch_ari: bool = False, eval_epoch: bool = False):
+        g = g.to(self.device)
+        g.ndata["order"] = g.ndata["label"] = g.ndata["feat_id"]
+        train_ids = np.where(g.ndata["label"].cpu().numpy() != -1)[0]
+        sampler = MultiLayerFullNeighborSampler(self.n_layers)
+        dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False)
+        optim = torch.optim.Adam(self.model.parameters(), lr=lr)
+        self.losses, aris, Z = [], [], {}
+        for epoch in range(epochs):
+            self.model.train()
+            z, order = [], []
+            for input_nodes, output_nodes, blocks in dataloader:
+                input_features = blocks[0].srcdata["features"]
+                last = blocks[-1]
+                adj_logits, emb = self.model.forward(blocks, input_features)
+                z.append(emb.detach())
+                order.append(last.dstdata["order"])
+                adj = block_dst_adjacency(last)
+                total = float(adj.shape[0] * adj.shape[0])
+                s = float(adj.sum())
+                pos_weight = torch.tensor([(total - s) / s], device=adj.device)
+                factor = (total - s) * 2 or 1
+                norm = total / factor
+                adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
+                loss = norm * F.binary_cross_entropy_with_logits(adj_logits, adj, pos_weight=pos_weight)
+                optim.zero_grad()
+                loss.backward()
+                optim.step()
+                self.losses.append(loss.item())
+            z = torch.cat(z).cpu().numpy()
+            order = np.argsort(torch.cat(order).cpu().numpy())
+            self.z = z[order]
+            if eval_epoch and y is not None:
+                aris.append(self.score(None, y))
+                Z[f"epoch{epoch}"] = self.z
+        if eval_epoch and aris:
+            self.z = Z[f"epoch{int(np.argmax(aris))}"]
+
+    def predict(self, x: Optional[Any] = None):
+        if self.cluster_method == "kmeans":
+            from sklearn.cluster import KMeans
+            return KMeans(n_clusters=self.n_clusters, init="k-means++", random_state=5, n_init=10).fit_predict(self.z)
+        if self.cluster_method == "leiden":
+            raise NotImplementedError("leiden needs scanpy/leidenalg, which are not available in this environment")
+        raise ValueError(f"Unknown clustering {self.cluster_method}, available options are: 'kmeans', 'leiden'")
+
+    def get_latent(self):
+        return self.z

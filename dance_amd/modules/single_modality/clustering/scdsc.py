@@ -23,3 +23,113 @@ class GNNLayer(nn.Module):
     def forward(self, features, adj, active=True):
         # relu(spmm(adj, mm(features, weight))): MFMA GEMM + fused-ReLU CSR SpMM (dance_amd/autograd.py)
         return gcn_layer(features, self.weight, as_graph(adj, features.device), None, bool(active))
+
+
+# ---- ScDSCModel: the 7-layer GCN module + autoencoder (scdsc.py:339-472) ----------------------------------------
+import torch.nn.functional as F  # noqa: E402
+
+from ....autograd import HipLinear  # noqa: E402
+
+
+class MeanAct(nn.Module):
+
+    def forward(self, x):
+        return torch.clamp(torch.exp(x), min=1e-5, max=1e6)
+
+
+class DispAct(nn.Module):
+
+    def forward(self, x):
+        return torch.clamp(F.softplus(x), min=1e-4, max=1e4)
+
+
+class ZINBLoss(nn.Module):
+    """Zero-inflated negative binomial NLL (contract of dance/utils/loss.py:780-829); stays in PyTorch."""
+
+    def forward(self, x, mean, disp, pi, scale_factor, ridge_lambda=0.0):
+        eps = 1e-10
+        mean = mean * scale_factor[:, None]
+        lg = torch.lgamma
+        t1 = lg(disp.double() + eps) + lg(x.double() + 1.0) - lg(x.double() + disp.double() + eps)
+        t2 = (disp + x) * torch.log(1.0 + (mean / (disp + eps))) + (x * (torch.log(disp + eps) - torch.log(mean + eps)))
+        nb_case = t1 + t2 - torch.log(1.0 - pi + eps)
+        zero_nb = torch.pow(disp / (disp + mean + eps), disp)
+        zero_case = -torch.log(pi + ((1.0 - pi) * zero_nb) + eps)
+        result = torch.where(torch.le(x, 1e-8), zero_case, nb_case)
+        if ridge_lambda > 0:
+            result = result + ridge_lambda * torch.square(pi)
+        return torch.mean(result)
+
+
+class AE(nn.Module):
+    """Autoencoder of scDSC (scdsc.py:504-606): 10 Linear (+9 BatchNorm) layers; same attribute names, so reference
+    ``state_dict``s load.  The Linear layers run on dh_gemm_f32."""
+
+    def __init__(self, n_enc_1, n_enc_2, n_enc_3, n_dec_1, n_dec_2, n_dec_3, n_input, n_z1, n_z2, n_z3):
+        super().__init__()
+        dims = [("enc_1", n_input, n_enc_1, "BN1"), ("enc_2", n_enc_1, n_enc_2, "BN2"), ("enc_3", n_enc_2, n_enc_3, "BN3"),
+                ("z1_layer", n_enc_3, n_z1, "BN4"), ("z2_layer", n_z1, n_z2, "BN5"), ("z3_layer", n_z2, n_z3, "BN6"),
+                ("dec_1", n_z3, n_dec_1, "BN7"), ("dec_2", n_dec_1, n_dec_2, "BN8"), ("dec_3", n_dec_2, n_dec_3, "BN9")]
+        for name, i, o, bn in dims:
+            setattr(self, name, HipLinear(i, o))
+            setattr(self, bn, nn.BatchNorm1d(o))
+        self.x_bar_layer = HipLinear(n_dec_3, n_input)
+
+    def forward(self, x):
+        enc_h1 = F.relu(self.BN1(self.enc_1(x)))
+        enc_h2 = F.relu(self.BN2(self.enc_2(enc_h1)))
+        enc_h3 = F.relu(self.BN3(self.enc_3(enc_h2)))
+        z1 = self.BN4(self.z1_layer(enc_h3))
+        z2 = self.BN5(self.z2_layer(z1))
+        z3 = self.BN6(self.z3_layer(z2))
+        dec_h1 = F.relu(self.BN7(self.dec_1(z3)))
+        dec_h2 = F.relu(self.BN8(self.dec_2(dec_h1)))
+        dec_h3 = F.relu(self.BN9(self.dec_3(dec_h2)))
+        return self.x_bar_layer(dec_h3), enc_h1, enc_h2, enc_h3, z3, z2, z1, dec_h3
+
+
+class ScDSCModel(nn.Module):
+    """scdsc.py:339-472 — AE + seven chained GNNLayers with sigma-mixing of the AE activations, softmax prediction,
+    Student-t soft assignment q and the ZINB heads.  Every GNNLayer is the HIP GCN op (GEMM + fused SpMM)."""
+
+    def __init__(self, sigma: float = 1, n_enc_1: int = 512, n_enc_2: int = 256, n_enc_3: int = 256, n_dec_1: int = 256,
+                 n_dec_2: int = 256, n_dec_3: int = 512, n_z1: int = 256, n_z2: int = 128, n_z3: int = 32,
+                 n_clusters: int = 10, n_input: int = 100, v: float = 1, device: str = "auto"):
+        super().__init__()
+        self.device = "cuda" if device == "auto" else device
+        self.sigma = sigma
+        self.ae = AE(n_enc_1=n_enc_1, n_enc_2=n_enc_2, n_enc_3=n_enc_3, n_dec_1=n_dec_1, n_dec_2=n_dec_2, n_dec_3=n_dec_3,
+                     n_input=n_input, n_z1=n_z1, n_z2=n_z2, n_z3=n_z3)
+        self.gnn_1 = GNNLayer(n_input, n_enc_1)
+        self.gnn_2 = GNNLayer(n_enc_1, n_enc_2)
+        self.gnn_3 = GNNLayer(n_enc_2, n_enc_3)
+        self.gnn_4 = GNNLayer(n_enc_3, n_z1)
+        self.gnn_5 = GNNLayer(n_z1, n_z2)
+        self.gnn_6 = GNNLayer(n_z2, n_z3)
+        self.gnn_7 = GNNLayer(n_z3, n_clusters)
+        self.cluster_layer = nn.Parameter(torch.empty(n_clusters, n_z3))
+        torch.nn.init.xavier_normal_(self.cluster_layer.data)
+        self._dec_mean = nn.Sequential(HipLinear(n_dec_3, n_input), MeanAct())
+        self._dec_disp = nn.Sequential(HipLinear(n_dec_3, n_input), DispAct())
+        self._dec_pi = nn.Sequential(HipLinear(n_dec_3, n_input), nn.Sigmoid())
+        self.v = v
+        self.zinb_loss = ZINBLoss()
+        self.to(self.device)
+
+    def forward(self, x, adj):
+        x_bar, tra1, tra2, tra3, z3, z2, z1, dec_h3 = self.ae(x)
+        sigma = self.sigma
+        adj = as_graph(adj, x.device)  # CSR (+ transpose) built once, reused by all 7 layers and every epoch
+        h = self.gnn_1(x, adj)
+        h = self.gnn_2((1 - sigma) * h + sigma * tra1, adj)
+        h = self.gnn_3((1 - sigma) * h + sigma * tra2, adj)
+        h = self.gnn_4((1 - sigma) * h + sigma * tra3, adj)
+        h = self.gnn_5((1 - sigma) * h + sigma * z1, adj)
+        h = self.gnn_6((1 - sigma) * h + sigma * z2, adj)
+        h = self.gnn_7((1 - sigma) * h + sigma * z3, adj, active=False)
+        predict = F.softmax(h, dim=1)
+        _mean, _disp, _pi = self._dec_mean(dec_h3), self._dec_disp(dec_h3), self._dec_pi(dec_h3)
+        q = 1.0 / (1.0 + torch.sum(torch.pow(z3.unsqueeze(1) - self.cluster_layer, 2), 2) / self.v)
+        q = q.pow((self.v + 1.0) / 2.0)
+        q = (q.t() / torch.sum(q, 1)).t()
+        return x_bar, q, predict, z3, _mean, _disp, _pi, self.zinb_loss

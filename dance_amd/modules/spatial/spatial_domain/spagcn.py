@@ -6,12 +6,21 @@ The reference multiplies by a DENSE N x N adjacency (spagcn.py:497,359).  A dens
 with the MFMA GEMM (exact reference arithmetic, small N); a sparse tensor / ``CSRGraph`` (the kNN-truncated
 Gaussian kernel used at scale) goes through the CSR SpMM.
 """
+import logging
+
 import numpy as np
 import torch
-from torch import nn
+from torch import nn, optim
+from torch.nn.parameter import Parameter
 
+from .... import kernels
 from ....autograd import dense_adj_layer, gcn_layer
 from ....graph import CSRGraph, as_graph
+from ....transforms import CellPCA, Compose, SetConfig
+from ....transforms.graph import SpaGCNGraph, SpaGCNGraph2D
+from ...base import BaseClusteringMethod
+
+logger = logging.getLogger("dance")
 
 
 class GraphConvolution(nn.Module):
@@ -42,3 +51,226 @@ class GraphConvolution(nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_features} -> {self.out_features})"
+
+
+def _to_device_f32(a, device):
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device, dtype=torch.float32)
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+def calculate_p(adj, l, device="cuda"):
+    """spagcn.py:249-251: mean_i sum_j exp(-adj_ij^2 / (2 l^2)) - 1.  One streaming pass over the distance matrix
+    (dh_gaussian_kernel_f32 row sums + dh_colsum_f32); the N x N kernel matrix is never materialised."""
+    d = _to_device_f32(adj, device)
+    _, rs = kernels.gaussian_kernel(d, l, want_out=False, want_rowsum=True)
+    return float(kernels.colsum(rs[:, None])[0]) / d.shape[0] - 1
+
+
+def search_l(p, adj, start=0.01, end=1000, tol=0.01, max_run=100, device="cuda"):
+    """spagcn.py:254-287 bisection on l; the distance matrix is moved to the device once."""
+    d = _to_device_f32(adj, device)
+    run = 0
+    p_low, p_high = calculate_p(d, start), calculate_p(d, end)
+    if p_low > p + tol:
+        logger.info("l not found, try smaller start point.")
+        return None
+    elif p_high < p - tol:
+        logger.info("l not found, try bigger end point.")
+        return None
+    elif np.abs(p_low - p) <= tol:
+        return start
+    elif np.abs(p_high - p) <= tol:
+        return end
+    while (p_low + tol) < p < (p_high - tol):
+        run += 1
+        if run > max_run:
+            logger.info(f"Exact l not found, closest values are:\nl={start}: p={p_low}\nl={end}: p={p_high}")
+            return None
+        mid = (start + end) / 2
+        p_mid = calculate_p(d, mid)
+        if np.abs(p_mid - p) <= tol:
+            logger.info(f"recommended l: {mid}")
+            return mid
+        if p_mid <= p:
+            start, p_low = mid, p_mid
+        else:
+            end, p_high = mid, p_mid
+    return None
+
+
+class SimpleGCDEC(nn.Module):
+    """Basic model used in SpaGCN training (spagcn.py:369-584): GraphConvolution + DEC clustering head."""
+
+    def __init__(self, nfeat, nhid, alpha=0.2, device="cuda"):
+        super().__init__()
+        self.gc = GraphConvolution(nfeat, nhid)
+        self.nhid = nhid
+        self.alpha = alpha
+        self.device = device
+
+    def forward(self, x, adj):
+        x = self.gc(x, adj)
+        # Student-t kernel exactly as written in the reference (:394-396), including q**(alpha+1)/2 precedence
+        q = 1.0 / ((1.0 + torch.sum((x.unsqueeze(1) - self.mu)**2, dim=2) / self.alpha) + 1e-8)
+        q = q**(self.alpha + 1.0) / 2.0
+        q = q / torch.sum(q, dim=1, keepdim=True)
+        return x, q
+
+    def loss_function(self, p, q):
+
+        def kld(target, pred):
+            return torch.mean(torch.sum(target * torch.log(target / (pred + 1e-6)), dim=1))
+
+        return kld(p, q)
+
+    def target_distribution(self, q):
+        p = q**2 / torch.sum(q, dim=0)
+        return p / torch.sum(p, dim=1, keepdim=True)
+
+    def _adj(self, adj):
+        if isinstance(adj, CSRGraph):
+            return adj
+        if isinstance(adj, torch.Tensor) and adj.layout != torch.strided:
+            return as_graph(adj, self.device)
+        return _to_device_f32(adj, self.device)
+
+    def fit(self, X, adj, lr=0.001, epochs=5000, update_interval=3, trajectory_interval=50, weight_decay=5e-4, opt="sgd",
+            init="louvain", n_neighbors=10, res=0.4, n_clusters=10, init_spa=True, tol=1e-3):
+        self.trajectory = []
+        self.to(self.device)
+        X = _to_device_f32(X, self.device)
+        adj = self._adj(adj)
+        if opt == "sgd":
+            optimizer = optim.SGD(self.parameters(), lr=lr, momentum=0.9)
+        elif opt == "admin":
+            optimizer = optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay)
+        else:
+            raise ValueError(f"Unknown optimizer {opt!r}")
+        with torch.no_grad():
+            features = self.gc(X, adj)
+        if init == "kmeans":
+            from sklearn.cluster import KMeans
+            self.n_clusters = n_clusters
+            kmeans = KMeans(self.n_clusters, n_init=20)
+            y_pred = kmeans.fit_predict(features.cpu().numpy() if init_spa else X.cpu().numpy())
+        elif init == "louvain":
+            raise NotImplementedError("init='louvain' needs scanpy + leidenalg (spagcn.py:480-492), which are not "
+                                      "installable here; use init='kmeans' with n_clusters")
+        else:
+            raise ValueError(f"Unknown init {init!r}")
+        y_pred_last = y_pred
+        self.mu = Parameter(torch.empty(self.n_clusters, self.nhid, device=self.device))
+        self.trajectory.append(y_pred)
+        yt = torch.from_numpy(y_pred).to(self.device)
+        centers = torch.stack([features[yt == c].mean(0) for c in range(self.n_clusters)])  # groupby("Group").mean()
+        self.mu.data.copy_(centers)
+        if opt == "sgd":  # mu was created after the optimizer in the reference too (:494), hence not optimised
+            pass
+        self.train()
+        for epoch in range(epochs):
+            if epoch % update_interval == 0:
+                _, q = self.forward(X, adj)
+                p = self.target_distribution(q).data
+            optimizer.zero_grad()
+            z, q = self(X, adj)
+            loss = self.loss_function(p, q)
+            loss.backward()
+            optimizer.step()
+            if epoch % trajectory_interval == 0:
+                self.trajectory.append(torch.argmax(q, dim=1).data.cpu().numpy())
+            y_pred = torch.argmax(q, dim=1).data.detach().cpu().numpy()
+            delta_label = np.sum(y_pred != y_pred_last).astype(np.float32) / X.shape[0]
+            y_pred_last = y_pred
+            if epoch > 0 and (epoch - 1) % update_interval == 0 and delta_label < tol:
+                logger.info(f"delta_label {delta_label} < tol {tol}; total epoch: {epoch}")
+                break
+
+    @torch.no_grad()
+    def predict(self, X, adj):
+        return self(_to_device_f32(X, self.device), self._adj(adj))
+
+
+def refine(sample_id, pred, dis, shape="hexagon"):
+    """spagcn.py:290-334: majority vote among the nearest spots (6 for hexagon, 4 for square) when more than half of
+    them disagree with the spot's own label.  The neighbour lists come from a device top-k of the distance rows
+    instead of a pandas sort per spot."""
+    num_nbs = {"hexagon": 6, "square": 4}.get(shape)
+    if num_nbs is None:
+        raise ValueError("Shape not recongized, shape='hexagon' for Visium data, 'square' for ST data.")
+    pred = np.asarray(pred)
+    d = torch.as_tensor(np.asarray(dis), dtype=torch.float32)
+    order = torch.argsort(d, dim=1, stable=True)[:, :num_nbs + 1].numpy()  # includes the spot itself
+    refined = []
+    for i in range(len(sample_id)):
+        nbs_pred = pred[order[i]]
+        self_pred = pred[i]
+        vals, counts = np.unique(nbs_pred, return_counts=True)
+        if counts[vals == self_pred][0] < num_nbs / 2 and counts.max() > num_nbs / 2:
+            refined.append(vals[counts.argmax()])
+        else:
+            refined.append(self_pred)
+    return refined
+
+
+class SpaGCN(BaseClusteringMethod):
+    """SpaGCN (spagcn.py:700-892): ``x = (embed, adj)`` with ``adj`` the distance matrix from SpaGCNGraph (dense
+    ndarray / device tensor) or a kNN-truncated ``CSRGraph`` of distances for large N."""
+
+    def __init__(self, l=None, device="cuda"):
+        self.l = l
+        self.res = None
+        self.device = device
+
+    @staticmethod
+    def preprocessing_pipeline(alpha: float = 1, beta: int = 49, dim: int = 50, log_level="INFO"):
+        """Graph + feature part of spagcn.py:715-731 (gene-name filtering and scanpy normalisation are CPU
+        preprocessing outside the hot path)."""
+        return Compose(
+            SpaGCNGraph(alpha=alpha, beta=beta),
+            SpaGCNGraph2D(),
+            CellPCA(n_components=dim),
+            SetConfig({
+                "feature_channel": ["CellPCA", "SpaGCNGraph", "SpaGCNGraph2D"],
+                "feature_channel_type": ["obsm", "obsp", "obsp"],
+                "label_channel": "label",
+                "label_channel_type": "obs"
+            }),
+            log_level=log_level,
+        )
+
+    def search_l(self, p, adj, start=0.01, end=1000, tol=0.01, max_run=100):
+        return search_l(p, adj, start, end, tol, max_run, device=self.device)
+
+    def set_l(self, l):
+        self.l = l
+
+    def calc_adj_exp(self, adj):
+        """exp(-adj^2 / (2 l^2)) on the device; a ``CSRGraph`` of distances keeps its sparsity pattern."""
+        if isinstance(adj, CSRGraph):
+            vals, _ = kernels.gaussian_kernel(adj.val[None, :], self.l)
+            return CSRGraph(adj.rowptr, adj.col, vals[0].contiguous(), adj.n_rows, adj.n_cols, symmetric=adj.symmetric)
+        out, _ = kernels.gaussian_kernel(_to_device_f32(adj, self.device), self.l)
+        return out
+
+    def fit(self, x, y=None, *, num_pcs=50, lr=0.005, epochs=2000, weight_decay=0, opt="admin", init_spa=True,
+            init="louvain", n_neighbors=10, n_clusters=None, res=0.4, tol=1e-3):
+        embed, adj = x
+        self.num_pcs, self.res, self.lr, self.epochs = num_pcs, res, lr, epochs
+        self.weight_decay, self.opt, self.init_spa, self.init = weight_decay, opt, init_spa, init
+        self.n_neighbors, self.n_clusters, self.tol = n_neighbors, n_clusters, tol
+        if self.l is None:
+            raise ValueError("l should be set before fitting the model!")
+        self.model = SimpleGCDEC(embed.shape[1], embed.shape[1], device=self.device)
+        adj_exp = self.calc_adj_exp(adj)
+        self.model.fit(embed, adj_exp, lr=self.lr, epochs=self.epochs, weight_decay=self.weight_decay, opt=self.opt,
+                       init_spa=self.init_spa, init=self.init, n_neighbors=self.n_neighbors, n_clusters=self.n_clusters,
+                       res=self.res, tol=self.tol)
+
+    def predict_proba(self, x):
+        embed, adj = x
+        _, pred_prob = self.model.predict(embed, self.calc_adj_exp(adj))
+        return pred_prob
+
+    def predict(self, x):
+        return torch.argmax(self.predict_proba(x), dim=1).data.cpu().numpy()

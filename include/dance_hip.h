@@ -102,6 +102,12 @@ DH_API int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* Y, i
  * and of GraphConvolution on a dense adjacency (spagcn.py:360-361).  bias may be NULL.            */
 DH_API int dh_bias_act_f32(int64_t n_rows, int64_t width, float* X, int64_t ldx, const float* bias, int act,
                     dh_stream_t stream);
+/* SpaGCN Gaussian kernel: e = exp(-d^2 / (2 l^2)) (spagcn.py:249-251 calculate_p, :807-809 calc_adj_exp),
+ * f32 like numpy.  out (may be NULL) receives e; rowsum (may be NULL) receives sum_j e[i,j], so
+ * calculate_p / search_l stream the N x N distance matrix without materialising the kernel.
+ * Also used on the value array of a kNN-truncated CSR (n_rows = 1).                              */
+DH_API int dh_gaussian_kernel_f32(int64_t n_rows, int64_t n_cols, const float* D, int64_t ldd, double l,
+                           float* out, int64_t ldo, float* rowsum, dh_stream_t stream);
 DH_API size_t dh_colsum_f32_workspace_bytes(int64_t n_rows, int64_t width);
 DH_API int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, float* out,
                   void* workspace, size_t workspace_bytes, dh_stream_t stream);
