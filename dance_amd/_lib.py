@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdancehip.so")
+LIB_PATH = os.environ.get("DANCE_HIP_LIB", os.path.join(_HERE, "libdancehip.so"))  # override: A/B builds only
 
 _lib = None
 

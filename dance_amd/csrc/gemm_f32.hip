@@ -5,118 +5,183 @@
 // semantics (torch.mm, scdsc.py:497 / spagcn.py:358) — gfx950 has no TF32-like mode and we
 // do not down-convert.  MFMA-bound: 157 TFLOP/s peak for f32 inputs.
 //
-// Block = 4 wavefronts computing a 128x128 tile; each wavefront owns 64x64 = 2x2 MFMA tiles
-// (64 accumulator VGPRs).  K is consumed 32 at a time through a register-staged,
-// double-buffered LDS pipeline (global loads of tile t+1 are in flight while tile t feeds
-// the matrix cores; one barrier per K-step).  LDS images are padded so the fragment reads
-// are bank-conflict free:
-//   "MK" image (operand stored with K contiguous): [128][32+4] floats, fragment = one
-//        ds_read_b128 per lane (4 consecutive k of one row) -> 4 MFMA steps;
-//   "KM" image (operand stored with M/N contiguous): [32][128+4] floats, fragment = 4
-//        ds_read_b32 (rows k, k+1.. of one column).
+// Block = 8 wavefronts computing a 256x256 tile; wave (wm, wn) of the 2x4 wave grid owns a
+// 128x64 patch = 4x2 MFMA tiles (128 accumulator VGPRs).  The big macro-tile is deliberate:
+// ablation on MI355X showed the 128x128 version of this kernel capped at 120 TFLOP/s by the
+// CU's global-load path (6 B/clk/CU of tile refills; 148 TFLOP/s with the loads removed);
+// 256x256 halves the bytes fetched per flop.  K is consumed 32 at a time through a
+// register-staged, double-buffered LDS pipeline; the global loads of tile t+1 are issued
+// piecewise between the four k-groups of tile t (no burst), and one barrier ends a K-step.
+// LDS images are padded so fragment reads are bank-conflict free:
+//   "MK" image (operand stored with K contiguous): [256][32+4] floats; a fragment is one
+//        ds_read_b128 per 32x32 tile (4 consecutive k of one row) feeding 4 MFMA steps; the
+//        wave's tiles are consecutive 32-row slabs of its span;
+//   "KM" image (operand stored with M/N contiguous): [32][256+4] floats; a fragment is one
+//        ds_read_b128 (A side, 4 ADJACENT rows) or ds_read_b64 (B side, 2 adjacent columns)
+//        per MFMA step feeding ALL of the wave's tiles on that side, which therefore
+//        interleave: tile x holds rows 4i + x (columns 2j + y) of the wave's span.
 // Lane half h = lane>>5 supplies k = 8*g + 4*h + s at MFMA step s of k-group g for BOTH
 // operands, so the hardware's (k = lane>>5) pairing is a permutation of the K-slice.
+// Fragments of k-group g+1 are fetched from LDS while the 32 MFMAs of group g execute, and the
+// per-K-step barrier sits in front of the LAST k-group so that it, the LDS store->load turnaround
+// and the next tile's first fragment reads hide behind that group's MFMAs.  Problems with too few
+// 256x256 tiles to fill the chip use the same kernel at 128x128 (4 waves, 2x2 tiles each).
 //
 // The transposed-A form (dW = X^T dZ, K = number of cells) is split over K across
 // gridDim.z; partial slabs are summed by a second deterministic kernel (no float atomics).
 // Block ids are remapped so that consecutive tiles land on the same XCD (private L2) and
 // share their A row panel.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LD_MK = BK + 4;    // 36 floats: 16-B aligned rows, b128 reads conflict-free
-constexpr int LD_KM = BM + 4;    // 132 floats
-constexpr int TILE_MK = BM * LD_MK;  // 4608 floats
-constexpr int TILE_KM = BK * LD_KM;  // 4224 floats
-constexpr int TILE_MAX = TILE_MK > TILE_KM ? TILE_MK : TILE_KM;
+constexpr int BK = 32;
+constexpr int LD_MK = BK + 4;  // K-contiguous image: 36-float rows (16-B aligned, b128 reads conflict-free)
 
-// Global -> registers for one operand tile.  KCONTIG: operand stored [rows][K] (k contiguous);
-// otherwise stored [K][rows].  `rows` is the M (or N) extent, r0 the tile's first row.
-template <bool KCONTIG, bool ALIGNED>
-__device__ __forceinline__ void load_tile(f32x4 (&st)[4], const float* __restrict__ P, int64_t ld,
-                                          int64_t rows, int64_t r0, int64_t k0, int64_t k_end,
-                                          int tid) {
+// Geometry of one kernel configuration: WM x WN wavefronts, each owning TM x TN MFMA tiles of 32x32.
+template <int WM, int WN, int TM_, int TN_>
+struct Cfg {
+  static constexpr int TM = TM_, TN = TN_;
+  static constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64;
+  static constexpr int WAVES_N = WN;
+  static constexpr int NLD_A = BM * BK / 4 / NT, NLD_B = BN * BK / 4 / NT;  // float4 pieces per thread per tile
+  static constexpr int TILE_A = (BM * LD_MK > BK * (BM + 4)) ? BM * LD_MK : BK * (BM + 4);
+  static constexpr int TILE_B = (BN * LD_MK > BK * (BN + 4)) ? BN * LD_MK : BK * (BN + 4);
+  static_assert(NLD_A % 2 == 0 && NLD_B % 2 == 0, "refill is issued in two halves");
+};
+using CfgLarge = Cfg<2, 4, 4, 2>;  // 256 x 256, 512 threads, 1 block / CU
+using CfgSmall = Cfg<2, 2, 2, 2>;  // 128 x 128, 256 threads, 2 blocks / CU (few-tile problems)
+
+// One float4 piece of an operand tile: global -> register.  KCONTIG: operand stored [rows][K]
+// (k contiguous); otherwise stored [K][rows].  ROWS_T = tile extent (BM or BN), NT = block threads.
+template <bool KCONTIG, bool ALIGNED, int ROWS_T, int NT>
+__device__ __forceinline__ f32x4 load_piece(int r, const float* __restrict__ P, int64_t ld, int64_t rows, int64_t r0,
+                                            int64_t k0, int64_t k_end, int tid) {
+  const int idx = tid + NT * r;
+  f32x4 v = f32x4(0.f);
+  if constexpr (KCONTIG) {
+    const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
+    const int64_t gr = min(r0 + row, rows - 1);  // clamped rows are never stored
+    const int64_t gk = k0 + kq;
+    const float* p = P + gr * ld + gk;
+    if constexpr (ALIGNED) {
+      if (gk < k_end) v = *reinterpret_cast<const f32x4*>(p);
+    } else {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int idx = tid + 256 * r;
-    f32x4 v = f32x4(0.f);
-    if constexpr (KCONTIG) {
-      const int row = idx >> 3, kq = (idx & 7) * 4;
-      const int64_t gr = min(r0 + row, rows - 1);  // clamped rows are never stored
-      const int64_t gk = k0 + kq;
-      const float* p = P + gr * ld + gk;
-      if constexpr (ALIGNED) {
-        if (gk < k_end) v = *reinterpret_cast<const f32x4*>(p);
-      } else {
+      for (int i = 0; i < 4; ++i)
+        if (gk + i < k_end) v[i] = p[i];
+    }
+  } else {
+    const int kk = idx / (ROWS_T / 4), mq = (idx % (ROWS_T / 4)) * 4;
+    const int64_t gk = k0 + kk;
+    const int64_t gm = r0 + mq;
+    if (gk < k_end) {
+      const float* p = P + gk * ld + gm;
+      if (ALIGNED && gm + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
+      else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          if (gk + i < k_end) v[i] = p[i];
-      }
-    } else {
-      const int kk = idx >> 5, mq = (idx & 31) * 4;
-      const int64_t gk = k0 + kk;
-      const int64_t gm = r0 + mq;
-      if (gk < k_end) {
-        const float* p = P + gk * ld + gm;
-        if constexpr (ALIGNED) {
-          if (gm + 3 < rows) v = *reinterpret_cast<const f32x4*>(p);
-          else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              if (gm + i < rows) v[i] = p[i];
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (gm + i < rows) v[i] = p[i];
-        }
+          if (gm + i < rows) v[i] = p[i];
       }
     }
-    st[r] = v;
   }
+  return v;
 }
 
-template <bool KCONTIG>
-__device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&st)[4], int tid) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int idx = tid + 256 * r;
-    if constexpr (KCONTIG) {
-      const int row = idx >> 3, kq = (idx & 7) * 4;
-      *reinterpret_cast<f32x4*>(lds + row * LD_MK + kq) = st[r];
-    } else {
-      const int kk = idx >> 5, mq = (idx & 31) * 4;
-      *reinterpret_cast<f32x4*>(lds + kk * LD_KM + mq) = st[r];
-    }
-  }
-}
-
-// Fragment for MFMA steps s = 0..3 of k-group g: element s = operand[row][8g + 4h + s].
-template <bool KCONTIG>
-__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int row, int g, int h) {
+template <bool KCONTIG, int ROWS_T, int NT>
+__device__ __forceinline__ void store_piece(int r, float* __restrict__ lds, f32x4 v, int tid) {
+  const int idx = tid + NT * r;
   if constexpr (KCONTIG) {
-    return *reinterpret_cast<const f32x4*>(lds + row * LD_MK + g * 8 + h * 4);
+    const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
+    *reinterpret_cast<f32x4*>(lds + row * LD_MK + kq) = v;
   } else {
-    f32x4 v;
-    const float* p = lds + (g * 8 + h * 4) * LD_KM + row;
-    v[0] = p[0]; v[1] = p[LD_KM]; v[2] = p[2 * LD_KM]; v[3] = p[3 * LD_KM];
-    return v;
+    const int kk = idx / (ROWS_T / 4), mq = (idx % (ROWS_T / 4)) * 4;
+    *reinterpret_cast<f32x4*>(lds + kk * (ROWS_T + 4) + mq) = v;
   }
 }
+
+// Fragments of one operand side for k-group g: f[x][s] = value of the wave's tile x at MFMA step s.
+// Plain float arrays (not vectors): the KM image delivers the tiles' values transposed, and scalar
+// registers let the compiler feed the ds_read results to the MFMAs in place (no v_mov shuffles).
+template <bool KCONTIG, int T, int ROWS_T>
+__device__ __forceinline__ void read_frags(float (&f)[T][4], const float* __restrict__ lds, int span0, int i32, int g, int h) {
+  if constexpr (KCONTIG) {
+#pragma unroll
+    for (int x = 0; x < T; ++x) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (span0 + x * 32 + i32) * LD_MK + g * 8 + h * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f[x][s] = v[s];
+    }
+  } else {
+    const float* p = lds + (g * 8 + h * 4) * (ROWS_T + 4) + span0 + T * i32;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if constexpr (T == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + s * (ROWS_T + 4));
+#pragma unroll
+        for (int x = 0; x < 4; ++x) f[x][s] = v[x];
+      } else {
+        static_assert(T == 2, "2 or 4 tiles per side");
+        const f32x2 v = *reinterpret_cast<const f32x2*>(p + s * (ROWS_T + 4));
+        f[0][s] = v[0];
+        f[1][s] = v[1];
+      }
+    }
+  }
+}
+
+// Byte offset of piece r of this thread inside an operand tile whose origin is (row r0, k = 0); loop invariant.
+// Rows beyond the matrix are clamped (their results are never stored).
+template <bool KCONTIG, int ROWS_T, int NT>
+__device__ __forceinline__ uint32_t piece_offset(int r, int64_t ld, int64_t rows, int64_t r0, int tid) {
+  const int idx = tid + NT * r;
+  if constexpr (KCONTIG) {
+    const int row = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
+    const int64_t rel = min((int64_t)row, rows - 1 - r0);
+    return (uint32_t)((rel * ld + kq) * 4);
+  } else {
+    const int kk = idx / (ROWS_T / 4), mq = (idx % (ROWS_T / 4)) * 4;
+    return (uint32_t)(((int64_t)kk * ld + mq) * 4);
+  }
+}
+
+// Buffer descriptor over [base, base + 4 GiB) built from a wave-uniform pointer (readfirstlane makes the
+// uniformity provable, so no waterfall loop is generated around the loads).
+// num_records = bytes up to the end of the matrix (capped at 4 GiB): loads past it return 0 instead of faulting.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const char* base, const char* end) {
+  const uint64_t b = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  const int64_t left = end - base;
+  const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(left < 0 ? 0 : (left > 0xffffffffLL ? 0xffffffffLL : left)));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buffer_load_x4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return __builtin_bit_cast(f32x4, v);
+}
+
+// position inside the wave's span of MFMA index i (0..31) of tile x (T tiles on this side)
+template <bool KCONTIG, int T>
+__device__ __forceinline__ int span_pos(int x, int i) { return KCONTIG ? x * 32 + i : T * i + x; }
 
 // TA: A stored [K][M]; TB: B stored [N][K].
-template <bool TA, bool TB, bool ALIGNED>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
+template <typename C_, bool TA, bool TB, bool ALIGNED>
+__global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
     int accumulate, int64_t k_chunk, float* __restrict__ slabs, int tiles_n, int n_tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * TILE_MAX];
-  // buffers: A[0], A[1], B[0], B[1]
+  constexpr int TM = C_::TM, TN = C_::TN, BM = C_::BM, BN = C_::BN, NT = C_::NT;
+  constexpr int NLA = C_::NLD_A, NLB = C_::NLD_B;
+  __shared__ __attribute__((aligned(16))) float lds[2 * C_::TILE_A + 2 * C_::TILE_B];  // A[0], A[1], B[0], B[1]
+  float* const lds_a = lds;
+  float* const lds_b = lds + 2 * C_::TILE_A;
 
   // XCD-aware bijective remap: the dispatcher places block b on XCD b % 8; give every XCD a
   // contiguous run of logical tiles so neighbours (same A row panel) share one L2.
@@ -131,56 +196,122 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / C_::WAVES_N, wn = wave % C_::WAVES_N;
   const int i32 = lane & 31, h = lane >> 5;
+  const int a_span = wm * (TM * 32), b_span = wn * (TN * 32);
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = f32x16(0.f);
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x16(0.f);
 
-  f32x4 sa[4], sb[4];
   const int64_t n_steps = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
+  float fa[2][TM][4], fb[2][TN][4];  // fragments [register set][tile][MFMA step]
   if (n_steps > 0) {
-    load_tile<!TA, ALIGNED>(sa, A, lda, M, m0, k_begin, k_end, tid);
-    load_tile<TB, ALIGNED>(sb, B, ldb, N, n0, k_begin, k_end, tid);
-    store_tile<!TA>(lds, sa, tid);
-    store_tile<TB>(lds + 2 * TILE_MAX, sb, tid);
+#pragma unroll
+    for (int r = 0; r < NLA; ++r)
+      store_piece<!TA, BM, NT>(r, lds_a, load_piece<!TA, ALIGNED, BM, NT>(r, A, lda, M, m0, k_begin, k_end, tid), tid);
+#pragma unroll
+    for (int r = 0; r < NLB; ++r)
+      store_piece<TB, BN, NT>(r, lds_b, load_piece<TB, ALIGNED, BN, NT>(r, B, ldb, N, n0, k_begin, k_end, tid), tid);
   }
   __syncthreads();
+  if (n_steps > 0) {
+    read_frags<!TA, TM, BM>(fa[0], lds_a, a_span, i32, 0, h);
+    read_frags<TB, TN, BN>(fb[0], lds_b, b_span, i32, 0, h);
+  }
 
-  for (int64_t t = 0; t < n_steps; ++t) {
+  // Fast refill path: when the whole next tile lies inside the matrix (always, except the K tail and the
+  // last row/column of tiles) a piece is ONE unguarded 16-byte buffer load: scalar descriptor (tile origin
+  // advanced along K with scalar adds) + a loop-invariant 32-bit lane offset.  Every non-MFMA instruction
+  // in this loop displaces matrix-pipe time (measured: the guarded, 64-bit-addressed refill cost 17 % of the
+  // kernel), so the main loop contains only the fast path and the guarded path runs in a separate tail loop.
+  uint32_t offa[NLA], offb[NLB];
+#pragma unroll
+  for (int r = 0; r < NLA; ++r) offa[r] = piece_offset<!TA, BM, NT>(r, lda, M, m0, tid);
+#pragma unroll
+  for (int r = 0; r < NLB; ++r) offb[r] = piece_offset<TB, BN, NT>(r, ldb, N, n0, tid);
+  // Edge tiles take the fast path too: K-contiguous operands clamp their rows; M/N-contiguous operands read up
+  // to 3 floats past column M (N) of a row, i.e. into the next row or (last row) past the matrix end, where the
+  // buffer descriptor returns 0 — such columns only feed C rows/columns >= M (N), which are never stored.
+  const bool tile_inside = ALIGNED;
+  const char* const a_end = reinterpret_cast<const char*>(A + (TA ? (K - 1) * lda + M : (M - 1) * lda + K));
+  const char* const b_end = reinterpret_cast<const char*>(B + (TB ? (N - 1) * ldb + K : (K - 1) * ldb + N));
+  const char* const a_origin = reinterpret_cast<const char*>(A + (TA ? m0 : m0 * lda));
+  const char* const b_origin = reinterpret_cast<const char*>(B + (TB ? n0 * ldb : n0));
+  const int64_t a_kstride = (TA ? lda : 1) * 4, b_kstride = (TB ? 1 : ldb) * 4;  // bytes per unit of k
+  // steps t whose NEXT tile (t+1) is completely inside K: (t + 2) * BK <= k_len
+  const int64_t n_fast = tile_inside ? max((int64_t)0, min(n_steps - 1, (k_end - k_begin) / BK - 1)) : 0;
+
+  // Software pipeline of one K-step (4 k-groups of TM*TN*4 MFMAs each):
+  //   g = 0: issue the first half of tile t+1's refill loads            | prefetch frags g=1
+  //   g = 1: retire that half into the idle LDS buffer, issue the rest   | prefetch frags g=2
+  //   g = 2: retire the second half                                      | prefetch frags g=3
+  //   g = 3: BARRIER, then prefetch frags g=0 of tile t+1 from the freshly filled buffer
+  // so the barrier, the store->load turnaround and the first fragment reads of the next tile are all
+  // covered by the last group's MFMAs instead of draining the matrix pipe once per K-step.
+  auto k_step = [&](int64_t t, auto fast_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(fast_tag)::value;
     const int cur = t & 1;
-    if (t + 1 < n_steps) {
-      const int64_t k0 = k_begin + (t + 1) * BK;
-      load_tile<!TA, ALIGNED>(sa, A, lda, M, m0, k0, k_end, tid);
-      load_tile<TB, ALIGNED>(sb, B, ldb, N, n0, k0, k_end, tid);
+    const bool more = FAST || (t + 1 < n_steps);
+    const int64_t k_next = k_begin + (t + 1) * BK;
+    const float* a_lds = lds_a + cur * C_::TILE_A;
+    const float* b_lds = lds_b + cur * C_::TILE_B;
+    float* a_nxt = lds_a + (cur ^ 1) * C_::TILE_A;  // not read by anyone during groups 0..2
+    float* b_nxt = lds_b + (cur ^ 1) * C_::TILE_B;
+    __amdgpu_buffer_rsrc_t ra, rb;
+    if constexpr (FAST) {
+      ra = make_rsrc(a_origin + k_next * a_kstride, a_end);
+      rb = make_rsrc(b_origin + k_next * b_kstride, b_end);
     }
-    const float* a_lds = lds + cur * TILE_MAX;
-    const float* b_lds = lds + (2 + cur) * TILE_MAX;
+    f32x4 pa[NLA / 2], pb[NLB / 2];  // refill pieces in flight
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      f32x4 fa[2], fb[2];
+      if (more && g >= 1 && g <= 2) {  // retire the half issued one group earlier
 #pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        fa[x] = read_frag<!TA>(a_lds, wm * 64 + x * 32 + i32, g, h);
-        fb[x] = read_frag<TB>(b_lds, wn * 64 + x * 32 + i32, g, h);
+        for (int r = 0; r < NLA / 2; ++r) store_piece<!TA, BM, NT>((g - 1) * (NLA / 2) + r, a_nxt, pa[r], tid);
+#pragma unroll
+        for (int r = 0; r < NLB / 2; ++r) store_piece<TB, BN, NT>((g - 1) * (NLB / 2) + r, b_nxt, pb[r], tid);
       }
+      if (more && g < 2) {
+        if constexpr (FAST) {
+#pragma unroll
+          for (int r = 0; r < NLA / 2; ++r) pa[r] = buffer_load_x4(ra, offa[g * (NLA / 2) + r]);
+#pragma unroll
+          for (int r = 0; r < NLB / 2; ++r) pb[r] = buffer_load_x4(rb, offb[g * (NLB / 2) + r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < NLA / 2; ++r)
+            pa[r] = load_piece<!TA, ALIGNED, BM, NT>(g * (NLA / 2) + r, A, lda, M, m0, k_next, k_end, tid);
+#pragma unroll
+          for (int r = 0; r < NLB / 2; ++r)
+            pb[r] = load_piece<TB, ALIGNED, BN, NT>(g * (NLB / 2) + r, B, ldb, N, n0, k_next, k_end, tid);
+        }
+      }
+      if (g + 1 < BK / 8) {
+        read_frags<!TA, TM, BM>(fa[(g + 1) & 1], a_lds, a_span, i32, g + 1, h);
+        read_frags<TB, TN, BN>(fb[(g + 1) & 1], b_lds, b_span, i32, g + 1, h);
+      } else if (more) {
+        __syncthreads();  // tile t+1 is complete in LDS; nobody reads tile t's buffer any more (g=3 frags are in registers)
+        read_frags<!TA, TM, BM>(fa[0], a_nxt, a_span, i32, 0, h);
+        read_frags<TB, TN, BN>(fb[0], b_nxt, b_span, i32, 0, h);
+      }
+      // keep loads / prefetches ABOVE this group's MFMAs (the scheduler otherwise sinks the reads to their
+      // first use to save registers and re-exposes the latency)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+        for (int x = 0; x < TM; ++x)
 #pragma unroll
-          for (int y = 0; y < 2; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][s], fb[y][s], acc[x][y], 0, 0, 0);
+          for (int y = 0; y < TN; ++y)
+            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][x][s], fb[g & 1][y][s], acc[x][y], 0, 0, 0);
     }
-    if (t + 1 < n_steps) {
-      store_tile<!TA>(lds + (cur ^ 1) * TILE_MAX, sa, tid);
-      store_tile<TB>(lds + (2 + (cur ^ 1)) * TILE_MAX, sb, tid);
-    }
-    __syncthreads();
-  }
+  };
+  int64_t t = 0;
+  for (; t < n_fast; ++t) k_step(t, std::true_type{});
+  for (; t < n_steps; ++t) k_step(t, std::false_type{});
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
   float* out = C;
@@ -192,17 +323,32 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
     add = false;
   }
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < TM; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      const int64_t col = n0 + wn * 64 + y * 32 + i32;
-      if (col >= N) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wm * 64 + x * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= M) continue;
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = m0 + a_span + span_pos<!TA, TM>(x, (r & 3) + 8 * (r >> 2) + 4 * h);
+      if (row >= M) continue;
+      if constexpr (!TB) {
+        // B image is N-contiguous: the wave's two column tiles interleave, lane j owns columns 2j, 2j+1
+        static_assert(TN == 2, "float2 epilogue assumes two column tiles");
+        const int64_t col = n0 + b_span + 2 * i32;
         float* p = out + row * ldo + col;
-        *p = add ? (*p + acc[x][y][r]) : acc[x][y][r];
+        if (col + 1 < N && (ldo % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0)) {
+          f32x2 v = {acc[x][0][r], acc[x][1][r]};
+          if (add) { const f32x2 o = *reinterpret_cast<const f32x2*>(p); v[0] += o[0]; v[1] += o[1]; }
+          *reinterpret_cast<f32x2*>(p) = v;
+        } else {
+          if (col < N) p[0] = add ? p[0] + acc[x][0][r] : acc[x][0][r];
+          if (col + 1 < N) p[1] = add ? p[1] + acc[x][1][r] : acc[x][1][r];
+        }
+      } else {
+#pragma unroll
+        for (int y = 0; y < TN; ++y) {
+          const int64_t col = n0 + b_span + y * 32 + i32;
+          if (col >= N) continue;
+          float* p = out + row * ldo + col;
+          *p = add ? (*p + acc[x][y][r]) : acc[x][y][r];
+        }
       }
     }
 }
@@ -223,21 +369,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N
 }
 
 struct Plan {
+  bool large;
   int tiles_m, tiles_n, n_tiles, S;
   int64_t k_chunk;
 };
 
-Plan make_plan(int64_t M, int64_t N, int64_t K) {
+Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
   Plan p;
-  p.tiles_m = (int)dh::ceil_div(M, BM);
-  p.tiles_n = (int)dh::ceil_div(N, BN);
+  p.large = bm == CfgLarge::BM;
+  p.tiles_m = (int)dh::ceil_div(M, bm);
+  p.tiles_n = (int)dh::ceil_div(N, bn);
   p.n_tiles = p.tiles_m * p.tiles_n;
   p.S = 1;
   p.k_chunk = dh::ceil_div(K > 0 ? K : 1, BK) * BK;
-  // Few output tiles and a long K (dW = X^T dZ): split K until ~4 blocks per CU are in flight,
-  // keeping at least 64 K-steps per block.
+  // Few output tiles and a long K (dW = X^T dZ): split K until ~16 blocks per CU are queued (many short rounds:
+  // the last, partially filled round then costs <= 1/16), keeping at least 64 K-steps per block.
   if (p.n_tiles < 512 && K >= 4096) {
-    int64_t want = dh::ceil_div(1024, p.n_tiles);
+    int64_t want = dh::ceil_div(4096, p.n_tiles);
     int64_t max_s = K / (64 * BK);
     if (max_s < 1) max_s = 1;
     int64_t S = want < max_s ? want : max_s;
@@ -247,6 +395,16 @@ Plan make_plan(int64_t M, int64_t N, int64_t K) {
     }
   }
   return p;
+}
+
+// The 256x256 configuration halves refill traffic per flop but needs >= 2 blocks per CU's worth of work to
+// fill the chip; smaller problems use 128x128 tiles.
+Plan make_plan(int64_t M, int64_t N, int64_t K) {
+  Plan big = plan_for(M, N, K, CfgLarge::BM, CfgLarge::BN);
+#ifndef DH_GEMM_FORCE_SMALL  // (A/B experiment builds only)
+  if ((int64_t)big.n_tiles * big.S >= 512) return big;
+#endif
+  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
 }
 
 }  // namespace
@@ -280,10 +438,16 @@ extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int tra
                        // K-contiguous operands are read 4 k at a time, M/N-contiguous ones are
                        // guarded per element at the edge, so only K % 4 matters for the former
                        ((trans_a != 0 && trans_b == 0) || K % 4 == 0);
-  dim3 grid((unsigned)p.n_tiles, 1, (unsigned)p.S), block(256);
-#define DH_GEMM_LAUNCH(TA, TB, AL)                                                              \
-  hipLaunchKernelGGL((gemm_f32_kernel<TA, TB, AL>), grid, block, 0, st, M, N, K, A, lda, B, ldb, \
-                     C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles)
+  dim3 grid((unsigned)p.n_tiles, 1, (unsigned)p.S);
+#define DH_GEMM_LAUNCH(TA, TB, AL)                                                                           \
+  do {                                                                                                       \
+    if (p.large)                                                                                             \
+      hipLaunchKernelGGL((gemm_f32_kernel<CfgLarge, TA, TB, AL>), grid, dim3(CfgLarge::NT), 0, st, M, N, K, A, \
+                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles);            \
+    else                                                                                                     \
+      hipLaunchKernelGGL((gemm_f32_kernel<CfgSmall, TA, TB, AL>), grid, dim3(CfgSmall::NT), 0, st, M, N, K, A, \
+                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles);            \
+  } while (0)
   const int key = (trans_a ? 4 : 0) | (trans_b ? 2 : 0) | (aligned ? 1 : 0);
   switch (key) {
     case 0: DH_GEMM_LAUNCH(false, false, false); break;

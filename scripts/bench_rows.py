@@ -1,0 +1,157 @@
+"""Per-row measurement of the SURVEY.md §8 kernels at BASELINE-config sizes: GPU time (HIP events), algorithmic
+bytes / ops, roofline fraction, and the CPU oracle (or the library the reference calls) timed on a bounded sample.
+
+    python scripts/bench_rows.py [--quick] > profiles/rNN_rows.json
+
+Not the headline bench (that is bench.py); this feeds the kernel table of DESIGN.md.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dance_amd import kernels  # noqa: E402
+
+HBM, VALU_OPS = 8000.0, 78.65  # GB/s peak; T non-fused f32 ops/s (157.3 TFLOP/s counts an FMA as 2)
+dev = torch.device("cuda:0")
+
+
+def gpu_ms(fn, iters=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def cpu_s(fn, iters=1):
+    t = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    return (time.perf_counter() - t) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    q = args.quick
+    from oracle import graphs as og
+    from oracle import matrix as om
+    from oracle import sage as osg
+    rows = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+
+    # ---- K8 exact kNN (A11/A12/A13) ------------------------------------------------------------------------
+    for n, d, k in ([(20_000, 50, 15)] if q else [(100_000, 50, 15), (1_000_000, 50, 15), (100_000, 2000, 15)]):
+        x = torch.randn(n, d, device=dev, generator=g)
+        ms = gpu_ms(lambda: kernels.knn(x, k), iters=1, warm=1 if n <= 100_000 else 0)
+        ops = 3.0 * n * n * d
+        ns = 4000
+        xs = x[:ns].cpu().numpy()
+        t_or = cpu_s(lambda: og.knn_exact(xs, k))
+        from sklearn.neighbors import NearestNeighbors
+        t_sk = cpu_s(lambda: NearestNeighbors(n_neighbors=k, algorithm="brute").fit(xs).kneighbors(xs))
+        rows[f"knn_bruteforce_f32 n={n} d={d} k={k}"] = dict(
+            ms=ms, bound="valu", achieved=ops / ms / 1e9, peak=VALU_OPS, unit="Tops/s (sub,mul,add)", frac=ops / ms / 1e9 / VALU_OPS,
+            cells_per_s=n / ms * 1e3,
+            cpu_baseline=dict(sample=f"{ns} points (pairs scale n^2)", oracle_numpy_pairs_per_s=ns * ns / t_or,
+                              sklearn_brute_pairs_per_s=ns * ns / t_sk, gpu_pairs_per_s=n * n / ms * 1e3, cores=os.cpu_count()))
+        if n == 1_000_000 or q:
+            idx, dist = kernels.knn(x, k)
+            ms_u = gpu_ms(lambda: kernels.umap_connectivities(idx, dist), iters=2)
+            t_u = cpu_s(lambda: og.fuzzy_simplicial_set(*og.knn_exact(xs, k), k))
+            rows[f"umap_connectivities n={n} k={k}"] = dict(ms=ms_u, cells_per_s=n / ms_u * 1e3,
+                                                            cpu_baseline=dict(sample=f"{ns} cells incl. kNN", cells_per_s=ns / t_u))
+        del x
+
+    # ---- A14 pairwise distance (SpaGCNGraph) ---------------------------------------------------------------
+    n = 4096 if q else 16384
+    xyz = torch.rand(n, 3, device=dev, generator=g) * 100
+    ms = gpu_ms(lambda: kernels.pairwise_distance(xyz, 0))
+    byt = n * n * 4.0
+    ns = 1500
+    t_or = cpu_s(lambda: om.pairwise_distance(xyz[:ns].cpu().numpy(), 0))
+    rows[f"pairwise_distance_f32 n={n} d=3"] = dict(ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s", frac=byt / ms / 1e6 / HBM,
+                                                    cpu_baseline=dict(sample=f"{ns} spots", pairs_per_s=ns * ns / t_or, gpu_pairs_per_s=n * n / ms * 1e3))
+    dmat = kernels.pairwise_distance(xyz, 0)
+    ms = gpu_ms(lambda: kernels.gaussian_kernel(dmat, 1.5, want_out=False, want_rowsum=True))
+    rows[f"gaussian_kernel_f32 rowsums (calculate_p) n={n}"] = dict(ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s", frac=byt / ms / 1e6 / HBM)
+    del dmat
+
+    # ---- A1 CellFeatureGraph build + A3 AdaptiveSAGE aggregation (full graph) ------------------------------
+    n_cells, n_genes, dfeat = (100_000 if q else 1_000_000), 2000, 400
+    per = 200  # 10 % density: 200 expressed genes per cell
+    col = torch.rand(n_cells, n_genes, device=dev, generator=g).topk(per, dim=1).indices.sort(dim=1).values.to(torch.int32).reshape(-1)
+    rp_x = torch.arange(0, n_cells * per + 1, per, dtype=torch.int32, device=dev)
+    val_x = torch.rand(n_cells * per, device=dev, generator=g) + 0.5
+    nnz = n_cells * per
+
+    def build():
+        rp_t, col_t, val_t, perm_t = kernels.csr_transpose(rp_x, col, val_x, n_cells, n_genes)
+        vx, vt = kernels.csr_row_normalize(rp_x, val_x), kernels.csr_row_normalize(rp_t, val_t)
+        return kernels.cellgene_graph_assemble(rp_x, col, vx, rp_t, col_t, vt, perm_t, n_cells, n_genes)
+
+    ms = gpu_ms(build, iters=2)
+    ns = 2000
+    xs = np.zeros((ns, n_genes), np.float32)
+    cc = col[:ns * per].cpu().numpy().reshape(ns, per)
+    xs[np.arange(ns)[:, None], cc] = val_x[:ns * per].cpu().numpy().reshape(ns, per)
+    t_or = cpu_s(lambda: og.cell_feature_graph(xs))
+    rows[f"cellgene graph build (transpose+normalize+assemble) cells={n_cells} nnz={nnz}"] = dict(
+        ms=ms, edges_per_s=(2 * nnz + n_cells + n_genes) / ms * 1e3, cells_per_s=n_cells / ms * 1e3,
+        cpu_baseline=dict(sample=f"{ns} cells (vectorised numpy oracle; the reference loops over nodes in Python)", cells_per_s=ns / t_or))
+    rowptr, gcol, gval, eid = build()
+    n_nodes = n_cells + n_genes
+    feats = torch.randn(n_nodes, dfeat, device=dev, generator=g)
+    cid = torch.cat((torch.arange(n_genes, dtype=torch.int32), -torch.ones(n_cells, dtype=torch.int32))).to(dev)
+    alpha = torch.rand(n_genes + 2, device=dev, generator=g) + 0.5
+    # cell <- gene aggregation (what scDeepSort's cell batches need): rows [G, G+N) of the CSR, gathered operand =
+    # the 3.2 MB gene-feature table (cache resident), SURVEY.md §8d: B = nnz (4+4) + 4 (N+1) + G D 4 + N D 4
+    rp_cells, cid_cells = rowptr[n_genes:], cid[n_genes:]
+    ms = gpu_ms(lambda: kernels.sage_aggregate(rp_cells, gcol, gval, cid, cid_cells, alpha, feats), iters=3)
+    e = nnz + n_cells
+    byt = e * 8.0 + 4.0 * (n_cells + 1) + n_genes * dfeat * 4.0 + n_cells * dfeat * 4.0
+    rows[f"sage_aggregate_f32 cell<-gene full graph cells={n_cells} D={dfeat} edges={e}"] = dict(
+        ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s", frac=byt / ms / 1e6 / HBM, cells_per_s=n_cells / ms * 1e3,
+        l2_gather_GBs=e * dfeat * 4.0 / ms / 1e6)
+    ms_all = gpu_ms(lambda: kernels.sage_aggregate(rowptr, gcol, gval, cid, cid, alpha, feats), iters=1)
+    rows[f"sage_aggregate_f32 all nodes (gene rows gather {nnz} cell rows) cells={n_cells}"] = dict(
+        ms=ms_all, note="dominated by the 2000 gene rows of ~1e5 in-edges each handled by one wavefront per row")
+    del feats, rowptr, gcol, gval, eid
+
+    # ---- SpaGCN-shape layer 50 -> 50 with bias, k = 15 -----------------------------------------------------
+    from dance_amd.autograd import gcn_layer
+    from dance_amd.graph import CSRGraph
+    n = 100_000 if q else 1_000_000
+    colk = torch.randint(0, n, (n, 15), device=dev, generator=g).sort(dim=1).values.to(torch.int32).reshape(-1)
+    graph = CSRGraph(torch.arange(0, n * 15 + 1, 15, dtype=torch.int32, device=dev), colk, torch.full((n * 15, ), 1 / 15., device=dev), n, n)
+    graph.transpose()
+    x50 = torch.randn(n, 50, device=dev, generator=g)
+    w50 = (torch.randn(50, 50, device=dev, generator=g) / 7).requires_grad_(True)
+    b50 = torch.zeros(50, device=dev, requires_grad=True)
+    dy = torch.randn(n, 50, device=dev, generator=g)
+
+    def step():
+        w50.grad = b50.grad = None
+        gcn_layer(x50, w50, graph, b50, False).backward(dy)
+
+    ms = gpu_ms(step, iters=5, warm=2)
+    byt = 1.85e3 * n
+    rows[f"GraphConvolution 50->50 fwd+bwd n={n} k=15"] = dict(ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s",
+                                                              frac=byt / ms / 1e6 / HBM, cells_per_s=n / ms * 1e3)
+    print(json.dumps(rows, indent=1))
+
+
+if __name__ == "__main__":
+    main()
