@@ -1,0 +1,152 @@
+"""GPU: BASELINE.json configurations at their FULL sizes, checked through size-independent properties and through
+exact parity on sampled rows (a row of a GCN output / kNN list / aggregation depends only on that row's neighbours,
+so the CPU oracle can evaluate sampled rows of a 1M-cell problem in float64 in milliseconds).
+
+config 2: GCN 100k x 2k, k=15           headline: GCN 1M x 2k, k=15
+config 3: scDeepSort cell-gene graph 1M x 2k (graph build + cell<-gene aggregation)
+config 5: SpaGCN 500k spots, spatial kNN k=15, 50 -> 50 GraphConvolution
+(config 4, graph-sc on 8 GPUs, shares the config-3 graph and the WeightedGraphConv kernels tested elsewhere.)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import graphs as og
+from oracle import sage as osg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand_graph(n, k, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    col = torch.randint(0, n, (n, k), device=DEV, generator=g).sort(dim=1).values.to(torch.int32).reshape(-1)
+    rowptr = torch.arange(0, n * k + 1, k, dtype=torch.int32, device=DEV)
+    val = torch.rand(n * k, device=DEV, generator=g) / k
+    return rowptr, col, val
+
+
+@pytest.mark.parametrize("n", [100_000, 1_000_000])
+def test_gcn_layer_full_size(cuda_device, n):
+    from dance_amd import kernels
+    from dance_amd.graph import CSRGraph
+    from dance_amd.modules.single_modality.clustering.scdsc import GNNLayer
+    fin, fout, k = 2000, 512, 15
+    gen = torch.Generator(device=DEV).manual_seed(n)
+    x = torch.randn(n, fin, device=DEV, generator=gen)
+    rowptr, col, val = _rand_graph(n, k, 1)
+    graph = CSRGraph(rowptr, col, val, n, n)
+    layer = GNNLayer(fin, fout).to(DEV)
+    dy = torch.randn(n, fout, device=DEV, generator=gen)
+    y = layer(x, graph)
+    y.backward(dy)
+    # (1) exact parity on sampled rows, float64 oracle arithmetic: y_i = relu(sum_e a_e (x_src W))
+    rows = np.random.default_rng(0).choice(n, 64, replace=False)
+    w64 = layer.weight.detach().double().cpu().numpy()
+    rp, c, v = rowptr.cpu().numpy(), col.cpu().numpy(), val.cpu().numpy()
+    ref = np.stack([np.maximum(sum(float(v[e]) * (x[int(c[e])].double().cpu().numpy() @ w64) for e in range(rp[i], rp[i + 1])), 0)
+                    for i in rows])
+    assert rel_err(y[torch.from_numpy(rows).to(DEV)].detach().cpu().numpy(), ref) < 1e-4
+    # (2) transpose round trip is the identity, bit for bit; A^T has the same nnz and column sums become row counts
+    gt = graph.transpose()
+    rp2, c2, v2, _ = kernels.csr_transpose(gt.rowptr, gt.col, gt.val, n, n)
+    assert torch.equal(rp2, rowptr) and torch.equal(c2, col) and torch.equal(v2, val)
+    # (3) checksum of checksums for dW = X^T dS with dS = A^T (dy * [y > 0]):  1^T dW 1 = (X 1)^T (dS 1)
+    g = torch.where(y.detach() > 0, dy, torch.zeros_like(dy))
+    ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g)
+    lhs = float(layer.weight.grad.double().sum())
+    rhs = float((x.double().sum(1) * ds.double().sum(1)).sum())
+    assert abs(lhs - rhs) < 1e-6 * float((x.double().abs().sum(1) * ds.double().abs().sum(1)).sum())
+    # (4) dS itself: sampled rows of A^T g against the explicit edge list
+    tr, tc, tv = gt.rowptr.cpu().numpy(), gt.col.cpu().numpy(), gt.val.cpu().numpy()
+    ref_ds = np.stack([sum((float(tv[e]) * g[int(tc[e])].double().cpu().numpy() for e in range(tr[i], tr[i + 1])), np.zeros(fout)) for i in rows])
+    assert rel_err(ds[torch.from_numpy(rows).to(DEV)].cpu().numpy(), ref_ds) < 1e-4
+    # (5) linearity of the un-activated layer: f(2x) = 2 f(x) exactly in fp32 (power-of-two scaling)
+    with torch.no_grad():
+        a = layer(x[:50_000].contiguous(), CSRGraph(*_rand_graph(50_000, k, 2), 50_000, 50_000), active=False)
+        b = layer((2 * x[:50_000]).contiguous(), CSRGraph(*_rand_graph(50_000, k, 2), 50_000, 50_000), active=False)
+    assert torch.equal(b, 2 * a)
+
+
+def test_scdeepsort_graph_full_size(cuda_device):
+    """config 3: 1M cells x 2k genes at 10 % density (nnz = 2e8): graph build + cell<-gene aggregation."""
+    from dance_amd import kernels
+    n_cells, n_genes, per, d = 1_000_000, 2000, 200, 400
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    col = torch.rand(n_cells, n_genes, device=DEV, generator=gen).topk(per, dim=1).indices.sort(dim=1).values.to(torch.int32).reshape(-1)
+    rp_x = torch.arange(0, n_cells * per + 1, per, dtype=torch.int32, device=DEV)
+    val_x = torch.rand(n_cells * per, device=DEV, generator=gen) + 0.5
+    nnz = n_cells * per
+    rp_t, col_t, val_t, perm_t = kernels.csr_transpose(rp_x, col, val_x, n_cells, n_genes)
+    vx, vt = kernels.csr_row_normalize(rp_x, val_x), kernels.csr_row_normalize(rp_t, val_t)
+    rowptr, gcol, gval, eid = kernels.cellgene_graph_assemble(rp_x, col, vx, rp_t, col_t, vt, perm_t, n_cells, n_genes)
+    n_nodes, n_edges = n_cells + n_genes, 2 * nnz + n_cells + n_genes
+    assert int(rowptr[-1]) == n_edges == gcol.numel()
+    # eid is a permutation of the reference edge ids
+    assert torch.equal(torch.sort(eid.to(torch.int64)).values, torch.arange(n_edges, device=DEV))
+    # normalisation property (cell_feature_graph.py:62-68): in-edge weights of a node sum to its in-degree; + 1 self loop
+    deg = (rowptr[1:] - rowptr[:-1]).double()
+    sums = torch.zeros(n_nodes, dtype=torch.float64, device=DEV).index_add_(
+        0, torch.repeat_interleave(torch.arange(n_nodes, device=DEV), (rowptr[1:] - rowptr[:-1]).long()), gval.double())
+    assert float((sums - deg).abs().max() / deg.max()) < 1e-5
+    # every cell row: its genes (ascending) then itself
+    r = 123_456
+    s, t = int(rowptr[n_genes + r]), int(rowptr[n_genes + r + 1])
+    assert torch.equal(gcol[s:t - 1], col[r * per:(r + 1) * per]) and int(gcol[t - 1]) == n_genes + r
+    # cell<-gene aggregation on all 1M cell rows; sampled rows vs the oracle restatement of gnn.py:62-82,90
+    feats = torch.randn(n_nodes, d, device=DEV, generator=gen)
+    cid = torch.cat((torch.arange(n_genes, dtype=torch.int32), -torch.ones(n_cells, dtype=torch.int32))).to(DEV)
+    alpha = torch.rand(n_genes + 2, device=DEV, generator=gen) + 0.5
+    neigh = kernels.sage_aggregate(rowptr[n_genes:], gcol, gval, cid, cid[n_genes:], alpha, feats)
+    rows = np.random.default_rng(1).choice(n_cells, 32, replace=False)
+    a_np, cid_np = alpha.cpu().numpy(), cid.cpu().numpy()
+    for i in rows:
+        s, t = int(rowptr[n_genes + i]), int(rowptr[n_genes + i + 1])
+        src = gcol[s:t].cpu().numpy().astype(np.int64)
+        ref = osg.sage_neigh(np.arange(t - s), np.zeros(t - s, dtype=np.int64), gval[s:t].cpu().numpy(), cid_np[src], cid_np[[n_genes + i]],
+                             a_np, feats[torch.from_numpy(src).to(DEV)].cpu().numpy(), 1)
+        assert rel_err(neigh[i].cpu().numpy(), ref[0]) < 1e-5
+
+
+def test_spagcn_full_size(cuda_device):
+    """config 5: 500k spots on a jittered hex grid, spatial kNN (k=15) truncated Gaussian adjacency, 50 -> 50 layer."""
+    from dance_amd import kernels
+    from dance_amd.graph import CSRGraph
+    from dance_amd.modules.spatial.spatial_domain.spagcn import GraphConvolution, SpaGCN
+    n, k = 500_000, 15
+    rng = np.random.default_rng(5)
+    side = int(np.ceil(np.sqrt(n)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    xy = np.stack([gx.ravel() + 0.5 * (gy.ravel() % 2), gy.ravel() * 0.866], 1)[:n] + rng.normal(0, 0.05, (n, 2))
+    xyz = np.hstack([xy, rng.normal(0, 0.3, (n, 1))]).astype(np.float32)
+    x_dev = torch.from_numpy(xyz).to(DEV)
+    idx, dist = kernels.knn(x_dev, k)
+    # exact parity of sampled queries against brute force over all 500k points (bit-defined distance, ties -> lower index)
+    q = rng.choice(n, 48, replace=False)
+    acc = np.zeros((q.size, n), dtype=np.float32)
+    for t in range(3):
+        diff = xyz[q, t, None] - xyz[None, :, t]
+        acc = acc + diff * diff
+    order = np.argsort(acc, axis=1, kind="stable")[:, :k]
+    assert np.array_equal(idx[torch.from_numpy(q).to(DEV)].cpu().numpy(), order)
+    assert np.array_equal(dist[torch.from_numpy(q).to(DEV)].cpu().numpy(), np.sqrt(np.take_along_axis(acc, order, 1)))
+    # sortedness / self-first properties on every row
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all()) and torch.equal(idx[:, 0], torch.arange(n, dtype=torch.int32, device=DEV))
+    order_t = torch.argsort(idx, dim=1)
+    g = CSRGraph(torch.arange(0, n * k + 1, k, dtype=torch.int32, device=DEV), torch.gather(idx, 1, order_t).reshape(-1).contiguous(),
+                 torch.gather(dist, 1, order_t).reshape(-1).contiguous(), n, n)
+    model = SpaGCN(l=1.2, device=DEV)
+    adj_exp = model.calc_adj_exp(g)
+    assert rel_err(adj_exp.val[:1000].cpu().numpy(), np.exp(-(g.val[:1000].cpu().numpy().astype(np.float64)**2) / (2 * 1.2**2))) < 1e-5
+    layer = GraphConvolution(50, 50).to(DEV)
+    emb = torch.randn(n, 50, device=DEV)
+    out = layer(emb, adj_exp)
+    out.sum().backward()
+    rows = rng.choice(n, 64, replace=False)
+    w64, b64 = layer.weight.detach().double().cpu().numpy(), layer.bias.detach().double().cpu().numpy()
+    rp, c, v = adj_exp.rowptr.cpu().numpy(), adj_exp.col.cpu().numpy(), adj_exp.val.cpu().numpy()
+    ref = np.stack([sum(float(v[e]) * (emb[int(c[e])].double().cpu().numpy() @ w64) for e in range(rp[i], rp[i + 1])) + b64 for i in rows])
+    assert rel_err(out[torch.from_numpy(rows).to(DEV)].detach().cpu().numpy(), ref) < 1e-4
+    # bias gradient of sum(out) is exactly the number of spots
+    assert rel_err(layer.bias.grad.cpu().numpy(), np.full(50, float(n))) < 1e-6
