@@ -31,17 +31,38 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(int64_t n_rows, int6
   }
 }
 
-// Column sums, pass 1: block b sums rows [b*rows_per_block, ...) for all columns -> partial[b][width]
+// Column sums, pass 1: block b sums rows [b*rows_per_block, ...) -> partial[b][width].  A group of G lanes (G = 64
+// for wide matrices, 64 / 32 / 16 for narrow ones so that a wavefront covers several rows) walks the columns of a
+// row with coalesced loads; the block's row groups run in parallel and are combined through LDS in a fixed order.
+template <int G>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(int64_t n_rows, int64_t width,
                                                              const float* __restrict__ X, int64_t ldx,
                                                              int64_t rows_per_block,
                                                              float* __restrict__ partial) {
+  constexpr int NG = 256 / G;  // row groups per block
+  __shared__ float red[256];
+  const int g = threadIdx.x % G, rg = threadIdx.x / G;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = min(n_rows, r0 + rows_per_block);
-  for (int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x; c < width; c += (int64_t)gridDim.y * 256) {
+  for (int64_t c = (int64_t)blockIdx.y * G + g; c < (int64_t)(blockIdx.y + 1) * G; c += G) {
     float s = 0.f;
-    for (int64_t r = r0; r < r1; ++r) s += X[r * ldx + c];
-    partial[(int64_t)blockIdx.x * width + c] = s;
+    if (c < width) {
+      int64_t r = r0 + rg;
+      for (; r + 3 * NG < r1; r += 4 * NG) {  // 4 independent loads in flight
+        const float a = X[r * ldx + c], b = X[(r + NG) * ldx + c], d = X[(r + 2 * NG) * ldx + c], e = X[(r + 3 * NG) * ldx + c];
+        s += a; s += b; s += d; s += e;
+      }
+      for (; r < r1; r += NG) s += X[r * ldx + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rg == 0 && c < width) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < NG; ++k) t += red[k * G + g];
+      partial[(int64_t)blockIdx.x * width + c] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -55,7 +76,7 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int64_t n_blocks, int
   out[c] = s;
 }
 
-constexpr int64_t kColsumRows = 512;
+constexpr int64_t kColsumRows = 2048;
 
 }  // namespace
 
@@ -101,8 +122,16 @@ extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int6
     return dh::fail(DH_ERR_WORKSPACE, "dh_colsum_f32: workspace %zu < %zu bytes", workspace_bytes, need);
   const int64_t nb = dh::ceil_div(n_rows, kColsumRows);
   float* partial = static_cast<float*>(workspace);
-  dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 256));
-  hipLaunchKernelGGL(colsum_partial_kernel, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+  if (width > 32) {
+    dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 64));
+    hipLaunchKernelGGL(colsum_partial_kernel<64>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+  } else if (width > 16) {
+    dim3 grid((unsigned)nb, 1);
+    hipLaunchKernelGGL(colsum_partial_kernel<32>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+  } else {
+    dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 16));
+    hipLaunchKernelGGL(colsum_partial_kernel<16>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+  }
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
   return dh::check_launch("dh_colsum_f32");
 }

@@ -412,6 +412,7 @@ Plan make_plan(int64_t M, int64_t N, int64_t K) {
 extern "C" size_t dh_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b) {
   (void)trans_a; (void)trans_b;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
+  if (dh::skinny_applies(M, N, K, trans_a)) return dh::skinny_workspace_bytes(M, N, K, trans_a);
   Plan p = make_plan(M, N, K);
   return p.S > 1 ? (size_t)p.S * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -426,6 +427,17 @@ extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int tra
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N)
     return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: leading dimension too small");
   hipStream_t st = dh::as_stream(stream);
+  if (K > 0 && dh::skinny_applies(M, N, K, trans_a)) {  // narrow layers: HBM-bound streaming kernels (gemm_skinny.hip)
+    const size_t need = dh::skinny_workspace_bytes(M, N, K, trans_a);
+    if (need && (!workspace || workspace_bytes < need))
+      return dh::fail(DH_ERR_WORKSPACE, "dh_gemm_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    int rc = dh::skinny_launch(M, N, K, trans_a, trans_b, A, lda, B, ldb, C, ldc, accumulate, static_cast<float*>(workspace), st);
+    if (rc != DH_OK || !trans_a) return rc;
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)dh::ceil_div(total, 256)), dim3(256), 0, st, M, N,
+                       dh::skinny_slab_count(K), static_cast<const float*>(workspace), C, ldc, accumulate);
+    return dh::check_launch("dh_gemm_f32(narrow reduce, slabs)");
+  }
   Plan p = make_plan(M, N, K);
   float* slabs = nullptr;
   if (p.S > 1) {

@@ -101,6 +101,10 @@ GEMM_SHAPES = [
     (77, 33, 4100, True, False),
     (300, 200, 64, False, True),  # dX-style
     (129, 50, 31, False, True), (65, 70, 129, True, True), (1, 1, 1, False, False),
+    # narrow-layer kernels (gemm_skinny.hip): rows form, reduce form, transposed B, N > K and N < K, edge sizes
+    (5000, 50, 50, False, False), (5000, 50, 50, False, True), (50, 50, 9000, True, False), (3000, 10, 32, False, False),
+    (4097, 64, 64, False, True), (64, 64, 100_001, True, False), (33, 7, 5000, True, False), (2000, 64, 3, False, False),
+    (1024, 1, 64, False, False),
 ]
 
 
@@ -130,7 +134,7 @@ def test_gemm_transpose_detecting_and_accumulate(cuda_device):
 
 def test_relu_backward_and_colsum(cuda_device):
     from dance_amd import kernels
-    for shape in [(1000, 512), (37, 50), (5, 3)]:
+    for shape in [(1000, 512), (37, 50), (5, 3), (70_000, 50), (10_000, 17), (5000, 200), (3, 1)]:
         y = torch.randn(*shape, device=cuda_device)
         y[y.abs() < 0.1] = 0  # exact zeros: gradient must be 0 there (threshold_backward)
         dy = torch.randn(*shape, device=cuda_device)
