@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--cells", type=int, default=N_CELLS, help="total cells (default: the BASELINE config)")
     ap.add_argument("--cpu-sample-cells", type=int, default=100_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["auto", "allgather", "alltoall"], default="auto",
+                    help="multi-GPU exchange (dance_amd/sharding.py); auto = alltoall when most remote rows are referenced")
     args = ap.parse_args()
 
     from dance_amd import _lib, kernels, sharding
@@ -116,7 +118,17 @@ def main():
     # ---- inputs resident in HBM before the timed region ---------------------------------------------------
     rowptr, col, val = synth_rand_graph(n, K_NEIGH, dev, seed=1)
     graph = CSRGraph(rowptr, col, val, n, n)
-    sg = sharding.ShardedGCNGraph.from_global_csr(graph)  # world == 1: the whole graph
+    mode = args.exchange
+    if mode == "auto":
+        mode = "allgather"
+        if world > 1 and N_HIDDEN % world == 0:
+            rng_lo, rng_hi = sharding.row_ranges(n, world)[0][rank]
+            e0, e1 = int(rowptr[rng_lo]), int(rowptr[rng_hi])
+            remote = float(((col[e0:e1] < rng_lo) | (col[e0:e1] >= rng_hi)).float().mean()) if e1 > e0 else 0.0
+            t = torch.tensor([remote], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # one decision for all ranks
+            mode = "alltoall" if float(t.item()) > 0.5 else "allgather"
+    sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)  # world == 1: the whole graph
     lo, hi = sg.ranges[sg.rank]
     n_local = hi - lo
     del graph, rowptr, col, val
@@ -191,7 +203,7 @@ def main():
             "config": {"workload": f"GCN layer (scDSC GNNLayer) fwd+bwd, {n} cells x {N_GENES} genes -> {N_HIDDEN}, "
                                    f"rand-k{K_NEIGH} graph (nnz={K_NEIGH * n}), fp32",
                        "cells": n, "genes": N_GENES, "hidden": N_HIDDEN, "k": K_NEIGH,
-                       "parallelism": f"dst-range x{world}" if world > 1 else "single GPU"},
+                       "parallelism": f"dst-range x{world}, {mode} exchange" if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels_out,
         }
         if world == 1 and not args.no_cpu_baseline:

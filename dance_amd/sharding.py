@@ -15,6 +15,18 @@ backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Rank p owns the cont
 Every rank computes exactly the rows it owns, in the same per-row order as the single-GPU path, so outputs
 are bit-identical to the 1-GPU result and independent of P (dW differs only by the all-reduce order).
 
+Two exchange modes (``ShardedGCNGraph.mode``), same inputs / outputs / numerics:
+
+* ``"allgather"`` — the halo exchange described above: the graph itself is sharded by destination range and every
+  rank receives all rows of S (resp. G): (P-1)/P * N*H*4 bytes inbound per all-gather.  Right when most remote
+  rows are NOT referenced (kNN graphs after locality reordering) — then it degenerates towards a halo all-to-all-v.
+* ``"alltoall"`` — for graphs without locality (the rand-k15 headline graph references ~88 % of all remote rows):
+  X, Y and all gradients stay sharded by destination range, but the aggregation itself is done feature-sliced.
+  S_p [n_p, H] --all_to_all--> S[:, H_q] for ALL rows; rank q aggregates its H/P columns over the whole graph
+  (CSR of A replicated: 12 bytes per edge); Y[:, H_q] --all_to_all--> Y_p [n_p, H].  Each all-to-all moves
+  (P-1)/P * N*H*4/P bytes inbound: two of them are 4x (P = 8) less traffic than one all-gather, and xGMI's
+  point-to-point links carry all P-1 pairwise transfers concurrently.  Per-row summation order is unchanged.
+
 The compute primitives come from an ``ops`` namespace; the default is ``dance_amd.kernels`` (HIP, fails loudly
 without a GPU).  The CPU test-suite injects an oracle-backed namespace to exercise the partition + collective
 logic under gloo — the product never selects a CPU backend by itself.
@@ -58,10 +70,16 @@ def slice_rows(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tens
 
 
 class ShardedGCNGraph:
-    """This rank's destination-range shard of A and of A^T."""
+    """This rank's destination-range shard of A and of A^T (+ optionally the replicated graph for "alltoall")."""
 
-    def __init__(self, a_shard: GraphShard, at_shard: GraphShard, n_nodes: int, group=None):
+    def __init__(self, a_shard: GraphShard, at_shard: GraphShard, n_nodes: int, group=None, *, mode: str = "allgather",
+                 full: Optional[Tuple[GraphShard, GraphShard]] = None):
+        if mode not in ("allgather", "alltoall"):
+            raise ValueError(f"unknown exchange mode {mode!r}")
+        if mode == "alltoall" and full is None:
+            raise ValueError("mode='alltoall' needs the replicated graph (full=(A, A^T) as GraphShards over all rows)")
         self.a, self.at = a_shard, at_shard
+        self.mode, self.full = mode, full
         self.n_nodes = n_nodes
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -72,15 +90,40 @@ class ShardedGCNGraph:
             raise ValueError(f"rank {self.rank} must own rows [{lo}, {hi})")
 
     @classmethod
-    def from_global_csr(cls, graph, group=None) -> "ShardedGCNGraph":
+    def from_global_csr(cls, graph, group=None, *, mode: str = "allgather") -> "ShardedGCNGraph":
         """Slice this rank's rows out of a full ``CSRGraph`` (and its transpose) replicated on every rank."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         ranges, _ = row_ranges(graph.n_rows, world)
         lo, hi = ranges[rank]
         gt = graph.transpose()
+        full = None
+        if mode == "alltoall":
+            full = (GraphShard(graph.rowptr, graph.col, graph.val, 0, graph.n_rows, graph.n_cols),
+                    GraphShard(gt.rowptr, gt.col, gt.val, 0, gt.n_rows, gt.n_cols))
         return cls(slice_rows(graph.rowptr, graph.col, graph.val, lo, hi, graph.n_cols),
-                   slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group)
+                   slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group, mode=mode, full=full)
+
+    # ---- feature-sliced exchange ("alltoall" mode) ---------------------------------------------------------
+    def rows_to_columns(self, local: torch.Tensor) -> torch.Tensor:
+        """[n_local, H] (my rows, all columns) -> [world*chunk, H/world] (all rows, my column slice)."""
+        h = local.shape[1]
+        if h % self.world:
+            raise ValueError(f"layer width {h} must be divisible by the world size {self.world} in alltoall mode")
+        hq = h // self.world
+        send = torch.zeros((self.world, self.chunk, hq), dtype=local.dtype, device=local.device)
+        send[:, :local.shape[0]] = local.reshape(local.shape[0], self.world, hq).transpose(0, 1)  # pack per destination
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)
+        return recv.reshape(self.world * self.chunk, hq)  # block r = rows of rank r: global row order
+
+    def columns_to_rows(self, cols: torch.Tensor, n_local: int) -> torch.Tensor:
+        """Inverse of ``rows_to_columns``: [world*chunk, H/world] -> [n_local, H]."""
+        hq = cols.shape[1]
+        send = cols.reshape(self.world, self.chunk, hq).contiguous()
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)  # recv[q] = column slice q of my rows
+        return recv[:, :n_local].transpose(0, 1).reshape(n_local, self.world * hq).contiguous()
 
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
         """[n_local, H] per rank -> [world*chunk, H] (rows of rank r at r*chunk; short shards zero-padded)."""
@@ -107,9 +150,23 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
     def forward(ctx, x_local, weight, bias, sg: ShardedGCNGraph, active: bool, ops):
         w = weight.contiguous()
         s_local = ops.gemm(x_local, w)
-        s_full = sg.all_gather_rows(s_local)
-        out = ops.spmm_csr(sg.a.rowptr, sg.a.col, sg.a.val, s_full, n_cols=s_full.shape[0], bias=bias,
-                           act=ops.ACT_RELU if active else ops.ACT_NONE, tag="spmm_csr_f32[fwd]")
+        act = ops.ACT_RELU if active else ops.ACT_NONE
+        if sg.mode == "alltoall" and sg.world > 1:
+            s_cols = sg.rows_to_columns(s_local)
+            a = sg.full[0]
+            hq = s_cols.shape[1]
+            b_cols = None if bias is None else bias[sg.rank * hq:(sg.rank + 1) * hq].contiguous()
+            y_cols = ops.spmm_csr(a.rowptr, a.col, a.val, s_cols, n_cols=s_cols.shape[0], bias=b_cols, act=act,
+                                  tag="spmm_csr_f32[fwd]")
+            if y_cols.shape[0] != s_cols.shape[0]:  # pad rows so the block layout matches world * chunk
+                pad = torch.zeros((s_cols.shape[0], hq), dtype=y_cols.dtype, device=y_cols.device)
+                pad[:y_cols.shape[0]] = y_cols
+                y_cols = pad
+            out = sg.columns_to_rows(y_cols, x_local.shape[0])
+        else:
+            s_full = sg.all_gather_rows(s_local)
+            out = ops.spmm_csr(sg.a.rowptr, sg.a.col, sg.a.val, s_full, n_cols=s_full.shape[0], bias=bias, act=act,
+                               tag="spmm_csr_f32[fwd]")
         ctx.sg, ctx.active, ctx.ops, ctx.has_bias = sg, active, ops, bias is not None
         ctx.save_for_backward(x_local, w, out if active else None)
         return out
@@ -124,9 +181,19 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = sg.all_reduce_sum(ops.colsum(g_local))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            g_full = sg.all_gather_rows(g_local)
-            ds = ops.spmm_csr(sg.at.rowptr, sg.at.col, sg.at.val, g_full, n_cols=g_full.shape[0],
-                              tag="spmm_csr_f32[bwd]")
+            if sg.mode == "alltoall" and sg.world > 1:
+                g_cols = sg.rows_to_columns(g_local)
+                at = sg.full[1]
+                ds_cols = ops.spmm_csr(at.rowptr, at.col, at.val, g_cols, n_cols=g_cols.shape[0], tag="spmm_csr_f32[bwd]")
+                if ds_cols.shape[0] != g_cols.shape[0]:
+                    pad = torch.zeros((g_cols.shape[0], g_cols.shape[1]), dtype=ds_cols.dtype, device=ds_cols.device)
+                    pad[:ds_cols.shape[0]] = ds_cols
+                    ds_cols = pad
+                ds = sg.columns_to_rows(ds_cols, x_local.shape[0])
+            else:
+                g_full = sg.all_gather_rows(g_local)
+                ds = ops.spmm_csr(sg.at.rowptr, sg.at.col, sg.at.val, g_full, n_cols=g_full.shape[0],
+                                  tag="spmm_csr_f32[bwd]")
             if ctx.needs_input_grad[1]:
                 dw = sg.all_reduce_sum(ops.gemm(x_local, ds, trans_a=True))
             if ctx.needs_input_grad[0]:

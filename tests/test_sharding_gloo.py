@@ -33,7 +33,7 @@ def _problem(n, fin, fout, k, seed):
     return x, w, b, dy, adj
 
 
-def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q):
+def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode="allgather"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import cpu_ops
@@ -49,7 +49,11 @@ def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q):
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
         a_sh = sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), lo, hi, n)
         at_sh = sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), lo, hi, n)
-        sg = sharding.ShardedGCNGraph(a_sh, at_sh, n)
+        full = None
+        if mode == "alltoall":
+            full = (sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), 0, n, n),
+                    sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), 0, n, n))
+        sg = sharding.ShardedGCNGraph(a_sh, at_sh, n, mode=mode, full=full)
         xl = torch.from_numpy(x[lo:hi].copy()).requires_grad_(True)
         wt = torch.from_numpy(w.copy()).requires_grad_(True)
         bt = torch.from_numpy(b.copy()).requires_grad_(True) if use_bias else None
@@ -60,13 +64,15 @@ def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,use_bias,active", [(2, 101, False, True), (2, 64, True, False), (3, 50, True, True)])
-def test_sharded_layer_matches_oracle(world, n, use_bias, active):
-    fin, fout, k, seed = 12, 7, 5, 17 + n
+@pytest.mark.parametrize("world,n,use_bias,active,mode", [(2, 101, False, True, "allgather"), (2, 64, True, False, "allgather"),
+                                                         (3, 50, True, True, "allgather"), (2, 101, True, True, "alltoall"),
+                                                         (3, 50, False, True, "alltoall")])
+def test_sharded_layer_matches_oracle(world, n, use_bias, active, mode):
+    fin, fout, k, seed = 12, 6, 5, 17 + n  # fout divisible by 2 and 3 (alltoall mode slices the layer width)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, fin, fout, k, seed, use_bias, active, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, fin, fout, k, seed, use_bias, active, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
