@@ -8,8 +8,9 @@
 
 One step = relu(A (X W)) forward, then backward from a fixed random dY producing dW (X is a non-grad leaf, as
 in the reference: scdsc.py:247,286-288).  With N > 1 the 1M cells are sharded by destination range
-(dance_amd/sharding.py): strong scaling, RCCL all-gather of the transformed features / output gradients and an
-all-reduce of dW inside the timed region.  Inputs are generated on the device and resident in HBM before
+(dance_amd/sharding.py): strong scaling; the transformed features / output gradients are exchanged over RCCL
+(all-gather, or the feature-sliced all-to-all when the graph has no locality) and dW is all-reduced, all inside
+the timed region.  Inputs are generated on the device and resident in HBM before
 the timed region; graph set-up (CSR transpose) is outside it, as graph construction is in the reference.
 Prints ONE JSON line on rank 0.
 """
@@ -171,8 +172,14 @@ def main():
         nnz_t_local = int(sg.at.col.numel())
         gemm_flops = 2.0 * n_local * N_GENES * N_HIDDEN
 
+        sliced = world > 1 and mode == "alltoall"  # every rank aggregates ALL rows over H / world columns
+        width = N_HIDDEN // world if sliced else N_HIDDEN
+        if sliced:
+            nnz_local = nnz_t_local = int(sg.full[0].col.numel())
+
         def spmm_bytes(nnz, rows):  # B_gather of SURVEY.md §8d: indices+values, row pointers, gathered rows, output
-            return nnz * 8.0 + 4.0 * (rows + 1) + nnz * N_HIDDEN * 4.0 + rows * N_HIDDEN * 4.0
+            rows = n if sliced else rows
+            return nnz * 8.0 + 4.0 * (rows + 1) + nnz * width * 4.0 + rows * width * 4.0
 
         kernels_out = {}
         for name, (launches, ms) in sorted(ksum.items()):
