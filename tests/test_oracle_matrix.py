@@ -37,3 +37,21 @@ def test_mean_rank_matches_scipy():
     for _ in range(5):
         x = rng.integers(0, 5, 12).astype(np.float32)
         assert np.array_equal(om.mean_rank_data(x), scipy.stats.rankdata(x).astype(np.float32))
+
+
+def test_c_restatement_matches_numpy_oracle_and_golden():
+    """oracle/csrc/pairwise_ref.c (the numba kernel restated in C) == the numpy restatement, bit for bit, and
+    satisfies the reference's golden test; its kNN distance definition equals oracle.graphs.knn_exact's."""
+    import pytest
+    from oracle import cref
+    from oracle import graphs as og
+    if not cref.available():
+        pytest.skip("oracle/_build not built (run __graft_entry__.build())")
+    mat = np.array(KA["mat"], dtype=np.float32)
+    assert np.allclose(np.array(KA["euclidean"]), cref.pairwise_euclidean(mat))
+    x = np.random.default_rng(0).standard_normal((200, 7)).astype(np.float32) * 30
+    assert np.array_equal(cref.pairwise_euclidean(x), om.pairwise_distance(x, 0))
+    d2 = cref.sqdist(x, 10, 60)
+    idx, dist = og.knn_exact(x, 9)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :9]
+    assert np.array_equal(order, idx[10:60]) and np.array_equal(np.sqrt(np.take_along_axis(d2, order, 1)), dist[10:60])
