@@ -26,6 +26,8 @@ def _declare(lib):
         "dh_last_error_string": (c_char_p, []),
         "dh_device_count": (c_int, []),
         "dh_spmm_csr_f32": (c_int, [i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, i32, i32, P]),
+        "dh_relu_mask_bytes": (c_size_t, [i64, i64]),
+        "dh_spmm_csr_relu_f32": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_csr_transpose_workspace_bytes": (c_size_t, [i64, i64, i64]),
         "dh_csr_transpose": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_gemm_f32_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),

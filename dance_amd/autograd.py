@@ -30,21 +30,41 @@ class _GCNLayerFn(torch.autograd.Function):
         x = x.contiguous() if x.stride(-1) != 1 else x
         w = weight.contiguous()
         support = kernels.gemm(x, w)
-        out = kernels.spmm_csr(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, bias=bias,
-                               rowscale=rowscale, colscale=colscale, reduce=reduce,
-                               act=kernels.ACT_RELU if active else kernels.ACT_NONE, tag="spmm_csr_f32[fwd]")
+        # ReLU fused into both SpMMs (sign mask instead of G = dY*[Y>0] in HBM) for the plain wide-layer case
+        mask = None
+        fused = (active and bias is None and rowscale is None and colscale is None and reduce == kernels.REDUCE_SUM
+                 and support.stride(0) % 4 == 0 and kernels.relu_mask_bytes(graph.n_rows, support.shape[1]) > 0)
+        if fused:
+            mask = torch.empty(kernels.relu_mask_bytes(graph.n_rows, support.shape[1]), dtype=torch.uint8, device=x.device)
+            out = kernels.spmm_csr_relu(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols,
+                                        act=kernels.ACT_RELU, out_mask=mask, tag="spmm_csr_f32[fwd]")
+        else:
+            out = kernels.spmm_csr(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, bias=bias,
+                                   rowscale=rowscale, colscale=colscale, reduce=reduce,
+                                   act=kernels.ACT_RELU if active else kernels.ACT_NONE, tag="spmm_csr_f32[fwd]")
         ctx.graph, ctx.active, ctx.has_bias = graph, active, bias is not None
         ctx.rowscale, ctx.colscale, ctx.reduce = rowscale, colscale, reduce
-        ctx.save_for_backward(x, w, out if active else None)
+        ctx.save_for_backward(x, w, out if (active and not fused) else None, mask)
         return out
 
     @staticmethod
     def backward(ctx, dy: torch.Tensor):
-        x, w, out = ctx.saved_tensors
+        x, w, out, mask = ctx.saved_tensors
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dy = dy.contiguous() if dy.stride(-1) != 1 else dy
-        g = kernels.relu_backward(out, dy) if ctx.active else dy
         dx = dw = db = None
+        if mask is not None:  # fused ReLU backward: dS = A^T (dy * [out > 0]) in one gather
+            if need_x or need_w:
+                gt = ctx.graph.transpose()
+                if dy.stride(0) % 4 != 0 or dy.data_ptr() % 16 != 0:
+                    dy = dy.clone(memory_format=torch.contiguous_format)  # fresh allocation: 16-byte aligned rows
+                ds = kernels.spmm_csr_relu(gt.rowptr, gt.col, gt.val, dy, n_cols=gt.n_cols, in_mask=mask, tag="spmm_csr_f32[bwd]")
+                if need_w:
+                    dw = kernels.gemm(x, ds, trans_a=True)
+                if need_x:
+                    dx = kernels.gemm(ds, w, trans_b=True)
+            return dx, dw, db, None, None, None, None, None
+        g = kernels.relu_backward(out, dy) if ctx.active else dy
         if need_b:
             db = kernels.colsum(g)
         if need_x or need_w:

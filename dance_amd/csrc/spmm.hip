@@ -71,14 +71,24 @@ __device__ __forceinline__ float sage_alpha(const SageScale& sg, int sid, int di
   return sg.alpha[idx];
 }
 
+// ReLU sign masks (fusing autograd's ReluBackward into the backward gather, dh_spmm_csr_relu_f32):
+// for the wavefront-per-row float4 configuration the forward pass stores, per row and per 256-column slice, the
+// four wave ballots "element i of lane l's float4 is > 0" (4 x uint64 = 256 bits); the backward pass gathers
+// dY rows and zeroes the elements whose bit is clear, so G = dY * [Y > 0] is never written to or read from HBM.
+struct ReluMask {
+  unsigned long long* out;       // forward: written when non-null   [n_rows][slices][4]
+  const unsigned long long* in;  // backward: applied to the gathered rows of Z when non-null [n_cols][slices][4]
+  int slices;                    // width / 256
+};
+
 // G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart).
-template <int G, int VEC, int NACC, bool SAGE>
+template <int G, int VEC, int NACC, bool SAGE, bool MASKED = false>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int64_t n_rows, int64_t width, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ rowscale, const float* __restrict__ colscale,
     const float* __restrict__ Z, int64_t ldz, float* __restrict__ Y, int64_t ldy,
-    const float* __restrict__ bias, int act, int reduce, SageScale sage) {
+    const float* __restrict__ bias, int act, int reduce, SageScale sage, ReluMask mask = ReluMask{nullptr, nullptr, 0}) {
   using V = typename VecT<VEC>::type;
   constexpr int ROWS_PER_BLOCK = 256 / G;
   const int g = threadIdx.x % G;
@@ -121,6 +131,17 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
           z[u][a] = live[a] ? *reinterpret_cast<const V*>(zr + a * G * VEC) : V(0.f);
+        if constexpr (MASKED) {
+          if (mask.in) {  // wave-uniform row ck: the 4 ballot words of each slice come through the scalar cache
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+              const unsigned long long* m = mask.in + ((int64_t)ck * mask.slices + blockIdx.y * NACC + a) * 4;
+#pragma unroll
+              for (int i = 0; i < VEC; ++i)
+                if (!((m[i] >> g) & 1ull)) z[u][a][i] = 0.f;
+            }
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -132,8 +153,19 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
       const float wk = bcast_f<G>(w, k);
       const float* zr = Z + (int64_t)ck * ldz + c0;
 #pragma unroll
-      for (int a = 0; a < NACC; ++a)
-        if (live[a]) fma_vec<VEC>(acc[a], wk, *reinterpret_cast<const V*>(zr + a * G * VEC));
+      for (int a = 0; a < NACC; ++a) {
+        if (!live[a]) continue;
+        V zv = *reinterpret_cast<const V*>(zr + a * G * VEC);
+        if constexpr (MASKED) {
+          if (mask.in) {
+            const unsigned long long* m = mask.in + ((int64_t)ck * mask.slices + blockIdx.y * NACC + a) * 4;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i)
+              if (!((m[i] >> g) & 1ull)) zv[i] = 0.f;
+          }
+        }
+        fma_vec<VEC>(acc[a], wk, zv);
+      }
     }
   }
 
@@ -144,6 +176,16 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
   for (int a = 0; a < NACC; ++a) {
     if (!live[a]) continue;
     epilogue<VEC>(acc[a], scale, bias, c0 + (int64_t)a * G * VEC, act);
+    if constexpr (MASKED) {
+      if (mask.out) {
+        unsigned long long* m = mask.out + (row * mask.slices + blockIdx.y * NACC + a) * 4;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const unsigned long long b = __ballot(acc[a][i] > 0.f);
+          if (g == 0) m[i] = b;
+        }
+      }
+    }
     __builtin_nontemporal_store(acc[a], reinterpret_cast<V*>(yr + a * G * VEC));
   }
 }
@@ -200,6 +242,42 @@ extern "C" int dh_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
   if (n_rows >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: n_rows >= 2^31");
   return dispatch<false>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce,
                          SageScale{nullptr, nullptr, nullptr, 0}, dh::as_stream(stream));
+}
+
+extern "C" size_t dh_relu_mask_bytes(int64_t n_rows, int64_t width) {
+  if (n_rows <= 0 || width <= 0 || width % 256 != 0) return 0;
+  return (size_t)n_rows * (size_t)(width / 256) * 4 * sizeof(unsigned long long);
+}
+
+// SpMM with the ReLU of a GCN layer fused on both sides (see ReluMask): forward = dh_spmm_csr_f32(act = relu)
+// that additionally records the sign mask of its output; backward = SpMM whose gathered operand is dY with the
+// recorded mask applied on the fly.  Only for the float4 wavefront-per-row configuration: width % 256 == 0 and
+// 16-byte aligned operands (the host falls back to dh_relu_backward_f32 + dh_spmm_csr_f32 otherwise).
+extern "C" int dh_spmm_csr_relu_f32(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr,
+                                    const int32_t* col, const float* val, const float* Z, int64_t ldz, float* Y,
+                                    int64_t ldy, const float* bias, int act, void* out_mask, const void* in_mask,
+                                    dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: negative size");
+  if (n_rows == 0 || width == 0) return DH_OK;
+  if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: null rowptr/Z/Y");
+  if (width % 256 != 0 || ldz % 4 != 0 || ldy % 4 != 0 || !dh::aligned16(Z) || !dh::aligned16(Y) || (bias && !dh::aligned16(bias)))
+    return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: needs width %% 256 == 0 and 16-byte aligned rows");
+  if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: leading dimension < width");
+  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: bad act %d", act);
+  if (n_rows >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: n_rows >= 2^31");
+  const ReluMask mask{static_cast<unsigned long long*>(out_mask), static_cast<const unsigned long long*>(in_mask), (int)(width / 256)};
+  const SageScale none{nullptr, nullptr, nullptr, 0};
+  hipStream_t st = dh::as_stream(stream);
+  if (width % 512 == 0) {
+    dim3 grid((unsigned)dh::ceil_div(n_rows, 4), (unsigned)(width / 512));
+    hipLaunchKernelGGL((spmm_csr_kernel<64, 4, 2, false, true>), grid, dim3(256), 0, st, n_rows, width, rowptr, col, val, nullptr,
+                       nullptr, Z, ldz, Y, ldy, bias, act, DH_REDUCE_SUM, none, mask);
+  } else {
+    dim3 grid((unsigned)dh::ceil_div(n_rows, 4), (unsigned)(width / 256));
+    hipLaunchKernelGGL((spmm_csr_kernel<64, 4, 1, false, true>), grid, dim3(256), 0, st, n_rows, width, rowptr, col, val, nullptr,
+                       nullptr, Z, ldz, Y, ldy, bias, act, DH_REDUCE_SUM, none, mask);
+  }
+  return dh::check_launch("dh_spmm_csr_relu_f32");
 }
 
 extern "C" int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,

@@ -104,6 +104,16 @@ class ShardedGCNGraph:
         return cls(slice_rows(graph.rowptr, graph.col, graph.val, lo, hi, graph.n_cols),
                    slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group, mode=mode, full=full)
 
+    def as_local_graph(self):
+        """world == 1: the shard IS the graph — expose it (with its transpose) as a ``CSRGraph``."""
+        if getattr(self, "_local_graph", None) is None:
+            from .graph import CSRGraph
+            g = CSRGraph(self.a.rowptr, self.a.col, self.a.val, self.a.n_rows, self.a.n_cols)
+            gt = CSRGraph(self.at.rowptr, self.at.col, self.at.val, self.at.n_rows, self.at.n_cols)
+            g._t, gt._t = gt, g
+            self._local_graph = g
+        return self._local_graph
+
     # ---- feature-sliced exchange ("alltoall" mode) ---------------------------------------------------------
     def rows_to_columns(self, local: torch.Tensor) -> torch.Tensor:
         """[n_local, H] (my rows, all columns) -> [world*chunk, H/world] (all rows, my column slice)."""
@@ -204,4 +214,7 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
 def sharded_gcn_layer(x_local: torch.Tensor, weight: torch.Tensor, sg: ShardedGCNGraph,
                       bias: Optional[torch.Tensor] = None, active: bool = False, ops=None) -> torch.Tensor:
     """This rank's rows of act(A (X W) + b); gradients of W / b are all-reduced, dX stays row-sharded."""
+    if sg.world == 1 and ops is None:  # one GPU: the plain layer op (same kernels, plus the fused ReLU mask path)
+        from .autograd import gcn_layer
+        return gcn_layer(x_local, weight, sg.as_local_graph(), bias, active)
     return _ShardedGCNLayerFn.apply(x_local, weight, bias, sg, active, ops or _hip_kernels)

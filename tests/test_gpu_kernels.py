@@ -151,3 +151,25 @@ def test_errors_are_loud(cuda_device):
     lib = _lib.load()
     assert lib.dh_spmm_csr_f32(4, 4, 4, None, None, None, None, None, None, 4, None, 4, None, 0, 0, None) < 0
     assert b"null" in lib.dh_last_error_string()
+
+
+@pytest.mark.parametrize("width", [256, 512, 1024])
+def test_spmm_fused_relu_mask(cuda_device, width):
+    """dh_spmm_csr_relu_f32: forward == SpMM+ReLU bit for bit and records the sign mask; backward with the mask ==
+    SpMM(A^T, relu_backward(Y, dY)) bit for bit (same per-element op order, masked terms contribute exact zeros)."""
+    from dance_amd import kernels
+    a = _rand_csr(700, 700, 11, seed=width, long_row=(9, 150), empty_rows=(4, ))
+    rp, c, v = _dev_csr(a, cuda_device)
+    z = torch.randn(700, width, device=cuda_device)
+    assert kernels.relu_mask_bytes(700, width) == 700 * (width // 256) * 32 and kernels.relu_mask_bytes(700, 50) == 0
+    mask = torch.zeros(kernels.relu_mask_bytes(700, width), dtype=torch.uint8, device=cuda_device)
+    y = kernels.spmm_csr_relu(rp, c, v, z, act=kernels.ACT_RELU, out_mask=mask)
+    y_ref = kernels.spmm_csr(rp, c, v, z, act=kernels.ACT_RELU)
+    assert torch.equal(y, y_ref)
+    dy = torch.randn(700, width, device=cuda_device)
+    rpt, ct, vt, _ = kernels.csr_transpose(rp, c, v, 700, 700)
+    ds = kernels.spmm_csr_relu(rpt, ct, vt, dy, in_mask=mask)
+    ds_ref = kernels.spmm_csr(rpt, ct, vt, kernels.relu_backward(y_ref, dy))
+    assert torch.equal(ds, ds_ref)
+    with pytest.raises(Exception):
+        kernels.spmm_csr_relu(rp, c, v, torch.randn(700, 50, device=cuda_device), act=kernels.ACT_RELU)
