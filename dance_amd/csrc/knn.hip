@@ -19,6 +19,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int QB = 256;  // queries per block
 constexpr int KLDS = 32; // largest k whose lists live in LDS
@@ -33,36 +34,59 @@ __device__ __forceinline__ bool before(float d2, int idx, float od, int oi) {
   return d2 < od || (d2 == od && idx < oi);
 }
 
-__device__ __forceinline__ void insert(const List& L, int k, int& cnt, float& tau_d, int& tau_i, float d2, int idx) {
-  int pos = cnt < k ? cnt : k - 1;
-  while (pos > 0) {
-    const float pd = L.d[(pos - 1) * L.stride];
-    const int pi = L.i[(pos - 1) * L.stride];
-    if (!before(d2, idx, pd, pi)) break;
-    L.d[pos * L.stride] = pd;
-    L.i[pos * L.stride] = pi;
-    --pos;
+// The per-lane list is kept UNSORTED with its worst entry (tau = the current k-th best) tracked by position:
+// an accepted candidate overwrites the worst entry and the list is rescanned for the new worst — k independent
+// LDS reads that pipeline, instead of a sorted insertion's chain of dependent read-compare-write steps.  While one
+// lane of a wavefront inserts, the other 63 wait, so this latency is what the scan pays per accepted candidate.
+__device__ __forceinline__ void rescan(const List& L, int k, float& tau_d, int& tau_i, int& tau_pos) {
+  float md = L.d[0];
+  int mi = L.i[0], mp = 0;
+  for (int s = 1; s < k; s += 4) {
+    float dd[4];
+    int ii[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ss = min(s + u, k - 1);
+      dd[u] = L.d[ss * L.stride];
+      ii[u] = L.i[ss * L.stride];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (before(md, mi, dd[u], ii[u])) { md = dd[u]; mi = ii[u]; mp = min(s + u, k - 1); }
   }
+  tau_d = md; tau_i = mi; tau_pos = mp;
+}
+
+__device__ __forceinline__ void insert(const List& L, int k, int& cnt, float& tau_d, int& tau_i, int& tau_pos, float d2, int idx) {
+  const int pos = cnt < k ? cnt : tau_pos;
   L.d[pos * L.stride] = d2;
   L.i[pos * L.stride] = idx;
   if (cnt < k) ++cnt;
-  if (cnt == k) {
-    tau_d = L.d[(k - 1) * L.stride];
-    tau_i = L.i[(k - 1) * L.stride];
-  }
+  if (cnt == k) rescan(L, k, tau_d, tau_i, tau_pos);
 }
 
+// Selection-sorts the lane's list in place by (d2, index) and writes indices + distances (or raw d2 for a partial
+// list that knn_merge_kernel will finish).
 __device__ __forceinline__ void finish(const List& L, bool lds_list, int k, int cnt, int64_t q_local, bool valid,
-                                       int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+                                       int32_t* __restrict__ out_idx, float* __restrict__ out_dist, bool raw_d2 = false) {
   if (!valid) return;
   int32_t* oi = out_idx + q_local * k;
   float* od = out_dist + q_local * k;
   for (int s = 0; s < k; ++s) {
     if (s < cnt) {
-      const float d2 = L.d[s * L.stride];
-      const int idx = L.i[s * L.stride];
-      oi[s] = idx;
-      od[s] = (float)sqrt((double)d2);  // f64 sqrt then one rounding == correctly rounded f32 sqrt
+      float bd = L.d[s * L.stride];
+      int bi = L.i[s * L.stride], bp = s;
+      for (int r = s + 1; r < cnt; ++r) {
+        const float rd = L.d[r * L.stride];
+        const int ri = L.i[r * L.stride];
+        if (before(rd, ri, bd, bi)) { bd = rd; bi = ri; bp = r; }
+      }
+      if (bp != s) {  // move the displaced entry into the hole
+        L.d[bp * L.stride] = L.d[s * L.stride];
+        L.i[bp * L.stride] = L.i[s * L.stride];
+      }
+      oi[s] = bi;
+      od[s] = raw_d2 ? bd : (float)sqrt((double)bd);  // f64 sqrt then one rounding == correctly rounded f32 sqrt
     } else {  // fewer than k points exist
       oi[s] = -1;
       od[s] = __int_as_float(0x7f800000);
@@ -77,6 +101,10 @@ __global__ __launch_bounds__(QB) void knn_small_kernel(int64_t n, int64_t d, con
                                                        int64_t q_begin, int64_t q_end, int k, bool lds_list,
                                                        int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
   constexpr int CT = 64;
+  // gridDim.y > 1: this block scans only its slice of the candidates and writes a partial (d2, idx) list
+  const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
+  const int64_t nq_all = q_end - q_begin;
+  if (gridDim.y > 1) { out_idx += (int64_t)blockIdx.y * nq_all * k; out_dist += (int64_t)blockIdx.y * nq_all * k; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* cand = reinterpret_cast<float*>(smem);                    // [CT][DCH]
   float* ld = cand + CT * DCH;                                     // [k][QB] when lds_list
@@ -94,33 +122,100 @@ __global__ __launch_bounds__(QB) void knn_small_kernel(int64_t n, int64_t d, con
   List L;
   if (lds_list) { L.d = ld + tid; L.i = li + tid; L.stride = QB; }
   else { L.d = out_dist + (valid ? q_local : 0) * k; L.i = out_idx + (valid ? q_local : 0) * k; L.stride = 1; }
-  int cnt = 0, tau_i = 0x7fffffff;
+  int cnt = 0, tau_i = 0x7fffffff, tau_pos = 0;
   float tau_d = __int_as_float(0x7f800000);
 
-  for (int64_t c0 = 0; c0 < n; c0 += CT) {
+  for (int64_t c0 = cand_lo; c0 < cand_hi; c0 += CT) {
     __syncthreads();
     for (int idx = tid; idx < CT * DCH; idx += QB) {
       const int c = idx / DCH, t = idx % DCH;
-      cand[idx] = (c0 + c < n && t < d) ? X[(c0 + c) * ldx + t] : 0.f;
+      cand[idx] = (c0 + c < cand_hi && t < d) ? X[(c0 + c) * ldx + t] : 0.f;
     }
     __syncthreads();
-    const int lim = (int)min((int64_t)CT, n - c0);
+    const int lim = (int)min((int64_t)CT, cand_hi - c0);
     for (int c = 0; c < lim; ++c) {
+      // all LDS reads of the candidate are issued back to back (broadcast ds_read_b128), then consumed in order:
+      // one read in flight at a time left the VALU idle for the LDS latency between 12-op bursts
+      f32x4 y[DCH / 4];
+#pragma unroll
+      for (int t = 0; t < DCH / 4; ++t) y[t] = *reinterpret_cast<const f32x4*>(cand + c * DCH + t * 4);
+      __builtin_amdgcn_sched_barrier(0);
       float acc = 0.f;
 #pragma unroll
-      for (int t = 0; t < DCH; t += 4) {
-        const f32x4 y = *reinterpret_cast<const f32x4*>(cand + c * DCH + t);
+      for (int t = 0; t < DCH / 4; ++t) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float diff = __fsub_rn(x[t + u], y[u]);
+          const float diff = __fsub_rn(x[t * 4 + u], y[t][u]);
           acc = __fadd_rn(acc, __fmul_rn(diff, diff));
         }
       }
       const int idx = (int)(c0 + c);
-      if (valid && (cnt < k || before(acc, idx, tau_d, tau_i))) insert(L, k, cnt, tau_d, tau_i, acc, idx);
+      if (valid && (cnt < k || before(acc, idx, tau_d, tau_i))) insert(L, k, cnt, tau_d, tau_i, tau_pos, acc, idx);
     }
   }
-  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist);
+  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, gridDim.y > 1);
+}
+
+// d <= 64, scalar-operand form: a candidate row is the same for every lane of a wavefront, so it belongs in
+// SGPRs, not in LDS — the rows of the zero-padded copy Xp [n][DCH] are fetched with scalar loads (s_load_dwordx8/16
+// through the scalar cache, shared by the block's 4 waves) and enter the VALU as the one SGPR operand of
+// v_sub_f32.  No LDS staging, no barriers in the scan; the per-lane lists stay in LDS.
+// (Scoring two candidates per lane with v_pk_add_f32 / v_pk_mul_f32 on a pair-interleaved copy was measured at the
+// same rate — packed f32 issues at half the rate of plain f32 on gfx950 — so the plain form is kept.)
+template <int DCH>
+__global__ __launch_bounds__(QB) void knn_sreg_kernel(int64_t n, const float* __restrict__ Xp, int64_t q_begin,
+                                                      int64_t q_end, int k, bool lds_list,
+                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+  const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
+  const int64_t nq_all = q_end - q_begin;
+  if (gridDim.y > 1) { out_idx += (int64_t)blockIdx.y * nq_all * k; out_dist += (int64_t)blockIdx.y * nq_all * k; }
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* ld = reinterpret_cast<float*>(smem);                      // [k][QB] when lds_list
+  int* li = reinterpret_cast<int*>(ld + (lds_list ? k * QB : 0));  // [k][QB]
+
+  const int tid = threadIdx.x;
+  const int64_t q_local = (int64_t)blockIdx.x * QB + tid;
+  const int64_t q = q_begin + q_local;
+  const bool valid = q < q_end;
+
+  constexpr int RS = DCH;  // row stride of Xp (padding rows to whole 64-byte lines measured slower: the scan is bound by scalar-cache bytes)
+  float x[DCH];
+  {
+    const f32x4* xq = reinterpret_cast<const f32x4*>(Xp + (valid ? q : 0) * RS);
+#pragma unroll
+    for (int t = 0; t < DCH / 4; ++t) {
+      const f32x4 v = xq[t];
+      x[t * 4] = v[0]; x[t * 4 + 1] = v[1]; x[t * 4 + 2] = v[2]; x[t * 4 + 3] = v[3];
+    }
+  }
+  List L;
+  if (lds_list) { L.d = ld + tid; L.i = li + tid; L.stride = QB; }
+  else { L.d = out_dist + (valid ? q_local : 0) * k; L.i = out_idx + (valid ? q_local : 0) * k; L.stride = 1; }
+  int cnt = 0, tau_i = 0x7fffffff, tau_pos = 0;
+  float tau_d = __int_as_float(0x7f800000);
+
+  for (int64_t c = cand_lo; c < cand_hi; ++c) {
+    const float* __restrict__ y = Xp + c * RS;  // wave-uniform address -> scalar loads
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < DCH; ++t) {
+      const float diff = __fsub_rn(x[t], y[t]);
+      acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+    }
+    const int idx = (int)c;
+    if (valid && (cnt < k || before(acc, idx, tau_d, tau_i))) insert(L, k, cnt, tau_d, tau_i, tau_pos, acc, idx);
+  }
+  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, gridDim.y > 1);
+}
+
+// Xp[r][0:RS] = X[r][0:d] followed by zeros (zero features add exact zeros to every distance)
+__global__ __launch_bounds__(256) void knn_pad_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx, int rs,
+                                                      float* __restrict__ Xp) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * rs) return;
+  const int64_t r = i / rs;
+  const int t = (int)(i % rs);
+  Xp[i] = t < d ? X[r * ldx + t] : 0.f;
 }
 
 // d > 64: features in chunks of 16; 16 candidates per tile with one register accumulator each.
@@ -128,6 +223,9 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
                                                      int64_t q_begin, int64_t q_end, int k, bool lds_list,
                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
   constexpr int CT = 16, DCH = 16;
+  const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
+  const int64_t nq_all = q_end - q_begin;
+  if (gridDim.y > 1) { out_idx += (int64_t)blockIdx.y * nq_all * k; out_dist += (int64_t)blockIdx.y * nq_all * k; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* cand = reinterpret_cast<float*>(smem);  // [CT][DCH]
   float* ld = cand + CT * DCH;
@@ -142,10 +240,10 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
   List L;
   if (lds_list) { L.d = ld + tid; L.i = li + tid; L.stride = QB; }
   else { L.d = out_dist + (valid ? q_local : 0) * k; L.i = out_idx + (valid ? q_local : 0) * k; L.stride = 1; }
-  int cnt = 0, tau_i = 0x7fffffff;
+  int cnt = 0, tau_i = 0x7fffffff, tau_pos = 0;
   float tau_d = __int_as_float(0x7f800000);
 
-  for (int64_t c0 = 0; c0 < n; c0 += CT) {
+  for (int64_t c0 = cand_lo; c0 < cand_hi; c0 += CT) {
     float acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
@@ -153,7 +251,7 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
       __syncthreads();
       {
         const int c = tid / DCH, t = tid % DCH;  // 256 threads == CT * DCH
-        cand[tid] = (c0 + c < n && t0 + t < d) ? X[(c0 + c) * ldx + t0 + t] : 0.f;
+        cand[tid] = (c0 + c < cand_hi && t0 + t < d) ? X[(c0 + c) * ldx + t0 + t] : 0.f;
       }
       float x[DCH];
 #pragma unroll
@@ -175,17 +273,74 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const int64_t ci = c0 + c;
-      if (valid && ci < n && (cnt < k || before(acc[c], (int)ci, tau_d, tau_i)))
-        insert(L, k, cnt, tau_d, tau_i, acc[c], (int)ci);
+      if (valid && ci < cand_hi && (cnt < k || before(acc[c], (int)ci, tau_d, tau_i)))
+        insert(L, k, cnt, tau_d, tau_i, tau_pos, acc[c], (int)ci);
     }
   }
-  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist);
+  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, gridDim.y > 1);
+}
+
+// Merge P partial (d2, idx) lists per query (each sorted ascending) into the final k smallest by (d2, idx): one
+// thread per query, P cursors, k selection steps — deterministic, the same order a single scan produces.
+__global__ __launch_bounds__(256) void knn_merge_kernel(int64_t nq, int k, int P, const int32_t* __restrict__ part_idx,
+                                                        const float* __restrict__ part_d2, int32_t* __restrict__ out_idx,
+                                                        float* __restrict__ out_dist) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= nq) return;
+  constexpr int MAXP = 64;
+  unsigned char cur[MAXP];
+  for (int p = 0; p < P; ++p) cur[p] = 0;
+  for (int s = 0; s < k; ++s) {
+    int best = -1, bi = -1;
+    float bd = 0.f;
+    for (int p = 0; p < P; ++p) {
+      if (cur[p] >= k) continue;
+      const int64_t off = ((int64_t)p * nq + q) * k + cur[p];
+      const int ci = part_idx[off];
+      if (ci < 0) continue;  // this slice ran out of points
+      const float cd = part_d2[off];
+      if (best < 0 || before(cd, ci, bd, bi)) { best = p; bd = cd; bi = ci; }
+    }
+    if (best < 0) {
+      out_idx[q * k + s] = -1;
+      out_dist[q * k + s] = __int_as_float(0x7f800000);
+    } else {
+      out_idx[q * k + s] = bi;
+      out_dist[q * k + s] = (float)sqrt((double)bd);
+      ++cur[best];
+    }
+  }
 }
 
 }  // namespace
 
+namespace {
+// candidate slices per query block so that >= ~2048 blocks (8 per CU) are in flight; k <= 255 for the merge cursors
+int knn_slices(int64_t nq, int k) {
+  const int64_t blocks = dh::ceil_div(nq, QB);
+  if (blocks >= 1024 || k > 255) return 1;
+  int64_t p = dh::ceil_div(2048, blocks);
+  return (int)(p > 64 ? 64 : p);
+}
+}  // namespace
+
+namespace {
+int knn_padded_width(int64_t d) { return d <= 64 ? (int)((d + 3) / 4 * 4) : 0; }
+int knn_row_stride(int64_t d) { return knn_padded_width(d); }
+size_t knn_padded_bytes(int64_t n, int64_t d) { return (size_t)n * (size_t)knn_row_stride(d) * sizeof(float); }
+}  // namespace
+
+extern "C" size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k) {
+  (void)n; (void)d;
+  if (n_queries <= 0 || k <= 0) return 0;
+  const int P = knn_slices(n_queries, k);
+  const size_t part = P > 1 ? ((size_t)P * (size_t)n_queries * (size_t)k * 8 + 63) / 64 * 64 : 0;
+  return part + knn_padded_bytes(n, d);
+}
+
 extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx, int64_t q_begin,
-                                     int64_t q_end, int k, int32_t* out_idx, float* out_dist, dh_stream_t stream) {
+                                     int64_t q_end, int k, int32_t* out_idx, float* out_dist, void* workspace,
+                                     size_t workspace_bytes, dh_stream_t stream) {
   if (n < 0 || d < 0 || k < 0) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: negative size");
   if (q_begin < 0 || q_end > n || q_begin > q_end)
     return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: bad query range [%lld, %lld)", (long long)q_begin, (long long)q_end);
@@ -194,19 +349,43 @@ extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64
   if (ldx < d) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: ldx < d");
   if (n >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: n >= 2^31");
   hipStream_t st = dh::as_stream(stream);
+  const int64_t nq = q_end - q_begin;
+  const int P = knn_slices(nq, k);
+  int32_t* k_idx = out_idx;
+  float* k_dist = out_dist;
+  const size_t part_bytes = P > 1 ? ((size_t)P * (size_t)nq * (size_t)k * 8 + 63) / 64 * 64 : 0;
+  const size_t need = part_bytes + knn_padded_bytes(n, d);
+  if (need && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 63u)))
+    return dh::fail(DH_ERR_WORKSPACE, "dh_knn_bruteforce_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+  if (P > 1) {
+    k_idx = static_cast<int32_t*>(workspace);
+    k_dist = reinterpret_cast<float*>(k_idx + (size_t)P * nq * k);
+  }
+  float* Xp = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);  // 64-byte aligned rows
+  const int dch = knn_padded_width(d);
+  if (dch)
+    hipLaunchKernelGGL(knn_pad_kernel, dim3((unsigned)dh::ceil_div(n * knn_row_stride(d), 256)), dim3(256), 0, st, n, d, X, ldx, knn_row_stride(d), Xp);
+  // per-lane lists live in LDS only for the single-slice case with small k (partial lists go straight to memory)
   const bool lds_list = k <= KLDS;
   const size_t list_bytes = lds_list ? (size_t)k * QB * 8 : 0;
-  dim3 grid((unsigned)dh::ceil_div(q_end - q_begin, QB)), block(QB);
+  dim3 grid((unsigned)dh::ceil_div(nq, QB), (unsigned)P), block(QB);
 #define DH_KNN_SMALL(DCH)                                                                            \
-  hipLaunchKernelGGL(knn_small_kernel<DCH>, grid, block, 64 * DCH * sizeof(float) + list_bytes, st, n, d, X, ldx, \
-                     q_begin, q_end, k, lds_list, out_idx, out_dist)
-  if (d <= 4) DH_KNN_SMALL(4);
-  else if (d <= 16) DH_KNN_SMALL(16);
-  else if (d <= 32) DH_KNN_SMALL(32);
-  else if (d <= 64) DH_KNN_SMALL(64);
-  else
-    hipLaunchKernelGGL(knn_big_kernel, grid, block, 16 * 16 * sizeof(float) + list_bytes, st, n, d, X, ldx, q_begin,
-                       q_end, k, lds_list, out_idx, out_dist);
+  case DCH:                                                                                          \
+    hipLaunchKernelGGL(knn_sreg_kernel<DCH>, grid, block, list_bytes, st, n, Xp, q_begin, q_end, k, lds_list, k_idx, \
+                       k_dist);                                                                      \
+    break
+  // the query row is held in registers, padded to a multiple of 4 features (zero padding adds exact zeros to the
+  // distance); one instantiation per padded width so that d = 50 does 52, not 64, features of work per pair
+  switch (dch) {
+    DH_KNN_SMALL(4); DH_KNN_SMALL(8); DH_KNN_SMALL(12); DH_KNN_SMALL(16); DH_KNN_SMALL(20); DH_KNN_SMALL(24);
+    DH_KNN_SMALL(28); DH_KNN_SMALL(32); DH_KNN_SMALL(36); DH_KNN_SMALL(40); DH_KNN_SMALL(44); DH_KNN_SMALL(48);
+    DH_KNN_SMALL(52); DH_KNN_SMALL(56); DH_KNN_SMALL(60); DH_KNN_SMALL(64);
+    default:
+      hipLaunchKernelGGL(knn_big_kernel, grid, block, 16 * 16 * sizeof(float) + list_bytes, st, n, d, X, ldx, q_begin,
+                         q_end, k, lds_list, k_idx, k_dist);
+  }
 #undef DH_KNN_SMALL
+  if (P > 1)
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)dh::ceil_div(nq, 256)), dim3(256), 0, st, nq, k, P, k_idx, k_dist, out_idx, out_dist);
   return dh::check_launch("dh_knn_bruteforce_f32");
 }

@@ -232,8 +232,10 @@ def knn(X: torch.Tensor, k: int, q_begin: int = 0, q_end: Optional[int] = None) 
     nq = q_end - q_begin
     idx = torch.empty((nq, k), dtype=torch.int32, device=X.device)
     dist = torch.empty((nq, k), dtype=torch.float32, device=X.device)
+    ws_bytes = lib.dh_knn_bruteforce_f32_workspace_bytes(n, d, nq, k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=X.device)
     _call("knn_bruteforce_f32", lib.dh_knn_bruteforce_f32, n, d, _dev(X, torch.float32, "X", 2), _ld(X), q_begin,
-          q_end, k, idx.data_ptr(), dist.data_ptr(), _stream())
+          q_end, k, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
     return idx, dist
 
 

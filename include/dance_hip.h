@@ -147,10 +147,14 @@ DH_API int dh_rank_rows_f32(int64_t n, int64_t d, const float* X, int64_t ldx, f
  * out_dist = sqrt(d2).  Fewer than k points: remaining slots get index -1, distance +inf.
  * Replaces sklearn NearestNeighbors.kneighbors at dance/transforms/graph/heteronet_graph.py:36-37,
  * dance/transforms/graph/spatial_graph.py:147-149 and the kNN stage of sc.pp.neighbors
- * (dance/transforms/graph/neighbor_graph.py:52).  out_idx/out_dist are [(q_end-q_begin), k].    */
+ * (dance/transforms/graph/neighbor_graph.py:52).  out_idx/out_dist are [(q_end-q_begin), k].
+ * Few queries (< 262k): the candidates are scanned in slices by several blocks per query group and the
+ * partial lists merged (same (d2, index) order); workspace from dh_knn_bruteforce_f32_workspace_bytes.  */
+DH_API size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k);
 DH_API int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx,
                           int64_t q_begin, int64_t q_end, int k,
-                          int32_t* out_idx, float* out_dist, dh_stream_t stream);
+                          int32_t* out_idx, float* out_dist,
+                          void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 /* ---- K8: UMAP fuzzy-simplicial-set connectivities on a kNN list ------------------------------
  * What sc.pp.neighbors(method="umap") computes after its kNN search (neighbor_graph.py:52-55;

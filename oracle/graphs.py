@@ -13,7 +13,7 @@ MIN_K_DIST_SCALE = 1e-3
 
 
 # ---- exact kNN -----------------------------------------------------------------------------------------------
-def knn_exact(x, k, chunk=512):
+def knn_exact(x, k, chunk=512, q_begin=0, q_end=None):
     """k nearest rows (self included) by (d2, index), d2 accumulated in f32 in feature order with separately
     rounded subtract / multiply / add — the bit-level definition shared with dh_knn_bruteforce_f32.
     Stands in for sklearn NearestNeighbors(n_neighbors=k).kneighbors (heteronet_graph.py:36-37,
@@ -21,10 +21,11 @@ def knn_exact(x, k, chunk=512):
     x = np.ascontiguousarray(x, dtype=np.float32)
     n, d = x.shape
     kk = min(k, n)
+    q_end = n if q_end is None else q_end
     idx = np.full((n, k), -1, dtype=np.int32)
     dist = np.full((n, k), np.inf, dtype=np.float32)
-    for q0 in range(0, n, chunk):
-        q1 = min(n, q0 + chunk)
+    for q0 in range(q_begin, q_end, chunk):
+        q1 = min(q_end, q0 + chunk)
         acc = np.zeros((q1 - q0, n), dtype=np.float32)
         for t in range(d):
             diff = x[q0:q1, t, None] - x[None, :, t]
@@ -32,7 +33,7 @@ def knn_exact(x, k, chunk=512):
         order = np.argsort(acc, axis=1, kind="stable")[:, :kk]  # stable: ties -> lower index
         idx[q0:q1, :kk] = order
         dist[q0:q1, :kk] = np.sqrt(np.take_along_axis(acc, order, axis=1))
-    return idx, dist
+    return idx[q_begin:q_end], dist[q_begin:q_end]
 
 
 # ---- UMAP connectivities (umap-learn, as called by scanpy 1.10.1 sc.pp.neighbors(method="umap")) -------------

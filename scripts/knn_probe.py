@@ -1,0 +1,10 @@
+"""kNN timing probe: python scripts/knn_probe.py  (GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dance_amd import kernels
+for n, d in [(100000, 50), (400000, 50), (100000, 16), (100000, 3), (50000, 2000), (20000, 50)]:
+    x = torch.randn(n, d, device="cuda")
+    kernels.knn(x, 15); torch.cuda.synchronize()
+    t = time.perf_counter(); kernels.knn(x, 15); torch.cuda.synchronize(); dt = time.perf_counter() - t
+    print(n, d, f"{dt*1e3:.1f} ms", f"{3*n*n*d/dt/1e12:.1f} Tops", flush=True)

@@ -75,6 +75,20 @@ def test_knn_ties_and_query_range(cuda_device):
     assert np.array_equal(dist.cpu().numpy(), ref_dist[90:110])
 
 
+def test_knn_single_scan_and_sliced_agree(cuda_device):
+    """>= 262144 queries run one scan per query; fewer queries slice the candidates and merge — same answer."""
+    from dance_amd import kernels
+    n, d, k = 270_000, 4, 5
+    x = np.random.default_rng(5).integers(-8, 8, size=(n, d)).astype(np.float32)  # many exact ties
+    xt = _t(x, cuda_device)
+    idx_all, dist_all = kernels.knn(xt, k)                    # single scan
+    idx_rng, dist_rng = kernels.knn(xt, k, 1000, 1512)        # 64 candidate slices + merge
+    ref_idx, ref_dist = og.knn_exact(x, k, q_begin=1000, q_end=1512)
+    assert np.array_equal(idx_rng.cpu().numpy(), ref_idx) and np.array_equal(dist_rng.cpu().numpy(), ref_dist)
+    assert np.array_equal(idx_all[1000:1512].cpu().numpy(), ref_idx)
+    assert np.array_equal(dist_all[1000:1512].cpu().numpy(), ref_dist)
+
+
 # ---- A11 UMAP connectivities ---------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,k", [(1500, 10, 15), (600, 50, 15), (300, 3, 6), (400, 20, 50)])
 def test_neighbor_graph_connectivities(cuda_device, n, d, k):
