@@ -1,0 +1,64 @@
+"""RCCL smoke on the one GPU a gpurun box has: a world-size-1 "nccl" group exercises every collective the sharded
+layer issues (dance_amd/sharding.py) with device tensors of the shapes it uses — API misuse (non-contiguous buffers,
+wrong split sizes, dtype) fails here instead of on the 8-GPU node.  The numerics of the sharded layer for world > 1
+are covered on CPU by tests/test_sharding_gloo.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def nccl_world1(cuda_device):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=cuda_device)
+    yield cuda_device
+    dist.destroy_process_group()
+
+
+def test_collectives_and_sharded_layer_world1(nccl_world1):
+    from dance_amd import autograd, sharding
+    from dance_amd.graph import CSRGraph
+    dev = nccl_world1
+    n, f, h, k = 3000, 96, 256, 7
+    g = torch.Generator(device="cpu").manual_seed(0)
+    col = torch.randint(0, n, (n, k), generator=g).sort(dim=1).values.reshape(-1).to(torch.int32).to(dev)
+    rowptr = (torch.arange(n + 1, dtype=torch.int32) * k).to(dev)
+    val = torch.rand(n * k, generator=g).to(dev)
+    graph = CSRGraph(rowptr, col, val, n, n)
+    x = torch.randn(n, f, generator=g).to(dev)
+    w = (torch.randn(f, h, generator=g) * 0.1).to(dev).requires_grad_(True)
+    dy = torch.randn(n, h, generator=g).to(dev)
+
+    y_ref = autograd.gcn_layer(x, w, graph, None, True)
+    y_ref.backward(dy)
+    dw_ref = w.grad.clone()
+
+    for mode in ("allgather", "alltoall"):
+        sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
+        assert sg.world == 1
+        # the raw exchanges on device buffers
+        s = torch.randn(n, h, device=dev)
+        cols = sg.rows_to_columns(s)                       # all_to_all_single
+        assert torch.equal(sg.columns_to_rows(cols, n), s)
+        out = torch.empty((sg.world * sg.chunk, h), device=dev)
+        dist.all_gather_into_tensor(out, s.contiguous())   # what all_gather_rows issues for world > 1
+        assert torch.equal(out[:n], s)
+        t = s[:4].clone()
+        assert torch.equal(sg.all_reduce_sum(t), s[:4])
+        # the sharded autograd function itself (collective branches are skipped at world 1, kernels are not)
+        w.grad = None
+        y = sharding._ShardedGCNLayerFn.apply(x, w, None, sg, True, sharding._hip_kernels)
+        y.backward(dy)
+        assert torch.equal(y, y_ref)
+        assert np.allclose(w.grad.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    dist.barrier()
+    torch.cuda.synchronize()
