@@ -50,6 +50,12 @@ def _declare(lib):
         "dh_exclusive_scan_i32": (c_int, [i64, P, P, P, c_size_t, P]),
         "dh_csr_row_normalize_f32": (c_int, [i64, P, P, P, P]),
         "dh_cellgene_graph_assemble": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, P, P, P, P]),
+        "dh_spmm_csr_bf16": (c_int, [i64, i64, i64, P, P, P, P, P, P, i64, P, i64, i32, P, i32, i32, P]),
+        "dh_sage_aggregate_bf16": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, P, i64, P, i64, i32, P]),
+        "dh_gemm_bf16_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
+        "dh_gemm_bf16": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, i32, i32, P, c_size_t, P]),
+        "dh_relu_backward_bf16": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
+        "dh_colsum_bf16": (c_int, [i64, i64, P, i64, P, P, c_size_t, P]),
         "dh_sage_aggregate_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, P, i64, P, i64, P]),
         "dh_sage_alpha_grad_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, P]),
     }

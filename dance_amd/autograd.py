@@ -127,35 +127,64 @@ def dense_adj_layer(x, weight, adj, bias=None):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x W^T + b (torch.nn.Linear semantics) on the f32 matrix cores."""
+    """y = act(x W^T + b) (torch.nn.Linear semantics, optional fused ReLU) on the matrix cores.
+
+    fp32 input: dh_gemm_f32 (exact fp32 MFMA) + dh_bias_act_f32.  bf16 input (config C3): dh_gemm_bf16 with the bias /
+    ReLU epilogue fused; W (an fp32 master parameter) is rounded to bf16 for the products, dW / db come back in fp32."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu, out_dtype):
         x = x.contiguous()
-        w = weight.contiguous()
-        y = kernels.gemm(x, w, trans_b=True)
-        if bias is not None:
-            kernels.bias_act_(y, bias)
-        ctx.has_bias = bias is not None
-        ctx.save_for_backward(x, w)
+        act = kernels.ACT_RELU if relu else kernels.ACT_NONE
+        if x.dtype == torch.bfloat16:
+            w = weight.detach().to(torch.bfloat16).contiguous()
+            y = kernels.gemm_bf16(x, w, trans_b=True, bias=None if bias is None else bias.detach().float(), act=act,
+                                  out_dtype=out_dtype or torch.bfloat16)
+        else:
+            w = weight.contiguous()
+            y = kernels.gemm(x, w, trans_b=True)
+            if bias is not None or relu:
+                kernels.bias_act_(y, bias, act)
+        ctx.has_bias, ctx.relu = bias is not None, relu
+        ctx.save_for_backward(x, w, y if relu else None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = kernels.gemm(dy, w) if ctx.needs_input_grad[0] else None
-        dw = kernels.gemm(dy, x, trans_a=True) if ctx.needs_input_grad[1] else None
-        db = kernels.colsum(dy) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        dx = dw = db = None
+        if x.dtype == torch.bfloat16:
+            g = dy.to(torch.bfloat16)
+            if ctx.relu:
+                g = kernels.relu_backward_bf16(y if y.dtype == torch.bfloat16 else y.to(torch.bfloat16), g)
+            if ctx.needs_input_grad[0]:
+                dx = kernels.gemm_bf16(g, w)
+            if ctx.needs_input_grad[1]:
+                dw = kernels.gemm_bf16(g, x, trans_a=True, out_dtype=torch.float32)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = kernels.colsum_bf16(g)
+        else:
+            g = kernels.relu_backward(y, dy) if ctx.relu else dy
+            if ctx.needs_input_grad[0]:
+                dx = kernels.gemm(g, w)
+            if ctx.needs_input_grad[1]:
+                dw = kernels.gemm(g, x, trans_a=True)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = kernels.colsum(g)
+        return dx, dw, db, None, None
 
 
-def linear(x, weight, bias=None):
-    return _LinearFn.apply(x, weight, bias)
+def linear(x, weight, bias=None, *, relu: bool = False, out_dtype=None):
+    return _LinearFn.apply(x, weight, bias, relu, out_dtype)
 
 
 class HipLinear(torch.nn.Linear):
-    """``nn.Linear`` (same parameters / state_dict) whose forward and backward run on dh_gemm_f32."""
+    """``nn.Linear`` (same parameters / state_dict) whose forward and backward run on dh_gemm_f32, or on
+    dh_gemm_bf16 when the input is a bf16 tensor.  ``fuse_relu`` folds a following ``nn.ReLU`` into the epilogue;
+    ``out_dtype`` (bf16 inputs only) selects fp32 output, e.g. for the logits of the last layer."""
 
-    def forward(self, input):
-        return linear(input, self.weight, self.bias)
+    out_dtype = None
+
+    def forward(self, input, fuse_relu: bool = False):
+        return linear(input, self.weight, self.bias, relu=fuse_relu, out_dtype=self.out_dtype)

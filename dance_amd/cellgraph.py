@@ -89,6 +89,10 @@ class CellGeneGraph:
                           {k: v.to(device) for k, v in self.ndata.items()})
         return g
 
+    def with_ndata(self, **updates) -> "CellGeneGraph":
+        """Shallow copy (same structure tensors) with some node-data entries replaced."""
+        return CellGeneGraph(self.rowptr, self.col, self.val, self.eid, self._n_nodes, {**self.ndata, **updates})
+
     def local_scope(self):
         import contextlib
         return contextlib.nullcontext()

@@ -208,6 +208,94 @@ def colsum(X: torch.Tensor) -> torch.Tensor:
     return out
 
 
+# ---- bf16 storage path (config C3) ----------------------------------------------------------------------------
+DTYPE_F32, DTYPE_BF16 = 0, 1
+_BF16 = torch.bfloat16
+
+
+def _out_dtype(dtype) -> int:
+    if dtype == torch.float32:
+        return DTYPE_F32
+    if dtype == _BF16:
+        return DTYPE_BF16
+    raise TypeError(f"output dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+
+
+def spmm_csr_bf16(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], Z: torch.Tensor, *,
+                  n_cols: Optional[int] = None, rowscale: Optional[torch.Tensor] = None,
+                  colscale: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                  reduce: int = REDUCE_SUM, out_dtype=_BF16, tag: str = "spmm_csr_bf16") -> torch.Tensor:
+    """dh_spmm_csr_bf16: bf16 gathered operand, fp32 accumulation, fp32 or bf16 output."""
+    lib = _lib_ready()
+    n_rows, width = rowptr.numel() - 1, Z.shape[1]
+    n_cols = Z.shape[0] if n_cols is None else n_cols
+    out = torch.empty((n_rows, width), dtype=out_dtype, device=Z.device)
+    _call(tag, lib.dh_spmm_csr_bf16, n_rows, n_cols, width, _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
+          _dev(rowscale, torch.float32, "rowscale", 1), _dev(colscale, torch.float32, "colscale", 1),
+          _dev(Z, _BF16, "Z", 2), _ld(Z), out.data_ptr(), _ld(out), _out_dtype(out_dtype),
+          _dev(bias, torch.float32, "bias", 1), act, reduce, _stream())
+    return out
+
+
+def sage_aggregate_bf16(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, *, out_dtype=_BF16) -> torch.Tensor:
+    """dh_sage_aggregate_bf16: AdaptiveSAGE weighted mean over bf16 node features."""
+    lib = _lib_ready()
+    n_dst, n_src, width = rowptr.numel() - 1, H.shape[0], H.shape[1]
+    out = torch.empty((n_dst, width), dtype=out_dtype, device=H.device)
+    _call("sage_aggregate_bf16", lib.dh_sage_aggregate_bf16, n_dst, n_src, width, alpha.numel() - 2,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
+          _dev(src_cell_id, torch.int32, "src_cell_id", 1), _dev(dst_cell_id, torch.int32, "dst_cell_id", 1),
+          _dev(alpha.reshape(-1), torch.float32, "alpha", 1), _dev(H, _BF16, "H", 2), _ld(H), out.data_ptr(),
+          _ld(out), _out_dtype(out_dtype), _stream())
+    return out
+
+
+def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
+              bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, out: Optional[torch.Tensor] = None,
+              out_dtype=_BF16, accumulate: bool = False, tag: Optional[str] = None) -> torch.Tensor:
+    """C (+)= act(op(A) @ op(B) + bias) on the bf16 matrix cores, fp32 accumulation; see dh_gemm_bf16."""
+    lib = _lib_ready()
+    M = A.shape[1] if trans_a else A.shape[0]
+    K = A.shape[0] if trans_a else A.shape[1]
+    Kb = B.shape[1] if trans_b else B.shape[0]
+    N = B.shape[0] if trans_b else B.shape[1]
+    if K != Kb:
+        raise ValueError(f"gemm_bf16: inner dimensions differ ({K} vs {Kb})")
+    if out is None:
+        if accumulate:
+            raise ValueError("gemm_bf16: accumulate=True needs an `out` tensor")
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    ws_bytes = lib.dh_gemm_bf16_workspace_bytes(M, N, K, int(trans_a), int(trans_b))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None
+    tag = tag or f"gemm_bf16_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
+    _call(tag, lib.dh_gemm_bf16, M, N, K, int(trans_a), int(trans_b), _dev(A, _BF16, "A", 2), _ld(A),
+          _dev(B, _BF16, "B", 2), _ld(B), _dev(out, out.dtype, "out", 2), _ld(out), _out_dtype(out.dtype),
+          _dev(bias, torch.float32, "bias", 1), act, int(accumulate), None if ws is None else ws.data_ptr(), ws_bytes,
+          _stream())
+    return out
+
+
+def relu_backward_bf16(Y: torch.Tensor, dY: torch.Tensor) -> torch.Tensor:
+    """G = dY * (Y > 0) on bf16 tensors."""
+    lib = _lib_ready()
+    G = torch.empty(Y.shape, dtype=_BF16, device=Y.device)
+    _call("relu_backward_bf16", lib.dh_relu_backward_bf16, Y.shape[0], Y.shape[1], _dev(Y, _BF16, "Y", 2), _ld(Y),
+          _dev(dY, _BF16, "dY", 2), _ld(dY), G.data_ptr(), _ld(G), _stream())
+    return G
+
+
+def colsum_bf16(X: torch.Tensor) -> torch.Tensor:
+    """out[j] = sum_i X[i, j] of a bf16 matrix, accumulated and returned in fp32."""
+    lib = _lib_ready()
+    out = torch.empty(X.shape[1], dtype=torch.float32, device=X.device)
+    ws_bytes = lib.dh_colsum_f32_workspace_bytes(X.shape[0], X.shape[1])
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=X.device)
+    _call("colsum_bf16", lib.dh_colsum_bf16, X.shape[0], X.shape[1], _dev(X, _BF16, "X", 2), _ld(X), out.data_ptr(),
+          ws.data_ptr(), ws_bytes, _stream())
+    return out
+
+
 # ---- graph builders ----------------------------------------------------------------------------------------
 def pairwise_distance(X: torch.Tensor, metric: int = METRIC_EUCLIDEAN) -> torch.Tensor:
     """Dense [n, n] f32 distance matrix (dh_pairwise_distance_f32); spearman ranks the rows on the device first."""

@@ -23,8 +23,11 @@ from ...base import BaseClassificationMethod
 class GNN(nn.Module):
 
     def __init__(self, dim_in: int, dim_out: int, dim_hid: int, n_layers: int, gene_num: int, activation=None, norm=None,
-                 dropout: float = 0.):
+                 dropout: float = 0., *, compute_dtype: str = "fp32"):
         super().__init__()
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        self.compute_dtype = compute_dtype
         self.n_layers = n_layers
         self.gene_num = gene_num
         # [gene_num] is alpha of gene-gene self loop, [gene_num+1] is alpha of cell-cell self loop, the rest are betas
@@ -36,10 +39,13 @@ class GNN(nn.Module):
         for i in range(n_layers):
             self.layers.append(AdaptiveSAGE(dim_in if i == 0 else dim_hid, dim_hid, self.alpha, dropout_layer, act_layer, norm_layer))
         self.linear = HipLinear(dim_hid, dim_out)
+        self.linear.out_dtype = torch.float32  # logits leave the bf16 path in fp32 (no effect on fp32 inputs)
         nn.init.xavier_uniform_(self.linear.weight, gain=nn.init.calculate_gain("relu"))
 
     def forward(self, blocks, x):
         assert len(blocks) == len(self.layers), f"Inonsistent layer info: {len(blocks)=} vs {len(self.layers)=}"
+        if self.compute_dtype == "bf16" and x.dtype != torch.bfloat16:
+            x = x.to(torch.bfloat16)  # bf16 storage of node features and activations
         for block, layer in zip(blocks, self.layers):
             x = layer(block, x)
         return self.linear(x)
@@ -48,7 +54,15 @@ class GNN(nn.Module):
 class ScDeepSort(BaseClassificationMethod):
 
     def __init__(self, dim_in: int, dim_hid: int, num_layers: int, species: str, tissue: str, *, dropout: int = 0,
-                 batch_size: int = 500, device: str = "cuda", save_root=None, verbose: bool = True):
+                 batch_size: int = 500, device: str = "cuda", save_root=None, verbose: bool = True,
+                 compute_dtype: str = "fp32"):
+        # compute_dtype="bf16" (not in the reference, which is fp32 only): node features / activations are stored as
+        # bf16 and the dense updates run on the bf16 matrix cores with fp32 accumulation (BASELINE.json config 3)
+        if compute_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'fp32' or 'bf16', got {compute_dtype!r}")
+        if compute_dtype == "bf16" and (dim_in % 8 or dim_hid % 8):
+            raise ValueError("compute_dtype='bf16' needs dim_in and dim_hid to be multiples of 8 (16-byte bf16 rows)")
+        self.compute_dtype = compute_dtype
         self.dense_dim = dim_in
         self.hidden_dim = dim_hid
         self.n_layers = num_layers
@@ -73,6 +87,13 @@ class ScDeepSort(BaseClassificationMethod):
             log_level=log_level,
         )
 
+    def _typed(self, graph):
+        """bf16 mode: a shallow copy of the device graph whose ``features`` are stored once as bf16 (the caller's
+        graph keeps its fp32 features)."""
+        if self.compute_dtype != "bf16" or graph.ndata["features"].dtype == torch.bfloat16:
+            return graph
+        return graph.with_ndata(features=graph.ndata["features"].to(torch.bfloat16))
+
     def _print(self, *a):
         if self.verbose:
             print(*a)
@@ -96,8 +117,9 @@ class ScDeepSort(BaseClassificationMethod):
         graph = graph.to(self.device)
         graph.ndata["label"] = full_labels.to(self.device)
 
+        graph = self._typed(graph)
         self.model = GNN(self.dense_dim, self.num_labels, self.hidden_dim, self.n_layers, num_genes, activation=nn.ReLU(),
-                         dropout=self.dropout).to(self.device)
+                         dropout=self.dropout, compute_dtype=self.compute_dtype).to(self.device)
         self.sampler = NeighborSampler(fanouts=[-1] * self.n_layers, edge_dir="in")
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         self.loss_fn = nn.CrossEntropyLoss(reduction="sum")
@@ -168,7 +190,7 @@ class ScDeepSort(BaseClassificationMethod):
         self.model.eval()
         cell_mask = (graph.ndata["cell_id"] == -1).cpu()
         idx = torch.where(cell_mask)[0]
-        graph = graph.to(self.device)
+        graph = self._typed(graph.to(self.device))
         logits = torch.zeros(graph.number_of_nodes(), self.num_labels)
         dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size)
         for _, output_nodes, blocks in dataloader:

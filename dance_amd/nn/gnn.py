@@ -22,7 +22,8 @@ class _SageAggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, alpha, block):
         cid_src, cid_dst = block.srcdata["cell_id"], block.dstdata["cell_id"]
-        neigh = kernels.sage_aggregate(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha, h.contiguous())
+        agg = kernels.sage_aggregate_bf16 if h.dtype == torch.bfloat16 else kernels.sage_aggregate  # C3: bf16 storage
+        neigh = agg(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous())
         ctx.block = block
         ctx.save_for_backward(h, alpha)
         return neigh
@@ -35,9 +36,10 @@ class _SageAggregateFn(torch.autograd.Function):
         dneigh = dneigh.contiguous()
         n_genes = alpha.numel() - 2
         dalpha = dh = None
-        if ctx.needs_input_grad[1]:
-            dalpha = kernels.sage_alpha_grad(blk.rowptr, blk.col, blk.val, cid_src, cid_dst, n_genes, h.contiguous(),
-                                             dneigh).reshape(alpha.shape)
+        bf16 = h.dtype == torch.bfloat16
+        if ctx.needs_input_grad[1]:  # per-edge dot products in fp32 (bf16 features are widened for this pass)
+            dalpha = kernels.sage_alpha_grad(blk.rowptr, blk.col, blk.val, cid_src, cid_dst, n_genes,
+                                             h.float().contiguous(), dneigh.float()).reshape(alpha.shape)
         if ctx.needs_input_grad[0]:
             # dh[u] = sum_{e=(u->v)} alpha[idx(e)] w_e / deg(v) * dneigh[v]: gather over the transposed block
             deg = (blk.rowptr[1:] - blk.rowptr[:-1]).to(torch.float32).clamp(min=1)
@@ -51,7 +53,10 @@ class _SageAggregateFn(torch.autograd.Function):
             ew = (alpha.reshape(-1)[idx] * blk.val / deg[rows]).contiguous()
             rp_t, col_t, val_t, _ = kernels.csr_transpose(blk.rowptr, blk.col, ew, blk.number_of_dst_nodes(),
                                                           blk.number_of_src_nodes())
-            dh = kernels.spmm_csr(rp_t, col_t, val_t, dneigh, n_cols=blk.number_of_dst_nodes())
+            if bf16:
+                dh = kernels.spmm_csr_bf16(rp_t, col_t, val_t, dneigh.to(torch.bfloat16), n_cols=blk.number_of_dst_nodes())
+            else:
+                dh = kernels.spmm_csr(rp_t, col_t, val_t, dneigh, n_cols=blk.number_of_dst_nodes())
         return dh, dalpha, None
 
 
@@ -88,6 +93,10 @@ class AdaptiveSAGE(nn.Module):
                 with torch.no_grad():  # computed and dropped, exactly like the reference (gnn.py:90-92)
                     self.last_neigh = self.aggregate(block, h.detach())
             z = h_dst
-        for layer in self.layers:
-            z = layer(z)
-        return z
+        dropout, lin, act, norm = self.layers
+        z = dropout(z)
+        if type(act) is nn.ReLU:  # the reference's configuration (scdeepsort.py:160): ReLU rides the GEMM epilogue
+            z = lin(z, fuse_relu=True)
+        else:
+            z = act(lin(z))
+        return norm(z)

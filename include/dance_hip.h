@@ -47,6 +47,7 @@ enum dh_status {
 
 enum dh_act { DH_ACT_NONE = 0, DH_ACT_RELU = 1 };
 enum dh_reduce { DH_REDUCE_SUM = 0, DH_REDUCE_MEAN = 1 };
+enum dh_dtype { DH_DTYPE_F32 = 0, DH_DTYPE_BF16 = 1 };
 enum dh_metric { DH_METRIC_EUCLIDEAN = 0, DH_METRIC_PEARSON = 1, DH_METRIC_SPEARMAN = 2 };
 
 /* ---- library ---------------------------------------------------------------------------- */
@@ -223,6 +224,40 @@ DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, i
                            const int32_t* src_cell_id, const int32_t* dst_cell_id,
                            const float* H, int64_t ldh, const float* dneigh, int64_t ldn,
                            float* dalpha, dh_stream_t stream);
+
+/* ---- bf16 storage path (scDeepSort at 1M cells, "bf16 with MFMA dense update") --------
+ * Features, activations and their gradients are STORED as bf16 (uint16_t bit patterns, torch.bfloat16); every sum is
+ * accumulated in fp32 and rounded once (nearest-even) when the output dtype is DH_DTYPE_BF16.  The reference has no
+ * reduced-precision path (it is fp32 DGL/torch on CPU): parity is <= 1e-2 relative against the fp32 oracle
+ * evaluated on the same bf16-rounded inputs, and the fp32 entry points above remain the default.
+ * Rows must be multiples of 8 features and 16-byte aligned (one lane moves 8 bf16 per load).
+ *
+ * dh_spmm_csr_bf16 / dh_sage_aggregate_bf16: dh_spmm_csr_f32 / dh_sage_aggregate_f32 with a bf16 gathered operand —
+ *   the aggregation of gnn.py:62-90 and graphsc.py:462-465 at half the HBM bytes per neighbour row.
+ * dh_gemm_bf16: C = act(op(A) op(B) + bias) (+ C), bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16 —
+ *   nn.Linear of AdaptiveSAGE (gnn.py:56-58,93-94: x W^T + b, then the activation) and its two gradient products.
+ *   op(A) is [M,K] (stored [K,M] if trans_a), op(B) is [K,N] (stored [N,K] if trans_b); bias [N] fp32 or NULL.
+ * dh_relu_backward_bf16 / dh_colsum_bf16: G = dY * [Y > 0]; out[j] = sum_i X[i,j] in fp32 (workspace as
+ *   dh_colsum_f32_workspace_bytes).                                                                              */
+DH_API int dh_spmm_csr_bf16(int64_t n_rows, int64_t n_cols, int64_t width,
+                     const int32_t* rowptr, const int32_t* col, const float* val,
+                     const float* rowscale, const float* colscale,
+                     const uint16_t* Z, int64_t ldz, void* Y, int64_t ldy, int y_dtype,
+                     const float* bias, int act, int reduce, dh_stream_t stream);
+DH_API int dh_sage_aggregate_bf16(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
+                           const int32_t* rowptr, const int32_t* col, const float* w,
+                           const int32_t* src_cell_id, const int32_t* dst_cell_id,
+                           const float* alpha, const uint16_t* H, int64_t ldh,
+                           void* neigh, int64_t ldn, int neigh_dtype, dh_stream_t stream);
+DH_API size_t dh_gemm_bf16_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b);
+DH_API int dh_gemm_bf16(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
+                 const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
+                 void* C, int64_t ldc, int c_dtype, const float* bias, int act, int accumulate,
+                 void* workspace, size_t workspace_bytes, dh_stream_t stream);
+DH_API int dh_relu_backward_bf16(int64_t n_rows, int64_t width, const uint16_t* Y, int64_t ldy,
+                          const uint16_t* dY, int64_t lddy, uint16_t* G, int64_t ldg, dh_stream_t stream);
+DH_API int dh_colsum_bf16(int64_t n_rows, int64_t width, const uint16_t* X, int64_t ldx, float* out,
+                   void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 #ifdef __cplusplus
 }
