@@ -44,6 +44,7 @@ def cpu_s(fn, iters=1):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--skip-knn", action="store_true", help="skip the (seconds-long) kNN rows")
     args = ap.parse_args()
     q = args.quick
     from oracle import graphs as og
@@ -53,7 +54,7 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
 
     # ---- K8 exact kNN (A11/A12/A13) ------------------------------------------------------------------------
-    for n, d, k in ([(20_000, 50, 15)] if q else [(100_000, 50, 15), (1_000_000, 50, 15), (100_000, 2000, 15)]):
+    for n, d, k in ([] if args.skip_knn else [(20_000, 50, 15)] if q else [(100_000, 50, 15), (1_000_000, 50, 15), (100_000, 2000, 15)]):
         x = torch.randn(n, d, device=dev, generator=g)
         ms = gpu_ms(lambda: kernels.knn(x, k), iters=1, warm=1 if n <= 100_000 else 0)
         ops = 3.0 * n * n * d
@@ -128,7 +129,35 @@ def main():
     ms_all = gpu_ms(lambda: kernels.sage_aggregate(rowptr, gcol, gval, cid, cid, alpha, feats), iters=1)
     rows[f"sage_aggregate_f32 all nodes (gene rows gather {nnz} cell rows) cells={n_cells}"] = dict(
         ms=ms_all, note="dominated by the 2000 gene rows of ~1e5 in-edges each handled by one wavefront per row")
-    del feats, rowptr, gcol, gval, eid
+    # ---- config C3: the same aggregation and the dense update with bf16 storage ------------------------------
+    feats16 = feats.to(torch.bfloat16)
+    ms16 = gpu_ms(lambda: kernels.sage_aggregate_bf16(rp_cells, gcol, gval, cid, cid_cells, alpha, feats16), iters=3)
+    byt16 = e * 8.0 + 4.0 * (n_cells + 1) + n_genes * dfeat * 2.0 + n_cells * dfeat * 2.0
+    rows[f"sage_aggregate_bf16 cell<-gene full graph cells={n_cells} D={dfeat} edges={e}"] = dict(
+        ms=ms16, bound="hbm", achieved=byt16 / ms16 / 1e6, peak=HBM, unit="GB/s", frac=byt16 / ms16 / 1e6 / HBM,
+        cells_per_s=n_cells / ms16 * 1e3, l2_gather_GBs=e * dfeat * 2.0 / ms16 / 1e6)
+    PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
+    hid = 200
+    h16 = feats16[n_genes:]  # [n_cells, 400] cell rows
+    w16 = (torch.randn(hid, dfeat, device=dev, generator=g) / 20).to(torch.bfloat16)
+    bias = torch.zeros(hid, device=dev)
+    dy16 = torch.randn(n_cells, hid, device=dev, generator=g).to(torch.bfloat16)
+    for name, fn, flops in [
+        ("fwd  y = relu(h W^T + b)  [NT]", lambda: kernels.gemm_bf16(h16, w16, trans_b=True, bias=bias, act=kernels.ACT_RELU), 2.0 * n_cells * dfeat * hid),
+        ("bwd  dh = g W             [NN]", lambda: kernels.gemm_bf16(dy16, w16), 2.0 * n_cells * dfeat * hid),
+        ("bwd  dW = g^T h     [TN, split-K]", lambda: kernels.gemm_bf16(dy16, h16, trans_a=True, out_dtype=torch.float32), 2.0 * n_cells * dfeat * hid),
+    ]:
+        msg = gpu_ms(fn, iters=5, warm=2)
+        rows[f"gemm_bf16 dense update {name} M={n_cells} in={dfeat} out={hid}"] = dict(
+            ms=msg, bound="mfma", achieved=flops / msg / 1e9, peak=PEAK_BF16, unit="TFLOP/s", frac=flops / msg / 1e9 / PEAK_BF16,
+            hbm_GBs=(n_cells * (dfeat + hid) * 2.0) / msg / 1e6)
+    xb = torch.randn(n_cells, 2048, device=dev, generator=g).to(torch.bfloat16)
+    wb = torch.randn(512, 2048, device=dev, generator=g).to(torch.bfloat16)
+    msg = gpu_ms(lambda: kernels.gemm_bf16(xb, wb, trans_b=True), iters=5, warm=2)
+    fl = 2.0 * n_cells * 2048 * 512
+    rows[f"gemm_bf16 NT M={n_cells} K=2048 N=512 (kernel rate at a compute-heavy shape)"] = dict(
+        ms=msg, bound="mfma", achieved=fl / msg / 1e9, peak=PEAK_BF16, unit="TFLOP/s", frac=fl / msg / 1e9 / PEAK_BF16)
+    del feats, feats16, xb, wb, rowptr, gcol, gval, eid
 
     # ---- SpaGCN-shape layer 50 -> 50 with bias, k = 15 -----------------------------------------------------
     from dance_amd.autograd import gcn_layer
