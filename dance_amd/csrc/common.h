@@ -25,12 +25,10 @@ inline hipStream_t as_stream(dh_stream_t s) { return reinterpret_cast<hipStream_
 
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
-// gemm_skinny.hip: narrow-layer (K, N <= 64) GEMM forms used by dh_gemm_f32
+// gemm_skinny.hip: narrow-layer (K, N <= 64, many rows) GEMM used by dh_gemm_f32
 bool skinny_applies(int64_t M, int64_t N, int64_t K, int trans_a);
-size_t skinny_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a);
-int skinny_slab_count(int64_t K);
-int skinny_launch(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda, const float* B,
-                  int64_t ldb, float* C, int64_t ldc, int accumulate, float* slabs, hipStream_t st);
+int skinny_launch(int64_t M, int64_t N, int64_t K, int trans_b, const float* A, int64_t lda, const float* B, int64_t ldb,
+                  float* C, int64_t ldc, int accumulate, hipStream_t st);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

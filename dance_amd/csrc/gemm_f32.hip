@@ -388,11 +388,7 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
   // rounds of the 256 CUs — floor(1024 / tiles) slices: at most 4 full rounds, the last one >= 98 % full —
   // keeping at least 64 K-steps per block.  Measured at 2000 x 512 x 1M: 1024 blocks 138 TFLOP/s, 4096 blocks 135.
   if (p.n_tiles < 512 && K >= 4096) {
-    static const int64_t target_blocks = [] {  // tuning knob for experiments
-      const char* e = getenv("DH_GEMM_SPLITK_BLOCKS");
-      return e ? (int64_t)atoll(e) : (int64_t)1024;
-    }();
-    int64_t want = target_blocks / p.n_tiles;
+    int64_t want = 1024 / p.n_tiles;
     if (want < 1) want = 1;
     int64_t max_s = K / (64 * BK);
     if (max_s < 1) max_s = 1;
@@ -409,9 +405,7 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
 // fill the chip; smaller problems use 128x128 tiles.
 Plan make_plan(int64_t M, int64_t N, int64_t K) {
   Plan big = plan_for(M, N, K, CfgLarge::BM, CfgLarge::BN);
-#ifndef DH_GEMM_FORCE_SMALL  // (A/B experiment builds only)
   if ((int64_t)big.n_tiles * big.S >= 512) return big;
-#endif
   return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
 }
 
@@ -420,7 +414,7 @@ Plan make_plan(int64_t M, int64_t N, int64_t K) {
 extern "C" size_t dh_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b) {
   (void)trans_a; (void)trans_b;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (dh::skinny_applies(M, N, K, trans_a)) return dh::skinny_workspace_bytes(M, N, K, trans_a);
+  if (dh::skinny_applies(M, N, K, trans_a)) return 0;
   Plan p = make_plan(M, N, K);
   return p.S > 1 ? (size_t)p.S * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
@@ -435,17 +429,8 @@ extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int tra
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N)
     return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: leading dimension too small");
   hipStream_t st = dh::as_stream(stream);
-  if (K > 0 && dh::skinny_applies(M, N, K, trans_a)) {  // narrow layers: HBM-bound streaming kernels (gemm_skinny.hip)
-    const size_t need = dh::skinny_workspace_bytes(M, N, K, trans_a);
-    if (need && (!workspace || workspace_bytes < need))
-      return dh::fail(DH_ERR_WORKSPACE, "dh_gemm_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-    int rc = dh::skinny_launch(M, N, K, trans_a, trans_b, A, lda, B, ldb, C, ldc, accumulate, static_cast<float*>(workspace), st);
-    if (rc != DH_OK || !trans_a) return rc;
-    const int64_t total = M * N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)dh::ceil_div(total, 256)), dim3(256), 0, st, M, N,
-                       dh::skinny_slab_count(K), static_cast<const float*>(workspace), C, ldc, accumulate);
-    return dh::check_launch("dh_gemm_f32(narrow reduce, slabs)");
-  }
+  if (K > 0 && dh::skinny_applies(M, N, K, trans_a))  // narrow layers: HBM-bound streaming kernel (gemm_skinny.hip)
+    return dh::skinny_launch(M, N, K, trans_b, A, lda, B, ldb, C, ldc, accumulate, st);
   Plan p = make_plan(M, N, K);
   float* slabs = nullptr;
   if (p.S > 1) {
