@@ -163,8 +163,8 @@ __global__ __launch_bounds__(QB) void knn_small_kernel(int64_t n, int64_t d, con
 // (Scoring two candidates per lane with v_pk_add_f32 / v_pk_mul_f32 on a pair-interleaved copy was measured at the
 // same rate — packed f32 issues at half the rate of plain f32 on gfx950 — so the plain form is kept.)
 template <int DCH>
-__global__ __launch_bounds__(QB) void knn_sreg_kernel(int64_t n, const float* __restrict__ Xp, int64_t q_begin,
-                                                      int64_t q_end, int k, bool lds_list,
+__global__ __launch_bounds__(QB) void knn_sreg_kernel(int64_t n, const float* __restrict__ Xp, const float* __restrict__ Cp,
+                                                      int64_t q_begin, int64_t q_end, int k, bool lds_list, bool raw_d2,
                                                       int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
   const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
   const int64_t nq_all = q_end - q_begin;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(QB) void knn_sreg_kernel(int64_t n, const float* __
   float tau_d = __int_as_float(0x7f800000);
 
   for (int64_t c = cand_lo; c < cand_hi; ++c) {
-    const float* __restrict__ y = Xp + c * RS;  // wave-uniform address -> scalar loads
+    const float* __restrict__ y = Cp + c * RS;  // wave-uniform address -> scalar loads
     float acc = 0.f;
 #pragma unroll
     for (int t = 0; t < DCH; ++t) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(QB) void knn_sreg_kernel(int64_t n, const float* __
     const int idx = (int)c;
     if (valid && (cnt < k || before(acc, idx, tau_d, tau_i))) insert(L, k, cnt, tau_d, tau_i, tau_pos, acc, idx);
   }
-  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, gridDim.y > 1);
+  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, raw_d2 || gridDim.y > 1);
 }
 
 // Xp[r][0:RS] = X[r][0:d] followed by zeros (zero features add exact zeros to every distance)
@@ -220,8 +220,9 @@ __global__ __launch_bounds__(256) void knn_pad_kernel(int64_t n, int64_t d, cons
 
 // d > 64: features in chunks of 16; 16 candidates per tile with one register accumulator each.
 __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
-                                                     int64_t q_begin, int64_t q_end, int k, bool lds_list,
-                                                     int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+                                                     const float* __restrict__ C, int64_t ldc, int64_t q_begin, int64_t q_end,
+                                                     int k, bool lds_list, bool raw_d2, int32_t* __restrict__ out_idx,
+                                                     float* __restrict__ out_dist) {
   constexpr int CT = 16, DCH = 16;
   const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
   const int64_t nq_all = q_end - q_begin;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
       __syncthreads();
       {
         const int c = tid / DCH, t = tid % DCH;  // 256 threads == CT * DCH
-        cand[tid] = (c0 + c < cand_hi && t0 + t < d) ? X[(c0 + c) * ldx + t0 + t] : 0.f;
+        cand[tid] = (c0 + c < cand_hi && t0 + t < d) ? C[(c0 + c) * ldc + t0 + t] : 0.f;
       }
       float x[DCH];
 #pragma unroll
@@ -277,12 +278,12 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
         insert(L, k, cnt, tau_d, tau_i, tau_pos, acc[c], (int)ci);
     }
   }
-  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, gridDim.y > 1);
+  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, raw_d2 || gridDim.y > 1);
 }
 
 // Merge P partial (d2, idx) lists per query (each sorted ascending) into the final k smallest by (d2, idx): one
 // thread per query, P cursors, k selection steps — deterministic, the same order a single scan produces.
-__global__ __launch_bounds__(256) void knn_merge_kernel(int64_t nq, int k, int P, const int32_t* __restrict__ part_idx,
+__global__ __launch_bounds__(256) void knn_merge_kernel(int64_t nq, int k, int P, bool raw_d2, const int32_t* __restrict__ part_idx,
                                                         const float* __restrict__ part_d2, int32_t* __restrict__ out_idx,
                                                         float* __restrict__ out_dist) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(int64_t nq, int k, int P
       out_dist[q * k + s] = __int_as_float(0x7f800000);
     } else {
       out_idx[q * k + s] = bi;
-      out_dist[q * k + s] = (float)sqrt((double)bd);
+      out_dist[q * k + s] = raw_d2 ? bd : (float)sqrt((double)bd);
       ++cur[best];
     }
   }
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(int64_t nq, int k, int P
 }  // namespace
 
 namespace {
+
 // candidate slices per query block so that >= ~2048 blocks (8 per CU) are in flight; k <= 255 for the merge cursors
 int knn_slices(int64_t nq, int k) {
   const int64_t blocks = dh::ceil_div(nq, QB);
@@ -322,57 +324,69 @@ int knn_slices(int64_t nq, int k) {
   int64_t p = dh::ceil_div(2048, blocks);
   return (int)(p > 64 ? 64 : p);
 }
-}  // namespace
 
-namespace {
 int knn_padded_width(int64_t d) { return d <= 64 ? (int)((d + 3) / 4 * 4) : 0; }
-int knn_row_stride(int64_t d) { return knn_padded_width(d); }
-size_t knn_padded_bytes(int64_t n, int64_t d) { return (size_t)n * (size_t)knn_row_stride(d) * sizeof(float); }
-}  // namespace
+size_t round64(size_t b) { return (b + 63) / 64 * 64; }
 
-extern "C" size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k) {
-  (void)n; (void)d;
-  if (n_queries <= 0 || k <= 0) return 0;
-  const int P = knn_slices(n_queries, k);
-  const size_t part = P > 1 ? ((size_t)P * (size_t)n_queries * (size_t)k * 8 + 63) / 64 * 64 : 0;
-  return part + knn_padded_bytes(n, d);
+// Workspace carve-up shared by the size query and the launcher (offsets in bytes, every region 64-byte aligned).
+struct Layout {
+  int algo;                      // resolved: DH_KNN_SCAN or DH_KNN_FILTER
+  int P;                         // candidate slices of the scan (of the sample scan in filter mode)
+  int dch;                       // padded width of the register kernel (0: d > 64)
+  int64_t S;                     // sample size (filter)
+  int cap;                       // survivor list capacity per query (filter)
+  size_t partial, xp, xs, norms, rq, cn, a2, b2, counts, surv, total;
+};
+
+Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
+  Layout L{};
+  // auto: the filter pays off once the n x n pair count dwarfs its fixed passes; it needs k <= 64 (one carried key per lane)
+  if (algo == DH_KNN_AUTO) algo = (n >= 16384 && nq >= 1024 && k <= 64) ? DH_KNN_FILTER : DH_KNN_SCAN;
+  L.algo = algo;
+  L.dch = knn_padded_width(d);
+  L.P = knn_slices(nq, k);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += round64(bytes); return o; };
+  L.partial = take(L.P > 1 ? (size_t)L.P * nq * k * 8 : 0);
+  L.xp = take(L.dch ? (size_t)n * L.dch * sizeof(float) : 0);
+  if (algo == DH_KNN_FILTER) {
+    L.S = dh::knn_filter_sample_size(n);
+    int n_seg, seg;
+    dh::knn_filter_geometry(n, d, nq, k, &n_seg, &seg);
+    L.cap = n_seg * seg;
+    const size_t K3 = (size_t)dh::knn_filter_k3(d);
+    L.xs = take((size_t)L.S * (L.dch ? L.dch : d) * sizeof(float));
+    L.norms = take((size_t)n * sizeof(float));
+    L.rq = take((size_t)nq * sizeof(float));
+    L.cn = take((size_t)n * sizeof(float));
+    L.a2 = take((size_t)n * K3 * 2);
+    L.b2 = take((size_t)n * K3 * 2);
+    L.counts = take((size_t)nq * n_seg * sizeof(int32_t));
+    L.surv = take((size_t)nq * L.cap * sizeof(int32_t));
+  }
+  L.total = off;
+  return L;
 }
 
-extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx, int64_t q_begin,
-                                     int64_t q_end, int k, int32_t* out_idx, float* out_dist, void* workspace,
-                                     size_t workspace_bytes, dh_stream_t stream) {
-  if (n < 0 || d < 0 || k < 0) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: negative size");
-  if (q_begin < 0 || q_end > n || q_begin > q_end)
-    return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: bad query range [%lld, %lld)", (long long)q_begin, (long long)q_end);
-  if (q_end == q_begin || k == 0) return DH_OK;
-  if (!X || !out_idx || !out_dist) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: null pointer");
-  if (ldx < d) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: ldx < d");
-  if (n >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: n >= 2^31");
-  hipStream_t st = dh::as_stream(stream);
+// Exact scan of queries [q_begin, q_end) (rows of Q) against the n_cand rows of C.  For d <= 64, Q and C are the
+// zero-padded copies (row stride dch); otherwise plain matrices with their leading dimensions.
+void scan_launch(int64_t n_cand, int64_t d, int dch, const float* Q, int64_t ldq, const float* C, int64_t ldc, int64_t q_begin,
+                 int64_t q_end, int k, int P, bool raw_d2, void* partial, int32_t* out_idx, float* out_dist, hipStream_t st) {
   const int64_t nq = q_end - q_begin;
-  const int P = knn_slices(nq, k);
   int32_t* k_idx = out_idx;
   float* k_dist = out_dist;
-  const size_t part_bytes = P > 1 ? ((size_t)P * (size_t)nq * (size_t)k * 8 + 63) / 64 * 64 : 0;
-  const size_t need = part_bytes + knn_padded_bytes(n, d);
-  if (need && (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 63u)))
-    return dh::fail(DH_ERR_WORKSPACE, "dh_knn_bruteforce_f32: workspace %zu < %zu bytes", workspace_bytes, need);
   if (P > 1) {
-    k_idx = static_cast<int32_t*>(workspace);
+    k_idx = static_cast<int32_t*>(partial);
     k_dist = reinterpret_cast<float*>(k_idx + (size_t)P * nq * k);
   }
-  float* Xp = reinterpret_cast<float*>(static_cast<char*>(workspace) + part_bytes);  // 64-byte aligned rows
-  const int dch = knn_padded_width(d);
-  if (dch)
-    hipLaunchKernelGGL(knn_pad_kernel, dim3((unsigned)dh::ceil_div(n * knn_row_stride(d), 256)), dim3(256), 0, st, n, d, X, ldx, knn_row_stride(d), Xp);
-  // per-lane lists live in LDS only for the single-slice case with small k (partial lists go straight to memory)
+  // per-lane lists live in LDS for small k, otherwise in the output (or partial) arrays themselves
   const bool lds_list = k <= KLDS;
   const size_t list_bytes = lds_list ? (size_t)k * QB * 8 : 0;
   dim3 grid((unsigned)dh::ceil_div(nq, QB), (unsigned)P), block(QB);
-#define DH_KNN_SMALL(DCH)                                                                            \
-  case DCH:                                                                                          \
-    hipLaunchKernelGGL(knn_sreg_kernel<DCH>, grid, block, list_bytes, st, n, Xp, q_begin, q_end, k, lds_list, k_idx, \
-                       k_dist);                                                                      \
+#define DH_KNN_SMALL(DCH)                                                                                             \
+  case DCH:                                                                                                           \
+    hipLaunchKernelGGL(knn_sreg_kernel<DCH>, grid, block, list_bytes, st, n_cand, Q, C, q_begin, q_end, k, lds_list,  \
+                       raw_d2, k_idx, k_dist);                                                                        \
     break
   // the query row is held in registers, padded to a multiple of 4 features (zero padding adds exact zeros to the
   // distance); one instantiation per padded width so that d = 50 does 52, not 64, features of work per pair
@@ -381,11 +395,58 @@ extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64
     DH_KNN_SMALL(28); DH_KNN_SMALL(32); DH_KNN_SMALL(36); DH_KNN_SMALL(40); DH_KNN_SMALL(44); DH_KNN_SMALL(48);
     DH_KNN_SMALL(52); DH_KNN_SMALL(56); DH_KNN_SMALL(60); DH_KNN_SMALL(64);
     default:
-      hipLaunchKernelGGL(knn_big_kernel, grid, block, 16 * 16 * sizeof(float) + list_bytes, st, n, d, X, ldx, q_begin,
-                         q_end, k, lds_list, k_idx, k_dist);
+      hipLaunchKernelGGL(knn_big_kernel, grid, block, 16 * 16 * sizeof(float) + list_bytes, st, n_cand, d, Q, ldq, C, ldc,
+                         q_begin, q_end, k, lds_list, raw_d2, k_idx, k_dist);
   }
 #undef DH_KNN_SMALL
   if (P > 1)
-    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)dh::ceil_div(nq, 256)), dim3(256), 0, st, nq, k, P, k_idx, k_dist, out_idx, out_dist);
-  return dh::check_launch("dh_knn_bruteforce_f32");
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)dh::ceil_div(nq, 256)), dim3(256), 0, st, nq, k, P, raw_d2, k_idx, k_dist,
+                       out_idx, out_dist);
+}
+
+}  // namespace
+
+extern "C" size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k, int algo) {
+  if (n <= 0 || n_queries <= 0 || k <= 0) return 0;
+  return make_layout(n, d, n_queries, k, algo).total;
+}
+
+extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx, int64_t q_begin,
+                                     int64_t q_end, int k, int algo, int32_t* out_idx, float* out_dist, void* workspace,
+                                     size_t workspace_bytes, dh_stream_t stream) {
+  if (n < 0 || d < 0 || k < 0) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: negative size");
+  if (q_begin < 0 || q_end > n || q_begin > q_end)
+    return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: bad query range [%lld, %lld)", (long long)q_begin, (long long)q_end);
+  if (algo != DH_KNN_AUTO && algo != DH_KNN_SCAN && algo != DH_KNN_FILTER)
+    return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: bad algo %d", algo);
+  if (q_end == q_begin || k == 0) return DH_OK;
+  if (!X || !out_idx || !out_dist) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: null pointer");
+  if (ldx < d) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: ldx < d");
+  if (n >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: n >= 2^31");
+  if (algo == DH_KNN_FILTER && k > 64) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: the filter path needs k <= 64");
+  hipStream_t st = dh::as_stream(stream);
+  const int64_t nq = q_end - q_begin;
+  const Layout L = make_layout(n, d, nq, k, algo);
+  if (L.total && (!workspace || workspace_bytes < L.total || (reinterpret_cast<uintptr_t>(workspace) & 63u)))
+    return dh::fail(DH_ERR_WORKSPACE, "dh_knn_bruteforce_f32: workspace %zu < %zu bytes (or not 64-byte aligned)", workspace_bytes, L.total);
+  char* ws = static_cast<char*>(workspace);
+  float* Xp = reinterpret_cast<float*>(ws + L.xp);
+  if (L.dch)
+    hipLaunchKernelGGL(knn_pad_kernel, dim3((unsigned)dh::ceil_div(n * L.dch, 256)), dim3(256), 0, st, n, d, X, ldx, L.dch, Xp);
+  const float* Q = L.dch ? Xp : X;          // what the scan kernels read
+  const int64_t ldq = L.dch ? L.dch : ldx;
+  if (L.algo == DH_KNN_SCAN) {
+    scan_launch(n, d, L.dch, Q, ldq, Q, ldq, q_begin, q_end, k, L.P, false, ws + L.partial, out_idx, out_dist, st);
+    return dh::check_launch("dh_knn_bruteforce_f32");
+  }
+  // filter: (1) exact k-th distance inside a strided sample -> out_dist[:, k-1] (raw d2), (2) + (3) in knn_filter.hip
+  float* Xs = reinterpret_cast<float*>(ws + L.xs);
+  const int rs = L.dch ? L.dch : (int)d;
+  dh::knn_filter_sample(n, d, X, ldx, rs, Xs, st);
+  scan_launch(L.S, d, L.dch, Q, ldq, Xs, rs, q_begin, q_end, k, L.P, true, ws + L.partial, out_idx, out_dist, st);
+  return dh::knn_filter_launch(n, d, X, ldx, Q, ldq, L.dch ? L.dch : d, q_begin, nq, k, out_dist,
+                               reinterpret_cast<uint16_t*>(ws + L.a2), reinterpret_cast<uint16_t*>(ws + L.b2),
+                               reinterpret_cast<float*>(ws + L.norms), reinterpret_cast<float*>(ws + L.rq),
+                               reinterpret_cast<float*>(ws + L.cn), reinterpret_cast<int32_t*>(ws + L.counts),
+                               reinterpret_cast<int32_t*>(ws + L.surv), out_idx, out_dist, st);
 }

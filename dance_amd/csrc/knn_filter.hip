@@ -1,0 +1,435 @@
+// Matrix-core filter + exact re-rank for the brute-force kNN (dh_knn_bruteforce_f32, algo = DH_KNN_FILTER).
+//
+// The kNN result is DEFINED by the sequential fp32 distance chain of knn.hip (that is what makes index lists bit-exact
+// against the oracle), which costs 3 VALU ops per (pair, feature).  The matrix cores cannot evaluate that chain, but
+// they can discard almost every pair first:
+//
+//   1. tau_q  = exact k-th chain distance of query q inside a strided SAMPLE of S candidates (knn.hip scan).  The true
+//               k-th distance over all candidates can only be smaller, so every true neighbour c has d2(q,c) <= tau_q.
+//   2. filter = for all pairs, d2~(q,c) = |q|^2 + |c|^2 - 2 q.c on v_mfma_f32_32x32x16_bf16, with every fp32 feature
+//               split into two bf16 terms (x = hi + lo + r, |r| <= 2^-16 |x|) and q.c ~ hi.hi + hi.lo + lo.hi (one GEMM
+//               with K = 3 d).  |d2~ - d2| <= eps (|q|^2 + |c|^2) with eps = 2^-13 + d 2^-20 (derivation below), so the
+//               pairs with d2~ <= tau_q + eps (|q|^2 + |c|^2) are a superset of the true neighbours; they are appended
+//               to a per-query survivor list (~ k n / S entries).
+//   3. rerank = the exact chain on the survivors only, k smallest (d2, index) per query — the same keys, hence the same
+//               bits, as the full scan.  A query whose list overflowed re-scans all candidates inside the same kernel.
+//
+// Error budget of step 2 (u = 2^-24; all worst case, no statistics):
+//   representation: dropped lo.lo and r terms            <= 3.1 * 2^-16 sum|q_i c_i|
+//   MFMA accumulation over 3d bf16 products (exact each) <= 3d u (1 + 2^-7) sum|q_i c_i|
+//   fp32 norms, the final subtraction/addition            <= (d + 6) u (|q|^2 + |c|^2)
+//   the chain itself vs the real d2                       <= 2 (d + 2) u (|q|^2 + |c|^2)
+// with sum|q_i c_i| <= (|q|^2 + |c|^2) / 2 and the factor 2 in front of the dot product:
+//   |d2~ - d2_chain| <= (|q|^2 + |c|^2) (3.1 * 2^-16 + (6d + 10) u)  <  (|q|^2 + |c|^2) (2^-13 + d 2^-20) / 2.
+// Inputs must be finite.
+#include "gemm_bf16_tile.h"
+
+namespace {
+
+using namespace dh_bf16;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float widen(unsigned int h) { return __uint_as_float(h << 16); }
+
+// norms[r] = sum_t x[r][t]^2 (one wavefront per row); A2[r] = [hi | hi | lo | 0], B2[r] = [hi | lo | hi | 0], each part
+// dp wide, rows K3 = roundup(3 dp, 16) long
+__global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx, int dp,
+                                                        int64_t K3, uint16_t* __restrict__ A2, uint16_t* __restrict__ B2,
+                                                        float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float* x = X + r * ldx;
+  uint16_t* a = A2 + r * K3;
+  uint16_t* b = B2 + r * K3;
+  for (int t = 3 * dp + lane; t < K3; t += 64) a[t] = b[t] = 0;
+  float s = 0.f;
+  for (int t = lane; t < dp; t += 64) {
+    const float v = t < d ? x[t] : 0.f;
+    s = fmaf(v, v, s);
+    const unsigned int hi = f32_to_bf16(v);
+    const unsigned int lo = f32_to_bf16(v - widen(hi));  // exact subtraction: hi is v rounded to 8 bits
+    a[t] = (uint16_t)hi; a[dp + t] = (uint16_t)hi; a[2 * dp + t] = (uint16_t)lo;
+    b[t] = (uint16_t)hi; b[dp + t] = (uint16_t)lo; b[2 * dp + t] = (uint16_t)hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) norms[r] = s;
+}
+
+// The filter test  |q|^2 + |c|^2 - 2 dot <= tau + eps (|q|^2 + |c|^2)  rearranged so that the epilogue is one fma and
+// one compare per pair:   fma(-2, dot, Cn[c]) <= Rq[q],   Cn = (1 - eps) |c|^2,   Rq = tau - (1 - eps) |q|^2.
+// (eps carries a factor 2 of slack over the bound above, which also covers these few extra roundings.)
+__global__ __launch_bounds__(256) void knn_thresholds_kernel(int64_t n, int64_t q_begin, int64_t nq, int k, float eps,
+                                                             const float* __restrict__ norms, const float* __restrict__ sample_d2,
+                                                             float* __restrict__ Rq, float* __restrict__ Cn, int32_t* __restrict__ counts) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) Cn[i] = (1.f - eps) * norms[i];
+  if (i < nq) {
+    Rq[i] = sample_d2[i * k + (k - 1)] - (1.f - eps) * norms[q_begin + i];  // +inf when the sample held < k points
+    counts[i] = 0;
+  }
+}
+
+// grid.x = query tiles x candidate tiles (candidate tile fastest: consecutive blocks share the query tile)
+__global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, int64_t K3, const uint16_t* __restrict__ A2,
+                                                         const uint16_t* __restrict__ B2, const float* __restrict__ Rq,
+                                                         const float* __restrict__ Cn, int32_t* __restrict__ counts,
+                                                         int32_t* __restrict__ surv, int cap) {
+  __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDT];
+  __shared__ float rq[BM];
+  const int64_t tiles_n = (n + BN - 1) / BN;
+  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM, n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
+  if (threadIdx.x < BM) rq[threadIdx.x] = (m0 + threadIdx.x < nq) ? Rq[m0 + threadIdx.x] : -__int_as_float(0x7f800000);
+  // (visible after the barriers inside nt_tile)
+  const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+  float cn[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t c = n0 + wn * 64 + j * 32 + (lane & 31);
+    cn[j] = c < n ? Cn[c] : 0.f;
+  }
+  nt_tile(nq, n, 0, K3, A2, K3, B2, K3, m0, n0, As, Bs, [&](int64_t m, int64_t c, float dot) {
+    const float cnj = ((c - n0 - wn * 64) >> 5) ? cn[1] : cn[0];
+    if (fmaf(-2.f, dot, cnj) <= rq[m - m0]) {
+      const int pos = atomicAdd(&counts[m], 1);
+      if (pos < cap) surv[m * cap + pos] = (int32_t)c;
+    }
+  });
+}
+
+// d <= 64 (K3 <= 192): "query-stationary" form of the same filter.  The tile kernel above re-reads both operands for
+// every 128 x 128 tile — 5.25 bytes of L2 traffic per pair at K3 = 168, which is what bounds it (counters: 4.6 TB/s
+// of L2 requests, matrix cores 13 % busy).  Here a block of 8 waves owns 256 queries for its whole life: each wave
+// keeps the MFMA A-fragments of its 64 queries (all of K3) in REGISTERS (thresholds in LDS), and the block only
+// streams 128-candidate tiles of B2 through a double-buffered LDS image (one barrier per tile) — 1.3 bytes per pair.
+template <int KS>  // 16-wide k steps: K3 = 16 KS
+__global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64_t n, const uint16_t* __restrict__ A2,
+                                                               const uint16_t* __restrict__ B2, const float* __restrict__ Rq,
+                                                               const float* __restrict__ Cn, int32_t* __restrict__ counts,
+                                                               int32_t* __restrict__ surv, int cap, int seg,
+                                                               int64_t tiles_per_slice) {
+  constexpr int K3 = 16 * KS;
+  constexpr int LD = K3 + 8;               // bf16 per LDS row: (LD / 2) % 8 == 4 -> conflict-free 16-byte fragment reads
+  constexpr int CPR = 2 * KS;              // 16-byte chunks per row
+  constexpr int NCH = (BN * CPR + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // 2 x [BN][LD]
+  __shared__ float rq_s[256];
+  __shared__ int cnt_s[256];  // survivors appended by THIS block per query: the block owns its 256 queries, so the
+                              // list cursors are LDS atomics (~100 cycles) instead of returning global atomics
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, kh = (lane >> 5) * 8;
+  const int64_t m0 = (int64_t)blockIdx.x * 256 + wr * 64;
+  const float ninf = -__int_as_float(0x7f800000);
+
+  if (tid < 256) {
+    rq_s[tid] = ((int64_t)blockIdx.x * 256 + tid < nq) ? Rq[(int64_t)blockIdx.x * 256 + tid] : ninf;
+    cnt_s[tid] = 0;
+  }
+  const float* rq = rq_s + wr * 64 + 4 * (lane >> 5);  // row (i, r) of this lane at rq[i * 32 + (r & 3) + 8 * (r >> 2)]
+  bf16x8 a[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int64_t row = m0 + i * 32 + lr;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      u32x4 v = u32x4(0u);
+      if (row < nq) v = *reinterpret_cast<const u32x4*>(A2 + row * K3 + kk * 16 + kh);
+      a[i][kk] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+
+  // (rows >= nq never pass the test: their threshold is -inf)
+  int* cnt = cnt_s + wr * 64 + 4 * (lane >> 5);
+  int32_t* surv_base = surv + (m0 + 4 * (lane >> 5)) * cap + (int64_t)blockIdx.y * seg;  // this slice's segment
+
+  const int64_t tiles_n = (n + BN - 1) / BN;
+  const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_slice, t_hi = min(tiles_n, t_lo + tiles_per_slice);
+  u32x4 stage[NCH];
+  auto load_tile = [&](int64_t t) {
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      const int c = tid + 512 * s;
+      const int64_t row = t * BN + c / CPR;
+      stage[s] = (c < BN * CPR && row < n) ? *reinterpret_cast<const u32x4*>(B2 + row * K3 + (c % CPR) * 8) : u32x4(0u);
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int s = 0; s < NCH; ++s) {
+      const int c = tid + 512 * s;
+      if (c < BN * CPR) *reinterpret_cast<u32x4*>(lds + (size_t)buf * BN * LD + (c / CPR) * LD + (c % CPR) * 8) = stage[s];
+    }
+  };
+  load_tile(t_lo < t_hi ? t_lo : 0);
+  store_tile(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t t = t_lo; t < t_hi; ++t) {
+    if (t + 1 < t_hi) load_tile(t + 1);  // in flight behind the MFMAs
+    const uint16_t* b_frag = lds + (size_t)cur * BN * LD + (wc * 64 + lr) * LD + kh;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      bf16x8 b[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(b_frag + j * 32 * LD + kk * 16);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (kk == 0) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j], z, 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+    // Epilogue in two steps so that the common case costs ~3 VALU ops per pair and no branch: (1) one pass bit per
+    // pair into two 32-bit masks per lane, (2) only lanes with a hit walk their set bits.  (An in-line "if (pass)
+    // append" per pair serialised ~10 returning atomics per tile and wave: 65 % of all wave cycles were spent waiting.)
+    unsigned int hits[2] = {0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t c = t * BN + wc * 64 + j * 32 + lr;
+      const float cn = c < n ? Cn[c] : __int_as_float(0x7f800000);  // +inf never passes
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          hits[i] = (hits[i] << 1) | (fmaf(-2.f, acc[i][j][r], cn) <= rq[i * 32 + (r & 3) + 8 * (r >> 2)] ? 1u : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned int mk = hits[i];
+      while (mk) {
+        const int b = 31 - __clz(mk);
+        mk &= ~(1u << b);
+        const int e = 31 - b, j = e >> 4, r = e & 15;  // element e = j * 16 + r was shifted in e-th
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2);
+        const int pos = atomicAdd(cnt + row, 1);
+        if (pos < seg) surv_base[(int64_t)row * cap + pos] = (int32_t)(t * BN + wc * 64 + j * 32 + lr);
+      }
+    }
+    if (t + 1 < t_hi) store_tile(cur ^ 1);
+    __syncthreads();  // everyone is done with `cur` and the next image is complete
+    cur ^= 1;
+  }
+  if (tid < 256 && (int64_t)blockIdx.x * 256 + tid < nq) counts[(int64_t)blockIdx.y * nq + (int64_t)blockIdx.x * 256 + tid] = cnt_s[tid];
+}
+
+// One wavefront per query: exact chain distances of its survivors (or of every candidate after an overflow), k smallest
+// (d2, index) keys by k rounds of wave-wide minimum.  Keys are (bits(d2) << 32 | index): d2 >= +0, so the unsigned order
+// of the bits is the order of the values and ties fall to the lower index.
+constexpr int RR_CHUNK = 1024;  // keys held in LDS per wavefront and round
+
+template <bool VEC>
+__device__ __forceinline__ float chain_d2(const float* __restrict__ xq, const float* __restrict__ xc, int64_t d) {
+  float acc = 0.f;
+  if constexpr (VEC) {  // 16-byte aligned rows, d % 4 == 0
+    for (int64_t t = 0; t < d; t += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xq + t), b = *reinterpret_cast<const f32x4*>(xc + t);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float diff = __fsub_rn(a[u], b[u]);
+        acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+      }
+    }
+  } else {
+    for (int64_t t = 0; t < d; ++t) {
+      const float diff = __fsub_rn(xq[t], xc[t]);
+      acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+    }
+  }
+  return acc;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
+                                                         int64_t q_begin, int64_t nq, int k, const int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ surv, int cap, int n_seg, int seg,
+                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t q = (int64_t)blockIdx.x * 4 + wave;
+  if (q >= nq) return;
+  // per wavefront: keys[0 .. RR_CHUNK) = this round's candidates, keys[RR_CHUNK .. RR_CHUNK + k) = best so far
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (RR_CHUNK + 64);
+  const unsigned long long kInf = ~0ull;
+  const float* xq = X + (q_begin + q) * ldx;
+  // the list of query q is n_seg segments of `seg` slots (one per candidate slice of the filter); counts[s * nq + q]
+  // entries of segment s are valid.  Any segment over capacity: the list is incomplete -> every candidate is re-scanned.
+  bool overflow = false;
+  for (int sg = 0; sg < n_seg; ++sg) overflow |= counts[(int64_t)sg * nq + q] > seg;
+  int carried = 0;
+  for (int sg = 0; sg < (overflow ? 1 : n_seg); ++sg) {
+  const int64_t total = overflow ? n : counts[(int64_t)sg * nq + q];
+  const int32_t* mine = surv + q * cap + (int64_t)sg * seg;
+  for (int64_t base = 0; base < total; base += RR_CHUNK) {
+    const int m = (int)min((int64_t)RR_CHUNK, total - base);
+    for (int i = lane; i < m; i += 64) {
+      const int c = overflow ? (int)(base + i) : mine[base + i];
+      const float d2 = chain_d2<VEC>(xq, X + (int64_t)c * ldx, d);
+      keys[i] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned int)c;
+    }
+    const unsigned long long carry = lane < carried ? keys[RR_CHUNK + lane] : kInf;  // snapshot (k <= 64)
+    __builtin_amdgcn_wave_barrier();
+    // k rounds of "smallest key above the previous pick" over this round's keys and the carried ones
+    unsigned long long last = 0;
+    int found = 0;
+    for (int s = 0; s < k; ++s) {
+      unsigned long long best = (s == 0 || carry > last) ? carry : kInf;
+      for (int i = lane; i < m; i += 64) {
+        const unsigned long long v = keys[i];
+        if ((s == 0 || v > last) && v < best) best = v;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other < best ? other : best;
+      }
+      if (best == kInf) break;
+      if (lane == 0) keys[RR_CHUNK + s] = best;
+      last = best;
+      ++found;
+    }
+    carried = found;
+    __builtin_amdgcn_wave_barrier();
+  }
+  }
+  for (int s = lane; s < k; s += 64) {
+    if (s < carried) {
+      const unsigned long long v = keys[RR_CHUNK + s];
+      out_idx[q * k + s] = (int32_t)(unsigned int)v;
+      out_dist[q * k + s] = (float)sqrt((double)__uint_as_float((unsigned int)(v >> 32)));
+    } else {
+      out_idx[q * k + s] = -1;
+      out_dist[q * k + s] = __int_as_float(0x7f800000);
+    }
+  }
+}
+
+// sample rows j * stride of X, zero-padded to `rs` columns
+__global__ __launch_bounds__(256) void knn_sample_kernel(int64_t S, int64_t stride, int64_t d, const float* __restrict__ X, int64_t ldx,
+                                                         int rs, float* __restrict__ Xs) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= S * rs) return;
+  const int64_t j = i / rs;
+  const int t = (int)(i % rs);
+  Xs[i] = t < d ? X[j * stride * ldx + t] : 0.f;
+}
+
+}  // namespace
+
+namespace dh {
+
+int64_t knn_filter_sample_size(int64_t n) {
+  int64_t S = n / 64;
+  if (S < 4096) S = 4096;
+  if (S > 32768) S = 32768;
+  return S < n ? S : n;
+}
+
+int knn_filter_cap(int64_t n, int k) {
+  // expected survivors ~ k n / S (times the eps margin); 4x that, at least 256, a power of two
+  const int64_t want = 4 * (int64_t)k * dh::ceil_div(n, knn_filter_sample_size(n));
+  int cap = 256;
+  while (cap < want && cap < (1 << 16)) cap <<= 1;
+  return cap;  // (split into per-slice segments by knn_filter_launch; an overfull segment only costs that query a re-scan)
+}
+
+// candidate slices of the query-stationary filter (each gets its own segment of every survivor list and its own
+// counter array): enough blocks for two rounds of the chip
+int knn_filter_slices(int64_t nq) {
+  const int64_t qblocks = ceil_div(nq, 256);
+  return (int)(qblocks >= 512 ? 1 : ceil_div(512, qblocks));
+}
+
+int64_t knn_filter_k3(int64_t d) { return (3 * (int64_t)((d + 7) / 8 * 8) + 15) / 16 * 16; }
+
+// Survivor lists: n_seg segments of `seg` slots per query (row stride n_seg * seg).  One segment for the tile kernel
+// (d > 64); one per candidate slice for the query-stationary kernel, each at least 1024 slots deep so that a query
+// whose neighbours all sit in one slice does not overflow (an overfull segment only costs that query a re-scan).
+void knn_filter_geometry(int64_t n, int64_t d, int64_t nq, int k, int* n_seg, int* seg) {
+  const int cap = knn_filter_cap(n, k);
+  *n_seg = 1;
+  *seg = cap;
+  if (knn_filter_k3(d) <= 192) {
+    const int64_t tiles_n = ceil_div(n, BN);
+    int64_t slices = knn_filter_slices(nq);
+    if (slices > tiles_n) slices = tiles_n;
+    const int64_t tps = ceil_div(tiles_n, slices);
+    *n_seg = (int)ceil_div(tiles_n, tps);
+    int sg = cap / *n_seg;
+    if (*n_seg > 1 && sg < 1024) sg = cap < 1024 ? cap : 1024;
+    *seg = sg;
+  }
+}
+
+int knn_filter_padded_d(int64_t d) { return (int)((d + 7) / 8 * 8); }
+
+
+void knn_filter_sample(int64_t n, int64_t d, const float* X, int64_t ldx, int rs, float* Xs, hipStream_t st) {
+  const int64_t S = knn_filter_sample_size(n);
+  hipLaunchKernelGGL(knn_sample_kernel, dim3((unsigned)ceil_div(S * rs, 256)), dim3(256), 0, st, S, n / S, d, X, ldx, rs, Xs);
+}
+
+// Steps 2 and 3 (the sample pass has already left the raw k-th sample distances in sample_d2 [nq][k]).
+// `Xr` (leading dimension ldr, dr >= d columns, extra columns zero) is what the re-rank reads: the zero-padded copy for
+// d <= 64, X itself otherwise.
+int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const float* Xr, int64_t ldr, int64_t dr,
+                      int64_t q_begin, int64_t nq, int k,
+                      const float* sample_d2, uint16_t* A2, uint16_t* B2, float* norms, float* Rq, float* Cn, int32_t* counts,
+                      int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st) {
+  const int dp = knn_filter_padded_d(d);
+  const int64_t K3 = knn_filter_k3(d);
+  const float eps = 1.220703125e-4f + (float)d * 9.5367431640625e-7f;  // 2^-13 + d 2^-20
+  hipLaunchKernelGGL(knn_split_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, dp, K3, A2, B2, norms);
+  hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, q_begin, nq, k, eps, norms,
+                     sample_d2, Rq, Cn, counts);
+  int n_seg, seg;
+  knn_filter_geometry(n, d, nq, k, &n_seg, &seg);
+  const int cap = n_seg * seg;  // slots per query
+  if (K3 <= 192) {  // query-stationary kernel; candidate tiles sliced over grid.y until >= 2 rounds of blocks exist
+    const int64_t qblocks = ceil_div(nq, 256), tiles_n = ceil_div(n, BN);
+    const int64_t tps = ceil_div(tiles_n, n_seg);
+    dim3 grid((unsigned)qblocks, (unsigned)n_seg);
+    const int ks = (int)(K3 / 16);
+    const size_t lds = 2 * (size_t)BN * (K3 + 8) * sizeof(uint16_t);
+#define DH_KNN_FS(KS)                                                                                                          \
+  case KS: {                                                                                                                   \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_small_kernel<KS>),                     \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,                                     \
+                                               (int)(2 * BN * (16 * KS + 8) * sizeof(uint16_t))) == hipSuccess;                \
+    if (!ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");                        \
+    hipLaunchKernelGGL(knn_filter_small_kernel<KS>, grid, dim3(512), lds, st, nq, n, A2 + q_begin * K3, B2, Rq, Cn, counts,    \
+                       surv, cap, seg, tps);                                                                                   \
+  } break
+    switch (ks) {
+      DH_KNN_FS(2); DH_KNN_FS(3); DH_KNN_FS(5); DH_KNN_FS(6); DH_KNN_FS(8); DH_KNN_FS(9); DH_KNN_FS(11); DH_KNN_FS(12);
+      default: return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: unexpected filter depth %d", ks);
+    }
+#undef DH_KNN_FS
+  } else {
+    const int64_t tiles = ceil_div(nq, BM) * ceil_div(n, BN);
+    if (tiles >= (int64_t)1 << 31) return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: too many filter tiles (%lld)", (long long)tiles);
+    hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)tiles), dim3(256), 0, st, nq, n, K3, A2 + q_begin * K3, B2, Rq, Cn, counts,
+                       surv, cap);
+  }
+  const size_t lds = 4 * (size_t)(RR_CHUNK + 64) * sizeof(unsigned long long);
+  const bool vec = dr % 4 == 0 && ldr % 4 == 0 && aligned16(Xr);
+  if (vec)
+    hipLaunchKernelGGL(knn_rerank_kernel<true>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
+                       surv, cap, n_seg, seg, out_idx, out_dist);
+  else
+    hipLaunchKernelGGL(knn_rerank_kernel<false>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
+                       surv, cap, n_seg, seg, out_idx, out_dist);
+  return check_launch("dh_knn_bruteforce_f32(filter)");
+}
+
+}  // namespace dh

@@ -312,18 +312,23 @@ def pairwise_distance(X: torch.Tensor, metric: int = METRIC_EUCLIDEAN) -> torch.
     return out
 
 
-def knn(X: torch.Tensor, k: int, q_begin: int = 0, q_end: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Exact kNN (self included), ordered by (distance, index); returns (idx int32 [nq,k], dist f32 [nq,k])."""
+KNN_AUTO, KNN_SCAN, KNN_FILTER = 0, 1, 2
+
+
+def knn(X: torch.Tensor, k: int, q_begin: int = 0, q_end: Optional[int] = None, *,
+        algo: int = KNN_AUTO) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact kNN (self included), ordered by (distance, index); returns (idx int32 [nq,k], dist f32 [nq,k]).
+    ``algo``: KNN_SCAN (vector-ALU scan), KNN_FILTER (matrix-core filter + exact re-rank) or KNN_AUTO — same result."""
     lib = _lib_ready()
     n, d = X.shape
     q_end = n if q_end is None else q_end
     nq = q_end - q_begin
     idx = torch.empty((nq, k), dtype=torch.int32, device=X.device)
     dist = torch.empty((nq, k), dtype=torch.float32, device=X.device)
-    ws_bytes = lib.dh_knn_bruteforce_f32_workspace_bytes(n, d, nq, k)
+    ws_bytes = lib.dh_knn_bruteforce_f32_workspace_bytes(n, d, nq, k, algo)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=X.device)
     _call("knn_bruteforce_f32", lib.dh_knn_bruteforce_f32, n, d, _dev(X, torch.float32, "X", 2), _ld(X), q_begin,
-          q_end, k, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+          q_end, k, algo, idx.data_ptr(), dist.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
     return idx, dist
 
 

@@ -47,6 +47,7 @@ enum dh_status {
 
 enum dh_act { DH_ACT_NONE = 0, DH_ACT_RELU = 1 };
 enum dh_reduce { DH_REDUCE_SUM = 0, DH_REDUCE_MEAN = 1 };
+enum dh_knn_algo { DH_KNN_AUTO = 0, DH_KNN_SCAN = 1, DH_KNN_FILTER = 2 };
 enum dh_dtype { DH_DTYPE_F32 = 0, DH_DTYPE_BF16 = 1 };
 enum dh_metric { DH_METRIC_EUCLIDEAN = 0, DH_METRIC_PEARSON = 1, DH_METRIC_SPEARMAN = 2 };
 
@@ -149,11 +150,17 @@ DH_API int dh_rank_rows_f32(int64_t n, int64_t d, const float* X, int64_t ldx, f
  * Replaces sklearn NearestNeighbors.kneighbors at dance/transforms/graph/heteronet_graph.py:36-37,
  * dance/transforms/graph/spatial_graph.py:147-149 and the kNN stage of sc.pp.neighbors
  * (dance/transforms/graph/neighbor_graph.py:52).  out_idx/out_dist are [(q_end-q_begin), k].
- * Few queries (< 262k): the candidates are scanned in slices by several blocks per query group and the
- * partial lists merged (same (d2, index) order); workspace from dh_knn_bruteforce_f32_workspace_bytes.  */
-DH_API size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k);
+ * Two evaluation strategies with IDENTICAL results (the neighbours are defined by the sequential fp32 distance
+ * chain and the (d2, index) order; both return exactly those):
+ *   DH_KNN_SCAN   — every (query, candidate) pair through the chain on the vector ALUs (knn.hip);
+ *   DH_KNN_FILTER — an upper bound of each query's k-th distance from a strided sample, a bf16x3 matrix-core pass
+ *                   that discards every pair provably beyond it, and the chain on the survivors only
+ *                   (knn_filter.hip; k <= 64, finite inputs);
+ *   DH_KNN_AUTO   — FILTER for n >= 16384 candidates, >= 1024 queries and k <= 64, SCAN otherwise.
+ * Workspace (64-byte aligned) from dh_knn_bruteforce_f32_workspace_bytes with the same algo.                     */
+DH_API size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k, int algo);
 DH_API int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx,
-                          int64_t q_begin, int64_t q_end, int k,
+                          int64_t q_begin, int64_t q_end, int k, int algo,
                           int32_t* out_idx, float* out_dist,
                           void* workspace, size_t workspace_bytes, dh_stream_t stream);
 

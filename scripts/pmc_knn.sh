@@ -1,14 +1,24 @@
 #!/bin/bash
-# SQ counter passes over one kNN call (separate --pmc runs, no trace flags)
+# kernel trace + counter passes over one kNN call (separate --pmc runs, no trace flags with counters)
+#   bash scripts/pmc_knn.sh [n] [d] [algo]
 R=${GRAFT_REPO_ROOT:-/root/repo}
+N=${1:-400000}; D=${2:-50}; ALGO=${3:-2}
 OUT=$R/gpurun_out/pmc_knn
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/scripts/knn_one.py 300000 50"
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAVES -d $OUT/sq1 -o sq1 --output-format csv -- $CMD > $OUT/sq1.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU -d $OUT/sq2 -o sq2 --output-format csv -- $CMD > $OUT/sq2.log 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_INST_LEVEL_SMEM SQ_INST_LEVEL_LDS SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_REQ -d $OUT/sq3 -o sq3 --output-format csv -- $CMD > $OUT/sq3.log 2>&1
-timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_LEVEL_WAVES SQC_DCACHE_BUSY_CYCLES -d $OUT/sq4 -o sq4 --output-format csv -- $CMD > $OUT/sq4.log 2>&1
-python $R/scripts/pmc_summary.py $OUT/*/*/*counter_collection.csv > $OUT/summary.json 2>$OUT/summary.err
-cat $OUT/summary.json | head -150
-grep -il "error\|invalid" $OUT/*.log
+CMD="python $R/scripts/knn_one.py $N $D $ALGO"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1
+DB=$(find $OUT/trace -name "*.db" | head -1); python $R/scripts/rocpd_stats.py $DB $OUT/knn > $OUT/rocpd.log 2>&1; head -12 $OUT/rocpd.log
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum -d $OUT/l2 -o l2 --output-format csv -- $CMD > $OUT/l2.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_LDS -d $OUT/sq -o sq --output-format csv -- $CMD > $OUT/sq.log 2>&1
+python $R/scripts/pmc_summary.py $(find $OUT/fetch $OUT/l2 $OUT/sq -name "*counter_collection.csv") > $OUT/summary.json 2>$OUT/summary.err
+python - <<PY
+import json
+d=json.load(open("$OUT/summary.json"))
+for k,v in d.items():
+    if "knn" in k:
+        print(k)
+        for c,x in v.items(): print("   %-28s %.4g  (%.2f ms, n=%d)"%(c,x["mean"],x["mean_ms"],x["dispatches"]))
+PY
+find $OUT -name "*.db" -delete

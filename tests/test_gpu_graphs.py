@@ -81,12 +81,59 @@ def test_knn_single_scan_and_sliced_agree(cuda_device):
     n, d, k = 270_000, 4, 5
     x = np.random.default_rng(5).integers(-8, 8, size=(n, d)).astype(np.float32)  # many exact ties
     xt = _t(x, cuda_device)
-    idx_all, dist_all = kernels.knn(xt, k)                    # single scan
-    idx_rng, dist_rng = kernels.knn(xt, k, 1000, 1512)        # 64 candidate slices + merge
+    idx_all, dist_all = kernels.knn(xt, k, algo=kernels.KNN_SCAN)              # single scan
+    idx_rng, dist_rng = kernels.knn(xt, k, 1000, 1512, algo=kernels.KNN_SCAN)  # 64 candidate slices + merge
     ref_idx, ref_dist = og.knn_exact(x, k, q_begin=1000, q_end=1512)
     assert np.array_equal(idx_rng.cpu().numpy(), ref_idx) and np.array_equal(dist_rng.cpu().numpy(), ref_dist)
     assert np.array_equal(idx_all[1000:1512].cpu().numpy(), ref_idx)
     assert np.array_equal(dist_all[1000:1512].cpu().numpy(), ref_dist)
+
+
+# ---- matrix-core filter + exact re-rank: must reproduce the scan bit for bit -----------------------------------
+def _knn_both(x, k, cuda_device, q=None):
+    from dance_amd import kernels
+    xt = _t(x, cuda_device)
+    a = kernels.knn(xt, k, *(q or ()), algo=kernels.KNN_SCAN)
+    b = kernels.knn(xt, k, *(q or ()), algo=kernels.KNN_FILTER)
+    return a, b
+
+
+@pytest.mark.parametrize("n,d,k,kind", [
+    (40_000, 50, 15, "normal"),        # PCA-like embedding, register-kernel sample scan
+    (33_000, 130, 10, "normal"),       # d > 64: LDS-tiled sample scan, unpadded re-rank
+    (36_000, 50, 15, "offset"),        # |x|^2 >> neighbour distances: wide filter margin
+    (34_000, 6, 64, "integer"),        # massive exact ties, k = 64
+    (50_000, 20, 1, "clustered"),
+])
+def test_knn_filter_equals_scan(cuda_device, n, d, k, kind):
+    rng = np.random.default_rng(n + d)
+    if kind == "normal":
+        x = rng.standard_normal((n, d))
+    elif kind == "offset":
+        x = rng.standard_normal((n, d)) + 40.0
+    elif kind == "integer":
+        x = rng.integers(-3, 4, size=(n, d))
+    else:
+        x = rng.standard_normal((n, d)) * 0.05 + rng.integers(0, 30, size=(n, 1)) * 3.0
+    (i_s, d_s), (i_f, d_f) = _knn_both(x.astype(np.float32), k, cuda_device)
+    assert torch.equal(i_s, i_f) and torch.equal(d_s, d_f)
+
+
+def test_knn_filter_small_and_overflow_and_range(cuda_device):
+    from dance_amd import kernels
+    rng = np.random.default_rng(9)
+    # small n: the "sample" is the whole set; checked against the oracle as well
+    x = rng.standard_normal((3000, 33)).astype(np.float32)
+    (i_s, d_s), (i_f, d_f) = _knn_both(x, 7, cuda_device, q=(100, 900))
+    ref_idx, ref_dist = og.knn_exact(x, 7, q_begin=100, q_end=900)
+    assert np.array_equal(i_f.cpu().numpy(), ref_idx) and np.array_equal(d_f.cpu().numpy(), ref_dist)
+    assert torch.equal(i_s, i_f) and torch.equal(d_s, d_f)
+    # every point identical: all n candidates survive the filter -> list overflow -> in-kernel full re-scan, ties by index
+    z = np.ones((5000, 16), dtype=np.float32)
+    idx, dist = kernels.knn(_t(z, cuda_device), 5, algo=kernels.KNN_FILTER)
+    assert np.array_equal(idx.cpu().numpy(), np.tile(np.arange(5, dtype=np.int32), (5000, 1))) and float(dist.abs().max()) == 0.0
+    with pytest.raises(Exception, match="k <= 64"):
+        kernels.knn(_t(x, cuda_device), 65, algo=kernels.KNN_FILTER)
 
 
 # ---- A11 UMAP connectivities ---------------------------------------------------------------------------------
