@@ -56,18 +56,28 @@ def main():
     # ---- K8 exact kNN (A11/A12/A13) ------------------------------------------------------------------------
     for n, d, k in ([] if args.skip_knn else [(20_000, 50, 15)] if q else [(100_000, 50, 15), (1_000_000, 50, 15), (100_000, 2000, 15)]):
         x = torch.randn(n, d, device=dev, generator=g)
-        ms = gpu_ms(lambda: kernels.knn(x, k), iters=1, warm=1 if n <= 100_000 else 0)
         ops = 3.0 * n * n * d
         ns = 4000
         xs = x[:ns].cpu().numpy()
         t_or = cpu_s(lambda: og.knn_exact(xs, k))
         from sklearn.neighbors import NearestNeighbors
         t_sk = cpu_s(lambda: NearestNeighbors(n_neighbors=k, algorithm="brute").fit(xs).kneighbors(xs))
-        rows[f"knn_bruteforce_f32 n={n} d={d} k={k}"] = dict(
+        cpu = dict(sample=f"{ns} points (pairs scale n^2)", oracle_numpy_pairs_per_s=ns * ns / t_or,
+                   sklearn_brute_pairs_per_s=ns * ns / t_sk, cores=os.cpu_count())
+        # the exact scan (vector ALUs, 3 ops per pair and feature) and the matrix-core filter + exact re-rank: same output
+        ms = gpu_ms(lambda: kernels.knn(x, k, algo=kernels.KNN_SCAN), iters=1, warm=1 if n <= 100_000 else 0)
+        rows[f"knn_bruteforce_f32 [scan] n={n} d={d} k={k}"] = dict(
             ms=ms, bound="valu", achieved=ops / ms / 1e9, peak=VALU_OPS, unit="Tops/s (sub,mul,add)", frac=ops / ms / 1e9 / VALU_OPS,
-            cells_per_s=n / ms * 1e3,
-            cpu_baseline=dict(sample=f"{ns} points (pairs scale n^2)", oracle_numpy_pairs_per_s=ns * ns / t_or,
-                              sklearn_brute_pairs_per_s=ns * ns / t_sk, gpu_pairs_per_s=n * n / ms * 1e3, cores=os.cpu_count()))
+            cells_per_s=n / ms * 1e3, gpu_pairs_per_s=n * n / ms * 1e3, cpu_baseline=cpu)
+        with kernels.KernelTimer() as tm:
+            ms_f = gpu_ms(lambda: kernels.knn(x, k, algo=kernels.KNN_FILTER), iters=2, warm=1)
+        dp = (d + 7) // 8 * 8
+        k3 = (3 * dp + 15) // 16 * 16
+        flops = 2.0 * n * n * k3  # bf16x3 filter GEMM (hi.hi + hi.lo + lo.hi)
+        rows[f"knn_bruteforce_f32 [filter] n={n} d={d} k={k}"] = dict(
+            ms=ms_f, speedup_vs_scan=ms / ms_f, bound="mfma", achieved=flops / ms_f / 1e9, peak=2500.0, unit="TFLOP/s (bf16 filter flops over the whole call)",
+            frac=flops / ms_f / 1e9 / 2500.0, cells_per_s=n / ms_f * 1e3, gpu_pairs_per_s=n * n / ms_f * 1e3, cpu_baseline=cpu,
+            note="sample scan + split + filter + re-rank; identical output to [scan] (tests/test_gpu_graphs.py)")
         if n == 1_000_000 or q:
             idx, dist = kernels.knn(x, k)
             ms_u = gpu_ms(lambda: kernels.umap_connectivities(idx, dist), iters=2)
