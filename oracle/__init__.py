@@ -13,7 +13,16 @@ Pinning status (see DESIGN.md "Oracle"):
   torch-CPU by tests/golden/make_golden.py.
 * ``oracle.matrix``  (pairwise_distance / normalize) — PINNED by the reference's known-answer tests
   (tests/utils/test_matrix.py:9-65, vectors copied into tests/golden/matrix_known_answers.json).
-* ``oracle.graphs`` / ``oracle.sage`` (DGL / scanpy / sklearn call sites) — the reference cannot run here
-  (dgl, scanpy, anndata, numba are not installed): PARITY UNPINNED by reference output; restated from the
-  cited lines and from the published algorithms of dgl 1.1.3 / umap-learn / scikit-learn.
+* ``oracle.graphs.cell_feature_graph / heteronet_edges / stagate_* / spagcn_xyz``, ``oracle.sage.*`` (AdaptiveSAGE
+  message + mean, WeightedGraphConv), ``oracle.spagcn.*`` — PINNED: tests/golden/graph_builders.npz holds outputs of
+  the reference's own methods (CellFeatureGraph.__call__, AdaptiveSAGE.message_func / forward,
+  WeightedGraphConv.forward, HeteronetGraph.build_graph, SpaGCNGraph.__call__, StagateGraph.__call__, calculate_p,
+  search_l, refine), lifted method by method by oracle.ref_extract.extract_method and executed on torch-CPU; where
+  that code calls dgl, oracle.ref_extract.DGLStubGraph supplies DGL's storage semantics (edge ids in insertion
+  order, mean over in-edges with 0 for isolated nodes) — those semantics are the only part not executed from the
+  reference tree.  sklearn is the installed 1.7 (reference pins 1.3.2).
+* ``oracle.graphs.knn_exact / fuzzy_simplicial_set / neighbor_graph`` (scanpy ``sc.pp.neighbors`` → pynndescent /
+  umap-learn) — PARITY UNPINNED by reference output (scanpy, numba, umap-learn are not installable here): kNN is
+  checked against scikit-learn's exact search, the fuzzy simplicial set is restated from umap-learn's published
+  algorithm.
 """

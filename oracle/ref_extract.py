@@ -35,3 +35,107 @@ def extract(rel_path: str, name: str, extra_ns=None):
             exec(compile(seg, f"<reference:{rel_path}:{node.lineno}>", "exec"), ns)
             return ns[name]
     raise KeyError(f"{name} not found in {path}")
+
+
+def extract_method(rel_path: str, cls: str, method: str, extra_ns=None):
+    """The function object of ``cls.method`` of ``rel_path``, exec'd on its own (no class body, no decorators, no
+    base classes): call it with a stand-in ``self``.  Lets reference methods run whose class cannot be defined here
+    because its bases / decorators need dgl, anndata or the dance registry."""
+    import logging
+    import textwrap
+
+    import numpy as np
+    import pandas as pd
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    path = os.path.join(REFERENCE_ROOT, rel_path)
+    src = open(path).read()
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name == method:
+                    seg = textwrap.dedent("\n".join(src.splitlines()[sub.lineno - 1:sub.end_lineno]))
+                    ns = {"torch": torch, "nn": nn, "F": F, "np": np, "pd": pd, "math": math,
+                          "logger": logging.getLogger("reference")}
+                    ns.update(extra_ns or {})
+                    exec(compile(seg, f"<reference:{rel_path}:{sub.lineno}>", "exec"), ns)
+                    return ns[method]
+    raise KeyError(f"{cls}.{method} not found in {path}")
+
+
+class DGLStubGraph:
+    """The slice of ``dgl.DGLGraph`` semantics the reference's graph builders and AdaptiveSAGE rely on, so that THEIR
+    code can run here without dgl: edges keep insertion order (edge id = position), ``in_edges(v, form="all")``
+    returns the in-edges of v in edge-id order, ``update_all(message, mean)`` averages messages over in-edges with 0 for
+    isolated nodes (dgl 1.1.3 documentation).  Test infrastructure only."""
+
+    def __init__(self, src, dst, num_src=None, num_dst=None):
+        import torch
+        self._src, self._dst = torch.as_tensor(src).long(), torch.as_tensor(dst).long()
+        n = int(max(int(self._src.max()) if self._src.numel() else -1, int(self._dst.max()) if self._dst.numel() else -1)) + 1
+        self._num_src = n if num_src is None else num_src
+        self._num_dst = n if num_dst is None else num_dst
+        self.edata, self.ndata = {}, {}
+        self.srcdata, self.dstdata = ({}, {}) if num_dst is not None else (self.ndata, self.ndata)
+
+    # homogeneous-graph surface (cell_feature_graph.py:53-69)
+    def number_of_nodes(self):
+        return self._num_src
+
+    def nodes(self):
+        import torch
+        return torch.arange(self._num_src)
+
+    def in_degrees(self):
+        import torch
+        return torch.bincount(self._dst, minlength=self._num_dst)
+
+    def out_degrees(self):
+        import torch
+        return torch.bincount(self._src, minlength=self._num_src)
+
+    def in_edges(self, v, form="uv"):
+        import torch
+        eid = torch.nonzero(self._dst == int(v)).reshape(-1)
+        return (self._src[eid], self._dst[eid], eid) if form == "all" else (self._src[eid], self._dst[eid])
+
+    def add_edges(self, u, v, data=None):
+        import torch
+        self._src = torch.cat((self._src, torch.as_tensor(u).long()))
+        self._dst = torch.cat((self._dst, torch.as_tensor(v).long()))
+        for key, val in (data or {}).items():
+            self.edata[key] = torch.cat((self.edata[key], val))
+
+    def edges(self):
+        return self._src, self._dst
+
+    # block surface (gnn.py:84-96)
+    def local_scope(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def number_of_dst_nodes(self):
+        return self._num_dst
+
+    def update_all(self, message_func, reduce_func):
+        import types
+
+        import torch
+        edges = types.SimpleNamespace(src={k: v[self._src] for k, v in self.srcdata.items()},
+                                      dst={k: v[self._dst] for k, v in self.dstdata.items()}, data=self.edata)
+        kind, msg_field, out_field = reduce_func
+        m = message_func(edges)[msg_field]
+        out = torch.zeros((self._num_dst, ) + tuple(m.shape[1:]), dtype=m.dtype)
+        out.index_add_(0, self._dst, m)
+        if kind == "mean":
+            deg = torch.bincount(self._dst, minlength=self._num_dst).clamp(min=1).to(m.dtype)
+            out = out / deg.reshape((-1, ) + (1, ) * (m.dim() - 1))
+        self.dstdata[out_field] = out
+
+
+def dgl_stub():
+    """A namespace standing in for ``import dgl`` in extracted reference code (see DGLStubGraph)."""
+    import types
+    fn = types.SimpleNamespace(mean=lambda msg, out: ("mean", msg, out), sum=lambda msg, out: ("sum", msg, out))
+    return types.SimpleNamespace(graph=lambda pair: DGLStubGraph(pair[0], pair[1]), function=fn)

@@ -155,6 +155,156 @@ def make_matrix_known_answers():
     print("matrix_known_answers.json written")
 
 
+def make_graph_builders():
+    """graph_builders.npz: outputs of the reference's OWN graph-builder / message-passing code, lifted method by method
+    (oracle.ref_extract.extract_method) and run on torch-CPU.  Where that code calls into dgl, oracle.ref_extract's
+    DGLStubGraph stands in for the DGL storage semantics (edge ids in insertion order, mean over in-edges); sklearn is
+    the installed one.  Pins oracle.graphs.cell_feature_graph / heteronet_edges, oracle.sage.* and oracle.spagcn.*."""
+    import logging
+    import types
+    rng = np.random.default_rng(7)
+    out = {}
+    dgl = ref_extract.dgl_stub()
+    log = logging.getLogger("reference")
+
+    # ---- CellFeatureGraph.__call__ (cell_feature_graph.py:34-79), both normalize_edges settings ----------------
+    call = ref_extract.extract_method("dance/transforms/graph/cell_feature_graph.py", "CellFeatureGraph", "__call__", {"dgl": dgl})
+    n_cells, n_genes, d = 13, 8, 5
+    x = ((rng.random((n_cells, n_genes)) < 0.35) * rng.integers(1, 7, (n_cells, n_genes))).astype(np.float32)
+    x[3] = 0      # a cell expressing nothing
+    x[:, 5] = 0   # a gene expressed nowhere
+    gene_f, cell_f = rng.standard_normal((n_genes, d)).astype(np.float32), rng.standard_normal((n_cells, d)).astype(np.float32)
+
+    def get_feature(return_type="default", mod=None, channel=None, channel_type=None):
+        if channel_type == "varm":
+            return torch.from_numpy(gene_f)
+        if channel_type == "obsm":
+            return torch.from_numpy(cell_f)
+        return x
+    out["cfg_x"], out["cfg_gene_feat"], out["cfg_cell_feat"] = x, gene_f, cell_f
+    for norm in (False, True):
+        data = types.SimpleNamespace(get_feature=get_feature, data=types.SimpleNamespace(uns={}))
+        self = types.SimpleNamespace(mod=None, normalize_edges=norm, cell_feature_channel="f", gene_feature_channel="f",
+                                     logger=log, out="g")
+        call(self, data)
+        g = data.data.uns["g"]
+        src, dst = g.edges()
+        tag = f"cfg_norm{int(norm)}_"
+        out[tag + "src"], out[tag + "dst"] = src.numpy(), dst.numpy()
+        out[tag + "weight"] = g.edata["weight"].numpy().ravel()
+        out[tag + "cell_id"], out[tag + "feat_id"] = g.ndata["cell_id"].numpy(), g.ndata["feat_id"].numpy()
+        out[tag + "features"] = g.ndata["features"].numpy()
+
+    # ---- AdaptiveSAGE.message_func / forward (gnn.py:62-96) on a block with all four edge kinds ----------------
+    gnn = "dance/models/nn/gnn.py"
+    message_func = ref_extract.extract_method(gnn, "AdaptiveSAGE", "message_func")
+    forward = ref_extract.extract_method(gnn, "AdaptiveSAGE", "forward", {"dgl": dgl})
+    G, n_src, n_dst, dim, dim_out = 6, 14, 9, 7, 4
+    cid = np.concatenate((np.arange(G), -np.ones(n_src - G))).astype(np.int32)
+    perm = rng.permutation(n_src)
+    cid = cid[perm]                                     # genes and cells interleaved among the source nodes
+    e = 60
+    e_src, e_dst = rng.integers(0, n_src, e), rng.integers(0, n_dst, e)
+    e_dst[e_dst == 4] = 3                               # destination 4 stays isolated (mean -> 0)
+    w = (rng.random(e).astype(np.float32) + 0.1)[:, None]
+    alpha = (rng.random((G + 2, 1)).astype(np.float32) + 0.5)
+    h = rng.standard_normal((n_src, dim)).astype(np.float32)
+    lin = torch.nn.Linear(dim, dim_out)
+    self = types.SimpleNamespace(gene_num=G, alpha=torch.from_numpy(alpha), layers=[torch.nn.Identity(), lin, torch.nn.ReLU(), torch.nn.Identity()])
+    self.message_func = lambda edges: message_func(self, edges)
+    blk = ref_extract.DGLStubGraph(e_src, e_dst, num_src=n_src, num_dst=n_dst)
+    blk.srcdata["cell_id"], blk.dstdata["cell_id"] = torch.from_numpy(cid), torch.from_numpy(cid[:n_dst])
+    blk.edata["weight"] = torch.from_numpy(w)
+    with torch.no_grad():
+        z = forward(self, blk, torch.from_numpy(h))
+    edges = types.SimpleNamespace(src={"h": torch.from_numpy(h)[e_src], "cell_id": torch.from_numpy(cid)[e_src]},
+                                  dst={"cell_id": torch.from_numpy(cid[:n_dst])[e_dst]}, data={"weight": torch.from_numpy(w)})
+    out.update(sage_src=e_src, sage_dst=e_dst, sage_w=w.ravel(), sage_cid=cid, sage_alpha=alpha, sage_h=h, sage_n_dst=np.int64(n_dst),
+               sage_m=message_func(self, edges)["m"].numpy(), sage_neigh=blk.dstdata["neigh"].numpy(), sage_z=z.numpy(),
+               sage_lin_w=lin.weight.detach().numpy(), sage_lin_b=lin.bias.detach().numpy())
+
+    # ---- WeightedGraphConv.forward (graphsc.py:428-484; GraphConv defaults norm="both", bias) on the same block --------
+    gsc = "dance/modules/single_modality/clustering/graphsc.py"
+    esel = ref_extract.extract_method(gsc, "WeightedGraphConv", "edge_selection_simple")
+    wfwd = ref_extract.extract_method(gsc, "WeightedGraphConv", "forward",
+                                      {"fn": dgl.function, "expand_as_pair": lambda feat, g: (feat, feat[:g.number_of_dst_nodes()]),
+                                       "DGLError": RuntimeError})
+    e_dst2 = e_dst.copy()
+    e_dst2[:n_dst] = np.arange(n_dst)                   # every destination has an in-edge (allow_zero_in_degree=False)
+    wmat = (rng.standard_normal((dim, dim_out)) * 0.3).astype(np.float32)
+    bvec = rng.standard_normal(dim_out).astype(np.float32)
+    out.update(wgc_src=e_src, wgc_dst=e_dst2, wgc_w=w.ravel(), wgc_feat=h, wgc_weight=wmat, wgc_bias=bvec)
+    for agg in ("sum", "mean"):
+        blk2 = ref_extract.DGLStubGraph(e_src, e_dst2, num_src=n_src, num_dst=n_dst)
+        blk2.edata["weight"] = torch.from_numpy(w)
+        conv = types.SimpleNamespace(_allow_zero_in_degree=False, _norm="both", weight=torch.from_numpy(wmat),
+                                     bias=torch.from_numpy(bvec), _activation=torch.relu)
+        conv.edge_selection_simple = lambda edges: esel(conv, edges)
+        out["wgc_out_" + agg] = wfwd(conv, blk2, torch.from_numpy(h), agg=agg).numpy()
+
+    # ---- HeteronetGraph.build_graph (heteronet_graph.py:27-40) ------------------------------------------------
+    from sklearn.neighbors import NearestNeighbors
+    build = ref_extract.extract_method("dance/transforms/graph/heteronet_graph.py", "HeteronetGraph", "build_graph",
+                                       {"NearestNeighbors": NearestNeighbors})
+    feats = rng.standard_normal((40, 6)).astype(np.float32)
+    out["het_feats"], out["het_edges"] = feats, build(None, feats, knears=5)
+
+    # ---- calculate_p / search_l (spagcn.py:249-287) ------------------------------------------------------------
+    spa = "dance/modules/spatial/spatial_domain/spagcn.py"
+    calculate_p = ref_extract.extract(spa, "calculate_p")
+    search_l = ref_extract.extract(spa, "search_l", {"calculate_p": calculate_p, "logger": log})
+    xy = rng.random((60, 2)).astype(np.float32) * 20
+    adj = np.sqrt(((xy[:, None] - xy[None]) ** 2).sum(-1)).astype(np.float32)
+    out["spa_adj"] = adj
+    out["spa_p_at"] = np.array([[l, calculate_p(adj, l)] for l in (0.3, 1.0, 2.5, 40.0)], dtype=np.float64)
+    out["spa_search"] = np.array([[p, (search_l(p, adj) or np.nan)] for p in (0.5, 2.0, 1e-9, 1e4)], dtype=np.float64)
+    # ---- SpaGCNGraph.__call__ (spatial_graph.py:36-62): the [x, y, z] coordinates handed to pairwise_distance -----------
+    sg = "dance/transforms/graph/spatial_graph.py"
+    captured = {}
+
+    def capture_pairwise(xyz, dist_func_id=0):
+        captured["xyz"], captured["dist_func_id"] = xyz, dist_func_id
+        return None
+    spa_call = ref_extract.extract_method(sg, "SpaGCNGraph", "__call__", {"pairwise_distance": capture_pairwise})
+    n_spots = 30
+    sxy = rng.integers(0, 50, (n_spots, 2)).astype(np.float32)
+    spix = rng.integers(0, 64, (n_spots, 2)).astype(np.int64)
+    spix[0], spix[1] = (0, 1), (63, 62)  # windows clipped by the image border
+    img = rng.integers(0, 256, (64, 64, 3)).astype(np.uint8)
+    feats_by_channel = {"spatial": sxy, "spatial_pixel": spix, "image": img}
+    sdata = types.SimpleNamespace(get_feature=lambda return_type, channel, channel_type: feats_by_channel[channel],
+                                  data=types.SimpleNamespace(obsp={}))
+    sself = types.SimpleNamespace(alpha=1.5, beta=9, channels=("spatial", "spatial_pixel", "image"),
+                                  channel_types=("obsm", "obsm", "uns"), logger=log, out="SpaGCNGraph")
+    spa_call(sself, sdata)
+    out.update(spg_xy=sxy, spg_xy_pixel=spix, spg_img=img, spg_alpha=np.float64(1.5), spg_beta=np.int64(9), spg_xyz=captured["xyz"],
+               spg_dist_func_id=np.int64(captured["dist_func_id"]))
+
+    # ---- StagateGraph.__call__ (spatial_graph.py:143-151), both models ------------------------------------------------------
+    st_call = ref_extract.extract_method(sg, "StagateGraph", "__call__", {"NearestNeighbors": NearestNeighbors})
+    pts = (rng.random((50, 2)) * 10).astype(np.float32)
+    out["stg_xy"] = pts
+    for model, kw in (("radius", dict(radius=1.7)), ("knn", dict(n_neighbors=4))):
+        tdata = types.SimpleNamespace(get_feature=lambda return_type, channel, channel_type: pts, data=types.SimpleNamespace(obsp={}))
+        tself = types.SimpleNamespace(model_name=model, radius=kw.get("radius", 1), n_neighbors=kw.get("n_neighbors", 5),
+                                      channel="spatial_pixel", channel_type="obsm", out="StagateGraph")
+        st_call(tself, tdata)
+        out["stg_" + model] = np.asarray(tdata.data.obsp["StagateGraph"].todense(), dtype=np.float32)
+
+    # ---- refine (spagcn.py:290-334) ------------------------------------------------------------------------------------------
+    refine = ref_extract.extract(spa, "refine", {"pd": __import__("pandas"), "logger": log})
+    hexxy = np.array([[i + 0.5 * (j % 2), j * 0.866] for i in range(7) for j in range(7)], dtype=np.float32)
+    dis = np.sqrt(((hexxy[:, None] - hexxy[None]) ** 2).sum(-1)).astype(np.float32)
+    pred0 = (hexxy[:, 0] > 3).astype(np.int64)
+    pred0[[8, 24, 40]] = 1 - pred0[[8, 24, 40]]  # isolated mislabelled spots get voted back
+    ids = [f"s{i}" for i in range(len(pred0))]
+    out.update(ref_dis=dis, ref_pred=pred0, ref_refined_hexagon=np.asarray(refine(ids, pred0, dis, shape="hexagon"), dtype=np.int64),
+               ref_refined_square=np.asarray(refine(ids, pred0, dis, shape="square"), dtype=np.int64))
+
+    np.savez_compressed(os.path.join(HERE, "graph_builders.npz"), **out)
+    print("graph_builders.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -162,3 +312,4 @@ if __name__ == "__main__":
     make_gcn_layers()
     make_models()
     make_matrix_known_answers()
+    make_graph_builders()
