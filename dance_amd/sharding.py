@@ -148,6 +148,19 @@ class ShardedGCNGraph:
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         return out
 
+    def inv_in_degree(self) -> torch.Tensor:
+        """1 / max(in-degree, 1) of every node (global [N], cached): the mean reduction's factor in backward."""
+        if getattr(self, "_inv_deg", None) is None:
+            if self.full is not None:
+                rp = self.full[0].rowptr
+                deg = (rp[1:] - rp[:-1]).to(torch.float32)
+            else:
+                rp = self.a.rowptr
+                local = (rp[1:] - rp[:-1]).to(torch.float32)
+                deg = self.all_gather_rows(local[:, None])[:self.n_nodes, 0] if self.world > 1 else local
+            self._inv_deg = 1.0 / deg.clamp(min=1)
+        return self._inv_deg
+
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -155,18 +168,25 @@ class ShardedGCNGraph:
 
 
 class _ShardedGCNLayerFn(torch.autograd.Function):
+    """Rows [lo, hi) of  act(rowscale * reduce_e(val_e * colscale[src] * (X W)[src]) + b).
+
+    ``rowscale`` / ``colscale`` are GLOBAL per-node vectors replicated on every rank (4 MB at 1M nodes): with
+    D_in^-1/2 / D_out^-1/2 they give DGL's GraphConv(norm="both") with edge weights (graphsc.py:444-476), with
+    ``reduce=mean`` its agg="mean" variant; all None is the plain GCN layer of scDSC / SpaGCN."""
 
     @staticmethod
-    def forward(ctx, x_local, weight, bias, sg: ShardedGCNGraph, active: bool, ops):
+    def forward(ctx, x_local, weight, bias, sg: ShardedGCNGraph, active: bool, ops, rowscale, colscale, reduce):
         w = weight.contiguous()
         s_local = ops.gemm(x_local, w)
         act = ops.ACT_RELU if active else ops.ACT_NONE
+        lo, hi = sg.ranges[sg.rank]
         if sg.mode == "alltoall" and sg.world > 1:
             s_cols = sg.rows_to_columns(s_local)
             a = sg.full[0]
             hq = s_cols.shape[1]
             b_cols = None if bias is None else bias[sg.rank * hq:(sg.rank + 1) * hq].contiguous()
-            y_cols = ops.spmm_csr(a.rowptr, a.col, a.val, s_cols, n_cols=s_cols.shape[0], bias=b_cols, act=act,
+            y_cols = ops.spmm_csr(a.rowptr, a.col, a.val, s_cols, n_cols=s_cols.shape[0], rowscale=rowscale,
+                                  colscale=_pad_to(colscale, s_cols.shape[0]), bias=b_cols, act=act, reduce=reduce,
                                   tag="spmm_csr_f32[fwd]")
             if y_cols.shape[0] != s_cols.shape[0]:  # pad rows so the block layout matches world * chunk
                 pad = torch.zeros((s_cols.shape[0], hq), dtype=y_cols.dtype, device=y_cols.device)
@@ -175,9 +195,12 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
             out = sg.columns_to_rows(y_cols, x_local.shape[0])
         else:
             s_full = sg.all_gather_rows(s_local)
-            out = ops.spmm_csr(sg.a.rowptr, sg.a.col, sg.a.val, s_full, n_cols=s_full.shape[0], bias=bias, act=act,
+            out = ops.spmm_csr(sg.a.rowptr, sg.a.col, sg.a.val, s_full, n_cols=s_full.shape[0],
+                               rowscale=None if rowscale is None else rowscale[lo:hi].contiguous(),
+                               colscale=_pad_to(colscale, s_full.shape[0]), bias=bias, act=act, reduce=reduce,
                                tag="spmm_csr_f32[fwd]")
         ctx.sg, ctx.active, ctx.ops, ctx.has_bias = sg, active, ops, bias is not None
+        ctx.rowscale, ctx.colscale, ctx.reduce = rowscale, colscale, reduce
         ctx.save_for_backward(x_local, w, out if active else None)
         return out
 
@@ -188,13 +211,20 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
         dy = dy.contiguous()
         g_local = ops.relu_backward(out, dy) if ctx.active else dy
         dx = dw = db = None
+        lo, hi = sg.ranges[sg.rank]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = sg.all_reduce_sum(ops.colsum(g_local))
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            # d(XW)[u] = colscale[u] * sum_{e: u -> v} val_e * m[v] * G[v],  m = rowscale (/ in-degree for mean): the
+            # roles of the two scale vectors swap on the transposed graph
+            m = ctx.rowscale
+            if ctx.reduce == ops.REDUCE_MEAN:
+                m = sg.inv_in_degree() if m is None else m * sg.inv_in_degree()
             if sg.mode == "alltoall" and sg.world > 1:
                 g_cols = sg.rows_to_columns(g_local)
                 at = sg.full[1]
-                ds_cols = ops.spmm_csr(at.rowptr, at.col, at.val, g_cols, n_cols=g_cols.shape[0], tag="spmm_csr_f32[bwd]")
+                ds_cols = ops.spmm_csr(at.rowptr, at.col, at.val, g_cols, n_cols=g_cols.shape[0], rowscale=ctx.colscale,
+                                       colscale=_pad_to(m, g_cols.shape[0]), tag="spmm_csr_f32[bwd]")
                 if ds_cols.shape[0] != g_cols.shape[0]:
                     pad = torch.zeros((g_cols.shape[0], g_cols.shape[1]), dtype=ds_cols.dtype, device=ds_cols.device)
                     pad[:ds_cols.shape[0]] = ds_cols
@@ -203,18 +233,31 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
             else:
                 g_full = sg.all_gather_rows(g_local)
                 ds = ops.spmm_csr(sg.at.rowptr, sg.at.col, sg.at.val, g_full, n_cols=g_full.shape[0],
-                                  tag="spmm_csr_f32[bwd]")
+                                  rowscale=None if ctx.colscale is None else ctx.colscale[lo:hi].contiguous(),
+                                  colscale=_pad_to(m, g_full.shape[0]), tag="spmm_csr_f32[bwd]")
             if ctx.needs_input_grad[1]:
                 dw = sg.all_reduce_sum(ops.gemm(x_local, ds, trans_a=True))
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(ds, w, trans_b=True)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def _pad_to(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:
+    """A global per-node vector padded with zeros to the world * chunk rows of an exchanged operand."""
+    if v is None or v.numel() == n:
+        return v
+    out = torch.zeros(n, dtype=v.dtype, device=v.device)
+    out[:v.numel()] = v
+    return out
 
 
 def sharded_gcn_layer(x_local: torch.Tensor, weight: torch.Tensor, sg: ShardedGCNGraph,
-                      bias: Optional[torch.Tensor] = None, active: bool = False, ops=None) -> torch.Tensor:
-    """This rank's rows of act(A (X W) + b); gradients of W / b are all-reduced, dX stays row-sharded."""
+                      bias: Optional[torch.Tensor] = None, active: bool = False, ops=None, *,
+                      rowscale: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None,
+                      reduce: int = 0) -> torch.Tensor:
+    """This rank's rows of act(rowscale * reduce(A diag(colscale) (X W)) + b); gradients of W / b are all-reduced, dX
+    stays row-sharded.  ``rowscale`` / ``colscale``: optional global [N] vectors (replicated); ``reduce``: 0 sum, 1 mean."""
     if sg.world == 1 and ops is None:  # one GPU: the plain layer op (same kernels, plus the fused ReLU mask path)
         from .autograd import gcn_layer
-        return gcn_layer(x_local, weight, sg.as_local_graph(), bias, active)
-    return _ShardedGCNLayerFn.apply(x_local, weight, bias, sg, active, ops or _hip_kernels)
+        return gcn_layer(x_local, weight, sg.as_local_graph(), bias, active, rowscale=rowscale, colscale=colscale, reduce=reduce)
+    return _ShardedGCNLayerFn.apply(x_local, weight, bias, sg, active, ops or _hip_kernels, rowscale, colscale, reduce)

@@ -56,9 +56,24 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
         assert torch.equal(sg.all_reduce_sum(t), s[:4])
         # the sharded autograd function itself (collective branches are skipped at world 1, kernels are not)
         w.grad = None
-        y = sharding._ShardedGCNLayerFn.apply(x, w, None, sg, True, sharding._hip_kernels)
+        y = sharding._ShardedGCNLayerFn.apply(x, w, None, sg, True, sharding._hip_kernels, None, None, 0)
         y.backward(dy)
         assert torch.equal(y, y_ref)
         assert np.allclose(w.grad.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # GraphConv(norm="both", agg="mean") form: global scale vectors + mean reduction through the sharded function
+    rs, cs = torch.rand(n, device=dev) + 0.5, torch.rand(n, device=dev) + 0.5
+    b = torch.randn(h, device=dev).requires_grad_(True)
+    w.grad = None
+    y_ref = autograd.gcn_layer(x, w, graph, b, True, rowscale=rs, colscale=cs, reduce=1)
+    y_ref.backward(dy)
+    dw_ref, db_ref = w.grad.clone(), b.grad.clone()
+    for mode in ("allgather", "alltoall"):
+        sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
+        w.grad = b.grad = None
+        y = sharding._ShardedGCNLayerFn.apply(x, w, b, sg, True, sharding._hip_kernels, rs, cs, 1)
+        y.backward(dy)
+        assert torch.equal(y, y_ref)
+        assert np.allclose(w.grad.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert np.allclose(b.grad.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
     dist.barrier()
     torch.cuda.synchronize()

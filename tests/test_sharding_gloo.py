@@ -93,6 +93,71 @@ def test_sharded_layer_matches_oracle(world, n, use_bias, active, mode):
             assert rel_err(r[6], ref["db"]) < 1e-5
 
 
+def _scaled_worker(rank, world, port, n, fin, fout, k, seed, reduce, q, mode):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_ops
+    from dance_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x, w, b, dy, adj = _problem(n, fin, fout, k, seed)
+        at = adj.T.tocsr()
+        at.sort_indices()
+        lo, hi = sharding.row_ranges(n, world)[0][rank]
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
+        sl = lambda m, a, b_: sharding.slice_rows(t(m.indptr, np.int32), t(m.indices, np.int32), t(m.data, np.float32), a, b_, n)
+        full = (sl(adj, 0, n), sl(at, 0, n)) if mode == "alltoall" else None
+        sg = sharding.ShardedGCNGraph(sl(adj, lo, hi), sl(at, lo, hi), n, mode=mode, full=full)
+        rs, cs = _norm_both(adj)
+        xl = torch.from_numpy(x[lo:hi].copy()).requires_grad_(True)
+        wt = torch.from_numpy(w.copy()).requires_grad_(True)
+        bt = torch.from_numpy(b.copy()).requires_grad_(True)
+        y = sharding.sharded_gcn_layer(xl, wt, sg, bt, True, ops=cpu_ops, rowscale=torch.from_numpy(rs),
+                                       colscale=torch.from_numpy(cs), reduce=reduce)
+        y.backward(torch.from_numpy(dy[lo:hi].copy()))
+        q.put((rank, y.detach().numpy(), wt.grad.numpy(), xl.grad.numpy(), bt.grad.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _norm_both(adj):
+    """GraphConv(norm="both") scales of graphsc.py:444-476: in-degree^-1/2 per destination, out-degree^-1/2 per source."""
+    in_deg = np.maximum(np.diff(adj.indptr), 1).astype(np.float32)
+    out_deg = np.maximum(np.bincount(adj.indices, minlength=adj.shape[0]), 1).astype(np.float32)
+    return in_deg**-0.5, out_deg**-0.5
+
+
+@pytest.mark.parametrize("world,n,reduce,mode", [(2, 77, 0, "allgather"), (2, 77, 1, "alltoall"), (3, 50, 1, "allgather"),
+                                                (3, 50, 0, "alltoall")])
+def test_sharded_graphconv_norm_both_matches_dense_reference(world, n, reduce, mode):
+    """The scaled / mean-reduced layer (WeightedGraphConv full-graph form, BASELINE config 4) sharded over `world`
+    ranks against a float64 dense autograd reference."""
+    fin, fout, k, seed = 10, 6, 5, 5 + n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scaled_worker, args=(r, world, port, n, fin, fout, k, seed, reduce, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, w, b, dy, adj = _problem(n, fin, fout, k, seed)
+    rs, cs = _norm_both(adj)
+    a = torch.from_numpy(adj.toarray()).double()
+    if reduce == 1:
+        a = a / torch.from_numpy(np.maximum(np.diff(adj.indptr), 1)).double()[:, None]
+    xt, wt, bt = (torch.from_numpy(v).double().requires_grad_(True) for v in (x, w, b))
+    y = torch.relu(torch.from_numpy(rs).double()[:, None] * (a @ (torch.from_numpy(cs).double()[:, None] * (xt @ wt))) + bt)
+    y.backward(torch.from_numpy(dy).double())
+    assert rel_err(np.concatenate([r[1] for r in results]), y.detach().numpy()) < 1e-5
+    assert rel_err(np.concatenate([r[3] for r in results]), xt.grad.numpy()) < 1e-5
+    for r in results:
+        assert rel_err(r[2], wt.grad.numpy()) < 1e-5 and rel_err(r[4], bt.grad.numpy()) < 1e-5
+
+
 def test_row_ranges_cover_everything():
     from dance_amd.sharding import row_ranges
     for n in (0, 1, 7, 8, 9, 1_000_000):
