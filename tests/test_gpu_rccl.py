@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
+from conftest import rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -72,8 +73,9 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
         w.grad = b.grad = None
         y = sharding._ShardedGCNLayerFn.apply(x, w, b, sg, True, sharding._hip_kernels, rs, cs, 1)
         y.backward(dy)
-        assert torch.equal(y, y_ref)
-        assert np.allclose(w.grad.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
-        assert np.allclose(b.grad.cpu().numpy(), db_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert rel_err(y.detach().cpu().numpy(), y_ref.detach().cpu().numpy()) < 1e-6
+        # (x * (1 / deg) here vs x / deg in gcn_layer: last-bit differences in the mean factor)
+        assert rel_err(w.grad.cpu().numpy(), dw_ref.cpu().numpy()) < 1e-5
+        assert rel_err(b.grad.cpu().numpy(), db_ref.cpu().numpy()) < 1e-5
     dist.barrier()
     torch.cuda.synchronize()
