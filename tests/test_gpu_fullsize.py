@@ -107,6 +107,39 @@ def test_scdeepsort_graph_full_size(cuda_device):
         ref = osg.sage_neigh(np.arange(t - s), np.zeros(t - s, dtype=np.int64), gval[s:t].cpu().numpy(), cid_np[src], cid_np[[n_genes + i]],
                              a_np, feats[torch.from_numpy(src).to(DEV)].cpu().numpy(), 1)
         assert rel_err(neigh[i].cpu().numpy(), ref[0]) < 1e-5
+    # config 3 proper: bf16 storage.  The bf16 kernel with fp32 output equals the fp32 kernel on the rounded features
+    # bit for bit (same edge order, same fmaf chain); the dense update runs on the bf16 matrix cores.
+    feats16 = feats.to(torch.bfloat16)
+    n32 = kernels.sage_aggregate(rowptr[n_genes:], gcol, gval, cid, cid[n_genes:], alpha, feats16.float())
+    n16 = kernels.sage_aggregate_bf16(rowptr[n_genes:], gcol, gval, cid, cid[n_genes:], alpha, feats16, out_dtype=torch.float32)
+    assert torch.equal(n16, n32)
+    del n32, neigh
+    w16 = (torch.randn(200, d, device=DEV, generator=gen) / 20).to(torch.bfloat16)
+    bias = torch.randn(200, device=DEV, generator=gen)
+    h16 = feats16[n_genes:]
+    z = kernels.gemm_bf16(h16, w16, trans_b=True, bias=bias, act=kernels.ACT_RELU)
+    assert z.shape == (n_cells, 200) and z.dtype == torch.bfloat16
+    sel = torch.from_numpy(np.sort(rows)).to(DEV)
+    ref = torch.relu(h16[sel].double() @ w16.double().T + bias.double())
+    assert rel_err(z[sel].float().cpu().numpy(), ref.cpu().numpy()) < 2**-8  # one bf16 rounding of an fp32 accumulation
+
+
+def test_knn_filter_full_size(cuda_device):
+    """NeighborGraph's kNN at the headline size (1M cells x 50 PCs, k = 15) through the matrix-core filter; sampled query
+    ranges against the exact vector-ALU scan (bit for bit), plus size-independent properties of the whole result."""
+    from dance_amd import kernels
+    n, d, k = 1_000_000, 50, 15
+    gen = torch.Generator(device=DEV).manual_seed(11)
+    centers = torch.randn(64, d, device=DEV, generator=gen) * 3
+    x = centers[torch.randint(0, 64, (n, ), device=DEV, generator=gen)] + torch.randn(n, d, device=DEV, generator=gen)
+    idx, dist = kernels.knn(x, k)  # auto -> filter
+    assert torch.equal(idx[:, 0], torch.arange(n, device=DEV, dtype=torch.int32)) and float(dist[:, 0].abs().max()) == 0.0  # self first
+    assert bool((dist[:, 1:] >= dist[:, :-1]).all())                                                  # sorted by distance
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    assert bool((torch.sort(idx, dim=1).values[:, 1:] != torch.sort(idx, dim=1).values[:, :-1]).all())   # no duplicates
+    for q0 in (0, 499_744, n - 256):
+        i_s, d_s = kernels.knn(x, k, q0, q0 + 256, algo=kernels.KNN_SCAN)
+        assert torch.equal(idx[q0:q0 + 256], i_s) and torch.equal(dist[q0:q0 + 256], d_s)
 
 
 def test_spagcn_full_size(cuda_device):
