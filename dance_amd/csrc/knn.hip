@@ -1,19 +1,21 @@
-// Exact brute-force kNN (rows A11/A12/A13 of §8a).
+// Exact brute-force kNN (rows A11/A12/A13 of §8a): the public entry point, the vector-ALU SCAN and
+// the sample scan of the matrix-core filter path (knn_filter.hip).
 //
 // Parity contract ("bit-exact graph indices"): the squared distance of a pair is DEFINED as
 //     d2 = (((0 + sq(x_0-y_0)) + sq(x_1-y_1)) + ...),  sq(u) = rn(u*u), every op a separate f32
 // round-to-nearest operation in feature order — exactly what the numpy oracle evaluates — and the
 // neighbours of a query are the k smallest (d2, index) pairs in lexicographic order (ties go to
 // the lower index; the query itself is its own nearest neighbour with d2 = 0, as in sklearn and
-// scanpy).  No |x|^2 - 2xy expansion: that is what makes the index lists reproducible bit for
-// bit; the matrix cores are deliberately not used here.
+// scanpy).  A |x|^2 - 2xy expansion does not reproduce those bits, so the scan evaluates the chain itself on
+// the VALUs; the filter path uses the expansion on the matrix cores only to discard pairs and re-ranks the
+// survivors with this same chain.
 //
-// Mapping: one lane per query (256 queries per block).  Candidate rows are staged through LDS in
-// tiles and broadcast to all lanes (same-address ds_read_b128, conflict-free); the query's own
-// features sit in registers.  Each lane keeps its current k-th best (tau) in registers; a
-// candidate that beats tau is inserted into the lane's sorted list (LDS for k <= 32, else the
-// output arrays themselves).  For random data a query sees only ~k ln(N/k) insertions, so the
-// kernel is bound by the 3 VALU ops per (pair, feature).
+// Scan mapping: one lane per query (256 queries per block), the query's features in registers.  d <= 64: candidate
+// rows are wave-uniform, so they arrive through scalar loads as SGPR operands (knn_sreg_kernel).  d > 64: features
+// in chunks of 16, 16 candidates per LDS tile broadcast to all lanes (knn_big_kernel).  Each lane keeps its
+// current k-th best (tau) in registers; a candidate that beats tau replaces the worst entry of the lane's unsorted
+// list (LDS for k <= 32, else the output arrays themselves).  For random data a query sees only ~k ln(N/k)
+// insertions, so the kernels are bound by the 3 VALU ops per (pair, feature).
 #include "common.h"
 
 namespace {
@@ -93,67 +95,6 @@ __device__ __forceinline__ void finish(const List& L, bool lds_list, int k, int 
     }
   }
   (void)lds_list;
-}
-
-// d <= DCH: the whole query row lives in registers, candidates stream through LDS 64 at a time.
-template <int DCH>
-__global__ __launch_bounds__(QB) void knn_small_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
-                                                       int64_t q_begin, int64_t q_end, int k, bool lds_list,
-                                                       int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
-  constexpr int CT = 64;
-  // gridDim.y > 1: this block scans only its slice of the candidates and writes a partial (d2, idx) list
-  const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
-  const int64_t nq_all = q_end - q_begin;
-  if (gridDim.y > 1) { out_idx += (int64_t)blockIdx.y * nq_all * k; out_dist += (int64_t)blockIdx.y * nq_all * k; }
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* cand = reinterpret_cast<float*>(smem);                    // [CT][DCH]
-  float* ld = cand + CT * DCH;                                     // [k][QB] when lds_list
-  int* li = reinterpret_cast<int*>(ld + (lds_list ? k * QB : 0));  // [k][QB]
-
-  const int tid = threadIdx.x;
-  const int64_t q_local = (int64_t)blockIdx.x * QB + tid;
-  const int64_t q = q_begin + q_local;
-  const bool valid = q < q_end;
-
-  float x[DCH];
-#pragma unroll
-  for (int t = 0; t < DCH; ++t) x[t] = (valid && t < d) ? X[q * ldx + t] : 0.f;
-
-  List L;
-  if (lds_list) { L.d = ld + tid; L.i = li + tid; L.stride = QB; }
-  else { L.d = out_dist + (valid ? q_local : 0) * k; L.i = out_idx + (valid ? q_local : 0) * k; L.stride = 1; }
-  int cnt = 0, tau_i = 0x7fffffff, tau_pos = 0;
-  float tau_d = __int_as_float(0x7f800000);
-
-  for (int64_t c0 = cand_lo; c0 < cand_hi; c0 += CT) {
-    __syncthreads();
-    for (int idx = tid; idx < CT * DCH; idx += QB) {
-      const int c = idx / DCH, t = idx % DCH;
-      cand[idx] = (c0 + c < cand_hi && t < d) ? X[(c0 + c) * ldx + t] : 0.f;
-    }
-    __syncthreads();
-    const int lim = (int)min((int64_t)CT, cand_hi - c0);
-    for (int c = 0; c < lim; ++c) {
-      // all LDS reads of the candidate are issued back to back (broadcast ds_read_b128), then consumed in order:
-      // one read in flight at a time left the VALU idle for the LDS latency between 12-op bursts
-      f32x4 y[DCH / 4];
-#pragma unroll
-      for (int t = 0; t < DCH / 4; ++t) y[t] = *reinterpret_cast<const f32x4*>(cand + c * DCH + t * 4);
-      __builtin_amdgcn_sched_barrier(0);
-      float acc = 0.f;
-#pragma unroll
-      for (int t = 0; t < DCH / 4; ++t) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float diff = __fsub_rn(x[t * 4 + u], y[t][u]);
-          acc = __fadd_rn(acc, __fmul_rn(diff, diff));
-        }
-      }
-      const int idx = (int)(c0 + c);
-      if (valid && (cnt < k || before(acc, idx, tau_d, tau_i))) insert(L, k, cnt, tau_d, tau_i, tau_pos, acc, idx);
-    }
-  }
-  finish(L, lds_list, k, cnt, q_local, valid, out_idx, out_dist, gridDim.y > 1);
 }
 
 // d <= 64, scalar-operand form: a candidate row is the same for every lane of a wavefront, so it belongs in
