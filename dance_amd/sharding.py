@@ -261,3 +261,29 @@ def sharded_gcn_layer(x_local: torch.Tensor, weight: torch.Tensor, sg: ShardedGC
         from .autograd import gcn_layer
         return gcn_layer(x_local, weight, sg.as_local_graph(), bias, active, rowscale=rowscale, colscale=colscale, reduce=reduce)
     return _ShardedGCNLayerFn.apply(x_local, weight, bias, sg, active, ops or _hip_kernels, rowscale, colscale, reduce)
+
+
+def sharded_knn(X: torch.Tensor, k: int, group=None, ops=None):
+    """Exact kNN of all rows of ``X`` (replicated on every rank) with the QUERIES split by contiguous range across the
+    ranks — ``dh_knn_bruteforce_f32`` takes a query range for exactly this — and the per-rank lists all-gathered, so
+    every rank ends up with the full [N, k] (idx int32, dist f32) of the single-GPU call, bit for bit (each query's
+    list depends only on that query).  The graph builders' one O(N^2) step scales with the GPU count; the 2 N k 4-byte
+    gather is negligible."""
+    ops = ops or _hip_kernels
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    n = X.shape[0]
+    ranges, chunk = row_ranges(n, world)
+    lo, hi = ranges[rank]
+    idx_l, dist_l = ops.knn(X, k, lo, hi) if hi > lo else (torch.empty((0, k), dtype=torch.int32, device=X.device),
+                                                            torch.empty((0, k), dtype=torch.float32, device=X.device))
+    if world == 1:
+        return idx_l, dist_l
+    pad_i = torch.full((chunk, k), -1, dtype=torch.int32, device=X.device)
+    pad_d = torch.full((chunk, k), float("inf"), dtype=torch.float32, device=X.device)
+    pad_i[:hi - lo], pad_d[:hi - lo] = idx_l, dist_l
+    out_i = torch.empty((world * chunk, k), dtype=torch.int32, device=X.device)
+    out_d = torch.empty((world * chunk, k), dtype=torch.float32, device=X.device)
+    dist.all_gather_into_tensor(out_i, pad_i, group=group)
+    dist.all_gather_into_tensor(out_d, pad_d, group=group)
+    return out_i[:n].contiguous(), out_d[:n].contiguous()

@@ -77,5 +77,11 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
         # (x * (1 / deg) here vs x / deg in gcn_layer: last-bit differences in the mean factor)
         assert rel_err(w.grad.cpu().numpy(), dw_ref.cpu().numpy()) < 1e-5
         assert rel_err(b.grad.cpu().numpy(), db_ref.cpu().numpy()) < 1e-5
+    # query-sharded kNN through the same group (world 1: the local range is everything)
+    from dance_amd import kernels
+    pts = torch.randn(5000, 20, device=dev)
+    i1, d1 = sharding.sharded_knn(pts, 9)
+    i0, d0 = kernels.knn(pts, 9)
+    assert torch.equal(i1, i0) and torch.equal(d1, d0)
     dist.barrier()
     torch.cuda.synchronize()

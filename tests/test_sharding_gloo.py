@@ -158,6 +158,40 @@ def test_sharded_graphconv_norm_both_matches_dense_reference(world, n, reduce, m
         assert rel_err(r[2], wt.grad.numpy()) < 1e-5 and rel_err(r[4], bt.grad.numpy()) < 1e-5
 
 
+def _knn_worker(rank, world, port, n, d, k, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_ops
+    from dance_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        x = torch.from_numpy(np.random.default_rng(3).standard_normal((n, d)).astype(np.float32))
+        idx, dst = sharding.sharded_knn(x, k, ops=cpu_ops)
+        q.put((rank, idx.numpy(), dst.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 203), (3, 100)])
+def test_sharded_knn_equals_single_process(world, n):
+    from oracle import graphs as og
+    d, k = 7, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_knn_worker, args=(r, world, port, n, d, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_idx, ref_dist = og.knn_exact(np.random.default_rng(3).standard_normal((n, d)).astype(np.float32), k)
+    for _, idx, dst in results:  # every rank holds the full, identical result
+        assert np.array_equal(idx, ref_idx) and np.array_equal(dst, ref_dist)
+
+
 def test_row_ranges_cover_everything():
     from dance_amd.sharding import row_ranges
     for n in (0, 1, 7, 8, 9, 1_000_000):
