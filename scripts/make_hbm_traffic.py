@@ -6,11 +6,12 @@ import json
 import sys
 
 d = json.load(open(sys.argv[1]))
-names = {  # bench.py kernel key -> substring of the device kernel name
-    "gemm_f32_nn": "gemm_f32_kernel<Cfg<2, 4, 4, 2>, false, false, true>",
-    "gemm_f32_tn": "gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, false, true>",
-    "spmm_csr_f32[fwd]": "spmm_csr_kernel<64, 4, 2, false, true>",
-    "spmm_csr_f32[bwd]": "spmm_csr_kernel<64, 4, 2, false, true>",
+names = {  # bench.py kernel key -> (device kernel name, launches per C-ABI call)
+    "gemm_f32_nn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, false, false, true>", 1),
+    "gemm_f32_tn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, false, true>", 1),
+    # the 512-wide SpMM runs as two 256-column passes (spmm.hip): bytes per call = 2 x bytes per launch
+    "spmm_csr_f32[fwd]": ("spmm_csr_kernel<64, 4, 1, false, true>", 2),
+    "spmm_csr_f32[bwd]": ("spmm_csr_kernel<64, 4, 1, false, true>", 2),
 }
 out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                    "scripts/refresh_round.sh, bench.py at 1M cells); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024: on "
@@ -22,8 +23,8 @@ for k, v in d.items():
         f, w = v["FETCH_SIZE"]["mean"] * 1024, v["WRITE_SIZE"]["mean"] * 1024
         raw[k] = {"FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w, "hbm_bytes_corrected": 2 * f + w,
                   "ms": v["FETCH_SIZE"]["mean_ms"]}
-for key, sub in names.items():
+for key, (sub, launches) in names.items():
     if sub in raw:
-        out[key] = raw[sub]["hbm_bytes_corrected"]
+        out[key] = raw[sub]["hbm_bytes_corrected"] * launches
 out["raw"] = raw
 print(json.dumps(out, indent=1))
