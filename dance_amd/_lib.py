@@ -50,6 +50,7 @@ def _declare(lib):
         "dh_exclusive_scan_i32": (c_int, [i64, P, P, P, c_size_t, P]),
         "dh_csr_row_normalize_f32": (c_int, [i64, P, P, P, P]),
         "dh_cellgene_graph_assemble": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, P, P, P, P]),
+        "dh_sddmm_csr_f32": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, P]),
         "dh_spmm_csr_bf16": (c_int, [i64, i64, i64, P, P, P, P, P, P, i64, P, i64, i32, P, i32, i32, P]),
         "dh_sage_aggregate_bf16": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, P, i64, P, i64, i32, P]),
         "dh_gemm_bf16_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),

@@ -1,0 +1,91 @@
+// CSR SDDMM: out[e] = scale[e]? * <U[row(e), :], V[col(e), :]> for every stored edge e — the sampled dense-dense
+// product of SURVEY.md §8b.  It is the edge-value gradient of the CSR SpMM (dval[e] = <dY[row(e)], Z[col(e)]>, i.e. the
+// backward of the edge-weighted aggregations graphsc.py:417-426 / gnn.py:81-82 with respect to the weights) and the
+// per-edge score of a sparse inner-product decoder (graphsc.py:386-411 evaluated on the stored edges only).
+//
+// HBM-bound gather like the SpMM: a group of G lanes owns one row, keeps its slice of U[row] in registers, streams the
+// V rows of the row's edges (16-byte loads per lane, 4 edges in flight) and reduces each edge's partial products across
+// the group with DPP/shuffle adds; accumulation order inside a lane is fixed (columns ascending), the cross-lane tree is
+// fixed, so results are bit-reproducible.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+  return v;
+}
+
+// G lanes per row; each lane covers columns [4 g + 4 G a, +4) for a = 0 .. NACC-1 (width <= 4 G NACC, width % 4 == 0)
+template <int G, int NACC>
+__global__ __launch_bounds__(256) void sddmm_csr_kernel(int64_t n_rows, int64_t width, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const float* __restrict__ scale,
+                                                        const float* __restrict__ U, int64_t ldu, const float* __restrict__ V,
+                                                        int64_t ldv, float* __restrict__ out) {
+  const int g = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
+  if (row >= n_rows) return;
+  f32x4 u[NACC];
+  bool live[NACC];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a) {
+    const int64_t c = 4 * g + 4 * G * a;
+    live[a] = c < width;
+    u[a] = live[a] ? *reinterpret_cast<const f32x4*>(U + row * ldu + c) : f32x4(0.f);
+  }
+  const int s = rowptr[row], t = rowptr[row + 1];
+  for (int e0 = s; e0 < t; e0 += 4) {
+    float part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      part[k] = 0.f;
+      if (e0 + k < t) {
+        const float* v = V + (int64_t)col[e0 + k] * ldv + 4 * g;
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+          if (!live[a]) continue;
+          const f32x4 x = *reinterpret_cast<const f32x4*>(v + 4 * G * a);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) part[k] = fmaf(u[a][i], x[i], part[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float d = group_sum<G>(part[k]);
+      if (g == 0 && e0 + k < t) out[e0 + k] = scale ? scale[e0 + k] * d : d;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col,
+                                const float* scale, const float* U, int64_t ldu, const float* V, int64_t ldv, float* out,
+                                dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: negative size");
+  if (n_rows == 0) return DH_OK;
+  if (!rowptr || !col || !U || !V || !out) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: null pointer");
+  if (width % 4 != 0 || ldu % 4 != 0 || ldv % 4 != 0 || !dh::aligned16(U) || !dh::aligned16(V))
+    return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: rows must be multiples of 4 floats and 16-byte aligned (pad the width)");
+  if (ldu < width || ldv < width) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: leading dimension < width");
+  if (width > 4 * 64 * 8) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: width %lld > 2048", (long long)width);
+  hipStream_t st = dh::as_stream(stream);
+  const int64_t vecs = width / 4;
+#define DH_SDDMM(G, NACC)                                                                                              \
+  hipLaunchKernelGGL((sddmm_csr_kernel<G, NACC>), dim3((unsigned)dh::ceil_div(n_rows, 256 / G)), dim3(256), 0, st, n_rows, \
+                     width, rowptr, col, scale, U, ldu, V, ldv, out)
+  if (vecs > 256) DH_SDDMM(64, 8);
+  else if (vecs > 128) DH_SDDMM(64, 4);
+  else if (vecs > 64) DH_SDDMM(64, 2);
+  else if (vecs > 32) DH_SDDMM(64, 1);
+  else if (vecs > 16) DH_SDDMM(32, 1);
+  else if (vecs > 8) DH_SDDMM(16, 1);
+  else DH_SDDMM(8, 1);
+#undef DH_SDDMM
+  return dh::check_launch("dh_sddmm_csr_f32");
+}

@@ -104,6 +104,19 @@ def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor
     return out
 
 
+def sddmm_csr(rowptr: torch.Tensor, col: torch.Tensor, U: torch.Tensor, V: torch.Tensor, *,
+              scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[e] = scale[e] * <U[row(e)], V[col(e)]> per stored edge (dh_sddmm_csr_f32): the edge-value gradient of
+    ``spmm_csr`` and sparse inner-product scores."""
+    lib = _lib_ready()
+    n_rows = rowptr.numel() - 1
+    out = torch.empty(col.numel(), dtype=torch.float32, device=U.device)
+    _call("sddmm_csr_f32", lib.dh_sddmm_csr_f32, n_rows, V.shape[0], U.shape[1], _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(scale, torch.float32, "scale", 1), _dev(U, torch.float32, "U", 2), _ld(U),
+          _dev(V, torch.float32, "V", 2), _ld(V), out.data_ptr(), _stream())
+    return out
+
+
 def relu_mask_bytes(n_rows: int, width: int) -> int:
     """Size of the fused-ReLU sign mask for an [n_rows, width] layer output; 0 = fused path not applicable."""
     return int(_lib.load().dh_relu_mask_bytes(n_rows, width))

@@ -232,6 +232,17 @@ DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, i
                            const float* H, int64_t ldh, const float* dneigh, int64_t ldn,
                            float* dalpha, dh_stream_t stream);
 
+/* ---- SDDMM ------------------------------------------------------------------------------------------------
+ * out[e] = scale[e] * <U[row(e), :], V[col(e), :]> for every stored edge e of a CSR pattern (scale may be NULL).
+ * The edge-value gradient of dh_spmm_csr_f32 (dval[e] = <dY[row(e)], Z[col(e)]>: backward of the edge-weighted
+ * aggregations of graphsc.py:417-426 and gnn.py:81-82 with respect to the weights) and the per-edge logits of the
+ * inner-product decoder graphsc.py:386-411 restricted to stored edges.  width % 4 == 0, 16-byte aligned rows,
+ * width <= 2048.                                                                                              */
+DH_API int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
+                     const int32_t* rowptr, const int32_t* col, const float* scale,
+                     const float* U, int64_t ldu, const float* V, int64_t ldv,
+                     float* out, dh_stream_t stream);
+
 /* ---- bf16 storage path (scDeepSort at 1M cells, "bf16 with MFMA dense update") --------
  * Features, activations and their gradients are STORED as bf16 (uint16_t bit patterns, torch.bfloat16); every sum is
  * accumulated in fp32 and rounded once (nearest-even) when the output dtype is DH_DTYPE_BF16.  The reference has no

@@ -144,6 +144,28 @@ def test_relu_backward_and_colsum(cuda_device):
         assert rel_err(s.cpu().numpy(), dy.cpu().numpy().astype(np.float64).sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("width", [4, 52, 128, 300, 512, 2048])
+def test_sddmm_csr(cuda_device, width):
+    """dh_sddmm_csr_f32 == per-edge dot products (float64 reference); it is the edge-value gradient of the SpMM."""
+    from dance_amd import kernels
+    a = _rand_csr(300, 280, 9, seed=width, long_row=(7, 120), empty_rows=(3, ))
+    rp, c, v = _dev_csr(a, cuda_device)
+    g = torch.Generator().manual_seed(width)
+    u, z = torch.randn(300, width, generator=g), torch.randn(280, width, generator=g)
+    rows = np.repeat(np.arange(300), np.diff(a.indptr))
+    ref = (u.double()[rows] * z.double()[a.indices]).sum(1).numpy()
+    out = kernels.sddmm_csr(rp, c, u.to(cuda_device), z.to(cuda_device))
+    assert rel_err(out.cpu().numpy(), ref) < 1e-5
+    out_s = kernels.sddmm_csr(rp, c, u.to(cuda_device), z.to(cuda_device), scale=v)
+    assert rel_err(out_s.cpu().numpy(), ref * a.data) < 1e-5
+    # gradient identity: d/dval of sum(dY * spmm(A(val), Z)) == sddmm(dY, Z)
+    val = v.clone().cpu().double().requires_grad_(True)
+    dense = torch.zeros(300, 280, dtype=torch.float64)
+    dense = dense.index_put((torch.from_numpy(rows), torch.from_numpy(a.indices.astype(np.int64))), val)
+    (u.double() * (dense @ z.double())).sum().backward()
+    assert rel_err(out.cpu().numpy(), val.grad.numpy()) < 1e-5
+
+
 def test_errors_are_loud(cuda_device):
     from dance_amd import _lib, kernels
     with pytest.raises(_lib.DanceHipError):
@@ -151,6 +173,22 @@ def test_errors_are_loud(cuda_device):
     lib = _lib.load()
     assert lib.dh_spmm_csr_f32(4, 4, 4, None, None, None, None, None, None, 4, None, 4, None, 0, 0, None) < 0
     assert b"null" in lib.dh_last_error_string()
+    # workspace contracts: the size queries are part of the ABI and an undersized / missing buffer is an error, not UB
+    x = torch.randn(20000, 16, device=cuda_device)
+    idx = torch.empty((20000, 5), dtype=torch.int32, device=cuda_device)
+    dst = torch.empty((20000, 5), dtype=torch.float32, device=cuda_device)
+    need = lib.dh_knn_bruteforce_f32_workspace_bytes(20000, 16, 20000, 5, kernels.KNN_FILTER)
+    assert need > lib.dh_knn_bruteforce_f32_workspace_bytes(20000, 16, 20000, 5, kernels.KNN_SCAN) > 0
+    small = torch.empty(need // 2, dtype=torch.uint8, device=cuda_device)
+    rc = lib.dh_knn_bruteforce_f32(20000, 16, x.data_ptr(), 16, 0, 20000, 5, kernels.KNN_FILTER, idx.data_ptr(), dst.data_ptr(),
+                                   small.data_ptr(), small.numel(), None)
+    assert rc == -3 and b"workspace" in lib.dh_last_error_string()  # DH_ERR_WORKSPACE
+    assert lib.dh_knn_bruteforce_f32(20000, 16, x.data_ptr(), 16, 0, 20000, 5, 7, idx.data_ptr(), dst.data_ptr(), small.data_ptr(),
+                                     small.numel(), None) < 0 and b"algo" in lib.dh_last_error_string()
+    a16 = torch.zeros((64, 64), dtype=torch.bfloat16, device=cuda_device)
+    out = torch.zeros((64, 64), dtype=torch.float32, device=cuda_device)
+    assert lib.dh_gemm_bf16(64, 64, 64, 1, 0, a16.data_ptr(), 64, a16.data_ptr(), 64, out.data_ptr(), 64, 0, None, 0, 0, None, 0, None) == -3
+    assert lib.dh_gemm_bf16(64, 64, 64, 0, 1, a16.data_ptr(), 64, a16.data_ptr(), 64, out.data_ptr(), 64, 9, None, 0, 0, None, 0, None) < 0
 
 
 @pytest.mark.parametrize("width", [256, 512, 1024])
