@@ -18,6 +18,36 @@ class _Frame(dict):
     """ndata / edata: name -> tensor."""
 
 
+class _GatherFrame(dict):
+    """srcdata / dstdata of a block: rows ``ids`` of the parent graph's node data, gathered on first access (a batch
+    only ever touches ``features``, ``cell_id`` and ``label``; gathering every ndata entry per batch was a measurable
+    part of the per-batch cost).  Entries assigned on the block live in the dict itself."""
+
+    def __init__(self, parent: Dict[str, torch.Tensor], ids: torch.Tensor):
+        super().__init__()
+        self._parent, self._ids = parent, ids
+
+    def __missing__(self, key):
+        val = self._parent[key][self._ids]  # KeyError of the parent propagates
+        self[key] = val
+        return val
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._parent
+
+    def keys(self):
+        return list(dict.fromkeys(list(dict.keys(self)) + list(self._parent.keys())))
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def __iter__(self):
+        return iter(self.keys())
+
+    def __len__(self):
+        return len(self.keys())
+
+
 class CellGeneGraph:
 
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, eid: Optional[torch.Tensor],
@@ -130,9 +160,10 @@ class Block:
     def __init__(self, rowptr, col, val, num_src: int, num_dst: int, src_ids: torch.Tensor, parent: CellGeneGraph):
         self.rowptr, self.col, self.val = rowptr, col, val
         self._num_src, self._num_dst = int(num_src), int(num_dst)
-        self.srcdata = _Frame({k: v[src_ids] for k, v in parent.ndata.items()})
+        self.srcdata = _GatherFrame(parent.ndata, src_ids)
         self.srcdata["_ID"] = src_ids
-        self.dstdata = _Frame({k: v[:num_dst] for k, v in self.srcdata.items()})
+        self.dstdata = _GatherFrame(parent.ndata, src_ids[:num_dst])  # destination nodes = the first num_dst sources
+        self.dstdata["_ID"] = src_ids[:num_dst]
         self.edata = _Frame(weight=val[:, None])
 
     def number_of_dst_nodes(self) -> int:
@@ -169,16 +200,18 @@ def _full_in_block(g: CellGeneGraph, seeds: torch.Tensor) -> Block:
     """All in-edges of ``seeds``; source nodes = seeds first, then the remaining in-neighbours (ascending id)."""
     dev = g.device
     seeds = seeds.to(dev).to(torch.int64)
-    rp = g.rowptr.to(torch.int64)
-    start, deg = rp[seeds], rp[seeds + 1] - rp[seeds]
+    start = g.rowptr[seeds].to(torch.int64)
+    deg = g.rowptr[seeds + 1].to(torch.int64) - start
     brp = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
     brp[1:] = torch.cumsum(deg, 0)
     total = int(brp[-1])
     pos = torch.repeat_interleave(start - brp[:-1], deg) + torch.arange(total, device=dev)
     gcol = g.col[pos].to(torch.int64)
-    is_seed = torch.zeros(g.number_of_nodes(), dtype=torch.bool, device=dev)
-    is_seed[seeds] = True
-    others = torch.unique(gcol[~is_seed[gcol]])  # sorted
+    # remaining in-neighbours in ascending id order: a node bitmap instead of sorting the 200-per-cell edge list
+    mark = torch.zeros(g.number_of_nodes(), dtype=torch.bool, device=dev)
+    mark[gcol] = True
+    mark[seeds] = False
+    others = torch.nonzero(mark).reshape(-1)
     src_ids = torch.cat((seeds, others))
     lut = torch.empty(g.number_of_nodes(), dtype=torch.int64, device=dev)
     lut[src_ids] = torch.arange(src_ids.numel(), device=dev)
@@ -215,7 +248,7 @@ class DataLoader:
     def __init__(self, graph: CellGeneGraph, indices, sampler: NeighborSampler, batch_size: int = 1,
                  shuffle: bool = False, drop_last: bool = False, generator: Optional[torch.Generator] = None, **_ignored):
         self.graph, self.sampler = graph, sampler
-        self.indices = torch.as_tensor(indices, dtype=torch.int64)
+        self.indices = torch.as_tensor(indices, dtype=torch.int64).to(graph.device)  # seeds live where the graph lives
         self.batch_size, self.shuffle, self.drop_last, self.generator = batch_size, shuffle, drop_last, generator
 
     def __len__(self):
@@ -225,7 +258,10 @@ class DataLoader:
     def __iter__(self):
         idx = self.indices
         if self.shuffle:
-            idx = idx[torch.randperm(idx.numel(), generator=self.generator)]
+            # shuffled on the device (a host randperm of 1M seeds cost more than a whole epoch of kernels); a user-supplied
+            # generator keeps its own (host) stream for reproducibility
+            perm = (torch.randperm(idx.numel(), device=idx.device) if self.generator is None else
+                    torch.randperm(idx.numel(), generator=self.generator).to(idx.device))
+            idx = idx[perm]
         for i in range(len(self)):
-            seeds = idx[i * self.batch_size:(i + 1) * self.batch_size]
-            yield self.sampler.sample(self.graph, seeds.to(self.graph.device))
+            yield self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size])

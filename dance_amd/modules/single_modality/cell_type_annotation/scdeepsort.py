@@ -107,10 +107,10 @@ class ScDeepSort(BaseClassificationMethod):
         labels = torch.as_tensor(labels)
         self.num_labels = labels.max().item() + 1
 
-        perm = torch.randperm(num_cells) + num_genes
+        perm = torch.randperm(num_cells, device=self.device) + num_genes  # (scdeepsort.py:157-160, drawn on the device)
         num_val = int(num_cells * val_ratio)
-        val_idx = perm[:num_val].to(self.device)
-        train_idx = perm[num_val:].to(self.device)
+        val_idx = perm[:num_val]
+        train_idx = perm[num_val:]
 
         full_labels = -torch.ones(num_genes + num_cells, dtype=torch.long)
         full_labels[-num_cells:] = labels.cpu()
@@ -148,7 +148,7 @@ class ScDeepSort(BaseClassificationMethod):
     def cal_loss(self, graph, idx: torch.Tensor):
         self.model.train()
         total_loss = total_size = 0
-        dataloader = DataLoader(graph=graph, indices=idx.cpu(), sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
+        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
         for _, _, blocks in dataloader:
             input_features = blocks[0].srcdata["features"]
             output_labels = blocks[-1].dstdata["label"]
@@ -165,7 +165,7 @@ class ScDeepSort(BaseClassificationMethod):
     def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0):
         self.model.eval()
         total_correct = total_unsure = 0
-        dataloader = DataLoader(graph=graph, indices=idx.cpu(), sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
+        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
         for _, _, blocks in dataloader:
             input_features = blocks[0].srcdata["features"]
             output_labels = blocks[-1].dstdata["label"]
