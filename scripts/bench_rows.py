@@ -192,7 +192,21 @@ def main():
         rows[f"ScDeepSort.fit 1 epoch (train + 2 eval passes) cells={n_cells} batch={bs} compute_dtype={cd}"] = dict(
             ms=dt * 1e3, cells_per_s=n_cells / dt, hip_kernels_calls_total_ms=ks,
             note="includes the block sampler (torch index ops) and checkpoint save per the reference's fit loop")
-    del feats, feats16, rowptr, gcol, gval, eid, cg
+    # ---- config C4 on one GPU: GraphSC.fit, one epoch of the GAE (two forwards per batch as in graphsc.py:202,215), 50 -> 200 -> 300 ----
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    cg50 = cg.with_ndata(features=feats[:, :50].contiguous())
+    for bsz in (8192, ):
+        gs = GraphSC(in_feats=50, n_clusters=10, device="cuda")
+        gs.fit(cg50, epochs=1, batch_size=bsz)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gs.fit(cg50, epochs=1, batch_size=bsz)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rows[f"GraphSC.fit 1 epoch cells={n_cells} batch={bsz} (reference default batch is 128)"] = dict(
+            ms=dt * 1e3, cells_per_s=n_cells / dt, note="per batch: block sampling, WeightedGraphConv x1, Linear, z z^T, dense "
+            "dst x dst adjacency + weighted BCE, Adam; embeddings of all cells collected on the host as the reference does")
+    del feats, feats16, rowptr, gcol, gval, eid, cg, cg50
 
     # ---- SpaGCN-shape layer 50 -> 50 with bias, k = 15 -----------------------------------------------------
     from dance_amd.autograd import gcn_layer
