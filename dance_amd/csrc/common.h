@@ -38,8 +38,10 @@ int knn_filter_padded_d(int64_t d);
 int64_t knn_filter_k3(int64_t d);
 void knn_filter_sample(int64_t n, int64_t d, const float* X, int64_t ldx, int rs, float* Xs, hipStream_t st);
 int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const float* Xr, int64_t ldr, int64_t dr,
-                      int64_t q_begin, int64_t nq, int k, const float* sample_d2, uint16_t* A2, uint16_t* B2, float* norms,
-                      float* Rq, float* Cn, int32_t* counts, int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st);
+                      int64_t q_begin, int64_t nq, int k, const float* sample_d2, float* mean_ws, uint16_t* A2, uint16_t* B2,
+                      float* norms, float* Rq, float* Cn, int32_t* counts, int32_t* surv, int32_t* out_idx, float* out_dist,
+                      hipStream_t st);
+size_t knn_filter_mean_floats(int64_t d);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

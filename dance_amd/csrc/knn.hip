@@ -276,7 +276,7 @@ struct Layout {
   int dch;                       // padded width of the register kernel (0: d > 64)
   int64_t S;                     // sample size (filter)
   int cap;                       // survivor list capacity per query (filter)
-  size_t partial, xp, xs, norms, rq, cn, a2, b2, counts, surv, total;
+  size_t partial, xp, xs, mean, norms, rq, cn, a2, b2, counts, surv, total;
 };
 
 Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
@@ -297,6 +297,7 @@ Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
     L.cap = n_seg * seg;
     const size_t K3 = (size_t)dh::knn_filter_k3(d);
     L.xs = take((size_t)L.S * (L.dch ? L.dch : d) * sizeof(float));
+    L.mean = take(dh::knn_filter_mean_floats(d) * sizeof(float));
     L.norms = take((size_t)n * sizeof(float));
     L.rq = take((size_t)nq * sizeof(float));
     L.cn = take((size_t)n * sizeof(float));
@@ -385,7 +386,7 @@ extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64
   const int rs = L.dch ? L.dch : (int)d;
   dh::knn_filter_sample(n, d, X, ldx, rs, Xs, st);
   scan_launch(L.S, d, L.dch, Q, ldq, Xs, rs, q_begin, q_end, k, L.P, true, ws + L.partial, out_idx, out_dist, st);
-  return dh::knn_filter_launch(n, d, X, ldx, Q, ldq, L.dch ? L.dch : d, q_begin, nq, k, out_dist,
+  return dh::knn_filter_launch(n, d, X, ldx, Q, ldq, L.dch ? L.dch : d, q_begin, nq, k, out_dist, reinterpret_cast<float*>(ws + L.mean),
                                reinterpret_cast<uint16_t*>(ws + L.a2), reinterpret_cast<uint16_t*>(ws + L.b2),
                                reinterpret_cast<float*>(ws + L.norms), reinterpret_cast<float*>(ws + L.rq),
                                reinterpret_cast<float*>(ws + L.cn), reinterpret_cast<int32_t*>(ws + L.counts),

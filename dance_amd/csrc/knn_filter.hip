@@ -21,7 +21,10 @@
 //   the chain itself vs the real d2                       <= 2 (d + 2) u (|q|^2 + |c|^2)
 // with sum|q_i c_i| <= (|q|^2 + |c|^2) / 2 and the factor 2 in front of the dot product:
 //   |d2~ - d2_chain| <= (|q|^2 + |c|^2) (3.1 * 2^-16 + (6d + 10) u)  <  (|q|^2 + |c|^2) (2^-13 + d 2^-20) / 2.
-// Inputs must be finite.
+// The margin scales with the NORMS, so the filter works on CENTRED copies x' = fl(x - mu), mu = column means: distances
+// are translation invariant (any mu is admissible — its rounding only costs efficiency), the subtraction's own rounding
+// moves d2 by <= 2 |x-y| u (|x'| + |y'|) <= 4 u (|x'|^2 + |y'|^2), well inside the slack above, and embeddings with a
+// large common offset (or non-negative expression rows) no longer inflate the survivor lists.  Inputs must be finite.
 #include "gemm_bf16_tile.h"
 
 namespace {
@@ -32,10 +35,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float widen(unsigned int h) { return __uint_as_float(h << 16); }
 
-// norms[r] = sum_t x[r][t]^2 (one wavefront per row); A2[r] = [hi | hi | lo | 0], B2[r] = [hi | lo | hi | 0], each part
-// dp wide, rows K3 = roundup(3 dp, 16) long
-__global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx, int dp,
-                                                        int64_t K3, uint16_t* __restrict__ A2, uint16_t* __restrict__ B2,
+// column sums of X in two deterministic stages: partial[b][t] over the rows b, b + gridDim.x, ... ; mu[t] = sum_b / n
+__global__ __launch_bounds__(256) void knn_colsum_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
+                                                         float* __restrict__ partial) {
+  for (int64_t t = threadIdx.x; t < d; t += 256) {
+    float s = 0.f;
+    for (int64_t r = blockIdx.x; r < n; r += gridDim.x) s += X[r * ldx + t];
+    partial[(int64_t)blockIdx.x * d + t] = s;
+  }
+}
+__global__ __launch_bounds__(256) void knn_mean_kernel(int64_t n, int64_t d, int n_partial, const float* __restrict__ partial,
+                                                       float* __restrict__ mu) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= d) return;
+  float s = 0.f;
+  for (int b = 0; b < n_partial; ++b) s += partial[(int64_t)b * d + t];
+  mu[t] = s / (float)n;
+}
+
+// x' = x - mu; norms[r] = sum_t x'[r][t]^2 (one wavefront per row); A2[r] = [hi | hi | lo | 0], B2[r] = [hi | lo | hi | 0] of
+// x', each part dp wide, rows K3 = roundup(3 dp, 16) long
+__global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
+                                                        const float* __restrict__ mu, int dp, int64_t K3,
+                                                        uint16_t* __restrict__ A2, uint16_t* __restrict__ B2,
                                                         float* __restrict__ norms) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -46,7 +68,7 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
   for (int t = 3 * dp + lane; t < K3; t += 64) a[t] = b[t] = 0;
   float s = 0.f;
   for (int t = lane; t < dp; t += 64) {
-    const float v = t < d ? x[t] : 0.f;
+    const float v = t < d ? x[t] - mu[t] : 0.f;
     s = fmaf(v, v, s);
     const unsigned int hi = f32_to_bf16(v);
     const unsigned int lo = f32_to_bf16(v - widen(hi));  // exact subtraction: hi is v rounded to 8 bits
@@ -328,6 +350,9 @@ __global__ __launch_bounds__(256) void knn_sample_kernel(int64_t S, int64_t stri
 
 namespace dh {
 
+constexpr int64_t kMeanBlocks = 1024;
+size_t knn_filter_mean_floats(int64_t d) { return (size_t)(kMeanBlocks + 1) * (size_t)d; }  // mu[d] + partial[1024][d]
+
 int64_t knn_filter_sample_size(int64_t n) {
   int64_t S = n / 64;
   if (S < 4096) S = 4096;
@@ -384,12 +409,15 @@ void knn_filter_sample(int64_t n, int64_t d, const float* X, int64_t ldx, int rs
 // d <= 64, X itself otherwise.
 int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const float* Xr, int64_t ldr, int64_t dr,
                       int64_t q_begin, int64_t nq, int k,
-                      const float* sample_d2, uint16_t* A2, uint16_t* B2, float* norms, float* Rq, float* Cn, int32_t* counts,
-                      int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st) {
+                      const float* sample_d2, float* mean_ws, uint16_t* A2, uint16_t* B2, float* norms, float* Rq, float* Cn,
+                      int32_t* counts, int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st) {
   const int dp = knn_filter_padded_d(d);
   const int64_t K3 = knn_filter_k3(d);
   const float eps = 1.220703125e-4f + (float)d * 9.5367431640625e-7f;  // 2^-13 + d 2^-20
-  hipLaunchKernelGGL(knn_split_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, dp, K3, A2, B2, norms);
+  const int n_partial = (int)(n < kMeanBlocks ? n : kMeanBlocks);
+  hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)n_partial), dim3(256), 0, st, n, d, X, ldx, mean_ws + d);
+  hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, n, d, n_partial, mean_ws + d, mean_ws);
+  hipLaunchKernelGGL(knn_split_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, A2, B2, norms);
   hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, q_begin, nq, k, eps, norms,
                      sample_d2, Rq, Cn, counts);
   int n_seg, seg;

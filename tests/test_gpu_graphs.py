@@ -101,7 +101,8 @@ def _knn_both(x, k, cuda_device, q=None):
 @pytest.mark.parametrize("n,d,k,kind", [
     (40_000, 50, 15, "normal"),        # PCA-like embedding, register-kernel sample scan
     (33_000, 130, 10, "normal"),       # d > 64: LDS-tiled sample scan, unpadded re-rank
-    (36_000, 50, 15, "offset"),        # |x|^2 >> neighbour distances: wide filter margin
+    (36_000, 50, 15, "offset"),        # |x|^2 >> neighbour distances (the filter centres the data first)
+    (33_000, 24, 8, "far_offset"),     # common offset 1000x the spread: centring is what keeps the margin small
     (34_000, 6, 64, "integer"),        # massive exact ties, k = 64
     (50_000, 20, 1, "clustered"),
 ])
@@ -111,6 +112,8 @@ def test_knn_filter_equals_scan(cuda_device, n, d, k, kind):
         x = rng.standard_normal((n, d))
     elif kind == "offset":
         x = rng.standard_normal((n, d)) + 40.0
+    elif kind == "far_offset":
+        x = rng.standard_normal((n, d)) + 1000.0
     elif kind == "integer":
         x = rng.integers(-3, 4, size=(n, d))
     else:
