@@ -12,7 +12,7 @@
 //
 // Scan mapping: one lane per query (256 queries per block), the query's features in registers.  d <= 64: candidate
 // rows are wave-uniform, so they arrive through scalar loads as SGPR operands (knn_sreg_kernel).  d > 64: features
-// in chunks of 16, 16 candidates per LDS tile broadcast to all lanes (knn_big_kernel).  Each lane keeps its
+// in blocks of 32 per 32 candidates, the candidates' features again through scalar loads (knn_big_kernel).  Each lane keeps its
 // current k-th best (tau) in registers; a candidate that beats tau replaces the worst entry of the lane's unsorted
 // list (LDS for k <= 32, else the output arrays themselves).  For random data a query sees only ~k ln(N/k)
 // insertions, so the kernels are bound by the 3 VALU ops per (pair, feature).
@@ -159,18 +159,21 @@ __global__ __launch_bounds__(256) void knn_pad_kernel(int64_t n, int64_t d, cons
   Xp[i] = t < d ? X[r * ldx + t] : 0.f;
 }
 
-// d > 64: features in chunks of 16; 16 candidates per tile with one register accumulator each.
+// d > 64: the query row no longer fits in registers, so the scan is blocked: CT candidates x FC features at a time.
+// Per block of work a lane loads FC features of its query (one 128-byte line), then for each of the CT candidates the
+// matching FC features arrive through scalar loads (wave-uniform row, SGPR operands as in knn_sreg_kernel) and extend
+// that candidate's accumulator — features strictly in ascending order for every pair, so the chain is the defined one.
+// No LDS staging and no barriers (the previous LDS-tiled form ran at 0.21 of the VALU rate).
 __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
                                                      const float* __restrict__ C, int64_t ldc, int64_t q_begin, int64_t q_end,
                                                      int k, bool lds_list, bool raw_d2, int32_t* __restrict__ out_idx,
                                                      float* __restrict__ out_dist) {
-  constexpr int CT = 16, DCH = 16;
+  constexpr int CT = 32, FC = 32;
   const int64_t cand_lo = n * blockIdx.y / gridDim.y, cand_hi = n * (blockIdx.y + 1) / gridDim.y;
   const int64_t nq_all = q_end - q_begin;
   if (gridDim.y > 1) { out_idx += (int64_t)blockIdx.y * nq_all * k; out_dist += (int64_t)blockIdx.y * nq_all * k; }
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* cand = reinterpret_cast<float*>(smem);  // [CT][DCH]
-  float* ld = cand + CT * DCH;
+  float* ld = reinterpret_cast<float*>(smem);
   int* li = reinterpret_cast<int*>(ld + (lds_list ? k * QB : 0));
 
   const int tid = threadIdx.x;
@@ -185,29 +188,42 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
   int cnt = 0, tau_i = 0x7fffffff, tau_pos = 0;
   float tau_d = __int_as_float(0x7f800000);
 
+  const int64_t d_full = d / FC * FC;
   for (int64_t c0 = cand_lo; c0 < cand_hi; c0 += CT) {
+    const int lim = (int)min((int64_t)CT, cand_hi - c0);  // wave-uniform
     float acc[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) acc[c] = 0.f;
-    for (int64_t t0 = 0; t0 < d; t0 += DCH) {
-      __syncthreads();
-      {
-        const int c = tid / DCH, t = tid % DCH;  // 256 threads == CT * DCH
-        cand[tid] = (c0 + c < cand_hi && t0 + t < d) ? C[(c0 + c) * ldc + t0 + t] : 0.f;
-      }
-      float x[DCH];
+    for (int64_t t0 = 0; t0 < d_full; t0 += FC) {
+      float x[FC];
 #pragma unroll
-      for (int t = 0; t < DCH; ++t) x[t] = (t0 + t < d) ? xq[t0 + t] : 0.f;
-      __syncthreads();
+      for (int t = 0; t < FC; ++t) x[t] = xq[t0 + t];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
+        if (c < lim) {
+          const float* __restrict__ y = C + (c0 + c) * ldc + t0;  // wave-uniform address -> scalar loads
 #pragma unroll
-        for (int t = 0; t < DCH; t += 4) {
-          const f32x4 y = *reinterpret_cast<const f32x4*>(cand + c * DCH + t);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float diff = __fsub_rn(x[t + u], y[u]);
+          for (int t = 0; t < FC; ++t) {
+            const float diff = __fsub_rn(x[t], y[t]);
             acc[c] = __fadd_rn(acc[c], __fmul_rn(diff, diff));
+          }
+        }
+      }
+    }
+    if (d_full < d) {  // last, partial feature block: guarded element by element (uniform guards)
+      float x[FC];
+#pragma unroll
+      for (int t = 0; t < FC; ++t) x[t] = (d_full + t < d) ? xq[d_full + t] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (c < lim) {
+          const float* __restrict__ y = C + (c0 + c) * ldc + d_full;
+#pragma unroll
+          for (int t = 0; t < FC; ++t) {
+            if (d_full + t < d) {
+              const float diff = __fsub_rn(x[t], y[t]);
+              acc[c] = __fadd_rn(acc[c], __fmul_rn(diff, diff));
+            }
           }
         }
       }
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(QB) void knn_big_kernel(int64_t n, int64_t d, const
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const int64_t ci = c0 + c;
-      if (valid && ci < cand_hi && (cnt < k || before(acc[c], (int)ci, tau_d, tau_i)))
+      if (valid && c < lim && (cnt < k || before(acc[c], (int)ci, tau_d, tau_i)))
         insert(L, k, cnt, tau_d, tau_i, tau_pos, acc[c], (int)ci);
     }
   }
@@ -337,7 +353,7 @@ void scan_launch(int64_t n_cand, int64_t d, int dch, const float* Q, int64_t ldq
     DH_KNN_SMALL(28); DH_KNN_SMALL(32); DH_KNN_SMALL(36); DH_KNN_SMALL(40); DH_KNN_SMALL(44); DH_KNN_SMALL(48);
     DH_KNN_SMALL(52); DH_KNN_SMALL(56); DH_KNN_SMALL(60); DH_KNN_SMALL(64);
     default:
-      hipLaunchKernelGGL(knn_big_kernel, grid, block, 16 * 16 * sizeof(float) + list_bytes, st, n_cand, d, Q, ldq, C, ldc,
+      hipLaunchKernelGGL(knn_big_kernel, grid, block, list_bytes, st, n_cand, d, Q, ldq, C, ldc,
                          q_begin, q_end, k, lds_list, raw_d2, k_idx, k_dist);
   }
 #undef DH_KNN_SMALL
