@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(int64_t M, int64_t N,
   const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM, n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
   const int64_t k_begin = (int64_t)blockIdx.z * k_per_slice;
   const int64_t k_end = min(K, k_begin + k_per_slice);
-  nt_tile(M, N, k_begin, k_end, A, lda, B, ldb, m0, n0, As, Bs, [&](int64_t m, int64_t n, float v) {
+  nt_tile(M, N, k_begin, k_end, A, lda, B, ldb, m0, n0, As, Bs, [&](int64_t m, int64_t n, float v, int) {
     if (slabs) slabs[((int64_t)blockIdx.z * M + m) * N + n] = v;
     else store_out(C, ldc, m, n, v, ep);
   });

@@ -2,7 +2,8 @@
 // K-contiguous (shared by gemm_bf16.hip and the kNN filter, knn_filter.hip).  4 waves (2x2) of 64x64 = 2x2
 // v_mfma_f32_32x32x16_bf16 tiles; LDS images [128][72] bf16 (144-byte rows: the 16-byte fragment reads of 32
 // consecutive rows fall on distinct 4-bank slots); the next K-step's global loads are issued before the MFMAs of the
-// current one.  `epi(m, n, value)` is called once per in-range output element.
+// current one.  `epi(m, n, value, e)` is called once per in-range output element; e = (i * 2 + j) * 16 + r numbers
+// the lane's 64 elements (compile-time constant at every call site after unrolling).
 #pragma once
 #include "common.h"
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ void nt_tile(int64_t M, int64_t N, int64_t k_begin, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < M) epi(m, n, acc[i][j][r]);
+        if (m < M) epi(m, n, acc[i][j][r], (i * 2 + j) * 16 + r);
       }
     }
 }

@@ -113,13 +113,23 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
     const int64_t c = n0 + wn * 64 + j * 32 + (lane & 31);
     cn[j] = c < n ? Cn[c] : 0.f;
   }
-  nt_tile(nq, n, 0, K3, A2, K3, B2, K3, m0, n0, As, Bs, [&](int64_t m, int64_t c, float dot) {
-    const float cnj = ((c - n0 - wn * 64) >> 5) ? cn[1] : cn[0];
-    if (fmaf(-2.f, dot, cnj) <= rq[m - m0]) {
-      const int pos = atomicAdd(&counts[m], 1);
-      if (pos < cap) surv[m * cap + pos] = (int32_t)c;
-    }
+  // pass bits first (branch-free), appends afterwards: an in-line "if (pass) atomicAdd" per element serialises one
+  // returning global atomic per hit (see the query-stationary kernel below)
+  unsigned long long hits = 0ull;
+  nt_tile(nq, n, 0, K3, A2, K3, B2, K3, m0, n0, As, Bs, [&](int64_t m, int64_t c, float dot, int e) {
+    const float cnj = ((e >> 4) & 1) ? cn[1] : cn[0];
+    hits |= (unsigned long long)(fmaf(-2.f, dot, cnj) <= rq[m - m0] ? 1u : 0u) << e;
   });
+  const int wm = threadIdx.x >> 7;
+  while (hits) {
+    const int e = __ffsll((long long)hits) - 1;
+    hits &= hits - 1;
+    const int i = e >> 5, j = (e >> 4) & 1, r = e & 15;
+    const int64_t m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int64_t c = n0 + wn * 64 + j * 32 + (lane & 31);
+    const int pos = atomicAdd(&counts[m], 1);
+    if (pos < cap) surv[m * cap + pos] = (int32_t)c;
+  }
 }
 
 // d <= 64 (K3 <= 192): "query-stationary" form of the same filter.  The tile kernel above re-reads both operands for
