@@ -104,10 +104,10 @@ size_t round256(size_t b) { return (b + 255) / 256 * 256; }
 Plan make_plan(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb) {
   Plan p{};
   p.kp = (K + 7) / 8 * 8;
-  // native = K-contiguous, 16-byte aligned rows, K a multiple of 8 (A == null: planning for the worst case)
+  // native = K-contiguous, 16-byte aligned rows, K a multiple of 8 (A == null: the size query, which assumes that
+  // K-contiguous operands ARE aligned — the caller aligns them or gets DH_ERR_WORKSPACE)
   p.repack_a = trans_a || K % 8 != 0 || (A && (lda % 8 != 0 || !dh::aligned16(A)));
   p.repack_b = !trans_b || K % 8 != 0 || (B && (ldb % 8 != 0 || !dh::aligned16(B)));
-  if (!A) p.repack_a = p.repack_b = true;
   p.a_bytes = p.repack_a ? round256((size_t)M * p.kp * 2) : 0;
   p.b_bytes = p.repack_b ? round256((size_t)N * p.kp * 2) : 0;
   const int64_t tiles = dh::ceil_div(M, BM) * dh::ceil_div(N, BN);

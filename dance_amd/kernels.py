@@ -279,6 +279,11 @@ def gemm_bf16(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_
         if accumulate:
             raise ValueError("gemm_bf16: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    # K-contiguous operands are read in place when their rows are 16-byte aligned; make them so (the size query assumes it)
+    if not trans_a and K % 8 == 0 and (A.data_ptr() % 16 or _ld(A) % 8):
+        A = A.contiguous()
+    if trans_b and K % 8 == 0 and (B.data_ptr() % 16 or _ld(B) % 8):
+        B = B.contiguous()
     ws_bytes = lib.dh_gemm_bf16_workspace_bytes(M, N, K, int(trans_a), int(trans_b))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None
     tag = tag or f"gemm_bf16_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"

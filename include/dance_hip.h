@@ -255,6 +255,9 @@ DH_API int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
  * dh_gemm_bf16: C = act(op(A) op(B) + bias) (+ C), bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16 —
  *   nn.Linear of AdaptiveSAGE (gnn.py:56-58,93-94: x W^T + b, then the activation) and its two gradient products.
  *   op(A) is [M,K] (stored [K,M] if trans_a), op(B) is [K,N] (stored [N,K] if trans_b); bias [N] fp32 or NULL.
+ *   K-contiguous operands are read in place when their rows are 16-byte aligned (base pointer and leading dimension
+ *   multiples of 8 elements, K % 8 == 0); the workspace query assumes that, anything else is repacked into the
+ *   workspace (K-strided operands always are).
  * dh_relu_backward_bf16 / dh_colsum_bf16: G = dY * [Y > 0]; out[j] = sum_i X[i,j] in fp32 (workspace as
  *   dh_colsum_f32_workspace_bytes).                                                                              */
 DH_API int dh_spmm_csr_bf16(int64_t n_rows, int64_t n_cols, int64_t width,

@@ -20,3 +20,16 @@ for width in (512, 256, 128, 64, 32):
     dt = (time.perf_counter() - t) / 5
     byt = n * k * 8.0 + 4.0 * (n + 1) + n * k * width * 4.0 + n * width * 4.0
     print(f"width {width:4d}: {dt*1e3:.3f} ms  {byt/dt/1e9:.0f} GB/s algorithmic", flush=True)
+
+# the same 128-wide pass through the float2 configuration (8-byte aligned view): one wavefront per row, VEC = 2
+big = torch.randn(n, 132, device=dev, generator=g)
+z2 = big[:, 2:130]
+out = torch.empty(n, 132, device=dev)[:, 2:130]
+for _ in range(2):
+    kernels.spmm_csr(rowptr, col, val, z2, act=kernels.ACT_RELU, out=out)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for _ in range(5):
+    kernels.spmm_csr(rowptr, col, val, z2, act=kernels.ACT_RELU, out=out)
+torch.cuda.synchronize()
+print(f"width  128 via float2 lanes (G=64): {(time.perf_counter() - t) / 5 * 1e3:.3f} ms", flush=True)

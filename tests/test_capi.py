@@ -51,3 +51,25 @@ def test_product_never_imports_oracle():
             if f.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(d, f)).read(), re.M):
                 bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_workspace_size_queries_need_no_device():
+    """The *_workspace_bytes entry points are pure host arithmetic: callable on a CPU-only box, consistent with the
+    contracts in include/dance_hip.h."""
+    from dance_amd import _lib
+    lib = _lib.load()
+    n, d, k = 1_000_000, 50, 15
+    scan = lib.dh_knn_bruteforce_f32_workspace_bytes(n, d, n, k, 1)
+    filt = lib.dh_knn_bruteforce_f32_workspace_bytes(n, d, n, k, 2)
+    assert scan == n * 52 * 4                      # only the zero-padded copy (d = 50 -> 52 columns)
+    assert filt > scan + 2 * n * 176 * 2           # + the two bf16x3 operand matrices (K3 = 176) and the survivor lists
+    assert lib.dh_knn_bruteforce_f32_workspace_bytes(n, d, n, k, 0) == filt        # auto -> filter at this size
+    assert lib.dh_knn_bruteforce_f32_workspace_bytes(1000, d, 1000, k, 0) == lib.dh_knn_bruteforce_f32_workspace_bytes(1000, d, 1000, k, 1)
+    assert lib.dh_knn_bruteforce_f32_workspace_bytes(0, d, 0, k, 0) == 0
+    assert lib.dh_relu_mask_bytes(n, 512) == n * 512 // 8 and lib.dh_relu_mask_bytes(n, 50) == 0
+    # headline dW GEMM: 16 tiles x 64 K-slices of fp32 slabs; the forward GEMM needs none
+    assert lib.dh_gemm_f32_workspace_bytes(2000, 512, n, 1, 0) == 64 * 2000 * 512 * 4
+    assert lib.dh_gemm_f32_workspace_bytes(n, 512, 2000, 0, 0) == 0
+    # bf16: the native NT form needs no workspace, K-strided operands are repacked
+    assert lib.dh_gemm_bf16_workspace_bytes(n, 200, 400, 0, 1) == 0
+    assert lib.dh_gemm_bf16_workspace_bytes(n, 400, 200, 0, 0) >= 400 * 200 * 2
