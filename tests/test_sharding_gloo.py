@@ -66,9 +66,12 @@ def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode=
 
 @pytest.mark.parametrize("world,n,use_bias,active,mode", [(2, 101, False, True, "allgather"), (2, 64, True, False, "allgather"),
                                                          (3, 50, True, True, "allgather"), (2, 101, True, True, "alltoall"),
-                                                         (3, 50, False, True, "alltoall")])
+                                                         (3, 50, False, True, "alltoall"),
+                                                         # the driver's scaling run goes to 4 and 8 ranks
+                                                         (4, 90, True, True, "allgather"), (8, 100, False, True, "alltoall"),
+                                                         (8, 37, True, True, "alltoall")])
 def test_sharded_layer_matches_oracle(world, n, use_bias, active, mode):
-    fin, fout, k, seed = 12, 6, 5, 17 + n  # fout divisible by 2 and 3 (alltoall mode slices the layer width)
+    fin, fout, k, seed = 12, 24, 5, 17 + n  # fout divisible by 2, 3, 4 and 8 (alltoall mode slices the layer width)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
