@@ -125,17 +125,18 @@ def relu_mask_bytes(n_rows: int, width: int) -> int:
 def spmm_csr_relu(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], Z: torch.Tensor, *,
                   n_cols: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                   out_mask: Optional[torch.Tensor] = None, in_mask: Optional[torch.Tensor] = None,
-                  tag: str = "spmm_csr_f32") -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, tag: str = "spmm_csr_f32") -> torch.Tensor:
     """dh_spmm_csr_relu_f32: forward records the ReLU sign mask (out_mask), backward applies it to the gathered
     rows (in_mask).  Masks are uint8 tensors of ``relu_mask_bytes`` bytes."""
     lib = _lib_ready()
     n_rows = rowptr.numel() - 1
     width = Z.shape[1]
     n_cols = Z.shape[0] if n_cols is None else n_cols
-    out = torch.empty((n_rows, width), dtype=torch.float32, device=Z.device)
+    if out is None:
+        out = torch.empty((n_rows, width), dtype=torch.float32, device=Z.device)
     _call(tag, lib.dh_spmm_csr_relu_f32, n_rows, n_cols, width, _dev(rowptr, torch.int32, "rowptr", 1),
           _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1), _dev(Z, torch.float32, "Z", 2), _ld(Z),
-          out.data_ptr(), _ld(out), _dev(bias, torch.float32, "bias", 1), act,
+          _dev(out, torch.float32, "out", 2), _ld(out), _dev(bias, torch.float32, "bias", 1), act,
           None if out_mask is None else out_mask.data_ptr(), None if in_mask is None else in_mask.data_ptr(), _stream())
     return out
 
