@@ -137,7 +137,7 @@ extern "C" int dh_gemm_bf16(int64_t M, int64_t N, int64_t K, int trans_a, int tr
                             int accumulate, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
   if (M < 0 || N < 0 || K < 0) return dh::fail(DH_ERR_INVALID, "dh_gemm_bf16: negative size");
   if (M == 0 || N == 0) return DH_OK;
-  if (!A || !B || !C) return dh::fail(DH_ERR_INVALID, "dh_gemm_bf16: null pointer");
+  if (!C || (K > 0 && (!A || !B))) return dh::fail(DH_ERR_INVALID, "dh_gemm_bf16: null pointer");
   if (c_dtype != DH_DTYPE_F32 && c_dtype != DH_DTYPE_BF16) return dh::fail(DH_ERR_INVALID, "dh_gemm_bf16: bad output dtype %d", c_dtype);
   if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_gemm_bf16: bad act %d", act);
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N) return dh::fail(DH_ERR_INVALID, "dh_gemm_bf16: leading dimension too small");

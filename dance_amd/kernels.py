@@ -111,6 +111,8 @@ def sddmm_csr(rowptr: torch.Tensor, col: torch.Tensor, U: torch.Tensor, V: torch
     lib = _lib_ready()
     n_rows = rowptr.numel() - 1
     out = torch.empty(col.numel(), dtype=torch.float32, device=U.device)
+    if col.numel() == 0:
+        return out
     _call("sddmm_csr_f32", lib.dh_sddmm_csr_f32, n_rows, V.shape[0], U.shape[1], _dev(rowptr, torch.int32, "rowptr", 1),
           _dev(col, torch.int32, "col", 1), _dev(scale, torch.float32, "scale", 1), _dev(U, torch.float32, "U", 2), _ld(U),
           _dev(V, torch.float32, "V", 2), _ld(V), out.data_ptr(), _stream())

@@ -211,3 +211,34 @@ def test_spmm_fused_relu_mask(cuda_device, width):
     assert torch.equal(ds, ds_ref)
     with pytest.raises(Exception):
         kernels.spmm_csr_relu(rp, c, v, torch.randn(700, 50, device=cuda_device), act=kernels.ACT_RELU)
+
+
+def test_degenerate_sizes(cuda_device):
+    """Empty inputs are legal and cheap everywhere on the ABI: no rows, no edges, no inner dimension, no queries."""
+    from dance_amd import kernels
+    dev = cuda_device
+    i32 = lambda *v: torch.tensor(v, dtype=torch.int32, device=dev)
+    # SpMM over a graph without edges / without rows
+    z = torch.randn(5, 8, device=dev)
+    y = kernels.spmm_csr(i32(0, 0, 0, 0), i32(), torch.empty(0, device=dev), z, bias=torch.ones(8, device=dev), act=kernels.ACT_RELU)
+    assert torch.equal(y, torch.ones(3, 8, device=dev))                      # empty rows -> act(bias)
+    assert kernels.spmm_csr(i32(0), i32(), None, z).shape == (0, 8)
+    assert kernels.sddmm_csr(i32(0, 0), i32(), z[:1], z).numel() == 0
+    # GEMM with an empty inner dimension: C = 0 (or unchanged when accumulating); empty outputs
+    a, b = torch.empty(4, 0, device=dev), torch.empty(0, 6, device=dev)
+    assert torch.equal(kernels.gemm(a, b), torch.zeros(4, 6, device=dev))
+    acc = torch.full((4, 6), 2.0, device=dev)
+    assert torch.equal(kernels.gemm(a, b, out=acc, accumulate=True), torch.full((4, 6), 2.0, device=dev))
+    assert kernels.gemm(torch.empty(0, 3, device=dev), torch.randn(3, 6, device=dev)).shape == (0, 6)
+    a16, b16 = torch.empty(4, 0, dtype=torch.bfloat16, device=dev), torch.empty(6, 0, dtype=torch.bfloat16, device=dev)
+    out = kernels.gemm_bf16(a16, b16, trans_b=True, bias=torch.arange(6., device=dev) - 2, act=kernels.ACT_RELU, out_dtype=torch.float32)
+    assert torch.equal(out, torch.relu(torch.arange(6., device=dev) - 2).expand(4, 6))
+    # kNN: empty query range; k larger than the number of points pads with (-1, inf)
+    x = torch.randn(6, 4, device=dev)
+    idx, dist = kernels.knn(x, 3, 2, 2)
+    assert idx.shape == (0, 3)
+    idx, dist = kernels.knn(x, 9)
+    assert bool((idx[:, 6:] == -1).all()) and bool(torch.isinf(dist[:, 6:]).all()) and bool((idx[:, 0] == torch.arange(6, device=dev)).all())
+    # reductions / elementwise on empty matrices
+    assert torch.equal(kernels.colsum(torch.empty(0, 5, device=dev)), torch.zeros(5, device=dev))
+    assert kernels.relu_backward(torch.empty(0, 5, device=dev), torch.empty(0, 5, device=dev)).shape == (0, 5)
