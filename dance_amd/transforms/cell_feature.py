@@ -14,13 +14,18 @@ class WeightedFeaturePCA(BaseTransform):
 
     _DISPLAY_ATTRS = ("n_components", "split_name", "feat_norm_mode", "feat_norm_axis")
 
-    def __init__(self, n_components=400, split_name=None, feat_norm_mode=None, feat_norm_axis=0, save_info=False, **kwargs):
+    def __init__(self, n_components=400, split_name=None, feat_norm_mode=None, feat_norm_axis=0, save_info=False, *,
+                 device=None, **kwargs):
         super().__init__(**kwargs)
         self.n_components = n_components
         self.split_name = split_name
         self.feat_norm_mode = feat_norm_mode
         self.feat_norm_axis = feat_norm_axis
         self.save_info = save_info
+        # device=None: scikit-learn on the host, exactly the reference's call.  device="cuda": the exact decomposition on
+        # the GPU (dance_amd.utils.pca) — an explicit opt-in, because sklearn's default solver for these shapes is a
+        # randomised SVD that the exact result only matches to that solver's accuracy.
+        self.device = device
 
     def __call__(self, data):
         feat = data.get_x(self.split_name)  # cells x genes
@@ -30,6 +35,8 @@ class WeightedFeaturePCA(BaseTransform):
             self.logger.warning(f"n_components={self.n_components} must be between 0 and "
                                 f"min(n_samples, n_features)={min(feat.shape)} with svd_solver='full'")
             self.n_components = min(feat.shape)
+        if self.device is not None:
+            return self._call_on_device(data, feat)
         gene_pca = PCA(n_components=self.n_components)
         gene_feat = gene_pca.fit_transform(feat.T)  # genes x components
         x = data.get_x()
@@ -44,23 +51,52 @@ class WeightedFeaturePCA(BaseTransform):
         return data
 
 
+    def _call_on_device(self, data, feat):
+        import torch
+
+        from .. import kernels
+        from ..utils.pca import pca_scores
+        if self.save_info:
+            raise NotImplementedError("save_info needs the cell-space components, which the device path never forms")
+        ft = torch.as_tensor(np.ascontiguousarray(feat.T, dtype=np.float32)).to(self.device)   # genes x cells
+        gene_feat, _, _ = pca_scores(ft, self.n_components)                                      # genes x components
+        x = torch.as_tensor(np.ascontiguousarray(data.get_x(), dtype=np.float32)).to(self.device)
+        cell_feat = kernels.gemm(normalize(x, mode="normalize", axis=1).contiguous(), gene_feat.contiguous())
+        data.data.obsm[self.out] = cell_feat.cpu().numpy()
+        data.data.varm[self.out] = gene_feat.cpu().numpy()
+        return data
+
+
 @register_preprocessor("feature", "cell")
 class CellPCA(BaseTransform):
     """PCA of the cell feature matrix -> obsm[out]."""
 
     _DISPLAY_ATTRS = ("n_components", )
 
-    def __init__(self, n_components=400, *, channel=None, mod=None, save_info=False, svd_solver="auto", **kwargs):
+    def __init__(self, n_components=400, *, channel=None, mod=None, save_info=False, svd_solver="auto", device=None, **kwargs):
         super().__init__(**kwargs)
         self.n_components = n_components
         self.channel = channel
         self.save_info = save_info
         self.svd_solver = svd_solver
+        self.device = device  # None: scikit-learn on the host (reference); "cuda": exact PCA on the GPU (opt-in)
 
     def __call__(self, data):
         feat = data.get_feature(return_type="numpy", channel=self.channel, channel_type="obsm" if self.channel else "X")
         if self.n_components > min(feat.shape):
             self.n_components = min(feat.shape)
+        if self.device is not None:
+            import torch
+
+            from ..utils.pca import pca_scores
+            scores, comps, _ = pca_scores(torch.as_tensor(np.ascontiguousarray(feat, dtype=np.float32)).to(self.device), self.n_components)
+            data.data.obsm[self.out] = scores.cpu().numpy()
+            if self.save_info:
+                if comps is None:
+                    raise NotImplementedError("save_info with more features than samples: components are not formed on the device")
+                data.data.uns["pca_components"] = comps.cpu().numpy()
+                data.data.uns["pca_mean"] = feat.mean(0)
+            return data
         pca = PCA(n_components=self.n_components, svd_solver=self.svd_solver)
         data.data.obsm[self.out] = pca.fit_transform(feat)
         if self.save_info:

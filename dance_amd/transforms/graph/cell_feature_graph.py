@@ -65,8 +65,9 @@ class PCACellFeatureGraph(BaseTransform):
     _DISPLAY_ATTRS = ("n_components", "split_name")
 
     def __init__(self, n_components: int = 400, split_name=None, *, normalize_edges: bool = True, feat_norm_mode=None,
-                 feat_norm_axis: int = 0, mod=None, log_level="WARNING", device="cuda"):
+                 feat_norm_axis: int = 0, mod=None, log_level="WARNING", device="cuda", pca_device=None):
         super().__init__(log_level=log_level)
+        self.pca_device = pca_device  # None: scikit-learn PCA on the host (reference); "cuda": exact PCA on the GPU (opt-in)
         self.n_components = n_components
         self.split_name = split_name
         self.normalize_edges = normalize_edges
@@ -77,7 +78,7 @@ class PCACellFeatureGraph(BaseTransform):
 
     def __call__(self, data):
         WeightedFeaturePCA(self.n_components, self.split_name, feat_norm_mode=self.feat_norm_mode,
-                           feat_norm_axis=self.feat_norm_axis, log_level=self.log_level)(data)
+                           feat_norm_axis=self.feat_norm_axis, log_level=self.log_level, device=self.pca_device)(data)
         CellFeatureGraph(cell_feature_channel="WeightedFeaturePCA", mod=self.mod, normalize_edges=self.normalize_edges,
                          log_level=self.log_level, device=self.device)(data)
         return data
