@@ -228,6 +228,26 @@ def main():
     byt = 1.85e3 * n
     rows[f"GraphConvolution 50->50 fwd+bwd n={n} k=15"] = dict(ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s",
                                                               frac=byt / ms / 1e6 / HBM, cells_per_s=n / ms * 1e3)
+    # ---- A2 preprocessing on the device (opt-in): exact PCA of the gene x cell matrix + the cell-feature projection -------
+    from dance_amd.utils.pca import pca_scores
+    npc, gpc = (100_000 if q else 1_000_000), 2000
+    xt = torch.rand(gpc, npc, device=dev, generator=g)          # genes x cells (WeightedFeaturePCA decomposes X^T)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gene_feat, _, _ = pca_scores(xt, 400)
+    torch.cuda.synchronize()
+    t_pca = (time.perf_counter() - t0) * 1e3
+    xrow = xt.t().contiguous()
+    del xt
+    t0 = time.perf_counter()
+    cell_feat = kernels.gemm(xrow / xrow.sum(1, keepdim=True), gene_feat.contiguous())
+    torch.cuda.synchronize()
+    t_proj = (time.perf_counter() - t0) * 1e3
+    rows[f"device PCA (WeightedFeaturePCA, opt-in) genes={gpc} cells={npc} k=400"] = dict(
+        ms=t_pca + t_proj, pca_ms=t_pca, projection_ms=t_proj,
+        note="Gram matrix over the cells on dh_gemm_f32 + float64 eigh of 2000 x 2000 (torch / rocSOLVER) + U S; then row-normalised X @ gene_feat")
+    del xrow, cell_feat, gene_feat
+
     # ---- SURVEY.md §8d "knn-k15" (realistic locality): clustered cells -> exact kNN -> UMAP connectivities -> GCN layer ----
     del x50, w50, b50, dy, graph
     n, dlat, fin, hid = (100_000 if q else 1_000_000), 50, 2000, 512
