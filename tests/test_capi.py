@@ -73,3 +73,23 @@ def test_workspace_size_queries_need_no_device():
     # bf16: the native NT form needs no workspace, K-strided operands are repacked
     assert lib.dh_gemm_bf16_workspace_bytes(n, 200, 400, 0, 1) == 0
     assert lib.dh_gemm_bf16_workspace_bytes(n, 400, 200, 0, 0) >= 400 * 200 * 2
+
+
+def test_bench_and_smoke_fail_loudly_without_a_gpu():
+    """bench.py and __graft_entry__.smoke() are GPU programs: on a box without a HIP device they raise instead of timing
+    (or checking) some fallback."""
+    import subprocess
+    import sys
+
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is visible here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "no HIP device" in r.stderr and "metric" not in r.stdout
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and "metric" not in r.stdout
+    # a multi-rank request without the launcher is refused before anything is initialised
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
