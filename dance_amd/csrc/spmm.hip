@@ -205,13 +205,14 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
                        width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act,   \
                        reduce, sage);                                                            \
   } while (0)
-  if (VEC == 4 && !SAGE && vecs >= 128 && vecs % 64 == 0) {
-    // Wide rows: one pass per 256-column slice instead of one launch over the whole width.  Every pass gathers from a
-    // working set of n_cols x 1 KB instead of n_cols x width x 4 bytes, which the L2 / MALL hold a larger share of:
-    // measured at 1M rows, k = 15: 2 x 2.45 ms for two 256-wide passes vs 5.44 ms for one 512-wide launch.
-    for (int64_t c = 0; c < width; c += 256) {
-      dim3 grid((unsigned)dh::ceil_div(n_rows, 4), 1);
-      hipLaunchKernelGGL((spmm_csr_kernel<64, VEC, 1, SAGE>), grid, dim3(256), 0, st, n_rows, (int64_t)256, rowptr, col, val,
+  if (VEC == 4 && !SAGE && vecs >= 64 && vecs % 32 == 0) {
+    // Wide rows: one pass per 128-column slice instead of one launch over the whole width.  Every pass gathers from a
+    // working set of n_cols x 512 bytes instead of n_cols x width x 4, which the L2 / MALL hold a larger share of.
+    // Measured at 1M rows, k = 15 (scripts/spmm_width_probe.py): one 512-wide launch 5.44 ms, two 256-wide passes
+    // 4.90 ms, four 128-wide passes (32 lanes per row, two rows per wavefront) 4.54 ms.
+    for (int64_t c = 0; c < width; c += 128) {
+      dim3 grid((unsigned)dh::ceil_div(n_rows, 8), 1);
+      hipLaunchKernelGGL((spmm_csr_kernel<32, VEC, 1, SAGE>), grid, dim3(256), 0, st, n_rows, (int64_t)128, rowptr, col, val,
                          rowscale, colscale, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, sage);
     }
   } else if (vecs > 64) DH_SPMM_LAUNCH(64, 2);
