@@ -181,3 +181,27 @@ def test_refine_pinned_to_reference_code(gold):
     for shape in ("hexagon", "square"):
         got = np.asarray(refine(ids, gold["ref_pred"], gold["ref_dis"], shape=shape), dtype=np.int64)
         assert np.array_equal(got, gold["ref_refined_" + shape])
+
+
+def test_scdeepsort_predict_rule_matches_reference_method():
+    """ScDeepSort.predict (argmax + "unsure" rule, scdeepsort.py:330-349): the reference's own method, lifted and run on a
+    stand-in ``self``, against the mirrored class on the same probabilities (host-side logic only)."""
+    from oracle import ref_extract
+    if not ref_extract.available():
+        pytest.skip("reference tree not mounted")
+    import types
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    ref_predict = ref_extract.extract_method("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "ScDeepSort", "predict",
+                                             {"dgl": types.SimpleNamespace(DGLGraph=object)})  # only a type annotation
+    rng = np.random.default_rng(0)
+    prob = rng.dirichlet(np.ones(5) * 0.7, size=200)
+    prob[:20] = 0.2 + rng.normal(0, 1e-3, (20, 5))     # near-uniform rows: "unsure" at unsure_rate 2 means max < 0.4
+    prob /= prob.sum(1, keepdims=True)
+    stub = types.SimpleNamespace(predict_proba=lambda g: prob, num_labels=5)
+    mine = object.__new__(ScDeepSort)
+    mine.predict_proba, mine.num_labels = (lambda g: prob), 5
+    for rate in (2.0, 1.0, 3.5):
+        r_pred, r_unsure = ref_predict(stub, None, unsure_rate=rate, return_unsure=True)
+        m_pred, m_unsure = mine.predict(None, unsure_rate=rate, return_unsure=True)
+        assert np.array_equal(np.asarray(r_pred), np.asarray(m_pred)) and np.array_equal(np.asarray(r_unsure), np.asarray(m_unsure))
+    assert np.array_equal(np.asarray(ref_predict(stub, None)), np.asarray(mine.predict(None)))
