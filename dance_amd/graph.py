@@ -87,7 +87,21 @@ class CSRGraph:
                              shape=(self.n_rows, self.n_cols))
 
 
-_CACHE = weakref.WeakKeyDictionary()
+# Keyed by IDENTITY (id + a finalizer that evicts the entry when the tensor dies).  A WeakKeyDictionary would compare
+# keys with ``==`` on lookup, and ``aten::eq`` is not implemented for sparse tensors (the second call with the same
+# adjacency raised).
+_CACHE = {}
+
+
+def _cache_get(adj):
+    hit = _CACHE.get(id(adj))
+    return hit[1] if hit is not None and hit[0]() is adj else None
+
+
+def _cache_put(adj, g):
+    key = id(adj)
+    _CACHE[key] = (weakref.ref(adj), g)
+    weakref.finalize(adj, _CACHE.pop, key, None)
 
 
 def as_graph(adj, device=None) -> CSRGraph:
@@ -99,9 +113,9 @@ def as_graph(adj, device=None) -> CSRGraph:
     if isinstance(adj, CSRGraph):
         return adj
     if isinstance(adj, torch.Tensor) and adj.layout in (torch.sparse_coo, torch.sparse_csr):
-        g = _CACHE.get(adj)
+        g = _cache_get(adj)
         if g is None:
             g = CSRGraph.from_torch_sparse(adj, device)
-            _CACHE[adj] = g
+            _cache_put(adj, g)
         return g
     raise TypeError(f"cannot interpret {type(adj)} as a sparse adjacency")

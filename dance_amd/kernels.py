@@ -203,8 +203,22 @@ def bias_act_(X: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE
 
 
 def gaussian_kernel(D: torch.Tensor, l: float, *, want_out: bool = True, want_rowsum: bool = False):
-    """exp(-D^2 / (2 l^2)) of a dense [n, m] matrix; returns (out | None, rowsum | None)."""
+    """exp(-D^2 / (2 l^2)) of a dense [n, m] matrix; returns (out | None, rowsum | None).
+    A 1-d ``D`` (the value array of a kNN-truncated CSR of distances) is processed as a tall [len/256, 256] view plus a
+    tail row, so the launch fills the chip instead of handing the whole array to one wavefront."""
     lib = _lib_ready()
+    if D.dim() == 1:
+        if want_rowsum:
+            raise ValueError("gaussian_kernel: row sums are undefined for a flat value array")
+        total = D.numel()
+        out = torch.empty(total, dtype=torch.float32, device=D.device)
+        base, obase, main = _dev(D, torch.float32, "D", 1), out.data_ptr(), (total // 256) * 256
+        if main:
+            _call("gaussian_kernel_f32", lib.dh_gaussian_kernel_f32, main // 256, 256, base, 256, float(l), obase, 256, None, _stream())
+        if total > main:
+            _call("gaussian_kernel_f32", lib.dh_gaussian_kernel_f32, 1, total - main, base + 4 * main, total - main, float(l),
+                  obase + 4 * main, total - main, None, _stream())
+        return out, None
     n, m = D.shape
     out = torch.empty((n, m), dtype=torch.float32, device=D.device) if want_out else None
     rs = torch.empty(n, dtype=torch.float32, device=D.device) if want_rowsum else None

@@ -53,6 +53,8 @@ class GNN(nn.Module):
 
 class ScDeepSort(BaseClassificationMethod):
 
+    shuffle_generator = None  # host torch.Generator for a reproducible train/val split and batch order (see fit)
+
     def __init__(self, dim_in: int, dim_hid: int, num_layers: int, species: str, tissue: str, *, dropout: int = 0,
                  batch_size: int = 500, device: str = "cuda", save_root=None, verbose: bool = True,
                  compute_dtype: str = "fp32"):
@@ -107,7 +109,11 @@ class ScDeepSort(BaseClassificationMethod):
         labels = torch.as_tensor(labels)
         self.num_labels = labels.max().item() + 1
 
-        perm = torch.randperm(num_cells, device=self.device) + num_genes  # (scdeepsort.py:157-160, drawn on the device)
+        # scdeepsort.py:157-160.  Drawn on the device by default; with ``self.shuffle_generator`` (a host torch.Generator)
+        # the split and every epoch's batch order come from that generator, as the reference draws them from the CPU RNG
+        gen = self.shuffle_generator
+        perm = (torch.randperm(num_cells, device=self.device) if gen is None
+                else torch.randperm(num_cells, generator=gen).to(self.device)) + num_genes
         num_val = int(num_cells * val_ratio)
         val_idx = perm[:num_val]
         train_idx = perm[num_val:]
@@ -148,7 +154,8 @@ class ScDeepSort(BaseClassificationMethod):
     def cal_loss(self, graph, idx: torch.Tensor):
         self.model.train()
         total_loss = total_size = 0
-        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
+        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
+                                generator=self.shuffle_generator)
         for _, _, blocks in dataloader:
             input_features = blocks[0].srcdata["features"]
             output_labels = blocks[-1].dstdata["label"]
@@ -165,7 +172,8 @@ class ScDeepSort(BaseClassificationMethod):
     def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0):
         self.model.eval()
         total_correct = total_unsure = 0
-        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True)
+        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
+                                generator=self.shuffle_generator)
         for _, _, blocks in dataloader:
             input_features = blocks[0].srcdata["features"]
             output_labels = blocks[-1].dstdata["label"]

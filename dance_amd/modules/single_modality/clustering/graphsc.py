@@ -55,10 +55,8 @@ class WeightedGraphConv(nn.Module):
         if self._norm == "both":
             colscale = graph.out_degrees().float().clamp(min=1).pow(-0.5)  # :444-449
             rowscale = in_deg.float().clamp(min=1).pow(-0.5)  # :467-471
-        elif self._norm == "right":
-            rowscale = 1.0 / in_deg.float().clamp(min=1)
-        elif self._norm == "left":
-            colscale = 1.0 / graph.out_degrees().float().clamp(min=1)
+        elif self._norm != "none":  # "right" AND "left": the reference only scales the source side for "both" (:444)
+            rowscale = 1.0 / in_deg.float().clamp(min=1)  # and divides by the in-degree for every other norm (:467-474)
         relu = self._activation in (F.relu, torch.relu) or isinstance(self._activation, nn.ReLU)
         g = CSRGraph(graph.rowptr, graph.col, graph.val, graph.number_of_dst_nodes(), graph.number_of_src_nodes())
         rst = gcn_layer(feat, weight, g, self.bias, relu, rowscale=rowscale, colscale=colscale,
@@ -129,6 +127,11 @@ def block_dst_adjacency(block) -> torch.Tensor:
 
 class GraphSC(BaseClusteringMethod):
 
+    # Seed order of the mini-batches: None = shuffled on the device; a (host) torch.Generator makes the order
+    # reproducible (``torch.randperm(n, generator=...)`` per epoch).  Not a constructor argument: the constructor is
+    # the reference's (graphsc.py:70-87).
+    shuffle_generator = None
+
     def __init__(self, agg: str = "sum", activation: str = "relu", in_feats: int = 50, n_hidden: int = 1, hidden_dim: int = 200,
                  hidden_1: int = 300, hidden_2: int = 0, dropout: float = 0.1, n_layers: int = 1, hidden_relu: bool = False,
                  hidden_bn: bool = False, n_clusters: int = 10, cluster_method: str = "kmeans", num_workers: int = 1,
@@ -164,7 +167,8 @@ class GraphSC(BaseClusteringMethod):
         g.ndata["order"] = g.ndata["label"] = g.ndata["feat_id"]
         train_ids = np.where(g.ndata["label"].cpu().numpy() != -1)[0]
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
-        dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False)
+        dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
+                                generator=self.shuffle_generator)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr)
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
@@ -202,8 +206,15 @@ class GraphSC(BaseClusteringMethod):
             from sklearn.cluster import KMeans
             return KMeans(n_clusters=self.n_clusters, init="k-means++", random_state=5, n_init=10).fit_predict(self.z)
         if self.cluster_method == "leiden":
-            raise NotImplementedError("leiden needs scanpy/leidenalg, which are not available in this environment")
+            return run_leiden(self.z, device=self.device)
         raise ValueError(f"Unknown clustering {self.cluster_method}, available options are: 'kmeans', 'leiden'")
 
     def get_latent(self):
         return self.z
+
+
+def run_leiden(data, device="cuda"):
+    """graphsc.py:568-587: ``sc.pp.neighbors(use_rep="X", n_neighbors=300, n_pcs=0)`` + ``sc.tl.leiden``.  Neighbour
+    graph on the GPU; modularity optimisation by the Louvain scheme on the host (dance_amd/utils/community.py)."""
+    from ....utils.community import leiden_like
+    return [int(x) for x in leiden_like(np.asarray(data, dtype=np.float32), 300, resolution=1.0, device=device)]

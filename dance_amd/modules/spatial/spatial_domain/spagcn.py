@@ -155,8 +155,13 @@ class SimpleGCDEC(nn.Module):
             kmeans = KMeans(self.n_clusters, n_init=20)
             y_pred = kmeans.fit_predict(features.cpu().numpy() if init_spa else X.cpu().numpy())
         elif init == "louvain":
-            raise NotImplementedError("init='louvain' needs scanpy + leidenalg (spagcn.py:480-492), which are not "
-                                      "installable here; use init='kmeans' with n_clusters")
+            # spagcn.py:480-492: sc.pp.neighbors(n_neighbors) + sc.tl.leiden(resolution=res).  Neighbour graph on the
+            # GPU (exact kNN + UMAP connectivities); the modularity optimisation itself is the Louvain scheme on the
+            # host (scanpy / leidenalg are not installable — deviation documented in dance_amd/utils/community.py)
+            from ....utils.community import leiden_like
+            logger.info(f"Initializing cluster centers with louvain, resolution = {res}")
+            y_pred = leiden_like(features if init_spa else X, n_neighbors, resolution=res, device=self.device)
+            self.n_clusters = len(np.unique(y_pred))
         else:
             raise ValueError(f"Unknown init {init!r}")
         y_pred_last = y_pred
@@ -248,8 +253,8 @@ class SpaGCN(BaseClusteringMethod):
     def calc_adj_exp(self, adj):
         """exp(-adj^2 / (2 l^2)) on the device; a ``CSRGraph`` of distances keeps its sparsity pattern."""
         if isinstance(adj, CSRGraph):
-            vals, _ = kernels.gaussian_kernel(adj.val[None, :], self.l)
-            return CSRGraph(adj.rowptr, adj.col, vals[0].contiguous(), adj.n_rows, adj.n_cols, symmetric=adj.symmetric)
+            vals, _ = kernels.gaussian_kernel(adj.val, self.l)  # flat launch over the nnz values
+            return CSRGraph(adj.rowptr, adj.col, vals, adj.n_rows, adj.n_cols, symmetric=adj.symmetric)
         out, _ = kernels.gaussian_kernel(_to_device_f32(adj, self.device), self.l)
         return out
 

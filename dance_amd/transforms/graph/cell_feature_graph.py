@@ -7,6 +7,8 @@ the expression matrix goes to the device as CSR once; its transpose (dh_csr_tran
 (dh_cellgene_graph_assemble) are HIP kernels.  The result is a ``CellGeneGraph`` (DGLGraph stand-in) in
 ``data.data.uns[out]`` carrying ``ndata["cell_id" | "feat_id" | "features"]`` and edge weights.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -64,10 +66,15 @@ class PCACellFeatureGraph(BaseTransform):
 
     _DISPLAY_ATTRS = ("n_components", "split_name")
 
+    # Where the gene PCA runs.  None: scikit-learn on the host, exactly the reference's call.  "cuda": the exact
+    # decomposition on the GPU (dance_amd.utils.pca).  Deliberately NOT a constructor argument — the constructor is the
+    # reference's (cell_feature_graph.py:87-97); opt in per instance (``t.pca_device = "cuda"``) or process-wide with
+    # DANCE_AMD_PCA_DEVICE.
+    pca_device = os.environ.get("DANCE_AMD_PCA_DEVICE") or None
+
     def __init__(self, n_components: int = 400, split_name=None, *, normalize_edges: bool = True, feat_norm_mode=None,
-                 feat_norm_axis: int = 0, mod=None, log_level="WARNING", device="cuda", pca_device=None):
+                 feat_norm_axis: int = 0, mod=None, log_level="WARNING", device="cuda"):
         super().__init__(log_level=log_level)
-        self.pca_device = pca_device  # None: scikit-learn PCA on the host (reference); "cuda": exact PCA on the GPU (opt-in)
         self.n_components = n_components
         self.split_name = split_name
         self.normalize_edges = normalize_edges

@@ -134,8 +134,66 @@ class DGLStubGraph:
         self.dstdata[out_field] = out
 
 
-def dgl_stub():
-    """A namespace standing in for ``import dgl`` in extracted reference code (see DGLStubGraph)."""
+    # surface used by GraphSC.fit (graphsc.py:180-215)
+    def to(self, device):
+        return self
+
+    def dstnodes(self):
+        import torch
+        return torch.arange(self._num_dst)
+
+    def adjacency_matrix(self):
+        """dgl >= 1.0 ``DGLGraph.adj()``: rows = source nodes, columns = destination nodes, one unit entry per edge."""
+        import torch
+        a = torch.zeros((self._num_src, self._num_dst))
+        a.index_put_((self._src, self._dst), torch.ones(self._src.numel()), accumulate=True)
+        import types
+        return types.SimpleNamespace(to_dense=lambda: a)
+
+
+def stub_full_in_block(g: DGLStubGraph, seeds):
+    """Message-flow block of ``dgl.dataloading.MultiLayerFullNeighborSampler(1)`` for ``seeds``: every in-edge of the
+    seeds (edge-id order); source nodes = the seeds first (dgl.to_block's "dst nodes come first" rule), then the other
+    in-neighbours.  srcdata / dstdata are the parent's ndata rows.  Stub of DGL semantics, test infrastructure."""
+    import torch
+    seeds = torch.as_tensor(seeds).long()
+    pos = torch.full((g.number_of_nodes(), ), -1, dtype=torch.long)
+    pos[seeds] = torch.arange(seeds.numel())
+    eid = torch.nonzero(pos[g._dst] >= 0).reshape(-1)
+    src, dst = g._src[eid], g._dst[eid]
+    extra = torch.unique(src[pos[src] < 0])
+    pos[extra] = seeds.numel() + torch.arange(extra.numel())
+    src_ids = torch.cat((seeds, extra))
+    blk = DGLStubGraph(pos[src], pos[dst], num_src=src_ids.numel(), num_dst=seeds.numel())
+    blk.srcdata.update({k: v[src_ids] for k, v in g.ndata.items()})
+    blk.dstdata.update({k: v[seeds] for k, v in g.ndata.items()})
+    blk.edata.update({k: v[eid] for k, v in g.edata.items()})
+    return src_ids, seeds, [blk]
+
+
+def dgl_stub(shuffle_generator=None):
+    """A namespace standing in for ``import dgl`` in extracted reference code (see DGLStubGraph).
+    ``dataloading.DataLoader`` yields one-layer full-neighbour blocks; with ``shuffle=True`` the seed order of each
+    epoch is ``torch.randperm(n, generator=shuffle_generator)`` (DGL's own shuffle order is not reproducible outside
+    DGL; the tests hand the same generator to the product's loader)."""
     import types
+
+    import torch
     fn = types.SimpleNamespace(mean=lambda msg, out: ("mean", msg, out), sum=lambda msg, out: ("sum", msg, out))
-    return types.SimpleNamespace(graph=lambda pair: DGLStubGraph(pair[0], pair[1]), function=fn)
+
+    class _Loader:
+        def __init__(self, g, ids, sampler, batch_size=1, shuffle=False, drop_last=False, num_workers=0):
+            self.g, self.ids, self.bs, self.shuffle = g, torch.as_tensor(ids).long(), batch_size, shuffle
+
+        def __iter__(self):
+            ids = self.ids[torch.randperm(self.ids.numel(), generator=shuffle_generator)] if self.shuffle else self.ids
+            for i in range(0, ids.numel(), self.bs):
+                yield stub_full_in_block(self.g, ids[i:i + self.bs])
+
+    def _sampler(n_layers):
+        if n_layers != 1:
+            raise NotImplementedError("stub: one-layer blocks only")
+        return None
+    dataloading = types.SimpleNamespace(MultiLayerFullNeighborSampler=_sampler, DataLoader=_Loader)
+    return types.SimpleNamespace(graph=lambda pair: DGLStubGraph(pair[0], pair[1]), function=fn, dataloading=dataloading,
+                                 DGLGraph=DGLStubGraph)

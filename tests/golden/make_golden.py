@@ -305,6 +305,92 @@ def make_graph_builders():
     print("graph_builders.npz:", len(out), "arrays")
 
 
+def make_graphsc():
+    """graphsc.npz — the reference's own GCNAE / InnerProductDecoder / WeightedGraphConv classes and the GraphSC.fit loop
+    (graphsc.py:148-246,274-484), AST-lifted and run on torch-CPU over the DGL stub (blocks of the full-neighbour
+    sampler, ``adjacency_matrix``; dgl.nn.GraphConv's constructor restated from the DGL 1.1.3 documentation).  Dropout
+    is switched off (GCNAE dropout=0, decoder.dropout=0) so the run is deterministic; seed order = randperm of a seeded
+    generator that the GPU test hands to the product's loader."""
+    import logging
+    import types
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+    rng = np.random.default_rng(11)
+    gsc = "dance/modules/single_modality/clustering/graphsc.py"
+    out = {}
+
+    class GraphConv(nn.Module):  # dgl.nn.pytorch.GraphConv.__init__ / reset_parameters
+        def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None, allow_zero_in_degree=False):
+            super().__init__()
+            self._in_feats, self._out_feats, self._norm, self._allow_zero_in_degree = in_feats, out_feats, norm, allow_zero_in_degree
+            self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats)) if weight else None
+            self.bias = nn.Parameter(torch.Tensor(out_feats)) if bias else None
+            nn.init.xavier_uniform_(self.weight)
+            nn.init.zeros_(self.bias)
+            self._activation = activation
+
+    n_cells, n_genes, d = 40, 12, 6
+    x = ((rng.random((n_cells, n_genes)) < 0.3) * rng.uniform(0.2, 2.0, (n_cells, n_genes))).astype(np.float32)
+    x[np.arange(n_cells), rng.integers(0, n_genes, n_cells)] = 1.0   # every cell expresses something
+    gene_f, cell_f = rng.standard_normal((n_genes, d)).astype(np.float32), rng.standard_normal((n_cells, d)).astype(np.float32)
+    out.update(gsc_x=x, gsc_gene_feat=gene_f, gsc_cell_feat=cell_f)
+
+    def build_graph(dgl):
+        call = ref_extract.extract_method("dance/transforms/graph/cell_feature_graph.py", "CellFeatureGraph", "__call__", {"dgl": dgl})
+        get_feature = lambda return_type="default", mod=None, channel=None, channel_type=None: (
+            torch.from_numpy(gene_f) if channel_type == "varm" else torch.from_numpy(cell_f) if channel_type == "obsm" else x)
+        data = types.SimpleNamespace(get_feature=get_feature, data=types.SimpleNamespace(uns={}))
+        call(types.SimpleNamespace(mod=None, normalize_edges=False, cell_feature_channel="f", gene_feature_channel="f",
+                                   logger=logging.getLogger("reference"), out="g"), data)
+        return data.data.uns["g"]
+
+    kw = dict(agg="sum", activation="relu", in_feats=d, n_hidden=1, hidden_dim=10, hidden_1=5, hidden_2=0, dropout=0.0,
+              n_layers=1, hidden_relu=False, hidden_bn=False)
+    out["gsc_kw"] = np.array(json.dumps(kw))
+    for tag, batch_size, agg in (("full", 64, "sum"), ("mb", 16, "sum"), ("mean", 16, "mean")):
+        gen = torch.Generator().manual_seed(123)
+        dgl = ref_extract.dgl_stub(shuffle_generator=gen)
+        ns = {"GraphConv": GraphConv, "fn": dgl.function, "DGLError": RuntimeError,
+              "expand_as_pair": lambda feat, g: (feat, feat[:g.number_of_dst_nodes()])}
+        WGC = ref_extract.extract(gsc, "WeightedGraphConv", ns)
+        IPD = ref_extract.extract(gsc, "InnerProductDecoder")
+        GCNAE = ref_extract.extract(gsc, "GCNAE", {"WeightedGraphConv": WGC, "InnerProductDecoder": IPD})
+        from typing import Any, Optional
+        fit = ref_extract.extract_method(gsc, "GraphSC", "fit", {"dgl": dgl, "get_device": lambda dev: "cpu", "tqdm": lambda it: it,
+                                                                 "BCELoss": F.binary_cross_entropy_with_logits, "Any": Any, "Optional": Optional})
+        torch.manual_seed(3)
+        model = GCNAE(**{**kw, "agg": agg})
+        model.decoder.dropout = 0.0
+        with torch.no_grad():
+            model.layer1.bias.uniform_(-0.1, 0.1)
+        for k, v in model.state_dict().items():
+            out[f"gsc_{tag}_sd0::{k}"] = v.numpy().copy()
+        g = build_graph(dgl)
+        # one forward on the block of ALL cells before training: pins GCNAE.forward / InnerProductDecoder
+        _, _, blocks = ref_extract.stub_full_in_block(g, torch.arange(n_genes, n_genes + n_cells))
+        with torch.no_grad():
+            logits, emb = model.forward(blocks, blocks[0].srcdata["features"])
+        out[f"gsc_{tag}_logits0"], out[f"gsc_{tag}_emb0"] = logits.numpy(), emb.numpy()
+        # the reference's training loop.  Its ``losses`` list is local, so record the tensor ``backward`` is called on.
+        import unittest.mock as mock
+        losses = []
+        self = types.SimpleNamespace(model=model, n_layers=1, num_workers=0, device="cpu", score=None)
+        real_backward = torch.Tensor.backward
+
+        def recording_backward(t, *a, **k):
+            losses.append(float(t.detach()))
+            return real_backward(t, *a, **k)
+        with mock.patch.object(torch.Tensor, "backward", recording_backward):
+            fit(self, g, epochs=3, lr=1e-2, batch_size=batch_size)
+        out[f"gsc_{tag}_losses"] = np.array(losses, dtype=np.float64)   # norm * BCE per batch (graphsc.py:211-216)
+        out[f"gsc_{tag}_z"] = np.asarray(self.z, dtype=np.float32)
+        for k, v in model.state_dict().items():
+            out[f"gsc_{tag}_sd1::{k}"] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "graphsc.npz"), **out)
+    print("graphsc.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -313,3 +399,4 @@ if __name__ == "__main__":
     make_models()
     make_matrix_known_answers()
     make_graph_builders()
+    make_graphsc()

@@ -58,6 +58,14 @@ def test_gcn_layer_full_size(cuda_device, n):
     lhs = float(layer.weight.grad.double().sum())
     rhs = float((x.double().sum(1) * ds.double().sum(1)).sum())
     assert abs(lhs - rhs) < 1e-6 * float((x.double().abs().sum(1) * ds.double().abs().sum(1)).sum())
+    # (3b) dW element by element on sampled genes x hidden columns, float64 on the device: the 64-slice split-K TN GEMM
+    # at K = n is otherwise only covered at K <= 100 001 (test_gpu_kernels)
+    genes = torch.from_numpy(np.random.default_rng(1).choice(fin, 24, replace=False)).to(DEV)
+    cols = torch.from_numpy(np.random.default_rng(2).choice(fout, 16, replace=False)).to(DEV)
+    ref_dw = x[:, genes].double().t() @ ds[:, cols].double()
+    got_dw = layer.weight.grad[genes][:, cols]
+    assert rel_err(got_dw.cpu().numpy(), ref_dw.cpu().numpy()) < 1e-4
+    assert float((got_dw.double() - ref_dw).abs().max() / layer.weight.grad.abs().max()) < 1e-5
     # (4) dS itself: sampled rows of A^T g against the explicit edge list
     tr, tc, tv = gt.rowptr.cpu().numpy(), gt.col.cpu().numpy(), gt.val.cpu().numpy()
     ref_ds = np.stack([sum((float(tv[e]) * g[int(tc[e])].double().cpu().numpy() for e in range(tr[i], tr[i + 1])), np.zeros(fout)) for i in rows])

@@ -1,0 +1,88 @@
+"""GPU: GCNAE / InnerProductDecoder forward and the GraphSC.fit loop (pos_weight, norm, the double forward, Adam steps,
+embedding re-ordering) against tests/golden/graphsc.npz — produced by the reference's OWN classes and its own ``fit``
+method (graphsc.py:148-246,274-484), AST-lifted and run on torch-CPU over the DGL stub (tests/golden/make_golden.py).
+Dropout is off on both sides; the seed order of every epoch comes from the same seeded generator."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "graphsc.npz")
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def _graph(gold):
+    from dance_amd.data import AnnDataLite, Data
+    from dance_amd.transforms.graph import CellFeatureGraph
+    data = Data(AnnDataLite(gold["gsc_x"], obsm={"f": gold["gsc_cell_feat"]}, varm={"f": gold["gsc_gene_feat"]}))
+    CellFeatureGraph("f", normalize_edges=False)(data)
+    return data.data.uns["CellFeatureGraph"]
+
+
+def _model(gold, tag, agg):
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    kw = json.loads(str(gold["gsc_kw"]))
+    kw["agg"] = agg
+    m = GraphSC(**kw, n_clusters=3, device="cuda")
+    m.model.decoder.dropout = 0.0
+    sd = {k.split("::", 1)[1]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(f"gsc_{tag}_sd0::")}
+    assert sorted(sd) == sorted(m.model.state_dict())  # the reference's parameter names
+    m.model.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize("tag,batch_size,agg", [("full", 64, "sum"), ("mb", 16, "sum"), ("mean", 16, "mean")])
+def test_graphsc_forward_and_fit_vs_reference(cuda_device, gold, tag, batch_size, agg):
+    from dance_amd.cellgraph import MultiLayerFullNeighborSampler
+    g = _graph(gold)
+    m = _model(gold, tag, agg)
+    n_cells, n_genes = gold["gsc_x"].shape
+    # GCNAE.forward + InnerProductDecoder on the block of all cells
+    _, _, blocks = MultiLayerFullNeighborSampler(1).sample(g, torch.arange(n_genes, n_genes + n_cells, device=cuda_device))
+    with torch.no_grad():
+        logits, emb = m.model.forward(blocks, blocks[0].srcdata["features"])
+    assert rel_err(emb.cpu().numpy(), gold[f"gsc_{tag}_emb0"]) < TOL
+    assert rel_err(logits.cpu().numpy(), gold[f"gsc_{tag}_logits0"]) < TOL
+    # the training loop
+    m.shuffle_generator = torch.Generator().manual_seed(123)
+    m.fit(g, epochs=3, lr=1e-2, batch_size=batch_size)
+    ref_losses = gold[f"gsc_{tag}_losses"]
+    assert len(m.losses) == len(ref_losses)
+    assert np.allclose(m.losses, ref_losses, rtol=2e-4, atol=0)
+    assert rel_err(m.get_latent(), gold[f"gsc_{tag}_z"]) < 1e-3  # after up to 9 Adam steps
+    for k in gold.files:
+        if k.startswith(f"gsc_{tag}_sd1::"):
+            got = m.model.state_dict()[k.split("::", 1)[1]].cpu().numpy()
+            assert rel_err(got, gold[k]) < 1e-3, k
+
+
+def test_weighted_graph_conv_left_norm_is_in_degree_division(cuda_device, gold):
+    """the reference divides by the in-degree for every norm other than "none"/"both" — "left" included —
+    and scales the source side only for "both" (graphsc.py:444,467-474)."""
+    from dance_amd.cellgraph import MultiLayerFullNeighborSampler
+    from dance_amd.modules.single_modality.clustering.graphsc import WeightedGraphConv
+    g = _graph(gold)
+    n_cells, n_genes = gold["gsc_x"].shape
+    _, _, blocks = MultiLayerFullNeighborSampler(1).sample(g, torch.arange(n_genes, n_genes + n_cells, device=cuda_device))
+    blk = blocks[0]
+    torch.manual_seed(0)
+    feat = blk.srcdata["features"]
+    outs = {}
+    for norm in ("left", "right", "none"):
+        conv = WeightedGraphConv(feat.shape[1], 7, norm=norm).to(cuda_device)
+        torch.manual_seed(1)
+        torch.nn.init.normal_(conv.weight)
+        outs[norm] = conv(blk, feat).detach()
+    assert torch.equal(outs["left"], outs["right"])
+    deg = blk.in_degrees().float().clamp(min=1)[:, None]
+    assert rel_err((outs["none"] / deg).cpu().numpy(), outs["left"].cpu().numpy()) < 1e-6

@@ -88,6 +88,12 @@ def test_graphsc_fit_predict(cuda_device):
     assert model.losses[-1] < model.losses[0]
     pred = model.predict()
     assert pred.shape == (300, ) and set(pred) <= {0, 1, 2}
+    model.cluster_method = "leiden"  # graphsc.py:264-265 run_leiden
+    pred = model.predict()
+    assert len(pred) == 300 and min(pred) == 0
+    model.cluster_method = "bogus"
+    with pytest.raises(ValueError):
+        model.predict()
 
 
 def test_simple_gcdec_matches_reference_golden(cuda_device, heads):
@@ -162,6 +168,12 @@ def test_spagcn_fit_predict_dense_and_truncated(cuda_device):
     assert adjusted_rand_score(pred, sparse.predict((embed, g))) > 0.99
     with pytest.raises(ValueError):
         SpaGCN(device="cuda").fit((embed, adj))  # l must be set first (spagcn.py:855-856)
+    # the reference's DEFAULT init ("louvain" = neighbours + leiden, spagcn.py:480-492) must run: GPU neighbour graph +
+    # host modularity clustering; the number of clusters comes out of the partition
+    default = SpaGCN(l, device="cuda")
+    default.fit((embed, adj), epochs=60, lr=0.01, tol=1e-4, res=0.4)
+    assert default.model.n_clusters == len(np.unique(default.model.trajectory[0])) >= 2
+    assert adjusted_rand_score(dom, default.predict((embed, adj))) > 0.8
 
 
 def test_scdsc_model_matches_reference_golden(cuda_device, heads):

@@ -205,3 +205,28 @@ def test_scdeepsort_predict_rule_matches_reference_method():
         m_pred, m_unsure = mine.predict(None, unsure_rate=rate, return_unsure=True)
         assert np.array_equal(np.asarray(r_pred), np.asarray(m_pred)) and np.array_equal(np.asarray(r_unsure), np.asarray(m_unsure))
     assert np.array_equal(np.asarray(ref_predict(stub, None)), np.asarray(mine.predict(None)))
+
+
+def test_graphsc_golden_regenerates_from_reference(tmp_path, monkeypatch):
+    """graphsc.npz is what the reference's own GCNAE / GraphSC.fit produce NOW (build container only)."""
+    import importlib.util
+    import os
+
+    import pytest
+
+    from oracle import ref_extract
+    if not ref_extract.available():
+        pytest.skip("reference tree not present")
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_gsc", os.path.join(here, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "HERE", str(tmp_path))
+    mod.make_graphsc()
+    new, old = np.load(tmp_path / "graphsc.npz"), np.load(os.path.join(here, "graphsc.npz"))
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if old[k].dtype.kind in "fc":
+            assert np.allclose(new[k], old[k], rtol=1e-5, atol=1e-6), k
+        else:
+            assert np.array_equal(new[k], old[k]), k

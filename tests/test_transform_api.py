@@ -112,3 +112,23 @@ def test_block_sampler_on_cpu_tensors():
     shuffled = [o for _, o, _ in DataLoader(g, torch.tensor([3, 4, 5, 6]), NeighborSampler([-1]), batch_size=4, shuffle=True,
                                             generator=torch.Generator().manual_seed(0))]
     assert sorted(shuffled[0].tolist()) == [3, 4, 5, 6]
+
+
+def test_as_graph_cache_is_identity_keyed(monkeypatch):
+    """ADVICE r1: a WeakKeyDictionary keyed by sparse tensors compared keys with ``==`` (aten::eq is not implemented for
+    sparse layouts) and raised on the second call with the same adjacency — the reference's epoch loop passes the same
+    ``adj`` every epoch (scdsc.py:257-288)."""
+    import gc
+
+    import torch
+
+    from dance_amd import graph
+    built = []
+    monkeypatch.setattr(graph.CSRGraph, "from_torch_sparse", classmethod(lambda cls, adj, device=None: (built.append(1), object())[1]))
+    adj = torch.sparse_coo_tensor(torch.tensor([[0, 1], [1, 0]]), torch.ones(2), (2, 2))
+    other = torch.sparse_coo_tensor(torch.tensor([[0, 1], [1, 0]]), torch.ones(2), (2, 2))
+    g1, g2, g3 = graph.as_graph(adj), graph.as_graph(adj), graph.as_graph(other)
+    assert g1 is g2 and g3 is not g1 and len(built) == 2
+    del adj, other
+    gc.collect()
+    assert len(graph._CACHE) == 0  # entries die with their tensors
