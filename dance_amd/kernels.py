@@ -458,6 +458,63 @@ def sage_aggregate_cells(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, gen
     return out, workspace
 
 
+def csr_densify_window(rowptr, col, val, col_begin: int, n_cols: int, *, rowscale=None, colscale=None, mean: bool = False,
+                       dtype=torch.float32, ld: Optional[int] = None, max_row_nnz: int = 0) -> torch.Tensor:
+    """dh_csr_densify_window: dense [n_rows, n_cols] copy (fp32 / bf16) of the columns [col_begin, col_begin + n_cols) of a
+    CSR matrix, optionally scaled per row / per window column / by 1 / row degree.  ``ld`` >= n_cols pads the rows."""
+    lib = _lib_ready()
+    n_rows = rowptr.numel() - 1
+    ld = n_cols if ld is None else ld
+    out = torch.empty((n_rows, ld), dtype=dtype, device=rowptr.device)
+    if ld > n_cols:
+        out[:, n_cols:].zero_()
+    _call("csr_densify_window", lib.dh_csr_densify_window, n_rows, max_row_nnz, _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1), _dev(rowscale, torch.float32, "rowscale", 1),
+          _dev(colscale, torch.float32, "colscale", 1), int(mean), col_begin, n_cols, out.data_ptr(), ld, _out_dtype(dtype), _stream())
+    return out
+
+
+def sage_tail(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *, out_dtype=None) -> torch.Tensor:
+    """dh_sage_tail: the mean-scaled AdaptiveSAGE contribution of the edges whose source lies outside the window."""
+    lib = _lib_ready()
+    n_dst, n_src, width = rowptr.numel() - 1, H.shape[0], H.shape[1]
+    out_dtype = out_dtype or H.dtype
+    out = torch.empty((n_dst, width), dtype=out_dtype, device=H.device)
+    _call("sage_tail", lib.dh_sage_tail, n_dst, n_src, width, alpha.numel() - 2, col_begin, n_cols, _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1), _dev(src_cell_id, torch.int32, "src_cell_id", 1),
+          _dev(dst_cell_id, torch.int32, "dst_cell_id", 1), _dev(alpha.reshape(-1), torch.float32, "alpha", 1), _dev(H, H.dtype, "H", 2),
+          _ld(H), _out_dtype(H.dtype), out.data_ptr(), _ld(out), _out_dtype(out_dtype), _stream())
+    return out
+
+
+def sage_aggregate_dense(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *,
+                         dst_are_genes: bool = False, max_row_nnz: int = 0, out_dtype=None) -> torch.Tensor:
+    """AdaptiveSAGE mean aggregation (the result of ``sage_aggregate``) through the matrix cores: the sources
+    [col_begin, col_begin + n_cols) — the gene rows of H for cell destinations, the cell rows for gene destinations — enter as
+    a dense weighted-adjacency operand of an MFMA GEMM (dh_csr_densify_window + dh_gemm_bf16 / dh_gemm_f32), every other
+    in-edge (self loops) through dh_sage_tail.  bf16 H: the adjacency entries alpha * w / deg are rounded to bf16 (one more
+    2^-9 rounding per term than the gather kernel); fp32 H: exact fp32 MFMA products, sums in a different order."""
+    bf16 = H.dtype == _BF16
+    out_dtype = out_dtype or H.dtype
+    a = alpha.reshape(-1)
+    if dst_are_genes:   # cell -> gene edge: alpha[cell_id of the destination gene] (gnn.py:74)
+        rowscale, colscale = a[dst_cell_id.clamp(min=0).to(torch.int64)].contiguous(), None
+    else:               # gene -> cell edge: alpha[cell_id of the source gene] (gnn.py:73)
+        rowscale, colscale = None, a[src_cell_id[col_begin:col_begin + n_cols].clamp(min=0).to(torch.int64)].contiguous()
+    k8 = (n_cols + 7) // 8 * 8 if bf16 else n_cols
+    A = csr_densify_window(rowptr, col, w, col_begin, n_cols, rowscale=rowscale, colscale=colscale, mean=True,
+                           dtype=H.dtype, ld=k8, max_row_nnz=max_row_nnz)
+    Hw = H[col_begin:col_begin + n_cols]
+    if k8 != n_cols:
+        Hw = torch.cat((Hw, torch.zeros((k8 - n_cols, H.shape[1]), dtype=H.dtype, device=H.device)))
+    out = sage_tail(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin, n_cols, out_dtype=out_dtype)
+    if bf16:
+        return gemm_bf16(A, Hw, out=out, accumulate=True, tag="gemm_bf16_sage_dense")
+    if out_dtype != torch.float32:
+        raise TypeError("fp32 features produce an fp32 result")
+    return gemm(A, Hw, out=out, accumulate=True, tag="gemm_f32_sage_dense")
+
+
 def sage_alpha_grad(rowptr, col, w, src_cell_id, dst_cell_id, n_genes, H, dneigh) -> torch.Tensor:
     """dalpha[idx(e)] += w_e <H[src(e)], dneigh[dst(e)]> / deg(dst(e)) (dh_sage_alpha_grad_f32)."""
     lib = _lib_ready()

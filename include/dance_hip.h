@@ -243,6 +243,22 @@ DH_API int dh_sage_aggregate_cells(int64_t n_dst, int64_t n_src, int64_t nnz, in
                             const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha,
                             const void* H, int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype,
                             void* workspace, size_t workspace_bytes, int reuse_segments, dh_stream_t stream);
+/* Densified-operand form of the same aggregation (densify.hip): at 10 % density the MFMA GEMM over a dense copy of the
+ * weighted adjacency beats every vector-ALU gather (measurements in DESIGN.md), most of all for the gene <- cell rows of
+ * ~1e5 in-edges.  dh_csr_densify_window writes out[r][c - col_begin] = val_e * rowscale[r] * colscale[c - col_begin]
+ * (* 1/deg(r) if mean) for the edges of row r with col_begin <= c < col_begin + n_cols and 0 elsewhere (fp32 or bf16);
+ * max_row_nnz (an upper bound of the longest row) only sizes the launch of the wide-window path (n_cols > 16384, at most
+ * 65535 rows).  dh_sage_tail computes the mean-scaled contribution of the edges whose source lies OUTSIDE that window
+ * (the self loops) with the alpha rule of dh_sage_aggregate_f32; the host then accumulates the GEMM into it:
+ *     neigh = dh_sage_tail(...);  neigh += A_dense * H[col_begin : col_begin + n_cols]   (dh_gemm_f32 / dh_gemm_bf16).  */
+DH_API int dh_csr_densify_window(int64_t n_rows, int64_t max_row_nnz, const int32_t* rowptr, const int32_t* col,
+                          const float* val, const float* rowscale, const float* colscale, int mean,
+                          int64_t col_begin, int64_t n_cols, void* out, int64_t ldo, int out_dtype,
+                          dh_stream_t stream);
+DH_API int dh_sage_tail(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes, int64_t col_begin, int64_t n_cols,
+                 const int32_t* rowptr, const int32_t* col, const float* w, const int32_t* src_cell_id,
+                 const int32_t* dst_cell_id, const float* alpha, const void* H, int64_t ldh, int h_dtype,
+                 void* neigh, int64_t ldn, int out_dtype, dh_stream_t stream);
 DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
                            const int32_t* rowptr, const int32_t* col, const float* w,
                            const int32_t* src_cell_id, const int32_t* dst_cell_id,

@@ -1,0 +1,110 @@
+"""GPU: the densified-operand AdaptiveSAGE aggregation (dh_csr_densify_window + dh_sage_tail + MFMA GEMM) against the
+gather kernel (pinned to the reference's message_func / fn.mean golden) and a float64 restatement of gnn.py:62-90, for
+cell destinations (window = the gene rows) in graph and block layout and for gene destinations (window = the cell rows)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from test_gpu_sage_lds import _bipartite
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ref(rowptr, col, w, cid_src, cid_dst, alpha, h, n_genes):
+    out = np.zeros((rowptr.size - 1, h.shape[1]))
+    for i in range(rowptr.size - 1):
+        s, t = rowptr[i], rowptr[i + 1]
+        if t > s:
+            c = col[s:t]
+            sid, did = cid_src[c], cid_dst[i]
+            idx = np.full(c.size, n_genes + 1)
+            idx = np.where((sid >= 0) & (did < 0), sid, idx)
+            idx = np.where((did >= 0) & (sid < 0), did, idx)
+            idx = np.where((did >= 0) & (sid >= 0), n_genes, idx)
+            out[i] = ((alpha[idx] * w[s:t])[:, None] * h[c].astype(np.float64)).sum(0) / (t - s)
+    return out
+
+
+def _gene_rows(n_cells, n_genes, density, seed):
+    """CSR rows = genes of the full graph (nodes: genes [0,G), cells [G,G+N)): in-edges from cells + the gene's self loop."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n_genes, n_cells)) < density
+    x[2] = False                                    # a gene no cell expresses: only its self loop
+    rowptr = np.zeros(n_genes + 1, np.int64)
+    rowptr[1:] = np.cumsum(x.sum(1) + 1)
+    col = np.empty(rowptr[-1], np.int32)
+    for g in range(n_genes):
+        cells = np.nonzero(x[g])[0] + n_genes
+        col[rowptr[g]] = g                          # self loop sorts first (gene id < cell ids)
+        col[rowptr[g] + 1:rowptr[g + 1]] = cells
+    w = (rng.random(col.size) + 0.25).astype(np.float32)
+    cid = np.concatenate((rng.permutation(n_genes), -np.ones(n_cells))).astype(np.int32)
+    return rowptr.astype(np.int32), col, w, cid, cid[:n_genes].copy()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("layout", ["graph", "block"])
+@pytest.mark.parametrize("n_cells,n_genes,width", [(700, 90, 400), (300, 1203, 104), (1000, 500, 200)])
+def test_dense_cells(cuda_device, dtype, layout, n_cells, n_genes, width):
+    from dance_amd import kernels
+    rowptr, col, w, cid, dst_cid, gene_begin, n_src = _bipartite(n_cells, n_genes, 0.12, n_cells + width, layout)
+    rng = np.random.default_rng(1)
+    h = torch.from_numpy(rng.standard_normal((n_src, width)).astype(np.float32)).to(DEV)
+    alpha = (rng.random(n_genes + 2) + 0.5).astype(np.float32)
+    if dtype == "bf16":
+        h = h.to(torch.bfloat16)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    args = (t(rowptr), t(col), t(w), t(cid), t(dst_cid), t(alpha), h)
+    got = kernels.sage_aggregate_dense(*args, gene_begin, n_genes)
+    ref = _ref(rowptr, col, w, cid, dst_cid, alpha.astype(np.float64), h.float().cpu().numpy(), n_genes)
+    if dtype == "f32":
+        assert rel_err(got.cpu().numpy(), ref) < 1e-5
+        assert rel_err(got.cpu().numpy(), kernels.sage_aggregate(*args).cpu().numpy()) < 1e-5
+    else:
+        assert got.dtype == torch.bfloat16
+        assert rel_err(got.float().cpu().numpy(), ref) < 1e-2   # bf16 adjacency entries + bf16 output (SURVEY.md §8c bf16 bar)
+        f32 = kernels.sage_aggregate_dense(*args, gene_begin, n_genes, out_dtype=torch.float32)
+        assert rel_err(f32.cpu().numpy(), ref) < 4e-3           # only the 2^-9 rounding of alpha * w / deg is left
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_dense_gene_rows(cuda_device, dtype):
+    from dance_amd import kernels
+    n_cells, n_genes, width = 20_000, 60, 128                   # window of 20k cell columns: the wide (scatter) path
+    rowptr, col, w, cid, dst_cid = _gene_rows(n_cells, n_genes, 0.1, 3)
+    rng = np.random.default_rng(4)
+    h = torch.from_numpy(rng.standard_normal((n_genes + n_cells, width)).astype(np.float32)).to(DEV)
+    alpha = (rng.random(n_genes + 2) + 0.5).astype(np.float32)
+    if dtype == "bf16":
+        h = h.to(torch.bfloat16)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    args = (t(rowptr), t(col), t(w), t(cid), t(dst_cid), t(alpha), h)
+    got = kernels.sage_aggregate_dense(*args, n_genes, n_cells, dst_are_genes=True, max_row_nnz=int(np.diff(rowptr).max()))
+    ref = _ref(rowptr, col, w, cid, dst_cid, alpha.astype(np.float64), h.float().cpu().numpy(), n_genes)
+    old = (kernels.sage_aggregate_bf16 if dtype == "bf16" else kernels.sage_aggregate)(*args)
+    if dtype == "f32":
+        assert rel_err(got.cpu().numpy(), ref) < 1e-5 and rel_err(old.cpu().numpy(), ref) < 1e-5
+    else:
+        assert rel_err(got.float().cpu().numpy(), ref) < 1e-2
+
+
+def test_densify_window_direct(cuda_device):
+    """Row / column scales, mean, padding and window clipping of dh_csr_densify_window against scipy."""
+    import scipy.sparse as sp
+
+    from dance_amd import kernels
+    rng = np.random.default_rng(0)
+    a = sp.random(300, 500, density=0.05, random_state=1, format="csr", dtype=np.float32)
+    a.sort_indices()
+    rs, cs = (rng.random(300) + 0.5).astype(np.float32), (rng.random(200) + 0.5).astype(np.float32)
+    t = lambda x: torch.from_numpy(x).to(DEV)
+    d = kernels.csr_densify_window(t(a.indptr.astype(np.int32)), t(a.indices.astype(np.int32)), t(a.data), 100, 200, rowscale=t(rs),
+                                   colscale=t(cs), mean=True, ld=208)
+    deg = np.maximum(np.diff(a.indptr), 1)
+    ref = a.toarray()[:, 100:300] * rs[:, None] * cs[None, :] / deg[:, None]
+    assert d.shape == (300, 208) and float(d[:, 200:].abs().max()) == 0.0
+    assert rel_err(d[:, :200].cpu().numpy(), ref) < 1e-6
+    d16 = kernels.csr_densify_window(t(a.indptr.astype(np.int32)), t(a.indices.astype(np.int32)), t(a.data), 0, 500, dtype=torch.bfloat16)
+    assert torch.equal(d16, torch.from_numpy(a.toarray()).to(DEV).to(torch.bfloat16))
