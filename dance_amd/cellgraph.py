@@ -82,6 +82,40 @@ class CellGeneGraph:
     def out_degrees(self) -> torch.Tensor:
         return torch.bincount(self.col.to(torch.int64), minlength=self._n_nodes)
 
+    def has_zero_in_degree(self) -> bool:
+        if getattr(self, "_zero_in_deg", None) is None:
+            self._zero_in_deg = bool((self.rowptr[1:] == self.rowptr[:-1]).any())
+        return self._zero_in_deg
+
+    def gene_prefix(self) -> int:
+        """G if the nodes are laid out as CellFeatureGraph builds them — genes (cell_id >= 0) are nodes [0, G), every later
+        node is a cell (cell_id == -1) — else -1.  One device read per graph, cached."""
+        if getattr(self, "_gene_prefix", None) is None:
+            cid = self.ndata["cell_id"]
+            g = int((cid >= 0).sum())
+            self._gene_prefix = g if bool((cid[:g] >= 0).all()) else -1
+        return self._gene_prefix
+
+    def cell_rows_block(self) -> "Block":
+        """The full-graph "block" whose destinations are ALL cells (rows [G, G+N) of the CSR, no copy, no sampling) and
+        whose sources are all nodes: what the union of the sampler's cell batches computes, in one piece.  Needs the
+        genes-first layout (``gene_prefix() >= 0``)."""
+        g = self.gene_prefix()
+        if g < 0:
+            raise ValueError("cell_rows_block needs the CellFeatureGraph node layout (genes first, then cells)")
+        n = self._n_nodes
+        blk = Block.__new__(Block)
+        blk.rowptr, blk.col, blk.val = self.rowptr[g:], self.col, self.val  # row pointers stay absolute offsets into col / val
+        blk._num_src, blk._num_dst = n, n - g
+        blk.parent, blk.dst_offset = self, g
+        ids = torch.arange(n, device=self.device)
+        blk.srcdata = _Frame(self.ndata)
+        blk.srcdata["_ID"] = ids
+        blk.dstdata = _Frame({k: v[g:] for k, v in self.ndata.items()})
+        blk.dstdata["_ID"] = ids[g:]
+        blk.edata = _Frame()
+        return blk
+
     def _dst_of_slots(self) -> torch.Tensor:
         deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
         return torch.repeat_interleave(torch.arange(self._n_nodes, device=self.device), deg)
@@ -160,6 +194,8 @@ class Block:
     def __init__(self, rowptr, col, val, num_src: int, num_dst: int, src_ids: torch.Tensor, parent: CellGeneGraph):
         self.rowptr, self.col, self.val = rowptr, col, val
         self._num_src, self._num_dst = int(num_src), int(num_dst)
+        self.parent = parent
+        self.dst_offset = 0  # destination node i is source node dst_offset + i (0 for sampled blocks: dgl.to_block order)
         self.srcdata = _GatherFrame(parent.ndata, src_ids)
         self.srcdata["_ID"] = src_ids
         self.dstdata = _GatherFrame(parent.ndata, src_ids[:num_dst])  # destination nodes = the first num_dst sources
@@ -183,7 +219,16 @@ class Block:
         return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
 
     def out_degrees(self) -> torch.Tensor:
-        return torch.bincount(self.col.to(torch.int64), minlength=self._num_src)
+        # scatter-add instead of torch.bincount: bincount reads max(col) back to the host to size its output
+        out = torch.zeros(self._num_src, dtype=torch.int64, device=self.col.device)
+        return out.index_add_(0, self.col.to(torch.int64), torch.ones(1, dtype=torch.int64, device=self.col.device).expand(self.col.numel()))
+
+    def has_zero_in_degree(self) -> bool:
+        """Whether some destination node has no in-edge.  Answered from the parent graph when that has none at all (one
+        device read per GRAPH, cached) — only otherwise from this block's own rows (a device read per block)."""
+        if not self.parent.has_zero_in_degree():
+            return False
+        return bool((self.rowptr[1:] == self.rowptr[:-1]).any())
 
     def to(self, device) -> "Block":
         return self  # blocks are created on the graph's device
@@ -197,26 +242,19 @@ class Block:
 
 
 def _full_in_block(g: CellGeneGraph, seeds: torch.Tensor) -> Block:
-    """All in-edges of ``seeds``; source nodes = seeds first, then the remaining in-neighbours (ascending id)."""
+    """All in-edges of ``seeds``; source nodes = seeds first, then the remaining in-neighbours (ascending id).  Built by
+    dh_block_plan / dh_block_fill (block.hip); the node bitmap and the node -> position table live on the graph and are
+    reused by every batch (the bitmap is handed back all-zero by the kernels, nothing is memset per batch)."""
+    from . import kernels
     dev = g.device
-    seeds = seeds.to(dev).to(torch.int64)
-    start = g.rowptr[seeds].to(torch.int64)
-    deg = g.rowptr[seeds + 1].to(torch.int64) - start
-    brp = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=dev)
-    brp[1:] = torch.cumsum(deg, 0)
-    total = int(brp[-1])
-    pos = torch.repeat_interleave(start - brp[:-1], deg) + torch.arange(total, device=dev)
-    gcol = g.col[pos].to(torch.int64)
-    # remaining in-neighbours in ascending id order: a node bitmap instead of sorting the 200-per-cell edge list
-    mark = torch.zeros(g.number_of_nodes(), dtype=torch.bool, device=dev)
-    mark[gcol] = True
-    mark[seeds] = False
-    others = torch.nonzero(mark).reshape(-1)
-    src_ids = torch.cat((seeds, others))
-    lut = torch.empty(g.number_of_nodes(), dtype=torch.int64, device=dev)
-    lut[src_ids] = torch.arange(src_ids.numel(), device=dev)
-    return Block(brp.to(torch.int32), lut[gcol].to(torch.int32), g.val[pos].contiguous(), src_ids.numel(),
-                 seeds.numel(), src_ids, g)
+    seeds = seeds.to(dev).to(torch.int64).contiguous()
+    scratch = getattr(g, "_block_scratch", None)
+    if scratch is None:
+        scratch = (torch.zeros(g.number_of_nodes(), dtype=torch.uint8, device=dev),
+                   torch.empty(g.number_of_nodes(), dtype=torch.int32, device=dev))
+        g._block_scratch = scratch
+    brp, bcol, bval, src_ids = kernels.block_build(g.rowptr, g.col, g.val, seeds, *scratch)
+    return Block(brp, bcol, bval, src_ids.numel(), seeds.numel(), src_ids, g)
 
 
 class NeighborSampler:
@@ -246,10 +284,12 @@ class DataLoader:
     """Mini-batch iterator yielding ``(input_nodes, output_nodes, blocks)`` like ``dgl.dataloading.DataLoader``."""
 
     def __init__(self, graph: CellGeneGraph, indices, sampler: NeighborSampler, batch_size: int = 1,
-                 shuffle: bool = False, drop_last: bool = False, generator: Optional[torch.Generator] = None, **_ignored):
+                 shuffle: bool = False, drop_last: bool = False, generator: Optional[torch.Generator] = None, prefetch: bool = True,
+                 **_ignored):
         self.graph, self.sampler = graph, sampler
         self.indices = torch.as_tensor(indices, dtype=torch.int64).to(graph.device)  # seeds live where the graph lives
         self.batch_size, self.shuffle, self.drop_last, self.generator = batch_size, shuffle, drop_last, generator
+        self.prefetch = prefetch
 
     def __len__(self):
         n = self.indices.numel()
@@ -263,5 +303,43 @@ class DataLoader:
             perm = (torch.randperm(idx.numel(), device=idx.device) if self.generator is None else
                     torch.randperm(idx.numel(), generator=self.generator).to(idx.device))
             idx = idx[perm]
-        for i in range(len(self)):
-            yield self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size])
+        n = len(self)
+        if not (self.prefetch and idx.is_cuda and n > 1):
+            for i in range(n):
+                yield self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size])
+            return
+        # Blocks are built one batch ahead on a side stream: the builder's only host round trip (the size read between
+        # dh_block_plan and dh_block_fill) then waits for a handful of small kernels instead of for the model's forward /
+        # backward of the previous batch still running on the caller's stream — the host keeps enqueuing, the GPU never idles.
+        main = torch.cuda.current_stream(idx.device)
+        side = _side_stream(idx.device)
+        side.wait_stream(main)  # the (shuffled) seeds and the graph are ready
+
+        def build(i):
+            with torch.cuda.stream(side):
+                out = self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size])
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return out, ev
+
+        nxt = build(0)
+        for i in range(n):
+            (inp, outn, blocks), ev = nxt
+            if i + 1 < n:
+                nxt = build(i + 1)
+            main.wait_event(ev)
+            for blk in blocks:  # allocated on the side stream, consumed on the caller's
+                for t in (blk.rowptr, blk.col, blk.val, blk.srcdata["_ID"]):
+                    if t is not None:
+                        t.record_stream(main)
+            yield inp, outn, blocks
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index or 0
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]

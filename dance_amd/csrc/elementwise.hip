@@ -199,3 +199,56 @@ extern "C" int dh_gaussian_kernel_f32(int64_t n_rows, int64_t n_cols, const floa
                      n_rows, n_cols, D, ldd, (float)(2.0 * (l * l)), out, ldo, rowsum);
   return dh::check_launch("dh_gaussian_kernel_f32");
 }
+
+// Dense part of the inner-product decoder loss of graph-sc (dance/modules/single_modality/clustering/graphsc.py:208-216:
+// binary_cross_entropy_with_logits(z z^T, adj, pos_weight) over a B x B block whose target `adj` is all zero except for the
+// few edges among the batch's own cells).  With y = 0 the element loss is softplus(x) and its derivative sigmoid(x); the
+// sparse y = 1 corrections are applied by the caller on the edge list.  torch evaluates this as ~15 elementwise passes over
+// the 268 MB logit matrix (B = 8192) plus a dense target; here the forward is ONE read (row sums of softplus, f64
+// accumulation, one wavefront per row — deterministic) and the backward one read + one write.
+namespace {
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void softplus_rowsum_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                              float* __restrict__ rowsum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* x = X + row * ldx;
+  double acc = 0.0;
+  for (int64_t c = lane; c < n_cols; c += 64) acc += (double)softplus_f(x[c]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) rowsum[row] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void sigmoid_scale_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ scale, float* __restrict__ out, int64_t ldo) {
+  const float s = scale[0];
+  const int64_t total = n_rows * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / n_cols, c = i - r * n_cols;
+    const float x = X[r * ldx + c];
+    out[r * ldo + c] = s / (1.f + expf(-x));
+  }
+}
+}  // namespace
+
+extern "C" int dh_softplus_rowsum_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, float* rowsum, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_softplus_rowsum_f32: negative size");
+  if (n_rows == 0) return DH_OK;
+  if (!rowsum || (n_cols > 0 && (!X || ldx < n_cols))) return dh::fail(DH_ERR_INVALID, "dh_softplus_rowsum_f32: bad pointer / leading dimension");
+  hipLaunchKernelGGL(softplus_rowsum_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx, rowsum);
+  return dh::check_launch("dh_softplus_rowsum_f32");
+}
+
+extern "C" int dh_sigmoid_scale_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* scale, float* out, int64_t ldo,
+                                    dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_sigmoid_scale_f32: negative size");
+  if (n_rows == 0 || n_cols == 0) return DH_OK;
+  if (!X || !out || !scale || ldx < n_cols || ldo < n_cols) return dh::fail(DH_ERR_INVALID, "dh_sigmoid_scale_f32: bad pointer / leading dimension");
+  const int64_t work = n_rows * n_cols;
+  const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 65536 ? dh::ceil_div(work, 256) : 65536);
+  hipLaunchKernelGGL(sigmoid_scale_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx, scale, out, ldo);
+  return dh::check_launch("dh_sigmoid_scale_f32");
+}

@@ -227,6 +227,24 @@ def gaussian_kernel(D: torch.Tensor, l: float, *, want_out: bool = True, want_ro
     return out, rs
 
 
+def softplus_rowsum(X: torch.Tensor) -> torch.Tensor:
+    """rowsum[r] = sum_c softplus(X[r, c]) (dh_softplus_rowsum_f32)."""
+    lib = _lib_ready()
+    out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+    _call("softplus_rowsum_f32", lib.dh_softplus_rowsum_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X), out.data_ptr(),
+          _stream())
+    return out
+
+
+def sigmoid_scale(X: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """scale * sigmoid(X) with a device-resident scalar ``scale`` (dh_sigmoid_scale_f32)."""
+    lib = _lib_ready()
+    out = torch.empty(X.shape, dtype=torch.float32, device=X.device)
+    _call("sigmoid_scale_f32", lib.dh_sigmoid_scale_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          _dev(scale.reshape(1), torch.float32, "scale", 1), out.data_ptr(), _ld(out), _stream())
+    return out
+
+
 def colsum(X: torch.Tensor) -> torch.Tensor:
     """out[j] = sum_i X[i, j] (deterministic two-pass)."""
     lib = _lib_ready()
@@ -420,6 +438,33 @@ def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     _call("csr_row_normalize_f32", lib.dh_csr_row_normalize_f32, rowptr.numel() - 1,
           _dev(rowptr, torch.int32, "rowptr", 1), _dev(val, torch.float32, "val", 1), out.data_ptr(), _stream())
     return out
+
+
+# ---- blocks of the full-neighbour sampler ---------------------------------------------------------------------
+def block_build(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], seeds: torch.Tensor, mark: torch.Tensor,
+                lut: torch.Tensor):
+    """dh_block_plan + dh_block_fill: the full-fan-out in-neighbour block of ``seeds`` (int64, unique).
+    ``mark`` (uint8 [n_nodes], all zero — it is returned all zero) and ``lut`` (int32 [n_nodes]) persist with the graph.
+    Returns (block_rowptr int32 [B+1], block_col int32 [E], block_val f32 [E] | None, src_ids int64 [B + others])."""
+    lib = _lib_ready()
+    n_nodes, n_seeds = rowptr.numel() - 1, seeds.numel()
+    dev = rowptr.device
+    brp = torch.empty(n_seeds + 1, dtype=torch.int32, device=dev)
+    totals = torch.empty(2, dtype=torch.int32, device=dev)
+    ws_bytes = lib.dh_block_workspace_bytes(n_nodes, n_seeds)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    sp = _dev(seeds, torch.int64, "seeds", 1)
+    _call("block_plan", lib.dh_block_plan, n_nodes, n_seeds, sp, _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),
+          _dev(mark, torch.uint8, "mark", 1), _dev(lut, torch.int32, "lut", 1), brp.data_ptr(), totals.data_ptr(), ws.data_ptr(), ws_bytes,
+          _stream())
+    n_edges, n_others = totals.tolist()  # the one host round trip of a block
+    bcol = torch.empty(n_edges, dtype=torch.int32, device=dev)
+    bval = torch.empty(n_edges, dtype=torch.float32, device=dev) if val is not None else None
+    src_ids = torch.empty(n_seeds + n_others, dtype=torch.int64, device=dev)
+    _call("block_fill", lib.dh_block_fill, n_nodes, n_seeds, sp, rowptr.data_ptr(), col.data_ptr(), _dev(val, torch.float32, "val", 1),
+          mark.data_ptr(), lut.data_ptr(), brp.data_ptr(), bcol.data_ptr(), None if bval is None else bval.data_ptr(), src_ids.data_ptr(),
+          ws.data_ptr(), ws_bytes, _stream())
+    return brp, bcol, bval, src_ids
 
 
 # ---- AdaptiveSAGE ------------------------------------------------------------------------------------------

@@ -54,6 +54,11 @@ class GNN(nn.Module):
 class ScDeepSort(BaseClassificationMethod):
 
     shuffle_generator = None  # host torch.Generator for a reproducible train/val split and batch order (see fit)
+    # Evaluation / prediction passes (model.eval(), no gradient): per-cell logits do not depend on how the cells are batched,
+    # so with one SAGE layer they are computed for ALL cells in one piece straight on the graph's CSR rows — no sampling, no
+    # feature gathers — and indexed; the two evaluate() calls of an epoch share one such pass.  False = the reference's
+    # batch-by-batch loop over sampled blocks (scdeepsort.py:272-283,299-330), kept for block-exact parity checks.
+    full_graph_eval = True
 
     def __init__(self, dim_in: int, dim_hid: int, num_layers: int, species: str, tissue: str, *, dropout: int = 0,
                  batch_size: int = 500, device: str = "cuda", save_root=None, verbose: bool = True,
@@ -136,8 +141,9 @@ class ScDeepSort(BaseClassificationMethod):
         best_state_dict = None
         for epoch in range(epochs):
             loss = self.cal_loss(graph, train_idx)
-            train_acc = self.evaluate(graph, train_idx)[-1]
-            val_correct, val_unsure, val_acc = self.evaluate(graph, val_idx) if len(val_idx) else (0, 0, 0.0)
+            logits = self._full_graph_logits(graph)  # None: block-by-block evaluation
+            train_acc = self.evaluate(graph, train_idx, _logits=logits)[-1]
+            val_correct, val_unsure, val_acc = self.evaluate(graph, val_idx, _logits=logits) if len(val_idx) else (0, 0, 0.0)
             if max_val_acc <= val_acc:
                 final_val_correct_num, final_val_unsure_num = val_correct, val_unsure
                 _train_acc, _epoch, max_val_acc = train_acc, epoch, val_acc
@@ -153,7 +159,7 @@ class ScDeepSort(BaseClassificationMethod):
 
     def cal_loss(self, graph, idx: torch.Tensor):
         self.model.train()
-        total_loss = total_size = 0
+        losses, sizes = [], []
         dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
                                 generator=self.shuffle_generator)
         for _, _, blocks in dataloader:
@@ -164,13 +170,32 @@ class ScDeepSort(BaseClassificationMethod):
             self.optimizer.zero_grad()
             loss.backward()
             self.optimizer.step()
-            total_size += (size := blocks[-1].num_dst_nodes())
-            total_loss += loss.item() * size
-        return total_loss / total_size
+            sizes.append(blocks[-1].num_dst_nodes())
+            losses.append(loss.detach())  # read back once per epoch, not once per batch (scdeepsort.py:247-248)
+        total = sum(v * n for v, n in zip(torch.stack(losses).tolist(), sizes)) if losses else 0.0
+        return total / max(sum(sizes), 1)
 
     @torch.no_grad()
-    def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0):
+    def _full_graph_logits(self, graph):
+        """Logits of every cell from ONE pass over the graph (see ``full_graph_eval``); None when that mode does not apply
+        (more than one layer, or a node order other than CellFeatureGraph's genes-first)."""
+        if not self.full_graph_eval or self.n_layers != 1 or graph.gene_prefix() < 0:
+            return None
         self.model.eval()
+        blk = graph.cell_rows_block()
+        return self.model([blk], blk.srcdata["features"])
+
+    @torch.no_grad()
+    def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0, *, _logits=None):
+        self.model.eval()
+        if _logits is None:
+            _logits = self._full_graph_logits(graph)
+        if _logits is not None:
+            rows = idx.to(_logits.device) - graph.gene_prefix()
+            pred, labels = _logits[rows], graph.ndata["label"][idx.to(_logits.device)]
+            unsure = pred.max(1).values < unsure_rate / self.num_labels  # :280-281 (on raw logits, as written)
+            stats = torch.stack((((pred.argmax(1) == labels) & ~unsure).sum(), unsure.sum())).tolist()
+            return stats[0], stats[1], stats[0] / len(idx)
         total_correct = total_unsure = 0
         dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
                                 generator=self.shuffle_generator)
@@ -199,6 +224,9 @@ class ScDeepSort(BaseClassificationMethod):
         cell_mask = (graph.ndata["cell_id"] == -1).cpu()
         idx = torch.where(cell_mask)[0]
         graph = self._typed(graph.to(self.device))
+        full = self._full_graph_logits(graph)
+        if full is not None:
+            return nn.functional.softmax(full.float(), dim=-1).cpu().numpy()
         logits = torch.zeros(graph.number_of_nodes(), self.num_labels)
         dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size)
         for _, output_nodes, blocks in dataloader:

@@ -43,20 +43,24 @@ class WeightedGraphConv(nn.Module):
             nn.init.zeros_(self.bias)
 
     def forward(self, graph, feat, weight=None, agg="sum"):
-        in_deg = graph.in_degrees()
-        if not self._allow_zero_in_degree and bool((in_deg == 0).any()):
+        if not self._allow_zero_in_degree and graph.has_zero_in_degree():  # answered per GRAPH when it has none (no sync per block)
             raise RuntimeError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
                                "Adding self-loop on the input graph will resolve the issue.")
         if weight is not None and self.weight is not None:
             raise RuntimeError("External weight is provided while at the same time the module has defined its own "
                                "weight parameter. Please create the module with flag weight=False.")
         weight = self.weight if weight is None else weight
-        colscale = rowscale = None
-        if self._norm == "both":
-            colscale = graph.out_degrees().float().clamp(min=1).pow(-0.5)  # :444-449
-            rowscale = in_deg.float().clamp(min=1).pow(-0.5)  # :467-471
-        elif self._norm != "none":  # "right" AND "left": the reference only scales the source side for "both" (:444)
-            rowscale = 1.0 / in_deg.float().clamp(min=1)  # and divides by the in-degree for every other norm (:467-474)
+        # degree scalings of this block: computed once per block (graph-sc runs two forwards per batch, graphsc.py:202,215)
+        cache = graph.__dict__.setdefault("_wgc_scales", {})
+        if self._norm not in cache:
+            colscale = rowscale = None
+            if self._norm == "both":
+                colscale = graph.out_degrees().float().clamp(min=1).pow(-0.5)  # :444-449
+                rowscale = graph.in_degrees().float().clamp(min=1).pow(-0.5)  # :467-471
+            elif self._norm != "none":  # "right" AND "left": the reference only scales the source side for "both" (:444)
+                rowscale = 1.0 / graph.in_degrees().float().clamp(min=1)  # and divides by the in-degree for every other norm (:467-474)
+            cache[self._norm] = (colscale, rowscale)
+        colscale, rowscale = cache[self._norm]
         relu = self._activation in (F.relu, torch.relu) or isinstance(self._activation, nn.ReLU)
         g = CSRGraph(graph.rowptr, graph.col, graph.val, graph.number_of_dst_nodes(), graph.number_of_src_nodes())
         rst = gcn_layer(feat, weight, g, self.bias, relu, rowscale=rowscale, colscale=colscale,
@@ -102,7 +106,9 @@ class GCNAE(nn.Module):
                     enc.append(nn.ReLU())
             self.encoder = nn.Sequential(*enc)
 
-    def forward(self, blocks, features):
+    def forward(self, blocks, features, decode: bool = True):
+        """``decode=False`` returns (None, embedding): GraphSC.fit's first forward of a batch only keeps the embedding
+        (graphsc.py:202-203 discards ``adj_logits``), so the B x B product need not be formed there."""
         x = blocks[0].srcdata["features"]
         for i in range(len(blocks)):
             if self.dropout is not None:
@@ -110,19 +116,57 @@ class GCNAE(nn.Module):
             x = (self.layer1 if i == 0 else self.layer2)(blocks[i], x, agg=self.agg)
         if self.hidden is not None:
             x = self.encoder(x)
-        return self.decoder(x), x
+        return (self.decoder(x) if decode else None), x
 
 
 def block_dst_adjacency(block) -> torch.Tensor:
     """``g.adjacency_matrix().to_dense()[dst][:, dst]`` of the reference (:208-209): B x B, entry [u, v] = 1 for an
     edge u -> v between two destination nodes of the block."""
     b = block.number_of_dst_nodes()
-    rows = torch.repeat_interleave(torch.arange(b, device=block.rowptr.device), block.in_degrees())
     cols = block.col.to(torch.int64)
-    keep = cols < b
+    rows = torch.repeat_interleave(torch.arange(b, device=block.rowptr.device), block.in_degrees(), output_size=cols.numel())
+    keep = cols < b  # edges whose source is itself a destination node; the others add 0 at a clamped position (no host sync)
     adj = torch.zeros((b, b), dtype=torch.float32, device=block.rowptr.device)
-    adj.index_put_((cols[keep], rows[keep]), torch.ones(int(keep.sum()), device=adj.device), accumulate=True)
+    adj.index_put_((cols.clamp(max=b - 1), rows), keep.to(torch.float32), accumulate=True)
     return adj
+
+
+def block_dst_edges(block):
+    """The edges of ``block_dst_adjacency`` as lists, without a host round trip: (u, v, m) over ALL block edges, m = 1 where
+    the source is itself a destination node of the block (u < B) and 0 otherwise (u is then clamped into range)."""
+    b = block.number_of_dst_nodes()
+    cols = block.col.to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(b, device=block.rowptr.device), block.in_degrees(), output_size=cols.numel())
+    return cols.clamp(max=b - 1), rows, (cols < b).to(torch.float32)
+
+
+class _SparseTargetBCE(torch.autograd.Function):
+    """mean(binary_cross_entropy_with_logits(x, y, pos_weight=p)) for a target y that is m[e] at (u[e], v[e]) and 0 elsewhere
+    (entries listed at most once) — graphsc.py:214-216 without the dense B x B target and torch's ~15 elementwise passes over
+    the logits: element loss softplus(x) (y = 0) resp. p * softplus(-x) (y = 1), evaluated as one fused pass over x
+    (dh_softplus_rowsum_f32) plus a correction on the edge list; backward = one pass (dh_sigmoid_scale_f32) + the same
+    correction."""
+
+    @staticmethod
+    def forward(ctx, x, u, v, m, p):
+        xe = x[u, v]
+        dense = kernels.softplus_rowsum(x).sum(dtype=torch.float64)
+        corr = (m * (p * F.softplus(-xe) - F.softplus(xe))).sum(dtype=torch.float64)
+        ctx.save_for_backward(x, u, v, m, p, xe)
+        return ((dense + corr) / x.numel()).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, u, v, m, p, xe = ctx.saved_tensors
+        scale = (g / x.numel()).to(torch.float32)
+        dx = kernels.sigmoid_scale(x, scale)
+        sig = torch.sigmoid(xe)
+        dx.index_put_((u, v), m * (p * (sig - 1) - sig) * scale, accumulate=True)
+        return dx, None, None, None, None
+
+
+def sparse_target_bce(logits, u, v, m, pos_weight):
+    return _SparseTargetBCE.apply(logits.contiguous(), u, v, m, pos_weight)
 
 
 class GraphSC(BaseClusteringMethod):
@@ -173,28 +217,33 @@ class GraphSC(BaseClusteringMethod):
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
             self.model.train()
-            z, order = [], []
+            z, order, losses = [], [], []
             for input_nodes, output_nodes, blocks in dataloader:
                 input_features = blocks[0].srcdata["features"]
                 last = blocks[-1]
-                adj_logits, emb = self.model.forward(blocks, input_features)
+                _, emb = self.model.forward(blocks, input_features, decode=False)  # :202 (its adj_logits are never used)
                 z.append(emb.detach())
                 order.append(last.dstdata["order"])
-                adj = block_dst_adjacency(last)
-                total = float(adj.shape[0] * adj.shape[0])
-                s = float(adj.sum())
-                pos_weight = torch.tensor([(total - s) / s], device=adj.device)
-                factor = (total - s) * 2 or 1
-                norm = total / factor
+                # the loss scalars of graphsc.py:208-214 stay on the device (the reference reads them back every batch; here the
+                # only host round trip of a batch is the block builder's size read)
+                # adj = g.adjacency_matrix().to_dense()[dst][:, dst] (:208-209) is zero except for the edges among the batch's own
+                # cells: it is kept as an edge list (block_dst_edges) and never materialised (block_dst_adjacency is the dense form)
+                eu, ev, em = block_dst_edges(last)
+                total = float(last.number_of_dst_nodes())**2
+                s = em.sum()
+                pos_weight = ((total - s) / s).reshape(1)
+                factor = (total - s) * 2
+                norm = total / torch.where(factor == 0, torch.ones_like(factor), factor)
                 adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
-                loss = norm * F.binary_cross_entropy_with_logits(adj_logits, adj, pos_weight=pos_weight)
+                loss = norm * sparse_target_bce(adj_logits, eu, ev, em, pos_weight)
                 optim.zero_grad()
                 loss.backward()
                 optim.step()
-                self.losses.append(loss.item())
-            z = torch.cat(z).cpu().numpy()
-            order = np.argsort(torch.cat(order).cpu().numpy())
-            self.z = z[order]
+                losses.append(loss.detach())
+            self.losses.extend(torch.stack(losses).tolist() if losses else [])
+            if eval_epoch or epoch == epochs - 1:  # the embedding only leaves the device when somebody reads it
+                zc = torch.cat(z).cpu().numpy()
+                self.z = zc[np.argsort(torch.cat(order).cpu().numpy())]
             if eval_epoch and y is not None:
                 aris.append(self.score(None, y))
                 Z[f"epoch{epoch}"] = self.z

@@ -83,7 +83,8 @@ class AdaptiveSAGE(nn.Module):
         return _SageAggregateFn.apply(h, self.alpha, block)
 
     def forward(self, block, h):
-        h_dst = h[:block.number_of_dst_nodes()]
+        off = getattr(block, "dst_offset", 0)  # 0 for sampled blocks (dst nodes lead the sources); G for the full-graph cell rows
+        h_dst = h[off:off + block.number_of_dst_nodes()]
         if self.use_neigh:
             neigh = self.aggregate(block, h)
             self.last_neigh = neigh.detach()

@@ -214,6 +214,36 @@ DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t 
                                const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
                                float* out_val, int32_t* out_eid, dh_stream_t stream);
 
+/* ---- dense part of graph-sc's inner-product decoder loss (graphsc.py:208-216) ------------------------------
+ * binary_cross_entropy_with_logits(X, adj, pos_weight) with a target that is zero almost everywhere: element loss
+ * softplus(x), derivative sigmoid(x); the y = 1 corrections are sparse and stay with the caller.
+ * dh_softplus_rowsum_f32: rowsum[r] = sum_c softplus(X[r,c]) (f64 accumulation, deterministic);
+ * dh_sigmoid_scale_f32:   out = scale[0] * sigmoid(X)  (scale is a DEVICE scalar: no host round trip).            */
+DH_API int dh_softplus_rowsum_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, float* rowsum,
+                           dh_stream_t stream);
+DH_API int dh_sigmoid_scale_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* scale,
+                         float* out, int64_t ldo, dh_stream_t stream);
+
+/* ---- message-flow blocks of the full-neighbour sampler (block.hip) -------------------------------------------
+ * What dgl.dataloading.NeighborSampler([-1]*L, edge_dir="in") / MultiLayerFullNeighborSampler produce for a batch of
+ * seed nodes (scdeepsort.py:183,233-236; graphsc.py:181-183): every in-edge of the seeds; source nodes = the seeds first,
+ * then the remaining in-neighbours by ascending id; block columns index that source list.
+ *   dh_block_plan: block_rowptr [n_seeds+1] (scan of the seed degrees) and totals[2] = {block edges, non-seed sources};
+ *                  the caller reads `totals` (its only host round trip) to size the outputs of
+ *   dh_block_fill: src_ids int64 [n_seeds + totals[1]], block_col int32 / block_val f32 [totals[0]] (block_val may be NULL
+ *                  together with val).
+ * mark: uint8 [n_nodes], all zero on entry and again on return of dh_block_fill; lut: int32 [n_nodes] scratch (node ->
+ * position in src_ids, valid for the block's sources only).  Both persist with the graph; workspace (same buffer for
+ * both calls) from dh_block_workspace_bytes.  Seeds must be unique.                                              */
+DH_API size_t dh_block_workspace_bytes(int64_t n_nodes, int64_t n_seeds);
+DH_API int dh_block_plan(int64_t n_nodes, int64_t n_seeds, const int64_t* seeds, const int32_t* rowptr,
+                  const int32_t* col, uint8_t* mark, int32_t* lut, int32_t* block_rowptr, int32_t* totals,
+                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
+DH_API int dh_block_fill(int64_t n_nodes, int64_t n_seeds, const int64_t* seeds, const int32_t* rowptr,
+                  const int32_t* col, const float* val, uint8_t* mark, int32_t* lut,
+                  const int32_t* block_rowptr, int32_t* block_col, float* block_val, int64_t* src_ids,
+                  void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
 /* ---- K4/K7: AdaptiveSAGE message + mean aggregation -----------------------------------------
  * neigh[v,:] = mean_{e=(u->v)} alpha[idx(e)] * w_e * H[u,:], idx(e) chosen from the src/dst
  * "cell_id" arrays exactly as dance/models/nn/gnn.py:72-76 (gene->cell: src id; cell->gene:

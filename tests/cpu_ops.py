@@ -52,3 +52,26 @@ def knn(X, k, q_begin=0, q_end=None, *, algo=0):
     from oracle import graphs as og
     idx, dist = og.knn_exact(X.numpy(), k, q_begin=q_begin, q_end=X.shape[0] if q_end is None else q_end)
     return torch.from_numpy(idx), torch.from_numpy(dist)
+
+
+def block_build(rowptr, col, val, seeds, mark, lut):
+    """Torch-op restatement of ``dance_amd.kernels.block_build`` (dh_block_plan / dh_block_fill): all in-edges of ``seeds``;
+    source nodes = seeds first, then the remaining in-neighbours by ascending id.  TEST ONLY (oracle for the HIP builder and
+    stand-in for the loader logic tests on CPU tensors)."""
+    seeds = seeds.to(torch.int64)
+    n_nodes = rowptr.numel() - 1
+    start = rowptr[seeds].to(torch.int64)
+    deg = rowptr[seeds + 1].to(torch.int64) - start
+    brp = torch.zeros(seeds.numel() + 1, dtype=torch.int64, device=rowptr.device)
+    brp[1:] = torch.cumsum(deg, 0)
+    total = int(brp[-1])
+    pos = torch.repeat_interleave(start - brp[:-1], deg) + torch.arange(total, device=rowptr.device)
+    gcol = col[pos].to(torch.int64)
+    m = torch.zeros(n_nodes, dtype=torch.bool, device=rowptr.device)
+    m[gcol] = True
+    m[seeds] = False
+    others = torch.nonzero(m).reshape(-1)
+    src_ids = torch.cat((seeds, others))
+    table = torch.empty(n_nodes, dtype=torch.int64, device=rowptr.device)
+    table[src_ids] = torch.arange(src_ids.numel(), device=rowptr.device)
+    return brp.to(torch.int32), table[gcol].to(torch.int32), None if val is None else val[pos].contiguous(), src_ids

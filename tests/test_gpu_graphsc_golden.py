@@ -86,3 +86,27 @@ def test_weighted_graph_conv_left_norm_is_in_degree_division(cuda_device, gold):
     assert torch.equal(outs["left"], outs["right"])
     deg = blk.in_degrees().float().clamp(min=1)[:, None]
     assert rel_err((outs["none"] / deg).cpu().numpy(), outs["left"].cpu().numpy()) < 1e-6
+
+
+def test_sparse_target_bce_matches_torch_dense(cuda_device):
+    """The fused decoder loss == F.binary_cross_entropy_with_logits on the dense block adjacency (value and gradient)."""
+    import torch.nn.functional as F
+
+    from dance_amd.modules.single_modality.clustering.graphsc import sparse_target_bce
+    torch.manual_seed(0)
+    b = 300
+    x = (torch.randn(b, b, device=cuda_device) * 3).requires_grad_(True)
+    e = 500
+    u, v = torch.randint(0, b, (e, ), device=cuda_device), torch.randint(0, b, (e, ), device=cuda_device)
+    key = torch.unique(u * b + v)                      # listed at most once
+    u, v = key // b, key % b
+    m = (torch.rand(u.numel(), device=cuda_device) < 0.7).float()
+    adj = torch.zeros(b, b, device=cuda_device)
+    adj[u, v] = m
+    p = torch.tensor([7.5], device=cuda_device)
+    ref = F.binary_cross_entropy_with_logits(x, adj, pos_weight=p)
+    gref, = torch.autograd.grad(ref * 3.0, x)
+    got = sparse_target_bce(x, u, v, m, p)
+    ggot, = torch.autograd.grad(got * 3.0, x)
+    assert abs(float(got) - float(ref)) < 1e-6 * abs(float(ref))
+    assert rel_err(ggot.cpu().numpy(), gref.cpu().numpy()) < 1e-5

@@ -119,3 +119,30 @@ def test_scdeepsort_fit_predict_small(cuda_device, tmp_path):
     assert np.abs(prob - ref_prob).max() < 1e-5
     assert torch.all(sd["alpha"] == 1)  # never trained in the reference as written
     assert (tmp_path / "saved_models/single_modality/cell_type_annotation/pretrained/synthetic/models/synthetic-blob.pt").exists()
+
+
+def test_full_graph_eval_equals_block_eval(cuda_device, tmp_path):
+    """``full_graph_eval`` (one pass over the CSR rows of all cells) gives the logits / statistics of the reference's
+    batch-by-batch loop over sampled blocks (scdeepsort.py:272-283,299-330), including the aggregated ``neigh``."""
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    n_cells, n_genes, d = 900, 70, 24
+    x, g = _graph(n_cells, n_genes, d, 11, cuda_device)
+    labels = torch.from_numpy(np.random.default_rng(0).integers(0, 5, n_cells))
+    model = ScDeepSort(d, 16, 1, "synthetic", "fg", batch_size=128, device="cuda", save_root=tmp_path, verbose=False)
+    model.shuffle_generator = torch.Generator().manual_seed(0)
+    model.fit(g, labels, epochs=2, lr=1e-2)
+    assert g.gene_prefix() == n_genes
+    idx = torch.arange(n_genes + 100, n_genes + 700, device=cuda_device)
+    gg = g.to("cuda")
+    gg.ndata["label"] = torch.cat((-torch.ones(n_genes, dtype=torch.long), labels)).to(cuda_device)
+    full = model.evaluate(gg, idx)
+    neigh_full = model.model.layers[0].last_neigh.clone()
+    prob_full = model.predict_proba(g)
+    model.full_graph_eval = False
+    blockwise = model.evaluate(gg, idx)
+    prob_block = model.predict_proba(g)
+    assert full == blockwise
+    assert np.abs(prob_full - prob_block).max() < 1e-6
+    # the full-graph neigh rows are those of the per-batch blocks (last batch of predict_proba = the last cells)
+    last = model.model.layers[0].last_neigh
+    assert torch.allclose(neigh_full[-last.shape[0]:], last, rtol=1e-5, atol=1e-6)

@@ -82,11 +82,16 @@ def test_weighted_feature_pca_shapes():
     assert d.data.obsm["WeightedFeaturePCA"].dtype == np.float32
 
 
-def test_block_sampler_on_cpu_tensors():
-    """The DGL-like graph / block / sampler / loader surface is index plumbing on torch tensors and runs on CPU tensors
-    too (no HIP involved): full in-neighbour blocks, lazy src/dst frames, seeds-first source order."""
+def test_block_sampler_on_cpu_tensors(monkeypatch):
+    """The DGL-like graph / block / sampler / loader surface around the block builder: lazy src/dst frames, seeds-first
+    source order, batching.  The builder itself is a HIP kernel (dh_block_plan / dh_block_fill, GPU-tested against the same
+    torch-op restatement); here that restatement is injected so the host logic runs on CPU tensors."""
     import torch
+
+    import cpu_ops
+    from dance_amd import kernels
     from dance_amd.cellgraph import CellGeneGraph, DataLoader, NeighborSampler
+    monkeypatch.setattr(kernels, "block_build", cpu_ops.block_build)
     # 3 genes (0..2), 4 cells (3..6); CSR by destination with a self loop per node
     src = [[0, 3, 5], [1, 4], [2, 3, 6], [0, 2, 3], [1, 4], [0, 5], [2, 6]]
     rowptr = torch.tensor(np.cumsum([0] + [len(r) for r in src]), dtype=torch.int32)
