@@ -12,7 +12,14 @@ in the reference: scdsc.py:247,286-288).  With N > 1 the 1M cells are sharded by
 (all-gather, or the feature-sliced all-to-all when the graph has no locality) and dW is all-reduced, all inside
 the timed region.  Inputs are generated on the device and resident in HBM before
 the timed region; graph set-up (CSR transpose) is outside it, as graph construction is in the reference.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0.  Besides the headline (rand-k15) the line carries
+
+* ``roofline``: the dominant kernel against its own roofline AND ``layer_hbm_frac`` = the layer's algorithmic bytes
+  (85.9 GB at the headline size) / step time / 8 TB/s — the metric's "fraction of HBM roofline";
+* ``knn_k15`` (1 GPU): the same layer timed on the metric's literal graph — exact kNN (k = 15, self included) of a
+  clustered 50-d embedding + UMAP connectivities, built by NeighborGraph's own kernels inside this script;
+* N > 1: ``exchange`` — every exchange mode timed with the same K steps (halo all-to-all-v, dense all-gather, feature-sliced
+  all-to-all), bytes on the wire per step and the exchange alone timed without compute; the headline is the fastest mode.
 """
 import argparse
 import json
@@ -55,6 +62,37 @@ def synth_rand_graph(n, k, device, seed):
     return rowptr, col.to(torch.int32).reshape(-1).contiguous(), val
 
 
+def synth_knn_graph(n, k, device, seed):
+    """'knn-k15' (SURVEY.md §8d): cells from 20 Gaussian clusters in a 50-d latent space; exact kNN (self included) and
+    UMAP connectivities by the NeighborGraph kernels (dh_knn_bruteforce_f32, dh_umap_membership_f32, ...)."""
+    from dance_amd import kernels
+    from dance_amd.graph import CSRGraph
+    g = torch.Generator(device=device).manual_seed(seed)
+    centers = torch.randn((20, 50), device=device, generator=g) * 4.0
+    emb = centers[torch.randint(0, 20, (n, ), device=device, generator=g)] + torch.randn((n, 50), device=device, generator=g)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx, dist_ = kernels.knn(emb, k)
+    (rowptr, col, val), _ = kernels.umap_connectivities(idx, dist_.contiguous())
+    torch.cuda.synchronize()
+    return CSRGraph(rowptr, col, val, n, n, symmetric=True), time.perf_counter() - t0
+
+
+def layer_bytes(n, nnz, f=N_GENES, h=N_HIDDEN, s=4):
+    """B_layer of SURVEY.md §8(d): GEMM fwd + SpMM(A) + SpMM(A^T) + GEMM dW."""
+    return 2.0 * n * f * s + 4.0 * n * h * s + 2.0 * nnz * h * s + 2.0 * nnz * (4 + s) + 8.0 * (n + 1) + 2.0 * f * h * s
+
+
+def source_hashes():
+    """sha256 of the kernel sources the PMC traffic file was collected for (stale counters must not be reported)."""
+    import hashlib
+    out = {}
+    for name in ("gemm_f32.hip", "spmm.hip", "common.h"):
+        with open(os.path.join(ROOT, "dance_amd", "csrc", name), "rb") as fh:
+            out[name] = hashlib.sha256(fh.read()).hexdigest()
+    return out
+
+
 def cpu_baseline(sample_cells, min_seconds=10.0, max_iters=5):
     """The reference's CPU path for the same layer — oracle.layers.GNNLayer (torch-CPU mm + spmm + autograd,
     a port of scdsc.py:475-501) — timed on this host's cores on a bounded sample of the workload."""
@@ -88,16 +126,69 @@ def cpu_baseline(sample_cells, min_seconds=10.0, max_iters=5):
             "host_cpu_count": os.cpu_count()}
 
 
+def time_steps(step, fence, steps, warmup, world, dev, timer_cls):
+    """W untimed + exactly K timed steps bracketed by barrier + synchronize; MAX over ranks.  Returns (seconds, timer)."""
+    for _ in range(warmup):
+        step()
+    fence()
+    with timer_cls() as timer:
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, timer
+
+
+def time_exchange_only(sg, h, iters, fence, dev):
+    """The collectives of one step (forward + backward exchange) on buffers of the real size, nothing else: ms per step."""
+    n_local = sg.a.n_rows
+    s = torch.randn((n_local, h), device=dev)
+
+    def once():
+        if sg.mode == "halo":
+            for plan in (sg.halo, sg.halo_t):
+                recv = torch.empty((plan.n_halo, h), device=dev)
+                w = sg.halo_exchange(plan, s[plan.send_idx.long()] if plan.send_idx.numel() else s[:0], recv)
+                if w is not None:
+                    w.wait()
+        elif sg.mode == "alltoall":
+            for _ in range(2):
+                sg.columns_to_rows(sg.rows_to_columns(s), n_local)
+        else:
+            sg.all_gather_rows(s)
+            sg.all_gather_rows(s)
+    once()
+    fence()
+    before = dict(sg.stats)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        once()
+    fence()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    t = torch.tensor([ms], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_step = (sg.stats["exchanged_bytes"] - before["exchanged_bytes"]) / iters
+    sg.stats.update(before)
+    return float(t.item()), per_step
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=N_CELLS, help="total cells (default: the BASELINE config)")
-    ap.add_argument("--cpu-sample-cells", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-cells", type=int, default=100_000,
+                    help="cells of the CPU baseline sample (1000000 = the full workload: ~1.5 min of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", choices=["auto", "allgather", "alltoall"], default="auto",
-                    help="multi-GPU exchange (dance_amd/sharding.py); auto = alltoall when most remote rows are referenced")
+    ap.add_argument("--no-knn-workload", action="store_true", help="skip the second (knn-k15) timed workload at 1 GPU")
+    ap.add_argument("--exchange", choices=["auto", "halo", "allgather", "alltoall"], default="auto",
+                    help="multi-GPU exchange (dance_amd/sharding.py); auto = time every mode, headline = the fastest")
     args = ap.parse_args()
 
     from dance_amd import _lib, kernels, sharding
@@ -116,34 +207,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.cells
-    # ---- inputs resident in HBM before the timed region ---------------------------------------------------
-    rowptr, col, val = synth_rand_graph(n, K_NEIGH, dev, seed=1)
-    graph = CSRGraph(rowptr, col, val, n, n)
-    mode = args.exchange
-    if mode == "auto":
-        mode = "allgather"
-        if world > 1 and N_HIDDEN % world == 0:
-            rng_lo, rng_hi = sharding.row_ranges(n, world)[0][rank]
-            e0, e1 = int(rowptr[rng_lo]), int(rowptr[rng_hi])
-            remote = float(((col[e0:e1] < rng_lo) | (col[e0:e1] >= rng_hi)).float().mean()) if e1 > e0 else 0.0
-            t = torch.tensor([remote], device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)  # one decision for all ranks
-            mode = "alltoall" if float(t.item()) > 0.5 else "allgather"
-    sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)  # world == 1: the whole graph
-    lo, hi = sg.ranges[sg.rank]
-    n_local = hi - lo
-    del graph, rowptr, col, val
-    x = synth_features(n_local, N_GENES, dev, seed=100 + rank)
-    gen = torch.Generator(device=dev).manual_seed(2)
-    bound = (6.0 / (N_GENES + N_HIDDEN))**0.5  # xavier_uniform, same W on every rank
-    w = ((torch.rand((N_GENES, N_HIDDEN), device=dev, generator=gen) * 2 - 1) * bound).requires_grad_(True)
-    dy = torch.randn((n_local, N_HIDDEN), device=dev, generator=torch.Generator(device=dev).manual_seed(3 + rank))
-    torch.cuda.synchronize()
-
-    def step():
-        w.grad = None
-        y = sharding.sharded_gcn_layer(x, w, sg, None, True)
-        y.backward(dy)
 
     def fence():
         torch.cuda.synchronize()
@@ -151,23 +214,65 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    with kernels.KernelTimer() as timer:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # ---- inputs resident in HBM before the timed region ---------------------------------------------------
+    rowptr, col, val = synth_rand_graph(n, K_NEIGH, dev, seed=1)
+    graph = CSRGraph(rowptr, col, val, n, n)
+    ranges, _ = sharding.row_ranges(n, world)
+    lo, hi = ranges[rank]
+    n_local = hi - lo
+    x = synth_features(n_local, N_GENES, dev, seed=100 + rank)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    bound = (6.0 / (N_GENES + N_HIDDEN))**0.5  # xavier_uniform, same W on every rank
+    w = ((torch.rand((N_GENES, N_HIDDEN), device=dev, generator=gen) * 2 - 1) * bound).requires_grad_(True)
+    dy = torch.randn((n_local, N_HIDDEN), device=dev, generator=torch.Generator(device=dev).manual_seed(3 + rank))
+    torch.cuda.synchronize()
+
+    def make_step(sg):
+        def step():
+            w.grad = None
+            y = sharding.sharded_gcn_layer(x, w, sg, None, True)
+            y.backward(dy)
+        return step
+
+    modes = [args.exchange]
+    if world == 1:
+        modes = ["allgather"]  # one GPU: the shard is the graph, no exchange
+    elif args.exchange == "auto":
+        modes = ["halo", "allgather"] + (["alltoall"] if N_HIDDEN % world == 0 else [])
+    runs = {}
+    for mode in modes:
+        sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)  # world == 1: the whole graph
+        elapsed, timer = time_steps(make_step(sg), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
+        runs[mode] = dict(sg=sg, elapsed=elapsed, ksum=timer.summary(), bytes_per_step=sg.stats["exchanged_bytes"] / max(args.steps + args.warmup, 1))
+        if world > 1:
+            ex_ms, ex_bytes = time_exchange_only(sg, N_HIDDEN, max(3, args.steps // 4), fence, dev)
+            runs[mode].update(exchange_only_ms=ex_ms, exchange_only_bytes=ex_bytes)
+        if len(modes) > 1:
+            runs[mode]["sg"] = None
+            sg_keep = None
+            del sg
+            torch.cuda.empty_cache()
+    mode = min(runs, key=lambda m: runs[m]["elapsed"])
+    elapsed, ksum = runs[mode]["elapsed"], runs[mode]["ksum"]
+    sg = runs[mode]["sg"] or sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
+    nnz_total = int(graph.nnz)
+
+    knn_out = None
+    if world == 1 and not args.no_knn_workload:
+        del sg
+        kg, build_s = synth_knn_graph(n, K_NEIGH, dev, seed=7)
+        sgk = sharding.ShardedGCNGraph.from_global_csr(kg)
+        k_elapsed, _ = time_steps(make_step(sgk), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
+        k_ms = k_elapsed / args.steps * 1e3
+        knn_out = {"workload": f"same layer on knn-k15: exact kNN (k={K_NEIGH}, self included) of a 20-cluster 50-d embedding + UMAP "
+                               f"connectivities, built on the device by the NeighborGraph kernels",
+                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "ms_per_step": k_ms, "value": n / (k_elapsed / args.steps),
+                   "unit": "cells/s", "layer_hbm_frac": round(layer_bytes(n, kg.nnz) / (k_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)}
+        del sgk, kg
+        sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        ksum = timer.summary()
         nnz_local = int(sg.a.col.numel())
         nnz_t_local = int(sg.at.col.numel())
         gemm_flops = 2.0 * n_local * N_GENES * N_HIDDEN
@@ -186,7 +291,7 @@ def main():
             e = {"launches": launches, "avg_ms": round(ms, 4)}
             if name.startswith("gemm_f32"):
                 e.update(bound="mfma", achieved=round(gemm_flops / ms / 1e9, 2), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s")
-            elif name.startswith("spmm_csr_f32"):
+            elif name.startswith("spmm_csr_f32") and (world == 1 or mode != "halo"):  # halo mode: two partial launches per call
                 b = spmm_bytes(nnz_local if "fwd" in name else nnz_t_local, n_local)
                 e.update(bound="hbm", achieved=round(b / ms / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s")
             elif name.startswith("relu_backward"):
@@ -196,12 +301,20 @@ def main():
             kernels_out[name] = e
         dominant = max((k for k in kernels_out if "achieved" in kernels_out[k]), key=lambda k: kernels_out[k]["avg_ms"] * kernels_out[k]["launches"])
         d = kernels_out[dominant]
-        traffic = None
+        traffic, traffic_note = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")  # PMC-derived bytes/launch, see profiles/README.md
         if os.path.exists(tpath) and n == N_CELLS and world == 1:
-            traffic = json.load(open(tpath)).get(dominant)
+            tj = json.load(open(tpath))
+            if tj.get("source_sha256") == source_hashes():
+                traffic = tj.get(dominant)
+            else:
+                traffic_note = "profiles/hbm_traffic.json was collected for other kernel sources (sha256 mismatch): not reported"
         roofline = {"kernel": dominant, "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
-                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic}
+                    "unit": d["unit"], "frac": d["frac"], "traffic": traffic,
+                    "layer_algorithmic_GB": round(layer_bytes(n, nnz_total) / 1e9, 2),
+                    "layer_hbm_frac": round(layer_bytes(n, nnz_total) / (ms_per_step * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)}
+        if traffic_note:
+            roofline["traffic_note"] = traffic_note
         out = {
             "metric": "cells/sec per GCN fwd+bwd, 1M cells x 2k genes k=15",
             "value": n / (elapsed / args.steps), "unit": "cells/s", "n_gpus": world, "steps": args.steps,
@@ -213,6 +326,13 @@ def main():
                        "parallelism": f"dst-range x{world}, {mode} exchange" if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels_out,
         }
+        if world > 1:
+            out["exchange"] = {m: {"ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4), "value": n / (r["elapsed"] / args.steps),
+                                   "bytes_on_wire_per_step_per_rank": int(r["exchange_only_bytes"]),
+                                   "exchange_only_ms_per_step": round(r["exchange_only_ms"], 4)} for m, r in runs.items()}
+            out["exchange"]["headline_mode"] = mode
+        if knn_out is not None:
+            out["knn_k15"] = knn_out
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_cells)
         print(json.dumps(out))

@@ -72,14 +72,15 @@ __device__ __forceinline__ float sage_alpha(const SageScale& sg, int sid, int di
 }
 
 // ReLU sign masks (fusing autograd's ReluBackward into the backward gather, dh_spmm_csr_relu_f32):
-// for the wavefront-per-row float4 configuration the forward pass stores, per row and per 256-column slice, the
-// four wave ballots "element i of lane l's float4 is > 0" (4 x uint64 = 256 bits); the backward pass gathers
-// dY rows and zeroes the elements whose bit is clear, so G = dY * [Y > 0] is never written to or read from HBM.
+// in the 32-lanes-per-row float4 configuration (128-column passes, two rows per wavefront) the forward pass stores, per
+// row and per 128-column slice, its half of the four wave ballots "element i of lane l's float4 is > 0" (4 x uint32 =
+// 128 bits); the backward pass gathers dY rows and zeroes the elements whose bit is clear, so G = dY * [Y > 0] is never
+// written to or read from HBM.
 struct ReluMask {
-  unsigned long long* out;       // forward: written when non-null   [n_rows][slices][4]
-  const unsigned long long* in;  // backward: applied to the gathered rows of Z when non-null [n_cols][slices][4]
-  int slices;                    // width / 256 of the whole layer
-  int slice0;                    // first 256-column slice of this launch (column-sliced passes)
+  uint32_t* out;       // forward: written when non-null   [n_rows][slices][4]
+  const uint32_t* in;  // backward: applied to the gathered rows of Z when non-null [n_cols][slices][4]
+  int slices;          // width / 128 of the whole layer
+  int slice0;          // 128-column slice of this launch (column-sliced passes)
 };
 
 // G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart).
@@ -89,12 +90,15 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ rowscale, const float* __restrict__ colscale,
     const float* __restrict__ Z, int64_t ldz, float* __restrict__ Y, int64_t ldy,
-    const float* __restrict__ bias, int act, int reduce, SageScale sage, ReluMask mask = ReluMask{nullptr, nullptr, 0, 0}) {
+    const float* __restrict__ bias, int act, int reduce, SageScale sage, const int32_t* __restrict__ row_ids,
+    ReluMask mask = ReluMask{nullptr, nullptr, 0, 0}) {
   using V = typename VecT<VEC>::type;
   constexpr int ROWS_PER_BLOCK = 256 / G;
   const int g = threadIdx.x % G;
-  const int64_t row = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
-  if (row >= n_rows) return;  // whole groups exit together
+  const int64_t slot = (int64_t)blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / G;
+  if (slot >= n_rows) return;  // whole groups exit together
+  // row_ids: the rows this launch computes (interior / boundary subsets of a shard, sharding.py); null = rows [0, n_rows)
+  const int64_t row = row_ids ? (int64_t)row_ids[slot] : slot;
 
   // this lane's first column in the current column block (blockIdx.y covers width in
   // G*VEC*NACC-wide blocks)
@@ -133,14 +137,13 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
         for (int a = 0; a < NACC; ++a)
           z[u][a] = live[a] ? *reinterpret_cast<const V*>(zr + a * G * VEC) : V(0.f);
         if constexpr (MASKED) {
-          if (mask.in) {  // wave-uniform row ck: the 4 ballot words of each slice come through the scalar cache
+          if (mask.in) {  // the 4 ballot words of row ck: one 16-byte load, the same address for the 32 lanes of the group
+            static_assert(!MASKED || (NACC == 1 && VEC == 4 && G == 32), "mask layout is 32 lanes x float4");
+            const uint4 m = *reinterpret_cast<const uint4*>(mask.in + ((int64_t)ck * mask.slices + mask.slice0) * 4);
+            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
-            for (int a = 0; a < NACC; ++a) {
-              const unsigned long long* m = mask.in + ((int64_t)ck * mask.slices + mask.slice0 + blockIdx.y * NACC + a) * 4;
-#pragma unroll
-              for (int i = 0; i < VEC; ++i)
-                if (!((m[i] >> g) & 1ull)) z[u][a][i] = 0.f;
-            }
+            for (int i = 0; i < VEC; ++i)
+              if (!((mw[i] >> g) & 1u)) z[u][0][i] = 0.f;
           }
         }
       }
@@ -159,10 +162,11 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
         V zv = *reinterpret_cast<const V*>(zr + a * G * VEC);
         if constexpr (MASKED) {
           if (mask.in) {
-            const unsigned long long* m = mask.in + ((int64_t)ck * mask.slices + mask.slice0 + blockIdx.y * NACC + a) * 4;
+            const uint4 m = *reinterpret_cast<const uint4*>(mask.in + ((int64_t)ck * mask.slices + mask.slice0) * 4);
+            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
-              if (!((m[i] >> g) & 1ull)) zv[i] = 0.f;
+              if (!((mw[i] >> g) & 1u)) zv[i] = 0.f;
           }
         }
         fma_vec<VEC>(acc[a], wk, zv);
@@ -179,11 +183,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     epilogue<VEC>(acc[a], scale, bias, c0 + (int64_t)a * G * VEC, act);
     if constexpr (MASKED) {
       if (mask.out) {
-        unsigned long long* m = mask.out + (row * mask.slices + mask.slice0 + blockIdx.y * NACC + a) * 4;
+        uint32_t* m = mask.out + (row * mask.slices + mask.slice0) * 4;
+        const int half = (threadIdx.x & 63) >> 5;  // which of the wavefront's two rows
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
           const unsigned long long b = __ballot(acc[a][i] > 0.f);
-          if (g == 0) m[i] = b;
+          if (g == 0) m[i] = (uint32_t)(b >> (32 * half));
         }
       }
     }
@@ -195,7 +200,7 @@ template <int VEC, bool SAGE>
 int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32_t* col,
                const float* val, const float* rowscale, const float* colscale, const float* Z,
                int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, int reduce,
-               SageScale sage, hipStream_t st) {
+               SageScale sage, const int32_t* row_ids, hipStream_t st) {
   const int64_t vecs = dh::ceil_div(width, VEC);
 #define DH_SPMM_LAUNCH(G, NACC)                                                                  \
   do {                                                                                           \
@@ -203,7 +208,7 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
               (unsigned)dh::ceil_div(vecs, (int64_t)G * NACC));                                  \
     hipLaunchKernelGGL((spmm_csr_kernel<G, VEC, NACC, SAGE>), grid, dim3(256), 0, st, n_rows,    \
                        width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act,   \
-                       reduce, sage);                                                            \
+                       reduce, sage, row_ids);                                                   \
   } while (0)
   if (VEC == 4 && !SAGE && vecs >= 64 && vecs % 32 == 0) {
     // Wide rows: one pass per 128-column slice instead of one launch over the whole width.  Every pass gathers from a
@@ -213,7 +218,7 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
     for (int64_t c = 0; c < width; c += 128) {
       dim3 grid((unsigned)dh::ceil_div(n_rows, 8), 1);
       hipLaunchKernelGGL((spmm_csr_kernel<32, VEC, 1, SAGE>), grid, dim3(256), 0, st, n_rows, (int64_t)128, rowptr, col, val,
-                         rowscale, colscale, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, sage);
+                         rowscale, colscale, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, sage, row_ids);
     }
   } else if (vecs > 64) DH_SPMM_LAUNCH(64, 2);
   else if (vecs > 32) DH_SPMM_LAUNCH(64, 1);
@@ -227,66 +232,126 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
 template <bool SAGE>
 int dispatch(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
              const float* rowscale, const float* colscale, const float* Z, int64_t ldz, float* Y,
-             int64_t ldy, const float* bias, int act, int reduce, SageScale sage, hipStream_t st) {
+             int64_t ldy, const float* bias, int act, int reduce, SageScale sage, const int32_t* row_ids, hipStream_t st) {
   const bool a16 = dh::aligned16(Z) && dh::aligned16(Y) && (!bias || dh::aligned16(bias));
   const bool a8 = ((uintptr_t)Z % 8 == 0) && ((uintptr_t)Y % 8 == 0) && (!bias || (uintptr_t)bias % 8 == 0);
   if (a16 && width % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0)
-    return launch_vec<4, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, st);
+    return launch_vec<4, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
   if (a8 && width % 2 == 0 && ldz % 2 == 0 && ldy % 2 == 0)
-    return launch_vec<2, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, st);
-  return launch_vec<1, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, st);
+    return launch_vec<2, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
+  return launch_vec<1, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
 }
 
 }  // namespace
+
+// Rows variant: computes the n_list rows listed in row_ids (null: rows [0, n_list)) of Y = act(rowscale * reduce(...) + bias).
+// rowptr / rowscale / Y are indexed by the row id itself.  Used by the sharded layer to run the rows that need no remote
+// operand while the halo exchange is still in flight (sharding.py).
+extern "C" int dh_spmm_csr_rows_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width,
+                                    const int32_t* rowptr, const int32_t* col, const float* val,
+                                    const float* rowscale, const float* colscale, const float* Z,
+                                    int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
+                                    int reduce, dh_stream_t stream) {
+  if (n_list < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: negative size");
+  if (n_list == 0 || width == 0) return DH_OK;
+  if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: null rowptr/Z/Y");
+  if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: leading dimension < width");
+  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad act %d", act);
+  if (reduce != DH_REDUCE_SUM && reduce != DH_REDUCE_MEAN) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad reduce %d", reduce);
+  if (n_list >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: n_rows >= 2^31");
+  return dispatch<false>(n_list, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce,
+                         SageScale{nullptr, nullptr, nullptr, 0}, row_ids, dh::as_stream(stream));
+}
 
 extern "C" int dh_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
                                const int32_t* rowptr, const int32_t* col, const float* val,
                                const float* rowscale, const float* colscale, const float* Z,
                                int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
                                int reduce, dh_stream_t stream) {
-  if (n_rows < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: negative size");
-  if (n_rows == 0 || width == 0) return DH_OK;
-  if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: null rowptr/Z/Y");
-  if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: leading dimension < width");
-  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad act %d", act);
-  if (reduce != DH_REDUCE_SUM && reduce != DH_REDUCE_MEAN) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad reduce %d", reduce);
-  if (n_rows >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: n_rows >= 2^31");
-  return dispatch<false>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce,
-                         SageScale{nullptr, nullptr, nullptr, 0}, dh::as_stream(stream));
+  return dh_spmm_csr_rows_f32(n_rows, nullptr, n_cols, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, stream);
 }
 
 extern "C" size_t dh_relu_mask_bytes(int64_t n_rows, int64_t width) {
-  if (n_rows <= 0 || width <= 0 || width % 256 != 0) return 0;
-  return (size_t)n_rows * (size_t)(width / 256) * 4 * sizeof(unsigned long long);
+  if (n_rows <= 0 || width <= 0 || width % 128 != 0) return 0;
+  return (size_t)n_rows * (size_t)(width / 128) * 4 * sizeof(uint32_t);
 }
 
 // SpMM with the ReLU of a GCN layer fused on both sides (see ReluMask): forward = dh_spmm_csr_f32(act = relu)
 // that additionally records the sign mask of its output; backward = SpMM whose gathered operand is dY with the
-// recorded mask applied on the fly.  Only for the float4 wavefront-per-row configuration: width % 256 == 0 and
-// 16-byte aligned operands (the host falls back to dh_relu_backward_f32 + dh_spmm_csr_f32 otherwise).
+// recorded mask applied on the fly.  Only for the float4 configuration: width % 128 == 0 and 16-byte aligned operands
+// (the host falls back to dh_relu_backward_f32 + dh_spmm_csr_f32 otherwise).  One pass per 128-column slice (32 lanes
+// per row, two rows per wavefront): the gathered working set of a pass is n_cols x 512 bytes, of which L2 / MALL hold a
+// larger share than of 256- or 512-column rows (measured 4.51 vs 4.90 vs 5.44 ms at 1M rows, k = 15, scripts/spmm_width_probe.py).
+// in_mask rows are indexed by the gathered COLUMN id: a caller whose operand has rows without a mask (halo rows that
+// arrive already masked) sets their words to all-ones.
+extern "C" int dh_spmm_csr_relu_rows_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width, const int32_t* rowptr,
+                                         const int32_t* col, const float* val, const float* Z, int64_t ldz, float* Y,
+                                         int64_t ldy, const float* bias, int act, void* out_mask, const void* in_mask,
+                                         dh_stream_t stream) {
+  if (n_list < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: negative size");
+  if (n_list == 0 || width == 0) return DH_OK;
+  if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: null rowptr/Z/Y");
+  if (width % 128 != 0 || ldz % 4 != 0 || ldy % 4 != 0 || !dh::aligned16(Z) || !dh::aligned16(Y) || (bias && !dh::aligned16(bias)) ||
+      (in_mask && !dh::aligned16(in_mask)))
+    return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: needs width %% 128 == 0 and 16-byte aligned rows / masks");
+  if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: leading dimension < width");
+  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: bad act %d", act);
+  if (n_list >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: n_rows >= 2^31");
+  const SageScale none{nullptr, nullptr, nullptr, 0};
+  hipStream_t st = dh::as_stream(stream);
+  for (int64_t c = 0; c < width; c += 128) {
+    const ReluMask mask{static_cast<uint32_t*>(out_mask), static_cast<const uint32_t*>(in_mask), (int)(width / 128), (int)(c / 128)};
+    dim3 grid((unsigned)dh::ceil_div(n_list, 8), 1);
+    hipLaunchKernelGGL((spmm_csr_kernel<32, 4, 1, false, true>), grid, dim3(256), 0, st, n_list, (int64_t)128, rowptr, col, val, nullptr,
+                       nullptr, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, DH_REDUCE_SUM, none, row_ids, mask);
+  }
+  return dh::check_launch("dh_spmm_csr_relu_f32");
+}
+
 extern "C" int dh_spmm_csr_relu_f32(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr,
                                     const int32_t* col, const float* val, const float* Z, int64_t ldz, float* Y,
                                     int64_t ldy, const float* bias, int act, void* out_mask, const void* in_mask,
                                     dh_stream_t stream) {
-  if (n_rows < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: negative size");
-  if (n_rows == 0 || width == 0) return DH_OK;
-  if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: null rowptr/Z/Y");
-  if (width % 256 != 0 || ldz % 4 != 0 || ldy % 4 != 0 || !dh::aligned16(Z) || !dh::aligned16(Y) || (bias && !dh::aligned16(bias)))
-    return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: needs width %% 256 == 0 and 16-byte aligned rows");
-  if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: leading dimension < width");
-  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: bad act %d", act);
-  if (n_rows >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: n_rows >= 2^31");
-  const SageScale none{nullptr, nullptr, nullptr, 0};
-  hipStream_t st = dh::as_stream(stream);
-  // one pass per 256-column slice (see launch_vec): the gathered working set of a pass is n_cols x 1 KB
-  for (int64_t c = 0; c < width; c += 256) {
-    const ReluMask mask{static_cast<unsigned long long*>(out_mask), static_cast<const unsigned long long*>(in_mask), (int)(width / 256),
-                        (int)(c / 256)};
-    dim3 grid((unsigned)dh::ceil_div(n_rows, 4), 1);
-    hipLaunchKernelGGL((spmm_csr_kernel<64, 4, 1, false, true>), grid, dim3(256), 0, st, n_rows, (int64_t)256, rowptr, col, val, nullptr,
-                       nullptr, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, DH_REDUCE_SUM, none, mask);
+  return dh_spmm_csr_relu_rows_f32(n_rows, nullptr, n_cols, width, rowptr, col, val, Z, ldz, Y, ldy, bias, act, out_mask, in_mask, stream);
+}
+
+// out[i,:] = X[idx[i],:] (* [mask bit] if a ReLU sign mask of X's rows is given): packs the rows a peer asked for into a
+// contiguous send buffer of the halo exchange; with a mask the receiver gets G = dY * [Y > 0] rows without G ever existing.
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n, int64_t width, const int32_t* __restrict__ idx, const float* __restrict__ X,
+                                                          int64_t ldx, const uint32_t* __restrict__ mask, int slices, float* __restrict__ out,
+                                                          int64_t ldo) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int64_t r = idx[i];
+  const float* x = X + r * ldx;
+  float* o = out + i * ldo;
+  for (int64_t c = (int64_t)lane * 4; c < width; c += 256) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+    if (mask) {  // element j of the float4 of lane l' = (c / 4) % 32 in slice c / 128: bit l' of word j
+      const uint32_t* m = mask + (r * slices + c / 128) * 4;
+      const int l = (int)((c / 4) % 32);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!((m[j] >> l) & 1u)) v[j] = 0.f;
+    }
+    *reinterpret_cast<f32x4*>(o + c) = v;
   }
-  return dh::check_launch("dh_spmm_csr_relu_f32");
+}
+}  // namespace
+
+extern "C" int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx, const void* relu_mask,
+                                  float* out, int64_t ldo, dh_stream_t stream) {
+  if (n < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_gather_rows_f32: negative size");
+  if (n == 0 || width == 0) return DH_OK;
+  if (!idx || !X || !out) return dh::fail(DH_ERR_INVALID, "dh_gather_rows_f32: null pointer");
+  if (width % 4 || ldx % 4 || ldo % 4 || ldx < width || ldo < width || !dh::aligned16(X) || !dh::aligned16(out))
+    return dh::fail(DH_ERR_INVALID, "dh_gather_rows_f32: needs width %% 4 == 0 and 16-byte aligned rows");
+  if (relu_mask && width % 128) return dh::fail(DH_ERR_INVALID, "dh_gather_rows_f32: a ReLU mask needs width %% 128 == 0");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, width, idx, X, ldx,
+                     static_cast<const uint32_t*>(relu_mask), (int)(width / 128), out, ldo);
+  return dh::check_launch("dh_gather_rows_f32");
 }
 
 extern "C" int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
@@ -300,5 +365,5 @@ extern "C" int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width
     return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: null pointer");
   if (ldh < width || ldn < width) return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: leading dimension < width");
   return dispatch<true>(n_dst, width, rowptr, col, w, nullptr, nullptr, H, ldh, neigh, ldn, nullptr, DH_ACT_NONE,
-                        DH_REDUCE_MEAN, SageScale{src_cell_id, dst_cell_id, alpha, (int)n_genes}, dh::as_stream(stream));
+                        DH_REDUCE_MEAN, SageScale{src_cell_id, dst_cell_id, alpha, (int)n_genes}, nullptr, dh::as_stream(stream));
 }

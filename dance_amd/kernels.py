@@ -88,14 +88,23 @@ def _lib_ready():
 def spmm_csr(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], Z: torch.Tensor, *,
              n_cols: Optional[int] = None, rowscale: Optional[torch.Tensor] = None,
              colscale: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-             reduce: int = REDUCE_SUM, out: Optional[torch.Tensor] = None, tag: str = "spmm_csr_f32") -> torch.Tensor:
-    """Y = act(rowscale * reduce_e(val[e] * colscale[col[e]] * Z[col[e]]) + bias); see dh_spmm_csr_f32."""
+             reduce: int = REDUCE_SUM, out: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None,
+             tag: str = "spmm_csr_f32") -> torch.Tensor:
+    """Y = act(rowscale * reduce_e(val[e] * colscale[col[e]] * Z[col[e]]) + bias); see dh_spmm_csr_f32.
+    ``rows`` (int32 row ids) restricts the launch to those rows of ``out`` (dh_spmm_csr_rows_f32); the others are left untouched."""
     lib = _lib_ready()
     n_rows = rowptr.numel() - 1
     width = Z.shape[1]
     n_cols = Z.shape[0] if n_cols is None else n_cols
     if out is None:
         out = torch.empty((n_rows, width), dtype=torch.float32, device=Z.device)
+    if rows is not None:
+        _call(tag, lib.dh_spmm_csr_rows_f32, rows.numel(), _dev(rows, torch.int32, "rows", 1), n_cols, width,
+              _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
+              _dev(rowscale, torch.float32, "rowscale", 1), _dev(colscale, torch.float32, "colscale", 1),
+              _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(out, torch.float32, "out", 2), _ld(out),
+              _dev(bias, torch.float32, "bias", 1), act, reduce, _stream())
+        return out
     _call(tag, lib.dh_spmm_csr_f32, n_rows, n_cols, width, _dev(rowptr, torch.int32, "rowptr", 1),
           _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
           _dev(rowscale, torch.float32, "rowscale", 1), _dev(colscale, torch.float32, "colscale", 1),
@@ -127,19 +136,37 @@ def relu_mask_bytes(n_rows: int, width: int) -> int:
 def spmm_csr_relu(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], Z: torch.Tensor, *,
                   n_cols: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                   out_mask: Optional[torch.Tensor] = None, in_mask: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None, tag: str = "spmm_csr_f32") -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None,
+                  tag: str = "spmm_csr_f32") -> torch.Tensor:
     """dh_spmm_csr_relu_f32: forward records the ReLU sign mask (out_mask), backward applies it to the gathered
-    rows (in_mask).  Masks are uint8 tensors of ``relu_mask_bytes`` bytes."""
+    rows (in_mask).  Masks are uint8 tensors of ``relu_mask_bytes`` bytes.  ``rows``: as in ``spmm_csr``."""
     lib = _lib_ready()
     n_rows = rowptr.numel() - 1
     width = Z.shape[1]
     n_cols = Z.shape[0] if n_cols is None else n_cols
     if out is None:
         out = torch.empty((n_rows, width), dtype=torch.float32, device=Z.device)
+    if rows is not None:
+        _call(tag, lib.dh_spmm_csr_relu_rows_f32, rows.numel(), _dev(rows, torch.int32, "rows", 1), n_cols, width,
+              _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
+              _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(out, torch.float32, "out", 2), _ld(out), _dev(bias, torch.float32, "bias", 1),
+              act, None if out_mask is None else out_mask.data_ptr(), None if in_mask is None else in_mask.data_ptr(), _stream())
+        return out
     _call(tag, lib.dh_spmm_csr_relu_f32, n_rows, n_cols, width, _dev(rowptr, torch.int32, "rowptr", 1),
           _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1), _dev(Z, torch.float32, "Z", 2), _ld(Z),
           _dev(out, torch.float32, "out", 2), _ld(out), _dev(bias, torch.float32, "bias", 1), act,
           None if out_mask is None else out_mask.data_ptr(), None if in_mask is None else in_mask.data_ptr(), _stream())
+    return out
+
+
+def gather_rows(X: torch.Tensor, idx: torch.Tensor, *, relu_mask: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[i] = X[idx[i]] (optionally times the ReLU sign mask recorded for X's rows): dh_gather_rows_f32."""
+    lib = _lib_ready()
+    if out is None:
+        out = torch.empty((idx.numel(), X.shape[1]), dtype=torch.float32, device=X.device)
+    _call("gather_rows_f32", lib.dh_gather_rows_f32, idx.numel(), X.shape[1], _dev(idx, torch.int32, "idx", 1), _dev(X, torch.float32, "X", 2),
+          _ld(X), None if relu_mask is None else relu_mask.data_ptr(), _dev(out, torch.float32, "out", 2), _ld(out), _stream())
     return out
 
 

@@ -15,9 +15,19 @@ backend "nccl" = RCCL over xGMI; "gloo" in the CPU tests).  Rank p owns the cont
 Every rank computes exactly the rows it owns, in the same per-row order as the single-GPU path, so outputs
 are bit-identical to the 1-GPU result and independent of P (dW differs only by the all-reduce order).
 
-Two exchange modes (``ShardedGCNGraph.mode``), same inputs / outputs / numerics:
+Three exchange modes (``ShardedGCNGraph.mode``), same inputs / outputs / numerics:
 
-* ``"allgather"`` — the halo exchange described above: the graph itself is sharded by destination range and every
+* ``"halo"`` — what BASELINE.json's north_star names: only the rows a rank's shard actually references travel.  At set-up
+  every rank finds the distinct remote columns of its rows of A (and of A^T), asks their owners for them once
+  (``HaloPlan``: per-peer send / receive index lists, columns renumbered into [own rows | received rows]) and splits its
+  rows into INTERIOR rows (all columns local) and BOUNDARY rows.  Per layer: the GEMM writes S_p straight into the head
+  of the operand buffer, the requested rows are packed (dh_gather_rows_f32) and exchanged with one
+  ``all_to_all_single`` (variable split sizes = all-to-all-v) that runs asynchronously while the interior rows are
+  aggregated (dh_spmm_csr[_relu]_rows_f32); the boundary rows follow when the halo has landed.  The fused ReLU mask is
+  kept at P > 1: halo rows of G = dY * [Y > 0] are masked while they are packed, local rows inside the backward SpMM.
+  Optional: ``halo_dtype="bf16"`` halves the bytes on the wire (halo rows rounded to bf16: not bit-identical any more),
+  ``reorder="rcm"`` renumbers the nodes by reverse Cuthill-McKee first so that kNN-like graphs reference mostly local rows.
+* ``"allgather"`` — the dense form of the above: the graph itself is sharded by destination range and every
   rank receives all rows of S (resp. G): (P-1)/P * N*H*4 bytes inbound per all-gather.  Right when most remote
   rows are NOT referenced (kNN graphs after locality reordering) — then it degenerates towards a halo all-to-all-v.
 * ``"alltoall"`` — for graphs without locality (the rand-k15 headline graph references ~88 % of all remote rows):
@@ -31,8 +41,8 @@ The compute primitives come from an ``ops`` namespace; the default is ``dance_am
 without a GPU).  The CPU test-suite injects an oracle-backed namespace to exercise the partition + collective
 logic under gloo — the product never selects a CPU backend by itself.
 """
-from dataclasses import dataclass
-from typing import Optional, Tuple
+from dataclasses import dataclass, field
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -69,13 +79,91 @@ def slice_rows(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tens
     return GraphShard(rp, col[s:e].contiguous(), None if val is None else val[s:e].contiguous(), lo, hi, n_cols)
 
 
+@dataclass
+class HaloPlan:
+    """Halo bookkeeping of one CSR shard (rows of A, or of A^T): which rows this rank receives from / sends to every peer and
+    the shard's columns renumbered into the operand buffer [own rows | rows received from rank 0 | rank 1 | ...]."""
+    n_local: int
+    col: torch.Tensor                 # int32 [nnz] local column ids
+    remote_ids: torch.Tensor          # int64 [n_halo] global ids of the received rows (ascending = grouped by owner)
+    recv_counts: List[int]            # rows received from each peer
+    send_idx: torch.Tensor            # int32 [sum(send_counts)] local row ids to send, grouped by destination peer
+    send_counts: List[int]
+    interior: torch.Tensor            # int32 row ids whose columns are all local
+    boundary: torch.Tensor            # int32 row ids with at least one received column
+    cache: dict = field(default_factory=dict)
+
+    @property
+    def n_halo(self) -> int:
+        return int(self.remote_ids.numel())
+
+
+def build_halo_plan(shard: "GraphShard", ranges, chunk: int, rank: int, world: int, group=None) -> HaloPlan:
+    """Set-up collective (once per graph): every rank tells the owners which of their rows it needs."""
+    lo, hi = ranges[rank]
+    n_local = hi - lo
+    col = shard.col.to(torch.int64)
+    dev = col.device
+    remote = (col < lo) | (col >= hi)
+    uniq = torch.unique(col[remote])  # sorted ascending, hence grouped by owner rank
+    slot = torch.searchsorted(uniq, col.clamp(min=0)) if uniq.numel() else torch.zeros_like(col)
+    col_local = torch.where(remote, n_local + slot, col - lo).to(torch.int32).contiguous()
+    bounds = torch.tensor([r[0] for r in ranges] + [ranges[-1][1]], dtype=torch.int64, device=dev)
+    cuts = torch.searchsorted(uniq, bounds)
+    recv_counts = (cuts[1:] - cuts[:-1]).tolist()
+    # rows with a remote column
+    rows_of_edges = torch.repeat_interleave(torch.arange(n_local, device=dev), (shard.rowptr[1:] - shard.rowptr[:-1]).to(torch.int64),
+                                            output_size=col.numel())
+    n_remote = torch.zeros(n_local, dtype=torch.int64, device=dev).index_add_(0, rows_of_edges, remote.to(torch.int64))
+    interior = torch.nonzero(n_remote == 0).reshape(-1).to(torch.int32)
+    boundary = torch.nonzero(n_remote > 0).reshape(-1).to(torch.int32)
+    # ask the owners: counts first, then the row ids (relative to the owner's range)
+    owner_lo = torch.repeat_interleave(bounds[:-1], cuts[1:] - cuts[:-1], output_size=uniq.numel())
+    want = (uniq - owner_lo).to(torch.int32)
+    if world > 1:
+        send_counts_t = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(send_counts_t, torch.tensor(recv_counts, dtype=torch.int64, device=dev), group=group)
+        send_counts = send_counts_t.tolist()
+        send_idx = torch.empty(sum(send_counts), dtype=torch.int32, device=dev)
+        dist.all_to_all_single(send_idx, want.contiguous(), output_split_sizes=send_counts, input_split_sizes=recv_counts, group=group)
+    else:
+        send_counts, send_idx = [0], torch.empty(0, dtype=torch.int32, device=dev)
+    return HaloPlan(n_local, col_local, uniq, recv_counts, send_idx, send_counts, interior, boundary)
+
+
+def rcm_order(graph) -> torch.Tensor:
+    """Reverse Cuthill-McKee order of the symmetrised pattern (host, scipy; set-up only): ``perm[new] = old``.  kNN-like
+    graphs renumbered this way reference mostly nearby — hence local — rows, which is what makes the halo small."""
+    import numpy as np
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    n = graph.n_rows
+    a = sp.csr_matrix((np.ones(graph.nnz, dtype=np.int8), graph.col.cpu().numpy(), graph.rowptr.cpu().numpy()), shape=(n, graph.n_cols))
+    return torch.from_numpy(np.ascontiguousarray(reverse_cuthill_mckee((a + a.T).tocsr(), symmetric_mode=True)).astype(np.int64))
+
+
+def permute_graph(graph, perm: torch.Tensor):
+    """P A P^T for ``perm[new] = old`` as a new CSRGraph on the same device (host scipy; set-up only)."""
+    import numpy as np
+    from .graph import CSRGraph
+    a = graph.to_scipy()
+    p = perm.cpu().numpy()
+    b = a[p][:, p].tocsr()
+    b.sort_indices()
+    return CSRGraph.from_scipy(b, graph.device, symmetric=graph.symmetric)
+
+
 class ShardedGCNGraph:
     """This rank's destination-range shard of A and of A^T (+ optionally the replicated graph for "alltoall")."""
 
     def __init__(self, a_shard: GraphShard, at_shard: GraphShard, n_nodes: int, group=None, *, mode: str = "allgather",
-                 full: Optional[Tuple[GraphShard, GraphShard]] = None):
-        if mode not in ("allgather", "alltoall"):
+                 full: Optional[Tuple[GraphShard, GraphShard]] = None, halo_dtype: str = "f32", perm: Optional[torch.Tensor] = None):
+        if mode not in ("allgather", "alltoall", "halo"):
             raise ValueError(f"unknown exchange mode {mode!r}")
+        if halo_dtype not in ("f32", "bf16"):
+            raise ValueError(f"halo_dtype must be 'f32' or 'bf16', got {halo_dtype!r}")
+        self.halo_dtype, self.perm = halo_dtype, perm
+        self.stats = {"exchanged_bytes": 0, "exchanges": 0}
         if mode == "alltoall" and full is None:
             raise ValueError("mode='alltoall' needs the replicated graph (full=(A, A^T) as GraphShards over all rows)")
         self.a, self.at = a_shard, at_shard
@@ -88,12 +176,25 @@ class ShardedGCNGraph:
         lo, hi = self.ranges[self.rank]
         if (a_shard.lo, a_shard.hi) != (lo, hi) or (at_shard.lo, at_shard.hi) != (lo, hi):
             raise ValueError(f"rank {self.rank} must own rows [{lo}, {hi})")
+        self.halo = self.halo_t = None
+        if mode == "halo":
+            self.halo = build_halo_plan(a_shard, self.ranges, self.chunk, self.rank, self.world, group)
+            self.halo_t = build_halo_plan(at_shard, self.ranges, self.chunk, self.rank, self.world, group)
 
     @classmethod
-    def from_global_csr(cls, graph, group=None, *, mode: str = "allgather") -> "ShardedGCNGraph":
-        """Slice this rank's rows out of a full ``CSRGraph`` (and its transpose) replicated on every rank."""
+    def from_global_csr(cls, graph, group=None, *, mode: str = "allgather", halo_dtype: str = "f32",
+                        reorder: Optional[str] = None) -> "ShardedGCNGraph":
+        """Slice this rank's rows out of a full ``CSRGraph`` (and its transpose) replicated on every rank.
+        ``reorder="rcm"`` first renumbers the nodes (``self.perm[new] = old``: callers feed X / read Y in the new order, i.e.
+        ``X_new = X[perm]``, and map results back with ``Y[inv]`` where ``inv[perm] = arange``)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
+        perm = None
+        if reorder is not None:
+            if reorder != "rcm":
+                raise ValueError(f"unknown reordering {reorder!r}")
+            perm = rcm_order(graph)
+            graph = permute_graph(graph, perm)
         ranges, _ = row_ranges(graph.n_rows, world)
         lo, hi = ranges[rank]
         gt = graph.transpose()
@@ -102,7 +203,39 @@ class ShardedGCNGraph:
             full = (GraphShard(graph.rowptr, graph.col, graph.val, 0, graph.n_rows, graph.n_cols),
                     GraphShard(gt.rowptr, gt.col, gt.val, 0, gt.n_rows, gt.n_cols))
         return cls(slice_rows(graph.rowptr, graph.col, graph.val, lo, hi, graph.n_cols),
-                   slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group, mode=mode, full=full)
+                   slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group, mode=mode, full=full,
+                   halo_dtype=halo_dtype, perm=perm)
+
+    # ---- halo exchange ("halo" mode) ------------------------------------------------------------------------
+    def halo_exchange(self, plan: HaloPlan, send_rows: torch.Tensor, recv_into: torch.Tensor):
+        """all-to-all-v of packed rows: ``send_rows`` [sum(send_counts), H] grouped by destination peer -> ``recv_into``
+        [n_halo, H] grouped by owner.  Returns a handle whose ``wait()`` makes the current stream wait (None at world 1)."""
+        if self.world == 1:
+            return None
+        h = send_rows.shape[1]
+        self.stats["exchanges"] += 1
+        if self.halo_dtype == "bf16":
+            wire_send = send_rows.to(torch.bfloat16)
+            wire_recv = torch.empty((plan.n_halo, h), dtype=torch.bfloat16, device=send_rows.device)
+            self.stats["exchanged_bytes"] += plan.n_halo * h * 2
+            work = dist.all_to_all_single(wire_recv, wire_send, output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts,
+                                          group=self.group, async_op=True)
+
+            class _Widen:
+                def wait(_self):
+                    work.wait()
+                    recv_into.copy_(wire_recv)
+            return _Widen()
+        self.stats["exchanged_bytes"] += plan.n_halo * h * 4
+        return dist.all_to_all_single(recv_into, send_rows, output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts,
+                                      group=self.group, async_op=True)
+
+    def halo_vector(self, plan: HaloPlan, v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """A replicated global per-node vector in the operand-buffer order of ``plan``: [own range | received rows]."""
+        if v is None:
+            return None
+        lo, hi = self.ranges[self.rank]
+        return torch.cat((v[lo:hi], v[plan.remote_ids])).contiguous()
 
     def as_local_graph(self):
         """world == 1: the shard IS the graph — expose it (with its transpose) as a ``CSRGraph``."""
@@ -125,6 +258,8 @@ class ShardedGCNGraph:
         send[:, :local.shape[0]] = local.reshape(local.shape[0], self.world, hq).transpose(0, 1)  # pack per destination
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)
+        self.stats["exchanges"] += 1
+        self.stats["exchanged_bytes"] += (self.world - 1) * self.chunk * hq * send.element_size()
         return recv.reshape(self.world * self.chunk, hq)  # block r = rows of rank r: global row order
 
     def columns_to_rows(self, cols: torch.Tensor, n_local: int) -> torch.Tensor:
@@ -133,6 +268,8 @@ class ShardedGCNGraph:
         send = cols.reshape(self.world, self.chunk, hq).contiguous()
         recv = torch.empty_like(send)
         dist.all_to_all_single(recv, send, group=self.group)  # recv[q] = column slice q of my rows
+        self.stats["exchanges"] += 1
+        self.stats["exchanged_bytes"] += (self.world - 1) * self.chunk * hq * send.element_size()
         return recv[:, :n_local].transpose(0, 1).reshape(n_local, self.world * hq).contiguous()
 
     def all_gather_rows(self, local: torch.Tensor) -> torch.Tensor:
@@ -146,6 +283,8 @@ class ShardedGCNGraph:
             local = pad
         out = torch.empty((self.world * self.chunk, h), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        self.stats["exchanges"] += 1
+        self.stats["exchanged_bytes"] += (self.world - 1) * self.chunk * h * local.element_size()
         return out
 
     def inv_in_degree(self) -> torch.Tensor:
@@ -177,9 +316,11 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_local, weight, bias, sg: ShardedGCNGraph, active: bool, ops, rowscale, colscale, reduce):
         w = weight.contiguous()
-        s_local = ops.gemm(x_local, w)
         act = ops.ACT_RELU if active else ops.ACT_NONE
         lo, hi = sg.ranges[sg.rank]
+        if sg.mode == "halo":
+            return _halo_forward(ctx, x_local, w, bias, sg, active, ops, rowscale, colscale, reduce)
+        s_local = ops.gemm(x_local, w)
         if sg.mode == "alltoall" and sg.world > 1:
             s_cols = sg.rows_to_columns(s_local)
             a = sg.full[0]
@@ -201,14 +342,16 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
                                tag="spmm_csr_f32[fwd]")
         ctx.sg, ctx.active, ctx.ops, ctx.has_bias = sg, active, ops, bias is not None
         ctx.rowscale, ctx.colscale, ctx.reduce = rowscale, colscale, reduce
-        ctx.save_for_backward(x_local, w, out if active else None)
+        ctx.save_for_backward(x_local, w, out if active else None, None)
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x_local, w, out = ctx.saved_tensors
+        x_local, w, out, mask = ctx.saved_tensors
         sg, ops = ctx.sg, ctx.ops
         dy = dy.contiguous()
+        if sg.mode == "halo":
+            return _halo_backward(ctx, dy, x_local, w, out, mask)
         g_local = ops.relu_backward(out, dy) if ctx.active else dy
         dx = dw = db = None
         lo, hi = sg.ranges[sg.rank]
@@ -240,6 +383,85 @@ class _ShardedGCNLayerFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = ops.gemm(ds, w, trans_b=True)
         return dx, dw, db, None, None, None, None, None, None
+
+
+def _run_split(spmm, plan: HaloPlan, work):
+    """Interior rows while the halo is in flight, boundary rows once it has landed."""
+    if work is None:  # nothing is travelling: one launch over all rows
+        spmm(None)
+        return
+    if plan.interior.numel():
+        spmm(plan.interior)
+    work.wait()
+    if plan.boundary.numel():
+        spmm(plan.boundary)
+
+
+def _halo_forward(ctx, x_local, w, bias, sg, active, ops, rowscale, colscale, reduce):
+    plan, plan_t = sg.halo, sg.halo_t
+    n_loc, h = plan.n_local, w.shape[1]
+    lo, hi = sg.ranges[sg.rank]
+    dev = x_local.device
+    buf = torch.empty((n_loc + plan.n_halo, h), dtype=torch.float32, device=dev)  # operand: [S_p | halo rows]
+    ops.gemm(x_local, w, out=buf[:n_loc])  # the GEMM writes S_p in place: no copy into the exchange buffer
+    send = ops.gather_rows(buf[:n_loc], plan.send_idx) if plan.send_idx.numel() else buf[:0]
+    work = sg.halo_exchange(plan, send, buf[n_loc:])
+    out = torch.empty((n_loc, h), dtype=torch.float32, device=dev)
+    act = ops.ACT_RELU if active else ops.ACT_NONE
+    row_bytes = ops.relu_mask_bytes(1, h) if hasattr(ops, "relu_mask_bytes") else 0
+    fused = (active and bias is None and rowscale is None and colscale is None and reduce == ops.REDUCE_SUM and row_bytes > 0
+             and hasattr(ops, "spmm_csr_relu"))
+    mask = None
+    if fused:  # sign mask of Y_p (head) + all-ones words for the rows of G that will arrive already masked (tail)
+        mask = torch.empty((n_loc + plan_t.n_halo) * row_bytes, dtype=torch.uint8, device=dev)
+        mask[n_loc * row_bytes:].fill_(255)
+        _run_split(lambda rows: ops.spmm_csr_relu(sg.a.rowptr, plan.col, sg.a.val, buf, n_cols=buf.shape[0], act=act, out_mask=mask,
+                                                  out=out, rows=rows, tag="spmm_csr_f32[fwd]"), plan, work)
+    else:
+        rs = None if rowscale is None else rowscale[lo:hi].contiguous()
+        cs = sg.halo_vector(plan, colscale)
+        _run_split(lambda rows: ops.spmm_csr(sg.a.rowptr, plan.col, sg.a.val, buf, n_cols=buf.shape[0], rowscale=rs, colscale=cs,
+                                             bias=bias, act=act, reduce=reduce, out=out, rows=rows, tag="spmm_csr_f32[fwd]"), plan, work)
+    ctx.sg, ctx.active, ctx.ops, ctx.has_bias = sg, active, ops, bias is not None
+    ctx.rowscale, ctx.colscale, ctx.reduce = rowscale, colscale, reduce
+    ctx.save_for_backward(x_local, w, out if (active and not fused) else None, mask)
+    return out
+
+
+def _halo_backward(ctx, dy, x_local, w, out, mask):
+    sg, ops = ctx.sg, ctx.ops
+    plan_t = sg.halo_t
+    n_loc, h = plan_t.n_local, dy.shape[1]
+    lo, hi = sg.ranges[sg.rank]
+    dev = dy.device
+    dx = dw = db = None
+    fused = mask is not None
+    g_local = dy if (fused or not ctx.active) else ops.relu_backward(out, dy)
+    if ctx.has_bias and ctx.needs_input_grad[2]:
+        db = sg.all_reduce_sum(ops.colsum(g_local))
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        buf = torch.empty((n_loc + plan_t.n_halo, h), dtype=torch.float32, device=dev)  # operand: [G_p (or dY_p + mask) | halo rows of G]
+        buf[:n_loc].copy_(g_local)
+        send = (ops.gather_rows(g_local, plan_t.send_idx, relu_mask=mask) if fused else ops.gather_rows(g_local, plan_t.send_idx)) \
+            if plan_t.send_idx.numel() else buf[:0]
+        work = sg.halo_exchange(plan_t, send, buf[n_loc:])
+        ds = torch.empty((n_loc, h), dtype=torch.float32, device=dev)
+        if fused:
+            _run_split(lambda rows: ops.spmm_csr_relu(sg.at.rowptr, plan_t.col, sg.at.val, buf, n_cols=buf.shape[0], in_mask=mask, out=ds,
+                                                      rows=rows, tag="spmm_csr_f32[bwd]"), plan_t, work)
+        else:
+            m = ctx.rowscale
+            if ctx.reduce == ops.REDUCE_MEAN:
+                m = sg.inv_in_degree() if m is None else m * sg.inv_in_degree()
+            rs = None if ctx.colscale is None else ctx.colscale[lo:hi].contiguous()
+            cs = sg.halo_vector(plan_t, m)
+            _run_split(lambda rows: ops.spmm_csr(sg.at.rowptr, plan_t.col, sg.at.val, buf, n_cols=buf.shape[0], rowscale=rs, colscale=cs,
+                                                 out=ds, rows=rows, tag="spmm_csr_f32[bwd]"), plan_t, work)
+        if ctx.needs_input_grad[1]:
+            dw = sg.all_reduce_sum(ops.gemm(x_local, ds, trans_a=True))
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(ds, w, trans_b=True)
+    return dx, dw, db, None, None, None, None, None, None
 
 
 def _pad_to(v: Optional[torch.Tensor], n: int) -> Optional[torch.Tensor]:

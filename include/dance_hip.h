@@ -74,16 +74,32 @@ DH_API int dh_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
 /* SpMM with the layer's ReLU fused on both sides, so autograd's ReluBackward (G = dY * [Y > 0],
  * scdsc.py:499-500 + :286-288) never touches HBM:
  *   forward : as dh_spmm_csr_f32(act) and, if out_mask != NULL, records the sign mask of Y
- *             (dh_relu_mask_bytes(n_rows, width) bytes: per row and 256-column slice, four wave ballots);
+ *             (dh_relu_mask_bytes(n_rows, width) bytes: per row and 128-column slice, four 32-bit ballot words);
  *   backward: called on the CSR of A^T with Z = dY and in_mask = the recorded mask: gathered rows are masked
  *             on the fly, i.e. it returns A^T (dY * [Y > 0]).
- * Requires width % 256 == 0 and 16-byte aligned rows (dh_relu_mask_bytes returns 0 otherwise; callers then use
- * dh_relu_backward_f32 + dh_spmm_csr_f32).                                                        */
+ * Requires width % 128 == 0 and 16-byte aligned rows (dh_relu_mask_bytes returns 0 otherwise; callers then use
+ * dh_relu_backward_f32 + dh_spmm_csr_f32).  in_mask is indexed by the gathered column id; rows of the operand that carry
+ * no mask (halo rows received already masked) get all-ones words.
+ * The _rows variants compute only the n_list rows named in row_ids (NULL: rows [0, n_list)); rowptr, rowscale, Y and
+ * out_mask are indexed by the row id itself.  The sharded layer uses them to run the rows that need no remote operand
+ * while the halo exchange is in flight.  dh_gather_rows_f32 packs out[i,:] = X[idx[i],:] (optionally times the ReLU sign
+ * mask of X's rows) into a contiguous send buffer.                                                   */
 DH_API size_t dh_relu_mask_bytes(int64_t n_rows, int64_t width);
 DH_API int dh_spmm_csr_relu_f32(int64_t n_rows, int64_t n_cols, int64_t width,
                          const int32_t* rowptr, const int32_t* col, const float* val,
                          const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
                          void* out_mask, const void* in_mask, dh_stream_t stream);
+DH_API int dh_spmm_csr_rows_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width,
+                         const int32_t* rowptr, const int32_t* col, const float* val,
+                         const float* rowscale, const float* colscale,
+                         const float* Z, int64_t ldz, float* Y, int64_t ldy,
+                         const float* bias, int act, int reduce, dh_stream_t stream);
+DH_API int dh_spmm_csr_relu_rows_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width,
+                         const int32_t* rowptr, const int32_t* col, const float* val,
+                         const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
+                         void* out_mask, const void* in_mask, dh_stream_t stream);
+DH_API int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx,
+                       const void* relu_mask, float* out, int64_t ldo, dh_stream_t stream);
 
 /* ---- K2: deterministic CSR transpose (CSR of A^T) ------------------------------------------
  * out_perm[p] = index into the input nnz arrays of output entry p; output rows are ordered by

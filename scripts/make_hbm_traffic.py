@@ -9,9 +9,9 @@ d = json.load(open(sys.argv[1]))
 names = {  # bench.py kernel key -> (device kernel name, launches per C-ABI call)
     "gemm_f32_nn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, false, false, true>", 1),
     "gemm_f32_tn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, false, true>", 1),
-    # the 512-wide SpMM runs as two 256-column passes (spmm.hip): bytes per call = 2 x bytes per launch
-    "spmm_csr_f32[fwd]": ("spmm_csr_kernel<64, 4, 1, false, true>", 2),
-    "spmm_csr_f32[bwd]": ("spmm_csr_kernel<64, 4, 1, false, true>", 2),
+    # the 512-wide SpMM runs as four 128-column passes (spmm.hip): bytes per call = 4 x bytes per launch
+    "spmm_csr_f32[fwd]": ("spmm_csr_kernel<32, 4, 1, false, true>", 4),
+    "spmm_csr_f32[bwd]": ("spmm_csr_kernel<32, 4, 1, false, true>", 4),
 }
 out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                    "scripts/refresh_round.sh, bench.py at 1M cells); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024: on "
@@ -26,5 +26,10 @@ for k, v in d.items():
 for key, (sub, launches) in names.items():
     if sub in raw:
         out[key] = raw[sub]["hbm_bytes_corrected"] * launches
+# the kernel sources these counters belong to: bench.py refuses to report them for any other build
+import hashlib
+import os
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dance_amd", "csrc")
+out["source_sha256"] = {f: hashlib.sha256(open(os.path.join(_csrc, f), "rb").read()).hexdigest() for f in ("gemm_f32.hip", "spmm.hip", "common.h")}
 out["raw"] = raw
 print(json.dumps(out, indent=1))

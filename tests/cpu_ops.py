@@ -19,7 +19,20 @@ def gemm(A, B, *, trans_a=False, trans_b=False, out=None, accumulate=False, tag=
 
 
 def spmm_csr(rowptr, col, val, Z, *, n_cols=None, rowscale=None, colscale=None, bias=None, act=ACT_NONE,
-             reduce=REDUCE_SUM, out=None, tag=None):
+             reduce=REDUCE_SUM, out=None, rows=None, tag=None):
+    y = _spmm_full(rowptr, col, val, Z, n_cols, rowscale, colscale, bias, act, reduce)
+    if out is None:
+        if rows is not None:
+            raise ValueError("rows needs out")
+        return y
+    if rows is None:
+        out.copy_(y)
+    else:
+        out[rows.long()] = y[rows.long()]
+    return out
+
+
+def _spmm_full(rowptr, col, val, Z, n_cols, rowscale, colscale, bias, act, reduce):
     n_rows = rowptr.numel() - 1
     n_cols = Z.shape[0] if n_cols is None else n_cols
     v = np.ones(col.numel(), np.float32) if val is None else val.numpy()
@@ -38,6 +51,52 @@ def spmm_csr(rowptr, col, val, Z, *, n_cols=None, rowscale=None, colscale=None, 
     if act == ACT_RELU:
         y = np.maximum(y, 0)
     return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+
+
+# ---- fused ReLU sign masks, in the byte layout of dh_spmm_csr_relu_f32: per row and 128-column slice four 32-bit words;
+#      bit l of word i = [element at column slice * 128 + 4 l + i is > 0] ---------------------------------------------------
+def relu_mask_bytes(n_rows, width):
+    return 0 if (n_rows <= 0 or width <= 0 or width % 128) else n_rows * (width // 128) * 16
+
+
+def _mask_to_bool(mask, n_rows, width):
+    words = mask.numpy()[:n_rows * (width // 128) * 16].view(np.uint32).reshape(n_rows, width // 128, 4)
+    bits = (words[..., None] >> np.arange(32, dtype=np.uint32)) & 1          # [row, slice, i, l]
+    return bits.transpose(0, 1, 3, 2).reshape(n_rows, width).astype(bool)     # column = slice * 128 + 4 l + i
+
+
+def _bool_to_mask(b):
+    n_rows, width = b.shape
+    bits = b.reshape(n_rows, width // 128, 32, 4).transpose(0, 1, 3, 2).astype(np.uint32)   # [row, slice, i, l]
+    words = (bits << np.arange(32, dtype=np.uint32)).sum(-1, dtype=np.uint64).astype(np.uint32)
+    return torch.from_numpy(words.reshape(-1).view(np.uint8).copy())
+
+
+def spmm_csr_relu(rowptr, col, val, Z, *, n_cols=None, bias=None, act=ACT_NONE, out_mask=None, in_mask=None, out=None, rows=None,
+                  tag=None):
+    n_rows, width = rowptr.numel() - 1, Z.shape[1]
+    if in_mask is not None:
+        Z = torch.where(torch.from_numpy(_mask_to_bool(in_mask, Z.shape[0], width)), Z, torch.zeros_like(Z))
+    y = _spmm_full(rowptr, col, val, Z, n_cols, None, None, bias, act, REDUCE_SUM)
+    sel = slice(None) if rows is None else rows.long()
+    if out is None:
+        out = torch.empty_like(y)
+    out[sel] = y[sel]
+    if out_mask is not None:
+        m = _bool_to_mask((y > 0).numpy()).reshape(n_rows, -1)
+        view = out_mask[:n_rows * m.shape[1]].reshape(n_rows, -1)
+        view[sel] = m[sel]
+    return out
+
+
+def gather_rows(X, idx, *, relu_mask=None, out=None):
+    r = X[idx.long()]
+    if relu_mask is not None:
+        r = torch.where(torch.from_numpy(_mask_to_bool(relu_mask, X.shape[0], X.shape[1]))[idx.long()], r, torch.zeros_like(r))
+    if out is not None:
+        out.copy_(r)
+        return out
+    return r.contiguous()
 
 
 def relu_backward(Y, dY):

@@ -191,7 +191,7 @@ def test_errors_are_loud(cuda_device):
     assert lib.dh_gemm_bf16(64, 64, 64, 0, 1, a16.data_ptr(), 64, a16.data_ptr(), 64, out.data_ptr(), 64, 9, None, 0, 0, None, 0, None) < 0
 
 
-@pytest.mark.parametrize("width", [256, 512, 1024])
+@pytest.mark.parametrize("width", [128, 256, 384, 512, 1024])
 def test_spmm_fused_relu_mask(cuda_device, width):
     """dh_spmm_csr_relu_f32: forward == SpMM+ReLU bit for bit and records the sign mask; backward with the mask ==
     SpMM(A^T, relu_backward(Y, dY)) bit for bit (same per-element op order, masked terms contribute exact zeros)."""
@@ -199,7 +199,7 @@ def test_spmm_fused_relu_mask(cuda_device, width):
     a = _rand_csr(700, 700, 11, seed=width, long_row=(9, 150), empty_rows=(4, ))
     rp, c, v = _dev_csr(a, cuda_device)
     z = torch.randn(700, width, device=cuda_device)
-    assert kernels.relu_mask_bytes(700, width) == 700 * (width // 256) * 32 and kernels.relu_mask_bytes(700, 50) == 0
+    assert kernels.relu_mask_bytes(700, width) == 700 * (width // 128) * 16 and kernels.relu_mask_bytes(700, 50) == 0
     mask = torch.zeros(kernels.relu_mask_bytes(700, width), dtype=torch.uint8, device=cuda_device)
     y = kernels.spmm_csr_relu(rp, c, v, z, act=kernels.ACT_RELU, out_mask=mask)
     y_ref = kernels.spmm_csr(rp, c, v, z, act=kernels.ACT_RELU)
@@ -211,6 +211,35 @@ def test_spmm_fused_relu_mask(cuda_device, width):
     assert torch.equal(ds, ds_ref)
     with pytest.raises(Exception):
         kernels.spmm_csr_relu(rp, c, v, torch.randn(700, 50, device=cuda_device), act=kernels.ACT_RELU)
+    # the mask bytes are the documented layout: bit l of word i of (row, 128-column slice) = [y[row, 128 slice + 4 l + i] > 0]
+    import cpu_ops
+    assert np.array_equal(cpu_ops._mask_to_bool(mask.cpu(), 700, width), (y_ref > 0).cpu().numpy())
+    # rows variants: the listed rows only, everything else untouched; mask rows likewise
+    rows = torch.from_numpy(np.random.default_rng(0).choice(700, 333, replace=False).astype(np.int32)).to(cuda_device)
+    rest = torch.ones(700, dtype=torch.bool, device=cuda_device)
+    rest[rows.long()] = False
+    out = torch.full((700, width), -7.0, device=cuda_device)
+    m2 = torch.zeros_like(mask)
+    kernels.spmm_csr_relu(rp, c, v, z, act=kernels.ACT_RELU, out_mask=m2, out=out, rows=rows)
+    assert torch.equal(out[rows.long()], y_ref[rows.long()]) and bool((out[rest] == -7.0).all())
+    bpr = kernels.relu_mask_bytes(1, width)
+    assert torch.equal(m2.reshape(700, bpr)[rows.long()], mask.reshape(700, bpr)[rows.long()]) and int(m2.reshape(700, bpr)[rest].sum()) == 0
+    out2 = torch.full((700, width), -7.0, device=cuda_device)
+    bias = torch.randn(width, device=cuda_device)
+    full = kernels.spmm_csr(rp, c, v, z, bias=bias, reduce=kernels.REDUCE_MEAN)
+    kernels.spmm_csr(rp, c, v, z, bias=bias, reduce=kernels.REDUCE_MEAN, out=out2, rows=rows)
+    assert torch.equal(out2[rows.long()], full[rows.long()]) and bool((out2[rest] == -7.0).all())
+    # packing rows for a peer, with the ReLU mask applied on the way: rows of G = dY * [Y > 0]
+    g_ref = kernels.relu_backward(y_ref, dy)
+    assert torch.equal(kernels.gather_rows(dy, rows, relu_mask=mask), g_ref[rows.long()])
+    assert torch.equal(kernels.gather_rows(dy, rows), dy[rows.long()])
+    # operand rows without a mask of their own (halo rows that arrive masked): all-ones words
+    ext_mask = torch.cat((mask, torch.full((5 * bpr, ), 255, dtype=torch.uint8, device=cuda_device)))
+    z_ext = torch.cat((dy, torch.randn(5, width, device=cuda_device)))
+    a_ext = _rand_csr(60, 705, 9, seed=3)
+    rpe, ce, ve = _dev_csr(a_ext, cuda_device)
+    got = kernels.spmm_csr_relu(rpe, ce, ve, z_ext, in_mask=ext_mask)
+    assert torch.equal(got, kernels.spmm_csr(rpe, ce, ve, torch.cat((g_ref, z_ext[700:]))))
 
 
 def test_degenerate_sizes(cuda_device):

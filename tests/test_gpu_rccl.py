@@ -43,7 +43,7 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
     y_ref.backward(dy)
     dw_ref = w.grad.clone()
 
-    for mode in ("allgather", "alltoall"):
+    for mode in ("allgather", "alltoall", "halo"):
         sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
         assert sg.world == 1
         # the raw exchanges on device buffers
@@ -68,7 +68,7 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
     y_ref = autograd.gcn_layer(x, w, graph, b, True, rowscale=rs, colscale=cs, reduce=1)
     y_ref.backward(dy)
     dw_ref, db_ref = w.grad.clone(), b.grad.clone()
-    for mode in ("allgather", "alltoall"):
+    for mode in ("allgather", "alltoall", "halo"):
         sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
         w.grad = b.grad = None
         y = sharding._ShardedGCNLayerFn.apply(x, w, b, sg, True, sharding._hip_kernels, rs, cs, 1)
@@ -77,6 +77,19 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
         # (x * (1 / deg) here vs x / deg in gcn_layer: last-bit differences in the mean factor)
         assert rel_err(w.grad.cpu().numpy(), dw_ref.cpu().numpy()) < 1e-5
         assert rel_err(b.grad.cpu().numpy(), db_ref.cpu().numpy()) < 1e-5
+    # the all-to-all-v of the halo exchange with explicit (here: trivial) split sizes on device buffers
+    sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode="halo")
+    assert sg.halo.n_halo == 0 and sg.halo.boundary.numel() == 0 and sg.halo.interior.numel() == n
+    send, recv = torch.randn(17, h, device=dev), torch.empty(17, h, device=dev)
+    dist.all_to_all_single(recv, send, output_split_sizes=[17], input_split_sizes=[17], async_op=True).wait()
+    assert torch.equal(recv, send)
+    # RCM renumbering: the permuted problem gives the permuted result
+    sgp = sharding.ShardedGCNGraph.from_global_csr(graph, mode="halo", reorder="rcm")
+    perm = sgp.perm.to(dev)
+    w.grad = None
+    yp = sharding._ShardedGCNLayerFn.apply(x[perm].contiguous(), w, None, sgp, True, sharding._hip_kernels, None, None, 0)
+    y0 = autograd.gcn_layer(x, w, graph, None, True)
+    assert rel_err(yp.detach().cpu().numpy(), y0[perm].detach().cpu().numpy()) < 1e-5
     # query-sharded kNN through the same group (world 1: the local range is everything)
     from dance_amd import kernels
     pts = torch.randn(5000, 20, device=dev)

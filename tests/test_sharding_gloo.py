@@ -33,7 +33,7 @@ def _problem(n, fin, fout, k, seed):
     return x, w, b, dy, adj
 
 
-def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode="allgather"):
+def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode="allgather", halo_dtype="f32"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import cpu_ops
@@ -53,13 +53,20 @@ def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode=
         if mode == "alltoall":
             full = (sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), 0, n, n),
                     sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), 0, n, n))
-        sg = sharding.ShardedGCNGraph(a_sh, at_sh, n, mode=mode, full=full)
+        sg = sharding.ShardedGCNGraph(a_sh, at_sh, n, mode=mode, full=full, halo_dtype=halo_dtype)
         xl = torch.from_numpy(x[lo:hi].copy()).requires_grad_(True)
         wt = torch.from_numpy(w.copy()).requires_grad_(True)
         bt = torch.from_numpy(b.copy()).requires_grad_(True) if use_bias else None
         y = sharding.sharded_gcn_layer(xl, wt, sg, bt, active, ops=cpu_ops)
         y.backward(torch.from_numpy(dy[lo:hi].copy()))
-        q.put((rank, lo, hi, y.detach().numpy(), wt.grad.numpy(), xl.grad.numpy(), None if bt is None else bt.grad.numpy()))
+        extra = None
+        if mode == "halo":  # what travelled: exactly the distinct remote columns of this rank's rows of A and of A^T
+            need = lambda m: np.unique(m[lo:hi].indices[(m[lo:hi].indices < lo) | (m[lo:hi].indices >= hi)])
+            assert np.array_equal(sg.halo.remote_ids.numpy(), need(adj)) and np.array_equal(sg.halo_t.remote_ids.numpy(), need(at))
+            assert sorted(sg.halo.interior.tolist() + sg.halo.boundary.tolist()) == list(range(hi - lo))
+            assert sg.stats["exchanges"] == (2 if world > 1 else 0)
+            extra = (sg.stats["exchanged_bytes"], (sg.halo.n_halo + sg.halo_t.n_halo) * fout * (2 if halo_dtype == "bf16" else 4))
+        q.put((rank, lo, hi, y.detach().numpy(), wt.grad.numpy(), xl.grad.numpy(), None if bt is None else bt.grad.numpy(), extra))
     finally:
         dist.destroy_process_group()
 
@@ -69,7 +76,12 @@ def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode=
                                                          (3, 50, False, True, "alltoall"),
                                                          # the driver's scaling run goes to 4 and 8 ranks
                                                          (4, 90, True, True, "allgather"), (8, 100, False, True, "alltoall"),
-                                                         (8, 37, True, True, "alltoall")])
+                                                         (8, 37, True, True, "alltoall"),
+                                                         # halo exchange (all-to-all-v of the referenced rows only), uneven shards,
+                                                         # ranks with nothing to send, bias / no bias, with and without ReLU
+                                                         (2, 101, False, True, "halo"), (3, 50, True, True, "halo"),
+                                                         (8, 100, True, False, "halo"), (8, 37, False, True, "halo"),
+                                                         (1, 40, True, True, "halo")])
 def test_sharded_layer_matches_oracle(world, n, use_bias, active, mode):
     fin, fout, k, seed = 12, 24, 5, 17 + n  # fout divisible by 2, 3, 4 and 8 (alltoall mode slices the layer width)
     ctx = mp.get_context("spawn")
@@ -94,6 +106,63 @@ def test_sharded_layer_matches_oracle(world, n, use_bias, active, mode):
         assert rel_err(r[4], ref["dW"]) < 1e-5
         if use_bias:
             assert rel_err(r[6], ref["db"]) < 1e-5
+        if r[7] is not None:
+            assert r[7][0] == r[7][1]  # bytes on the wire = referenced remote rows x width x 4
+
+
+def _halo_fused_worker(rank, world, port, n, fin, fout, k, seed, halo_dtype, q):
+    _worker(rank, world, port, n, fin, fout, k, seed, False, True, q, "halo", halo_dtype)
+
+
+def _halo_linear_bf16_worker(rank, world, port, n, fin, fout, k, seed, q):
+    _worker(rank, world, port, n, fin, fout, k, seed, True, False, q, "halo", "bf16")
+
+
+def test_halo_bf16_wire_linear_layer():
+    """bf16 halos on a layer without ReLU (no mask flips): the only difference to one rank is the 2^-9 rounding of the rows
+    that crossed the wire."""
+    world, n, fin, fout, k, seed = 3, 80, 10, 24, 6, 9
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_linear_bf16_worker, args=(r, world, port, n, fin, fout, k, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, w, b, dy, adj = _problem(n, fin, fout, k, seed)
+    ref = ol.gcn_layer_fwd_bwd(x, adj, w, dy, bias=b, active=False, x_requires_grad=True)
+    out, dx = np.concatenate([r[3] for r in results]), np.concatenate([r[5] for r in results])
+    assert 1e-7 < rel_err(out, ref["out"]) < 1e-2 and rel_err(dx, ref["dX"]) < 1e-2   # rounded, but only at the bf16 level
+    for r in results:
+        assert rel_err(r[4], ref["dW"]) < 1e-2 and r[7][0] == r[7][1]
+
+
+@pytest.mark.parametrize("world,n,halo_dtype", [(2, 90, "f32"), (3, 77, "f32"), (8, 120, "f32")])
+def test_halo_fused_relu_mask_path(world, n, halo_dtype):
+    """Layer width 128: the fused ReLU-mask SpMM pair stays in use at P > 1 — local rows of G are masked inside the backward
+    SpMM, halo rows while they are packed (all-ones mask words for the received rows) — and the interior / boundary row split.
+    fp32 halos: same sums as one rank."""
+    fin, fout, k, seed = 10, 128, 6, 3 + n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_halo_fused_worker, args=(r, world, port, n, fin, fout, k, seed, halo_dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    x, w, b, dy, adj = _problem(n, fin, fout, k, seed)
+    ref = ol.gcn_layer_fwd_bwd(x, adj, w, dy, bias=None, active=True, x_requires_grad=True)
+    tol = 1e-5
+    assert rel_err(np.concatenate([r[3] for r in results]), ref["out"]) < tol
+    assert rel_err(np.concatenate([r[5] for r in results]), ref["dX"]) < tol
+    for r in results:
+        assert rel_err(r[4], ref["dW"]) < tol and r[7][0] == r[7][1]
 
 
 def _scaled_worker(rank, world, port, n, fin, fout, k, seed, reduce, q, mode):
