@@ -90,6 +90,36 @@ def gcn_layer(x: torch.Tensor, weight: torch.Tensor, graph: CSRGraph, bias: Opti
     return _GCNLayerFn.apply(x, weight, bias, graph, active, rowscale, colscale, reduce)
 
 
+class _SpMMFn(torch.autograd.Function):
+    """y = rowscale * reduce_e(val_e * colscale[src] * x[src]) — the aggregation alone (no dense transform), e.g. HetConv of
+    scHeteroNet (scheteronet.py:383-386) and the energy propagation (:611-640).  Backward = the same kernel on the cached
+    CSR of A^T with the two scale vectors swapped."""
+
+    @staticmethod
+    def forward(ctx, x, graph: CSRGraph, rowscale, colscale, reduce: int):
+        x = x.contiguous()
+        ctx.graph, ctx.rowscale, ctx.colscale, ctx.reduce = graph, rowscale, colscale, reduce
+        return kernels.spmm_csr(graph.rowptr, graph.col, graph.val, x, n_cols=graph.n_cols, rowscale=rowscale, colscale=colscale, reduce=reduce)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        gt = ctx.graph.transpose()
+        m = ctx.rowscale
+        if ctx.reduce == kernels.REDUCE_MEAN:
+            deg = (ctx.graph.rowptr[1:] - ctx.graph.rowptr[:-1]).to(torch.float32).clamp(min=1)
+            m = (1.0 / deg) if m is None else m / deg
+        dx = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, dy.contiguous(), n_cols=gt.n_cols, rowscale=ctx.colscale, colscale=m)
+        return dx, None, None, None, None
+
+
+def spmm(x: torch.Tensor, graph: CSRGraph, *, rowscale: Optional[torch.Tensor] = None, colscale: Optional[torch.Tensor] = None,
+         reduce: int = kernels.REDUCE_SUM) -> torch.Tensor:
+    """rowscale * reduce(A diag(colscale) x) on the CSR SpMM kernel, differentiable in x."""
+    return _SpMMFn.apply(x, graph, rowscale, colscale, reduce)
+
+
 class _DenseAdjLayerFn(torch.autograd.Function):
     """Same op for a DENSE adjacency (SpaGCN passes a dense N x N FloatTensor, spagcn.py:497,359)."""
 

@@ -467,6 +467,33 @@ def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def csr_two_hop(rowptr: torch.Tensor, col: torch.Tensor, *, drop_diag: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Pattern of ((A A) - A) > 0 for a square 0/1 CSR pattern (dh_csr_two_hop_*): returns (rowptr2, col2)."""
+    lib = _lib_ready()
+    n = rowptr.numel() - 1
+    dev = rowptr.device
+    rp, cp = _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1)
+    rowcnt = torch.empty(n, dtype=torch.int32, device=dev)
+    overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+    _call("csr_two_hop_count", lib.dh_csr_two_hop_count, n, rp, cp, rowcnt.data_ptr(), overflow.data_ptr(), _stream())
+    offs = exclusive_scan(rowcnt)
+    total, ovf = int(offs[-1]), int(overflow)
+    if ovf or total < 0:
+        raise _lib.DanceHipError("csr_two_hop: more than 2^31 two-edge paths")
+    flags = torch.empty(total, dtype=torch.int32, device=dev)
+    ws_bytes = lib.dh_csr_two_hop_workspace_bytes(n, total)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    _call("csr_two_hop_expand", lib.dh_csr_two_hop_expand, n, total, rp, cp, offs.data_ptr(), int(drop_diag), flags.data_ptr(), ws.data_ptr(),
+          ws_bytes, _stream())
+    pos = exclusive_scan(flags)
+    nnz2 = int(pos[-1])
+    rowptr2 = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col2 = torch.empty(nnz2, dtype=torch.int32, device=dev)
+    _call("csr_two_hop_compact", lib.dh_csr_two_hop_compact, n, total, flags.data_ptr(), pos.data_ptr(), rowptr2.data_ptr(), col2.data_ptr(),
+          ws.data_ptr(), _stream())
+    return rowptr2, col2
+
+
 # ---- blocks of the full-neighbour sampler ---------------------------------------------------------------------
 def block_build(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], seeds: torch.Tensor, mark: torch.Tensor,
                 lut: torch.Tensor):

@@ -82,6 +82,80 @@ class BaseMethod(ABC):
         return self.score(x, y, score_func=score_func, return_pred=return_pred)
 
 
+class BasePretrain(ABC):
+    """dance/modules/base.py:72-117: pre-train once (or load ``pretrain_path``), remember it, save the result."""
+
+    @property
+    def is_pretrained(self) -> bool:
+        return getattr(self, "_is_pretrained", False)
+
+    def _pretrain(self, *args, force_pretrain: bool = False, **kwargs):
+        import os
+        pt_path = getattr(self, "pretrain_path", None)
+        if not force_pretrain:
+            if self.is_pretrained:
+                return
+            if pt_path is not None and os.path.isfile(pt_path):
+                self.load_pretrained(pt_path)
+                self._is_pretrained = True
+                return
+        self.pretrain(*args, **kwargs)
+        self._is_pretrained = True
+        if pt_path is not None:
+            self.save_pretrained(pt_path)
+
+    def pretrain(self, *args, **kwargs):
+        ...
+
+    def save_pretrained(self, path, **kwargs):
+        ...
+
+    def load_pretrained(self, path, **kwargs):
+        ...
+
+
+class TorchNNPretrain(BasePretrain, ABC):
+    """dance/modules/base.py:120-153: lock / unlock sub-modules (``requires_grad``) around pre-training."""
+
+    def _fix_unfix_modules(self, *module_names, unfix: bool = False, single: bool = True):
+        from operator import attrgetter
+        modules = attrgetter(*module_names)(self)
+        for module in ([modules] if single else modules):
+            for p in module.parameters():
+                p.requires_grad = unfix
+
+    def fix_module(self, *names):
+        self._fix_unfix_modules(*names, unfix=False, single=True)
+
+    def fix_modules(self, *names):
+        self._fix_unfix_modules(*names, unfix=False, single=False)
+
+    def unfix_module(self, *names):
+        self._fix_unfix_modules(*names, unfix=True, single=True)
+
+    def unfix_modules(self, *names):
+        self._fix_unfix_modules(*names, unfix=True, single=False)
+
+    def pretrain_context(self, *module_names):
+        from contextlib import contextmanager
+
+        @contextmanager
+        def ctx():
+            single = len(module_names) == 1
+            self._fix_unfix_modules(*module_names, unfix=True, single=single)
+            try:
+                yield
+            finally:
+                self._fix_unfix_modules(*module_names, unfix=False, single=single)
+        return ctx()
+
+    def save_pretrained(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_pretrained(self, path):
+        self.load_state_dict(torch.load(path, map_location=getattr(self, "device", None)))
+
+
 class BaseClassificationMethod(BaseMethod):
     _DEFAULT_METRIC = "acc"
 
@@ -94,6 +168,7 @@ class BaseClusteringMethod(BaseMethod):
         func = resolve_score_func(score_func or self._DEFAULT_METRIC)
         if valid_idx is None:
             score = func(y, y_pred)
-        else:
-            score = func(np.asarray(y)[valid_idx], np.asarray(y_pred)[valid_idx])
+        else:  # dance/modules/base.py:177-186
+            score = {"valid_score": func([y[i] for i in valid_idx], [y_pred[i] for i in valid_idx]),
+                     "test_score": func([y[i] for i in test_idx], [y_pred[i] for i in test_idx])}
         return (score, y_pred) if return_pred else score

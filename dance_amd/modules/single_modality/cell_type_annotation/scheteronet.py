@@ -1,0 +1,387 @@
+"""scHeteroNet on MI355X — drop-in for the GNN part of
+dance/modules/single_modality/cell_type_annotation/scheteronet.py (``MLP`` :339-371, ``HetConv`` :374-386,
+``ZINBDecoder`` :389-442, ``HeteroNet`` :465-573, ``scHeteroNet`` :576-789, ``ZINBLoss`` :289-336, ``contrastive_loss``
+:281-286): same constructors, parameter names (``state_dict`` keys: ``encoder.feature_embed.lins.*``, ``encoder.bns.*``,
+``encoder.final_project.*``, ``encoder.ZINB.*``) and method signatures.
+
+What runs where:
+
+* ``HeteroNet.init_adj`` (:507-539) — the reference builds the one-hop and the "two-hop minus one-hop" adjacencies with
+  torch_sparse + scipy on the host and keeps them as SparseTensors.  Here both are device CSR patterns: the one-hop CSR by
+  destination comes straight from the edge list, the two-hop pattern from a symbolic SpGEMM on the device
+  (dh_csr_two_hop_*: path keys, radix sort, run heads); ``gcn_norm(add_self_loops=False)`` is not materialised — its
+  D^-1/2 factors ride the SpMM as row / column scales.
+* ``HetConv.forward`` (:383-386; the reference moves x to the CPU for torch_sparse.matmul) = two fused CSR SpMM launches
+  (dh_spmm_csr_f32 with rowscale / colscale) + the concat; backward = the same kernel on the cached transposes.
+* ``propagation`` / ``two_hop_propagation`` (:611-640) = mean-aggregation SpMVs of the same kernel ((adj @ adj) e is
+  evaluated as adj (adj e)).
+* MLP / decoder / final projection: ``HipLinear`` (dh_gemm_f32 on the matrix cores); BatchNorm, dropout, the ZINB and
+  contrastive losses are torch elementwise ops, as in the reference.
+
+PARITY NOTE.  ``adj_t.remove_diag(0)`` at :522 and :524 discards its result (torch_sparse's ``remove_diag`` returns a new
+tensor), so the reference's adjacencies KEEP their self loops (HeteronetGraph lists every cell as its own first neighbour)
+despite the docstring; ``adj_t2 = (A A - A > 0)`` is evaluated on those.  ``remove_self_loops=False`` (the default)
+reproduces the code as written; ``True`` gives what the docstring says.
+"""
+from functools import partial
+from typing import Any, Mapping, Optional, Tuple, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .... import kernels
+from ....autograd import HipLinear, spmm
+from ....graph import CSRGraph
+from ....transforms import Compose, SetConfig
+from ....transforms.graph import HeteronetGraph
+from ...base import BaseClassificationMethod
+
+
+def eval_acc(true_labels, model_output, acc):
+    """scheteronet.py:44-65: one-hot the labels and score the argmax predictions with ``acc``."""
+    predicted = torch.argmax(model_output, dim=1)
+    if true_labels.ndim == 2 and true_labels.shape[1] == 1:
+        true_labels = true_labels.squeeze(1)
+    return acc(F.one_hot(true_labels.long(), num_classes=model_output.shape[1]), predicted)
+
+
+class NCDataset:
+    """scheteronet.py:68-107: ``graph`` = {edge_index, edge_feat, node_feat, num_nodes}, ``label``; attribute access to
+    ``x`` / ``edge_index`` / ``y`` / ``splits`` / ``node_idx`` as the model methods use them."""
+
+    def __init__(self, name):
+        self.name = name
+        self.graph = {}
+        self.label = None
+
+    def __getitem__(self, idx):
+        assert idx == 0, "This dataset has only one graph"
+        return self.graph, self.label
+
+    def __len__(self):
+        return 1
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({len(self)})"
+
+
+def contrastive_loss(z1, z2, temperature=0.5):
+    z1 = F.normalize(z1, dim=-1)
+    z2 = F.normalize(z2, dim=-1)
+    logits = torch.mm(z1, z2.t()) / temperature
+    labels = torch.arange(z1.size(0), device=z1.device)
+    return F.cross_entropy(logits, labels)
+
+
+class ZINBLoss(nn.Module):
+
+    def forward(self, x, mean, disp, pi, scale_factor, ridge_lambda=0.0):
+        eps = 1e-10
+        mean = mean * scale_factor[:, None]
+        t1 = torch.lgamma(disp + eps) + torch.lgamma(x + 1.0) - torch.lgamma(x + disp + eps)
+        t2 = (disp + x) * torch.log(1.0 + (mean / (disp + eps))) + (x * (torch.log(disp + eps) - torch.log(mean + eps)))
+        nb_case = t1 + t2 - torch.log(1.0 - pi + eps)
+        zero_nb = torch.pow(disp / (disp + mean + eps), disp)
+        zero_case = -torch.log(pi + ((1.0 - pi) * zero_nb) + eps)
+        result = torch.where(torch.le(x, 1e-8), zero_case, nb_case)
+        if ridge_lambda > 0:
+            result = result + ridge_lambda * torch.square(pi)
+        return torch.mean(result)
+
+
+class MLP(nn.Module):
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout=.5):
+        super().__init__()
+        self.lins = nn.ModuleList()
+        self.bns = nn.ModuleList()
+        if num_layers == 1:
+            self.lins.append(HipLinear(in_channels, out_channels))
+        else:
+            self.lins.append(HipLinear(in_channels, hidden_channels))
+            self.bns.append(nn.BatchNorm1d(hidden_channels))
+            for _ in range(num_layers - 2):
+                self.lins.append(HipLinear(hidden_channels, hidden_channels))
+                self.bns.append(nn.BatchNorm1d(hidden_channels))
+            self.lins.append(HipLinear(hidden_channels, out_channels))
+        self.dropout = dropout
+
+    def reset_parameters(self):
+        for lin in self.lins:
+            lin.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+    def forward(self, x, edge_index=None):
+        for i, lin in enumerate(self.lins[:-1]):
+            x = lin(x, fuse_relu=True)
+            x = self.bns[i](x)
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        return self.lins[-1](x)
+
+
+class NormAdj:
+    """A 0/1 adjacency pattern (CSR by destination, on the device) with its gcn_norm factors D^-1/2 (row sums; 0 for an
+    empty row, as ``deg_inv_sqrt.masked_fill_(inf, 0)``): ``matmul(gcn_norm(A), x)`` = rowscale * (A (colscale * x))."""
+
+    def __init__(self, rowptr, col, n):
+        self.graph = CSRGraph(rowptr, col, None, n, n)
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+        self.dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+
+    def matmul(self, x):
+        return spmm(x, self.graph, rowscale=self.dis, colscale=self.dis)
+
+    def to_dense(self):
+        a = torch.zeros((self.graph.n_rows, self.graph.n_cols), device=self.dis.device)
+        rows = torch.repeat_interleave(torch.arange(self.graph.n_rows, device=a.device),
+                                       (self.graph.rowptr[1:] - self.graph.rowptr[:-1]).long())
+        a[rows, self.graph.col.long()] = 1.0
+        return self.dis[:, None] * a * self.dis[None, :]
+
+
+class HetConv(nn.Module):
+    """Neighborhood aggregation step: [A1_norm x | A2_norm x]."""
+
+    def reset_parameters(self):
+        pass
+
+    def forward(self, x, adj_t, adj_t2):
+        return torch.cat([adj_t.matmul(x), adj_t2.matmul(x)], dim=1)
+
+
+class MeanAct(nn.Module):
+
+    def forward(self, x):
+        return torch.clamp(torch.exp(x), min=1e-5, max=1e6)
+
+
+class DispAct(nn.Module):
+
+    def forward(self, x):
+        return torch.clamp(F.softplus(x), min=1e-4, max=1e4)
+
+
+class ZINBDecoder(nn.Module):
+
+    def __init__(self, input_dim, n_z, n_dec_1=128, n_dec_2=256, n_dec_3=512):
+        super().__init__()
+        self.n_dec_3 = n_dec_3
+        self.input_dim = input_dim
+        self.dec_1 = HipLinear(n_z, n_dec_1)
+        self.dec_2 = HipLinear(n_dec_1, n_dec_3)
+        self.dec_3 = HipLinear(n_dec_2, n_dec_3)  # unused in forward, as in the reference (:413,:438); kept for the state_dict
+        self.dec_mean = nn.Sequential(HipLinear(self.n_dec_3, self.input_dim), MeanAct())
+        self.dec_disp = nn.Sequential(HipLinear(self.n_dec_3, self.input_dim), DispAct())
+        self.dec_pi = nn.Sequential(HipLinear(self.n_dec_3, self.input_dim), nn.Sigmoid())
+
+    def forward(self, z):
+        dec_h1 = self.dec_1(z, fuse_relu=True)
+        dec_h3 = self.dec_2(dec_h1, fuse_relu=True)
+        return self.dec_mean(dec_h3), self.dec_disp(dec_h3), self.dec_pi(dec_h3)
+
+
+def edge_index_to_csr(edge_index, n, device):
+    """``SparseTensor(row=col, col=row)`` of scheteronet.py:520: CSR by DESTINATION (row = edge target), ascending
+    duplicate-free columns, 0/1 pattern."""
+    row, col = edge_index[0].to(device).long(), edge_index[1].to(device).long()
+    key = torch.unique(col * n + row)  # (dst, src) sorted
+    dst, src = key // n, key % n
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+    return rowptr.to(torch.int32), src.to(torch.int32).contiguous()
+
+
+class HeteroNet(nn.Module):
+
+    def __init__(self, in_channels, hidden_channels, out_channels, edge_index, num_nodes, num_layers=2, dropout=0.5,
+                 num_mlp_layers=1, use_bn=True, conv_dropout=True, dec_dim=[], device="cuda", remove_self_loops=False):
+        super().__init__()
+        self.feature_embed = MLP(in_channels, hidden_channels, hidden_channels, num_layers=num_mlp_layers, dropout=dropout)
+        self.convs = nn.ModuleList()
+        self.convs.append(HetConv())
+        self.bns = nn.ModuleList()
+        self.bns.append(nn.BatchNorm1d(hidden_channels * 2 * len(self.convs)))
+        for l in range(num_layers - 1):
+            self.convs.append(HetConv())
+            if l != num_layers - 2:
+                self.bns.append(nn.BatchNorm1d(hidden_channels * 2 * len(self.convs)))
+        self.dropout = dropout
+        self.activation = F.relu
+        self.use_bn = use_bn
+        self.conv_dropout = conv_dropout
+        last_dim = hidden_channels * (2**(num_layers + 1) - 1)
+        self.final_project = HipLinear(last_dim, out_channels)
+        self.num_nodes = num_nodes
+        self.device = device
+        self.remove_self_loops = remove_self_loops
+        self.init_adj(edge_index)
+        self.ZINB = ZINBDecoder(in_channels, last_dim, n_dec_1=dec_dim[0], n_dec_2=dec_dim[1], n_dec_3=dec_dim[2])
+
+    def reset_parameters(self):
+        self.feature_embed.reset_parameters()
+        self.final_project.reset_parameters()
+        for bn in self.bns:
+            bn.reset_parameters()
+
+    def init_adj(self, edge_index):
+        """Normalised one-hop adjacency and normalised ((A A) - A > 0) adjacency (scheteronet.py:507-539)."""
+        n = self.num_nodes
+        rowptr, col = edge_index_to_csr(edge_index, n, self.device)
+        if self.remove_self_loops:
+            rows = torch.repeat_interleave(torch.arange(n, device=col.device), (rowptr[1:] - rowptr[:-1]).long())
+            keep = rows != col.long()
+            rowptr = torch.zeros(n + 1, dtype=torch.int64, device=col.device)
+            rowptr[1:] = torch.cumsum(torch.bincount(rows[keep], minlength=n), 0)
+            rowptr, col = rowptr.to(torch.int32), col[keep].contiguous()
+        rowptr2, col2 = kernels.csr_two_hop(rowptr, col, drop_diag=self.remove_self_loops)
+        self.adj_t = NormAdj(rowptr, col, n)
+        self.adj_t2 = NormAdj(rowptr2, col2, n)
+
+    def forward(self, x, edge_index, decoder=False, save_path=None):
+        adj_t, adj_t2 = self.adj_t, self.adj_t2
+        x = self.feature_embed(x)
+        x = self.activation(x)
+        xs = [x]
+        if self.conv_dropout:
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        for i, conv in enumerate(self.convs[:-1]):
+            x = conv(x, adj_t, adj_t2)
+            if self.use_bn:
+                x = self.bns[i](x)
+            xs.append(x)
+            if self.conv_dropout:
+                x = F.dropout(x, p=self.dropout, training=self.training)
+        x = self.convs[-1](x, adj_t, adj_t2)
+        if self.conv_dropout:
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        xs.append(x)
+        x = torch.cat(xs, dim=-1)  # JumpingKnowledge('cat')
+        if not self.conv_dropout:
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        if save_path is not None:
+            torch.save(x, save_path + "_embeddings.pt")
+        if decoder:
+            _mean, _disp, _pi = self.ZINB(x)
+            return self.final_project(x), _mean, _disp, _pi
+        return self.final_project(x)
+
+
+def _mean_in_adj(edge_index, n, device):
+    """``SparseTensor(row=col, col=row, value=1/d[col])`` of :616-621: out[c] = mean of e over the in-edges of c (edge
+    multiplicities kept) — CSR by destination with the SpMM's mean reduction."""
+    row, col = edge_index[0].to(device).long(), edge_index[1].to(device).long()
+    order = torch.argsort(col * n + row)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=device)
+    rowptr[1:] = torch.cumsum(torch.bincount(col, minlength=n), 0)
+    return CSRGraph(rowptr.to(torch.int32), row[order].to(torch.int32).contiguous(), None, n, n)
+
+
+class scHeteroNet(nn.Module, BaseClassificationMethod):
+
+    def __init__(self, d, c, edge_index, num_nodes, hidden_channels, num_layers, dropout, use_bn, device, min_loss):
+        super().__init__()
+        self.device = device
+        self.encoder = HeteroNet(d, hidden_channels, c, edge_index=edge_index, num_nodes=num_nodes, num_layers=num_layers,
+                                 dropout=dropout, use_bn=use_bn, dec_dim=[32, 64, 128], device=device)
+        self.encoder.to(device)
+        self.to(device)
+        self.min_loss = min_loss
+        self._prop_cache = {}
+
+    def reset_parameters(self):
+        self.encoder.reset_parameters()
+
+    @staticmethod
+    def preprocessing_pipeline(log_level="INFO"):
+        """Graph part of scheteronet.py:592-604 (the scanpy filtering / HVG / normalisation steps are CPU count-matrix
+        preprocessing outside the hot path: feed a matrix that already went through them)."""
+        return Compose(HeteronetGraph(), SetConfig({"label_channel": "cell_type"}), log_level=log_level)
+
+    def forward(self, dataset, save_path=None):
+        x, edge_index = dataset.x.to(self.device), dataset.edge_index.to(self.device)
+        return self.encoder(x, edge_index, save_path=save_path)
+
+    def _prop_graph(self, edge_index, n):
+        key = (edge_index.data_ptr(), tuple(edge_index.shape))
+        if key not in self._prop_cache:
+            self._prop_cache = {key: _mean_in_adj(edge_index, n, self.device)}
+        return self._prop_cache[key]
+
+    def propagation(self, e, edge_index, prop_layers=1, alpha=0.5):
+        """Energy belief propagation (scheteronet.py:611-623): e <- alpha e + (1 - alpha) mean_in(e)."""
+        g = self._prop_graph(edge_index, e.shape[0])
+        e = e.unsqueeze(1)
+        for _ in range(prop_layers):
+            e = e * alpha + spmm(e, g, reduce=kernels.REDUCE_MEAN) * (1 - alpha)
+        return e.squeeze(1)
+
+    def two_hop_propagation(self, e, edge_index, prop_layers=1, alpha=0.5):
+        """:625-640: the two-hop operator adj @ adj applied as two mean-aggregation SpMVs."""
+        g = self._prop_graph(edge_index, e.shape[0])
+        e = e.unsqueeze(1)
+        for _ in range(prop_layers):
+            e = e * alpha + spmm(spmm(e, g, reduce=kernels.REDUCE_MEAN), g, reduce=kernels.REDUCE_MEAN) * (1 - alpha)
+        return e.squeeze(1)
+
+    def detect(self, dataset, node_idx, device, T, use_prop, use_2hop, oodprop, oodalpha):
+        x, edge_index = dataset.x.to(device), dataset.edge_index.to(device)
+        logits = self.encoder(x, edge_index)
+        if dataset in ("proteins", "ppi"):
+            logits = torch.stack([logits, torch.zeros_like(logits)], dim=2)
+            neg_energy = T * torch.logsumexp(logits / T, dim=-1).sum(dim=1)
+        else:
+            neg_energy = T * torch.logsumexp(logits / T, dim=-1)
+        if use_prop:
+            prop = self.two_hop_propagation if use_2hop else self.propagation
+            neg_energy = prop(neg_energy, edge_index, oodprop, oodalpha)
+        return neg_energy[node_idx]
+
+    def loss_compute(self, dataset_ind, dataset_ood, criterion, device, use_zinb):
+        x_out, edge_index_out = dataset_ood.x.to(device), dataset_ood.edge_index.to(device)
+        train_in_idx = dataset_ind.splits["train"]
+        logits_in, _mean, _disp, _pi = (i[train_in_idx] for i in self.encoder(dataset_ind.x.to(device), dataset_ind.edge_index.to(device),
+                                                                               decoder=use_zinb))
+        self.encoder(x_out, edge_index_out)  # logits_out: computed and unused, as in the reference (:667)
+        pred_in = F.log_softmax(logits_in, dim=1)
+        loss = criterion(pred_in, (dataset_ind.y.to(device))[train_in_idx].squeeze(1))
+        return loss, _mean, _disp, _pi, train_in_idx, logits_in
+
+    def fit(self, dataset_ind, dataset_ood_tr, use_zinb, adata, zinb_weight, cl_weight, mask_ratio, criterion, optimizer):
+        self.train()
+        optimizer.zero_grad()
+        loss, _mean, _disp, _pi, train_idx, logit_in = self.loss_compute(dataset_ind, dataset_ood_tr, criterion, self.device, use_zinb)
+        if use_zinb:
+            import scipy.sparse
+            x_raw = adata.raw.X
+            if scipy.sparse.issparse(x_raw):
+                x_raw = x_raw.toarray()
+            x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(self.device)[train_idx]
+            size_factors = torch.as_tensor(np.asarray(adata.obs["size_factors"]), device=self.device)[train_idx]
+            loss = loss + zinb_weight * ZINBLoss()(x_raw, _mean, _disp, _pi, size_factors)
+        if cl_weight != 0:
+            X = dataset_ind.x.to(self.device)
+            mask1 = (torch.rand_like(X) > mask_ratio).float()
+            z1 = self.encoder(X * mask1, dataset_ind.edge_index.to(self.device))
+            loss = loss + cl_weight * contrastive_loss(logit_in, z1)
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    def predict_proba(self, dataset_ind, save_path=None):
+        self.eval()
+        with torch.no_grad():
+            return F.softmax(self(dataset_ind, save_path=save_path), dim=1).cpu()
+
+    def predict(self, dataset_ind):
+        return torch.argmax(self.predict_proba(dataset_ind), dim=1)
+
+    def score(self, x, y, idx, *, score_func: Optional[Union[str, Mapping[Any, float]]] = None, return_pred: bool = False,
+              save_path=None, batch=None) -> Union[float, Tuple[float, Any]]:
+        from ...base import resolve_score_func
+        y_pred = self.predict_proba(x, save_path=save_path)
+        func = partial(eval_acc, acc=resolve_score_func(score_func or self._DEFAULT_METRIC))
+        score = func(y[idx], y_pred[idx])
+        return (score, y_pred) if return_pred else score

@@ -133,3 +133,110 @@ class ScDSCModel(nn.Module):
         q = q.pow((self.v + 1.0) / 2.0)
         q = (q.t() / torch.sum(q, 1)).t()
         return x_bar, q, predict, z3, _mean, _disp, _pi, self.zinb_loss
+
+
+# ---- ScDSC: the method wrapper (scdsc.py:33-336) ------------------------------------------------------------------
+import numpy as np  # noqa: E402
+from torch.optim import Adam  # noqa: E402
+from torch.utils.data import DataLoader, TensorDataset  # noqa: E402
+
+from ....graph import CSRGraph  # noqa: E402
+from ....transforms import Compose, SetConfig  # noqa: E402
+from ....transforms.graph import NeighborGraph  # noqa: E402
+from ...base import BaseClusteringMethod, TorchNNPretrain  # noqa: E402
+
+
+class ScDSC(TorchNNPretrain, BaseClusteringMethod):
+    """scDSC method wrapper (scdsc.py:33-336): ``fit((adj, x, x_raw, n_counts), y, ...)`` pre-trains the autoencoder, then
+    trains the AE + 7-layer GCN jointly (BCE + KL + MSE + ZINB); ``predict`` / ``predict_proba`` return the soft assignment
+    of the best-ARI checkpoint, as the reference does.  ``adj`` may be the scipy matrix the NeighborGraph transform leaves in
+    ``obsp`` (converted once to a device CSR — the reference goes through ``sparse_mx_to_torch_sparse_tensor``,
+    preprocess.py:526-532) or a ready ``CSRGraph``."""
+
+    def __init__(self, pretrain_path: str, sigma: float = 1, n_enc_1: int = 512, n_enc_2: int = 256, n_enc_3: int = 256,
+                 n_dec_1: int = 256, n_dec_2: int = 256, n_dec_3: int = 512, n_z1: int = 256, n_z2: int = 128, n_z3: int = 32,
+                 n_clusters: int = 100, n_input: int = 10, v: float = 1, device: str = "auto"):
+        super().__init__()
+        self.pretrain_path = pretrain_path
+        self.device = "cuda" if device == "auto" else device
+        self.model = ScDSCModel(sigma=sigma, n_enc_1=n_enc_1, n_enc_2=n_enc_2, n_enc_3=n_enc_3, n_dec_1=n_dec_1, n_dec_2=n_dec_2,
+                                n_dec_3=n_dec_3, n_z1=n_z1, n_z2=n_z2, n_z3=n_z3, n_clusters=n_clusters, n_input=n_input, v=v,
+                                device=self.device).to(self.device)
+        self.fix_module("model.ae")
+
+    @staticmethod
+    def preprocessing_pipeline(n_top_genes: int = 2000, n_neighbors: int = 50, log_level="INFO"):
+        """Graph part of scdsc.py:113-138 (the scanpy filtering / normalisation / HVG steps are CPU count-matrix preprocessing
+        outside the hot path: feed a matrix that already went through them, with ``raw_X`` and ``n_counts`` set)."""
+        return Compose(
+            NeighborGraph(n_neighbors=n_neighbors, metric="correlation", channel=None),
+            SetConfig({"feature_channel": ["NeighborGraph", None, None, "n_counts"],
+                       "feature_channel_type": ["obsp", "X", "raw_X", "obs"], "label_channel": "Group"}),
+            log_level=log_level,
+        )
+
+    def target_distribution(self, q):
+        p = q**2 / q.sum(0)
+        return (p.t() / p.sum(1)).t()
+
+    def pretrain(self, x, batch_size=256, epochs=200, lr=1e-3):
+        with self.pretrain_context("model.ae"):
+            train_loader = DataLoader(TensorDataset(torch.from_numpy(x)), batch_size, shuffle=True)
+            model = self.model.ae
+            optimizer = Adam(model.parameters(), lr=lr)
+            for _ in range(epochs):
+                for (x_batch, ) in train_loader:
+                    x_batch = x_batch.to(self.device)
+                    loss = F.mse_loss(model(x_batch)[0], x_batch)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+
+    def save_pretrained(self, path):
+        torch.save(self.model.ae.state_dict(), path)
+
+    def load_pretrained(self, path):
+        self.model.ae.load_state_dict(torch.load(self.pretrain_path, map_location=self.device))
+
+    def fit(self, inputs, y, lr: float = 1e-03, epochs: int = 300, bcl: float = 0.1, cl: float = 0.01, rl: float = 1, zl: float = 0.1,
+            pt_epochs: int = 200, pt_batch_size: int = 256, pt_lr: float = 1e-3):
+        adj, x, x_raw, n_counts = inputs
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        self._pretrain(x, batch_size=pt_batch_size, epochs=pt_epochs, lr=pt_lr, force_pretrain=True)
+        device, model = self.device, self.model
+        optimizer = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=lr)
+        if not isinstance(adj, (CSRGraph, torch.Tensor)):
+            adj = CSRGraph.from_scipy(adj, device)  # one device CSR (+ cached transpose) for all 7 layers of every epoch
+        x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(device)
+        n_counts = np.asarray(n_counts, dtype=np.float64)
+        sf = torch.as_tensor(n_counts / np.median(n_counts)).to(device)
+        data = torch.from_numpy(x).to(device)
+        aris, keys, Q = [], [], {}
+        p = None
+        with torch.no_grad():  # :253-254 — its result is unused, but the module is in train mode here: this full-batch pass
+            model.ae(data)     # moves the BatchNorm running statistics that the eval-mode passes below read
+        for epoch in range(epochs):
+            if epoch % 10 == 0:
+                model.eval()
+                with torch.no_grad():
+                    _, tmp_q, _, _, _, _, _, _ = model(data, adj)
+                    self.q = tmp_q.data
+                    p = self.target_distribution(self.q)
+                    aris.append(self.score(None, y))  # ARI for model selection (:261-263)
+                    keys.append(key := f"epoch{epoch}")
+                    Q[key] = self.q
+            model.train()
+            x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model(data, adj)
+            loss = (bcl * F.binary_cross_entropy(q, p) + cl * F.kl_div(pred.log(), p, reduction="batchmean") + rl * F.mse_loss(x_bar, data)
+                    + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf))
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            self.last_loss = loss.detach()
+        self.q = Q[keys[int(np.argmax(aris))]]
+
+    def predict_proba(self, x=None) -> np.ndarray:
+        return self.q.detach().clone().cpu().numpy()
+
+    def predict(self, x=None) -> np.ndarray:
+        return self.predict_proba().argmax(1)

@@ -230,6 +230,23 @@ DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t 
                                const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
                                float* out_val, int32_t* out_eid, dh_stream_t stream);
 
+/* ---- two-hop adjacency pattern of scHeteroNet (scheteronet.py:507-539, HeteroNet.init_adj) ------------------
+ * Pattern of ((A A) - A) > 0 for a 0/1 CSR pattern A (ascending, duplicate-free columns): (i, c) is kept when c is reached
+ * from i by two edges and is not "used up" by a direct edge, i.e. (i, c) is not in A or has >= 2 two-edge paths; drop_diag
+ * additionally removes c == i.  Symbolic SpGEMM on the device: path keys (i << 32 | c), radix sort, run heads.
+ *   dh_csr_two_hop_count  : rowcnt[i] = number of two-edge paths starting at row i (*overflow = 1 if one row exceeds 2^31)
+ *   dh_csr_two_hop_expand : offs = exclusive scan of rowcnt, total = offs[n]; writes flags[total] (1 at kept run heads)
+ *   dh_csr_two_hop_compact: pos = exclusive scan of flags; out_rowptr [n+1], out_col [pos[total]]
+ * The workspace (dh_csr_two_hop_workspace_bytes, 256-byte aligned) carries the sorted keys from expand to compact.   */
+DH_API int dh_csr_two_hop_count(int64_t n, const int32_t* rowptr, const int32_t* col, int32_t* rowcnt,
+                         int32_t* overflow, dh_stream_t stream);
+DH_API size_t dh_csr_two_hop_workspace_bytes(int64_t n, int64_t total);
+DH_API int dh_csr_two_hop_expand(int64_t n, int64_t total, const int32_t* rowptr, const int32_t* col,
+                          const int32_t* offs, int drop_diag, int32_t* flags, void* workspace,
+                          size_t workspace_bytes, dh_stream_t stream);
+DH_API int dh_csr_two_hop_compact(int64_t n, int64_t total, const int32_t* flags, const int32_t* pos,
+                           int32_t* out_rowptr, int32_t* out_col, const void* workspace, dh_stream_t stream);
+
 /* ---- dense part of graph-sc's inner-product decoder loss (graphsc.py:208-216) ------------------------------
  * binary_cross_entropy_with_logits(X, adj, pos_weight) with a target that is zero almost everywhere: element loss
  * softplus(x), derivative sigmoid(x); the y = 1 corrections are sparse and stay with the caller.

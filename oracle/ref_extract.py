@@ -197,3 +197,80 @@ def dgl_stub(shuffle_generator=None):
     dataloading = types.SimpleNamespace(MultiLayerFullNeighborSampler=_sampler, DataLoader=_Loader)
     return types.SimpleNamespace(graph=lambda pair: DGLStubGraph(pair[0], pair[1]), function=fn, dataloading=dataloading,
                                  DGLGraph=DGLStubGraph)
+
+
+# ---- torch_sparse / torch_geometric stand-ins for the extracted scHeteroNet code --------------------------------------------
+def pyg_stub():
+    """What dance/modules/single_modality/cell_type_annotation/scheteronet.py imports from torch_sparse (0.6.x) and
+    torch_geometric (2.4): ``SparseTensor`` (row / col / value storage; ``remove_diag`` RETURNS a new tensor — it is not in
+    place), ``matmul`` (sparse x dense with autograd for the dense operand, sparse x sparse), ``gcn_norm(adj_t, None, n,
+    add_self_loops=False)`` = D^-1/2 A D^-1/2 with D = row sums and inf -> 0, ``JumpingKnowledge('cat')``, ``degree``.
+    Restated from the libraries' documentation [3P-memory, SURVEY.md §8c]; test infrastructure only."""
+    import types
+
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+
+    class SparseTensor:
+        def __init__(self, row=None, col=None, value=None, sparse_sizes=None, _csr=None):
+            if _csr is not None:
+                self.csr = _csr
+            else:
+                v = np.ones(len(row), dtype=np.float32) if value is None else np.asarray(value.detach().cpu(), dtype=np.float32)
+                self.csr = sp.coo_matrix((v, (np.asarray(row.cpu()), np.asarray(col.cpu()))), shape=sparse_sizes).tocsr()
+                self.csr.sum_duplicates()
+            self.device = torch.device("cpu")
+
+        @classmethod
+        def from_scipy(cls, m):
+            return cls(_csr=sp.csr_matrix(m, dtype=np.float32))
+
+        def to_scipy(self, layout=None):
+            return self.csr.copy()
+
+        def remove_diag(self, k=0):
+            m = self.csr.tolil(copy=True)
+            m.setdiag(0, k)
+            out = SparseTensor.from_scipy(m.tocsr())
+            out.csr.eliminate_zeros()
+            return out
+
+        def to(self, device):
+            return self
+
+        def cpu(self):
+            return self
+
+        def __matmul__(self, other):
+            return matmul(self, other)
+
+        def torch_sparse(self):
+            c = self.csr.tocoo()
+            return torch.sparse_coo_tensor(np.vstack((c.row, c.col)).astype(np.int64), c.data.astype(np.float32), c.shape).coalesce()
+
+    def matmul(a, b):
+        if isinstance(b, SparseTensor):
+            return SparseTensor.from_scipy(a.csr @ b.csr)
+        return torch.sparse.mm(a.torch_sparse(), b)
+
+    def gcn_norm(adj_t, edge_weight=None, num_nodes=None, improved=False, add_self_loops=True, flow="source_to_target", dtype=None):
+        assert not add_self_loops and edge_weight is None
+        m = adj_t.csr.astype(np.float32)
+        deg = np.asarray(m.sum(1)).ravel()
+        with np.errstate(divide="ignore"):
+            dis = deg**-0.5
+        dis[np.isinf(dis)] = 0
+        return SparseTensor.from_scipy(sp.diags(dis) @ m @ sp.diags(dis))
+
+    class JumpingKnowledge:
+        def __init__(self, mode):
+            assert mode == "cat"
+
+        def __call__(self, xs):
+            return torch.cat(xs, dim=-1)
+
+    def degree(index, num_nodes=None, dtype=None):
+        return torch.bincount(index, minlength=num_nodes).to(torch.float32)
+
+    return types.SimpleNamespace(SparseTensor=SparseTensor, matmul=matmul, gcn_norm=gcn_norm, JumpingKnowledge=JumpingKnowledge, degree=degree)

@@ -391,6 +391,113 @@ def make_graphsc():
     print("graphsc.npz:", len(out), "arrays")
 
 
+def make_scheteronet():
+    """scheteronet.npz — the reference's own HeteroNet / scHeteroNet classes (scheteronet.py:281-789), AST-lifted and run on
+    torch-CPU over stand-ins for torch_sparse / torch_geometric (oracle.ref_extract.pyg_stub): init_adj's two normalised
+    adjacencies, the eval-mode forward with the ZINB decoder, energy propagation (one- and two-hop), and one ``fit`` step
+    (dropout = 0, ZINB loss on, contrastive term off — it draws a random mask)."""
+    import types
+
+    import scipy.sparse
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from typing import Any, Mapping, Optional, Tuple, Union
+    sh = "dance/modules/single_modality/cell_type_annotation/scheteronet.py"
+    pyg = ref_extract.pyg_stub()
+    ns = {"SparseTensor": pyg.SparseTensor, "matmul": pyg.matmul, "gcn_norm": pyg.gcn_norm, "JumpingKnowledge": pyg.JumpingKnowledge,
+          "degree": pyg.degree, "scipy": scipy, "BaseClassificationMethod": object, "LogLevel": str, "Any": Any, "Mapping": Mapping,
+          "Optional": Optional, "Tuple": Tuple, "Union": Union, "logger": __import__("logging").getLogger("reference")}
+    for name in ("contrastive_loss", "ZINBLoss", "MLP", "HetConv", "MeanAct", "DispAct", "ZINBDecoder", "HeteroNet", "scHeteroNet"):
+        ns[name] = ref_extract.extract(sh, name, ns)
+    rng = np.random.default_rng(5)
+    n, d, c, hid, k = 70, 18, 4, 8, 4
+    lab = rng.integers(0, c, n)
+    x = (rng.standard_normal((n, d)) + np.eye(c, d)[lab] * 2).astype(np.float32)
+    from sklearn.neighbors import NearestNeighbors
+    idx = NearestNeighbors(n_neighbors=k + 1).fit(x).kneighbors(x, return_distance=False)   # HeteronetGraph: self is neighbour 0
+    edge_index = np.stack((np.repeat(np.arange(n), k + 1), idx.reshape(-1))).astype(np.int64)
+    out = dict(sh_x=x, sh_edge_index=edge_index, sh_y=lab.astype(np.int64), sh_dims=np.array([n, d, c, hid], dtype=np.int64))
+    torch.manual_seed(11)
+    model = ns["scHeteroNet"](d, c, torch.from_numpy(edge_index), n, hid, 2, 0.0, True, "cpu", 100.0)
+    enc = model.encoder
+    out["sh_adj_t"] = np.asarray(enc.adj_t.csr.todense(), dtype=np.float32)
+    out["sh_adj_t2"] = np.asarray(enc.adj_t2.csr.todense(), dtype=np.float32)
+    for kk, v in model.state_dict().items():
+        out["sh_sd0::" + kk] = v.numpy().copy()
+    ds = types.SimpleNamespace(x=torch.from_numpy(x), edge_index=torch.from_numpy(edge_index), y=torch.from_numpy(lab)[:, None],
+                               splits={"train": torch.arange(0, n, 2)}, node_idx=torch.arange(n))
+    model.eval()
+    with torch.no_grad():
+        h, m_, d_, p_ = enc(ds.x, ds.edge_index, decoder=True)
+        e = torch.from_numpy(rng.standard_normal(n).astype(np.float32))
+        out.update(sh_logits=h.numpy(), sh_mean=m_.numpy(), sh_disp=d_.numpy(), sh_pi=p_.numpy(), sh_e=e.numpy(),
+                   sh_prop=model.propagation(e, ds.edge_index, 2, 0.5).numpy(),
+                   sh_prop2=model.two_hop_propagation(e, ds.edge_index, 1, 0.3).numpy(),
+                   sh_detect=model.detect(ds, ds.node_idx, "cpu", 1.0, True, False, 2, 0.5).numpy())
+    # one training step (train mode: BatchNorm on batch statistics; dropout 0)
+    counts = rng.poisson(np.exp(x[:, :d] * 0.3)).astype(np.float32)
+    adata = types.SimpleNamespace(raw=types.SimpleNamespace(X=counts), obs=types.SimpleNamespace(size_factors=(counts.sum(1) / counts.sum(1).mean()).astype(np.float32)))
+    out.update(sh_counts=counts, sh_size_factors=adata.obs.size_factors)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    loss = model.fit(ds, ds, True, adata, 0.5, 0.0, 0.4, nn.NLLLoss(), opt)
+    out["sh_loss"] = np.array(float(loss.detach()), dtype=np.float64)
+    for kk, v in model.state_dict().items():
+        out["sh_sd1::" + kk] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "scheteronet.npz"), **out)
+    print("scheteronet.npz:", len(out), "arrays; loss", out["sh_loss"])
+
+
+def make_scdsc_fit():
+    """scdsc_fit.npz — the reference's own ``ScDSC`` method class (scdsc.py:33-336: AE pre-training, the joint training loop
+    with BCE + KL + MSE + ZINB, best-ARI checkpoint selection) AST-lifted together with its ScDSCModel / AE / GNNLayer /
+    ZINBLoss and ``sparse_mx_to_torch_sparse_tensor`` (preprocess.py:526-532) and run on torch-CPU.  The pre-train / fix-module
+    mixins (dance/modules/base.py:72-153, pure Python plumbing) are dance_amd's mirrors of them."""
+    import logging
+    from typing import Any, Optional, Tuple
+
+    import pandas as pd
+    from torch.nn import Linear
+    from torch.optim import Adam
+    from torch.utils.data import DataLoader, TensorDataset
+
+    from dance_amd.modules.base import BaseClusteringMethod, TorchNNPretrain
+    sc_ = "dance/modules/single_modality/clustering/scdsc.py"
+    ns = {"Linear": Linear, "get_device": lambda d: "cpu", "Adam": Adam, "DataLoader": DataLoader, "TensorDataset": TensorDataset,
+          "TorchNNPretrain": TorchNNPretrain, "BaseClusteringMethod": BaseClusteringMethod, "logger": logging.getLogger("reference"),
+          "LogLevel": str, "Tuple": Tuple, "Optional": Optional, "Any": Any, "sp": sp, "pd": pd}
+    for name in ("GNNLayer", "AE", "MeanAct", "DispAct"):
+        ns[name] = ref_extract.extract(sc_, name, ns)
+    ns["ZINBLoss"] = ref_extract.extract("dance/utils/loss.py", "ZINBLoss")
+    ns["ScDSCModel"] = ref_extract.extract(sc_, "ScDSCModel", ns)
+    ns["sparse_mx_to_torch_sparse_tensor"] = ref_extract.extract("dance/transforms/preprocess.py", "sparse_mx_to_torch_sparse_tensor", {"sp": sp})
+    ScDSC = ref_extract.extract(sc_, "ScDSC", ns)
+    rng = np.random.default_rng(21)
+    n, g, c = 120, 30, 3
+    lab = rng.integers(0, c, n)
+    x = (rng.standard_normal((n, g)) * 0.6 + np.eye(c, g)[lab] * 2.5).astype(np.float32)
+    counts = rng.poisson(np.exp(np.clip(x, -2, 2) * 0.5)).astype(np.float32)
+    n_counts = counts.sum(1) + 1.0
+    from sklearn.neighbors import kneighbors_graph
+    a = kneighbors_graph(x, 6, include_self=True)
+    a = ((a + a.T) > 0).astype(np.float32)
+    adj = sp.csr_matrix(sp.diags(1.0 / np.asarray(a.sum(1)).ravel()) @ a, dtype=np.float32)   # row-normalised kNN graph
+    kw = dict(sigma=0.5, n_enc_1=24, n_enc_2=16, n_enc_3=16, n_dec_1=16, n_dec_2=16, n_dec_3=24, n_z1=16, n_z2=12, n_z3=8, n_clusters=c,
+              n_input=g, v=1)
+    torch.manual_seed(9)
+    m = ScDSC(pretrain_path=None, device="cpu", **kw)
+    out = dict(sf_x=x, sf_counts=counts, sf_n_counts=n_counts.astype(np.float32), sf_y=lab.astype(np.int64), sf_adj_indptr=adj.indptr.astype(np.int32),
+               sf_adj_indices=adj.indices.astype(np.int32), sf_adj_data=adj.data, sf_kw=np.array(json.dumps(kw)))
+    for k, v in m.model.state_dict().items():
+        out["sf_sd0::" + k] = v.numpy().copy()
+    torch.manual_seed(10)
+    m.fit((adj, x, counts, pd.Series(n_counts)), lab, lr=1e-3, epochs=12, pt_epochs=3, pt_batch_size=32, pt_lr=1e-3)
+    out.update(sf_q=m.predict_proba(), sf_pred=m.predict().astype(np.int64))
+    for k, v in m.model.state_dict().items():
+        out["sf_sd1::" + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "scdsc_fit.npz"), **out)
+    print("scdsc_fit.npz:", len(out), "arrays; ARI-selected q", out["sf_q"].shape)
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -400,3 +507,5 @@ if __name__ == "__main__":
     make_matrix_known_answers()
     make_graph_builders()
     make_graphsc()
+    make_scheteronet()
+    make_scdsc_fit()

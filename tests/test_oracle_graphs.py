@@ -230,3 +230,27 @@ def test_graphsc_golden_regenerates_from_reference(tmp_path, monkeypatch):
             assert np.allclose(new[k], old[k], rtol=1e-5, atol=1e-6), k
         else:
             assert np.array_equal(new[k], old[k]), k
+
+
+@pytest.mark.parametrize("maker,fname", [("make_scheteronet", "scheteronet.npz"), ("make_scdsc_fit", "scdsc_fit.npz")])
+def test_model_goldens_regenerate_from_reference(tmp_path, monkeypatch, maker, fname):
+    """scheteronet.npz / scdsc_fit.npz are what the reference's own classes produce NOW (build container only)."""
+    import importlib.util
+    import os
+
+    from oracle import ref_extract
+    if not ref_extract.available():
+        pytest.skip("reference tree not present")
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden_" + maker, os.path.join(here, "make_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "HERE", str(tmp_path))
+    getattr(mod, maker)()
+    new, old = np.load(tmp_path / fname), np.load(os.path.join(here, fname))
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if old[k].dtype.kind in "fc":
+            assert np.allclose(new[k], old[k], rtol=1e-4, atol=1e-5), k
+        else:
+            assert np.array_equal(new[k], old[k]), k
