@@ -274,3 +274,41 @@ def pyg_stub():
         return torch.bincount(index, minlength=num_nodes).to(torch.float32)
 
     return types.SimpleNamespace(SparseTensor=SparseTensor, matmul=matmul, gcn_norm=gcn_norm, JumpingKnowledge=JumpingKnowledge, degree=degree)
+
+
+def dgl_tagconv_stub():
+    """``dgl.nn.TAGConv`` (dgl 1.1.3) restated from its documentation / source [3P-memory], over DGLStubGraph: K hops of
+    sum-aggregation with D_in^-1/2 on both sides (in-degrees clamped at 1) when no edge weights are given, and with
+    ``EdgeWeightNorm("both")`` weights w_uv / sqrt(out_sum(u) * in_sum(v)) — and no degree factor — when they are; then one
+    Linear over the concatenated hops.  Test infrastructure only."""
+    import torch
+    import torch.nn as nn
+
+    class TAGConv(nn.Module):
+        def __init__(self, in_feats, out_feats, k=2, bias=True, activation=None):
+            super().__init__()
+            self._k, self._activation = k, activation
+            self.lin = nn.Linear(in_feats * (k + 1), out_feats, bias=bias)
+            nn.init.xavier_normal_(self.lin.weight, gain=nn.init.calculate_gain("relu"))
+
+        def forward(self, graph, feat, edge_weight=None):
+            src, dst = graph.edges()
+            n = graph.number_of_nodes()
+            if edge_weight is None:
+                norm = torch.bincount(dst, minlength=n).to(feat).clamp(min=1).pow(-0.5)[:, None]
+                w = None
+            else:
+                ew = edge_weight.reshape(-1)
+                out_sum = torch.zeros(n).index_add_(0, src, ew)
+                in_sum = torch.zeros(n).index_add_(0, dst, ew)
+                w = ew * out_sum.pow(-0.5)[src] * in_sum.pow(-0.5)[dst]
+            fstack = [feat]
+            for _ in range(self._k):
+                h = fstack[-1] if w is not None else fstack[-1] * norm
+                m = h[src] if w is None else h[src] * w[:, None]
+                rst = torch.zeros_like(h).index_add_(0, dst, m)
+                fstack.append(rst if w is not None else rst * norm)
+            rst = self.lin(torch.cat(fstack, dim=-1))
+            return rst if self._activation is None else self._activation(rst)
+
+    return TAGConv

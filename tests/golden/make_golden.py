@@ -498,6 +498,65 @@ def make_scdsc_fit():
     print("scdsc_fit.npz:", len(out), "arrays; ARI-selected q", out["sf_q"].shape)
 
 
+def make_sctag():
+    """sctag.npz — the reference's own ScTAG / DecoderAdj / DecoderX (sctag.py:32-528) and ZINBLoss / dist_loss
+    (utils/loss.py), AST-lifted and run on torch-CPU over the DGL graph stub and the restated dgl.nn.TAGConv
+    (oracle.ref_extract.dgl_tagconv_stub): a forward before training, then ``fit`` with 3 pre-training and 4 training epochs
+    (decoder dropout 0: the only random draw left is KMeans', seeded through numpy)."""
+    import logging
+    from typing import Any, Optional, Tuple
+
+    import torch.optim as optim
+    from sklearn.cluster import KMeans
+    from torch.nn import Parameter
+
+    from dance_amd.modules.base import BaseClusteringMethod, TorchNNPretrain
+    st = "dance/modules/single_modality/clustering/sctag.py"
+    dgl = ref_extract.dgl_stub()
+    ns = {"dgl": dgl, "TAGConv": ref_extract.dgl_tagconv_stub(), "KMeans": KMeans, "Parameter": Parameter, "optim": optim,
+          "get_device": lambda d: "cpu", "TorchNNPretrain": TorchNNPretrain, "BaseClusteringMethod": BaseClusteringMethod,
+          "logger": logging.getLogger("reference"), "LogLevel": str, "Tuple": Tuple, "Optional": Optional, "Any": Any}
+    ns["ZINBLoss"] = ref_extract.extract("dance/utils/loss.py", "ZINBLoss")
+    ns["cdisttf"] = ref_extract.extract("dance/utils/loss.py", "cdisttf")
+    ns["dist_loss"] = ref_extract.extract("dance/utils/loss.py", "dist_loss", ns)
+    for name in ("MeanAct", "DispAct", "DecoderAdj", "DecoderX", "ScTAG"):
+        ns[name] = ref_extract.extract(st, name, ns)
+    rng = np.random.default_rng(31)
+    n, g, c = 60, 20, 3
+    lab = rng.integers(0, c, n)
+    x = (rng.standard_normal((n, g)) * 0.6 + np.eye(c, g)[lab] * 2.0).astype(np.float32)
+    counts = rng.poisson(np.exp(np.clip(x, -2, 2) * 0.5)).astype(np.float32)
+    n_counts = counts.sum(1) + 1.0
+    from sklearn.neighbors import kneighbors_graph
+    a = kneighbors_graph(x, 5, include_self=False)
+    w = rng.uniform(0.2, 1.0, a.nnz).astype(np.float32)     # weighted, symmetric (UMAP-connectivity-like)
+    a = sp.csr_matrix((w, a.indices, a.indptr), shape=a.shape)
+    adj = np.asarray(a.maximum(a.T).todense(), dtype=np.float32)
+    out = dict(tg_x=x, tg_counts=counts, tg_n_counts=n_counts.astype(np.float32), tg_y=lab.astype(np.int64), tg_adj=adj)
+    torch.manual_seed(4)
+    m = ns["ScTAG"](n_clusters=c, k=3, hidden_dim=16, latent_dim=6, dec_dim=[12, 16, 20], dropout=0.0, device="cpu")
+    m.init_model(adj, x)
+    with torch.no_grad():
+        m.mu.copy_(torch.from_numpy(rng.standard_normal((c, 6)).astype(np.float32)))
+    for k, v in m.state_dict().items():
+        out["tg_sd0::" + k] = v.numpy().copy()
+    with torch.no_grad():
+        xt = torch.from_numpy(x)
+        adj_out, z, q, mean, disp, pi = m.forward(m.g_n, xt)
+        out.update(tg_adj_out=adj_out.numpy(), tg_z=z.numpy(), tg_q=q.numpy(), tg_mean=mean.numpy(), tg_disp=disp.numpy(), tg_pi=pi.numpy(),
+                   tg_enc_unweighted=m.encoder1(m.g_n, xt).numpy())
+    # fit() re-initialises the model: same torch seed on both sides -> same initial weights; KMeans draws from numpy's generator
+    torch.manual_seed(5)
+    np.random.seed(0)
+    m2 = ns["ScTAG"](n_clusters=c, k=3, hidden_dim=16, latent_dim=6, dec_dim=[12, 16, 20], dropout=0.0, device="cpu")
+    m2.fit((adj, x, counts, n_counts), lab, epochs=4, pretrain_epochs=3, lr=5e-3, w_d=0.1)
+    out.update(tg_fit_q=m2.predict_proba(), tg_fit_pred=m2.predict().astype(np.int64))
+    for k, v in m2.state_dict().items():
+        out["tg_sd1::" + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "sctag.npz"), **out)
+    print("sctag.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -509,3 +568,4 @@ if __name__ == "__main__":
     make_graphsc()
     make_scheteronet()
     make_scdsc_fit()
+    make_sctag()
