@@ -67,6 +67,8 @@ def _declare(lib):
         "dh_sage_tail": (c_int, [i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P]),
         "dh_softplus_rowsum_f32": (c_int, [i64, i64, P, i64, P, P]),
         "dh_sigmoid_scale_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
+        "dh_edge_softmax_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P]),
+        "dh_edge_softmax_backward_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P, P, P, P]),
         "dh_csr_two_hop_count": (c_int, [i64, P, P, P, P, P]),
         "dh_csr_two_hop_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_csr_two_hop_expand": (c_int, [i64, i64, P, P, P, i32, P, P, c_size_t, P]),

@@ -120,6 +120,50 @@ def spmm(x: torch.Tensor, graph: CSRGraph, *, rowscale: Optional[torch.Tensor] =
     return _SpMMFn.apply(x, graph, rowscale, colscale, reduce)
 
 
+class _GATAggregateFn(torch.autograd.Function):
+    """out[i] = sum_{e=(j->i)} att[e] x[j],  att = edge_softmax(act(a_src[j] + a_dst[i]))  — GATConv.propagate of
+    stagate.py:104-124 without the [E, C] messages: dh_edge_softmax_f32 + dh_spmm_csr_f32 forward; backward from
+    dh_sddmm_csr_f32 (d att), dh_edge_softmax_backward_f32 (softmax / activation Jacobians, d a_dst), a scatter-add over the
+    source ids (d a_src) and the SpMM on the transposed CSR with the attention values carried along (d x)."""
+
+    @staticmethod
+    def forward(ctx, x, a_src, a_dst, graph: CSRGraph, act: int, slope: float):
+        x, a_src, a_dst = x.contiguous(), a_src.contiguous(), a_dst.contiguous()
+        att = kernels.edge_softmax(graph.rowptr, graph.col, a_src, a_dst, act=act, negative_slope=slope)
+        out = kernels.spmm_csr(graph.rowptr, graph.col, att, x, n_cols=graph.n_cols)
+        ctx.graph, ctx.act, ctx.slope = graph, act, slope
+        ctx.save_for_backward(x, a_src, a_dst, att)
+        ctx.mark_non_differentiable(att)
+        return out, att
+
+    @staticmethod
+    def backward(ctx, dout, _datt_unused):
+        x, a_src, a_dst, att = ctx.saved_tensors
+        g = ctx.graph
+        dout = dout.contiguous()
+        dx = da_src = da_dst = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            u, v = dout, x
+            if x.shape[1] % 4:  # the SDDMM moves 16 bytes per lane: zero-pad the inner dimension (the products are unchanged)
+                pad = 4 - x.shape[1] % 4
+                u, v = torch.nn.functional.pad(dout, (0, pad)), torch.nn.functional.pad(x, (0, pad))
+            datt = kernels.sddmm_csr(g.rowptr, g.col, u, v)
+            dt, da_dst = kernels.edge_softmax_backward(g.rowptr, g.col, a_src, a_dst, att, datt, act=ctx.act, negative_slope=ctx.slope)
+            da_src = torch.zeros_like(a_src).index_add_(0, g.col.long(), dt)
+        if ctx.needs_input_grad[0]:
+            if getattr(g, "_t_perm", None) is None:  # structure of A^T + where each of its entries sits in A: once per graph
+                g._t_struct = kernels.csr_transpose(g.rowptr, g.col, None, g.n_rows, g.n_cols)
+                g._t_perm = g._t_struct[3].long()
+            rp_t, col_t = g._t_struct[0], g._t_struct[1]
+            dx = kernels.spmm_csr(rp_t, col_t, att[g._t_perm].contiguous(), dout, n_cols=g.n_rows)
+        return dx, da_src, da_dst, None, None, None
+
+
+def gat_aggregate(x, a_src, a_dst, graph: CSRGraph, *, act: int = kernels.ATT_SIGMOID, negative_slope: float = 0.2):
+    """(out, att): attention-weighted aggregation over the in-edges of every row and the per-edge coefficients (CSR order)."""
+    return _GATAggregateFn.apply(x, a_src, a_dst, graph, act, negative_slope)
+
+
 class _DenseAdjLayerFn(torch.autograd.Function):
     """Same op for a DENSE adjacency (SpaGCN passes a dense N x N FloatTensor, spagcn.py:497,359)."""
 

@@ -467,6 +467,30 @@ def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     return out
 
 
+ATT_SIGMOID, ATT_LEAKY_RELU = 0, 1
+
+
+def edge_softmax(rowptr, col, a_src, a_dst, *, act: int = ATT_SIGMOID, negative_slope: float = 0.2) -> torch.Tensor:
+    """att[e] = softmax over each row's in-edges of act(a_src[col[e]] + a_dst[row]) (dh_edge_softmax_f32)."""
+    lib = _lib_ready()
+    att = torch.empty(col.numel(), dtype=torch.float32, device=col.device)
+    _call("edge_softmax_f32", lib.dh_edge_softmax_f32, rowptr.numel() - 1, _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),
+          _dev(a_src, torch.float32, "a_src", 1), _dev(a_dst, torch.float32, "a_dst", 1), act, float(negative_slope), att.data_ptr(), _stream())
+    return att
+
+
+def edge_softmax_backward(rowptr, col, a_src, a_dst, att, datt, *, act: int = ATT_SIGMOID, negative_slope: float = 0.2):
+    """(dt [E], d_a_dst [n_rows]) of ``edge_softmax`` given d att (dh_edge_softmax_backward_f32)."""
+    lib = _lib_ready()
+    n_rows = rowptr.numel() - 1
+    dt = torch.empty(col.numel(), dtype=torch.float32, device=col.device)
+    d_dst = torch.empty(n_rows, dtype=torch.float32, device=col.device)
+    _call("edge_softmax_backward_f32", lib.dh_edge_softmax_backward_f32, n_rows, _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(a_src, torch.float32, "a_src", 1), _dev(a_dst, torch.float32, "a_dst", 1), act,
+          float(negative_slope), _dev(att, torch.float32, "att", 1), _dev(datt, torch.float32, "datt", 1), dt.data_ptr(), d_dst.data_ptr(), _stream())
+    return dt, d_dst
+
+
 def csr_two_hop(rowptr: torch.Tensor, col: torch.Tensor, *, drop_diag: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Pattern of ((A A) - A) > 0 for a square 0/1 CSR pattern (dh_csr_two_hop_*): returns (rowptr2, col2)."""
     lib = _lib_ready()

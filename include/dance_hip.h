@@ -230,6 +230,19 @@ DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t 
                                const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
                                float* out_val, int32_t* out_eid, dh_stream_t stream);
 
+/* ---- edge softmax of graph attention (stagate.py:31-128 GATConv.message; scgnn2.py:1091-1118) --------------------
+ * att[e] = softmax over the in-edges e = (j -> i) of row i of act(a_src[j] + a_dst[i]); act 0 = sigmoid (STAGATE),
+ * 1 = leaky_relu(negative_slope) (GAT); denominator + 1e-16 as torch_geometric.utils.softmax.  a_dst may be NULL.
+ * The weighted aggregation itself is dh_spmm_csr_f32 with val = att (no [E, C] message tensor).
+ * Backward: dt[e] = act'(t_e) att[e] (datt[e] - sum_k att[k] datt[k]) per row, datt from dh_sddmm_csr_f32;
+ * d_a_dst[i] = sum_e dt[e] (may be NULL); d a_src is the column-wise sum of dt (caller: scatter-add over col).      */
+DH_API int dh_edge_softmax_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col, const float* a_src,
+                        const float* a_dst, int act, float negative_slope, float* att, dh_stream_t stream);
+DH_API int dh_edge_softmax_backward_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col,
+                                 const float* a_src, const float* a_dst, int act, float negative_slope,
+                                 const float* att, const float* datt, float* dt, float* d_a_dst,
+                                 dh_stream_t stream);
+
 /* ---- two-hop adjacency pattern of scHeteroNet (scheteronet.py:507-539, HeteroNet.init_adj) ------------------
  * Pattern of ((A A) - A) > 0 for a 0/1 CSR pattern A (ascending, duplicate-free columns): (i, c) is kept when c is reached
  * from i by two edges and is not "used up" by a direct edge, i.e. (i, c) is not in A or has >= 2 two-edge paths; drop_diag

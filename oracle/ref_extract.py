@@ -312,3 +312,49 @@ def dgl_tagconv_stub():
             return rst if self._activation is None else self._activation(rst)
 
     return TAGConv
+
+
+def pyg_message_passing_stub():
+    """``torch_geometric.nn.conv.MessagePassing`` (aggr="add", node_dim=0, flow source_to_target) and
+    ``torch_geometric.utils.softmax / add_self_loops / remove_self_loops`` as STAGATE's GATConv uses them (stagate.py:19-20):
+    ``propagate`` gathers ``*_j`` arguments at edge_index[0] and ``*_i`` at edge_index[1], calls ``message`` and scatter-adds
+    the result at edge_index[1]; ``softmax(src, index, ptr, N)`` = exp(src - segment max) / (segment sum + 1e-16).
+    Restated from the library documentation [3P-memory]; test infrastructure only."""
+    import types
+
+    import torch
+    import torch.nn as nn
+
+    def softmax(src, index, ptr=None, num_nodes=None, dim=0):
+        n = int(index.max()) + 1 if num_nodes is None else num_nodes
+        shape = (n, ) + tuple(src.shape[1:])
+        mx = torch.full(shape, -float("inf"), dtype=src.dtype).scatter_reduce(0, index.reshape((-1, ) + (1, ) * (src.dim() - 1)).expand_as(src), src,
+                                                                                reduce="amax", include_self=True)
+        out = (src - mx[index]).exp()
+        den = torch.zeros(shape, dtype=src.dtype).index_add_(0, index, out) + 1e-16
+        return out / den[index]
+
+    class MessagePassing(nn.Module):
+        def __init__(self, aggr="add", node_dim=0, **kwargs):
+            super().__init__()
+            assert aggr == "add" and node_dim == 0
+
+        def propagate(self, edge_index, size=None, **kwargs):
+            src, dst = edge_index[0], edge_index[1]
+            x = kwargs["x"]
+            alpha = kwargs["alpha"]
+            n_dst = x[1].shape[0] if x[1] is not None else x[0].shape[0]
+            msg = self.message(x_j=x[0][src], alpha_j=alpha[0][src], alpha_i=None if alpha[1] is None else alpha[1][dst], index=dst, ptr=None,
+                               size_i=n_dst)
+            out = torch.zeros((n_dst, ) + tuple(msg.shape[1:]), dtype=msg.dtype)
+            return out.index_add_(0, dst, msg)
+
+    def remove_self_loops(edge_index, edge_attr=None):
+        keep = edge_index[0] != edge_index[1]
+        return edge_index[:, keep], None
+
+    def add_self_loops(edge_index, edge_attr=None, num_nodes=None):
+        loops = torch.arange(num_nodes)
+        return torch.cat((edge_index, torch.stack((loops, loops))), dim=1), None
+
+    return types.SimpleNamespace(MessagePassing=MessagePassing, softmax=softmax, remove_self_loops=remove_self_loops, add_self_loops=add_self_loops)

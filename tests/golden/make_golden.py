@@ -557,6 +557,60 @@ def make_sctag():
     print("sctag.npz:", len(out), "arrays")
 
 
+def make_stagate():
+    """stagate.npz — the reference's own GATConv / Stagate (stagate.py:31-330), AST-lifted and run on torch-CPU over the
+    restated torch_geometric MessagePassing / softmax (oracle.ref_extract.pyg_message_passing_stub): a GATConv forward +
+    backward (output, attention weights, gradients of x, lin_src, att_src, att_dst), the auto-encoder forward, and
+    ``pretrain`` for 5 epochs (deterministic: no dropout)."""
+    import logging
+    from typing import Any, Optional, Tuple
+
+    from torch import Tensor
+    from torch.nn import Parameter
+
+    from dance_amd.modules.base import BaseClusteringMethod, BasePretrain
+    sg = "dance/modules/spatial/spatial_domain/stagate.py"
+    pyg = ref_extract.pyg_message_passing_stub()
+    ns = {"MessagePassing": pyg.MessagePassing, "softmax": pyg.softmax, "add_self_loops": pyg.add_self_loops,
+          "remove_self_loops": pyg.remove_self_loops, "Tensor": Tensor, "Parameter": Parameter, "get_device": lambda d: "cpu",
+          "BasePretrain": BasePretrain, "BaseClusteringMethod": BaseClusteringMethod, "logger": logging.getLogger("reference"), "LogLevel": str,
+          "Tuple": Tuple, "Optional": Optional, "Any": Any, "tqdm": lambda it: it}
+    ns["GATConv"] = ref_extract.extract(sg, "GATConv", ns)
+    Stagate = ref_extract.extract(sg, "Stagate", ns)
+    rng = np.random.default_rng(41)
+    n, d = 80, 24
+    xy = rng.random((n, 2)) * 10
+    dist = np.sqrt(((xy[:, None] - xy[None])**2).sum(-1))
+    a = (dist < 1.9)                                   # StagateGraph(radius): self included
+    src, dst = np.nonzero(a)
+    edge_index = np.stack((src, dst)).astype(np.int64)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    out = dict(sg_x=x, sg_edge_index=edge_index)
+    torch.manual_seed(2)
+    conv = ns["GATConv"](d, 10, heads=1, concat=False, dropout=0, add_self_loops=False, bias=False)
+    xt = torch.from_numpy(x).requires_grad_(True)
+    y, (ei, alpha) = conv(xt, torch.from_numpy(edge_index), return_attention_weights=True)
+    dy = torch.from_numpy(rng.standard_normal(y.shape).astype(np.float32))
+    y.backward(dy)
+    out.update(sg_conv_lin=conv.lin_src.detach().numpy().copy(), sg_conv_att_src=conv.att_src.detach().numpy().copy(),
+               sg_conv_att_dst=conv.att_dst.detach().numpy().copy(), sg_conv_out=y.detach().numpy(), sg_conv_alpha=alpha.detach().numpy(),
+               sg_conv_dy=dy.numpy(), sg_conv_dx=xt.grad.numpy().copy(), sg_conv_dlin=conv.lin_src.grad.numpy().copy(),
+               sg_conv_datt_src=conv.att_src.grad.numpy().copy(), sg_conv_datt_dst=conv.att_dst.grad.numpy().copy())
+    torch.manual_seed(3)
+    m = Stagate([d, 12, 6], device="cpu")
+    for k, v in m.state_dict().items():
+        out["sg_sd0::" + k] = v.numpy().copy()
+    with torch.no_grad():
+        h2, h4 = m(torch.from_numpy(x), torch.from_numpy(edge_index))
+    out.update(sg_h2=h2.numpy().copy(), sg_h4=h4.numpy().copy())
+    m.pretrain(x, edge_index, lr=1e-2, weight_decay=1e-4, epochs=5, gradient_clipping=5)
+    out["sg_rep"] = m.rep
+    for k, v in m.state_dict().items():
+        out["sg_sd1::" + k] = v.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "stagate.npz"), **out)
+    print("stagate.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -569,3 +623,4 @@ if __name__ == "__main__":
     make_scheteronet()
     make_scdsc_fit()
     make_sctag()
+    make_stagate()
