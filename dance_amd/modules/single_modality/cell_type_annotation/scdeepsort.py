@@ -119,6 +119,9 @@ class ScDeepSort(BaseClassificationMethod):
         gen = self.shuffle_generator
         perm = (torch.randperm(num_cells, device=self.device) if gen is None
                 else torch.randperm(num_cells, generator=gen).to(self.device)) + num_genes
+        from .... import sharding
+        if sharding.world_info()[1] > 1:  # data parallel: one train / validation split for all ranks
+            torch.distributed.broadcast(perm, src=0)
         num_val = int(num_cells * val_ratio)
         val_idx = perm[:num_val]
         train_idx = perm[num_val:]
@@ -135,6 +138,11 @@ class ScDeepSort(BaseClassificationMethod):
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
         self.loss_fn = nn.CrossEntropyLoss(reduction="sum")
 
+        # more than one process: data parallelism over the training cells (the graph is replicated, the model is small):
+        # every rank trains on its share, gradients are averaged with one flat all-reduce per step (dance_amd/sharding.py)
+        self._world = sharding.world_info()[1]
+        if self._world > 1:
+            sharding.broadcast_parameters(self.model)
         self._print(f"Train Number: {len(train_idx)}, Val Number: {len(val_idx)}")
         max_val_acc, _train_acc, _epoch = 0, 0, 0
         final_val_correct_num = final_val_unsure_num = 0
@@ -160,6 +168,9 @@ class ScDeepSort(BaseClassificationMethod):
     def cal_loss(self, graph, idx: torch.Tensor):
         self.model.train()
         losses, sizes = [], []
+        from .... import sharding
+        if getattr(self, "_world", 1) > 1:
+            idx = sharding.shard_seed_ids(idx)
         dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
                                 generator=self.shuffle_generator)
         for _, _, blocks in dataloader:
@@ -169,6 +180,7 @@ class ScDeepSort(BaseClassificationMethod):
             loss = self.loss_fn(output_predictions, output_labels)
             self.optimizer.zero_grad()
             loss.backward()
+            sharding.allreduce_gradients(self.model)
             self.optimizer.step()
             sizes.append(blocks[-1].num_dst_nodes())
             losses.append(loss.detach())  # read back once per epoch, not once per batch (scdeepsort.py:247-248)

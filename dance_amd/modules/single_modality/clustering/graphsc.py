@@ -210,6 +210,14 @@ class GraphSC(BaseClusteringMethod):
         g = g.to(self.device)
         g.ndata["order"] = g.ndata["label"] = g.ndata["feat_id"]
         train_ids = np.where(g.ndata["label"].cpu().numpy() != -1)[0]
+        # more than one process (torch.distributed initialised, one rank per GPU): plain data parallelism over the seed cells
+        # (BASELINE config 4) — every rank samples blocks for its share of the cells from the replicated graph, gradients are
+        # averaged with one flat all-reduce per step, embeddings are gathered at the end of an epoch
+        from .... import sharding
+        rank, world = sharding.world_info()
+        if world > 1:
+            sharding.broadcast_parameters(self.model)
+            train_ids = sharding.shard_seed_ids(torch.from_numpy(train_ids)).numpy()
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator)
@@ -238,12 +246,13 @@ class GraphSC(BaseClusteringMethod):
                 loss = norm * sparse_target_bce(adj_logits, eu, ev, em, pos_weight)
                 optim.zero_grad()
                 loss.backward()
+                sharding.allreduce_gradients(self.model)
                 optim.step()
                 losses.append(loss.detach())
             self.losses.extend(torch.stack(losses).tolist() if losses else [])
             if eval_epoch or epoch == epochs - 1:  # the embedding only leaves the device when somebody reads it
-                zc = torch.cat(z).cpu().numpy()
-                self.z = zc[np.argsort(torch.cat(order).cpu().numpy())]
+                zc, oc = sharding.gather_embeddings(torch.cat(z), torch.cat(order))  # one process: a sort by cell order
+                self.z = zc.cpu().numpy()
             if eval_epoch and y is not None:
                 aris.append(self.score(None, y))
                 Z[f"epoch{epoch}"] = self.z

@@ -16,6 +16,7 @@ from torch.nn.parameter import Parameter
 from .... import kernels
 from ....autograd import dense_adj_layer, gcn_layer
 from ....graph import CSRGraph, as_graph
+from ....sharding import ShardedGCNGraph, sharded_gcn_layer
 from ....transforms import CellPCA, Compose, SetConfig
 from ....transforms.graph import SpaGCNGraph, SpaGCNGraph2D
 from ...base import BaseClusteringMethod
@@ -44,6 +45,8 @@ class GraphConvolution(nn.Module):
             self.bias.data.uniform_(-stdv, stdv)
 
     def forward(self, input, adj):
+        if isinstance(adj, ShardedGCNGraph):  # destination-range shard of the graph (BASELINE config 5): input = this rank's rows
+            return sharded_gcn_layer(input, self.weight, adj, self.bias, False, ops=getattr(adj, "ops", None))
         if isinstance(adj, torch.Tensor) and adj.layout == torch.strided:
             return dense_adj_layer(input, self.weight, adj, self.bias)
         graph = adj if isinstance(adj, CSRGraph) else as_graph(adj, input.device)
@@ -117,19 +120,34 @@ class SimpleGCDEC(nn.Module):
         q = q / torch.sum(q, dim=1, keepdim=True)
         return x, q
 
+    # Sharded training (``adj`` is a ``ShardedGCNGraph``; one process per GPU): X, q, p are this rank's rows; the reductions
+    # over all spots below are completed with all-reduces, so the arithmetic is that of the single-process model.
+    _sg = None
+
+    def _allsum(self, t):
+        if self._sg is not None and self._sg.world > 1:
+            import torch.distributed as dist
+            t = t.clone()
+            dist.all_reduce(t, group=self._sg.group)
+        return t
+
     def loss_function(self, p, q):
 
         def kld(target, pred):
-            return torch.mean(torch.sum(target * torch.log(target / (pred + 1e-6)), dim=1))
+            per_spot = torch.sum(target * torch.log(target / (pred + 1e-6)), dim=1)
+            if self._sg is None:
+                return torch.mean(per_spot)
+            # mean over ALL spots: local sum / N (its gradient is the local part of the global mean's; mu's is all-reduced in fit)
+            return per_spot.sum() / self._sg.n_nodes
 
         return kld(p, q)
 
     def target_distribution(self, q):
-        p = q**2 / torch.sum(q, dim=0)
+        p = q**2 / self._allsum(torch.sum(q, dim=0))
         return p / torch.sum(p, dim=1, keepdim=True)
 
     def _adj(self, adj):
-        if isinstance(adj, CSRGraph):
+        if isinstance(adj, (CSRGraph, ShardedGCNGraph)):
             return adj
         if isinstance(adj, torch.Tensor) and adj.layout != torch.strided:
             return as_graph(adj, self.device)
@@ -141,6 +159,16 @@ class SimpleGCDEC(nn.Module):
         self.to(self.device)
         X = _to_device_f32(X, self.device)
         adj = self._adj(adj)
+        self._sg = adj if isinstance(adj, ShardedGCNGraph) else None
+        sharded = self._sg is not None and self._sg.world > 1
+        if self._sg is not None:
+            import torch.distributed as dist
+            lo, hi = self._sg.ranges[self._sg.rank]
+            if X.shape[0] == self._sg.n_nodes:
+                X = X[lo:hi].contiguous()  # the caller handed the whole matrix: keep this rank's rows
+            if sharded:
+                for t in self.gc.parameters():
+                    dist.broadcast(t.data, src=0, group=self._sg.group)
         if opt == "sgd":
             optimizer = optim.SGD(self.parameters(), lr=lr, momentum=0.9)
         elif opt == "admin":
@@ -149,26 +177,37 @@ class SimpleGCDEC(nn.Module):
             raise ValueError(f"Unknown optimizer {opt!r}")
         with torch.no_grad():
             features = self.gc(X, adj)
+        feats_all, x_all = features, X
+        if sharded:  # the initial clustering sees all spots: gather (N x nhid floats), cluster on rank 0, broadcast the labels
+            feats_all = self._sg.all_gather_rows(features)[:self._sg.n_nodes]
+            x_all = self._sg.all_gather_rows(X)[:self._sg.n_nodes]
         if init == "kmeans":
             from sklearn.cluster import KMeans
             self.n_clusters = n_clusters
             kmeans = KMeans(self.n_clusters, n_init=20)
-            y_pred = kmeans.fit_predict(features.cpu().numpy() if init_spa else X.cpu().numpy())
+            y_pred = kmeans.fit_predict(feats_all.cpu().numpy() if init_spa else x_all.cpu().numpy())
         elif init == "louvain":
             # spagcn.py:480-492: sc.pp.neighbors(n_neighbors) + sc.tl.leiden(resolution=res).  Neighbour graph on the
             # GPU (exact kNN + UMAP connectivities); the modularity optimisation itself is the Louvain scheme on the
             # host (scanpy / leidenalg are not installable — deviation documented in dance_amd/utils/community.py)
             from ....utils.community import leiden_like
             logger.info(f"Initializing cluster centers with louvain, resolution = {res}")
-            y_pred = leiden_like(features if init_spa else X, n_neighbors, resolution=res, device=self.device)
+            y_pred = leiden_like(feats_all if init_spa else x_all, n_neighbors, resolution=res, device=self.device)
             self.n_clusters = len(np.unique(y_pred))
         else:
             raise ValueError(f"Unknown init {init!r}")
+        if sharded:
+            yb = torch.from_numpy(np.asarray(y_pred, dtype=np.int64)).to(self.device)
+            dist.broadcast(yb, src=0, group=self._sg.group)
+            y_pred = yb.cpu().numpy()
+            self.n_clusters = int(yb.max()) + 1
+        yt_all = torch.from_numpy(np.asarray(y_pred)).to(self.device)
+        centers = torch.stack([feats_all[yt_all == c].mean(0) for c in range(self.n_clusters)])  # groupby("Group").mean()
+        if self._sg is not None:
+            y_pred = y_pred[lo:hi]  # from here on: this rank's spots
         y_pred_last = y_pred
         self.mu = Parameter(torch.empty(self.n_clusters, self.nhid, device=self.device))
         self.trajectory.append(y_pred)
-        yt = torch.from_numpy(y_pred).to(self.device)
-        centers = torch.stack([features[yt == c].mean(0) for c in range(self.n_clusters)])  # groupby("Group").mean()
         self.mu.data.copy_(centers)
         if opt == "sgd":  # mu was created after the optimizer in the reference too (:494), hence not optimised
             pass
@@ -181,11 +220,14 @@ class SimpleGCDEC(nn.Module):
             z, q = self(X, adj)
             loss = self.loss_function(p, q)
             loss.backward()
+            if sharded and self.mu.grad is not None:  # gc's gradients are all-reduced inside the sharded layer; mu's here
+                dist.all_reduce(self.mu.grad, group=self._sg.group)
             optimizer.step()
             if epoch % trajectory_interval == 0:
                 self.trajectory.append(torch.argmax(q, dim=1).data.cpu().numpy())
             y_pred = torch.argmax(q, dim=1).data.detach().cpu().numpy()
-            delta_label = np.sum(y_pred != y_pred_last).astype(np.float32) / X.shape[0]
+            changed = torch.tensor([float(np.sum(y_pred != y_pred_last))], device=self.device)
+            delta_label = np.float32(float(self._allsum(changed)) / (self._sg.n_nodes if self._sg is not None else X.shape[0]))
             y_pred_last = y_pred
             if epoch > 0 and (epoch - 1) % update_interval == 0 and delta_label < tol:
                 logger.info(f"delta_label {delta_label} < tol {tol}; total epoch: {epoch}")
@@ -193,7 +235,12 @@ class SimpleGCDEC(nn.Module):
 
     @torch.no_grad()
     def predict(self, X, adj):
-        return self(_to_device_f32(X, self.device), self._adj(adj))
+        X, adj = _to_device_f32(X, self.device), self._adj(adj)
+        if isinstance(adj, ShardedGCNGraph):  # this rank's rows in, ALL rows out (gathered), like the single-process call
+            lo, hi = adj.ranges[adj.rank]
+            z, q = self(X[lo:hi].contiguous() if X.shape[0] == adj.n_nodes else X, adj)
+            return adj.all_gather_rows(z)[:adj.n_nodes], adj.all_gather_rows(q)[:adj.n_nodes]
+        return self(X, adj)
 
 
 def refine(sample_id, pred, dis, shape="hexagon"):
@@ -252,6 +299,17 @@ class SpaGCN(BaseClusteringMethod):
 
     def calc_adj_exp(self, adj):
         """exp(-adj^2 / (2 l^2)) on the device; a ``CSRGraph`` of distances keeps its sparsity pattern."""
+        if isinstance(adj, ShardedGCNGraph):  # shards of the distance graph -> shards of the kernel graph (same structure, same halo plan)
+            import copy
+
+            from ....sharding import GraphShard
+            out = copy.copy(adj)
+            kern = lambda sh: GraphShard(sh.rowptr, sh.col, kernels.gaussian_kernel(sh.val, self.l)[0], sh.lo, sh.hi, sh.n_cols)
+            out.a, out.at = kern(adj.a), kern(adj.at)
+            if adj.full is not None:
+                out.full = (kern(adj.full[0]), kern(adj.full[1]))
+            out._local_graph = None
+            return out
         if isinstance(adj, CSRGraph):
             vals, _ = kernels.gaussian_kernel(adj.val, self.l)  # flat launch over the nnz values
             return CSRGraph(adj.rowptr, adj.col, vals, adj.n_rows, adj.n_cols, symmetric=adj.symmetric)

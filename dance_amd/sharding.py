@@ -509,3 +509,72 @@ def sharded_knn(X: torch.Tensor, k: int, group=None, ops=None):
     dist.all_gather_into_tensor(out_i, pad_i, group=group)
     dist.all_gather_into_tensor(out_d, pad_d, group=group)
     return out_i[:n].contiguous(), out_d[:n].contiguous()
+
+
+# ---- mini-batch data parallelism (scDeepSort / graph-sc, SURVEY.md §8e: "plain data parallel over seed-cell batches with
+#      gradient all-reduce of the (small) model") ---------------------------------------------------------------------------
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_seed_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
+    """This rank's share of the seed cells: contiguous slices of ceil(n / P) ids; short slices are padded by repeating the
+    slice's own ids so that every rank runs the same number of batches (the all-reduce of every step needs all of them).
+    Padded duplicates only re-visit cells the rank already owns; ``gather_embeddings`` drops them again."""
+    rank, world = world_info(group)
+    if world == 1:
+        return ids
+    n = ids.numel()
+    per = -(-n // world)
+    mine = ids[rank * per:min(n, (rank + 1) * per)]
+    if mine.numel() == 0:
+        mine = ids[:1]
+    if mine.numel() < per:
+        reps = -(-per // mine.numel())
+        mine = mine.repeat(reps)[:per]
+    return mine.contiguous()
+
+
+def broadcast_parameters(module: torch.nn.Module, group=None, src: int = 0):
+    """Same initial weights (and buffers) everywhere before data-parallel training."""
+    _, world = world_info(group)
+    if world == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src=src, group=group)
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None):
+    """Average the gradients over the ranks with ONE all-reduce of a flat bucket (the models on this path have a few hundred
+    thousand parameters: one latency-bound collective per step instead of one per tensor)."""
+    _, world = world_info(group)
+    if world == 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= world
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].reshape(g.shape))
+        off += g.numel()
+
+
+def gather_embeddings(z: torch.Tensor, order: torch.Tensor, group=None):
+    """All ranks' (embedding rows, cell order ids) -> one copy per cell on every rank (padded duplicates dropped, rows sorted
+    by order id).  Every rank contributes the same number of rows (``shard_seed_ids`` pads)."""
+    _, world = world_info(group)
+    if world > 1:
+        zs = torch.empty((world * z.shape[0], z.shape[1]), dtype=z.dtype, device=z.device)
+        os_ = torch.empty(world * order.shape[0], dtype=order.dtype, device=order.device)
+        dist.all_gather_into_tensor(zs, z.contiguous(), group=group)
+        dist.all_gather_into_tensor(os_, order.contiguous(), group=group)
+        z, order = zs, os_
+    order_sorted, idx = torch.sort(order, stable=True)
+    first = torch.ones_like(order_sorted, dtype=torch.bool)
+    first[1:] = order_sorted[1:] != order_sorted[:-1]
+    return z[idx[first]], order_sorted[first]

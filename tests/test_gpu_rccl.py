@@ -98,3 +98,31 @@ def test_collectives_and_sharded_layer_world1(nccl_world1):
     assert torch.equal(i1, i0) and torch.equal(d1, d0)
     dist.barrier()
     torch.cuda.synchronize()
+
+
+def test_spagcn_sharded_equals_single_process_world1(nccl_world1):
+    """BASELINE config 5 plumbing: SpaGCN trained through the destination-range sharded layer (every all-reduce / gather /
+    broadcast of the sharded fit issued on a world-size-1 RCCL group) reproduces the plain single-GPU fit."""
+    from dance_amd import kernels, sharding
+    from dance_amd.graph import CSRGraph
+    from dance_amd.modules.spatial.spatial_domain.spagcn import SpaGCN
+    dev = nccl_world1
+    rng = np.random.default_rng(0)
+    side = 30
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    xy = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    n = xy.shape[0]
+    dom = (xy[:, 0] >= side / 2).astype(int)
+    embed = (np.eye(2)[dom] @ rng.standard_normal((2, 12)) * 2 + rng.standard_normal((n, 12))).astype(np.float32)
+    idx, dist_ = kernels.knn(torch.from_numpy(xy).to(dev), 25)
+    order = torch.argsort(idx, dim=1)
+    rowptr = torch.arange(0, n * 25 + 1, 25, dtype=torch.int32, device=dev)
+    g = CSRGraph(rowptr, torch.gather(idx, 1, order).reshape(-1).contiguous(), torch.gather(dist_, 1, order).reshape(-1).contiguous(), n, n)
+    outs = []
+    for adj in (g, sharding.ShardedGCNGraph.from_global_csr(g, mode="halo")):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = SpaGCN(l=1.5, device="cuda")
+        m.fit((embed, adj), init="kmeans", n_clusters=2, epochs=15, lr=0.01, tol=0.0)
+        outs.append((m.predict_proba((embed, adj)).cpu().numpy(), m.model.gc.weight.detach().cpu().numpy()))
+    assert rel_err(outs[1][0], outs[0][0]) < 1e-4 and rel_err(outs[1][1], outs[0][1]) < 1e-4
