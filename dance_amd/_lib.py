@@ -54,6 +54,7 @@ def _declare(lib):
         "dh_csr_row_normalize_f32": (c_int, [i64, P, P, P, P]),
         "dh_cellgene_graph_assemble": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, P, P, P, P]),
         "dh_sddmm_csr_f32": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, P]),
+        "dh_sddmm_csr_bf16": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, P]),
         "dh_spmm_csr_bf16": (c_int, [i64, i64, i64, P, P, P, P, P, P, i64, P, i64, i32, P, i32, i32, P]),
         "dh_sage_aggregate_bf16": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, P, i64, P, i64, i32, P]),
         "dh_gemm_bf16_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
@@ -67,6 +68,8 @@ def _declare(lib):
         "dh_sage_tail": (c_int, [i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P]),
         "dh_softplus_rowsum_f32": (c_int, [i64, i64, P, i64, P, P]),
         "dh_sigmoid_scale_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
+        "dh_spatial_gaussian_knn_workspace_bytes": (c_size_t, [i64, i64, i32]),
+        "dh_spatial_gaussian_knn": (c_int, [i64, i64, P, i64, i32, c_double, P, P, P, P, c_size_t, P]),
         "dh_edge_softmax_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P]),
         "dh_edge_softmax_backward_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P, P, P, P]),
         "dh_csr_two_hop_count": (c_int, [i64, P, P, P, P, P]),

@@ -20,11 +20,24 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// four consecutive features as fp32: one 16-byte load (f32 storage) or one 8-byte load widened exactly (bf16 storage)
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<uint16_t>(const uint16_t* p) {
+  const uint2 w = *reinterpret_cast<const uint2*>(p);
+  f32x4 r;
+  r[0] = __uint_as_float(w.x << 16);
+  r[1] = __uint_as_float(w.x & 0xffff0000u);
+  r[2] = __uint_as_float(w.y << 16);
+  r[3] = __uint_as_float(w.y & 0xffff0000u);
+  return r;
+}
+
 // G lanes per row; each lane covers columns [4 g + 4 G a, +4) for a = 0 .. NACC-1 (width <= 4 G NACC, width % 4 == 0)
-template <int G, int NACC>
+template <int G, int NACC, typename T>
 __global__ __launch_bounds__(256) void sddmm_csr_kernel(int64_t n_rows, int64_t width, const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, const float* __restrict__ scale,
-                                                        const float* __restrict__ U, int64_t ldu, const float* __restrict__ V,
+                                                        const T* __restrict__ U, int64_t ldu, const T* __restrict__ V,
                                                         int64_t ldv, float* __restrict__ out) {
   const int g = threadIdx.x % G;
   const int64_t row = (int64_t)blockIdx.x * (256 / G) + threadIdx.x / G;
@@ -35,7 +48,7 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(int64_t n_rows, int64_t 
   for (int a = 0; a < NACC; ++a) {
     const int64_t c = 4 * g + 4 * G * a;
     live[a] = c < width;
-    u[a] = live[a] ? *reinterpret_cast<const f32x4*>(U + row * ldu + c) : f32x4(0.f);
+    u[a] = live[a] ? load4<T>(U + row * ldu + c) : f32x4(0.f);
   }
   const int s = rowptr[row], t = rowptr[row + 1];
   for (int e0 = s; e0 < t; e0 += 4) {
@@ -44,11 +57,11 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(int64_t n_rows, int64_t 
     for (int k = 0; k < 4; ++k) {
       part[k] = 0.f;
       if (e0 + k < t) {
-        const float* v = V + (int64_t)col[e0 + k] * ldv + 4 * g;
+        const T* v = V + (int64_t)col[e0 + k] * ldv + 4 * g;
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
           if (!live[a]) continue;
-          const f32x4 x = *reinterpret_cast<const f32x4*>(v + 4 * G * a);
+          const f32x4 x = load4<T>(v + 4 * G * a);
 #pragma unroll
           for (int i = 0; i < 4; ++i) part[k] = fmaf(u[a][i], x[i], part[k]);
         }
@@ -62,22 +75,21 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(int64_t n_rows, int64_t 
   }
 }
 
-}  // namespace
-
-extern "C" int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col,
-                                const float* scale, const float* U, int64_t ldu, const float* V, int64_t ldv, float* out,
-                                dh_stream_t stream) {
-  if (n_rows < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: negative size");
+template <typename T>
+int sddmm_launch(const char* me, int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col, const float* scale,
+                 const T* U, int64_t ldu, const T* V, int64_t ldv, float* out, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "%s: negative size", me);
   if (n_rows == 0) return DH_OK;
-  if (!rowptr || !col || !U || !V || !out) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: null pointer");
-  if (width % 4 != 0 || ldu % 4 != 0 || ldv % 4 != 0 || !dh::aligned16(U) || !dh::aligned16(V))
-    return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: rows must be multiples of 4 floats and 16-byte aligned (pad the width)");
-  if (ldu < width || ldv < width) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: leading dimension < width");
-  if (width > 4 * 64 * 8) return dh::fail(DH_ERR_INVALID, "dh_sddmm_csr_f32: width %lld > 2048", (long long)width);
+  if (!rowptr || !col || !U || !V || !out) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  const uintptr_t align = 4 * sizeof(T);
+  if (width % 4 != 0 || ldu % 4 != 0 || ldv % 4 != 0 || (uintptr_t)U % align || (uintptr_t)V % align)
+    return dh::fail(DH_ERR_INVALID, "%s: rows must be multiples of 4 features and %d-byte aligned (pad the width)", me, (int)align);
+  if (ldu < width || ldv < width) return dh::fail(DH_ERR_INVALID, "%s: leading dimension < width", me);
+  if (width > 4 * 64 * 8) return dh::fail(DH_ERR_INVALID, "%s: width %lld > 2048", me, (long long)width);
   hipStream_t st = dh::as_stream(stream);
   const int64_t vecs = width / 4;
-#define DH_SDDMM(G, NACC)                                                                                              \
-  hipLaunchKernelGGL((sddmm_csr_kernel<G, NACC>), dim3((unsigned)dh::ceil_div(n_rows, 256 / G)), dim3(256), 0, st, n_rows, \
+#define DH_SDDMM(G, NACC)                                                                                                 \
+  hipLaunchKernelGGL((sddmm_csr_kernel<G, NACC, T>), dim3((unsigned)dh::ceil_div(n_rows, 256 / G)), dim3(256), 0, st, n_rows, \
                      width, rowptr, col, scale, U, ldu, V, ldv, out)
   if (vecs > 256) DH_SDDMM(64, 8);
   else if (vecs > 128) DH_SDDMM(64, 4);
@@ -87,5 +99,20 @@ extern "C" int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width, c
   else if (vecs > 8) DH_SDDMM(16, 1);
   else DH_SDDMM(8, 1);
 #undef DH_SDDMM
-  return dh::check_launch("dh_sddmm_csr_f32");
+  return dh::check_launch(me);
+}
+
+}  // namespace
+
+extern "C" int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col,
+                                const float* scale, const float* U, int64_t ldu, const float* V, int64_t ldv, float* out,
+                                dh_stream_t stream) {
+  return sddmm_launch<float>("dh_sddmm_csr_f32", n_rows, n_cols, width, rowptr, col, scale, U, ldu, V, ldv, out, stream);
+}
+
+// bf16-stored operands (config C3), fp32 products and sums, fp32 result
+extern "C" int dh_sddmm_csr_bf16(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col,
+                                 const float* scale, const uint16_t* U, int64_t ldu, const uint16_t* V, int64_t ldv, float* out,
+                                 dh_stream_t stream) {
+  return sddmm_launch<uint16_t>("dh_sddmm_csr_bf16", n_rows, n_cols, width, rowptr, col, scale, U, ldu, V, ldv, out, stream);
 }

@@ -122,9 +122,11 @@ def sddmm_csr(rowptr: torch.Tensor, col: torch.Tensor, U: torch.Tensor, V: torch
     out = torch.empty(col.numel(), dtype=torch.float32, device=U.device)
     if col.numel() == 0:
         return out
-    _call("sddmm_csr_f32", lib.dh_sddmm_csr_f32, n_rows, V.shape[0], U.shape[1], _dev(rowptr, torch.int32, "rowptr", 1),
-          _dev(col, torch.int32, "col", 1), _dev(scale, torch.float32, "scale", 1), _dev(U, torch.float32, "U", 2), _ld(U),
-          _dev(V, torch.float32, "V", 2), _ld(V), out.data_ptr(), _stream())
+    bf16 = U.dtype == torch.bfloat16
+    fn, dt = (lib.dh_sddmm_csr_bf16, torch.bfloat16) if bf16 else (lib.dh_sddmm_csr_f32, torch.float32)
+    _call("sddmm_csr_bf16" if bf16 else "sddmm_csr_f32", fn, n_rows, V.shape[0], U.shape[1], _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(scale, torch.float32, "scale", 1), _dev(U, dt, "U", 2), _ld(U),
+          _dev(V, dt, "V", 2), _ld(V), out.data_ptr(), _stream())
     return out
 
 
@@ -465,6 +467,22 @@ def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     _call("csr_row_normalize_f32", lib.dh_csr_row_normalize_f32, rowptr.numel() - 1,
           _dev(rowptr, torch.int32, "rowptr", 1), _dev(val, torch.float32, "val", 1), out.data_ptr(), _stream())
     return out
+
+
+def spatial_gaussian_knn(X: torch.Tensor, k: int, l: float = 0.0):
+    """dh_spatial_gaussian_knn: CSR (rowptr, col, val) of every spot's k nearest spots (self included), columns ascending;
+    val = exp(-d^2 / (2 l^2)) for l > 0, the distance d for l <= 0."""
+    lib = _lib_ready()
+    n, d = X.shape
+    dev = X.device
+    rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(n * k, dtype=torch.int32, device=dev)
+    val = torch.empty(n * k, dtype=torch.float32, device=dev)
+    ws_bytes = lib.dh_spatial_gaussian_knn_workspace_bytes(n, d, k)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    _call("spatial_gaussian_knn", lib.dh_spatial_gaussian_knn, n, d, _dev(X, torch.float32, "X", 2), _ld(X), k, float(l), rowptr.data_ptr(),
+          col.data_ptr(), val.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+    return rowptr, col, val
 
 
 ATT_SIGMOID, ATT_LEAKY_RELU = 0, 1

@@ -37,19 +37,26 @@ class _SageAggregateFn(torch.autograd.Function):
         n_genes = alpha.numel() - 2
         dalpha = dh = None
         bf16 = h.dtype == torch.bfloat16
-        if ctx.needs_input_grad[1]:  # per-edge dot products in fp32 (bf16 features are widened for this pass)
-            dalpha = kernels.sage_alpha_grad(blk.rowptr, blk.col, blk.val, cid_src, cid_dst, n_genes,
-                                             h.float().contiguous(), dneigh.float()).reshape(alpha.shape)
+        deg = (blk.rowptr[1:] - blk.rowptr[:-1]).to(torch.float32).clamp(min=1)
+        rows = torch.repeat_interleave(torch.arange(blk.number_of_dst_nodes(), device=h.device),
+                                       (blk.rowptr[1:] - blk.rowptr[:-1]).to(torch.int64), output_size=blk.col.numel())
+        sid, did = cid_src[blk.col.to(torch.int64)], cid_dst[rows]
+        idx = torch.full_like(sid, n_genes + 1, dtype=torch.int64)
+        idx = torch.where((sid >= 0) & (did < 0), sid.to(torch.int64), idx)
+        idx = torch.where((did >= 0) & (sid < 0), did.to(torch.int64), idx)
+        idx = torch.where((did >= 0) & (sid >= 0), torch.full_like(idx, n_genes), idx)
+        if ctx.needs_input_grad[1]:
+            # dalpha[idx(e)] += w_e <H[src(e)], dneigh[dst(e)]> / deg(dst(e)): the per-edge dot products are an SDDMM
+            # (dh_sddmm_csr_f32, fp32, fixed order); the (G + 2)-bin reduction runs in float64, where the order in which the
+            # scatter-add visits the edges no longer reaches the fp32 result (dh_sage_alpha_grad_f32's fp32 atomics did)
+            hf, df = h.float(), dneigh.float()
+            if hf.shape[1] % 4:
+                pad = 4 - hf.shape[1] % 4
+                hf, df = torch.nn.functional.pad(hf, (0, pad)), torch.nn.functional.pad(df, (0, pad))
+            c = kernels.sddmm_csr(blk.rowptr, blk.col, df.contiguous(), hf.contiguous(), scale=(blk.val / deg[rows]).contiguous())
+            dalpha = torch.zeros(n_genes + 2, dtype=torch.float64, device=h.device).index_add_(0, idx, c.double()).float().reshape(alpha.shape)
         if ctx.needs_input_grad[0]:
             # dh[u] = sum_{e=(u->v)} alpha[idx(e)] w_e / deg(v) * dneigh[v]: gather over the transposed block
-            deg = (blk.rowptr[1:] - blk.rowptr[:-1]).to(torch.float32).clamp(min=1)
-            rows = torch.repeat_interleave(torch.arange(blk.number_of_dst_nodes(), device=h.device),
-                                           (blk.rowptr[1:] - blk.rowptr[:-1]).to(torch.int64))
-            sid, did = cid_src[blk.col.to(torch.int64)], cid_dst[rows]
-            idx = torch.full_like(sid, n_genes + 1, dtype=torch.int64)
-            idx = torch.where((sid >= 0) & (did < 0), sid.to(torch.int64), idx)
-            idx = torch.where((did >= 0) & (sid < 0), did.to(torch.int64), idx)
-            idx = torch.where((did >= 0) & (sid >= 0), torch.full_like(idx, n_genes), idx)
             ew = (alpha.reshape(-1)[idx] * blk.val / deg[rows]).contiguous()
             rp_t, col_t, val_t, _ = kernels.csr_transpose(blk.rowptr, blk.col, ew, blk.number_of_dst_nodes(),
                                                           blk.number_of_src_nodes())

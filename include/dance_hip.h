@@ -230,6 +230,15 @@ DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t 
                                const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
                                float* out_val, int32_t* out_eid, dh_stream_t stream);
 
+/* ---- kNN-truncated Gaussian spatial adjacency (SpaGCN at scale; spagcn.py:249-251,807-809 evaluate the DENSE kernel) ----
+ * Rows = spots; each row keeps the spot's k nearest spots (exact, self included) with value exp(-d^2 / (2 l^2)) in the
+ * reference's fp32 expression, columns ascending; l <= 0 writes the distances d instead.  out_rowptr [n+1],
+ * out_col / out_val [n*k]; k <= min(n, 64).                                                                        */
+DH_API size_t dh_spatial_gaussian_knn_workspace_bytes(int64_t n, int64_t d, int k);
+DH_API int dh_spatial_gaussian_knn(int64_t n, int64_t d, const float* X, int64_t ldx, int k, double l,
+                            int32_t* out_rowptr, int32_t* out_col, float* out_val,
+                            void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
 /* ---- edge softmax of graph attention (stagate.py:31-128 GATConv.message; scgnn2.py:1091-1118) --------------------
  * att[e] = softmax over the in-edges e = (j -> i) of row i of act(a_src[j] + a_dst[i]); act 0 = sigmoid (STAGATE),
  * 1 = leaky_relu(negative_slope) (GAT); denominator + 1e-16 as torch_geometric.utils.softmax.  a_dst may be NULL.
@@ -351,6 +360,11 @@ DH_API int dh_sddmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
                      const int32_t* rowptr, const int32_t* col, const float* scale,
                      const float* U, int64_t ldu, const float* V, int64_t ldv,
                      float* out, dh_stream_t stream);
+/* the same with bf16-stored U / V (fp32 products, sums and result) */
+DH_API int dh_sddmm_csr_bf16(int64_t n_rows, int64_t n_cols, int64_t width,
+                      const int32_t* rowptr, const int32_t* col, const float* scale,
+                      const uint16_t* U, int64_t ldu, const uint16_t* V, int64_t ldv,
+                      float* out, dh_stream_t stream);
 
 /* ---- bf16 storage path (scDeepSort at 1M cells, "bf16 with MFMA dense update") --------
  * Features, activations and their gradients are STORED as bf16 (uint16_t bit patterns, torch.bfloat16); every sum is

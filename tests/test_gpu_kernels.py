@@ -271,3 +271,27 @@ def test_degenerate_sizes(cuda_device):
     # reductions / elementwise on empty matrices
     assert torch.equal(kernels.colsum(torch.empty(0, 5, device=dev)), torch.zeros(5, device=dev))
     assert kernels.relu_backward(torch.empty(0, 5, device=dev), torch.empty(0, 5, device=dev)).shape == (0, 5)
+
+
+def test_sddmm_bf16_and_spatial_gaussian_knn(cuda_device):
+    from dance_amd import kernels
+    from oracle import graphs as og
+    rng = np.random.default_rng(5)
+    a = _rand_csr(400, 300, 9, seed=2)
+    rp, c, v = _dev_csr(a, cuda_device)
+    u = torch.randn(400, 72, device=cuda_device).to(torch.bfloat16)
+    w = torch.randn(300, 72, device=cuda_device).to(torch.bfloat16)
+    got = kernels.sddmm_csr(rp, c, u, w, scale=v)
+    rows = np.repeat(np.arange(400), np.diff(a.indptr))
+    ref = (u.double().cpu().numpy()[rows] * w.double().cpu().numpy()[a.indices]).sum(1) * a.data
+    assert rel_err(got.cpu().numpy(), ref) < 1e-5            # bf16 inputs, fp32 products and sums
+    # kNN-truncated Gaussian adjacency == kNN (oracle) + the reference's kernel expression, rows sorted by column
+    xy = (rng.random((1500, 2)) * 30).astype(np.float32)
+    for l in (0.0, 1.7):
+        rowptr, col, val = kernels.spatial_gaussian_knn(torch.from_numpy(xy).to(cuda_device), 12, l)
+        idx, dist = og.knn_exact(xy, 12)
+        order = np.argsort(idx, axis=1)
+        ref_col, ref_d = np.take_along_axis(idx, order, 1), np.take_along_axis(dist, order, 1)
+        assert np.array_equal(rowptr.cpu().numpy(), np.arange(0, 1500 * 12 + 1, 12)) and np.array_equal(col.cpu().numpy().reshape(1500, 12), ref_col)
+        want = ref_d if l <= 0 else np.exp(-(ref_d * ref_d) / np.float32(2 * l * l))
+        assert rel_err(val.cpu().numpy().reshape(1500, 12), want) < 1e-6
