@@ -68,6 +68,11 @@ def _declare(lib):
         "dh_sage_tail": (c_int, [i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P]),
         "dh_softplus_rowsum_f32": (c_int, [i64, i64, P, i64, P, P]),
         "dh_sigmoid_scale_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
+        "dh_rowsum_masked_f32": (c_int, [i64, i64, P, i64, P, P, P]),
+        "dh_rowscale_log1p_f32": (c_int, [i64, i64, P, i64, P, i32, c_double, P, i64, P]),
+        "dh_col_standardize_f32": (c_int, [i64, i64, P, i64, P, P, c_double, P, i64, P]),
+        "dh_col_moments_f32": (c_int, [i64, i64, P, i64, i64, P, P]),
+        "dh_col_any_gt_f32": (c_int, [i64, i64, P, i64, P, P, P]),
         "dh_spatial_gaussian_knn_workspace_bytes": (c_size_t, [i64, i64, i32]),
         "dh_spatial_gaussian_knn": (c_int, [i64, i64, P, i64, i32, c_double, P, P, P, P, c_size_t, P]),
         "dh_edge_softmax_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P]),

@@ -252,3 +252,142 @@ extern "C" int dh_sigmoid_scale_f32(int64_t n_rows, int64_t n_cols, const float*
   hipLaunchKernelGGL(sigmoid_scale_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx, scale, out, ldo);
   return dh::check_launch("dh_sigmoid_scale_f32");
 }
+
+// Count-matrix normalisation feeding the graph builders: the arithmetic of scanpy's normalize_total /
+// log1p / scale, which the reference pipelines call through AnnDataTransform (scdsc.py:113-131, sctag.py:119-139,
+// dance/transforms/normalize.py:531-679), as streaming kernels over the dense cell x gene matrix.
+//   dh_rowsum_masked_f32     : out[r] = sum_c X[r,c] over the columns with colmask[c] != 0 (NULL: all) — counts per cell,
+//                              optionally without the "highly expressed" genes; f64 accumulation, one wavefront per row
+//   dh_rowscale_log1p_f32    : out[r,c] = g(X[r,c] / divisor[r]), g = identity or log1p(.) / ln(base)  (a true division, as numpy's)
+//   dh_col_standardize_f32   : out[r,c] = clip((X[r,c] - mean[c]) / std[c], +-max_value)  (f64 statistics; max_value <= 0: no clipping)
+//   dh_col_moments_f32       : per-row-block f64 column sums of X and of fl32(X^2) (mean / variance of every gene)
+//   dh_col_any_gt_f32        : flag[c] = any_r X[r,c] > thresh[r]   (the "highly expressed in some cell" test)
+namespace {
+__global__ __launch_bounds__(256) void rowsum_masked_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                            const uint8_t* __restrict__ colmask, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* x = X + row * ldx;
+  double acc = 0.0;
+  for (int64_t c = lane; c < n_cols; c += 64)
+    if (!colmask || colmask[c]) acc += (double)x[c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) out[row] = (float)acc;
+}
+
+__global__ __launch_bounds__(256) void rowscale_log1p_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ factor, int do_log1p, float inv_log_base,
+                                                             float* __restrict__ out, int64_t ldo) {
+  const int64_t total = n_rows * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / n_cols, c = i - r * n_cols;
+    float v = X[r * ldx + c];
+    if (factor) v = v / factor[r];
+    if (do_log1p) v = log1pf(v) * inv_log_base;
+    out[r * ldo + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void col_standardize_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                              const double* __restrict__ mean, const double* __restrict__ std, float max_value,
+                                                              float* __restrict__ out, int64_t ldo) {
+  const int64_t total = n_rows * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / n_cols, c = i - r * n_cols;
+    float v = X[r * ldx + c];
+    if (mean) v = (float)((double)v - mean[c]);  // numpy's in-place "X -= mean" with a float64 mean: f64 arithmetic, f32 store
+    v = (float)((double)v / std[c]);
+    if (max_value > 0.f) {
+      v = fminf(v, max_value);
+      if (mean) v = fmaxf(v, -max_value);
+    }
+    out[r * ldo + c] = v;
+  }
+}
+
+// partial[b][0][c] = sum over the block's rows of X[r,c], partial[b][1][c] = sum of fl32(X[r,c]^2), both in f64
+// (numpy's mean(X, dtype=f64) and mean(multiply(X, X), dtype=f64)); the caller adds the blocks in order.
+__global__ __launch_bounds__(256) void col_moments_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                          int64_t rows_per_block, double* __restrict__ partial) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= n_cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n_rows ? r0 + rows_per_block : n_rows;
+  double s = 0.0, q = 0.0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float x = X[r * ldx + c];
+    s += (double)x;
+    q += (double)(x * x);
+  }
+  partial[((int64_t)blockIdx.y * 2 + 0) * n_cols + c] = s;
+  partial[((int64_t)blockIdx.y * 2 + 1) * n_cols + c] = q;
+}
+
+// flag[c] = 1 if X[r,c] > thresh[r] for any row r (flag zero-initialised by the launcher; all writers store the same value)
+__global__ __launch_bounds__(256) void col_any_gt_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ thresh, uint8_t* __restrict__ flag) {
+  const int64_t total = n_rows * n_cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / n_cols, c = i - r * n_cols;
+    if (X[r * ldx + c] > thresh[r]) flag[c] = 1;
+  }
+}
+unsigned flat_grid(int64_t work) { return (unsigned)(dh::ceil_div(work, 256) < 65536 ? dh::ceil_div(work, 256) : 65536); }
+}  // namespace
+
+extern "C" int dh_rowsum_masked_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const uint8_t* colmask, float* out,
+                                    dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_rowsum_masked_f32: negative size");
+  if (n_rows == 0) return DH_OK;
+  if (!out || (n_cols > 0 && (!X || ldx < n_cols))) return dh::fail(DH_ERR_INVALID, "dh_rowsum_masked_f32: bad pointer / leading dimension");
+  hipLaunchKernelGGL(rowsum_masked_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx, colmask, out);
+  return dh::check_launch("dh_rowsum_masked_f32");
+}
+
+extern "C" int dh_rowscale_log1p_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* factor, int do_log1p,
+                                     double log_base, float* out, int64_t ldo, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_rowscale_log1p_f32: negative size");
+  if (n_rows == 0 || n_cols == 0) return DH_OK;
+  if (!X || !out || ldx < n_cols || ldo < n_cols) return dh::fail(DH_ERR_INVALID, "dh_rowscale_log1p_f32: bad pointer / leading dimension");
+  const float inv = (do_log1p && log_base > 0) ? (float)(1.0 / log(log_base)) : 1.f;
+  hipLaunchKernelGGL(rowscale_log1p_kernel, dim3(flat_grid(n_rows * n_cols)), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx, factor,
+                     do_log1p, inv, out, ldo);
+  return dh::check_launch("dh_rowscale_log1p_f32");
+}
+
+extern "C" int dh_col_standardize_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const double* mean, const double* std,
+                                      double max_value, float* out, int64_t ldo, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_col_standardize_f32: negative size");
+  if (n_rows == 0 || n_cols == 0) return DH_OK;
+  if (!X || !out || !std || ldx < n_cols || ldo < n_cols) return dh::fail(DH_ERR_INVALID, "dh_col_standardize_f32: bad pointer / leading dimension");
+  hipLaunchKernelGGL(col_standardize_kernel, dim3(flat_grid(n_rows * n_cols)), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx, mean, std,
+                     (float)max_value, out, ldo);
+  return dh::check_launch("dh_col_standardize_f32");
+}
+
+extern "C" int dh_col_moments_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, int64_t rows_per_block, double* partial,
+                                  dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0 || rows_per_block <= 0) return dh::fail(DH_ERR_INVALID, "dh_col_moments_f32: bad size");
+  if (n_rows == 0 || n_cols == 0) return DH_OK;
+  if (!X || !partial || ldx < n_cols) return dh::fail(DH_ERR_INVALID, "dh_col_moments_f32: bad pointer / leading dimension");
+  const int64_t nb = dh::ceil_div(n_rows, rows_per_block);
+  if (nb > 65535) return dh::fail(DH_ERR_INVALID, "dh_col_moments_f32: more than 65535 row blocks (raise rows_per_block)");
+  hipLaunchKernelGGL(col_moments_kernel, dim3((unsigned)dh::ceil_div(n_cols, 256), (unsigned)nb), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx,
+                     rows_per_block, partial);
+  return dh::check_launch("dh_col_moments_f32");
+}
+
+extern "C" int dh_col_any_gt_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* thresh, uint8_t* flag,
+                                 dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_col_any_gt_f32: negative size");
+  if (n_cols == 0) return DH_OK;
+  if (!flag) return dh::fail(DH_ERR_INVALID, "dh_col_any_gt_f32: null flag");
+  hipStream_t st = dh::as_stream(stream);
+  if (hipMemsetAsync(flag, 0, (size_t)n_cols, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_col_any_gt_f32: memset failed");
+  if (n_rows == 0) return DH_OK;
+  if (!X || !thresh || ldx < n_cols) return dh::fail(DH_ERR_INVALID, "dh_col_any_gt_f32: bad pointer / leading dimension");
+  hipLaunchKernelGGL(col_any_gt_kernel, dim3(flat_grid(n_rows * n_cols)), dim3(256), 0, st, n_rows, n_cols, X, ldx, thresh, flag);
+  return dh::check_launch("dh_col_any_gt_f32");
+}

@@ -469,6 +469,51 @@ def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rowsum_masked(X: torch.Tensor, colmask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib_ready()
+    out = torch.empty(X.shape[0], dtype=torch.float32, device=X.device)
+    _call("rowsum_masked_f32", lib.dh_rowsum_masked_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          _dev(colmask, torch.uint8, "colmask", 1), out.data_ptr(), _stream())
+    return out
+
+
+def rowscale_log1p(X: torch.Tensor, divisor: Optional[torch.Tensor], *, log1p: bool, base: Optional[float] = None, inplace: bool = False) -> torch.Tensor:
+    lib = _lib_ready()
+    out = X if inplace else torch.empty_like(X)
+    _call("rowscale_log1p_f32", lib.dh_rowscale_log1p_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          _dev(divisor, torch.float32, "divisor", 1), int(log1p), float(base or 0.0), out.data_ptr(), _ld(out), _stream())
+    return out
+
+
+def col_standardize(X: torch.Tensor, mean: Optional[torch.Tensor], std: torch.Tensor, max_value: Optional[float] = None, inplace: bool = False):
+    """(X - mean) / std per column with float64 statistics (numpy's in-place arithmetic), clipped to +-max_value."""
+    lib = _lib_ready()
+    out = X if inplace else torch.empty_like(X)
+    _call("col_standardize_f32", lib.dh_col_standardize_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          _dev(mean, torch.float64, "mean", 1), _dev(std, torch.float64, "std", 1), float(max_value or 0.0), out.data_ptr(), _ld(out), _stream())
+    return out
+
+
+def col_moments(X: torch.Tensor, rows_per_block: int = 512):
+    """float64 column sums of X and of fl32(X * X): (sum [n_cols], sumsq [n_cols])."""
+    lib = _lib_ready()
+    n, f = X.shape
+    rows_per_block = max(int(rows_per_block), -(-n // 65535))
+    nb = max(-(-n // rows_per_block), 1)
+    partial = torch.zeros(nb, 2, f, dtype=torch.float64, device=X.device)
+    _call("col_moments_f32", lib.dh_col_moments_f32, n, f, _dev(X, torch.float32, "X", 2), _ld(X), rows_per_block, partial.data_ptr(), _stream())
+    tot = partial.sum(0)
+    return tot[0], tot[1]
+
+
+def col_any_gt(X: torch.Tensor, thresh: torch.Tensor) -> torch.Tensor:
+    lib = _lib_ready()
+    flag = torch.empty(X.shape[1], dtype=torch.uint8, device=X.device)
+    _call("col_any_gt_f32", lib.dh_col_any_gt_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          _dev(thresh, torch.float32, "thresh", 1), flag.data_ptr(), _stream())
+    return flag
+
+
 def spatial_gaussian_knn(X: torch.Tensor, k: int, l: float = 0.0):
     """dh_spatial_gaussian_knn: CSR (rowptr, col, val) of every spot's k nearest spots (self included), columns ascending;
     val = exp(-d^2 / (2 l^2)) for l > 0, the distance d for l <= 0."""

@@ -230,6 +230,27 @@ DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t 
                                const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
                                float* out_val, int32_t* out_eid, dh_stream_t stream);
 
+/* ---- count-matrix normalisation feeding the graph builders (scanpy normalize_total / log1p / scale as the reference
+ * pipelines call them: scdsc.py:113-131, sctag.py:119-139, transforms/normalize.py:531-679) --------------------------
+ * dh_rowsum_masked_f32: out[r] = sum of X[r,c] over columns with colmask[c] != 0 (NULL = all), f64 accumulation;
+ * dh_rowscale_log1p_f32: out = X / divisor[r] (divisor NULL = 1), then log1p(.) / ln(log_base) if do_log1p (log_base <= 0: natural);
+ * dh_col_standardize_f32: out = (X - mean[c]) / std[c] with f64 statistics and f32 stores after each step (numpy's in-place
+ *   arithmetic), clipped to [-max_value, max_value] (mean NULL: no centring and only the upper clip; max_value <= 0: none);
+ * dh_col_moments_f32: partial[b][0][c] / partial[b][1][c] = f64 sums of X[r,c] / fl32(X[r,c]^2) over row block b
+ *   (b < ceil(n_rows / rows_per_block) <= 65535), the caller adds the blocks;
+ * dh_col_any_gt_f32: flag[c] = 1 iff X[r,c] > thresh[r] for some row r.
+ * out may alias X.                                                                                                  */
+DH_API int dh_rowsum_masked_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const uint8_t* colmask,
+                         float* out, dh_stream_t stream);
+DH_API int dh_rowscale_log1p_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* divisor,
+                          int do_log1p, double log_base, float* out, int64_t ldo, dh_stream_t stream);
+DH_API int dh_col_standardize_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const double* mean,
+                           const double* std, double max_value, float* out, int64_t ldo, dh_stream_t stream);
+DH_API int dh_col_moments_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, int64_t rows_per_block,
+                       double* partial, dh_stream_t stream);
+DH_API int dh_col_any_gt_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* thresh,
+                      uint8_t* flag, dh_stream_t stream);
+
 /* ---- kNN-truncated Gaussian spatial adjacency (SpaGCN at scale; spagcn.py:249-251,807-809 evaluate the DENSE kernel) ----
  * Rows = spots; each row keeps the spot's k nearest spots (exact, self included) with value exp(-d^2 / (2 l^2)) in the
  * reference's fp32 expression, columns ascending; l <= 0 writes the distances d instead.  out_rowptr [n+1],

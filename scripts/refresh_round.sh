@@ -8,9 +8,9 @@ cd $R
 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-knn-workload > $OUT/bench_line_under_rocprof.json 2> $OUT/prof.err
 DB=$(find $OUT/prof -name "*.db" | head -1); python $R/scripts/rocpd_stats.py $DB $OUT/bench > $OUT/rocpd.log 2>&1; head -12 $OUT/rocpd.log
-CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-knn-workload"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $OUT/fetch -o fetch --output-format csv -- $CMD > $OUT/fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $OUT/write -o write --output-format csv -- $CMD > $OUT/write.log 2>&1
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS -d $OUT/sq -o sq --output-format csv -- $CMD > $OUT/sq.log 2>&1
