@@ -35,6 +35,8 @@ def _declare(lib):
         "dh_csr_transpose": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_gemm_f32_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
         "dh_gemm_f32": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
+        "dh_gemm_f32x3_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
+        "dh_gemm_f32x3": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
         "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
         "dh_bias_act_f32": (c_int, [i64, i64, P, i64, P, i32, P]),
         "dh_gaussian_kernel_f32": (c_int, [i64, i64, P, i64, c_double, P, i64, P, P]),

@@ -6,6 +6,8 @@ wrappers never copy to the host and never compute on the CPU.
 """
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -191,10 +193,20 @@ def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
     return rowptr_t, col_t, val_t, perm
 
 
+# How fp32 GEMMs run on the matrix cores: "x3" = split-bf16 kernel (dh_gemm_f32x3: fp32 operands/result, bf16 x 3 operand
+# split, 6 partial products, fp32 accumulation; fp32-level accuracy), "exact" = v_mfma_f32_32x32x2_f32 (dh_gemm_f32, a
+# bit-exact k-ordered fmaf chain).  Set with DANCE_AMD_GEMM or per call.
+GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "x3")
+
+
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
-         out: Optional[torch.Tensor] = None, accumulate: bool = False, tag: Optional[str] = None) -> torch.Tensor:
-    """C (+)= op(A) @ op(B) on the f32 matrix cores; see dh_gemm_f32."""
+         out: Optional[torch.Tensor] = None, accumulate: bool = False, tag: Optional[str] = None,
+         mode: Optional[str] = None) -> torch.Tensor:
+    """C (+)= op(A) @ op(B), fp32 in / fp32 out, on the matrix cores; see dh_gemm_f32x3 / dh_gemm_f32 and GEMM_MODE."""
     lib = _lib_ready()
+    mode = mode or GEMM_MODE
+    if mode not in ("x3", "exact"):
+        raise ValueError(f"gemm: mode must be 'x3' or 'exact', got {mode!r}")
     M = A.shape[1] if trans_a else A.shape[0]
     K = A.shape[0] if trans_a else A.shape[1]
     Kb = B.shape[1] if trans_b else B.shape[0]
@@ -205,10 +217,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         if accumulate:
             raise ValueError("gemm: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
-    ws_bytes = lib.dh_gemm_f32_workspace_bytes(M, N, K, int(trans_a), int(trans_b))
+    size_fn, fn = (lib.dh_gemm_f32x3_workspace_bytes, lib.dh_gemm_f32x3) if mode == "x3" else (lib.dh_gemm_f32_workspace_bytes, lib.dh_gemm_f32)
+    ws_bytes = size_fn(M, N, K, int(trans_a), int(trans_b))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None
     tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
-    _call(tag, lib.dh_gemm_f32, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A),
+    _call(tag, fn, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A),
           _dev(B, torch.float32, "B", 2), _ld(B), _dev(out, torch.float32, "out", 2), _ld(out), int(accumulate),
           None if ws is None else ws.data_ptr(), ws_bytes, _stream())
     return out

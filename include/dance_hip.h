@@ -124,6 +124,15 @@ DH_API int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b
                 float* C, int64_t ldc, int accumulate,
                 void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* Same contract as dh_gemm_f32 (operands, result and accumulation in fp32), computed on the bf16 matrix cores: each fp32
+ * operand is split exactly into three bf16 terms and six of the nine partial products are accumulated in fp32 (the dropped
+ * ones are <= 2^-23 of a product; csrc/gemm_f32x3.hip) — fp32-level accuracy at 6/16 of the fp32 matrix-pipe time.
+ * Inputs must be finite.  Problems too small or unaligned for the split kernel run dh_gemm_f32 itself.               */
+DH_API size_t dh_gemm_f32x3_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b);
+DH_API int dh_gemm_f32x3(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
+                  size_t workspace_bytes, dh_stream_t stream);
+
 /* ---- elementwise / reductions used by the layers' backward ---------------------------------
  * dh_relu_backward_f32: G = dY where Y > 0 else 0 (autograd of F.relu, scdsc.py:499-500).
  * dh_colsum_f32: out[j] = sum_i X[i,j] (bias gradient of spagcn.py:360-361); deterministic
