@@ -7,11 +7,16 @@
 //
 // Block = 8 wavefronts computing a 256x256 tile; wave (wm, wn) of the 2x4 wave grid owns a
 // 128x64 patch = 4x2 MFMA tiles (128 accumulator VGPRs).  The big macro-tile is deliberate:
-// ablation on MI355X showed the 128x128 version of this kernel capped at 120 TFLOP/s by the
-// CU's global-load path (6 B/clk/CU of tile refills; 148 TFLOP/s with the loads removed);
-// 256x256 halves the bytes fetched per flop.  K is consumed 32 at a time through a
-// register-staged, double-buffered LDS pipeline; the global loads of tile t+1 are issued
-// piecewise between the four k-groups of tile t (no burst), and one barrier ends a K-step.
+// 256x256 halves the bytes fetched per flop relative to 128x128.  K is consumed 32 at a time through a register-staged,
+// double-buffered LDS pipeline two k-groups deep (see the main loop), one barrier per K-step, and inside each k-group every
+// LDS read / LDS write / global load is paired with one MFMA by sched_group_barrier, so a wave's non-MFMA issue slots hide
+// behind its own 64-clock MFMAs.  What was measured on the way (1M x 2000 x 512, TFLOP/s NN / TN, rocBLAS 148 / 137-142):
+//   bursts of memory instructions between 32-MFMA blocks, refill one k-group deep      136.7 / 137.0
+//   + all tiles of a K-slice on one XCD (TN traffic 25.4 -> 10.05 GB = algorithmic)     136.7 / 137.9
+//   + refill two k-groups deep, no vmcnt(0) at the barrier (bursts kept)                135.7 / 138.2   (latency was not it)
+//   + one memory instruction per MFMA                                                   139.8 / 142.7
+//   + constant descriptors, K advance on the lane offsets                               141.8 / 143.8
+// The 128x128 configuration (2 blocks per CU) runs the same loop at 140.1 / 141.0.
 // LDS images are padded so fragment reads are bank-conflict free:
 //   "MK" image (operand stored with K contiguous): [256][32+4] floats; a fragment is one
 //        ds_read_b128 per 32x32 tile (4 consecutive k of one row) feeding 4 MFMA steps; the
@@ -27,10 +32,9 @@
 // and the next tile's first fragment reads hide behind that group's MFMAs.  Problems with too few
 // 256x256 tiles to fill the chip use the same kernel at 128x128 (4 waves, 2x2 tiles each).
 //
-// The transposed-A form (dW = X^T dZ, K = number of cells) is split over K across
-// gridDim.z; partial slabs are summed by a second deterministic kernel (no float atomics).
-// Block ids are remapped so that consecutive tiles land on the same XCD (private L2) and
-// share their A row panel.
+// The transposed-A form (dW = X^T dZ, K = number of cells) is split over K into slices of a linear grid;
+// partial slabs are summed by a second deterministic kernel (no float atomics).  Block ids are remapped so
+// that consecutive tiles (one K-slice: same A row panel; split-K: the whole slice) land on the same XCD (private L2).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -42,6 +46,11 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// A/B switches for scripts/gemm_variants.sh (defaults = the measured winners)
+#ifndef DH_GEMM_SLICEMAP
+#define DH_GEMM_SLICEMAP 1  // split-K: all tiles of a K-slice on one XCD
+#endif
 
 constexpr int BK = 32;
 constexpr int LD_MK = BK + 4;  // K-contiguous image: 36-float rows (16-B aligned, b128 reads conflict-free)
@@ -178,22 +187,36 @@ template <typename C_, bool TA, bool TB, bool ALIGNED>
 __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    int accumulate, int64_t k_chunk, float* __restrict__ slabs, int tiles_n, int n_tiles) {
+    int accumulate, int64_t k_chunk, float* __restrict__ slabs, int tiles_n, int n_tiles, int n_slices) {
   constexpr int TM = C_::TM, TN = C_::TN, BM = C_::BM, BN = C_::BN, NT = C_::NT;
   constexpr int NLA = C_::NLD_A, NLB = C_::NLD_B;
   __shared__ __attribute__((aligned(16))) float lds[2 * C_::TILE_A + 2 * C_::TILE_B];  // A[0], A[1], B[0], B[1]
   float* const lds_a = lds;
   float* const lds_b = lds + 2 * C_::TILE_A;
 
-  // XCD-aware bijective remap: the dispatcher places block b on XCD b % 8; give every XCD a
-  // contiguous run of logical tiles so neighbours (same A row panel) share one L2.
+  // XCD-aware bijective remap of the LINEAR block id b (the dispatcher places block b on XCD b % 8, observed):
+  //  * one K-slice: every XCD gets a contiguous run of logical tiles, so neighbours (same A row panel) share one L2;
+  //  * split-K (dW = X^T dS): all tiles of a K-slice run on ONE XCD at the same time (slice = xcd + 8 * round), so the
+  //    slice's rows of X and dS are fetched from HBM once and the other tiles of the slice hit that XCD's L2 — the
+  //    row tiles re-reading dS (and the column tiles re-reading X) were 2.5x the algorithmic traffic before.
   const int bid = blockIdx.x;
-  const int q = n_tiles / 8, rr = n_tiles % 8, xcd = bid % 8;
-  const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + bid / 8;
+  int logical, slice;
+  if (n_slices == 1) {
+    const int q = n_tiles / 8, rr = n_tiles % 8, xcd = bid % 8;
+    logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + bid / 8;
+    slice = 0;
+  } else if (DH_GEMM_SLICEMAP && n_slices % 8 == 0) {
+    const int xcd = bid % 8, j = bid / 8;
+    slice = xcd + 8 * (j / n_tiles);
+    logical = j % n_tiles;
+  } else {
+    logical = bid % n_tiles;
+    slice = bid / n_tiles;
+  }
   const int64_t m0 = (int64_t)(logical / tiles_n) * BM;
   const int64_t n0 = (int64_t)(logical % tiles_n) * BN;
 
-  const int64_t k_begin = (int64_t)blockIdx.z * k_chunk;
+  const int64_t k_begin = (int64_t)slice * k_chunk;
   const int64_t k_end = min(K, k_begin + k_chunk);
 
   const int tid = threadIdx.x;
@@ -224,11 +247,10 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     read_frags<TB, TN, BN>(fb[0], lds_b, b_span, i32, 0, h);
   }
 
-  // Fast refill path: when the whole next tile lies inside the matrix (always, except the K tail and the
-  // last row/column of tiles) a piece is ONE unguarded 16-byte buffer load: scalar descriptor (tile origin
-  // advanced along K with scalar adds) + a loop-invariant 32-bit lane offset.  Every non-MFMA instruction
-  // in this loop displaces matrix-pipe time (measured: the guarded, 64-bit-addressed refill cost 17 % of the
-  // kernel), so the main loop contains only the fast path and the guarded path runs in a separate tail loop.
+  // Fast refill path: when a whole tile lies inside the matrix (always, except the K tail) a piece is ONE unguarded
+  // 16-byte buffer load: one descriptor per operand per block + a 32-bit lane offset.  Every non-MFMA instruction in the
+  // main loop displaces matrix-pipe time (measured: the guarded, 64-bit-addressed refill cost 17 % of the kernel), so the
+  // main loop contains only the fast path and the guarded path runs in a separate tail loop.
   uint32_t offa[NLA], offb[NLB];
 #pragma unroll
   for (int r = 0; r < NLA; ++r) offa[r] = piece_offset<!TA, BM, NT>(r, lda, M, m0, tid);
@@ -243,65 +265,97 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
   const char* const a_origin = reinterpret_cast<const char*>(A + (TA ? m0 : m0 * lda));
   const char* const b_origin = reinterpret_cast<const char*>(B + (TB ? n0 * ldb : n0));
   const int64_t a_kstride = (TA ? lda : 1) * 4, b_kstride = (TB ? 1 : ldb) * 4;  // bytes per unit of k
-  // steps t whose NEXT tile (t+1) is completely inside K: (t + 2) * BK <= k_len
-  const int64_t n_fast = tile_inside ? max((int64_t)0, min(n_steps - 1, (k_end - k_begin) / BK - 1)) : 0;
+  // Refill pipeline, two k-groups deep.  The 16-byte pieces of a tile are split in two halves that share one set of
+  // staging registers (pa, pb), live across K-steps:
+  //   g = 0: retire half 0 of tile t+1 into the idle LDS buffer, issue half 1 of tile t+1, frags g=1
+  //   g = 1: frags g=2
+  //   g = 2: retire half 1 of tile t+1, issue half 0 of tile t+2, frags g=3
+  //   g = 3: BARRIER, frags g=0 of tile t+1 from the freshly filled buffer
+  // Every global load has two k-groups (64 MFMAs, ~4000 clocks per wave) between issue and the ds_write that consumes it,
+  // and the barrier carries no vmcnt(0): the loads of tile t+2 stay in flight across it.
+  // Steps whose tiles t+1 AND t+2 are completely inside K take the unguarded fast path: (t + 3) * BK <= k_len.
+  // One descriptor per operand per block (origin at k_begin, records up to the end of the matrix); a lane's offset is
+  // piece offset + k * k-stride and advances by one K-step after each use (8 VALU adds per K-step; rebuilding four
+  // descriptors per step cost ~60 scalar / 64-bit compare instructions: 139.8 -> 141.8 TFLOP/s NN).  Needs the whole
+  // K-slice within 32 bits of the origin, else every step takes the guarded path.
+  const int64_t span_a = (k_end - k_begin + BK) * a_kstride + (int64_t)BM * lda * 4 + 4096;
+  const int64_t span_b = (k_end - k_begin + BK) * b_kstride + (int64_t)BN * ldb * 4 + 4096;
+  const bool voff_ok = span_a < 0xffffffffLL && span_b < 0xffffffffLL;
+  const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(a_origin + k_begin * a_kstride, a_end);
+  const __amdgpu_buffer_rsrc_t rb0 = make_rsrc(b_origin + k_begin * b_kstride, b_end);
+  const uint32_t kstep_a = (uint32_t)(BK * a_kstride), kstep_b = (uint32_t)(BK * b_kstride);
+#pragma unroll
+  for (int r = 0; r < NLA; ++r) offa[r] += (r < NLA / 2 ? 2u : 1u) * kstep_a;  // half 0 is first loaded for tile 2, half 1 for tile 1
+#pragma unroll
+  for (int r = 0; r < NLB; ++r) offb[r] += (r < NLB / 2 ? 2u : 1u) * kstep_b;
+  const int64_t n_fast = (tile_inside && voff_ok) ? max((int64_t)0, min(n_steps, (k_end - k_begin) / BK - 2)) : 0;
+  f32x4 pa[NLA / 2], pb[NLB / 2];  // refill pieces in flight
+  auto issue_half = [&](int half, int64_t k0, auto fast_tag) __attribute__((always_inline)) {
+    if constexpr (decltype(fast_tag)::value) {
+#pragma unroll
+      for (int r = 0; r < NLA / 2; ++r) {
+        pa[r] = buffer_load_x4(ra0, offa[half * (NLA / 2) + r]);
+        offa[half * (NLA / 2) + r] += kstep_a;
+      }
+#pragma unroll
+      for (int r = 0; r < NLB / 2; ++r) {
+        pb[r] = buffer_load_x4(rb0, offb[half * (NLB / 2) + r]);
+        offb[half * (NLB / 2) + r] += kstep_b;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < NLA / 2; ++r)
+        pa[r] = load_piece<!TA, ALIGNED, BM, NT>(half * (NLA / 2) + r, A, lda, M, m0, k0, k_end, tid);
+#pragma unroll
+      for (int r = 0; r < NLB / 2; ++r)
+        pb[r] = load_piece<TB, ALIGNED, BN, NT>(half * (NLB / 2) + r, B, ldb, N, n0, k0, k_end, tid);
+    }
+  };
+  auto retire_half = [&](int half, float* a_nxt, float* b_nxt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < NLA / 2; ++r) store_piece<!TA, BM, NT>(half * (NLA / 2) + r, a_nxt, pa[r], tid);
+#pragma unroll
+    for (int r = 0; r < NLB / 2; ++r) store_piece<TB, BN, NT>(half * (NLB / 2) + r, b_nxt, pb[r], tid);
+  };
+  if (n_steps > 1) issue_half(0, k_begin + BK, std::false_type{});
 
-  // Software pipeline of one K-step (4 k-groups of TM*TN*4 MFMAs each):
-  //   g = 0: issue the first half of tile t+1's refill loads            | prefetch frags g=1
-  //   g = 1: retire that half into the idle LDS buffer, issue the rest   | prefetch frags g=2
-  //   g = 2: retire the second half                                      | prefetch frags g=3
-  //   g = 3: BARRIER, then prefetch frags g=0 of tile t+1 from the freshly filled buffer
-  // so the barrier, the store->load turnaround and the first fragment reads of the next tile are all
-  // covered by the last group's MFMAs instead of draining the matrix pipe once per K-step.
   auto k_step = [&](int64_t t, auto fast_tag) __attribute__((always_inline)) {
     constexpr bool FAST = decltype(fast_tag)::value;
     const int cur = t & 1;
-    const bool more = FAST || (t + 1 < n_steps);
-    const int64_t k_next = k_begin + (t + 1) * BK;
+    const bool has1 = FAST || (t + 1 < n_steps), has2 = FAST || (t + 2 < n_steps);
+    const int64_t k1 = k_begin + (t + 1) * BK, k2 = k1 + BK;
     const float* a_lds = lds_a + cur * C_::TILE_A;
     const float* b_lds = lds_b + cur * C_::TILE_B;
-    float* a_nxt = lds_a + (cur ^ 1) * C_::TILE_A;  // not read by anyone during groups 0..2
+    float* a_nxt = lds_a + (cur ^ 1) * C_::TILE_A;  // last read at g=2 of step t-1, before that step's barrier
     float* b_nxt = lds_b + (cur ^ 1) * C_::TILE_B;
-    __amdgpu_buffer_rsrc_t ra, rb;
-    if constexpr (FAST) {
-      ra = make_rsrc(a_origin + k_next * a_kstride, a_end);
-      rb = make_rsrc(b_origin + k_next * b_kstride, b_end);
-    }
-    f32x4 pa[NLA / 2], pb[NLB / 2];  // refill pieces in flight
+    // One scheduling region per k-group; inside it every memory instruction is paired with one MFMA (64 clocks of matrix
+    // pipe each), so the wave's non-MFMA issue slots hide behind its own MFMAs instead of forming a burst during which the
+    // pipe only runs if the SIMD's other wave happens to be in a different phase (both run this same code in step).
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      if (more && g >= 1 && g <= 2) {  // retire the half issued one group earlier
-#pragma unroll
-        for (int r = 0; r < NLA / 2; ++r) store_piece<!TA, BM, NT>((g - 1) * (NLA / 2) + r, a_nxt, pa[r], tid);
-#pragma unroll
-        for (int r = 0; r < NLB / 2; ++r) store_piece<TB, BN, NT>((g - 1) * (NLB / 2) + r, b_nxt, pb[r], tid);
+      if (g == BK / 8 - 1 && has1) {
+        // this wave's ds_writes of tile t+1 are complete (lgkmcnt), then the workgroup meets; no vmcnt(0): the loads of
+        // tile t+2 stay in flight.  Nobody reads tile t's buffer any more (the g=3 fragments are in registers).
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (more && g < 2) {
-        if constexpr (FAST) {
-#pragma unroll
-          for (int r = 0; r < NLA / 2; ++r) pa[r] = buffer_load_x4(ra, offa[g * (NLA / 2) + r]);
-#pragma unroll
-          for (int r = 0; r < NLB / 2; ++r) pb[r] = buffer_load_x4(rb, offb[g * (NLB / 2) + r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < NLA / 2; ++r)
-            pa[r] = load_piece<!TA, ALIGNED, BM, NT>(g * (NLA / 2) + r, A, lda, M, m0, k_next, k_end, tid);
-#pragma unroll
-          for (int r = 0; r < NLB / 2; ++r)
-            pb[r] = load_piece<TB, ALIGNED, BN, NT>(g * (NLB / 2) + r, B, ldb, N, n0, k_next, k_end, tid);
-        }
-      }
+      // source order = LDS order the compiler must keep (it cannot prove the two LDS buffers distinct): fragment reads of
+      // the live buffer first, then the writes into the idle one, then the loads that reuse the staging registers
       if (g + 1 < BK / 8) {
         read_frags<!TA, TM, BM>(fa[(g + 1) & 1], a_lds, a_span, i32, g + 1, h);
         read_frags<TB, TN, BN>(fb[(g + 1) & 1], b_lds, b_span, i32, g + 1, h);
-      } else if (more) {
-        __syncthreads();  // tile t+1 is complete in LDS; nobody reads tile t's buffer any more (g=3 frags are in registers)
+      } else if (has1) {
         read_frags<!TA, TM, BM>(fa[0], a_nxt, a_span, i32, 0, h);
         read_frags<TB, TN, BN>(fb[0], b_nxt, b_span, i32, 0, h);
       }
-      // keep loads / prefetches ABOVE this group's MFMAs (the scheduler otherwise sinks the reads to their
-      // first use to save registers and re-exposes the latency)
-      __builtin_amdgcn_sched_barrier(0);
+      if (g == 0 && has1) {
+        retire_half(0, a_nxt, b_nxt);
+        issue_half(1, k1, fast_tag);
+      }
+      if (g == 2) {
+        if (has1) retire_half(1, a_nxt, b_nxt);
+        if (has2) issue_half(0, k2, fast_tag);
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -309,6 +363,29 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
 #pragma unroll
           for (int y = 0; y < TN; ++y)
             acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][x][s], fb[g & 1][y][s], acc[x][y], 0, 0, 0);
+      // issue order of the region: (MFMA, LDS read) x 8, then for g = 0, 2 (MFMA, LDS write) x 4, (MFMA, global load) x 4,
+      // then the remaining MFMAs; groups that find fewer candidates than asked for stay short
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      if (g == 0 || g == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * 4 - 16, 0);
+      } else {
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN * 4 - 8, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
   int64_t t = 0;
@@ -320,7 +397,7 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
   int64_t ldo = ldc;
   bool add = accumulate != 0;
   if (slabs) {
-    out = slabs + (int64_t)blockIdx.z * M * N;
+    out = slabs + (int64_t)slice * M * N;
     ldo = N;
     add = false;
   }
@@ -405,6 +482,9 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
 // fill the chip; smaller problems use 128x128 tiles.
 Plan make_plan(int64_t M, int64_t N, int64_t K) {
   Plan big = plan_for(M, N, K, CfgLarge::BM, CfgLarge::BN);
+#ifdef DH_GEMM_FORCE_SMALL
+  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
+#endif
   if ((int64_t)big.n_tiles * big.S >= 512) return big;
   return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
 }
@@ -443,15 +523,15 @@ extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int tra
                        // K-contiguous operands are read 4 k at a time, M/N-contiguous ones are
                        // guarded per element at the edge, so only K % 4 matters for the former
                        ((trans_a != 0 && trans_b == 0) || K % 4 == 0);
-  dim3 grid((unsigned)p.n_tiles, 1, (unsigned)p.S);
+  dim3 grid((unsigned)p.n_tiles * (unsigned)p.S);
 #define DH_GEMM_LAUNCH(TA, TB, AL)                                                                           \
   do {                                                                                                       \
     if (p.large)                                                                                             \
       hipLaunchKernelGGL((gemm_f32_kernel<CfgLarge, TA, TB, AL>), grid, dim3(CfgLarge::NT), 0, st, M, N, K, A, \
-                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles);            \
+                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles, p.S);       \
     else                                                                                                     \
       hipLaunchKernelGGL((gemm_f32_kernel<CfgSmall, TA, TB, AL>), grid, dim3(CfgSmall::NT), 0, st, M, N, K, A, \
-                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles);            \
+                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles, p.S);       \
   } while (0)
   const int key = (trans_a ? 4 : 0) | (trans_b ? 2 : 0) | (aligned ? 1 : 0);
   switch (key) {

@@ -73,8 +73,8 @@ __device__ __forceinline__ float sage_alpha(const SageScale& sg, int sid, int di
 
 // ReLU sign masks (fusing autograd's ReluBackward into the backward gather, dh_spmm_csr_relu_f32):
 // in the 32-lanes-per-row float4 configuration (128-column passes, two rows per wavefront) the forward pass stores, per
-// row and per 128-column slice, its half of the four wave ballots "element i of lane l's float4 is > 0" (4 x uint32 =
-// 128 bits); the backward pass gathers dY rows and zeroes the elements whose bit is clear, so G = dY * [Y > 0] is never
+// row and per 128-column slice, the bitmap "column c of the slice is > 0" (4 x uint32 = 128 bits, bit c % 32 of word
+// c / 32); the backward pass gathers dY rows and zeroes the elements whose bit is clear, so G = dY * [Y > 0] is never
 // written to or read from HBM.
 struct ReluMask {
   uint32_t* out;       // forward: written when non-null   [n_rows][slices][4]
@@ -84,14 +84,13 @@ struct ReluMask {
 };
 
 // G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart).
-template <int G, int VEC, int NACC, bool SAGE, bool MASKED = false>
+template <int G, int VEC, int NACC, bool SAGE>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int64_t n_rows, int64_t width, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ rowscale, const float* __restrict__ colscale,
     const float* __restrict__ Z, int64_t ldz, float* __restrict__ Y, int64_t ldy,
-    const float* __restrict__ bias, int act, int reduce, SageScale sage, const int32_t* __restrict__ row_ids,
-    ReluMask mask = ReluMask{nullptr, nullptr, 0, 0}) {
+    const float* __restrict__ bias, int act, int reduce, SageScale sage, const int32_t* __restrict__ row_ids) {
   using V = typename VecT<VEC>::type;
   constexpr int ROWS_PER_BLOCK = 256 / G;
   const int g = threadIdx.x % G;
@@ -136,16 +135,6 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
 #pragma unroll
         for (int a = 0; a < NACC; ++a)
           z[u][a] = live[a] ? *reinterpret_cast<const V*>(zr + a * G * VEC) : V(0.f);
-        if constexpr (MASKED) {
-          if (mask.in) {  // the 4 ballot words of row ck: one 16-byte load, the same address for the 32 lanes of the group
-            static_assert(!MASKED || (NACC == 1 && VEC == 4 && G == 32), "mask layout is 32 lanes x float4");
-            const uint4 m = *reinterpret_cast<const uint4*>(mask.in + ((int64_t)ck * mask.slices + mask.slice0) * 4);
-            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-            for (int i = 0; i < VEC; ++i)
-              if (!((mw[i] >> g) & 1u)) z[u][0][i] = 0.f;
-          }
-        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -160,15 +149,6 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
       for (int a = 0; a < NACC; ++a) {
         if (!live[a]) continue;
         V zv = *reinterpret_cast<const V*>(zr + a * G * VEC);
-        if constexpr (MASKED) {
-          if (mask.in) {
-            const uint4 m = *reinterpret_cast<const uint4*>(mask.in + ((int64_t)ck * mask.slices + mask.slice0) * 4);
-            const uint32_t mw[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-            for (int i = 0; i < VEC; ++i)
-              if (!((mw[i] >> g) & 1u)) zv[i] = 0.f;
-          }
-        }
         fma_vec<VEC>(acc[a], wk, zv);
       }
     }
@@ -181,23 +161,142 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
   for (int a = 0; a < NACC; ++a) {
     if (!live[a]) continue;
     epilogue<VEC>(acc[a], scale, bias, c0 + (int64_t)a * G * VEC, act);
-    if constexpr (MASKED) {
-      if (mask.out) {
-        uint32_t* m = mask.out + (row * mask.slices + mask.slice0) * 4;
-        const int half = (threadIdx.x & 63) >> 5;  // which of the wavefront's two rows
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          const unsigned long long b = __ballot(acc[a][i] > 0.f);
-          if (g == 0) m[i] = (uint32_t)(b >> (32 * half));
-        }
-      }
-    }
     __builtin_nontemporal_store(acc[a], reinterpret_cast<V*>(yr + a * G * VEC));
   }
 }
 
+// One 128-column slice of a wide layer: 32 lanes x float4 per row, two rows per wavefront, every lane live.  This is the
+// kernel of the headline layer (four passes per SpMM).  MIN: the gathered rows are dY and the ReLU sign mask of the same
+// row is applied on the fly (backward); MOUT: the sign mask of the output is recorded (forward).  IDX32: n_cols * ldz fits
+// 32 bits, so a neighbour's row offset is one 32-bit multiply.  All loads of a batch of 4 neighbours (4 x 16 B of Z, and with
+// MIN 4 x 16 B of mask) are issued before the first use: the version this replaces applied the mask per neighbour behind a
+// run-time branch and drained vmcnt after every mask load (one neighbour in flight; backward 5.4 ms vs 4.6 ms forward).
+template <bool MIN, bool MOUT, bool IDX32>
+__global__ __launch_bounds__(256) void spmm_slice128_kernel(
+    int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ rowscale, const float* __restrict__ colscale, const float* __restrict__ Z, int64_t ldz,
+    float* __restrict__ Y, int64_t ldy, const float* __restrict__ bias, int act, int reduce,
+    const int32_t* __restrict__ row_ids, ReluMask mask) {
+  const int g = threadIdx.x & 31;
+  const int64_t slot = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (slot >= n_rows) return;  // whole 32-lane groups exit together
+  const int64_t row = row_ids ? (int64_t)row_ids[slot] : slot;
+  const float* zc = Z + g * 4;
+  const uint32_t* min_base = MIN ? mask.in + (int64_t)mask.slice0 * 4 : nullptr;
+  auto zrow = [&](int ck) -> const f32x4* {
+    if constexpr (IDX32) return reinterpret_cast<const f32x4*>(zc + (uint32_t)ck * (uint32_t)ldz);
+    else return reinterpret_cast<const f32x4*>(zc + (int64_t)ck * ldz);
+  };
+  // the mask of a (row, slice) is a plain 128-bit bitmap (bit c = column c of the slice): this lane's four columns
+  // 4 g .. 4 g + 3 are bits 4 (g & 7) .. + 3 of word g >> 3 — one 4-byte load per neighbour (a 16-byte load per lane cost
+  // the texture path as much as the 16 bytes of data it guards: 5.35 vs 4.49 ms unmasked)
+  const uint32_t* min_lane = MIN ? min_base + (g >> 3) : nullptr;
+  const uint32_t bit0 = 4u * (uint32_t)(g & 7);
+  auto mrow = [&](int ck) -> uint32_t { return min_lane[(int64_t)ck * (mask.slices * 4)]; };
+  auto masked = [&](f32x4 z, uint32_t m) -> f32x4 {  // v_bfe_i32 (bit -> 0 / ~0) + v_and per element
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      z[i] = __uint_as_float(__float_as_uint(z[i]) & (uint32_t)__builtin_amdgcn_sbfe((int)m, bit0 + i, 1u));
+    return z;
+  };
+
+  f32x4 acc = f32x4(0.f);
+  const int s = rowptr[row], t = rowptr[row + 1];
+  for (int base = s; base < t; base += 32) {
+    const int e = base + g;
+    int c = 0;
+    float w = 0.f;
+    if (e < t) {
+      c = col[e];
+      w = val ? val[e] : 1.f;
+      if (colscale) w *= colscale[c];
+    }
+    const int cnt = min(32, t - base);
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+      int ck[4];
+      float wk[4];
+      f32x4 z[4];
+      uint32_t m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ck[u] = __shfl(c, k + u, 32);
+        wk[u] = __shfl(w, k + u, 32);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[u] = *zrow(ck[u]);
+      if constexpr (MIN) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = mrow(ck[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) z[u] = masked(z[u], m[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) fma_vec<4>(acc, wk[u], z[u]);
+    }
+    const int rem = cnt - k;  // 0..3 neighbours left: their loads go out together as well
+    if (rem > 0) {
+      int ck[3];
+      float wk[3];
+      f32x4 z[3];
+      uint32_t m[3];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        ck[u] = __shfl(c, k + u, 32);  // lanes beyond cnt hold c = 0, w = 0 (never used below)
+        wk[u] = __shfl(w, k + u, 32);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (u < rem) {
+          z[u] = *zrow(ck[u]);
+          if constexpr (MIN) m[u] = mrow(ck[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        if (u < rem) {
+          if constexpr (MIN) z[u] = masked(z[u], m[u]);
+          fma_vec<4>(acc, wk[u], z[u]);
+        }
+      }
+    }
+  }
+
+  float scale = rowscale ? rowscale[row] : 1.f;
+  if (reduce == DH_REDUCE_MEAN) scale = (t > s) ? scale / (float)(t - s) : 0.f;
+  epilogue<4>(acc, scale, bias, (int64_t)g * 4, act);
+  if constexpr (MOUT) {
+    uint32_t nib = (acc[0] > 0.f ? 1u : 0u) | (acc[1] > 0.f ? 2u : 0u) | (acc[2] > 0.f ? 4u : 0u) | (acc[3] > 0.f ? 8u : 0u);
+    nib <<= 4 * (g & 7);
+    nib |= __shfl_xor(nib, 1, 8);  // OR over the 8 lanes that share a word
+    nib |= __shfl_xor(nib, 2, 8);
+    nib |= __shfl_xor(nib, 4, 8);
+    if ((g & 7) == 0) mask.out[(row * mask.slices + mask.slice0) * 4 + (g >> 3)] = nib;
+  }
+  __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Y + row * ldy + g * 4));
+}
+
+// launches the slice kernel over every 128-column slice of [0, width)
+template <bool MIN, bool MOUT>
+void launch_slices(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
+                   const float* rowscale, const float* colscale, const float* Z, int64_t ldz, float* Y, int64_t ldy,
+                   const float* bias, int act, int reduce, const int32_t* row_ids, const uint32_t* in_mask, uint32_t* out_mask,
+                   hipStream_t st) {
+  const bool idx32 = n_cols >= 0 && (double)n_cols * (double)ldz < 4294967296.0;
+  for (int64_t c = 0; c < width; c += 128) {
+    const ReluMask mask{out_mask, in_mask, (int)(width / 128), (int)(c / 128)};
+    dim3 grid((unsigned)dh::ceil_div(n_rows, 8), 1);
+    if (idx32)
+      hipLaunchKernelGGL((spmm_slice128_kernel<MIN, MOUT, true>), grid, dim3(256), 0, st, n_rows, rowptr, col, val, rowscale, colscale,
+                         Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, row_ids, mask);
+    else
+      hipLaunchKernelGGL((spmm_slice128_kernel<MIN, MOUT, false>), grid, dim3(256), 0, st, n_rows, rowptr, col, val, rowscale, colscale,
+                         Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, row_ids, mask);
+  }
+}
+
 template <int VEC, bool SAGE>
-int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32_t* col,
+int launch_vec(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col,
                const float* val, const float* rowscale, const float* colscale, const float* Z,
                int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, int reduce,
                SageScale sage, const int32_t* row_ids, hipStream_t st) {
@@ -215,11 +314,9 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
     // working set of n_cols x 512 bytes instead of n_cols x width x 4, which the L2 / MALL hold a larger share of.
     // Measured at 1M rows, k = 15 (scripts/spmm_width_probe.py): one 512-wide launch 5.44 ms, two 256-wide passes
     // 4.90 ms, four 128-wide passes (32 lanes per row, two rows per wavefront) 4.54 ms.
-    for (int64_t c = 0; c < width; c += 128) {
-      dim3 grid((unsigned)dh::ceil_div(n_rows, 8), 1);
-      hipLaunchKernelGGL((spmm_csr_kernel<32, VEC, 1, SAGE>), grid, dim3(256), 0, st, n_rows, (int64_t)128, rowptr, col, val,
-                         rowscale, colscale, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, sage, row_ids);
-    }
+    if constexpr (VEC == 4 && !SAGE)
+      launch_slices<false, false>(n_rows, n_cols, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, row_ids,
+                                  nullptr, nullptr, st);
   } else if (vecs > 64) DH_SPMM_LAUNCH(64, 2);
   else if (vecs > 32) DH_SPMM_LAUNCH(64, 1);
   else if (vecs > 16) DH_SPMM_LAUNCH(32, 1);
@@ -230,16 +327,16 @@ int launch_vec(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32
 }
 
 template <bool SAGE>
-int dispatch(int64_t n_rows, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
+int dispatch(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
              const float* rowscale, const float* colscale, const float* Z, int64_t ldz, float* Y,
              int64_t ldy, const float* bias, int act, int reduce, SageScale sage, const int32_t* row_ids, hipStream_t st) {
   const bool a16 = dh::aligned16(Z) && dh::aligned16(Y) && (!bias || dh::aligned16(bias));
   const bool a8 = ((uintptr_t)Z % 8 == 0) && ((uintptr_t)Y % 8 == 0) && (!bias || (uintptr_t)bias % 8 == 0);
   if (a16 && width % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0)
-    return launch_vec<4, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
+    return launch_vec<4, SAGE>(n_rows, n_cols, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
   if (a8 && width % 2 == 0 && ldz % 2 == 0 && ldy % 2 == 0)
-    return launch_vec<2, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
-  return launch_vec<1, SAGE>(n_rows, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
+    return launch_vec<2, SAGE>(n_rows, n_cols, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
+  return launch_vec<1, SAGE>(n_rows, n_cols, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce, sage, row_ids, st);
 }
 
 }  // namespace
@@ -259,7 +356,7 @@ extern "C" int dh_spmm_csr_rows_f32(int64_t n_list, const int32_t* row_ids, int6
   if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad act %d", act);
   if (reduce != DH_REDUCE_SUM && reduce != DH_REDUCE_MEAN) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: bad reduce %d", reduce);
   if (n_list >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_f32: n_rows >= 2^31");
-  return dispatch<false>(n_list, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce,
+  return dispatch<false>(n_list, n_cols, width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act, reduce,
                          SageScale{nullptr, nullptr, nullptr, 0}, row_ids, dh::as_stream(stream));
 }
 
@@ -297,14 +394,17 @@ extern "C" int dh_spmm_csr_relu_rows_f32(int64_t n_list, const int32_t* row_ids,
   if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: leading dimension < width");
   if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: bad act %d", act);
   if (n_list >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: n_rows >= 2^31");
-  const SageScale none{nullptr, nullptr, nullptr, 0};
   hipStream_t st = dh::as_stream(stream);
-  for (int64_t c = 0; c < width; c += 128) {
-    const ReluMask mask{static_cast<uint32_t*>(out_mask), static_cast<const uint32_t*>(in_mask), (int)(width / 128), (int)(c / 128)};
-    dim3 grid((unsigned)dh::ceil_div(n_list, 8), 1);
-    hipLaunchKernelGGL((spmm_csr_kernel<32, 4, 1, false, true>), grid, dim3(256), 0, st, n_list, (int64_t)128, rowptr, col, val, nullptr,
-                       nullptr, Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, DH_REDUCE_SUM, none, row_ids, mask);
-  }
+  const uint32_t* mi = static_cast<const uint32_t*>(in_mask);
+  uint32_t* mo = static_cast<uint32_t*>(out_mask);
+#define DH_SLICES(MIN, MOUT)                                                                                                        \
+  launch_slices<MIN, MOUT>(n_list, n_cols, width, rowptr, col, val, nullptr, nullptr, Z, ldz, Y, ldy, bias, act, DH_REDUCE_SUM, row_ids, \
+                           mi, mo, st)
+  if (mi && mo) DH_SLICES(true, true);
+  else if (mi) DH_SLICES(true, false);
+  else if (mo) DH_SLICES(false, true);
+  else DH_SLICES(false, false);
+#undef DH_SLICES
   return dh::check_launch("dh_spmm_csr_relu_f32");
 }
 
@@ -329,12 +429,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n, int64_t wid
   float* o = out + i * ldo;
   for (int64_t c = (int64_t)lane * 4; c < width; c += 256) {
     f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
-    if (mask) {  // element j of the float4 of lane l' = (c / 4) % 32 in slice c / 128: bit l' of word j
-      const uint32_t* m = mask + (r * slices + c / 128) * 4;
-      const int l = (int)((c / 4) % 32);
+    if (mask) {  // columns c .. c + 3 of slice c / 128: bits (c % 32) .. + 3 of word (c % 128) / 32
+      const uint32_t m = mask[(r * slices + c / 128) * 4 + (c % 128) / 32] >> (c % 32);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (!((m[j] >> l) & 1u)) v[j] = 0.f;
+        if (!((m >> j) & 1u)) v[j] = 0.f;
     }
     *reinterpret_cast<f32x4*>(o + c) = v;
   }
@@ -364,6 +463,6 @@ extern "C" int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width
   if (!rowptr || !H || !neigh || !src_cell_id || !dst_cell_id || !alpha)
     return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: null pointer");
   if (ldh < width || ldn < width) return dh::fail(DH_ERR_INVALID, "dh_sage_aggregate_f32: leading dimension < width");
-  return dispatch<true>(n_dst, width, rowptr, col, w, nullptr, nullptr, H, ldh, neigh, ldn, nullptr, DH_ACT_NONE,
+  return dispatch<true>(n_dst, n_src, width, rowptr, col, w, nullptr, nullptr, H, ldh, neigh, ldn, nullptr, DH_ACT_NONE,
                         DH_REDUCE_MEAN, SageScale{src_cell_id, dst_cell_id, alpha, (int)n_genes}, nullptr, dh::as_stream(stream));
 }

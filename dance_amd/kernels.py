@@ -196,7 +196,7 @@ def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
 # How fp32 GEMMs run on the matrix cores: "x3" = split-bf16 kernel (dh_gemm_f32x3: fp32 operands/result, bf16 x 3 operand
 # split, 6 partial products, fp32 accumulation; fp32-level accuracy), "exact" = v_mfma_f32_32x32x2_f32 (dh_gemm_f32, a
 # bit-exact k-ordered fmaf chain).  Set with DANCE_AMD_GEMM or per call.
-GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "x3")
+GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "exact")
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,

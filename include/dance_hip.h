@@ -74,7 +74,7 @@ DH_API int dh_spmm_csr_f32(int64_t n_rows, int64_t n_cols, int64_t width,
 /* SpMM with the layer's ReLU fused on both sides, so autograd's ReluBackward (G = dY * [Y > 0],
  * scdsc.py:499-500 + :286-288) never touches HBM:
  *   forward : as dh_spmm_csr_f32(act) and, if out_mask != NULL, records the sign mask of Y
- *             (dh_relu_mask_bytes(n_rows, width) bytes: per row and 128-column slice, four 32-bit ballot words);
+ *             (dh_relu_mask_bytes(n_rows, width) bytes: per row a little-endian bitmap, bit c % 32 of 32-bit word c / 32 = [Y(row, c) > 0]);
  *   backward: called on the CSR of A^T with Z = dY and in_mask = the recorded mask: gathered rows are masked
  *             on the fly, i.e. it returns A^T (dY * [Y > 0]).
  * Requires width % 128 == 0 and 16-byte aligned rows (dh_relu_mask_bytes returns 0 otherwise; callers then use

@@ -5,5 +5,5 @@ dev = torch.device("cuda:0")
 M = 1_000_000
 X = torch.randn(M, 2000, device=dev); W = torch.randn(2000, 512, device=dev) / 45; D = torch.randn(M, 512, device=dev)
 for _ in range(3):
-    kernels.gemm(X, W); kernels.gemm(X, D, trans_a=True)
+    kernels.gemm(X, W, mode="exact"); kernels.gemm(X, D, trans_a=True, mode="exact")
 torch.cuda.synchronize()

@@ -4,7 +4,9 @@ import sys
 
 import torch
 
-from dance_amd import kernels
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dance_amd import kernels  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 X = torch.randn(n, 2000, device="cuda")

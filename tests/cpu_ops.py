@@ -53,21 +53,21 @@ def _spmm_full(rowptr, col, val, Z, n_cols, rowscale, colscale, bias, act, reduc
     return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
 
 
-# ---- fused ReLU sign masks, in the byte layout of dh_spmm_csr_relu_f32: per row and 128-column slice four 32-bit words;
-#      bit l of word i = [element at column slice * 128 + 4 l + i is > 0] ---------------------------------------------------
+# ---- fused ReLU sign masks, in the byte layout of dh_spmm_csr_relu_f32: per row and 128-column slice four 32-bit words
+#      = a little-endian 128-bit bitmap: bit c % 32 of word c / 32 = [element at column slice * 128 + c is > 0] ---------------
 def relu_mask_bytes(n_rows, width):
     return 0 if (n_rows <= 0 or width <= 0 or width % 128) else n_rows * (width // 128) * 16
 
 
 def _mask_to_bool(mask, n_rows, width):
-    words = mask.numpy()[:n_rows * (width // 128) * 16].view(np.uint32).reshape(n_rows, width // 128, 4)
-    bits = (words[..., None] >> np.arange(32, dtype=np.uint32)) & 1          # [row, slice, i, l]
-    return bits.transpose(0, 1, 3, 2).reshape(n_rows, width).astype(bool)     # column = slice * 128 + 4 l + i
+    words = mask.numpy()[:n_rows * (width // 128) * 16].view(np.uint32).reshape(n_rows, width // 32)
+    bits = (words[..., None] >> np.arange(32, dtype=np.uint32)) & 1          # [row, word, bit]
+    return bits.reshape(n_rows, width).astype(bool)
 
 
 def _bool_to_mask(b):
     n_rows, width = b.shape
-    bits = b.reshape(n_rows, width // 128, 32, 4).transpose(0, 1, 3, 2).astype(np.uint32)   # [row, slice, i, l]
+    bits = b.reshape(n_rows, width // 32, 32).astype(np.uint32)
     words = (bits << np.arange(32, dtype=np.uint32)).sum(-1, dtype=np.uint64).astype(np.uint32)
     return torch.from_numpy(words.reshape(-1).view(np.uint8).copy())
 

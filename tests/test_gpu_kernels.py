@@ -211,7 +211,7 @@ def test_spmm_fused_relu_mask(cuda_device, width):
     assert torch.equal(ds, ds_ref)
     with pytest.raises(Exception):
         kernels.spmm_csr_relu(rp, c, v, torch.randn(700, 50, device=cuda_device), act=kernels.ACT_RELU)
-    # the mask bytes are the documented layout: bit l of word i of (row, 128-column slice) = [y[row, 128 slice + 4 l + i] > 0]
+    # the mask bytes are the documented layout: a plain bitmap, bit c % 32 of word c / 32 of the row = [y[row, c] > 0]
     import cpu_ops
     assert np.array_equal(cpu_ops._mask_to_bool(mask.cpu(), 700, width), (y_ref > 0).cpu().numpy())
     # rows variants: the listed rows only, everything else untouched; mask rows likewise
