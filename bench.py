@@ -16,6 +16,8 @@ Prints ONE JSON line on rank 0.  Besides the headline (rand-k15)
 
 * ``roofline``: the dominant kernel against its own roofline AND ``layer_hbm_frac`` = the layer's algorithmic bytes
   (85.9 GB at the headline size) / step time / 8 TB/s — the metric's "fraction of HBM roofline";
+* ``gemm_f32x3_row`` (1 GPU): a separately labelled row, NOT the headline — the same layer with the GEMMs on the bf16
+  matrix cores via an exact three-way operand split (dh_gemm_f32x3);
 * ``knn_k15`` (1 GPU): the same layer timed on the metric's literal graph — exact kNN (k = 15, self included) of a
   clustered 50-d embedding + UMAP connectivities, built by NeighborGraph's own kernels inside this script;
 * N > 1: ``exchange`` — every exchange mode timed with the same K steps (halo all-to-all-v, dense all-gather, feature-sliced
@@ -187,6 +189,7 @@ def main():
                     help="cells of the CPU baseline sample (1000000 = the full workload: ~1.5 min of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn-workload", action="store_true", help="skip the second (knn-k15) timed workload at 1 GPU")
+    ap.add_argument("--no-x3-row", action="store_true", help="skip the separately labelled split-bf16 GEMM row at 1 GPU")
     ap.add_argument("--exchange", choices=["auto", "halo", "allgather", "alltoall"], default="auto",
                     help="multi-GPU exchange (dance_amd/sharding.py); auto = time every mode, headline = the fastest")
     args = ap.parse_args()
@@ -256,6 +259,23 @@ def main():
     elapsed, ksum = runs[mode]["elapsed"], runs[mode]["ksum"]
     sg = runs[mode]["sg"] or sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
     nnz_total = int(graph.nnz)
+
+    x3_out = None
+    if world == 1 and not args.no_x3_row:
+        # NOT the headline: the same layer with both GEMMs on the bf16 matrix cores (dh_gemm_f32x3: every fp32 operand split
+        # exactly into three bf16 terms, 6 partial products, fp32 accumulation; gated at the exact kernel's error vs float64 by
+        # tests/test_gpu_gemm_x3.py).  The headline above computes in fp32 on the f32-input matrix cores (dtype "f32").
+        prev = kernels.GEMM_MODE
+        kernels.GEMM_MODE = "x3"
+        try:
+            x_elapsed, x_timer = time_steps(make_step(sg), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
+        finally:
+            kernels.GEMM_MODE = prev
+        x_ms = x_elapsed / args.steps * 1e3
+        x3_out = {"label": "separate row, not the headline: GEMMs by dh_gemm_f32x3 (fp32 in / fp32 out, bf16 x 3 operand split, "
+                           "6 products, fp32 accumulate; error vs float64 <= the exact kernel's, tests/test_gpu_gemm_x3.py)",
+                  "ms_per_step": x_ms, "value": n / (x_elapsed / args.steps), "unit": "cells/s",
+                  "kernels_ms": {k: round(v[1], 4) for k, v in sorted(x_timer.summary().items())}}
 
     knn_out = None
     if world == 1 and not args.no_knn_workload:
@@ -331,6 +351,8 @@ def main():
                                    "bytes_on_wire_per_step_per_rank": int(r["exchange_only_bytes"]),
                                    "exchange_only_ms_per_step": round(r["exchange_only_ms"], 4)} for m, r in runs.items()}
             out["exchange"]["headline_mode"] = mode
+        if x3_out is not None:
+            out["gemm_f32x3_row"] = x3_out
         if knn_out is not None:
             out["knn_k15"] = knn_out
         if world == 1 and not args.no_cpu_baseline:

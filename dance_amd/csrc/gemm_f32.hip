@@ -162,6 +162,13 @@ __device__ __forceinline__ uint32_t piece_offset(int r, int64_t ld, int64_t rows
   }
 }
 
+// k index (inside the tile) of piece r of this thread
+template <bool KCONTIG, int ROWS_T, int NT>
+__device__ __forceinline__ int piece_k(int r, int tid) {
+  const int idx = tid + NT * r;
+  return KCONTIG ? (idx % (BK / 4)) * 4 : idx / (ROWS_T / 4);
+}
+
 // Buffer descriptor over [base, base + 4 GiB) built from a wave-uniform pointer (readfirstlane makes the
 // uniformity provable, so no waterfall loop is generated around the loads).
 // num_records = bytes up to the end of the matrix (capped at 4 GiB): loads past it return 0 instead of faulting.
@@ -277,10 +284,8 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
   // One descriptor per operand per block (origin at k_begin, records up to the end of the matrix); a lane's offset is
   // piece offset + k * k-stride and advances by one K-step after each use (8 VALU adds per K-step; rebuilding four
   // descriptors per step cost ~60 scalar / 64-bit compare instructions: 139.8 -> 141.8 TFLOP/s NN).  Needs the whole
-  // K-slice within 32 bits of the origin, else every step takes the guarded path.
-  const int64_t span_a = (k_end - k_begin + BK) * a_kstride + (int64_t)BM * lda * 4 + 4096;
-  const int64_t span_b = (k_end - k_begin + BK) * b_kstride + (int64_t)BN * ldb * 4 + 4096;
-  const bool voff_ok = span_a < 0xffffffffLL && span_b < 0xffffffffLL;
+  // K-slice within 32 bits of the origin
+  // (the host checks that and runs the unaligned instantiation otherwise: fast_path_ok)
   const __amdgpu_buffer_rsrc_t ra0 = make_rsrc(a_origin + k_begin * a_kstride, a_end);
   const __amdgpu_buffer_rsrc_t rb0 = make_rsrc(b_origin + k_begin * b_kstride, b_end);
   const uint32_t kstep_a = (uint32_t)(BK * a_kstride), kstep_b = (uint32_t)(BK * b_kstride);
@@ -288,10 +293,13 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
   for (int r = 0; r < NLA; ++r) offa[r] += (r < NLA / 2 ? 2u : 1u) * kstep_a;  // half 0 is first loaded for tile 2, half 1 for tile 1
 #pragma unroll
   for (int r = 0; r < NLB; ++r) offb[r] += (r < NLB / 2 ? 2u : 1u) * kstep_b;
-  const int64_t n_fast = (tile_inside && voff_ok) ? max((int64_t)0, min(n_steps, (k_end - k_begin) / BK - 2)) : 0;
+  const int64_t n_fast = tile_inside ? max((int64_t)0, min(n_steps, (k_end - k_begin) / BK - 2)) : 0;
   f32x4 pa[NLA / 2], pb[NLB / 2];  // refill pieces in flight
-  auto issue_half = [&](int half, int64_t k0, auto fast_tag) __attribute__((always_inline)) {
-    if constexpr (decltype(fast_tag)::value) {
+  // MODE 1: unguarded buffer loads (tile completely inside the K-slice); MODE 2: the same loads, pieces whose k lies beyond
+  // the slice are zeroed on their way into LDS (the K tail: a piece is 4 consecutive k of one row or 4 columns of one k, and
+  // K % 4 == 0 on this path, so a piece is entirely in or out); MODE 0: guarded 64-bit-addressed loads (unaligned operands).
+  auto issue_half = [&](int half, int64_t k0, auto mode_tag) __attribute__((always_inline)) {
+    if constexpr (decltype(mode_tag)::value != 0) {
 #pragma unroll
       for (int r = 0; r < NLA / 2; ++r) {
         pa[r] = buffer_load_x4(ra0, offa[half * (NLA / 2) + r]);
@@ -311,16 +319,28 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
         pb[r] = load_piece<TB, ALIGNED, BN, NT>(half * (NLB / 2) + r, B, ldb, N, n0, k0, k_end, tid);
     }
   };
-  auto retire_half = [&](int half, float* a_nxt, float* b_nxt) __attribute__((always_inline)) {
+  auto retire_half = [&](int half, float* a_nxt, float* b_nxt, int64_t k0, auto mode_tag) __attribute__((always_inline)) {
+    constexpr bool MASK = decltype(mode_tag)::value == 2;
 #pragma unroll
-    for (int r = 0; r < NLA / 2; ++r) store_piece<!TA, BM, NT>(half * (NLA / 2) + r, a_nxt, pa[r], tid);
+    for (int r = 0; r < NLA / 2; ++r) {
+      f32x4 v = pa[r];
+      if (MASK && k0 + piece_k<!TA, BM, NT>(half * (NLA / 2) + r, tid) >= k_end) v = f32x4(0.f);
+      store_piece<!TA, BM, NT>(half * (NLA / 2) + r, a_nxt, v, tid);
+    }
 #pragma unroll
-    for (int r = 0; r < NLB / 2; ++r) store_piece<TB, BN, NT>(half * (NLB / 2) + r, b_nxt, pb[r], tid);
+    for (int r = 0; r < NLB / 2; ++r) {
+      f32x4 v = pb[r];
+      if (MASK && k0 + piece_k<TB, BN, NT>(half * (NLB / 2) + r, tid) >= k_end) v = f32x4(0.f);
+      store_piece<TB, BN, NT>(half * (NLB / 2) + r, b_nxt, v, tid);
+    }
   };
-  if (n_steps > 1) issue_half(0, k_begin + BK, std::false_type{});
+  using Slow = std::integral_constant<int, 0>;
+  using Fast = std::integral_constant<int, 1>;
+  using FastTail = std::integral_constant<int, 2>;
+  if (n_steps > 1) issue_half(0, k_begin + BK, Slow{});
 
-  auto k_step = [&](int64_t t, auto fast_tag) __attribute__((always_inline)) {
-    constexpr bool FAST = decltype(fast_tag)::value;
+  auto k_step = [&](int64_t t, auto mode_tag) __attribute__((always_inline)) {
+    constexpr bool FAST = decltype(mode_tag)::value == 1;
     const int cur = t & 1;
     const bool has1 = FAST || (t + 1 < n_steps), has2 = FAST || (t + 2 < n_steps);
     const int64_t k1 = k_begin + (t + 1) * BK, k2 = k1 + BK;
@@ -331,8 +351,11 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     // One scheduling region per k-group; inside it every memory instruction is paired with one MFMA (64 clocks of matrix
     // pipe each), so the wave's non-MFMA issue slots hide behind its own MFMAs instead of forming a burst during which the
     // pipe only runs if the SIMD's other wave happens to be in a different phase (both run this same code in step).
+    // the last step of a K-slice runs only the k-groups that hold data (K = 2000: 16 of its 32 k)
+    const int live_groups = FAST ? BK / 8 : (int)((min(k_end - (k1 - BK), (int64_t)BK) + 7) / 8);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
+      if (!FAST && g >= live_groups) break;  // only ever true in the last step (has1 == false): nothing left to retire
       if (g == BK / 8 - 1 && has1) {
         // this wave's ds_writes of tile t+1 are complete (lgkmcnt), then the workgroup meets; no vmcnt(0): the loads of
         // tile t+2 stay in flight.  Nobody reads tile t's buffer any more (the g=3 fragments are in registers).
@@ -349,12 +372,12 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
         read_frags<TB, TN, BN>(fb[0], b_nxt, b_span, i32, 0, h);
       }
       if (g == 0 && has1) {
-        retire_half(0, a_nxt, b_nxt);
-        issue_half(1, k1, fast_tag);
+        retire_half(0, a_nxt, b_nxt, k1, mode_tag);
+        issue_half(1, k1, mode_tag);
       }
       if (g == 2) {
-        if (has1) retire_half(1, a_nxt, b_nxt);
-        if (has2) issue_half(0, k2, fast_tag);
+        if (has1) retire_half(1, a_nxt, b_nxt, k1, mode_tag);
+        if (has2) issue_half(0, k2, mode_tag);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
@@ -389,8 +412,12 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     }
   };
   int64_t t = 0;
-  for (; t < n_fast; ++t) k_step(t, std::true_type{});
-  for (; t < n_steps; ++t) k_step(t, std::false_type{});
+  for (; t < n_fast; ++t) k_step(t, Fast{});
+  if constexpr (ALIGNED) {
+    for (; t < n_steps; ++t) k_step(t, FastTail{});
+  } else {
+    for (; t < n_steps; ++t) k_step(t, Slow{});
+  }
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
   float* out = C;
@@ -519,7 +546,12 @@ extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int tra
       return dh::fail(DH_ERR_WORKSPACE, "dh_gemm_f32: workspace %zu < %zu bytes", workspace_bytes, need);
     slabs = static_cast<float*>(workspace);
   }
-  const bool aligned = dh::aligned16(A) && dh::aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 &&
+  // the fast path addresses a block's K-slice with 32-bit lane offsets from the block origin
+  const int64_t k_span = (p.k_chunk < K ? p.k_chunk : K) + BK;
+  const int64_t span_a = k_span * (trans_a ? lda : 1) * 4 + (int64_t)CfgLarge::BM * lda * 4 + 4096;
+  const int64_t span_b = k_span * (trans_b ? 1 : ldb) * 4 + (int64_t)CfgLarge::BN * ldb * 4 + 4096;
+  const bool fast_path_ok = span_a < 0xffffffffLL && span_b < 0xffffffffLL;
+  const bool aligned = fast_path_ok && dh::aligned16(A) && dh::aligned16(B) && lda % 4 == 0 && ldb % 4 == 0 &&
                        // K-contiguous operands are read 4 k at a time, M/N-contiguous ones are
                        // guarded per element at the edge, so only K % 4 matters for the former
                        ((trans_a != 0 && trans_b == 0) || K % 4 == 0);

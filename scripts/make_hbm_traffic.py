@@ -10,8 +10,8 @@ names = {  # bench.py kernel key -> (device kernel name, launches per C-ABI call
     "gemm_f32_nn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, false, false, true>", 1),
     "gemm_f32_tn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, false, true>", 1),
     # the 512-wide SpMM runs as four 128-column passes (spmm.hip): bytes per call = 4 x bytes per launch
-    "spmm_csr_f32[fwd]": ("spmm_csr_kernel<32, 4, 1, false, true>", 4),
-    "spmm_csr_f32[bwd]": ("spmm_csr_kernel<32, 4, 1, false, true>", 4),
+    "spmm_csr_f32[fwd]": ("spmm_slice128_kernel<false, true, true>", 4),   # records the ReLU bitmap
+    "spmm_csr_f32[bwd]": ("spmm_slice128_kernel<true, false, true>", 4),   # applies it to the gathered dY rows
 }
 out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                    "scripts/refresh_round.sh, bench.py at 1M cells); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024: on "
