@@ -48,6 +48,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A/B switches for scripts/gemm_variants.sh (defaults = the measured winners)
+#ifndef DH_GEMM_LIVEGROUPS
+#define DH_GEMM_LIVEGROUPS 1
+#endif
 #ifndef DH_GEMM_SLICEMAP
 #define DH_GEMM_SLICEMAP 1  // split-K: all tiles of a K-slice on one XCD
 #endif
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     const int live_groups = FAST ? BK / 8 : (int)((min(k_end - (k1 - BK), (int64_t)BK) + 7) / 8);
 #pragma unroll
     for (int g = 0; g < BK / 8; ++g) {
-      if (!FAST && g >= live_groups) break;  // only ever true in the last step (has1 == false): nothing left to retire
+      if (DH_GEMM_LIVEGROUPS && !FAST && g >= live_groups) break;  // only ever true in the last step (has1 == false): nothing left to retire
       if (g == BK / 8 - 1 && has1) {
         // this wave's ds_writes of tile t+1 are complete (lgkmcnt), then the workgroup meets; no vmcnt(0): the loads of
         // tile t+2 stay in flight.  Nobody reads tile t's buffer any more (the g=3 fragments are in registers).

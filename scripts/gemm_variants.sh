@@ -4,10 +4,8 @@
 #   run (on the GPU box):   bash scripts/gemm_variants.sh run  > gpurun_out/gemm_variants.jsonl
 # Variants: name:flags
 VARIANTS=(
-  "p3m1:-DDH_GEMM_PIPE=3 -DDH_GEMM_VOFF=0"
-  "p3v:-DDH_GEMM_PIPE=3 -DDH_GEMM_VOFF=1"
-  "p3vsmall:-DDH_GEMM_PIPE=3 -DDH_GEMM_VOFF=1 -DDH_GEMM_FORCE_SMALL"
-  "p2v:-DDH_GEMM_PIPE=2 -DDH_GEMM_VOFF=1"
+  "lg1:-DDH_GEMM_LIVEGROUPS=1"
+  "lg0:-DDH_GEMM_LIVEGROUPS=0"
 )
 R=$(cd "$(dirname "$0")/.." && pwd)
 V=$R/build/variants

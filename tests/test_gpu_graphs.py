@@ -166,6 +166,28 @@ def test_neighbor_graph_connectivities(cuda_device, n, d, k):
     assert np.all(np.abs(got - want) <= want * 2.5e-7 * (4 + a) + 1e-12)
 
 
+def test_umap_closed_form_known_answers_on_device(cuda_device):
+    """The hand-computed fuzzy simplicial sets of tests/test_oracle_graphs.py (closed form of the published algorithm)
+    against the HIP kernels directly — the known-answer pin of row A11 that does not go through the numpy restatement."""
+    from dance_amd import kernels
+    from test_oracle_graphs import _umap_known_answer_case
+    pts, a, b, c = _umap_known_answer_case()
+    idx, dist = kernels.knn(_t(pts, cuda_device), 3)
+    (rp, col, val), (sigma, rho) = kernels.umap_connectivities(idx, dist)
+    sigma, rho = sigma.cpu().numpy(), rho.cpu().numpy()
+    for t in range(3):
+        assert np.allclose(rho[3 * t:3 * t + 3], [a, a, b])
+        assert np.allclose(sigma[3 * t:3 * t + 3], np.array([b, b - a, a]) / -np.log(c), rtol=3e-5)
+    import scipy.sparse as sp
+    d = sp.csr_matrix((val.cpu().numpy(), col.cpu().numpy(), rp.cpu().numpy()), shape=(9, 9)).toarray()
+    w02, w12 = c + c - c * c, c + 1 - c
+    for t in range(3):
+        assert np.allclose(d[3 * t:3 * t + 3, 3 * t:3 * t + 3], [[0, 1, w02], [1, 0, w12], [w02, w12, 0]], atol=2e-5)
+    idx2, dist2 = kernels.knn(_t(pts, cuda_device), 2)
+    (_, _, val2), (sigma2, _) = kernels.umap_connectivities(idx2, dist2)
+    assert bool((sigma2 == 1.0).all()) and bool((val2 == 1.0).all())
+
+
 def test_exclusive_scan(cuda_device):
     from dance_amd import kernels
     for n in (1, 5, 1000, 100_003):

@@ -51,6 +51,43 @@ def test_umap_connectivities_properties():
     assert np.array_equal(pat.indptr, conn.indptr) and np.array_equal(pat.indices, conn.indices)
 
 
+def _umap_known_answer_case():
+    """Inputs whose fuzzy simplicial set has a closed form under umap-learn's published algorithm (scanpy / umap-learn are not
+    installable here, so these hand-computed values are the known-answer pin of row A11).  Three well-separated triples of
+    collinear points at 0, a, a + b (k = 3, self first): for the outer points rho = d1 and
+    1 + exp(-(d2 - d1) / sigma) = log2(3)  =>  sigma = (d2 - d1) / -ln(log2(3) - 1),  membership(2nd neighbour) = log2(3) - 1."""
+    a, b = 1.0, 2.5
+    pts = np.array([[o, 0.0] for base in (0.0, 100.0, 200.0) for o in (base, base + a, base + a + b)], dtype=np.float32)
+    c = float(np.log2(3.0) - 1.0)
+    return pts, a, b, c
+
+
+def test_umap_closed_form_known_answers():
+    pts, a, b, c = _umap_known_answer_case()
+    idx, dist = og.knn_exact(pts, 3)
+    sig, rho = og.smooth_knn_dist(dist, 3.0)
+    # point 0 of a triple: neighbours at a, a + b; point 1: at a, b; point 2: at b, a + b
+    for t in range(3):
+        assert np.allclose(rho[3 * t:3 * t + 3], [a, a, b])
+        want_sigma = np.array([b, b - a, a]) / -np.log(c)   # (d2 - d1) / -ln(log2 3 - 1)
+        assert np.allclose(sig[3 * t:3 * t + 3], want_sigma, rtol=3e-5)  # bisection stops at |psum - log2 k| < 1e-5
+    conn, _, _ = og.fuzzy_simplicial_set(idx, dist, 3)
+    d = conn.toarray()
+    for t in range(3):
+        blk = d[3 * t:3 * t + 3, 3 * t:3 * t + 3]
+        # directed memberships: nearest neighbour 1, second neighbour c; union a + b - ab
+        w01 = 1 + 1 - 1          # 0 -> 1 nearest (1), 1 -> 0 nearest (1)
+        w02 = c + c - c * c      # 0 -> 2 second (c), 2 -> 0 second (c)
+        w12 = c + 1 - c * 1      # 1 -> 2 second (c), 2 -> 1 nearest (1)
+        assert np.allclose(blk, [[0, w01, w02], [w01, 0, w12], [w02, w12, 0]], atol=2e-5)
+    assert d.sum() == sum(d[3 * t:3 * t + 3, 3 * t:3 * t + 3].sum() for t in range(3))  # no edges between triples
+    # k = 2: psum = 1 = log2(2) at the first iterate, so sigma = 1 and every kNN edge has membership exactly 1
+    idx2, dist2 = og.knn_exact(pts, 2)
+    sig2, _ = og.smooth_knn_dist(dist2, 2.0)
+    conn2, _, _ = og.fuzzy_simplicial_set(idx2, dist2, 2)
+    assert np.all(sig2 == 1.0) and np.all(conn2.data == 1.0)
+
+
 def test_cell_feature_graph_reference_order():
     feat = np.array([[0, 2, 0], [1, 0, 3]], dtype=np.float32)  # 2 cells x 3 genes
     g = og.cell_feature_graph(feat, normalize_edges=False)
