@@ -25,6 +25,8 @@
 // are translation invariant (any mu is admissible — its rounding only costs efficiency), the subtraction's own rounding
 // moves d2 by <= 2 |x-y| u (|x'| + |y'|) <= 4 u (|x'|^2 + |y'|^2), well inside the slack above, and embeddings with a
 // large common offset (or non-negative expression rows) no longer inflate the survivor lists.  Inputs must be finite.
+#include <type_traits>
+
 #include "gemm_bf16_tile.h"
 
 namespace {
@@ -53,10 +55,26 @@ __global__ __launch_bounds__(256) void knn_mean_kernel(int64_t n, int64_t d, int
   mu[t] = s / (float)n;
 }
 
+// exact three-way split of an fp32 value into bf16 terms (24 = 8 + 8 + 8 significant bits): v == hi + mid + lo
+__device__ __forceinline__ void split3(float v, unsigned int out[3]) {
+  out[0] = f32_to_bf16(v);
+  if (!(fabsf(v) < __int_as_float(0x7f800000))) {  // +-inf thresholds (rows that pass everything / nothing): no inf - inf
+    out[1] = out[2] = 0u;
+    return;
+  }
+  const float r1 = v - widen(out[0]);
+  out[1] = f32_to_bf16(r1);
+  out[2] = f32_to_bf16(r1 - widen(out[1]));
+}
+
 // x' = x - mu; norms[r] = sum_t x'[r][t]^2 (one wavefront per row); A2[r] = [hi | hi | lo | 0], B2[r] = [hi | lo | hi | 0] of
-// x', each part dp wide, rows K3 = roundup(3 dp, 16) long
+// x', each part dp wide, rows K3 = roundup(3 dp, 16) long.
+// FOLD (query-stationary kernel, d <= 64): the whole filter test rides the matrix cores.  A2[r] = [-2 hi | -2 hi | -2 lo |
+// -Rq split3 (written by knn_thresholds_kernel) | 1 1 1 | 0], B2[r] = [hi | lo | hi | 1 1 1 | Cn split3 | 0] with
+// Cn = (1 - eps) |x'|^2, so that the accumulator IS  -2 q.c + Cn[c] - Rq[q]  and a pair survives iff it is <= 0.
+template <bool FOLD>
 __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
-                                                        const float* __restrict__ mu, int dp, int64_t K3,
+                                                        const float* __restrict__ mu, int dp, int64_t K3, float eps,
                                                         uint16_t* __restrict__ A2, uint16_t* __restrict__ B2,
                                                         float* __restrict__ norms) {
   const int lane = threadIdx.x & 63;
@@ -65,19 +83,33 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
   const float* x = X + r * ldx;
   uint16_t* a = A2 + r * K3;
   uint16_t* b = B2 + r * K3;
-  for (int t = 3 * dp + lane; t < K3; t += 64) a[t] = b[t] = 0;
+  for (int t = 3 * dp + (FOLD ? 6 : 0) + lane; t < K3; t += 64) a[t] = b[t] = 0;
   float s = 0.f;
   for (int t = lane; t < dp; t += 64) {
     const float v = t < d ? x[t] - mu[t] : 0.f;
     s = fmaf(v, v, s);
     const unsigned int hi = f32_to_bf16(v);
     const unsigned int lo = f32_to_bf16(v - widen(hi));  // exact subtraction: hi is v rounded to 8 bits
-    a[t] = (uint16_t)hi; a[dp + t] = (uint16_t)hi; a[2 * dp + t] = (uint16_t)lo;
+    // -2 x: exponent + 1 and the sign flipped, exact in bf16 (finite inputs; an overflow to inf only widens the test)
+    const unsigned int ahi = FOLD ? f32_to_bf16(-2.f * widen(hi)) : hi, alo = FOLD ? f32_to_bf16(-2.f * widen(lo)) : lo;
+    a[t] = (uint16_t)ahi; a[dp + t] = (uint16_t)ahi; a[2 * dp + t] = (uint16_t)alo;
     b[t] = (uint16_t)hi; b[dp + t] = (uint16_t)lo; b[2 * dp + t] = (uint16_t)hi;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) norms[r] = s;
+  if (lane == 0) {
+    norms[r] = s;
+    if (FOLD) {
+      unsigned int c3[3];
+      split3((1.f - eps) * s, c3);
+      for (int i = 0; i < 3; ++i) {
+        a[3 * dp + 3 + i] = 0x3f80;  // 1.0 against Cn
+        b[3 * dp + i] = 0x3f80;      // 1.0 against -Rq
+        b[3 * dp + 3 + i] = (uint16_t)c3[i];
+        a[3 * dp + i] = 0;           // -Rq: knn_thresholds_kernel (query rows only)
+      }
+    }
+  }
 }
 
 // The filter test  |q|^2 + |c|^2 - 2 dot <= tau + eps (|q|^2 + |c|^2)  rearranged so that the epilogue is one fma and
@@ -85,12 +117,19 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
 // (eps carries a factor 2 of slack over the bound above, which also covers these few extra roundings.)
 __global__ __launch_bounds__(256) void knn_thresholds_kernel(int64_t n, int64_t q_begin, int64_t nq, int k, float eps,
                                                              const float* __restrict__ norms, const float* __restrict__ sample_d2,
-                                                             float* __restrict__ Rq, float* __restrict__ Cn, int32_t* __restrict__ counts) {
+                                                             float* __restrict__ Rq, float* __restrict__ Cn, int32_t* __restrict__ counts,
+                                                             uint16_t* __restrict__ A2_fold, int64_t K3, int dp) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) Cn[i] = (1.f - eps) * norms[i];
   if (i < nq) {
-    Rq[i] = sample_d2[i * k + (k - 1)] - (1.f - eps) * norms[q_begin + i];  // +inf when the sample held < k points
+    const float rq = sample_d2[i * k + (k - 1)] - (1.f - eps) * norms[q_begin + i];  // +inf when the sample held < k points
+    Rq[i] = rq;
     counts[i] = 0;
+    if (A2_fold) {  // the folded filter: -Rq rides three K columns of the query's A row
+      unsigned int r3[3];
+      split3(-rq, r3);
+      for (int j = 0; j < 3; ++j) A2_fold[(q_begin + i) * K3 + 3 * dp + j] = (uint16_t)r3[j];
+    }
   }
 }
 
@@ -132,15 +171,21 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
   }
 }
 
-// d <= 64 (K3 <= 192): "query-stationary" form of the same filter.  The tile kernel above re-reads both operands for
-// every 128 x 128 tile — 5.25 bytes of L2 traffic per pair at K3 = 168, which is what bounds it (counters: 4.6 TB/s
-// of L2 requests, matrix cores 13 % busy).  Here a block of 8 waves owns 256 queries for its whole life: each wave
-// keeps the MFMA A-fragments of its 64 queries (all of K3) in REGISTERS (thresholds in LDS), and the block only
-// streams 128-candidate tiles of B2 through a double-buffered LDS image (one barrier per tile) — 1.3 bytes per pair.
+// d <= 64: "query-stationary" form of the same filter.  The tile kernel above re-reads both operands for every
+// 128 x 128 tile — 5.25 bytes of L2 traffic per pair at K3 = 168, which is what bounds it (counters: 4.6 TB/s of L2
+// requests, matrix cores 13 % busy).  Here a block of 8 waves owns 256 queries for its whole life: each wave keeps the MFMA
+// A-fragments of its 64 queries (all of K3) in REGISTERS, and the block only streams 128-candidate tiles of B2 through a
+// double-buffered LDS image (one barrier per tile) — 1.3 bytes per pair.
+//
+// Round 2: the threshold test itself rides the matrix cores (FOLD layout of knn_split_kernel: the accumulator is
+// -2 q.c + Cn[c] - Rq[q], a pair survives iff it is <= 0), so the epilogue is one compare + one add-with-carry per pair
+// (was fma + compare against an LDS operand + shift/or), and it is ROTATED half a tile against the MFMAs: while the
+// matrix cores work on candidate sub-tile j of tile t the vector ALUs test sub-tile 1-j of the previous half, paired one
+// MFMA : three VALU ops by sched_group_barrier.  The six extra K columns cost no K-step at d = 50 (3 * 56 + 6 <= 176); their
+// products are exact and the extra accumulation roundings (<= 7 u (|q|^2 + |c|^2)) sit inside the factor 2 of slack in eps.
 template <int KS>  // 16-wide k steps: K3 = 16 KS
 __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64_t n, const uint16_t* __restrict__ A2,
-                                                               const uint16_t* __restrict__ B2, const float* __restrict__ Rq,
-                                                               const float* __restrict__ Cn, int32_t* __restrict__ counts,
+                                                               const uint16_t* __restrict__ B2, int32_t* __restrict__ counts,
                                                                int32_t* __restrict__ surv, int cap, int seg,
                                                                int64_t tiles_per_slice) {
   constexpr int K3 = 16 * KS;
@@ -148,19 +193,13 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
   constexpr int CPR = 2 * KS;              // 16-byte chunks per row
   constexpr int NCH = (BN * CPR + 511) / 512;
   extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // 2 x [BN][LD]
-  __shared__ float rq_s[256];
   __shared__ int cnt_s[256];  // survivors appended by THIS block per query: the block owns its 256 queries, so the
                               // list cursors are LDS atomics (~100 cycles) instead of returning global atomics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, kh = (lane >> 5) * 8;
   const int64_t m0 = (int64_t)blockIdx.x * 256 + wr * 64;
-  const float ninf = -__int_as_float(0x7f800000);
 
-  if (tid < 256) {
-    rq_s[tid] = ((int64_t)blockIdx.x * 256 + tid < nq) ? Rq[(int64_t)blockIdx.x * 256 + tid] : ninf;
-    cnt_s[tid] = 0;
-  }
-  const float* rq = rq_s + wr * 64 + 4 * (lane >> 5);  // row (i, r) of this lane at rq[i * 32 + (r & 3) + 8 * (r >> 2)]
+  if (tid < 256) cnt_s[tid] = 0;
   bf16x8 a[2][KS];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -173,19 +212,36 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
     }
   }
 
-  // (rows >= nq never pass the test: their threshold is -inf)
   int* cnt = cnt_s + wr * 64 + 4 * (lane >> 5);
-  int32_t* surv_base = surv + (m0 + 4 * (lane >> 5)) * cap + (int64_t)blockIdx.y * seg;  // this slice's segment
+  const int64_t row0 = m0 + 4 * (lane >> 5);                                      // query of accumulator register (i, r):
+  int32_t* surv_base = surv + row0 * cap + (int64_t)blockIdx.y * seg;  // row0 + i * 32 + (r & 3) + 8 * (r >> 2); this slice's segment
 
   const int64_t tiles_n = (n + BN - 1) / BN;
   const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_slice, t_hi = min(tiles_n, t_lo + tiles_per_slice);
   u32x4 stage[NCH];
-  auto load_tile = [&](int64_t t) {
+  // chunk s of this thread: row c / CPR of the tile, 16-byte column c % CPR (fixed per thread); only the last tile of the
+  // matrix can hold rows >= n, so every other tile is loaded without guards (the per-chunk 64-bit compares and branches of
+  // the guarded form were a sixth of the kernel's non-MFMA instructions)
+  const uint16_t* b_chunk[NCH];
 #pragma unroll
-    for (int s = 0; s < NCH; ++s) {
-      const int c = tid + 512 * s;
-      const int64_t row = t * BN + c / CPR;
-      stage[s] = (c < BN * CPR && row < n) ? *reinterpret_cast<const u32x4*>(B2 + row * K3 + (c % CPR) * 8) : u32x4(0u);
+  for (int s = 0; s < NCH; ++s) {
+    const int c = tid + 512 * s;
+    b_chunk[s] = B2 + (int64_t)(c / CPR) * K3 + (c % CPR) * 8;
+  }
+  const bool chunk_tail_live = tid + 512 * (NCH - 1) < BN * CPR;  // the last chunk index may run past the tile
+  auto load_tile = [&](int64_t t) {
+    const int64_t off = t * BN * (int64_t)K3;
+    if (t * BN + BN <= n) {
+#pragma unroll
+      for (int s = 0; s < NCH; ++s)
+        if (s + 1 < NCH || chunk_tail_live) stage[s] = *reinterpret_cast<const u32x4*>(b_chunk[s] + off);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NCH; ++s) {
+        const int c = tid + 512 * s;
+        const int64_t row = t * BN + c / CPR;
+        stage[s] = (c < BN * CPR && row < n) ? *reinterpret_cast<const u32x4*>(b_chunk[s] + off) : u32x4(0u);
+      }
     }
   };
   auto store_tile = [&](int buf) {
@@ -195,63 +251,97 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
       if (c < BN * CPR) *reinterpret_cast<u32x4*>(lds + (size_t)buf * BN * LD + (c / CPR) * LD + (c % CPR) * 8) = stage[s];
     }
   };
+  f32x16 acc[2][2];
+  // Only lanes with a hit walk their set bits (an in-line "if (pass) append" per pair serialised ~10 returning atomics per
+  // tile and wave: 65 % of all wave cycles were spent waiting).  Both query sub-tiles advance together, so the two
+  // returning LDS atomics of a round are in flight at the same time and the wave waits once per round, not once per hit.
+  auto append = [&](int j, int64_t t, const unsigned int (&h)[2]) __attribute__((always_inline)) {
+    const int64_t c = t * BN + wc * 64 + j * 32 + lr;
+    const bool live = c < n;  // zero-padded candidate rows pass the folded test
+    unsigned int mk0 = live ? h[0] : 0u, mk1 = live ? h[1] : 0u;
+    while (mk0 | mk1) {
+      const int b0 = 31 - __clz(mk0 | 1u), b1 = 31 - __clz(mk1 | 1u);  // (| 1: defined for an empty mask, then unused)
+      const int r0 = 15 - b0, r1 = 15 - b1;
+      const int q0 = (r0 & 3) + 8 * (r0 >> 2), q1 = 32 + (r1 & 3) + 8 * (r1 >> 2);
+      // rows beyond the query range hold zero fragments and pass: skip them
+      const bool p0 = mk0 != 0u && row0 + q0 < nq, p1 = mk1 != 0u && row0 + q1 < nq;
+      int pos0 = 0, pos1 = 0;
+      if (p0) pos0 = atomicAdd(cnt + q0, 1);
+      if (p1) pos1 = atomicAdd(cnt + q1, 1);
+      if (p0 && pos0 < seg) surv_base[(int64_t)q0 * cap + pos0] = (int32_t)c;
+      if (p1 && pos1 < seg) surv_base[(int64_t)q1 * cap + pos1] = (int32_t)c;
+      mk0 &= ~(1u << b0);
+      mk1 &= ~(1u << b1);
+    }
+  };
+  // One half tile: all K steps of candidate sub-tile JM on the matrix cores (fragments four steps ahead of their MFMAs)
+  // while the vector ALUs take the pass bits of sub-tile JT from the previous half: bit (15 - r) of h[i] =
+  // [acc[i][JT][r] <= 0], one v_cmp + one v_addc (h + h + carry) per pair, a fixed number of pairs behind every MFMA.
+  // The order is written out and pinned (sched_barrier): left to itself the compiler sinks the pass bits into the
+  // (rarely taken) append branch behind the MFMAs and packs them with three VALU ops per pair.
+  auto half_tile = [&](auto jm_tag, const uint16_t* b_frag, unsigned int (&h)[2]) __attribute__((always_inline)) {
+    constexpr int JM = decltype(jm_tag)::value, JT = 1 - JM;
+    constexpr int PER = (32 + 2 * KS - 1) / (2 * KS);  // pairs behind each MFMA
+    constexpr int AHEAD = 4;  // fragment reads in flight ahead of their MFMAs (an LDS read is ~128 clocks, an MFMA pair 64)
+    bf16x8 b[KS];
+#pragma unroll
+    for (int kk = 0; kk < AHEAD && kk < KS; ++kk) b[kk] = *reinterpret_cast<const bf16x8*>(b_frag + JM * 32 * LD + kk * 16);
+    h[0] = h[1] = 0u;
+#pragma unroll
+    for (int m = 0; m < 2 * KS; ++m) {
+      const int kk = m >> 1, i = m & 1;
+      if (i == 0 && kk + AHEAD < KS) b[kk + AHEAD] = *reinterpret_cast<const bf16x8*>(b_frag + JM * 32 * LD + (kk + AHEAD) * 16);
+      if (kk == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[kk], z, 0, 0, 0);
+      } else {
+        acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[kk], acc[i][JM], 0, 0, 0);
+      }
+#pragma unroll
+      for (int e = m * PER; e < (m + 1) * PER && e < 32; ++e)
+        asm("v_cmp_ge_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h[e >> 4]) : "v"(acc[e >> 4][JT][e & 15]) : "vcc");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   load_tile(t_lo < t_hi ? t_lo : 0);
   store_tile(0);
   __syncthreads();
   int cur = 0;
+  unsigned int h[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][1][r] = 1.f;  // nothing passes in the first rotated half
   for (int64_t t = t_lo; t < t_hi; ++t) {
-    if (t + 1 < t_hi) load_tile(t + 1);  // in flight behind the MFMAs
     const uint16_t* b_frag = lds + (size_t)cur * BN * LD + (wc * 64 + lr) * LD + kh;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      bf16x8 b[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const bf16x8*>(b_frag + j * 32 * LD + kk * 16);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (kk == 0) {
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j], z, 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[j], acc[i][j], 0, 0, 0);
-          }
-        }
-    }
-    // Epilogue in two steps so that the common case costs ~3 VALU ops per pair and no branch: (1) one pass bit per
-    // pair into two 32-bit masks per lane, (2) only lanes with a hit walk their set bits.  (An in-line "if (pass)
-    // append" per pair serialised ~10 returning atomics per tile and wave: 65 % of all wave cycles were spent waiting.)
-    unsigned int hits[2] = {0u, 0u};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t c = t * BN + wc * 64 + j * 32 + lr;
-      const float cn = c < n ? Cn[c] : __int_as_float(0x7f800000);  // +inf never passes
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          hits[i] = (hits[i] << 1) | (fmaf(-2.f, acc[i][j][r], cn) <= rq[i * 32 + (r & 3) + 8 * (r >> 2)] ? 1u : 0u);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      unsigned int mk = hits[i];
-      while (mk) {
-        const int b = 31 - __clz(mk);
-        mk &= ~(1u << b);
-        const int e = 31 - b, j = e >> 4, r = e & 15;  // element e = j * 16 + r was shifted in e-th
-        const int row = i * 32 + (r & 3) + 8 * (r >> 2);
-        const int pos = atomicAdd(cnt + row, 1);
-        if (pos < seg) surv_base[(int64_t)row * cap + pos] = (int32_t)(t * BN + wc * 64 + j * 32 + lr);
-      }
-    }
+    // half A: matrix cores on sub-tile 0 of tile t, vector ALUs on sub-tile 1 of tile t - 1 (first tile: preset to "no pass")
+    __builtin_amdgcn_sched_barrier(0);
+    half_tile(std::integral_constant<int, 0>{}, b_frag, h);
+    append(1, t - 1, h);
+    // the next tile's loads go out here, behind the appends of this half: the compiler drains vmcnt (the appends' global
+    // stores) in front of the MFMA block that follows them, and loads issued before that point would be drained with them
+    if (t + 1 < t_hi) load_tile(t + 1);
+    // half B: matrix cores on sub-tile 1, vector ALUs on sub-tile 0 of the same tile
+    __builtin_amdgcn_sched_barrier(0);
+    half_tile(std::integral_constant<int, 1>{}, b_frag, h);
+    append(0, t, h);
     if (t + 1 < t_hi) store_tile(cur ^ 1);
     __syncthreads();  // everyone is done with `cur` and the next image is complete
     cur ^= 1;
   }
+  if (t_hi > t_lo) {  // the last half's pass bits
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      h[i] = 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h[i] = h[i] + h[i] + (unsigned int)(acc[i][1][r] <= 0.f);
+    }
+    append(1, t_hi - 1, h);
+  }
+  __syncthreads();
   if (tid < 256 && (int64_t)blockIdx.x * 256 + tid < nq) counts[(int64_t)blockIdx.y * nq + (int64_t)blockIdx.x * 256 + tid] = cnt_s[tid];
 }
 
@@ -385,7 +475,10 @@ int knn_filter_slices(int64_t nq) {
   return (int)(qblocks >= 512 ? 1 : ceil_div(512, qblocks));
 }
 
-int64_t knn_filter_k3(int64_t d) { return (3 * (int64_t)((d + 7) / 8 * 8) + 15) / 16 * 16; }
+// bf16 columns of an operand row: three dp-wide parts, for d <= 64 (the query-stationary kernel) plus the six columns that
+// carry the folded thresholds; rounded up to whole 16-wide MFMA steps
+bool knn_filter_folds(int64_t d) { return (d + 7) / 8 * 8 <= 64; }
+int64_t knn_filter_k3(int64_t d) { return (3 * (int64_t)((d + 7) / 8 * 8) + (knn_filter_folds(d) ? 6 : 0) + 15) / 16 * 16; }
 
 // Survivor lists: n_seg segments of `seg` slots per query (row stride n_seg * seg).  One segment for the tile kernel
 // (d > 64); one per candidate slice for the query-stationary kernel, each at least 1024 slots deep so that a query
@@ -394,7 +487,7 @@ void knn_filter_geometry(int64_t n, int64_t d, int64_t nq, int k, int* n_seg, in
   const int cap = knn_filter_cap(n, k);
   *n_seg = 1;
   *seg = cap;
-  if (knn_filter_k3(d) <= 192) {
+  if (knn_filter_folds(d)) {
     const int64_t tiles_n = ceil_div(n, BN);
     int64_t slices = knn_filter_slices(nq);
     if (slices > tiles_n) slices = tiles_n;
@@ -427,13 +520,17 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
   const int n_partial = (int)(n < kMeanBlocks ? n : kMeanBlocks);
   hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)n_partial), dim3(256), 0, st, n, d, X, ldx, mean_ws + d);
   hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, n, d, n_partial, mean_ws + d, mean_ws);
-  hipLaunchKernelGGL(knn_split_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, A2, B2, norms);
+  const bool fold = knn_filter_folds(d);
+  if (fold)
+    hipLaunchKernelGGL(knn_split_kernel<true>, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, eps, A2, B2, norms);
+  else
+    hipLaunchKernelGGL(knn_split_kernel<false>, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, eps, A2, B2, norms);
   hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, q_begin, nq, k, eps, norms,
-                     sample_d2, Rq, Cn, counts);
+                     sample_d2, Rq, Cn, counts, fold ? A2 : nullptr, K3, dp);
   int n_seg, seg;
   knn_filter_geometry(n, d, nq, k, &n_seg, &seg);
   const int cap = n_seg * seg;  // slots per query
-  if (K3 <= 192) {  // query-stationary kernel; candidate tiles sliced over grid.y until >= 2 rounds of blocks exist
+  if (fold) {  // query-stationary kernel; candidate tiles sliced over grid.y until >= 2 rounds of blocks exist
     const int64_t qblocks = ceil_div(nq, 256), tiles_n = ceil_div(n, BN);
     const int64_t tps = ceil_div(tiles_n, n_seg);
     dim3 grid((unsigned)qblocks, (unsigned)n_seg);
@@ -445,11 +542,11 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
                                                hipFuncAttributeMaxDynamicSharedMemorySize,                                     \
                                                (int)(2 * BN * (16 * KS + 8) * sizeof(uint16_t))) == hipSuccess;                \
     if (!ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");                        \
-    hipLaunchKernelGGL(knn_filter_small_kernel<KS>, grid, dim3(512), lds, st, nq, n, A2 + q_begin * K3, B2, Rq, Cn, counts,    \
+    hipLaunchKernelGGL(knn_filter_small_kernel<KS>, grid, dim3(512), lds, st, nq, n, A2 + q_begin * K3, B2, counts,            \
                        surv, cap, seg, tps);                                                                                   \
   } break
     switch (ks) {
-      DH_KNN_FS(2); DH_KNN_FS(3); DH_KNN_FS(5); DH_KNN_FS(6); DH_KNN_FS(8); DH_KNN_FS(9); DH_KNN_FS(11); DH_KNN_FS(12);
+      DH_KNN_FS(2); DH_KNN_FS(4); DH_KNN_FS(5); DH_KNN_FS(7); DH_KNN_FS(8); DH_KNN_FS(10); DH_KNN_FS(11); DH_KNN_FS(13);
       default: return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: unexpected filter depth %d", ks);
     }
 #undef DH_KNN_FS
