@@ -20,6 +20,7 @@ python $R/scripts/make_hbm_traffic.py $OUT/pmc_summary.json > $OUT/hbm_traffic.j
 cp $OUT/hbm_traffic.json $R/profiles/hbm_traffic.json; cd $R; python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; cat $OUT/bench_line.json; cd /tmp
 [ -n "$QUICK" ] || ( cd $R && timeout 400 python bench.py --cpu-sample-cells 1000000 --steps 5 --warmup 1 --no-knn-workload --no-x3-row > $OUT/bench_line_cpu1M.json 2> $OUT/bench_cpu1M.err )
 [ -n "$QUICK" ] || ( cd $R && python scripts/bench_rows.py > $OUT/rows.json 2> $OUT/rows.err; tail -c 600 $OUT/rows.json )
+[ -n "$QUICK" ] || ( bash $R/scripts/pmc_gemm2.sh $TAG/pmc_gemm2 > $OUT/gemm_pmc_vs_rocblas.json 2> $OUT/gemm_pmc.err; bash $R/scripts/pmc_knn2.sh $TAG/pmc_knn2 > $OUT/knn_filter_pmc.txt 2>&1 )
 # keep the merge-back small: drop the raw rocpd database, keep CSV/JSON
 find $OUT -name "*.db" -delete
 du -sh $OUT
