@@ -181,7 +181,10 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
 // -2 q.c + Cn[c] - Rq[q], a pair survives iff it is <= 0), so the epilogue is one compare + one add-with-carry per pair
 // (was fma + compare against an LDS operand + shift/or), and it is ROTATED half a tile against the MFMAs: while the
 // matrix cores work on candidate sub-tile j of tile t the vector ALUs test sub-tile 1-j of the previous half, paired one
-// MFMA : three VALU ops by sched_group_barrier.  The six extra K columns cost no K-step at d = 50 (3 * 56 + 6 <= 176); their
+// MFMA with a fixed number of test pairs behind it (order written out and pinned).  Measured at 1M x 50 (profiles/): 388 -> 353 ms;
+// ablation builds (-DDH_KNN_ABL=1: no appends) run 272 ms, i.e. the survivor appends (~960 per query, one returning LDS
+// atomic + one 4-byte global store each) cost 81 ms and the tile loop itself sits at ~59 % matrix-pipe utilisation behind its
+// one barrier per 128-candidate tile.  The six extra K columns cost no K-step at d = 50 (3 * 56 + 6 <= 176); their
 // products are exact and the extra accumulation roundings (<= 7 u (|q|^2 + |c|^2)) sit inside the factor 2 of slack in eps.
 template <int KS>  // 16-wide k steps: K3 = 16 KS
 __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64_t n, const uint16_t* __restrict__ A2,
@@ -256,6 +259,10 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
   // tile and wave: 65 % of all wave cycles were spent waiting).  Both query sub-tiles advance together, so the two
   // returning LDS atomics of a round are in flight at the same time and the wave waits once per round, not once per hit.
   auto append = [&](int j, int64_t t, const unsigned int (&h)[2]) __attribute__((always_inline)) {
+#if defined(DH_KNN_ABL) && (DH_KNN_ABL == 1 || DH_KNN_ABL == 2)
+    if (h[0] == 0xdeadbeefu && h[1] == 0x12345u) cnt[0] = 1;  // ablation build: keep h alive, never append
+    return;
+#endif
     const int64_t c = t * BN + wc * 64 + j * 32 + lr;
     const bool live = c < n;  // zero-padded candidate rows pass the folded test
     unsigned int mk0 = live ? h[0] : 0u, mk1 = live ? h[1] : 0u;
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
   // [acc[i][JT][r] <= 0], one v_cmp + one v_addc (h + h + carry) per pair, a fixed number of pairs behind every MFMA.
   // The order is written out and pinned (sched_barrier): left to itself the compiler sinks the pass bits into the
   // (rarely taken) append branch behind the MFMAs and packs them with three VALU ops per pair.
-  auto half_tile = [&](auto jm_tag, const uint16_t* b_frag, unsigned int (&h)[2]) __attribute__((always_inline)) {
+  auto half_tile = [&](auto jm_tag, const uint16_t* b_frag, unsigned int (&h)[2], int64_t prefetch_tile) __attribute__((always_inline)) {
     constexpr int JM = decltype(jm_tag)::value, JT = 1 - JM;
     constexpr int PER = (32 + 2 * KS - 1) / (2 * KS);  // pairs behind each MFMA
     constexpr int AHEAD = 4;  // fragment reads in flight ahead of their MFMAs (an LDS read is ~128 clocks, an MFMA pair 64)
@@ -303,6 +310,12 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
       for (int e = m * PER; e < (m + 1) * PER && e < 32; ++e)
         asm("v_cmp_ge_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h[e >> 4]) : "v"(acc[e >> 4][JT][e & 15]) : "vcc");
       __builtin_amdgcn_sched_barrier(0);
+      // the next tile's loads go out behind the FIRST MFMA of the tile: the compiler drains vmcnt (the previous half's append
+      // stores share the counter with loads) in front of this block, so this is the earliest point that keeps them in flight
+      if (JM == 0 && m == 0 && prefetch_tile >= 0) {
+        load_tile(prefetch_tile);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
 
@@ -319,17 +332,18 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
     const uint16_t* b_frag = lds + (size_t)cur * BN * LD + (wc * 64 + lr) * LD + kh;
     // half A: matrix cores on sub-tile 0 of tile t, vector ALUs on sub-tile 1 of tile t - 1 (first tile: preset to "no pass")
     __builtin_amdgcn_sched_barrier(0);
-    half_tile(std::integral_constant<int, 0>{}, b_frag, h);
+    half_tile(std::integral_constant<int, 0>{}, b_frag, h, t + 1 < t_hi ? t + 1 : -1);
     append(1, t - 1, h);
-    // the next tile's loads go out here, behind the appends of this half: the compiler drains vmcnt (the appends' global
-    // stores) in front of the MFMA block that follows them, and loads issued before that point would be drained with them
-    if (t + 1 < t_hi) load_tile(t + 1);
     // half B: matrix cores on sub-tile 1, vector ALUs on sub-tile 0 of the same tile
     __builtin_amdgcn_sched_barrier(0);
-    half_tile(std::integral_constant<int, 1>{}, b_frag, h);
+    half_tile(std::integral_constant<int, 1>{}, b_frag, h, -1);
     append(0, t, h);
     if (t + 1 < t_hi) store_tile(cur ^ 1);
+#if defined(DH_KNN_ABL) && DH_KNN_ABL == 3
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ablation build: no barrier (results are garbage)
+#else
     __syncthreads();  // everyone is done with `cur` and the next image is complete
+#endif
     cur ^= 1;
   }
   if (t_hi > t_lo) {  // the last half's pass bits

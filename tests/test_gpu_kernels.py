@@ -120,6 +120,32 @@ def test_gemm_f32(cuda_device, M, N, K, ta, tb):
     assert rel_err(c.cpu().numpy(), ref) < 1e-5  # exact-f32 MFMA chain: f32 round-off only
 
 
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_f32_k_boundaries(cuda_device, ta, tb):
+    """The refill pipeline of gemm_f32.hip switches between fast, fast-tail and (unaligned) guarded K-steps around
+    K = 32 t: every boundary, for aligned operands in both tile configurations, plus an accumulate into C."""
+    from dance_amd import kernels
+    g = torch.Generator(device=cuda_device).manual_seed(5)
+
+    def check(M, N, K, accumulate=False):
+        a = torch.randn((K, M) if ta else (M, K), device=cuda_device, generator=g)
+        b = torch.randn((N, K) if tb else (K, N), device=cuda_device, generator=g)
+        c0 = torch.randn(M, N, device=cuda_device, generator=g) if accumulate else None
+        ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double() + (c0.double() if accumulate else 0)
+        got = kernels.gemm(a, b, trans_a=ta, trans_b=tb, out=None if c0 is None else c0.clone(), accumulate=accumulate, mode="exact")
+        err = float((got.double() - ref).abs().max() / ref.abs().max())
+        assert err < 1e-5, (M, N, K, ta, tb, accumulate, err)
+
+    for K in (4, 8, 28, 32, 36, 60, 64, 68, 96, 100, 132, 2000):
+        check(260, 264, K)                    # 128 x 128 configuration, ragged edge tiles
+    check(260, 264, 100, accumulate=True)
+    for K in (36, 64, 100):
+        check(4100, 8192, K)                  # 256 x 256 configuration (>= 512 tiles), ragged M
+    if ta and not tb:
+        for K in (8200, 65536 + 36, 300_004):  # split-K slices with a K tail in the last slice
+            check(520, 512, K)
+
+
 def test_gemm_transpose_detecting_and_accumulate(cuda_device):
     # asymmetric operands (A = I-like selector, B[i][j] = i*1000 + j) catch swapped C rows/cols
     from dance_amd import kernels
