@@ -714,6 +714,30 @@ def sage_aggregate_dense(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col
     return gemm(A, Hw, out=out, accumulate=True, tag="gemm_f32_sage_dense")
 
 
+def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *, out_dtype=None) -> torch.Tensor:
+    """AdaptiveSAGE mean aggregation for CELL destinations (the result of ``sage_aggregate``) with the gene window
+    [col_begin, col_begin + n_cols) of H on the matrix cores and no dense adjacency in HBM (dh_sage_window_mfma: the
+    workgroup densifies 128 cells x 128 genes at a time in LDS); the other in-edges (self loops, at the rows' ends) are
+    added in the kernel's epilogue — one launch.
+    fp32 H: entries and features enter as bf16 hi + lo pairs (three exact products per term, fp32 accumulation, ~1e-5
+    worst-case relative error per term); bf16 H: features exact, entries hi + lo."""
+    lib = _lib_ready()
+    out_dtype = out_dtype or H.dtype
+    a = alpha.reshape(-1)
+    colscale = a[src_cell_id[col_begin:col_begin + n_cols].clamp(min=0).to(torch.int64)].contiguous()  # gnn.py:73
+    out = torch.empty((rowptr.numel() - 1, H.shape[1]), dtype=out_dtype, device=H.device)
+    ws_bytes = lib.dh_sage_window_mfma_workspace_bytes(n_cols, H.shape[1], _out_dtype(H.dtype))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=H.device)
+    # src / dst ids + alpha given: the kernel adds the out-of-window edges (self loops) itself and writes the mean
+    _call("sage_window_mfma", lib.dh_sage_window_mfma, rowptr.numel() - 1, H.shape[0], H.shape[1], col_begin, n_cols,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
+          _dev(colscale, torch.float32, "colscale", 1), _dev(H, H.dtype, "H", 2), _ld(H), _out_dtype(H.dtype), out.data_ptr(),
+          _ld(out), _out_dtype(out_dtype), col.numel(), _dev(src_cell_id, torch.int32, "src_cell_id", 1),
+          _dev(dst_cell_id, torch.int32, "dst_cell_id", 1), _dev(a, torch.float32, "alpha", 1), a.numel() - 2,
+          ws.data_ptr(), ws_bytes, _stream())
+    return out
+
+
 def sage_alpha_grad(rowptr, col, w, src_cell_id, dst_cell_id, n_genes, H, dneigh) -> torch.Tensor:
     """dalpha[idx(e)] += w_e <H[src(e)], dneigh[dst(e)]> / deg(dst(e)) (dh_sage_alpha_grad_f32)."""
     lib = _lib_ready()

@@ -374,6 +374,21 @@ DH_API int dh_sage_tail(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_g
                  const int32_t* rowptr, const int32_t* col, const float* w, const int32_t* src_cell_id,
                  const int32_t* dst_cell_id, const float* alpha, const void* H, int64_t ldh, int h_dtype,
                  void* neigh, int64_t ldn, int out_dtype, dh_stream_t stream);
+/* The same window product on the matrix cores WITHOUT the dense copy: neigh[v,:] += 1/deg(v) * sum over the in-edges
+ * (u -> v) with col_begin <= u < col_begin + n_cols of (w_e * colscale[u - col_begin]) * H[u,:].  A workgroup densifies its
+ * 128 cells x 128 window columns at a time into LDS in MFMA fragment order (adjacency entries and fp32 features split
+ * into bf16 hi + lo, fp32 accumulation: ~1e-5 worst-case relative error per term).  With src_cell_id / dst_cell_id / alpha
+ * (all three or none) the out-of-window in-edges (the self loops, at the rows' ends) are added in the epilogue with the
+ * alpha rule of dh_sage_aggregate_f32 and neigh is WRITTEN (the whole AdaptiveSAGE mean in one launch); without them neigh
+ * is accumulated into (dh_sage_tail initialises it).  Preconditions: inside a row the in-window edges are contiguous and ascending by column
+ * (CellFeatureGraph / block layout), width <= 448, n_cols <= 4096.  nnz = length of col / w (bounds the stream prefetch);
+ * workspace: dh_sage_window_mfma_workspace_bytes (the K-permuted bf16 planes of the window's feature rows).           */
+DH_API size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t width, int h_dtype);
+DH_API int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,
+                        const int32_t* rowptr, const int32_t* col, const float* w, const float* colscale,
+                        const void* H, int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
+                        const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha, int64_t n_genes,
+                        void* workspace, size_t workspace_bytes, dh_stream_t stream);
 DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
                            const int32_t* rowptr, const int32_t* col, const float* w,
                            const int32_t* src_cell_id, const int32_t* dst_cell_id,

@@ -70,6 +70,36 @@ def test_dense_cells(cuda_device, dtype, layout, n_cells, n_genes, width):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("layout", ["graph", "block"])
+@pytest.mark.parametrize("n_cells,n_genes,width,density", [(700, 90, 400, 0.12), (300, 1203, 104, 0.12), (1000, 500, 200, 0.12),
+                                                           (260, 2000, 400, 0.10), (130, 300, 448, 0.6)])
+def test_mfma_cells(cuda_device, dtype, layout, n_cells, n_genes, width, density):
+    """dh_sage_window_mfma (adjacency densified per workgroup in LDS, bf16 hi + lo splits on the matrix cores) against the
+    float64 restatement of gnn.py:62-90 and the gather kernel; the dense 0.6 case overflows the 16-entry stream prefetch."""
+    from dance_amd import kernels
+    rowptr, col, w, cid, dst_cid, gene_begin, n_src = _bipartite(n_cells, n_genes, density, n_cells + width, layout)
+    rng = np.random.default_rng(1)
+    h = torch.from_numpy(rng.standard_normal((n_src, width)).astype(np.float32)).to(DEV)
+    alpha = (rng.random(n_genes + 2) + 0.5).astype(np.float32)
+    if dtype == "bf16":
+        h = h.to(torch.bfloat16)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    args = (t(rowptr), t(col), t(w), t(cid), t(dst_cid), t(alpha), h)
+    ref = _ref(rowptr, col, w, cid, dst_cid, alpha.astype(np.float64), h.float().cpu().numpy(), n_genes)
+    if dtype == "f32":
+        got = kernels.sage_aggregate_mfma(*args, gene_begin, n_genes)
+        # three exact bf16 x bf16 products per term: 2^-18 residuals of the two splits + the dropped lo * lo
+        assert rel_err(got.cpu().numpy(), ref) < 1e-5
+        assert rel_err(got.cpu().numpy(), kernels.sage_aggregate(*args).cpu().numpy()) < 1e-5
+        assert torch.equal(got, kernels.sage_aggregate_mfma(*args, gene_begin, n_genes))  # deterministic
+    else:
+        f32 = kernels.sage_aggregate_mfma(*args, gene_begin, n_genes, out_dtype=torch.float32)
+        assert rel_err(f32.cpu().numpy(), ref) < 1e-5           # bf16 features are exact operands; entries hi + lo
+        got = kernels.sage_aggregate_mfma(*args, gene_begin, n_genes)
+        assert got.dtype == torch.bfloat16 and rel_err(got.float().cpu().numpy(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_dense_gene_rows(cuda_device, dtype):
     from dance_amd import kernels
     n_cells, n_genes, width = 20_000, 60, 128                   # window of 20k cell columns: the wide (scatter) path
