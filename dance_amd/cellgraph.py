@@ -108,6 +108,7 @@ class CellGeneGraph:
         blk.rowptr, blk.col, blk.val = self.rowptr[g:], self.col, self.val  # row pointers stay absolute offsets into col / val
         blk._num_src, blk._num_dst = n, n - g
         blk.parent, blk.dst_offset = self, g
+        blk.gene_window = (0, g)  # every destination is a cell; their gene in-neighbours are source rows [0, g)
         ids = torch.arange(n, device=self.device)
         blk.srcdata = _Frame(self.ndata)
         blk.srcdata["_ID"] = ids
@@ -196,6 +197,7 @@ class Block:
         self._num_src, self._num_dst = int(num_src), int(num_dst)
         self.parent = parent
         self.dst_offset = 0  # destination node i is source node dst_offset + i (0 for sampled blocks: dgl.to_block order)
+        self.gene_window = None  # (first source row, count) of the gene rows when every destination is known to be a cell
         self.srcdata = _GatherFrame(parent.ndata, src_ids)
         self.srcdata["_ID"] = src_ids
         self.dstdata = _GatherFrame(parent.ndata, src_ids[:num_dst])  # destination nodes = the first num_dst sources
@@ -266,11 +268,13 @@ class NeighborSampler:
             raise NotImplementedError("only full in-neighbour sampling ([-1]*L, edge_dir='in') is used by the hot path")
         self.num_layers = len(fanouts)
 
-    def sample(self, g: CellGeneGraph, seeds: torch.Tensor):
+    def sample(self, g: CellGeneGraph, seeds: torch.Tensor, cells_only: bool = False):
         blocks: List[Block] = []
         out_nodes = seeds
-        for _ in range(self.num_layers):
+        for layer in range(self.num_layers):
             blk = _full_in_block(g, seeds)
+            if cells_only and layer == 0:  # destinations = the seed cells, remaining sources = their genes (ascending id)
+                blk.gene_window = (blk.number_of_dst_nodes(), blk.number_of_src_nodes() - blk.number_of_dst_nodes())
             blocks.insert(0, blk)
             seeds = blk.srcdata["_ID"]
         return seeds, out_nodes, blocks
@@ -290,6 +294,10 @@ class DataLoader:
         self.indices = torch.as_tensor(indices, dtype=torch.int64).to(graph.device)  # seeds live where the graph lives
         self.batch_size, self.shuffle, self.drop_last, self.generator = batch_size, shuffle, drop_last, generator
         self.prefetch = prefetch
+        # seeds that are all cells of a CellFeatureGraph-layout graph: a one-layer block then is [seed cells | their genes,
+        # ascending], which lets AdaptiveSAGE aggregate on the matrix cores (one device read per loader, not per batch)
+        g = graph.gene_prefix() if hasattr(graph, "gene_prefix") else -1
+        self.cells_only = bool(g >= 0 and self.indices.numel() > 0 and int(self.indices.min()) >= g)
 
     def __len__(self):
         n = self.indices.numel()
@@ -306,7 +314,7 @@ class DataLoader:
         n = len(self)
         if not (self.prefetch and idx.is_cuda and n > 1):
             for i in range(n):
-                yield self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size])
+                yield self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size], self.cells_only)
             return
         # Blocks are built one batch ahead on a side stream: the builder's only host round trip (the size read between
         # dh_block_plan and dh_block_fill) then waits for a handful of small kernels instead of for the model's forward /
@@ -317,7 +325,7 @@ class DataLoader:
 
         def build(i):
             with torch.cuda.stream(side):
-                out = self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size])
+                out = self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size], self.cells_only)
                 ev = torch.cuda.Event()
                 ev.record(side)
             return out, ev

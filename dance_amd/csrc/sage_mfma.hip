@@ -595,6 +595,11 @@ extern "C" __attribute__((visibility("default"))) int dh_sage_mfma_prof_read(uns
 }
 #endif
 
+extern "C" int dh_sage_window_mfma_supported(int64_t n_cols, int64_t width, int h_dtype) {
+  if (n_cols <= 0 || width <= 0 || width > 32 * 2 * MAX_TILES || n_cols > 4096) return 0;
+  return geometry(n_cols, width, h_dtype == DH_DTYPE_BF16).lds_bytes <= 160 * 1024 ? 1 : 0;
+}
+
 extern "C" size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t width, int h_dtype) {
   if (n_cols <= 0 || width <= 0) return 0;
   return geometry(n_cols, width, h_dtype == DH_DTYPE_BF16).prep_bytes;

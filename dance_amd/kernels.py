@@ -714,6 +714,16 @@ def sage_aggregate_dense(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col
     return gemm(A, Hw, out=out, accumulate=True, tag="gemm_f32_sage_dense")
 
 
+# How AdaptiveSAGE aggregates into CELL destinations when the gene rows form a known window of the sources (CellFeatureGraph
+# layout, blocks of the device block builder): "mfma" = dh_sage_window_mfma where the shape fits, "gather" = always the gather
+# kernels (dh_sage_aggregate_f32 / _bf16).  Set with DANCE_AMD_SAGE.
+SAGE_MODE = os.environ.get("DANCE_AMD_SAGE", "mfma")
+
+
+def sage_mfma_supported(n_cols: int, width: int, dtype) -> bool:
+    return bool(_lib_ready().dh_sage_window_mfma_supported(int(n_cols), int(width), _out_dtype(dtype)))
+
+
 def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *, out_dtype=None) -> torch.Tensor:
     """AdaptiveSAGE mean aggregation for CELL destinations (the result of ``sage_aggregate``) with the gene window
     [col_begin, col_begin + n_cols) of H on the matrix cores and no dense adjacency in HBM (dh_sage_window_mfma: the

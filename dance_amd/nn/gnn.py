@@ -22,8 +22,15 @@ class _SageAggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, alpha, block):
         cid_src, cid_dst = block.srcdata["cell_id"], block.dstdata["cell_id"]
-        agg = kernels.sage_aggregate_bf16 if h.dtype == torch.bfloat16 else kernels.sage_aggregate  # C3: bf16 storage
-        neigh = agg(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous())
+        win = getattr(block, "gene_window", None)
+        if (win is not None and win[1] > 0 and kernels.SAGE_MODE == "mfma" and h.shape[1] % 4 == 0
+                and kernels.sage_mfma_supported(win[1], h.shape[1], h.dtype)):
+            # cell destinations whose gene rows are a known window of the sources: the matrix-core kernel (one launch)
+            neigh = kernels.sage_aggregate_mfma(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous(),
+                                                win[0], win[1])
+        else:
+            agg = kernels.sage_aggregate_bf16 if h.dtype == torch.bfloat16 else kernels.sage_aggregate  # C3: bf16 storage
+            neigh = agg(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous())
         ctx.block = block
         ctx.save_for_backward(h, alpha)
         return neigh

@@ -383,6 +383,7 @@ DH_API int dh_sage_tail(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_g
  * is accumulated into (dh_sage_tail initialises it).  Preconditions: inside a row the in-window edges are contiguous and ascending by column
  * (CellFeatureGraph / block layout), width <= 448, n_cols <= 4096.  nnz = length of col / w (bounds the stream prefetch);
  * workspace: dh_sage_window_mfma_workspace_bytes (the K-permuted bf16 planes of the window's feature rows).           */
+DH_API int dh_sage_window_mfma_supported(int64_t n_cols, int64_t width, int h_dtype);  /* 1 if the shape fits the kernel's LDS plan */
 DH_API size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t width, int h_dtype);
 DH_API int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,
                         const int32_t* rowptr, const int32_t* col, const float* w, const float* colscale,

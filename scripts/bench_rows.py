@@ -146,6 +146,15 @@ def main():
     rows[f"sage_aggregate_bf16 cell<-gene full graph cells={n_cells} D={dfeat} edges={e}"] = dict(
         ms=ms16, bound="hbm", achieved=byt16 / ms16 / 1e6, peak=HBM, unit="GB/s", frac=byt16 / ms16 / 1e6 / HBM,
         cells_per_s=n_cells / ms16 * 1e3, l2_gather_GBs=e * dfeat * 2.0 / ms16 / 1e6)
+    # the same aggregation on the matrix cores (dh_sage_window_mfma: adjacency densified per workgroup in LDS, bf16 hi + lo
+    # splits; dense-equivalent flops 2 N G D per product plane, 3 planes for fp32 features, 2 for bf16)
+    for tag, ft, planes in (("f32", feats, 3), ("bf16", feats16, 2)):
+        msm = gpu_ms(lambda: kernels.sage_aggregate_mfma(rp_cells, gcol, gval, cid, cid_cells, alpha, ft, 0, n_genes), iters=3)
+        fl = 2.0 * n_cells * n_genes * dfeat * planes
+        rows[f"sage_window_mfma {tag} cell<-gene full graph cells={n_cells} D={dfeat} edges={e}"] = dict(
+            ms=msm, bound="mfma", achieved=fl / msm / 1e9, peak=2500.0, unit="TFLOP/s (bf16 MFMA, dense-equivalent incl. the split planes)",
+            frac=fl / msm / 1e9 / 2500.0, cells_per_s=n_cells / msm * 1e3,
+            speedup_vs_gather=(ms if tag == "f32" else ms16) / msm)
     PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
     hid = 200
     h16 = feats16[n_genes:]  # [n_cells, 400] cell rows
