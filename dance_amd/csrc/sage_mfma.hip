@@ -221,18 +221,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint16_t* const a_grp = a_img + grp * A_GROUP;
   const int my_cell_local = 32 * nh + r;  // position of my stream's cell inside the group
   const int n_chunks = (J + JC - 1) / JC;
+  __syncthreads();  // the colscale table is complete; the first two feature blocks have landed (vmcnt is drained here)
   PROF_T(t_pro);
   PROF_ADD(0, t_start, t_pro);
   for (int chunk = 0; chunk < n_chunks; ++chunk) {
     PROF_T(t_c0);
     // ---- densify this chunk's window genes of the group's 64 cells into fragment order -----------------------------
     {
-      u32x4* z = reinterpret_cast<u32x4*>(a_grp);
-      constexpr int PIECES = A_GROUP / 8;  // 16-byte pieces, zeroed by the group's 128 lanes
+      // every stream owner clears exactly the 2 planes x JC fragment slots its own entries can land in (its cell, its k half),
+      // so no barrier is needed between the clearing and the scatter (LDS executes a lane's accesses in order)
+      u32x4* z = reinterpret_cast<u32x4*>(a_grp) + half * 64 + my_cell_local;
 #pragma unroll
-      for (int i = 0; i < PIECES / 128; ++i) z[(nh * 64 + lane) + 128 * i] = u32x4(0u);
+      for (int i = 0; i < 2 * JC; ++i) z[i * 128] = u32x4(0u);
     }
-    __syncthreads();
     PROF_T(t_c1);
     PROF_ADD(1, t_c0, t_c1);
     {
@@ -425,6 +426,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
         constexpr int y = decltype(y_c)::value;
         if (y < my_tiles) {  // wave-uniform
+        // the first out-of-window edge's feature segment (the self loop) is requested before the transpose and used after it
+        const int64_t c0p = (int64_t)(tile0 + y) * 32 + c16;
+        float hv0[16];
+        const bool pre = FOLD && n_tail > 0 && cell < n_dst && c0p < width;
+        if (pre) h_row16(tck[0], c0p, hv0);
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * half) * 36 + r] = acc[m][y][i];
         __builtin_amdgcn_wave_barrier();
@@ -440,8 +446,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const int64_t c0 = (int64_t)(tile0 + y) * 32 + c16;
         if (FOLD && cell < n_dst && c0 < width) {
           float hv[16];
+          if (pre) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
+            for (int e = 0; e < 16; ++e) v[e] = fmaf(tfk[0], hv0[e], v[e]);
+          }
+#pragma unroll
+          for (int q = 1; q < 4; ++q)
             if (q < n_tail) {
               h_row16(tck[q], c0, hv);
 #pragma unroll
