@@ -423,14 +423,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           }
         }
       };
+      // the first out-of-window edge's feature segments (the self loop's row of H: cold in the caches) are requested one tile
+      // ahead of their use
+      float hvp[2][16];
+      auto pre_ok = [&](int yy) -> bool { return FOLD && n_tail > 0 && cell < n_dst && yy < my_tiles && (int64_t)(tile0 + yy) * 32 + c16 < width; };
+      if (pre_ok(0)) h_row16(tck[0], (int64_t)tile0 * 32 + c16, hvp[0]);
       static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
         constexpr int y = decltype(y_c)::value;
         if (y < my_tiles) {  // wave-uniform
-        // the first out-of-window edge's feature segment (the self loop) is requested before the transpose and used after it
-        const int64_t c0p = (int64_t)(tile0 + y) * 32 + c16;
-        float hv0[16];
-        const bool pre = FOLD && n_tail > 0 && cell < n_dst && c0p < width;
-        if (pre) h_row16(tck[0], c0p, hv0);
+        const bool pre = pre_ok(y);
+        float (&hv0)[16] = hvp[y & 1];
+        if (y + 1 < NT && pre_ok(y + 1)) h_row16(tck[0], (int64_t)(tile0 + y + 1) * 32 + c16, hvp[(y + 1) & 1]);
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[((i & 3) + 8 * (i >> 2) + 4 * half) * 36 + r] = acc[m][y][i];
         __builtin_amdgcn_wave_barrier();
