@@ -387,3 +387,74 @@ def test_sharded_spagcn_fit_independent_of_world_size():
             assert np.array_equal(r[1], res[0][1]) and np.allclose(r[2], res[0][2], rtol=1e-6, atol=1e-7)   # every rank: same model, same output
         outs[world] = res[0]
     assert rel_err(outs[3][1], outs[1][1]) < 1e-4 and rel_err(outs[3][2], outs[1][2]) < 1e-4 and rel_err(outs[3][3], outs[1][3]) < 1e-5
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's own multi-rank helpers (never run on hardware here: the boxes have one GPU) on gloo / CPU tensors:
+    time_steps (barrier + MAX over ranks) and time_exchange_only for every exchange mode."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import bench
+    import cpu_ops
+    from dance_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, fin, fout, k = 90, 12, 8, 5
+        x, w, b, dy, adj = _problem(n, fin, fout, k, 11)
+        at = adj.T.tocsr()
+        at.sort_indices()
+        ranges, _ = sharding.row_ranges(n, world)
+        lo, hi = ranges[rank]
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
+        out = {}
+        for mode in ("halo", "allgather", "alltoall"):
+            a_sh = sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), lo, hi, n)
+            at_sh = sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), lo, hi, n)
+            full = None
+            if mode == "alltoall":
+                full = (sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), 0, n, n),
+                        sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), 0, n, n))
+            sg = sharding.ShardedGCNGraph(a_sh, at_sh, n, mode=mode, full=full)
+            xl, wt = torch.from_numpy(x[lo:hi].copy()), torch.from_numpy(w.copy()).requires_grad_(True)
+            dyl = torch.from_numpy(dy[lo:hi].copy())
+
+            def step():
+                wt.grad = None
+                sharding.sharded_gcn_layer(xl, wt, sg, None, True, ops=cpu_ops).backward(dyl)
+
+            class _NoTimer:
+                def __enter__(self):
+                    return self
+
+                def __exit__(self, *a):
+                    return False
+
+            elapsed, _ = bench.time_steps(step, dist.barrier, 2, 1, world, torch.device("cpu"), _NoTimer)
+            before = sg.stats["exchanged_bytes"]
+            ms, per_step = bench.time_exchange_only(sg, fout, 2, dist.barrier, torch.device("cpu"))
+            assert sg.stats["exchanged_bytes"] == before  # the dry exchange leaves the layer's own accounting alone
+            out[mode] = (elapsed, ms, per_step)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_multirank_helpers_on_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for mode in ("halo", "allgather", "alltoall"):
+        e0, ms0, b0 = res[0][mode]
+        e1, ms1, b1 = res[1][mode]
+        assert e0 == e1 > 0 and ms0 == ms1 > 0  # MAX over ranks: identical on both
+        assert b0 > 0 and b1 > 0
