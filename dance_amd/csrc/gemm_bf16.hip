@@ -45,13 +45,23 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(int64_t M, int64_t N,
                                                            int64_t lda, const uint16_t* __restrict__ B, int64_t ldb,
                                                            void* __restrict__ C, int64_t ldc, Epilogue ep,
                                                            float* __restrict__ slabs, int64_t k_per_slice) {
-  __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDT];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDT];
+  extern __shared__ __attribute__((aligned(16))) uint16_t tile_lds[];  // TILE_LDS_ELEMS bf16 (two pipeline stages)
   const int64_t tiles_n = (N + BN - 1) / BN;
-  const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM, n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
+  // XCD-aware bijective remap (the dispatcher places block b on XCD b % 8, observed): every XCD gets a contiguous run of
+  // logical tiles, so the column tiles that share an A row panel share one L2 (with the plain order each of the 8 XCDs
+  // fetched every panel itself: 1M x 2048 x 512 ran HBM-bound at 690 TFLOP/s)
+  const int64_t n_tiles = gridDim.x, bid = blockIdx.x;
+  const int64_t q = n_tiles / 8, rr = n_tiles % 8, xcd = bid % 8;
+  const int64_t logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + bid / 8;
+  // inside an XCD's run: groups of 8 tile rows x all tile columns, rows fastest, so the ~64 tiles an XCD runs at a time form a
+  // patch that shares 8 A panels and a few B panels instead of one A panel and every B panel
+  const int64_t tiles_m = n_tiles / tiles_n, GM = 8;
+  const int64_t group = logical / (GM * tiles_n), first_m = group * GM, in_group = logical % (GM * tiles_n);
+  const int64_t gm = min(GM, tiles_m - first_m);
+  const int64_t m0 = (first_m + in_group % gm) * BM, n0 = (in_group / gm) * BN;
   const int64_t k_begin = (int64_t)blockIdx.z * k_per_slice;
   const int64_t k_end = min(K, k_begin + k_per_slice);
-  nt_tile(M, N, k_begin, k_end, A, lda, B, ldb, m0, n0, As, Bs, [&](int64_t m, int64_t n, float v, int) {
+  nt_tile(M, N, k_begin, k_end, A, lda, B, ldb, m0, n0, tile_lds, [&](int64_t m, int64_t n, float v, int) {
     if (slabs) slabs[((int64_t)blockIdx.z * M + m) * N + n] = v;
     else store_out(C, ldc, m, n, v, ep);
   });
@@ -173,7 +183,11 @@ extern "C" int dh_gemm_bf16(int64_t M, int64_t N, int64_t K, int trans_a, int tr
   }
   float* slabs = p.slices > 1 ? reinterpret_cast<float*>(ws + p.a_bytes + p.b_bytes) : nullptr;
   dim3 grid((unsigned)(dh::ceil_div(M, BM) * dh::ceil_div(N, BN)), 1, (unsigned)p.slices);
-  hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), 0, st, M, N, K, a, la, b, lb, C, ldc, ep, slabs, p.k_per_slice);
+  constexpr size_t kTileLds = (size_t)TILE_LDS_ELEMS * sizeof(uint16_t);  // 72 KB: above the 64 KB default limit of dynamic LDS
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)kTileLds) == hipSuccess;
+  if (!lds_ok) return dh::fail(DH_ERR_LAUNCH, "dh_gemm_bf16: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(gemm_bf16_nt_kernel, grid, dim3(256), kTileLds, st, M, N, K, a, la, b, lb, C, ldc, ep, slabs, p.k_per_slice);
   if (slabs)
     hipLaunchKernelGGL(gemm_bf16_reduce_kernel, dim3((unsigned)dh::ceil_div(M * N, 256)), dim3(256), 0, st, M, N, p.slices, slabs, C, ldc, ep);
   return dh::check_launch("dh_gemm_bf16");

@@ -138,8 +138,7 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
                                                          const uint16_t* __restrict__ B2, const float* __restrict__ Rq,
                                                          const float* __restrict__ Cn, int32_t* __restrict__ counts,
                                                          int32_t* __restrict__ surv, int cap) {
-  __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDT];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDT];
+  extern __shared__ __attribute__((aligned(16))) uint16_t tile_lds[];  // TILE_LDS_ELEMS bf16 (two pipeline stages of nt_tile)
   __shared__ float rq[BM];
   const int64_t tiles_n = (n + BN - 1) / BN;
   const int64_t m0 = (int64_t)(blockIdx.x / tiles_n) * BM, n0 = (int64_t)(blockIdx.x % tiles_n) * BN;
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
   // pass bits first (branch-free), appends afterwards: an in-line "if (pass) atomicAdd" per element serialises one
   // returning global atomic per hit (see the query-stationary kernel below)
   unsigned long long hits = 0ull;
-  nt_tile(nq, n, 0, K3, A2, K3, B2, K3, m0, n0, As, Bs, [&](int64_t m, int64_t c, float dot, int e) {
+  nt_tile(nq, n, 0, K3, A2, K3, B2, K3, m0, n0, tile_lds, [&](int64_t m, int64_t c, float dot, int e) {
     const float cnj = ((e >> 4) & 1) ? cn[1] : cn[0];
     hits |= (unsigned long long)(fmaf(-2.f, dot, cnj) <= rq[m - m0] ? 1u : 0u) << e;
   });
@@ -567,7 +566,11 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
   } else {
     const int64_t tiles = ceil_div(nq, BM) * ceil_div(n, BN);
     if (tiles >= (int64_t)1 << 31) return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: too many filter tiles (%lld)", (long long)tiles);
-    hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)tiles), dim3(256), 0, st, nq, n, K3, A2 + q_begin * K3, B2, Rq, Cn, counts,
+    constexpr size_t kTileLds = (size_t)TILE_LDS_ELEMS * sizeof(uint16_t);
+    static const bool tile_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)kTileLds) == hipSuccess;
+    if (!tile_ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)tiles), dim3(256), kTileLds, st, nq, n, K3, A2 + q_begin * K3, B2, Rq, Cn, counts,
                        surv, cap);
   }
   const size_t lds = 4 * (size_t)(RR_CHUNK + 64) * sizeof(unsigned long long);
