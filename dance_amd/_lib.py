@@ -73,6 +73,9 @@ def _declare(lib):
         "dh_sage_tail": (c_int, [i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P]),
         "dh_softplus_rowsum_f32": (c_int, [i64, i64, P, i64, P, P]),
         "dh_sigmoid_scale_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
+        "dh_gram_sigmoid_supported": (c_int, [i64, i64]),
+        "dh_gram_sigmoid_workspace_bytes": (c_size_t, [i64, i64]),
+        "dh_gram_sigmoid_f32": (c_int, [i64, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_rowsum_masked_f32": (c_int, [i64, i64, P, i64, P, P, P]),
         "dh_rowscale_log1p_f32": (c_int, [i64, i64, P, i64, P, i32, c_double, P, i64, P]),
         "dh_col_standardize_f32": (c_int, [i64, i64, P, i64, P, P, c_double, P, i64, P]),

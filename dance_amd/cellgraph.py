@@ -289,8 +289,12 @@ class DataLoader:
 
     def __init__(self, graph: CellGeneGraph, indices, sampler: NeighborSampler, batch_size: int = 1,
                  shuffle: bool = False, drop_last: bool = False, generator: Optional[torch.Generator] = None, prefetch: bool = True,
-                 **_ignored):
+                 block_hook=None, **_ignored):
         self.graph, self.sampler = graph, sampler
+        # block_hook(blocks) runs right after a batch's blocks are built, on the stream that built them (the side stream when
+        # prefetching): per-batch set-up whose results the host needs (e.g. a count) then never waits for the model's kernels.
+        # Its return value is stored as blocks[-1].hook_out.
+        self.block_hook = block_hook
         self.indices = torch.as_tensor(indices, dtype=torch.int64).to(graph.device)  # seeds live where the graph lives
         self.batch_size, self.shuffle, self.drop_last, self.generator = batch_size, shuffle, drop_last, generator
         self.prefetch = prefetch
@@ -314,7 +318,10 @@ class DataLoader:
         n = len(self)
         if not (self.prefetch and idx.is_cuda and n > 1):
             for i in range(n):
-                yield self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size], self.cells_only)
+                out = self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size], self.cells_only)
+                if self.block_hook is not None:
+                    out[2][-1].hook_out = self.block_hook(out[2])
+                yield out
             return
         # Blocks are built one batch ahead on a side stream: the builder's only host round trip (the size read between
         # dh_block_plan and dh_block_fill) then waits for a handful of small kernels instead of for the model's forward /
@@ -326,6 +333,8 @@ class DataLoader:
         def build(i):
             with torch.cuda.stream(side):
                 out = self.sampler.sample(self.graph, idx[i * self.batch_size:(i + 1) * self.batch_size], self.cells_only)
+                if self.block_hook is not None:
+                    out[2][-1].hook_out = self.block_hook(out[2])
                 ev = torch.cuda.Event()
                 ev.record(side)
             return out, ev
@@ -337,7 +346,9 @@ class DataLoader:
                 nxt = build(i + 1)
             main.wait_event(ev)
             for blk in blocks:  # allocated on the side stream, consumed on the caller's
-                for t in (blk.rowptr, blk.col, blk.val, blk.srcdata["_ID"]):
+                hook_out = getattr(blk, "hook_out", None)
+                extra = tuple(t for t in hook_out if torch.is_tensor(t) and t.is_cuda) if isinstance(hook_out, (tuple, list)) else ()
+                for t in (blk.rowptr, blk.col, blk.val, blk.srcdata["_ID"]) + extra:
                     if t is not None:
                         t.record_stream(main)
             yield inp, outn, blocks

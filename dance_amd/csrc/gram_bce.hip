@@ -1,0 +1,303 @@
+// Fused inner-product decoder of graph-sc (dance/modules/single_modality/clustering/graphsc.py:208-216, :405-411):
+//   adj_logits = z z^T (B x B), loss = norm * mean(binary_cross_entropy_with_logits(adj_logits, adj, pos_weight)).
+// The target `adj` is zero except for the few edges among the batch's own cells, so the dense part of the loss is
+//   sum_ij softplus(x_ij),  x = z z^T,  and its gradient  dz_i = 2 * sum_j sigmoid(x_ij) z_j   (x is symmetric);
+// the y = 1 corrections live on the edge list and stay with the caller.  Unfused this is a B x B fp32 GEMM, two passes over
+// the 268 MB logit matrix (B = 8192) and two more B x B x d GEMMs in the backward.  Here the logits never leave the
+// registers (flash-attention shape):
+//
+//   dh_gram_sigmoid_f32:  rowloss[i] = sum_j softplus(<z_i, z_j>),   O[i, :] = sum_j sigmoid(<z_i, z_j>) z_j
+//
+// both products on the exact-fp32 matrix cores (v_mfma_f32_32x32x2_f32).  One wavefront owns 32 rows i: their features are
+// the B operand of the first product and stay in registers for the whole kernel (DP / 2 VGPRs); the j rows stream through
+// LDS in tiles of 32 (double buffered, one barrier per tile, shared by the four wavefronts of the workgroup).  The first
+// product is computed transposed, S^T[j][i], so that its accumulator layout (column = lane % 32 = i) IS the A-operand layout
+// of the second product (row = lane % 32 = i, k = the j of register r / lane half): sigmoid(S) feeds the second MFMA
+// straight from the accumulator registers, no LDS round trip.  The j range is split across blockIdx.y to fill the chip; the
+// partial sums are combined in a fixed order by a second kernel (deterministic, no atomics).
+//
+// Roofline: matrix-core bound, 4 * B^2 * DP flop (DP = d padded to 64): B = 8192, d = 300 -> 85.9 GFLOP = 0.55 ms at the
+// 157.3 TFLOP/s fp32 peak; HBM traffic is the 10 MB of z (L2 resident) plus the partial outputs.
+#include <type_traits>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+constexpr int BI = 128;  // rows i per workgroup (4 wavefronts x 32)
+constexpr int BJ = 32;   // rows j per LDS tile
+constexpr int MAX_D = 320;
+
+__host__ __device__ constexpr int lds_stride(int dp) { return dp + 4; }  // == 4 (mod 64): the 32 rows of a tile start 4 banks apart
+
+// DP: d padded to a multiple of 64.  VEC: ldz % 4 == 0, d % 4 == 0 and Z 16-byte aligned (float4 loads), else scalar loads.
+template <int DP, bool VEC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void gram_sigmoid_kernel(int n, int d, const float* __restrict__ Z, int64_t ldz, int j_per_split, int n_pad,
+                         float* __restrict__ Opart, double* __restrict__ Lpart) {
+  constexpr int STRIDE = lds_stride(DP);
+  constexpr int HALF = DP / 2;
+  constexpr int NT = DP / 32;              // column tiles of the second product
+  constexpr int ROW4 = DP / 4;             // float4 per tile row
+  constexpr int F4 = BJ * ROW4 / 256;      // float4 per thread per tile (= DP / 32)
+  extern __shared__ float lds[];           // [2][BJ][STRIDE]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 31, h = lane >> 5;
+  const int i0 = blockIdx.x * BI + wave * 32;
+  const int split = blockIdx.y;
+  const int j_begin = split * j_per_split;
+  const int j_end = min(n, j_begin + j_per_split);
+  const int n_tiles = (j_end - j_begin + BJ - 1) / BJ;
+
+  auto load4 = [&](int row, int col) -> f32x4 {  // Z[row][col .. col + 3], zero outside the matrix
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+      const float* p = Z + (int64_t)row * ldz + col;
+      if (VEC) {
+        if (col < d) v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+        if (col + 0 < d) v.x = p[0];
+        if (col + 1 < d) v.y = p[1];
+        if (col + 2 < d) v.z = p[2];
+        if (col + 3 < d) v.w = p[3];
+      }
+    }
+    return v;
+  };
+
+  // B operand of the first product: lane (m, h) holds Z[i0 + m][h * HALF + t], t = 0 .. HALF - 1 (k is enumerated as
+  // (h, t); the A operand read from LDS uses the same enumeration, so any order is a valid K order)
+  float zi[HALF];
+  static_for<HALF / 4>([&](auto q_c) __attribute__((always_inline)) {
+    constexpr int q = decltype(q_c)::value;
+    const f32x4 v = load4(i0 + m, h * HALF + 4 * q);
+    zi[4 * q + 0] = v.x; zi[4 * q + 1] = v.y; zi[4 * q + 2] = v.z; zi[4 * q + 3] = v.w;
+  });
+
+  f32x4 st[F4];
+  auto load_tile = [&](int j0) {
+    static_for<F4>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      const int f = tid + 256 * q;
+      const int row = f / ROW4, c4 = f - row * ROW4;
+      const int j = j0 + row;
+      st[q] = load4(j < j_end ? j : n, 4 * c4);
+    });
+  };
+  auto store_tile = [&](int buf) {
+    float* base = lds + buf * (BJ * STRIDE);
+    static_for<F4>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      const int f = tid + 256 * q;
+      const int row = f / ROW4, c4 = f - row * ROW4;
+      *reinterpret_cast<f32x4*>(base + row * STRIDE + 4 * c4) = st[q];
+    });
+  };
+
+  f32x16 O[NT];
+  static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
+    constexpr int y = decltype(y_c)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[y][r] = 0.f;
+  });
+  double lsum = 0.0;
+
+  if (n_tiles > 0) {
+    load_tile(j_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const float* buf = lds + (t & 1) * (BJ * STRIDE);
+    const bool more = t + 1 < n_tiles;
+    if (more) load_tile(j_begin + BJ * (t + 1));
+
+    // S^T tile: c[j][i] = sum_k Z[j0 + j][k] * Z[i0 + i][k]
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    const float* arow = buf + m * STRIDE + h * HALF;
+    // The A fragment of the next four k-steps is requested before the current four MFMAs are issued, so that the LDS
+    // latency hides behind them.  sched_barrier(0) pins that order: left alone, the scheduler (register pressure is near the
+    // 512 budget) sinks every read to just before its use and the wavefront waits ~100 cycles per four MFMAs.
+    f32x4 a = *reinterpret_cast<const f32x4*>(arow);
+    static_for<HALF / 4>([&](auto q_c) __attribute__((always_inline)) {
+      constexpr int q = decltype(q_c)::value;
+      f32x4 an = a;
+      if (q + 1 < HALF / 4) an = *reinterpret_cast<const f32x4*>(arow + 4 * (q + 1));
+      __builtin_amdgcn_sched_barrier(0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, zi[4 * q + 0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, zi[4 * q + 1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, zi[4 * q + 2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, zi[4 * q + 3], c, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a = an;
+    });
+
+    // softplus for the loss, sigmoid for the gradient; register r of lane half h is row j = 8 (r / 4) + 4 h + r % 4 of the tile
+    const int jb = j_begin + BJ * t + 4 * h;
+    float tile_loss = 0.f;
+    float sg[16];
+    auto act = [&](int r) __attribute__((always_inline)) {
+      const int j = jb + 8 * (r >> 2) + (r & 3);
+      const float x = c[r];
+      const float e = __expf(-fabsf(x));
+      const float inv = __builtin_amdgcn_rcpf(1.f + e);
+      const float sig = x >= 0.f ? inv : e * inv;
+      const float sp = fmaxf(x, 0.f) + __logf(1.f + e);
+      const bool valid = j < j_end;
+      sg[r] = valid ? sig : 0.f;
+      tile_loss += valid ? sp : 0.f;
+    };
+
+    // O[i][:] += sum_j sigmoid(S[i][j]) Z[j0 + j][:]: A = sigmoid(c) (row i = lane % 32, k = the j of register r in this lane
+    // half).  Step r issues the LDS reads of step r + 1 first, then its ten MFMAs with the sigmoid of step r + 1 in their shadow.
+    auto load_b = [&](int r, float (&bv)[NT]) __attribute__((always_inline)) {
+      const float* brow = buf + (8 * (r >> 2) + 4 * h + (r & 3)) * STRIDE + m;
+      static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
+        constexpr int y = decltype(y_c)::value;
+        bv[y] = brow[32 * y];
+      });
+    };
+    float bc[NT], bn[NT];
+    load_b(0, bc);
+    act(0);
+    static_for<16>([&](auto r_c) __attribute__((always_inline)) {
+      constexpr int r = decltype(r_c)::value;
+      if (r + 1 < 16) load_b(r + 1, bn);
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 1 < 16) act(r + 1);
+      static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
+        constexpr int y = decltype(y_c)::value;
+        O[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(sg[r], bc[y], O[y], 0, 0, 0);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      if (r + 1 < 16) {
+        static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
+          constexpr int y = decltype(y_c)::value;
+          bc[y] = bn[y];
+        });
+      }
+    });
+    lsum += (double)tile_loss;
+
+    if (more) store_tile((t + 1) & 1);
+    __syncthreads();
+  }
+
+  // partial results of this j range: rows up to n_pad exist in the workspace, so no row guard
+  float* op = Opart + ((int64_t)split * n_pad + i0) * DP;
+  static_for<NT>([&](auto y_c) __attribute__((always_inline)) {
+    constexpr int y = decltype(y_c)::value;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) op[(int64_t)(8 * (r >> 2) + 4 * h + (r & 3)) * DP + 32 * y + m] = O[y][r];
+  });
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (h == 0) Lpart[(int64_t)split * n_pad + i0 + m] = lsum;
+}
+
+// O[i][c] = sum_s Opart[s][i][c], rowloss[i] = sum_s Lpart[s][i] — fixed order over the splits
+__global__ __launch_bounds__(256) void gram_reduce_kernel(int n, int d, int dp, int n_pad, int splits, const float* __restrict__ Opart,
+                                                         const double* __restrict__ Lpart, float* __restrict__ O, int64_t ldo,
+                                                         float* __restrict__ rowloss) {
+  const int64_t total = (int64_t)n * d;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int i = (int)(e / d), c = (int)(e - (int64_t)i * d);
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += Opart[((int64_t)s * n_pad + i) * dp + c];
+    O[(int64_t)i * ldo + c] = acc;
+    if (c == 0) {
+      double l = 0.0;
+      for (int s = 0; s < splits; ++s) l += Lpart[(int64_t)s * n_pad + i];
+      rowloss[i] = (float)l;
+    }
+  }
+}
+
+struct Plan {
+  int dp, i_blocks, splits, j_per_split, n_pad;
+  size_t opart_bytes, lpart_bytes;
+};
+
+Plan make_plan(int64_t n, int64_t d) {
+  Plan p{};
+  p.dp = (int)(dh::ceil_div(d, 64) * 64);
+  p.i_blocks = (int)dh::ceil_div(n, BI);
+  p.n_pad = p.i_blocks * BI;
+  const int64_t j_tiles = dh::ceil_div(n, BJ);
+  int64_t want = dh::ceil_div(512, p.i_blocks);  // two workgroups per CU
+  if (want > j_tiles) want = j_tiles;
+  if (want < 1) want = 1;
+  p.j_per_split = (int)(dh::ceil_div(j_tiles, want) * BJ);
+  p.splits = (int)dh::ceil_div(n, p.j_per_split);
+  p.opart_bytes = (size_t)p.splits * p.n_pad * p.dp * sizeof(float);
+  p.lpart_bytes = (size_t)p.splits * p.n_pad * sizeof(double);
+  return p;
+}
+
+template <int DP>
+int launch(const Plan& p, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
+  const bool vec = (ldz % 4 == 0) && (d % 4 == 0) && dh::aligned16(Z);
+  const size_t lds_bytes = (size_t)2 * BJ * lds_stride(DP) * sizeof(float);
+  const dim3 grid((unsigned)p.i_blocks, (unsigned)p.splits);
+  if (vec) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, true>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
+  } else {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, false>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
+  }
+  return dh::check_launch("dh_gram_sigmoid_f32");
+}
+
+}  // namespace
+
+extern "C" int dh_gram_sigmoid_supported(int64_t n, int64_t d) { return n >= 0 && n <= (int64_t)1 << 24 && d >= 1 && d <= MAX_D; }
+
+extern "C" size_t dh_gram_sigmoid_workspace_bytes(int64_t n, int64_t d) {
+  if (n <= 0 || !dh_gram_sigmoid_supported(n, d)) return 0;
+  const Plan p = make_plan(n, d);
+  return p.opart_bytes + p.lpart_bytes;
+}
+
+extern "C" int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
+                                   void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  if (n < 0 || d < 0) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: negative size");
+  if (n == 0) return DH_OK;
+  if (!dh_gram_sigmoid_supported(n, d))
+    return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: d = %lld outside [1, %d] (use the unfused decoder)", (long long)d, MAX_D);
+  if (!Z || !O || !rowloss || ldz < d || ldo < d) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: bad pointer / leading dimension");
+  const Plan p = make_plan(n, d);
+  if (!workspace || workspace_bytes < p.opart_bytes + p.lpart_bytes)
+    return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: workspace of %zu bytes needed, %zu given", p.opart_bytes + p.lpart_bytes, workspace_bytes);
+  if (!dh::aligned16(workspace)) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: workspace must be 16-byte aligned");
+  hipStream_t st = dh::as_stream(stream);
+  double* Lpart = reinterpret_cast<double*>(workspace);                      // doubles first: keeps both parts aligned
+  float* Opart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.lpart_bytes);
+  int rc;
+  switch (p.dp) {
+    case 64: rc = launch<64>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
+    case 128: rc = launch<128>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
+    case 192: rc = launch<192>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
+    case 256: rc = launch<256>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
+    default: rc = launch<320>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
+  }
+  if (rc != DH_OK) return rc;
+  const int64_t work = n * d;
+  const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 65536 ? dh::ceil_div(work, 256) : 65536);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)n, (int)d, p.dp, p.n_pad, p.splits, Opart, Lpart, O, ldo, rowloss);
+  return dh::check_launch("dh_gram_sigmoid_f32 (reduce)");
+}

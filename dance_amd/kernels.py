@@ -287,6 +287,24 @@ def sigmoid_scale(X: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gram_sigmoid_supported(n: int, d: int) -> bool:
+    return bool(_lib_ready().dh_gram_sigmoid_supported(int(n), int(d)))
+
+
+def gram_sigmoid(Z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowloss, O) with rowloss[i] = sum_j softplus(<z_i, z_j>) and O[i] = sum_j sigmoid(<z_i, z_j>) z_j: the dense part of
+    graph-sc's inner-product decoder loss and (x2) its gradient, without the B x B logits (dh_gram_sigmoid_f32)."""
+    lib = _lib_ready()
+    n, d = Z.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=Z.device)
+    rowloss = torch.empty(n, dtype=torch.float32, device=Z.device)
+    ws_bytes = lib.dh_gram_sigmoid_workspace_bytes(n, d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Z.device) if ws_bytes else None
+    _call("gram_sigmoid_f32", lib.dh_gram_sigmoid_f32, n, d, _dev(Z, torch.float32, "Z", 2), _ld(Z), out.data_ptr(), _ld(out),
+          rowloss.data_ptr(), None if ws is None else ws.data_ptr(), ws_bytes, _stream())
+    return rowloss, out
+
+
 def colsum(X: torch.Tensor) -> torch.Tensor:
     """out[j] = sum_i X[i, j] (deterministic two-pass)."""
     lib = _lib_ready()

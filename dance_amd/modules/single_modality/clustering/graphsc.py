@@ -6,6 +6,7 @@ weighted sum/mean aggregation, the in-degree^-1/2 scaling, bias and ReLU are ONE
 (dh_spmm_csr_f32 with colscale / rowscale / bias / act) after the MFMA GEMM; degrees are those of the block, as in
 the reference (:444-449,:467-476).
 """
+import os
 from typing import Any, Optional
 
 import numpy as np
@@ -95,6 +96,8 @@ class GCNAE(nn.Module):
         if n_layers == 2:
             self.layer2 = WeightedGraphConv(in_feats=hidden_dim, out_feats=hidden_dim, activation=activation)
         self.decoder = InnerProductDecoder(activation=lambda x: x)
+        self.decoder.linear_logits = True  # adj_logits = z z^T exactly: GraphSC.fit may use the fused decoder loss
+        self.embedding_dim = hidden_dim if hidden is None else hidden[-1]
         self.hidden = hidden
         if hidden is not None:
             enc = []
@@ -169,6 +172,83 @@ def sparse_target_bce(logits, u, v, m, pos_weight):
     return _SparseTargetBCE.apply(logits.contiguous(), u, v, m, pos_weight)
 
 
+class _GramListedBCE(torch.autograd.Function):
+    """mean(binary_cross_entropy_with_logits(z z^T, y, pos_weight=p)) for a target y that is 1 at the listed (us[e], vs[e])
+    (each at most once) and 0 elsewhere, as a function of z and without the B x B logits: the dense part (sum of
+    softplus(<z_i, z_j>) and its gradient 2 sum_j sigmoid(<z_i, z_j>) z_j) is ONE matrix-core kernel that keeps every logit
+    tile in registers (dh_gram_sigmoid_f32); the y = 1 corrections need the logits of the listed entries only, which are
+    recomputed as dot products.  Replaces the z z^T GEMM, the two passes over the logits and the two B x B x d GEMMs of
+    the backward of graphsc.py:208-216 / :405-411.  ``p``: python float or 1-element tensor."""
+
+    @staticmethod
+    def forward(ctx, z, us, vs, p):
+        n = z.shape[0]
+        rowloss, o = kernels.gram_sigmoid(z)
+        xe = (z[us] * z[vs]).sum(1)
+        dense = rowloss.sum(dtype=torch.float64)
+        corr = (p * F.softplus(-xe) - F.softplus(xe)).sum(dtype=torch.float64)
+        ctx.save_for_backward(z, o, us, vs, xe)
+        ctx.p = p
+        return ((dense + corr) / float(n * n)).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, o, us, vs, xe = ctx.saved_tensors
+        p = ctx.p
+        scale = (g / float(z.shape[0]**2)).to(torch.float32)
+        dz = o * (2.0 * scale)
+        sig = torch.sigmoid(xe)
+        c = ((p * (sig - 1) - sig) * scale)[:, None]
+        # x_e = <z_u, z_v>: both end points receive c_e times the other one (sorted accumulation: deterministic)
+        dz.index_put_((us, ), c * z[vs], accumulate=True)
+        dz.index_put_((vs, ), c * z[us], accumulate=True)
+        return dz, None, None, None
+
+
+def gram_listed_bce(z, us, vs, pos_weight):
+    return _GramListedBCE.apply(z.contiguous(), us, vs, pos_weight)
+
+
+def gram_target_bce(z, u, v, m, pos_weight):
+    """``sparse_target_bce(z z^T, u, v, m, p)`` with 0 / 1 weights m, as a function of z (see _GramListedBCE).  Selecting the
+    entries with m = 1 is a host round trip (nonzero); GraphSC.fit gets them without one (``_dst_edge_hook``)."""
+    sel = torch.nonzero(m).reshape(-1)
+    return gram_listed_bce(z, u[sel], v[sel], pos_weight)
+
+
+_PINNED_COUNTS = []
+
+
+def _pinned_count_slot():
+    """A small ring of pinned int64 scalars for asynchronous count reads (a slot is reused four batches later)."""
+    if not _PINNED_COUNTS:
+        _PINNED_COUNTS.extend([torch.empty(1, dtype=torch.int64).pin_memory() for _ in range(4)] + [0])
+    i = _PINNED_COUNTS[-1]
+    _PINNED_COUNTS[-1] = (i + 1) % 4
+    return _PINNED_COUNTS[i]
+
+
+def _dst_edge_hook(blocks):
+    """DataLoader block hook of GraphSC.fit: the edges of the last block whose source is itself a destination node — the
+    non-zeros of ``g.adjacency_matrix().to_dense()[dst][:, dst]`` (graphsc.py:208-209) — as (edge ids with those edges
+    first and in edge order, their count in pinned host memory, event).  Runs on the stream that built the block (the
+    loader's side stream, one batch ahead), so reading the count later does not wait for the model's kernels."""
+    last = blocks[-1]
+    outside = (last.col >= last.number_of_dst_nodes()).to(torch.uint8)
+    order = torch.sort(outside, stable=True).indices
+    cnt = _pinned_count_slot()
+    cnt.copy_((outside.numel() - outside.sum(dtype=torch.int64)).reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    return order, cnt, ev
+
+
+# "fused": GraphSC.fit evaluates the decoder loss by dh_gram_sigmoid_f32 (no B x B logits), the listed target entries come
+# from the loader's block hook (no host round trip on the model's stream); "fused-sync": same kernel, entries selected by
+# nonzero(); "dense": z z^T GEMM + passes over the logits
+DECODER_MODE = os.environ.get("DANCE_AMD_GRAPHSC_DECODER", "fused")
+
+
 class GraphSC(BaseClusteringMethod):
 
     # Seed order of the mini-batches: None = shuffled on the device; a (host) torch.Generator makes the order
@@ -219,8 +299,11 @@ class GraphSC(BaseClusteringMethod):
             sharding.broadcast_parameters(self.model)
             train_ids = sharding.shard_seed_ids(torch.from_numpy(train_ids)).numpy()
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
+        can_fuse = (getattr(self.model.decoder, "linear_logits", False) and torch.device(self.device).type == "cuda"
+                    and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
+        fused, fused_sync = can_fuse and DECODER_MODE == "fused", can_fuse and DECODER_MODE == "fused-sync"
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
-                                generator=self.shuffle_generator)
+                                generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr)
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
@@ -232,18 +315,40 @@ class GraphSC(BaseClusteringMethod):
                 _, emb = self.model.forward(blocks, input_features, decode=False)  # :202 (its adj_logits are never used)
                 z.append(emb.detach())
                 order.append(last.dstdata["order"])
-                # the loss scalars of graphsc.py:208-214 stay on the device (the reference reads them back every batch; here the
-                # only host round trip of a batch is the block builder's size read)
-                # adj = g.adjacency_matrix().to_dense()[dst][:, dst] (:208-209) is zero except for the edges among the batch's own
-                # cells: it is kept as an edge list (block_dst_edges) and never materialised (block_dst_adjacency is the dense form)
-                eu, ev, em = block_dst_edges(last)
-                total = float(last.number_of_dst_nodes())**2
-                s = em.sum()
-                pos_weight = ((total - s) / s).reshape(1)
-                factor = (total - s) * 2
-                norm = total / torch.where(factor == 0, torch.ones_like(factor), factor)
-                adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
-                loss = norm * sparse_target_bce(adj_logits, eu, ev, em, pos_weight)
+                if fused:
+                    # adj = g.adjacency_matrix().to_dense()[dst][:, dst] (:208-209) is zero except for the edges among the
+                    # batch's own cells: _dst_edge_hook listed them one batch ahead on the loader's stream, so their count —
+                    # adj.sum() of :210-213 — is on the host by now and pos_weight / norm are plain floats
+                    order_e, cnt, ev = last.hook_out
+                    ev.synchronize()
+                    n_listed = int(cnt)
+                    sel = order_e[:n_listed]
+                    us = last.col[sel].to(torch.int64)
+                    vs = torch.searchsorted(last.rowptr, sel.to(last.rowptr.dtype), right=True).to(torch.int64) - 1
+                    total = float(last.number_of_dst_nodes())**2
+                    pos_weight = (total - n_listed) / n_listed if n_listed else float("inf")
+                    factor = (total - n_listed) * 2
+                    norm = total / (factor if factor != 0 else 1.0)
+                    # second forward, fresh dropout (:215); the decoder's own dropout (:409) is the last draw, as in the reference
+                    _, emb2 = self.model.forward(blocks, input_features, decode=False)
+                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), us, vs, pos_weight)
+                    if not n_listed:  # the reference's 0 * inf (pos_weight = inf against an all-zero target)
+                        loss = loss * float("nan")
+                else:
+                    # the loss scalars of graphsc.py:208-214 stay on the device (the reference reads them back every batch);
+                    # adj is kept as an edge list (block_dst_edges) and never materialised (block_dst_adjacency is the dense form)
+                    eu, ev_, em = block_dst_edges(last)
+                    total = float(last.number_of_dst_nodes())**2
+                    s_ = em.sum()
+                    pos_weight = ((total - s_) / s_).reshape(1)
+                    factor = (total - s_) * 2
+                    norm = total / torch.where(factor == 0, torch.ones_like(factor), factor)
+                    if fused_sync:  # fused decoder, listed entries selected by nonzero() (one host round trip per batch)
+                        _, emb2 = self.model.forward(blocks, input_features, decode=False)
+                        loss = norm * gram_target_bce(F.dropout(emb2, self.model.decoder.dropout), eu, ev_, em, pos_weight)
+                    else:
+                        adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
+                        loss = norm * sparse_target_bce(adj_logits, eu, ev_, em, pos_weight)
                 optim.zero_grad()
                 loss.backward()
                 sharding.allreduce_gradients(self.model)

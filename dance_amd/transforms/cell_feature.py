@@ -14,6 +14,12 @@ class WeightedFeaturePCA(BaseTransform):
 
     _DISPLAY_ATTRS = ("n_components", "split_name", "feat_norm_mode", "feat_norm_axis")
 
+    # solver of the device path (attributes, so the constructor stays the reference's): "full" = exact decomposition
+    # (dance_amd.utils.pca.pca_scores); "randomized" = the solver sklearn's "auto" picks for these shapes, seeded by
+    # ``device_random_state`` through the same numpy stream (pca_scores_randomized) — reproduces a seeded host run
+    device_solver = "full"
+    device_random_state = None
+
     def __init__(self, n_components=400, split_name=None, feat_norm_mode=None, feat_norm_axis=0, save_info=False, *,
                  device=None, **kwargs):
         super().__init__(**kwargs)
@@ -55,11 +61,22 @@ class WeightedFeaturePCA(BaseTransform):
         import torch
 
         from .. import kernels
-        from ..utils.pca import pca_scores
-        if self.save_info:
-            raise NotImplementedError("save_info needs the cell-space components, which the device path never forms")
+        from ..utils.pca import pca_scores, pca_scores_randomized
+        if self.device_solver not in ("full", "randomized"):
+            raise ValueError(f"device_solver must be 'full' or 'randomized', got {self.device_solver!r}")
+        if self.save_info and self.device_solver == "full":
+            raise NotImplementedError("save_info needs the cell-space components, which the exact device path never forms")
         ft = torch.as_tensor(np.ascontiguousarray(feat.T, dtype=np.float32)).to(self.device)   # genes x cells
-        gene_feat, _, _ = pca_scores(ft, self.n_components)                                      # genes x components
+        if self.device_solver == "randomized":
+            gene_feat, comps, var = pca_scores_randomized(ft, self.n_components, self.device_random_state)
+            if self.save_info:
+                data.data.uns["pca_components"] = comps.cpu().numpy()
+                data.data.uns["pca_mean"] = ft.mean(0).cpu().numpy()
+                data.data.uns["pca_explained_variance"] = var.cpu().numpy()
+                total = ft.var(0, unbiased=True).sum() if ft.shape[0] > 1 else ft.new_zeros(())
+                data.data.uns["pca_explained_variance_ratio"] = (var / total).cpu().numpy()
+        else:
+            gene_feat, _, _ = pca_scores(ft, self.n_components)                                  # genes x components
         x = torch.as_tensor(np.ascontiguousarray(data.get_x(), dtype=np.float32)).to(self.device)
         cell_feat = kernels.gemm(normalize(x, mode="normalize", axis=1).contiguous(), gene_feat.contiguous())
         data.data.obsm[self.out] = cell_feat.cpu().numpy()
@@ -79,7 +96,10 @@ class CellPCA(BaseTransform):
         self.channel = channel
         self.save_info = save_info
         self.svd_solver = svd_solver
-        self.device = device  # None: scikit-learn on the host (reference); "cuda": exact PCA on the GPU (opt-in)
+        # None: scikit-learn on the host (reference); "cuda": PCA on the GPU (opt-in) — exact for svd_solver "auto" / "full" /
+        # "covariance_eigh", sklearn's randomised solver restated for svd_solver="randomized" (seed: ``device_random_state``)
+        self.device = device
+        self.device_random_state = None
 
     def __call__(self, data):
         feat = data.get_feature(return_type="numpy", channel=self.channel, channel_type="obsm" if self.channel else "X")
@@ -88,8 +108,14 @@ class CellPCA(BaseTransform):
         if self.device is not None:
             import torch
 
-            from ..utils.pca import pca_scores
-            scores, comps, _ = pca_scores(torch.as_tensor(np.ascontiguousarray(feat, dtype=np.float32)).to(self.device), self.n_components)
+            from ..utils.pca import pca_scores, pca_scores_randomized
+            xd = torch.as_tensor(np.ascontiguousarray(feat, dtype=np.float32)).to(self.device)
+            if self.svd_solver == "randomized":
+                scores, comps, _ = pca_scores_randomized(xd, self.n_components, self.device_random_state)
+            elif self.svd_solver in ("auto", "full", "covariance_eigh"):
+                scores, comps, _ = pca_scores(xd, self.n_components)
+            else:
+                raise ValueError(f"svd_solver={self.svd_solver!r} has no device path (use 'auto', 'full' or 'randomized')")
             data.data.obsm[self.out] = scores.cpu().numpy()
             if self.save_info:
                 if comps is None:

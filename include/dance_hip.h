@@ -309,6 +309,18 @@ DH_API int dh_softplus_rowsum_f32(int64_t n_rows, int64_t n_cols, const float* X
 DH_API int dh_sigmoid_scale_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const float* scale,
                          float* out, int64_t ldo, dh_stream_t stream);
 
+/* ---- the same decoder without the B x B logit matrix (gram_bce.hip) --------------------------------------------
+ * Replaces, for GraphSC.fit (graphsc.py:208-216) with InnerProductDecoder (:405-411, adj_logits = z z^T): the logits
+ * GEMM, the two passes above and the two B x B x d GEMMs of the backward.  One pass on the fp32 matrix cores:
+ *   rowloss[i] = sum_j softplus(<z_i, z_j>),   O[i, :] = sum_j sigmoid(<z_i, z_j>) z_j     (i, j < n; Z [n, d] fp32)
+ * so that  sum_ij softplus(x_ij) = sum_i rowloss[i]  and  d/dz of it = 2 O  (x = z z^T is symmetric).  d <= 320
+ * (dh_gram_sigmoid_supported); fixed summation order, no atomics.  workspace: dh_gram_sigmoid_workspace_bytes, 16-byte
+ * aligned.                                                                                                          */
+DH_API int dh_gram_sigmoid_supported(int64_t n, int64_t d);
+DH_API size_t dh_gram_sigmoid_workspace_bytes(int64_t n, int64_t d);
+DH_API int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
+                        void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
 /* ---- message-flow blocks of the full-neighbour sampler (block.hip) -------------------------------------------
  * What dgl.dataloading.NeighborSampler([-1]*L, edge_dir="in") / MultiLayerFullNeighborSampler produce for a batch of
  * seed nodes (scdeepsort.py:183,233-236; graphsc.py:181-183): every in-edge of the seeds; source nodes = the seeds first,

@@ -110,3 +110,67 @@ def test_sparse_target_bce_matches_torch_dense(cuda_device):
     ggot, = torch.autograd.grad(got * 3.0, x)
     assert abs(float(got) - float(ref)) < 1e-6 * abs(float(ref))
     assert rel_err(ggot.cpu().numpy(), gref.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("n,d,ld", [(1, 1, 1), (16, 300, 300), (33, 64, 64), (300, 7, 7), (129, 130, 136), (257, 320, 320),
+                                    (1000, 300, 300), (200, 301, 301), (640, 128, 131)])
+def test_gram_sigmoid_kernel_vs_float64(cuda_device, n, d, ld):
+    """dh_gram_sigmoid_f32 (logit tiles kept in registers): rowloss[i] = sum_j softplus(<z_i, z_j>) and
+    O[i] = sum_j sigmoid(<z_i, z_j>) z_j against float64, over every padded width (64 .. 320), ragged row / column counts,
+    several j splits, vector and scalar load paths (ld % 4, d % 4)."""
+    from dance_amd import kernels
+    torch.manual_seed(n * 1000 + d)
+    base = torch.randn(n, ld, device=cuda_device) * (2.0 / d**0.5)
+    z = base[:, :d]
+    if ld == d:
+        z = z.contiguous()
+    assert kernels.gram_sigmoid_supported(n, d)
+    rowloss, o = kernels.gram_sigmoid(z)
+    zz = z.double()
+    x = zz @ zz.t()
+    ref_loss = torch.nn.functional.softplus(x).sum(1)
+    ref_o = torch.sigmoid(x) @ zz
+    assert rel_err(rowloss.cpu().numpy(), ref_loss.cpu().numpy()) < 2e-6
+    assert rel_err(o.cpu().numpy(), ref_o.cpu().numpy()) < 5e-6
+    r2, o2 = kernels.gram_sigmoid(z)                       # fixed summation order: bit-identical run to run
+    assert torch.equal(r2, rowloss) and torch.equal(o2, o)
+    assert not kernels.gram_sigmoid_supported(n, 321)
+
+
+def test_gram_target_bce_matches_torch_dense(cuda_device):
+    """The decoder loss as a function of z without the logit matrix == F.binary_cross_entropy_with_logits(z z^T, adj,
+    pos_weight) (value and gradient wrt z), with repeated end points and zero-weight listed entries."""
+    import torch.nn.functional as F
+
+    from dance_amd.modules.single_modality.clustering.graphsc import gram_target_bce
+    torch.manual_seed(0)
+    b, d = 300, 40
+    z = (torch.randn(b, d, device=cuda_device) * 0.5).requires_grad_(True)
+    e = 900
+    u, v = torch.randint(0, b, (e, ), device=cuda_device), torch.randint(0, b, (e, ), device=cuda_device)
+    key = torch.unique(u * b + v)                      # listed at most once
+    u, v = key // b, key % b
+    m = (torch.rand(u.numel(), device=cuda_device) < 0.7).float()
+    adj = torch.zeros(b, b, device=cuda_device, dtype=torch.float64)
+    adj[u, v] = m.double()
+    p = torch.tensor([7.5], device=cuda_device)
+    zd = z.detach().double().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(zd @ zd.t(), adj, pos_weight=p.double())
+    gref, = torch.autograd.grad(ref * 3.0, zd)
+    got = gram_target_bce(z, u, v, m, p)
+    ggot, = torch.autograd.grad(got * 3.0, z)
+    assert abs(float(got) - float(ref)) < 2e-6 * abs(float(ref))
+    assert rel_err(ggot.cpu().numpy(), gref.cpu().numpy()) < 1e-5
+
+
+def test_graphsc_fit_dense_decoder_mode_vs_reference(cuda_device, gold, monkeypatch):
+    """The unfused decoder path (DANCE_AMD_GRAPHSC_DECODER=dense: z z^T GEMM + the two elementwise passes) stays pinned to
+    the reference's fit losses as well; the parametrised test above runs the default (fused) mode."""
+    from dance_amd.modules.single_modality.clustering import graphsc
+    assert graphsc.DECODER_MODE == "fused"
+    monkeypatch.setattr(graphsc, "DECODER_MODE", "dense")
+    g = _graph(gold)
+    m = _model(gold, "mb", "sum")
+    m.shuffle_generator = torch.Generator().manual_seed(123)
+    m.fit(g, epochs=3, lr=1e-2, batch_size=16)
+    assert np.allclose(m.losses, gold["gsc_mb_losses"], rtol=2e-4, atol=0)

@@ -175,3 +175,46 @@ def test_device_pca_matches_sklearn_full(cuda_device):
     CellPCA(10, device="cuda")(d_dev)
     CellPCA(10, svd_solver="full")(d_host)
     same_up_to_sign(d_dev.data.obsm["CellPCA"], d_host.data.obsm["CellPCA"], 2e-4)
+
+
+def test_device_randomized_pca_matches_sklearn(cuda_device):
+    """svd_solver="randomized" on the device (pca_scores_randomized: dh_gemm_f32 products, same numpy random stream as
+    scikit-learn) == scikit-learn's randomised PCA with the same seed up to the component signs; both orientations and the
+    two transforms (cell_feature.py:60-62 WeightedFeaturePCA, :176-181 CellPCA)."""
+    from sklearn.decomposition import PCA
+    from dance_amd.data import AnnDataLite, Data
+    from dance_amd.transforms import CellPCA, WeightedFeaturePCA
+    from dance_amd.utils.pca import pca_scores_randomized
+    rng = np.random.default_rng(1)
+    lat = rng.standard_normal((3000, 12)) @ rng.standard_normal((12, 200)) * 2 + rng.standard_normal((3000, 200)) * 0.3
+    x = np.maximum(lat + 1.0, 0).astype(np.float32)
+
+    def same_up_to_sign(a, b, tol):
+        s = np.sign((a * b).sum(0))
+        assert rel_err(a * s, b) < tol
+
+    for mat, k in ((x, 12), (np.ascontiguousarray(x.T), 12), (x, 30)):   # 7 iterations (k < 0.1 min) and 4 (k = 30 of 200)
+        ref = PCA(n_components=k, svd_solver="randomized", random_state=3)
+        ref_scores = ref.fit_transform(mat)
+        scores, comps, var = pca_scores_randomized(torch.from_numpy(mat).to(cuda_device), k, 3)
+        kk = 12                                   # the 12 latent directions are separated; the noise tail is compared by variance
+        same_up_to_sign(scores.cpu().numpy()[:, :kk], ref_scores[:, :kk], 2e-4)
+        same_up_to_sign(comps.cpu().numpy().T[:, :kk], ref.components_.T[:, :kk], 2e-4)
+        assert rel_err(var.cpu().numpy(), ref.explained_variance_) < 1e-4
+        u = scores.cpu().numpy()
+        assert (u[np.abs(u).argmax(0), np.arange(k)] > 0).all()
+    d_dev, d_host = Data(AnnDataLite(x.copy())), Data(AnnDataLite(x.copy()))
+    t = WeightedFeaturePCA(12, save_info=True, device="cuda")
+    t.device_solver, t.device_random_state = "randomized", 5
+    t(d_dev)
+    host = PCA(n_components=12, svd_solver="randomized", random_state=5)
+    gene_ref = host.fit_transform(x.T)
+    same_up_to_sign(d_dev.data.varm["WeightedFeaturePCA"], gene_ref, 2e-4)
+    assert rel_err(d_dev.data.uns["pca_explained_variance_ratio"], host.explained_variance_ratio_) < 1e-4
+    assert rel_err(d_dev.data.uns["pca_mean"], host.mean_) < 1e-5
+    c = CellPCA(10, svd_solver="randomized", device="cuda")
+    c.device_random_state = 5
+    c(d_dev)
+    same_up_to_sign(d_dev.data.obsm["CellPCA"], PCA(n_components=10, svd_solver="randomized", random_state=5).fit_transform(x), 2e-4)
+    with pytest.raises(ValueError):
+        CellPCA(10, svd_solver="arpack", device="cuda")(d_host)

@@ -137,3 +137,34 @@ def test_as_graph_cache_is_identity_keyed(monkeypatch):
     del adj, other
     gc.collect()
     assert len(graph._CACHE) == 0  # entries die with their tensors
+
+
+def test_randomized_pca_host_logic_matches_sklearn():
+    """dance_amd.utils.pca.pca_scores_randomized (device solver for sklearn's ``svd_solver="randomized"``, the solver
+    ``"auto"`` picks for the reference's WeightedFeaturePCA / CellPCA shapes) with the GEMMs injected as torch-CPU
+    stand-ins: same numpy random stream, same iteration count, same subspace as scikit-learn's randomized_svd -> equal
+    scores / components / variances to fp32 rounding, up to the per-component sign (scikit-learn >= 1.5 decides it on
+    the feature side, 1.3 — the reference's pin — on the sample side, which is the rule implemented and checked here)."""
+    import torch
+    from sklearn.decomposition import PCA
+
+    import cpu_ops
+    from dance_amd.utils.pca import pca_scores_randomized
+    rng = np.random.RandomState(0)
+    for n, f, k in ((300, 40, 8), (40, 500, 6), (600, 100, 30), (64, 64, 5)):   # tall, wide, k >= 0.1 min (4 its), square
+        x = (rng.randn(n, 12) @ rng.randn(12, f) * np.linspace(3, 1, f) + 0.3 * rng.randn(n, f)).astype(np.float32)
+        ref = PCA(n_components=k, svd_solver="randomized", random_state=7)
+        ref_scores = ref.fit_transform(x)
+        scores, comps, var = (t.numpy() for t in pca_scores_randomized(torch.from_numpy(x), k, 7, ops=cpu_ops))
+        sg = np.sign((scores * ref_scores).sum(0))
+        assert np.abs(scores * sg - ref_scores).max() < 5e-5 * np.abs(ref_scores).max()
+        assert np.abs(comps * sg[:, None] - ref.components_).max() < 5e-4
+        assert np.abs(var - ref.explained_variance_).max() < 1e-5 * ref.explained_variance_.max()
+        assert (scores[np.abs(scores).argmax(0), np.arange(k)] > 0).all()      # svd_flip, u-based (scikit-learn 1.3)
+        # a RandomState instance is consumed exactly like the seed
+        again = pca_scores_randomized(torch.from_numpy(x), k, np.random.RandomState(7), ops=cpu_ops)[0].numpy()
+        assert np.array_equal(again, scores)
+    with pytest.raises(ValueError):
+        pca_scores_randomized(torch.zeros(5, 4), 5, 0, ops=cpu_ops)
+    with pytest.raises(TypeError):
+        pca_scores_randomized(torch.zeros(5, 4, dtype=torch.float64), 2, 0, ops=cpu_ops)
