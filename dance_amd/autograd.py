@@ -13,12 +13,18 @@ Forward and backward are sequences of libdancehip kernels on the current HIP str
 This is the arithmetic torch autograd performs for the reference layers
 (dance/modules/single_modality/clustering/scdsc.py:496-501, dance/modules/spatial/spatial_domain/spagcn.py:357-363).
 """
+import os
 from typing import Optional
 
 import torch
 
 from . import kernels
 from .graph import CSRGraph
+
+
+# ReLU mask in the backward SpMM of the fused layer: "fused" = applied to every gathered row inside dh_spmm_csr_relu_f32 (the
+# measured default), "premask" = dy masked once into a scratch matrix, then the plain SpMM (A/B switch, scripts/bwd_mask_ab.py)
+BWD_MASK_MODE = os.environ.get("DANCE_AMD_BWD_MASK", "fused")
 
 
 class _GCNLayerFn(torch.autograd.Function):
@@ -58,7 +64,17 @@ class _GCNLayerFn(torch.autograd.Function):
                 gt = ctx.graph.transpose()
                 if dy.stride(0) % 4 != 0 or dy.data_ptr() % 16 != 0:
                     dy = dy.clone(memory_format=torch.contiguous_format)  # fresh allocation: 16-byte aligned rows
-                ds = kernels.spmm_csr_relu(gt.rowptr, gt.col, gt.val, dy, n_cols=gt.n_cols, in_mask=mask, tag="spmm_csr_f32[bwd]")
+                if BWD_MASK_MODE == "premask":
+                    # A/B variant (not the default): G = dy * [out > 0] written once (one streaming pass), then the plain
+                    # gather — four requests per neighbour instead of five, at the price of 2 x N x D x 4 bytes of traffic
+                    ident = getattr(ctx.graph, "_row_ids", None)
+                    if ident is None or ident.numel() != dy.shape[0]:
+                        ident = torch.arange(dy.shape[0], dtype=torch.int32, device=dy.device)
+                        ctx.graph._row_ids = ident
+                    g = kernels.gather_rows(dy, ident, relu_mask=mask)
+                    ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols, tag="spmm_csr_f32[bwd-premasked]")
+                else:
+                    ds = kernels.spmm_csr_relu(gt.rowptr, gt.col, gt.val, dy, n_cols=gt.n_cols, in_mask=mask, tag="spmm_csr_f32[bwd]")
                 if need_w:
                     dw = kernels.gemm(x, ds, trans_a=True)
                 if need_x:

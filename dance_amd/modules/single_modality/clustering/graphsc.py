@@ -299,9 +299,10 @@ class GraphSC(BaseClusteringMethod):
             sharding.broadcast_parameters(self.model)
             train_ids = sharding.shard_seed_ids(torch.from_numpy(train_ids)).numpy()
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
-        can_fuse = (getattr(self.model.decoder, "linear_logits", False) and torch.device(self.device).type == "cuda"
+        can_fuse = (DECODER_MODE in ("fused", "fused-sync") and getattr(self.model.decoder, "linear_logits", False)
                     and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
-        fused, fused_sync = can_fuse and DECODER_MODE == "fused", can_fuse and DECODER_MODE == "fused-sync"
+        fused = can_fuse and DECODER_MODE == "fused" and g.device.type == "cuda"  # the block hook works with streams / events
+        fused_sync = can_fuse and not fused
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr)

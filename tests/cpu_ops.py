@@ -134,3 +134,40 @@ def block_build(rowptr, col, val, seeds, mark, lut):
     table = torch.empty(n_nodes, dtype=torch.int64, device=rowptr.device)
     table[src_ids] = torch.arange(src_ids.numel(), device=rowptr.device)
     return brp.to(torch.int32), table[gcol].to(torch.int32), None if val is None else val[pos].contiguous(), src_ids
+
+
+def csr_transpose(rowptr, col, val, n_rows, n_cols):
+    """(rowptr_t, col_t, val_t, perm) of A^T, stable by input position (dh_csr_transpose)."""
+    nnz = col.numel()
+    rows = torch.repeat_interleave(torch.arange(n_rows), (rowptr[1:] - rowptr[:-1]).to(torch.int64))
+    perm = torch.sort(col.to(torch.int64), stable=True).indices
+    counts = torch.bincount(col.to(torch.int64), minlength=n_cols)
+    rowptr_t = torch.zeros(n_cols + 1, dtype=torch.int64)
+    rowptr_t[1:] = torch.cumsum(counts, 0)
+    assert perm.numel() == nnz
+    return rowptr_t.to(torch.int32), rows[perm].to(torch.int32), None if val is None else val[perm].contiguous(), perm.to(torch.int32)
+
+
+def bias_act_(X, bias, act=ACT_NONE):
+    if bias is not None:
+        X.add_(bias.detach())
+    if act == ACT_RELU:
+        X.clamp_(min=0)
+    return X
+
+
+def softplus_rowsum(X):
+    return torch.nn.functional.softplus(X.double()).sum(1).float()
+
+
+def sigmoid_scale(X, scale):
+    return torch.sigmoid(X) * scale.reshape(())
+
+
+def gram_sigmoid_supported(n, d):
+    return 1 <= d <= 320
+
+
+def gram_sigmoid(Z):
+    x = Z.double() @ Z.double().t()
+    return torch.nn.functional.softplus(x).sum(1).float(), (torch.sigmoid(x) @ Z.double()).float()

@@ -102,3 +102,29 @@ def test_same_sparse_adj_every_epoch(cuda_device, golden_gcn):
     assert graph.as_graph(adj) is graph.as_graph(adj)
     gc_layer = GraphConvolution(g["x"].shape[1], g["w"].shape[1]).to(cuda_device)
     assert torch.equal(gc_layer(x, adj), gc_layer(x, adj))
+
+
+def test_premasked_backward_variant_is_bit_identical(cuda_device, monkeypatch):
+    """DANCE_AMD_BWD_MASK=premask (dy masked once, then the plain SpMM — an A/B switch, not the default) computes the same
+    sums in the same order as the fused-mask backward: dW and dX bit for bit."""
+    from dance_amd import autograd
+    from dance_amd.graph import CSRGraph
+    from dance_amd.modules.single_modality.clustering.scdsc import GNNLayer
+    rng = np.random.default_rng(5)
+    n, fin, fout, k = 4000, 96, 512, 7
+    x = torch.from_numpy(rng.standard_normal((n, fin)).astype(np.float32)).to(cuda_device)
+    dy = torch.from_numpy(rng.standard_normal((n, fout)).astype(np.float32)).to(cuda_device)
+    cols = np.stack([rng.choice(n, k, replace=False) for _ in range(n)])
+    cols.sort(axis=1)
+    adj = sp.csr_matrix((rng.random(n * k).astype(np.float32), cols.ravel(), np.arange(0, n * k + 1, k)), shape=(n, n))
+    graph = CSRGraph.from_scipy(adj, cuda_device)
+    torch.manual_seed(0)
+    layer = GNNLayer(fin, fout).to(cuda_device)
+    grads = {}
+    for mode in ("fused", "premask"):
+        monkeypatch.setattr(autograd, "BWD_MASK_MODE", mode)
+        xt = x.clone().requires_grad_(True)
+        layer.weight.grad = None
+        layer(xt, graph).backward(dy)
+        grads[mode] = (layer.weight.grad.clone(), xt.grad.clone())
+    assert torch.equal(grads["fused"][0], grads["premask"][0]) and torch.equal(grads["fused"][1], grads["premask"][1])

@@ -198,8 +198,8 @@ def test_device_randomized_pca_matches_sklearn(cuda_device):
         ref_scores = ref.fit_transform(mat)
         scores, comps, var = pca_scores_randomized(torch.from_numpy(mat).to(cuda_device), k, 3)
         kk = 12                                   # the 12 latent directions are separated; the noise tail is compared by variance
-        same_up_to_sign(scores.cpu().numpy()[:, :kk], ref_scores[:, :kk], 2e-4)
-        same_up_to_sign(comps.cpu().numpy().T[:, :kk], ref.components_.T[:, :kk], 2e-4)
+        same_up_to_sign(scores.cpu().numpy()[:, :kk], ref_scores[:, :kk], 5e-4)
+        same_up_to_sign(comps.cpu().numpy().T[:, :kk], ref.components_.T[:, :kk], 5e-4)
         assert rel_err(var.cpu().numpy(), ref.explained_variance_) < 1e-4
         u = scores.cpu().numpy()
         assert (u[np.abs(u).argmax(0), np.arange(k)] > 0).all()
@@ -209,12 +209,12 @@ def test_device_randomized_pca_matches_sklearn(cuda_device):
     t(d_dev)
     host = PCA(n_components=12, svd_solver="randomized", random_state=5)
     gene_ref = host.fit_transform(x.T)
-    same_up_to_sign(d_dev.data.varm["WeightedFeaturePCA"], gene_ref, 2e-4)
+    same_up_to_sign(d_dev.data.varm["WeightedFeaturePCA"], gene_ref, 5e-4)
     assert rel_err(d_dev.data.uns["pca_explained_variance_ratio"], host.explained_variance_ratio_) < 1e-4
     assert rel_err(d_dev.data.uns["pca_mean"], host.mean_) < 1e-5
     c = CellPCA(10, svd_solver="randomized", device="cuda")
     c.device_random_state = 5
     c(d_dev)
-    same_up_to_sign(d_dev.data.obsm["CellPCA"], PCA(n_components=10, svd_solver="randomized", random_state=5).fit_transform(x), 2e-4)
+    same_up_to_sign(d_dev.data.obsm["CellPCA"], PCA(n_components=10, svd_solver="randomized", random_state=5).fit_transform(x), 5e-4)
     with pytest.raises(ValueError):
         CellPCA(10, svd_solver="arpack", device="cuda")(d_host)
