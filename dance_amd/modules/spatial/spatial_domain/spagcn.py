@@ -74,7 +74,7 @@ def search_l(p, adj, start=0.01, end=1000, tol=0.01, max_run=100, device="cuda")
     """spagcn.py:254-287 bisection on l; the distance matrix is moved to the device once."""
     d = _to_device_f32(adj, device)
     run = 0
-    p_low, p_high = calculate_p(d, start), calculate_p(d, end)
+    p_low, p_high = calculate_p(d, start, device), calculate_p(d, end, device)
     if p_low > p + tol:
         logger.info("l not found, try smaller start point.")
         return None
@@ -91,7 +91,7 @@ def search_l(p, adj, start=0.01, end=1000, tol=0.01, max_run=100, device="cuda")
             logger.info(f"Exact l not found, closest values are:\nl={start}: p={p_low}\nl={end}: p={p_high}")
             return None
         mid = (start + end) / 2
-        p_mid = calculate_p(d, mid)
+        p_mid = calculate_p(d, mid, device)
         if np.abs(p_mid - p) <= tol:
             logger.info(f"recommended l: {mid}")
             return mid

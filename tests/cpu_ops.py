@@ -171,3 +171,137 @@ def gram_sigmoid_supported(n, d):
 def gram_sigmoid(Z):
     x = Z.double() @ Z.double().t()
     return torch.nn.functional.softplus(x).sum(1).float(), (torch.sigmoid(x) @ Z.double()).float()
+
+
+ATT_SIGMOID, ATT_LEAKY_RELU = 0, 1
+
+
+def _edge_rows(rowptr):
+    n = rowptr.numel() - 1
+    return torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).to(torch.int64))
+
+
+def _att_act(t, act, slope):
+    return torch.sigmoid(t) if act == ATT_SIGMOID else torch.nn.functional.leaky_relu(t, slope)
+
+
+def edge_softmax(rowptr, col, a_src, a_dst, *, act=ATT_SIGMOID, negative_slope=0.2):
+    """att[e] = softmax over each row's in-edges of act(a_src[col[e]] + a_dst[row]) (dh_edge_softmax_f32), in float64."""
+    rows, n = _edge_rows(rowptr), rowptr.numel() - 1
+    e = _att_act(a_src.double()[col.long()] + a_dst.double()[rows], act, negative_slope)
+    mx = torch.full((n, ), -float("inf"), dtype=torch.float64).scatter_reduce(0, rows, e, reduce="amax", include_self=True)
+    ex = (e - mx[rows]).exp()
+    den = torch.zeros(n, dtype=torch.float64).index_add_(0, rows, ex)
+    return (ex / den[rows]).float()
+
+
+def edge_softmax_backward(rowptr, col, a_src, a_dst, att, datt, *, act=ATT_SIGMOID, negative_slope=0.2):
+    """(dt [E], d_a_dst [n_rows]): softmax Jacobian per row, then the activation's derivative (dh_edge_softmax_backward_f32)."""
+    rows, n = _edge_rows(rowptr), rowptr.numel() - 1
+    a, d = att.double(), datt.double()
+    dot = torch.zeros(n, dtype=torch.float64).index_add_(0, rows, a * d)
+    de = a * (d - dot[rows])
+    t = a_src.double()[col.long()] + a_dst.double()[rows]
+    if act == ATT_SIGMOID:
+        sg = torch.sigmoid(t)
+        dt = de * sg * (1 - sg)
+    else:
+        dt = de * torch.where(t > 0, torch.ones_like(t), torch.full_like(t, negative_slope))
+    return dt.float(), torch.zeros(n, dtype=torch.float64).index_add_(0, rows, dt).float()
+
+
+def sddmm_csr(rowptr, col, U, V, *, scale=None):
+    """out[e] = scale[e] * <U[row(e)], V[col(e)]> (dh_sddmm_csr_f32)."""
+    rows = _edge_rows(rowptr)
+    out = (U.double()[rows] * V.double()[col.long()]).sum(1)
+    if scale is not None:
+        out = out * scale.double()
+    return out.float()
+
+
+def csr_two_hop(rowptr, col, *, drop_diag=False):
+    """Pattern of ((A A) - A) > 0, optionally without the diagonal (dh_csr_two_hop_*)."""
+    n = rowptr.numel() - 1
+    a = sp.csr_matrix((np.ones(col.numel(), np.int64), col.numpy(), rowptr.numpy()), shape=(n, n))
+    a.data[:] = 1
+    a.sum_duplicates()
+    a.data[:] = 1
+    two = ((a @ a) - a).tocsr()
+    two.data = (two.data > 0).astype(np.int64)
+    two.eliminate_zeros()
+    if drop_diag:
+        two.setdiag(0)
+        two.eliminate_zeros()
+    two.sort_indices()
+    return torch.from_numpy(two.indptr.astype(np.int32)), torch.from_numpy(two.indices.astype(np.int32))
+
+
+def gaussian_kernel(D, l, *, want_out=True, want_rowsum=False):
+    out = torch.exp(-(D.double() ** 2) / (2.0 * float(l) ** 2))
+    if D.dim() == 1:
+        return out.float(), None
+    return (out.float() if want_out else None), (out.sum(1).float() if want_rowsum else None)
+
+
+def exclusive_scan(x):
+    out = torch.zeros(x.numel() + 1, dtype=x.dtype)
+    out[1:] = torch.cumsum(x, 0)
+    return out
+
+
+def csr_row_normalize(rowptr, val):
+    """out[e] = deg(row) * val[e] / sum(val[row]) (dh_csr_row_normalize_f32; float64 row sums like the kernel's)."""
+    rows, n = _edge_rows(rowptr), rowptr.numel() - 1
+    deg = (rowptr[1:] - rowptr[:-1]).to(torch.float32)
+    sums = torch.zeros(n, dtype=torch.float64).index_add_(0, rows, val.double()).float()
+    return deg[rows] * val / sums[rows]
+
+
+def cellgene_graph_assemble(rowptr_x, col_x, val_x, rowptr_t, col_t, val_t, perm_t, n_cells, n_genes):
+    """The layout dh_cellgene_graph_assemble writes: gene rows = their cells (ascending, edge id = position in X) + self loop,
+    then cell rows = their genes (ascending, edge id = nnz + position) + self loop (edge ids 2 nnz + node)."""
+    nnz, n_nodes = col_x.numel(), n_cells + n_genes
+    rowptr, col, val, eid = [0], [], [], []
+    for g in range(n_genes):
+        s, t = int(rowptr_t[g]), int(rowptr_t[g + 1])
+        col += (n_genes + col_t[s:t].to(torch.int64)).tolist() + [g]
+        val += val_t[s:t].tolist() + [1.0]
+        eid += perm_t[s:t].tolist() + [2 * nnz + g]
+        rowptr.append(len(col))
+    for c in range(n_cells):
+        s, t = int(rowptr_x[c]), int(rowptr_x[c + 1])
+        col += col_x[s:t].tolist() + [n_genes + c]
+        val += val_x[s:t].tolist() + [1.0]
+        eid += list(range(nnz + s, nnz + t)) + [2 * nnz + n_genes + c]
+        rowptr.append(len(col))
+    return (torch.tensor(rowptr, dtype=torch.int32), torch.tensor(col, dtype=torch.int32), torch.tensor(val, dtype=torch.float32),
+            torch.tensor(eid, dtype=torch.int32))
+
+
+def sage_mfma_supported(n_cols, width, dtype):
+    return False
+
+
+def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H):
+    """neigh[v] = mean_e alpha[idx(e)] * w_e * H[src(e)] with the alpha rule of gnn.py:72-76 (dh_sage_aggregate_f32)."""
+    rows, n_dst = _edge_rows(rowptr), rowptr.numel() - 1
+    e0, e1 = int(rowptr[0]), int(rowptr[-1])      # row pointers may be absolute offsets into a larger edge array
+    col, w = col[e0:e1], w[e0:e1]
+    alpha = alpha.reshape(-1)
+    n_genes = alpha.numel() - 2
+    sid, did = src_cell_id[col.long()].long(), dst_cell_id[rows].long()
+    idx = torch.full_like(sid, n_genes + 1)
+    idx = torch.where((sid >= 0) & (did < 0), sid, idx)
+    idx = torch.where((did >= 0) & (sid < 0), did, idx)
+    idx = torch.where((did >= 0) & (sid >= 0), torch.full_like(idx, n_genes), idx)
+    m = (H[col.long()] * alpha[idx][:, None]) * w[:, None]
+    out = torch.zeros((n_dst, H.shape[1]), dtype=torch.float64).index_add_(0, rows, m.double())
+    deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).to(torch.float64)
+    return (out / deg[:, None]).float()
+
+
+# every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
+STAND_INS = ("gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
+             "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
+             "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
+             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate")

@@ -15,8 +15,7 @@ from conftest import rel_err
 from oracle import graphs as og
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "graphsc.npz")
-STAND_INS = ("gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "block_build",
-             "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported")
+STAND_INS = cpu_ops.STAND_INS
 
 
 def _graph(gold):

@@ -1,0 +1,263 @@
+"""Model-level host logic on CPU tensors against the reference's golden outputs: the ``fit`` / ``predict`` loops, loss
+arithmetic, optimiser wiring and state-dict layout of the mirrored models, with every HIP kernel replaced by the torch /
+scipy stand-ins of tests/cpu_ops.py.  The goldens come from the reference's OWN classes (tests/golden/make_golden.py); the
+GPU suite runs the same comparisons through the kernels (tests/test_gpu_*.py).  Nothing here needs a GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import cpu_ops
+from conftest import rel_err
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    from dance_amd import kernels
+    for name in cpu_ops.STAND_INS:
+        monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
+    return kernels
+
+
+def test_scdsc_fit_predict_vs_reference_on_cpu(cpu_kernels, tmp_path):
+    """ScDSC.fit (pre-training, joint loop, best-ARI checkpoint; scdsc.py:200-288) == the reference's own fit."""
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSC
+    g = np.load(os.path.join(GOLDEN, "scdsc_fit.npz"))
+    kw = json.loads(str(g["sf_kw"]))
+    n = g["sf_x"].shape[0]
+    m = ScDSC(pretrain_path=str(tmp_path / "ae.pt"), device="cpu", **kw)
+    sd0 = {k.split("::", 1)[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sf_sd0::")}
+    assert sorted(sd0) == sorted(m.model.state_dict())
+    m.model.load_state_dict(sd0)
+    adj = sp.csr_matrix((g["sf_adj_data"], g["sf_adj_indices"], g["sf_adj_indptr"]), shape=(n, n))
+    torch.manual_seed(10)
+    m.fit((adj, g["sf_x"], g["sf_counts"], g["sf_n_counts"].astype(np.float64)), g["sf_y"], lr=1e-3, epochs=12, pt_epochs=3, pt_batch_size=32,
+          pt_lr=1e-3)
+    q = m.predict_proba()
+    assert q.shape == g["sf_q"].shape and np.allclose(q.sum(1), 1, atol=1e-5)
+    assert rel_err(q, g["sf_q"]) < 5e-3
+    assert (m.predict() == g["sf_pred"]).mean() > 0.98
+    for k in g.files:
+        if k.startswith("sf_sd1::") and "num_batches_tracked" not in k:
+            got = m.model.state_dict()[k.split("::", 1)[1]].cpu().numpy()
+            assert np.abs(got - g[k]).max() < 1.5e-2 * max(1.0, np.abs(g[k]).max()), k
+
+
+SCTAG_KW = dict(n_clusters=3, k=3, hidden_dim=16, latent_dim=6, dec_dim=[12, 16, 20], dropout=0.0, device="cpu")
+
+
+def test_sctag_forward_and_fit_vs_reference_on_cpu(cpu_kernels):
+    """ScTAG forward (TAGConv hops, adjacency / ZINB decoders) and fit (pre-training + AMSGrad loop; sctag.py:84-528)."""
+    from dance_amd.modules.single_modality.clustering.sctag import ScTAG
+    g = np.load(os.path.join(GOLDEN, "sctag.npz"))
+    m = ScTAG(**SCTAG_KW)
+    m.init_model(g["tg_adj"], g["tg_x"])
+    sd = {k.split("::", 1)[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith("tg_sd0::")}
+    assert sorted(sd) == sorted(m.state_dict())
+    m.load_state_dict(sd)
+    x = torch.from_numpy(g["tg_x"])
+    with torch.no_grad():
+        adj_out, z, q, mean, disp, pi = m.forward(m.g_n, x)
+        enc_u = m.encoder1(m.g_n, x)
+    for got, name in ((adj_out, "adj_out"), (z, "z"), (q, "q"), (mean, "mean"), (disp, "disp"), (pi, "pi"), (enc_u, "enc_unweighted")):
+        assert rel_err(got.numpy(), g["tg_" + name]) < 1e-4, name
+    torch.manual_seed(5)
+    np.random.seed(0)
+    m = ScTAG(**SCTAG_KW)
+    m.fit((g["tg_adj"], g["tg_x"], g["tg_counts"], g["tg_n_counts"].astype(np.float64)), g["tg_y"], epochs=4, pretrain_epochs=3, lr=5e-3, w_d=0.1)
+    q = m.predict_proba()
+    assert rel_err(q, g["tg_fit_q"]) < 2e-2
+    assert (m.predict() == g["tg_fit_pred"]).mean() > 0.95
+    for k in g.files:
+        if k.startswith("tg_sd1::"):
+            got = m.state_dict()[k.split("::", 1)[1]].numpy()
+            assert np.abs(got - g[k]).max() < 4e-2 * max(1.0, np.abs(g[k]).max()), k
+
+
+def test_stagate_gatconv_and_pretrain_vs_reference_on_cpu(cpu_kernels):
+    """GATConv forward / hand-written backward wiring and the tied-weight Stagate auto-encoder (stagate.py:31-330)."""
+    from dance_amd.modules.spatial.spatial_domain.stagate import GATConv, Stagate
+    g = np.load(os.path.join(GOLDEN, "stagate.npz"))
+    d, c = g["sg_conv_lin"].shape
+    conv = GATConv(d, c, heads=1, concat=False, dropout=0, add_self_loops=False, bias=False)
+    with torch.no_grad():
+        conv.lin_src.copy_(torch.from_numpy(g["sg_conv_lin"]))
+        conv.att_src.copy_(torch.from_numpy(g["sg_conv_att_src"]))
+        conv.att_dst.copy_(torch.from_numpy(g["sg_conv_att_dst"]))
+    x = torch.from_numpy(g["sg_x"]).requires_grad_(True)
+    ei = torch.from_numpy(g["sg_edge_index"])
+    y, (ei2, alpha) = conv(x, ei, return_attention_weights=True)
+    assert torch.equal(ei2, ei)
+    assert rel_err(y.detach().numpy(), g["sg_conv_out"]) < 1e-5
+    assert rel_err(alpha.detach().numpy(), g["sg_conv_alpha"]) < 1e-5
+    y.backward(torch.from_numpy(g["sg_conv_dy"]))
+    assert rel_err(x.grad.numpy(), g["sg_conv_dx"]) < 1e-4
+    assert rel_err(conv.lin_src.grad.numpy(), g["sg_conv_dlin"]) < 1e-4
+    assert rel_err(conv.att_src.grad.numpy(), g["sg_conv_datt_src"]) < 1e-4
+    assert rel_err(conv.att_dst.grad.numpy(), g["sg_conv_datt_dst"]) < 1e-4
+    m = Stagate([g["sg_x"].shape[1], 12, 6], device="cpu")
+    sd = {k.split("::", 1)[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sg_sd0::")}
+    assert sorted(sd) == sorted(m.state_dict())
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        h2, h4 = m(torch.from_numpy(g["sg_x"]), ei)
+    assert rel_err(h2.numpy(), g["sg_h2"]) < 1e-5 and rel_err(h4.numpy(), g["sg_h4"]) < 1e-5
+    m.pretrain(g["sg_x"], g["sg_edge_index"], lr=1e-2, weight_decay=1e-4, epochs=5, gradient_clipping=5)
+    assert rel_err(m.rep, g["sg_rep"]) < 5e-3
+
+
+def _scheteronet(gold):
+    import types
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import scHeteroNet
+    n, d, c, hid = (int(v) for v in gold["sh_dims"])
+    m = scHeteroNet(d, c, torch.from_numpy(gold["sh_edge_index"]), n, hid, 2, 0.0, True, "cpu", 100.0)
+    sd = {k.split("::", 1)[1]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sh_sd0::")}
+    assert sorted(sd) == sorted(m.state_dict())
+    m.load_state_dict(sd)
+    ds = types.SimpleNamespace(x=torch.from_numpy(gold["sh_x"]), edge_index=torch.from_numpy(gold["sh_edge_index"]),
+                               y=torch.from_numpy(gold["sh_y"])[:, None], splits={"train": torch.arange(0, n, 2)}, node_idx=torch.arange(n))
+    return m, ds
+
+
+def test_scheteronet_forward_and_fit_step_vs_reference_on_cpu(cpu_kernels):
+    """init_adj (gcn_norm, strict two-hop pattern), HetConv forward, energy propagation, detect and one fit step
+    (scheteronet.py:374-789)."""
+    import types
+    gold = np.load(os.path.join(GOLDEN, "scheteronet.npz"))
+    m, ds = _scheteronet(gold)
+    enc = m.encoder
+    assert rel_err(enc.adj_t.to_dense().numpy(), gold["sh_adj_t"]) < 1e-6
+    assert np.array_equal(enc.adj_t2.to_dense().numpy() != 0, gold["sh_adj_t2"] != 0)
+    assert rel_err(enc.adj_t2.to_dense().numpy(), gold["sh_adj_t2"]) < 1e-6
+    m.eval()
+    with torch.no_grad():
+        h, mean, disp, pi = enc(ds.x, ds.edge_index, decoder=True)
+        assert rel_err(h.numpy(), gold["sh_logits"]) < 1e-4
+        assert rel_err(mean.numpy(), gold["sh_mean"]) < 1e-4 and rel_err(disp.numpy(), gold["sh_disp"]) < 1e-4
+        assert rel_err(pi.numpy(), gold["sh_pi"]) < 1e-4
+        e = torch.from_numpy(gold["sh_e"])
+        assert rel_err(m.propagation(e, ds.edge_index, 2, 0.5).numpy(), gold["sh_prop"]) < 1e-5
+        assert rel_err(m.two_hop_propagation(e, ds.edge_index, 1, 0.3).numpy(), gold["sh_prop2"]) < 1e-5
+        assert rel_err(m.detect(ds, ds.node_idx, "cpu", 1.0, True, False, 2, 0.5).numpy(), gold["sh_detect"]) < 1e-4
+    assert np.array_equal(m.predict(ds).numpy(), gold["sh_logits"].argmax(1))
+    m, ds = _scheteronet(gold)
+    adata = types.SimpleNamespace(raw=types.SimpleNamespace(X=gold["sh_counts"]), obs={"size_factors": gold["sh_size_factors"]})
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    loss = m.fit(ds, ds, True, adata, 0.5, 0.0, 0.4, torch.nn.NLLLoss(), opt)
+    assert abs(float(loss) - float(gold["sh_loss"])) < 1e-4 * abs(float(gold["sh_loss"]))
+    for k in gold.files:
+        if k.startswith("sh_sd1::") and "num_batches_tracked" not in k:
+            got = m.state_dict()[k.split("::", 1)[1]].numpy()
+            assert np.abs(got - gold[k]).max() < 2e-3 * max(1.0, np.abs(gold[k]).max()), k
+
+
+def test_spagcn_heads_vs_reference_on_cpu(cpu_kernels):
+    """SimpleGCDEC forward / target distribution / KL loss / gradients vs the reference's class (spagcn.py:369-478), the
+    calculate_p / search_l bisection and calc_adj_exp vs the oracle restatement (spagcn.py:249-334), and a planted-domain fit
+    (kmeans init, dense adjacency) through the host loop."""
+    from oracle import matrix as om
+    from oracle import spagcn as osp
+    from sklearn.metrics import adjusted_rand_score
+    from dance_amd.modules.spatial.spatial_domain.spagcn import SimpleGCDEC, SpaGCN, calculate_p
+    h = np.load(os.path.join(GOLDEN, "model_heads.npz"))
+    m = SimpleGCDEC(12, 12, device="cpu")
+    t = torch.from_numpy
+    m.gc.weight.data, m.gc.bias.data = t(h["gcdec_w"]), t(h["gcdec_b"])
+    m.mu = torch.nn.Parameter(t(h["gcdec_mu"]))
+    z, q = m.forward(t(h["gcdec_x"]), t(h["gcdec_adj"]))
+    p = m.target_distribution(q)
+    loss = m.loss_function(p.data, q)
+    loss.backward()
+    assert rel_err(z.detach().numpy(), h["gcdec_z"]) < 1e-5 and rel_err(q.detach().numpy(), h["gcdec_q"]) < 1e-5
+    assert rel_err(p.detach().numpy(), h["gcdec_p"]) < 1e-5
+    assert abs(loss.item() - float(h["gcdec_loss"])) < 1e-5 * max(1, abs(float(h["gcdec_loss"])))
+    assert rel_err(m.gc.weight.grad.numpy(), h["gcdec_dw"]) < 1e-3 and rel_err(m.mu.grad.numpy(), h["gcdec_dmu"]) < 1e-3
+    rng = np.random.default_rng(0)
+    xyz = (rng.random((300, 3)) * 40).astype(np.float32)
+    adj = om.pairwise_distance(xyz, 0)
+    for l in (0.5, 2.0, 10.0):
+        assert abs(calculate_p(adj, l, "cpu") - osp.calculate_p(adj, l)) < 1e-4 * max(1.0, osp.calculate_p(adj, l))
+    model = SpaGCN(device="cpu")
+    l_hip, l_ref = model.search_l(0.5, adj, start=0.01, end=1000, tol=0.01, max_run=100), osp.search_l(0.5, adj)
+    assert l_ref is not None and l_hip == pytest.approx(l_ref, rel=1e-6)
+    model.set_l(l_hip)
+    assert rel_err(model.calc_adj_exp(adj).numpy(), osp.calc_adj_exp(adj, l_hip)) < 1e-5
+    torch.manual_seed(0)
+    rng = np.random.default_rng(1)
+    side = 16
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    xy = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    dom = (xy[:, 0] >= side / 2).astype(int) + 2 * (xy[:, 1] >= side / 2).astype(int)
+    embed = (np.eye(4)[dom] @ rng.standard_normal((4, 10)) * 2 + rng.standard_normal((xy.shape[0], 10))).astype(np.float32)
+    adj = om.pairwise_distance(xy, 0)
+    model = SpaGCN(device="cpu")
+    model.set_l(model.search_l(0.5, adj))
+    np.random.seed(0)
+    model.fit((embed, adj), init="kmeans", n_clusters=4, epochs=40, lr=0.01, tol=1e-4)
+    assert adjusted_rand_score(dom, model.predict((embed, adj))) > 0.9
+    with pytest.raises(ValueError):
+        SpaGCN(device="cpu").fit((embed, adj))
+
+
+def test_scdsc_model_forward_vs_reference_on_cpu(cpu_kernels):
+    """ScDSCModel.forward (AE + four GNNLayers + ZINB heads; scdsc.py:291-472) with the reference's weights."""
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSCModel
+    h = np.load(os.path.join(GOLDEN, "model_heads.npz"))
+    kw = json.loads(str(h["scdsc_kw"]))
+    model = ScDSCModel(**kw, device="cpu").eval()
+    sd = {k.split("::", 1)[1]: torch.from_numpy(h[k]) for k in h.files if k.startswith("scdsc_sd::")}
+    assert set(sd) == set(model.state_dict())
+    model.load_state_dict(sd)
+    n = h["scdsc_x"].shape[0]
+    a = sp.csr_matrix((h["scdsc_adj_data"], h["scdsc_adj_indices"], h["scdsc_adj_indptr"]), shape=(n, n)).tocoo()
+    adj = torch.sparse_coo_tensor(np.vstack((a.row, a.col)).astype(np.int64), a.data, (n, n))
+    with torch.no_grad():
+        x_bar, q, predict, z3, _mean, _disp, _pi, zinb = model(torch.from_numpy(h["scdsc_x"]), adj)
+    for name, val in (("x_bar", x_bar), ("q", q), ("predict", predict), ("z3", z3), ("mean", _mean), ("disp", _disp), ("pi", _pi)):
+        assert rel_err(val.numpy(), h[f"scdsc_{name}"]) < 1e-5, name
+
+
+def test_scdeepsort_fit_predict_small_on_cpu(cpu_kernels, tmp_path):
+    """BASELINE config 1 through the host logic: PCACellFeatureGraph -> ScDeepSort.fit (train / validation split, block
+    loader, AdaptiveSAGE with the computed-and-dropped ``neigh``, checkpointing) -> predict with the unsure rule; the logits
+    equal the reference arithmetic (gnn.py:92-96, scdeepsort.py:84-88) evaluated in plain torch."""
+    from dance_amd.data import AnnDataLite, Data
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    n_cells, n_genes, n_types, n_train = 360, 80, 4, 300
+    types = rng.integers(0, n_types, n_cells)
+    rates = rng.gamma(0.3, 1.0, (n_types, n_genes)) * 2
+    x = rng.poisson(rates[types]).astype(np.float32)
+    onehot = np.eye(n_types, dtype=np.float32)[types]
+    data = Data(AnnDataLite(x, obsm={"cell_type": onehot}), train_size=n_train)
+    data.set_config(feature_channel=None, feature_channel_type="X")
+    pipe = ScDeepSort.preprocessing_pipeline(n_components=16, log_level="WARNING")
+    for t in getattr(pipe, "transforms", []):
+        if hasattr(t, "device"):
+            t.device = "cpu"
+    pipe(data)
+    g = data.data.uns["CellFeatureGraph"]
+    train_nodes = torch.cat((torch.arange(n_genes), n_genes + torch.arange(n_train)))
+    test_nodes = torch.cat((torch.arange(n_genes), n_genes + torch.arange(n_train, n_cells)))
+    g_train, g_test = g.subgraph(train_nodes), g.subgraph(test_nodes)
+    model = ScDeepSort(16, 16, 1, "synthetic", "blob", batch_size=64, device="cpu", save_root=tmp_path, verbose=False)
+    model.fit(g_train, torch.from_numpy(types)[:n_train], epochs=15, lr=1e-2, val_ratio=0.2)
+    prob = model.predict_proba(g_test)
+    assert prob.shape == (n_cells - n_train, n_types) and np.allclose(prob.sum(1), 1, atol=1e-5)
+    pred, unsure = model.predict(g_test, return_unsure=True)
+    acc = model.score(g_test, onehot[n_train:])
+    assert acc == pytest.approx((pred == types[n_train:]).mean()) and acc > 0.85
+    sd = model.model.state_dict()
+    feats = g_test.ndata["features"][n_genes:]
+    hid = torch.relu(feats @ sd["layers.0.layers.1.weight"].t() + sd["layers.0.layers.1.bias"])
+    ref_prob = torch.softmax(hid @ sd["linear.weight"].t() + sd["linear.bias"], -1).numpy()
+    assert np.abs(prob - ref_prob).max() < 1e-5
+    assert torch.all(sd["alpha"] == 1)
+    assert model.model.layers[0].last_neigh is not None   # the aggregation ran (and was dropped, as in the reference)
+    assert (tmp_path / "saved_models/single_modality/cell_type_annotation/pretrained/synthetic/models/synthetic-blob.pt").exists()
