@@ -236,8 +236,11 @@ def _dst_edge_hook(blocks):
     last = blocks[-1]
     outside = (last.col >= last.number_of_dst_nodes()).to(torch.uint8)
     order = torch.sort(outside, stable=True).indices
+    inside = (outside.numel() - outside.sum(dtype=torch.int64)).reshape(1)
+    if not inside.is_cuda:  # host tensors (tests): nothing to wait for
+        return order, inside, None
     cnt = _pinned_count_slot()
-    cnt.copy_((outside.numel() - outside.sum(dtype=torch.int64)).reshape(1), non_blocking=True)
+    cnt.copy_(inside, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
     return order, cnt, ev
@@ -301,8 +304,7 @@ class GraphSC(BaseClusteringMethod):
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
         can_fuse = (DECODER_MODE in ("fused", "fused-sync") and getattr(self.model.decoder, "linear_logits", False)
                     and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
-        fused = can_fuse and DECODER_MODE == "fused" and g.device.type == "cuda"  # the block hook works with streams / events
-        fused_sync = can_fuse and not fused
+        fused, fused_sync = can_fuse and DECODER_MODE == "fused", can_fuse and DECODER_MODE == "fused-sync"
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr)
@@ -321,7 +323,8 @@ class GraphSC(BaseClusteringMethod):
                     # batch's own cells: _dst_edge_hook listed them one batch ahead on the loader's stream, so their count —
                     # adj.sum() of :210-213 — is on the host by now and pos_weight / norm are plain floats
                     order_e, cnt, ev = last.hook_out
-                    ev.synchronize()
+                    if ev is not None:
+                        ev.synchronize()
                     n_listed = int(cnt)
                     sel = order_e[:n_listed]
                     us = last.col[sel].to(torch.int64)

@@ -32,14 +32,14 @@ def _graph(gold):
                          {"cell_id": torch.from_numpy(e["cell_id"]), "feat_id": torch.from_numpy(e["feat_id"]), "features": torch.from_numpy(feats)})
 
 
-@pytest.mark.parametrize("mode", ["fused", "dense"])
+@pytest.mark.parametrize("mode", ["fused", "fused-sync", "dense"])
 @pytest.mark.parametrize("tag,batch_size,agg", [("full", 64, "sum"), ("mb", 16, "sum"), ("mean", 16, "mean")])
 def test_graphsc_fit_host_logic_vs_reference(monkeypatch, tag, batch_size, agg, mode):
     from dance_amd import kernels
     from dance_amd.modules.single_modality.clustering import graphsc
     for name in STAND_INS:
         monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
-    monkeypatch.setattr(graphsc, "DECODER_MODE", mode)   # "fused" on CPU tensors = the fused loss with nonzero()-selected entries
+    monkeypatch.setattr(graphsc, "DECODER_MODE", mode)   # "fused": listed entries from the loader's block hook (the GPU default)
     gold = np.load(GOLD)
     kw = json.loads(str(gold["gsc_kw"]))
     kw["agg"] = agg
