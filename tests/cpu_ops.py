@@ -300,8 +300,13 @@ def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H):
     return (out / deg[:, None]).float()
 
 
+def pairwise_distance(X, metric=0):
+    from oracle import matrix as om
+    return torch.from_numpy(np.ascontiguousarray(om.pairwise_distance(X.numpy().astype(np.float32), int(metric)), dtype=np.float32))
+
+
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
 STAND_INS = ("gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
-             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate")
+             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance")

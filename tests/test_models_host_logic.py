@@ -261,3 +261,43 @@ def test_scdeepsort_fit_predict_small_on_cpu(cpu_kernels, tmp_path):
     assert torch.all(sd["alpha"] == 1)
     assert model.model.layers[0].last_neigh is not None   # the aggregation ran (and was dropped, as in the reference)
     assert (tmp_path / "saved_models/single_modality/cell_type_annotation/pretrained/synthetic/models/synthetic-blob.pt").exists()
+
+
+def test_graph_transforms_vs_reference_on_cpu(cpu_kernels):
+    """The graph transforms' host logic (CSR views of X, edge-id bookkeeping that restores the reference's edge order, node
+    frames, kNN / radius edge lists, the histology z coordinate) against tests/golden/graph_builders.npz — outputs of the
+    reference's own ``__call__`` / ``build_graph`` methods."""
+    from oracle import matrix as om
+    from dance_amd.data import AnnDataLite, Data
+    from dance_amd.transforms.graph import CellFeatureGraph, HeteronetGraph, SpaGCNGraph, StagateGraph
+    gold = np.load(os.path.join(GOLDEN, "graph_builders.npz"))
+    for norm in (0, 1):
+        data = Data(AnnDataLite(gold["cfg_x"], obsm={"f": gold["cfg_cell_feat"]}, varm={"f": gold["cfg_gene_feat"]}))
+        t = CellFeatureGraph("f", normalize_edges=bool(norm))
+        t.device = "cpu"
+        t(data)
+        g = data.data.uns["CellFeatureGraph"]
+        tag = f"cfg_norm{norm}_"
+        src, dst = g.edges()
+        assert np.array_equal(src.numpy(), gold[tag + "src"]) and np.array_equal(dst.numpy(), gold[tag + "dst"])
+        assert rel_err(g.edata["weight"].numpy().ravel(), gold[tag + "weight"]) < 1e-6
+        assert np.array_equal(g.ndata["cell_id"].numpy(), gold[tag + "cell_id"])
+        assert np.array_equal(g.ndata["feat_id"].numpy(), gold[tag + "feat_id"])
+        assert np.array_equal(g.ndata["features"].numpy(), gold[tag + "features"])
+    het = HeteronetGraph(knn_num=5)
+    het.device = "cpu"
+    assert np.array_equal(het.build_graph(gold["het_feats"], knears=5), gold["het_edges"])
+    xy = gold["stg_xy"]
+    data = Data(AnnDataLite(np.zeros((xy.shape[0], 2), np.float32), obsm={"spatial_pixel": xy}))
+    for t in (StagateGraph("radius", radius=1.7, out="r"), StagateGraph("knn", n_neighbors=4, out="k")):
+        t.device = "cpu"
+        t(data)
+    assert np.array_equal(np.asarray(data.data.obsp["r"].todense(), dtype=np.float32), gold["stg_radius"])
+    assert np.array_equal(np.asarray(data.data.obsp["k"].todense(), dtype=np.float32), gold["stg_knn"])
+    n = gold["spg_xy"].shape[0]
+    data = Data(AnnDataLite(np.zeros((n, 2), np.float32), obsm={"spatial": gold["spg_xy"], "spatial_pixel": gold["spg_xy_pixel"]},
+                            uns={"image": gold["spg_img"]}))
+    t = SpaGCNGraph(alpha=float(gold["spg_alpha"]), beta=int(gold["spg_beta"]))
+    t.device = "cpu"
+    t(data)
+    assert np.array_equal(data.data.obsp["SpaGCNGraph"], om.pairwise_distance(gold["spg_xyz"], 0))
