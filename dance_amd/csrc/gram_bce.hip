@@ -227,6 +227,69 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(int n, int d, int dp, 
   }
 }
 
+// ---- the y = 1 entries of the target (edges among the batch's own cells), listed as (us[e], vs[e]) ---------------------------
+// forward: xe[e] = <z_us, z_vs> and term[e] = p * softplus(-xe) - softplus(xe), the correction that turns the all-zero-target
+// loss of the dense pass into the weighted BCE; one wavefront per entry, butterfly reduction (every lane ends with the same sum).
+__device__ __forceinline__ float softplus_exact(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void gram_listed_forward_kernel(int64_t n_listed, int d, const float* __restrict__ Z, int64_t ldz,
+                                                                 const int32_t* __restrict__ us, const int32_t* __restrict__ vs, float p,
+                                                                 float* __restrict__ xe, float* __restrict__ term) {
+  const int lane = threadIdx.x & 63;
+  const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= n_listed) return;
+  const float* a = Z + (int64_t)us[e] * ldz;
+  const float* b = Z + (int64_t)vs[e] * ldz;
+  float acc = 0.f;
+  for (int c = lane; c < d; c += 64) acc = fmaf(a[c], b[c], acc);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) {
+    xe[e] = acc;
+    term[e] = p * softplus_exact(-acc) - softplus_exact(acc);
+  }
+}
+
+// backward: dZ[i, :] = 2 s O[i, :] + s sum_e c_e ([us[e] == i] z[vs[e], :] + [vs[e] == i] z[us[e], :]),  s = scale[0],
+// c_e = p (sigmoid(xe) - 1) - sigmoid(xe).  One workgroup per row i, one column per thread; every wavefront scans the entry list
+// 64 at a time (coalesced), ballots the entries that touch row i and applies them in list order: fixed summation order, no
+// atomics, no sort.
+__global__ __launch_bounds__(320) void gram_listed_backward_kernel(int d, int64_t n_listed, const float* __restrict__ Z, int64_t ldz,
+                                                                  const float* __restrict__ O, int64_t ldo, const int32_t* __restrict__ us,
+                                                                  const int32_t* __restrict__ vs, const float* __restrict__ xe, float p,
+                                                                  const float* __restrict__ scale, float* __restrict__ dZ, int64_t ldd) {
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int c = threadIdx.x;  // column owned by this thread (threads beyond d only help scanning)
+  const float s = scale[0];
+  float acc = c < d ? 2.f * O[(int64_t)i * ldo + c] : 0.f;
+  for (int64_t base = 0; base < n_listed; base += 64) {
+    const int64_t e = base + lane;
+    int u = -1, v = -1;
+    float x = 0.f;
+    if (e < n_listed) {
+      u = us[e];
+      v = vs[e];
+    }
+    const bool hit = (u == i) || (v == i);
+    if (hit) x = xe[e];
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int l = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int uu = __shfl(u, l, 64), vv = __shfl(v, l, 64);
+      const float xx = __shfl(x, l, 64);
+      const float sg = 1.f / (1.f + expf(-xx));
+      const float ce = p * (sg - 1.f) - sg;
+      if (c < d) {
+        if (uu == i) acc = fmaf(ce, Z[(int64_t)vv * ldz + c], acc);
+        if (vv == i) acc = fmaf(ce, Z[(int64_t)uu * ldz + c], acc);
+      }
+    }
+  }
+  if (c < d) dZ[(int64_t)i * ldd + c] = s * acc;
+}
+
 struct Plan {
   int dp, i_blocks, splits, j_per_split, n_pad;
   size_t opart_bytes, lpart_bytes;
@@ -300,4 +363,27 @@ extern "C" int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t
   const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 65536 ? dh::ceil_div(work, 256) : 65536);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)n, (int)d, p.dp, p.n_pad, p.splits, Opart, Lpart, O, ldo, rowloss);
   return dh::check_launch("dh_gram_sigmoid_f32 (reduce)");
+}
+
+extern "C" int dh_gram_listed_forward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const int32_t* us,
+                                          const int32_t* vs, float pos_weight, float* xe, float* term, dh_stream_t stream) {
+  if (n < 0 || d < 0 || n_listed < 0) return dh::fail(DH_ERR_INVALID, "dh_gram_listed_forward_f32: negative size");
+  if (n_listed == 0) return DH_OK;
+  if (!Z || !us || !vs || !xe || !term || ldz < d) return dh::fail(DH_ERR_INVALID, "dh_gram_listed_forward_f32: bad pointer / leading dimension");
+  hipLaunchKernelGGL(gram_listed_forward_kernel, dim3((unsigned)dh::ceil_div(n_listed, 4)), dim3(256), 0, dh::as_stream(stream), n_listed, (int)d, Z,
+                     ldz, us, vs, pos_weight, xe, term);
+  return dh::check_launch("dh_gram_listed_forward_f32");
+}
+
+extern "C" int dh_gram_listed_backward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const float* O, int64_t ldo,
+                                           const int32_t* us, const int32_t* vs, const float* xe, float pos_weight, const float* scale,
+                                           float* dZ, int64_t ldd, dh_stream_t stream) {
+  if (n < 0 || d < 0 || n_listed < 0) return dh::fail(DH_ERR_INVALID, "dh_gram_listed_backward_f32: negative size");
+  if (n == 0 || d == 0) return DH_OK;
+  if (d > MAX_D) return dh::fail(DH_ERR_INVALID, "dh_gram_listed_backward_f32: d = %lld outside [1, %d]", (long long)d, MAX_D);
+  if (!Z || !O || !scale || !dZ || ldz < d || ldo < d || ldd < d || (n_listed > 0 && (!us || !vs || !xe)))
+    return dh::fail(DH_ERR_INVALID, "dh_gram_listed_backward_f32: bad pointer / leading dimension");
+  hipLaunchKernelGGL(gram_listed_backward_kernel, dim3((unsigned)n), dim3(320), 0, dh::as_stream(stream), (int)d, n_listed, Z, ldz, O, ldo, us, vs, xe,
+                     pos_weight, scale, dZ, ldd);
+  return dh::check_launch("dh_gram_listed_backward_f32");
 }

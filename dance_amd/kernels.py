@@ -305,6 +305,31 @@ def gram_sigmoid(Z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return rowloss, out
 
 
+def gram_listed_forward(Z: torch.Tensor, us: torch.Tensor, vs: torch.Tensor, pos_weight: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(xe, term) for the listed y = 1 entries (us[e], vs[e]) of graph-sc's decoder target: xe = <z_us, z_vs>,
+    term = pos_weight * softplus(-xe) - softplus(xe) (dh_gram_listed_forward_f32)."""
+    lib = _lib_ready()
+    n, d = Z.shape
+    e = us.numel()
+    xe = torch.empty(e, dtype=torch.float32, device=Z.device)
+    term = torch.empty(e, dtype=torch.float32, device=Z.device)
+    _call("gram_listed_forward_f32", lib.dh_gram_listed_forward_f32, n, d, e, _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(us, torch.int32, "us", 1),
+          _dev(vs, torch.int32, "vs", 1), float(pos_weight), xe.data_ptr(), term.data_ptr(), _stream())
+    return xe, term
+
+
+def gram_listed_backward(Z: torch.Tensor, O: torch.Tensor, us: torch.Tensor, vs: torch.Tensor, xe: torch.Tensor, pos_weight: float,
+                         scale: torch.Tensor) -> torch.Tensor:
+    """dZ = scale * (2 O + the listed entries' corrections), scale a device scalar (dh_gram_listed_backward_f32)."""
+    lib = _lib_ready()
+    n, d = Z.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=Z.device)
+    _call("gram_listed_backward_f32", lib.dh_gram_listed_backward_f32, n, d, us.numel(), _dev(Z, torch.float32, "Z", 2), _ld(Z),
+          _dev(O, torch.float32, "O", 2), _ld(O), _dev(us, torch.int32, "us", 1), _dev(vs, torch.int32, "vs", 1), _dev(xe, torch.float32, "xe", 1),
+          float(pos_weight), _dev(scale.reshape(1), torch.float32, "scale", 1), out.data_ptr(), _ld(out), _stream())
+    return out
+
+
 def colsum(X: torch.Tensor) -> torch.Tensor:
     """out[j] = sum_i X[i, j] (deterministic two-pass)."""
     lib = _lib_ready()

@@ -205,7 +205,31 @@ class _GramListedBCE(torch.autograd.Function):
         return dz, None, None, None
 
 
-def gram_listed_bce(z, us, vs, pos_weight):
+class _GramListedKernelBCE(torch.autograd.Function):
+    """_GramListedBCE with the listed entries handled by two small kernels instead of ~40 torch launches (gathers, softplus,
+    two sorted ``index_put_``): dh_gram_listed_forward_f32 / _backward_f32.  ``us`` / ``vs`` int32, ``p`` a python float.
+    Written at the end of round 2 and validated against the kernel stand-ins only (DANCE_AMD_GRAPHSC_DECODER=fused-listed);
+    not the default until it has run on the hardware."""
+
+    @staticmethod
+    def forward(ctx, z, us, vs, p):
+        n = z.shape[0]
+        rowloss, o = kernels.gram_sigmoid(z)
+        xe, term = kernels.gram_listed_forward(z, us, vs, p)
+        ctx.save_for_backward(z, o, us, vs, xe)
+        ctx.p = p
+        return ((rowloss.sum(dtype=torch.float64) + term.sum(dtype=torch.float64)) / float(n * n)).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, o, us, vs, xe = ctx.saved_tensors
+        scale = (g / float(z.shape[0]**2)).to(torch.float32)
+        return kernels.gram_listed_backward(z, o, us, vs, xe, ctx.p, scale), None, None, None
+
+
+def gram_listed_bce(z, us, vs, pos_weight, *, listed_kernels: bool = False):
+    if listed_kernels:
+        return _GramListedKernelBCE.apply(z.contiguous(), us.to(torch.int32), vs.to(torch.int32), float(pos_weight))
     return _GramListedBCE.apply(z.contiguous(), us, vs, pos_weight)
 
 
@@ -248,7 +272,8 @@ def _dst_edge_hook(blocks):
 
 # "fused": GraphSC.fit evaluates the decoder loss by dh_gram_sigmoid_f32 (no B x B logits), the listed target entries come
 # from the loader's block hook (no host round trip on the model's stream); "fused-sync": same kernel, entries selected by
-# nonzero(); "dense": z z^T GEMM + passes over the logits
+# nonzero(); "dense": z z^T GEMM + passes over the logits; "fused-listed": as "fused" with the listed entries handled by
+# dh_gram_listed_* (written at the end of round 2, not yet run on the hardware — opt-in)
 DECODER_MODE = os.environ.get("DANCE_AMD_GRAPHSC_DECODER", "fused")
 
 
@@ -302,9 +327,9 @@ class GraphSC(BaseClusteringMethod):
             sharding.broadcast_parameters(self.model)
             train_ids = sharding.shard_seed_ids(torch.from_numpy(train_ids)).numpy()
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
-        can_fuse = (DECODER_MODE in ("fused", "fused-sync") and getattr(self.model.decoder, "linear_logits", False)
+        can_fuse = (DECODER_MODE in ("fused", "fused-sync", "fused-listed") and getattr(self.model.decoder, "linear_logits", False)
                     and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
-        fused, fused_sync = can_fuse and DECODER_MODE == "fused", can_fuse and DECODER_MODE == "fused-sync"
+        fused, fused_sync = can_fuse and DECODER_MODE in ("fused", "fused-listed"), can_fuse and DECODER_MODE == "fused-sync"
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr)
@@ -335,7 +360,8 @@ class GraphSC(BaseClusteringMethod):
                     norm = total / (factor if factor != 0 else 1.0)
                     # second forward, fresh dropout (:215); the decoder's own dropout (:409) is the last draw, as in the reference
                     _, emb2 = self.model.forward(blocks, input_features, decode=False)
-                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), us, vs, pos_weight)
+                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), us, vs, pos_weight,
+                                                  listed_kernels=DECODER_MODE == "fused-listed")
                     if not n_listed:  # the reference's 0 * inf (pos_weight = inf against an all-zero target)
                         loss = loss * float("nan")
                 else:

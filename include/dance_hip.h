@@ -321,6 +321,16 @@ DH_API size_t dh_gram_sigmoid_workspace_bytes(int64_t n, int64_t d);
 DH_API int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
                         void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* The y = 1 entries of the same loss (graphsc.py:208-214: the non-zeros of adj[dst][:, dst]), listed as (us[e], vs[e]), each at
+ * most once: forward xe[e] = <z_us, z_vs>, term[e] = pos_weight * softplus(-xe) - softplus(xe) (add sum(term) to sum(rowloss));
+ * backward dZ = scale[0] * (2 O + sum_e c_e (e_us z_vs^T + e_vs z_us^T)), c_e = pos_weight (sigmoid(xe) - 1) - sigmoid(xe), in list
+ * order (no atomics); scale is a DEVICE scalar.  Written in round 2, not yet on GraphSC.fit's default path.              */
+DH_API int dh_gram_listed_forward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const int32_t* us,
+                               const int32_t* vs, float pos_weight, float* xe, float* term, dh_stream_t stream);
+DH_API int dh_gram_listed_backward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const float* O,
+                                int64_t ldo, const int32_t* us, const int32_t* vs, const float* xe, float pos_weight,
+                                const float* scale, float* dZ, int64_t ldd, dh_stream_t stream);
+
 /* ---- message-flow blocks of the full-neighbour sampler (block.hip) -------------------------------------------
  * What dgl.dataloading.NeighborSampler([-1]*L, edge_dir="in") / MultiLayerFullNeighborSampler produce for a batch of
  * seed nodes (scdeepsort.py:183,233-236; graphsc.py:181-183): every in-edge of the seeds; source nodes = the seeds first,

@@ -305,8 +305,23 @@ def pairwise_distance(X, metric=0):
     return torch.from_numpy(np.ascontiguousarray(om.pairwise_distance(X.numpy().astype(np.float32), int(metric)), dtype=np.float32))
 
 
+def gram_listed_forward(Z, us, vs, pos_weight):
+    xe = (Z.double()[us.long()] * Z.double()[vs.long()]).sum(1)
+    sp = torch.nn.functional.softplus
+    return xe.float(), (pos_weight * sp(-xe) - sp(xe)).float()
+
+
+def gram_listed_backward(Z, O, us, vs, xe, pos_weight, scale):
+    sg = torch.sigmoid(xe.double())
+    ce = (pos_weight * (sg - 1) - sg)[:, None]
+    dz = 2 * O.double()
+    dz.index_add_(0, us.long(), ce * Z.double()[vs.long()])
+    dz.index_add_(0, vs.long(), ce * Z.double()[us.long()])
+    return (dz * scale.double().reshape(())).float()
+
+
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
 STAND_INS = ("gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
-             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance")
+             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward")
