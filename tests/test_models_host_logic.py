@@ -301,3 +301,38 @@ def test_graph_transforms_vs_reference_on_cpu(cpu_kernels):
     t.device = "cpu"
     t(data)
     assert np.array_equal(data.data.obsp["SpaGCNGraph"], om.pairwise_distance(gold["spg_xyz"], 0))
+
+
+def test_adaptive_sage_gradient_wiring_on_cpu(cpu_kernels):
+    """The intended AdaptiveSAGE model (use_neigh=True): the hand-written backward of the aggregation — alpha gradient through
+    the SDDMM + float64 bins, h gradient through the transposed block — against the float64 restatement (oracle/sage.py)."""
+    from oracle import sage as osg
+    from dance_amd.cellgraph import CellGeneGraph, NeighborSampler
+    from dance_amd.nn.gnn import _SageAggregateFn
+    import test_graphsc_host_logic as gh
+    gold = np.load(gh.GOLD)
+    g = gh._graph(gold)
+    n_cells, n_genes = gold["gsc_x"].shape
+    d = g.ndata["features"].shape[1]
+    seeds = torch.arange(n_genes, n_genes + 12)
+    _, _, blocks = NeighborSampler([-1]).sample(g, seeds)
+    blk = blocks[0]
+    torch.manual_seed(0)
+    feats = torch.randn(blk.number_of_src_nodes(), 8)
+    h = feats.clone().requires_grad_(True)
+    alpha = (torch.rand(n_genes + 2, 1) + 0.5).requires_grad_(True)
+    dn = torch.randn(12, 8)
+    neigh = _SageAggregateFn.apply(h, alpha, blk)
+    neigh.backward(dn)
+    rp = blk.rowptr.numpy()
+    e_dst = np.repeat(np.arange(12), np.diff(rp))
+    e_src, w = blk.col.numpy(), blk.val.numpy()
+    cid = blk.srcdata["cell_id"].numpy()
+    assert rel_err(neigh.detach().numpy(), osg.sage_neigh(e_src, e_dst, w, cid, cid[:12], alpha.detach().numpy(), feats.numpy(), 12)) < 1e-5
+    da_ref = osg.sage_alpha_grad(e_src, e_dst, w, cid, cid[:12], n_genes, feats.numpy(), dn.numpy())
+    assert rel_err(alpha.grad.numpy().ravel(), da_ref) < 1e-4
+    idx = osg.sage_alpha_index(cid[e_src], cid[:12][e_dst], n_genes)
+    coef = alpha.detach().numpy().ravel()[idx] * w / np.maximum(np.diff(rp), 1)[e_dst]
+    dh_ref = np.zeros((blk.number_of_src_nodes(), 8))
+    np.add.at(dh_ref, e_src, coef[:, None] * dn.numpy()[e_dst].astype(np.float64))
+    assert rel_err(h.grad.numpy(), dh_ref) < 1e-5
