@@ -240,16 +240,22 @@ def gram_target_bce(z, u, v, m, pos_weight):
     return gram_listed_bce(z, u[sel], v[sel], pos_weight)
 
 
-_PINNED_COUNTS = []
+class _PinnedCounts:
+    """A small ring of pinned int64 scalars for asynchronous count reads: a slot is handed out again ``slots`` batches later,
+    long after its value was read (the loader runs one batch ahead)."""
+
+    def __init__(self, slots: int = 4):
+        self._slots, self._n, self._next = [], slots, 0
+
+    def take(self) -> torch.Tensor:
+        if not self._slots:
+            self._slots = [torch.empty(1, dtype=torch.int64).pin_memory() for _ in range(self._n)]
+        slot = self._slots[self._next]
+        self._next = (self._next + 1) % self._n
+        return slot
 
 
-def _pinned_count_slot():
-    """A small ring of pinned int64 scalars for asynchronous count reads (a slot is reused four batches later)."""
-    if not _PINNED_COUNTS:
-        _PINNED_COUNTS.extend([torch.empty(1, dtype=torch.int64).pin_memory() for _ in range(4)] + [0])
-    i = _PINNED_COUNTS[-1]
-    _PINNED_COUNTS[-1] = (i + 1) % 4
-    return _PINNED_COUNTS[i]
+_PINNED_COUNTS = _PinnedCounts()
 
 
 def _dst_edge_hook(blocks):
@@ -263,7 +269,7 @@ def _dst_edge_hook(blocks):
     inside = (outside.numel() - outside.sum(dtype=torch.int64)).reshape(1)
     if not inside.is_cuda:  # host tensors (tests): nothing to wait for
         return order, inside, None
-    cnt = _pinned_count_slot()
+    cnt = _PINNED_COUNTS.take()
     cnt.copy_(inside, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
