@@ -104,6 +104,34 @@ def _cache_put(adj, g):
     weakref.finalize(adj, _CACHE.pop, key, None)
 
 
+class TensorKeyedCache:
+    """One-entry-per-tensor cache of derived graph structures, keyed by tensor IDENTITY and ``_version``.
+
+    A key built from ``data_ptr()`` + shape returns a stale structure after an in-place edit of the tensor and can alias a
+    NEW tensor that the caching allocator placed in a freed block of the same shape.  Here an entry is hit
+    only when the very same tensor object is passed again with an unchanged version counter; it is evicted when the tensor
+    dies.  ``extra`` distinguishes derived structures that depend on more than the tensor (e.g. the node count)."""
+
+    def __init__(self):
+        self._d = {}
+
+    def get(self, t: torch.Tensor, extra=None):
+        hit = self._d.get(id(t))
+        if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == extra:
+            return hit[3]
+        return None
+
+    def put(self, t: torch.Tensor, value, extra=None):
+        key = id(t)
+        if key not in self._d or self._d[key][0]() is not t:
+            weakref.finalize(t, self._d.pop, key, None)
+        self._d[key] = (weakref.ref(t), t._version, extra, value)
+        return value
+
+    def __len__(self):
+        return len(self._d)
+
+
 def as_graph(adj, device=None) -> CSRGraph:
     """Accept what the reference layers accept (torch sparse tensor) or a ready CSRGraph.
 

@@ -33,7 +33,7 @@ import torch.nn.functional as F
 
 from .... import kernels
 from ....autograd import HipLinear, spmm
-from ....graph import CSRGraph
+from ....graph import CSRGraph, TensorKeyedCache
 from ....transforms import Compose, SetConfig
 from ....transforms.graph import HeteronetGraph
 from ...base import BaseClassificationMethod
@@ -289,7 +289,7 @@ class scHeteroNet(nn.Module, BaseClassificationMethod):
         self.encoder.to(device)
         self.to(device)
         self.min_loss = min_loss
-        self._prop_cache = {}
+        self._prop_cache = TensorKeyedCache()
 
     def reset_parameters(self):
         self.encoder.reset_parameters()
@@ -305,10 +305,10 @@ class scHeteroNet(nn.Module, BaseClassificationMethod):
         return self.encoder(x, edge_index, save_path=save_path)
 
     def _prop_graph(self, edge_index, n):
-        key = (edge_index.data_ptr(), tuple(edge_index.shape))
-        if key not in self._prop_cache:
-            self._prop_cache = {key: _mean_in_adj(edge_index, n, self.device)}
-        return self._prop_cache[key]
+        g = self._prop_cache.get(edge_index, n)
+        if g is None:
+            g = self._prop_cache.put(edge_index, _mean_in_adj(edge_index, n, self.device), n)
+        return g
 
     def propagation(self, e, edge_index, prop_layers=1, alpha=0.5):
         """Energy belief propagation (scheteronet.py:611-623): e <- alpha e + (1 - alpha) mean_in(e)."""

@@ -20,19 +20,19 @@ from torch.nn import Parameter
 
 from .... import kernels
 from ....autograd import gat_aggregate
-from ....graph import CSRGraph
+from ....graph import CSRGraph, TensorKeyedCache
 from ....transforms import Compose, SetConfig
 from ....transforms.graph import StagateGraph
 from ...base import BaseClusteringMethod, BasePretrain
 
-_EDGE_CACHE = {}
+_EDGE_CACHE = TensorKeyedCache()
+_LOOP_CACHE = TensorKeyedCache()
 
 
 def edge_index_graph(edge_index: torch.Tensor, n: int):
     """CSR by destination of a PyG ``edge_index`` [2, E] (duplicates kept) + ``slot_of_edge`` (position of every original
     edge in the CSR arrays).  Cached per tensor: the reference passes the same ``edge_index`` to all four layers, every epoch."""
-    key = (edge_index.data_ptr(), tuple(edge_index.shape), n)
-    hit = _EDGE_CACHE.get(key)
+    hit = _EDGE_CACHE.get(edge_index, n)  # identity + in-place version: never a recycled allocation or an edited tensor
     if hit is None:
         src, dst = edge_index[0].long(), edge_index[1].long()
         order = torch.argsort(dst * n + src, stable=True)
@@ -41,8 +41,7 @@ def edge_index_graph(edge_index: torch.Tensor, n: int):
         g = CSRGraph(rowptr.to(torch.int32), src[order].to(torch.int32).contiguous(), None, n, n)
         slot = torch.empty_like(order)
         slot[order] = torch.arange(order.numel(), device=order.device)
-        _EDGE_CACHE.clear()
-        hit = _EDGE_CACHE[key] = (g, slot)
+        hit = _EDGE_CACHE.put(edge_index, (g, slot), n)
     return hit
 
 
@@ -80,10 +79,13 @@ class GATConv(nn.Module):
         else:
             alpha = (tied_attention[0].reshape(-1), tied_attention[1].reshape(-1))
         n = xs.shape[0]
-        if self.add_self_loops:
-            keep = edge_index[0] != edge_index[1]
-            loops = torch.arange(n, device=edge_index.device)
-            edge_index = torch.cat((edge_index[:, keep], torch.stack((loops, loops))), dim=1)
+        if self.add_self_loops:  # the augmented list is derived once per caller tensor, so its CSR below is cached too
+            aug = _LOOP_CACHE.get(edge_index, n)
+            if aug is None:
+                keep = edge_index[0] != edge_index[1]
+                loops = torch.arange(n, device=edge_index.device)
+                aug = _LOOP_CACHE.put(edge_index, torch.cat((edge_index[:, keep], torch.stack((loops, loops))), dim=1), n)
+            edge_index = aug
         graph, slot = edge_index_graph(edge_index, n)
         out, att = gat_aggregate(xs, alpha[0], alpha[1], graph, act=kernels.ATT_SIGMOID)
         if self.dropout and self.training:

@@ -176,13 +176,7 @@ def test_graphsc_fit_dense_decoder_mode_vs_reference(cuda_device, gold, monkeypa
     assert np.allclose(m.losses, gold["gsc_mb_losses"], rtol=2e-4, atol=0)
 
 
-# dh_gram_listed_forward_f32 / _backward_f32 were written after the round's GPU budget was spent: their host wiring is pinned on
-# CPU tensors (tests/test_graphsc_host_logic.py, mode "fused-listed"), the kernels themselves wait for their first run
-experimental = pytest.mark.skipif(os.environ.get("DANCE_AMD_EXPERIMENTAL") != "1",
-                                  reason="not yet run on the hardware; set DANCE_AMD_EXPERIMENTAL=1")
-
-
-@experimental
+# dh_gram_listed_forward_f32 / _backward_f32: first run on the hardware in round 3 (profiles/r03a_gram_listed_tests.log), un-gated since
 def test_gram_listed_kernels_vs_float64(cuda_device):
     from dance_amd import kernels
     torch.manual_seed(3)
@@ -209,7 +203,6 @@ def test_gram_listed_kernels_vs_float64(cuda_device):
         assert torch.equal(dz, kernels.gram_listed_backward(z, o, us, vs, xe, p, scale))   # fixed order
 
 
-@experimental
 def test_graphsc_fit_fused_listed_mode_vs_reference(cuda_device, gold, monkeypatch):
     from dance_amd.modules.single_modality.clustering import graphsc
     monkeypatch.setattr(graphsc, "DECODER_MODE", "fused-listed")
