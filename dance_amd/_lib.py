@@ -30,11 +30,14 @@ def _declare(lib):
         "dh_spmm_csr_relu_f32": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_spmm_csr_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, P, P, i64, P, i64, P, i32, i32, P]),
         "dh_spmm_csr_relu_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
+        "dh_spmm_csr_relu_slices_f32": (c_int, [i64, P, i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_gather_rows_f32": (c_int, [i64, i64, P, P, i64, P, P, i64, P]),
         "dh_csr_transpose_workspace_bytes": (c_size_t, [i64, i64, i64]),
         "dh_csr_transpose": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_gemm_f32_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
         "dh_gemm_f32": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
+        "dh_gemm_f32_ex_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32, i32]),
+        "dh_gemm_f32_ex": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, i32, P]),
         "dh_gemm_f32x3_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
         "dh_gemm_f32x3": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
         "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),

@@ -27,6 +27,88 @@ from .graph import CSRGraph
 BWD_MASK_MODE = os.environ.get("DANCE_AMD_BWD_MASK", "fused")
 
 
+# Software pipeline of the wide fused layer (relu(A (X W)), width % 128 == 0).  The GEMM is bound by the matrix cores and the
+# aggregation by HBM, and they saturate different units of a CU — but run one after the other they add up (the serial floor
+# of the headline: 26.0 ms of MFMA time + 8.2 ms of HBM time).  The aggregation is column-sliced anyway (128-column passes,
+# spmm.hip), and slice c of A S only needs the columns c of S = X W: so the GEMM is issued per column slice on the caller's
+# stream in the 128 x 128 macro-tile configuration (two blocks per CU at ~170 VGPRs, which leaves a third of every SIMD's
+# registers and 16 wave slots per CU free), and the aggregation of slice c runs on a second stream next to the GEMM of
+# slice c + 1; backward the same way round (A^T slice c, then dW[:, c] = X^T dS[:, c] next to the gather of slice c + 1).
+# Arithmetic, summation order and therefore every output bit are those of the unpipelined layer.
+#   DANCE_AMD_LAYER_PIPELINE = "off" | "auto" | comma-separated slice widths (multiples of 128 that sum to the layer width)
+PIPELINE = os.environ.get("DANCE_AMD_LAYER_PIPELINE", "auto")
+PIPELINE_MIN_ROWS = 1 << 17  # below this a layer is a handful of waves of tiles: nothing to overlap
+PIPELINE_TILE = kernels.GEMM_TILE_128
+PIPELINE_SIDE_PRIORITY = 0   # torch stream priority of the aggregation stream (0 = default, -1 = high)
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device: torch.device) -> torch.cuda.Stream:
+    key = (device.index if device.index is not None else torch.cuda.current_device(), PIPELINE_SIDE_PRIORITY)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device, priority=PIPELINE_SIDE_PRIORITY)
+    return _SIDE_STREAMS[key]
+
+
+def pipeline_slices(n_rows: int, width: int):
+    """Column-slice boundaries [(c0, c1), ...] of the pipelined layer, or None when the layer runs unpipelined."""
+    if PIPELINE == "off" or width % 128 != 0 or width < 256:
+        return None
+    if PIPELINE == "auto":
+        if n_rows < PIPELINE_MIN_ROWS:
+            return None
+        widths = [128] * (width // 128)
+    else:
+        widths = [int(t) for t in PIPELINE.split(",")]
+        if any(w <= 0 or w % 128 for w in widths) or sum(widths) != width:
+            raise ValueError(f"DANCE_AMD_LAYER_PIPELINE={PIPELINE!r}: slice widths must be multiples of 128 summing to {width}")
+    if len(widths) < 2:
+        return None
+    out, c = [], 0
+    for w in widths:
+        out.append((c, c + w))
+        c += w
+    return out
+
+
+def _pipelined_forward(x, w, graph, mask, slices):
+    """S = X W and Y = relu(A S) (+ sign mask), GEMM of slice c + 1 on the current stream next to the aggregation of slice c."""
+    main, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
+    n, h = x.shape[0], w.shape[1]
+    support = torch.empty((n, h), dtype=torch.float32, device=x.device)
+    out = torch.empty((graph.n_rows, h), dtype=torch.float32, device=x.device)
+    side.wait_stream(main)  # the buffers above may recycle blocks whose last use is still queued on the caller's stream
+    for c0, c1 in slices:
+        kernels.gemm(x, w[:, c0:c1], out=support[:, c0:c1], tile=PIPELINE_TILE)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            kernels.spmm_csr_relu(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, act=kernels.ACT_RELU, out_mask=mask,
+                                  out=out, slices=(c0 // 128, c1 // 128), tag="spmm_csr_f32[fwd]")
+    main.wait_stream(side)
+    return out
+
+
+def _pipelined_backward(x, dy, gt, mask, slices):
+    """dS = A^T (dy * [Y > 0]) and dW = X^T dS, the gather of slice c + 1 on the side stream next to the GEMM of slice c."""
+    main, side = torch.cuda.current_stream(x.device), _side_stream(x.device)
+    h = dy.shape[1]
+    ds = torch.empty((gt.n_rows, h), dtype=torch.float32, device=x.device)
+    dw = torch.empty((x.shape[1], h), dtype=torch.float32, device=x.device)
+    side.wait_stream(main)  # dy (and the recycled blocks of ds / dw) are ready on the caller's stream
+    for c0, c1 in slices:
+        with torch.cuda.stream(side):
+            kernels.spmm_csr_relu(gt.rowptr, gt.col, gt.val, dy, n_cols=gt.n_cols, in_mask=mask, out=ds, slices=(c0 // 128, c1 // 128),
+                                  tag="spmm_csr_f32[bwd]")
+            ready = torch.cuda.Event()
+            ready.record(side)
+        main.wait_event(ready)
+        kernels.gemm(x, ds[:, c0:c1], trans_a=True, out=dw[:, c0:c1], tile=PIPELINE_TILE)
+    main.wait_stream(side)
+    return ds, dw
+
+
 class _GCNLayerFn(torch.autograd.Function):
     """out = act(rowscale * reduce_e(val_e * colscale[src] * (x W)[src]) + bias); scales / mean are optional."""
 
@@ -35,11 +117,20 @@ class _GCNLayerFn(torch.autograd.Function):
                 active: bool, rowscale: Optional[torch.Tensor], colscale: Optional[torch.Tensor], reduce: int):
         x = x.contiguous() if x.stride(-1) != 1 else x
         w = weight.contiguous()
-        support = kernels.gemm(x, w)
         # ReLU fused into both SpMMs (sign mask instead of G = dY*[Y>0] in HBM) for the plain wide-layer case
         mask = None
         fused = (active and bias is None and rowscale is None and colscale is None and reduce == kernels.REDUCE_SUM
-                 and support.stride(0) % 4 == 0 and kernels.relu_mask_bytes(graph.n_rows, support.shape[1]) > 0)
+                 and w.shape[1] % 4 == 0 and kernels.relu_mask_bytes(graph.n_rows, w.shape[1]) > 0)
+        slices = pipeline_slices(graph.n_rows, w.shape[1]) if (fused and kernels.GEMM_MODE == "exact" and x.is_cuda) else None
+        ctx.slices = slices
+        if slices is not None:
+            mask = torch.empty(kernels.relu_mask_bytes(graph.n_rows, w.shape[1]), dtype=torch.uint8, device=x.device)
+            out = _pipelined_forward(x, w, graph, mask, slices)
+            ctx.graph, ctx.active, ctx.has_bias = graph, active, False
+            ctx.rowscale, ctx.colscale, ctx.reduce = None, None, reduce
+            ctx.save_for_backward(x, w, None, mask)
+            return out
+        support = kernels.gemm(x, w)
         if fused:
             mask = torch.empty(kernels.relu_mask_bytes(graph.n_rows, support.shape[1]), dtype=torch.uint8, device=x.device)
             out = kernels.spmm_csr_relu(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols,
@@ -64,6 +155,9 @@ class _GCNLayerFn(torch.autograd.Function):
                 gt = ctx.graph.transpose()
                 if dy.stride(0) % 4 != 0 or dy.data_ptr() % 16 != 0:
                     dy = dy.clone(memory_format=torch.contiguous_format)  # fresh allocation: 16-byte aligned rows
+                if ctx.slices is not None and need_w and not need_x:
+                    _, dw = _pipelined_backward(x, dy, gt, mask, ctx.slices)
+                    return None, dw, None, None, None, None, None, None
                 if BWD_MASK_MODE == "premask":
                     # A/B variant (not the default): G = dy * [out > 0] written once (one streaming pass), then the plain
                     # gather — four requests per neighbour instead of five, at the price of 2 x N x D x 4 bytes of traffic

@@ -510,38 +510,58 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
 
 // The 256x256 configuration halves refill traffic per flop but needs >= 2 blocks per CU's worth of work to
 // fill the chip; smaller problems use 128x128 tiles.
-Plan make_plan(int64_t M, int64_t N, int64_t K) {
+// tile: DH_GEMM_TILE_AUTO, or a request for one configuration (dh_gemm_f32_ex).  AUTO also avoids 256-wide tiles that
+// would be at most half full in N or in M (a 128-column slice of a layer, dh_gcn_layer_*: the large tile computed
+// twice the flops there).
+Plan make_plan(int64_t M, int64_t N, int64_t K, int tile = DH_GEMM_TILE_AUTO) {
   Plan big = plan_for(M, N, K, CfgLarge::BM, CfgLarge::BN);
 #ifdef DH_GEMM_FORCE_SMALL
   return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
 #endif
-  if ((int64_t)big.n_tiles * big.S >= 512) return big;
+  if (tile == DH_GEMM_TILE_128) return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
+  if (tile == DH_GEMM_TILE_256) return big;
+  const bool half_empty = (N % CfgLarge::BN != 0 && N % CfgLarge::BN <= CfgSmall::BN && N < 4 * CfgLarge::BN) ||
+                          (M % CfgLarge::BM != 0 && M % CfgLarge::BM <= CfgSmall::BM && M < 4 * CfgLarge::BM);
+  if ((int64_t)big.n_tiles * big.S >= 512 && !half_empty) return big;
   return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
 }
 
 }  // namespace
 
-extern "C" size_t dh_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b) {
-  (void)trans_a; (void)trans_b;
+extern "C" size_t dh_gemm_f32_ex_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, int tile) {
+  (void)trans_b;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  if (dh::skinny_applies(M, N, K, trans_a)) return 0;
-  Plan p = make_plan(M, N, K);
+  if (tile == DH_GEMM_TILE_AUTO && dh::skinny_applies(M, N, K, trans_a)) return 0;
+  Plan p = make_plan(M, N, K, tile);
   return p.S > 1 ? (size_t)p.S * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" size_t dh_gemm_f32_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b) {
+  return dh_gemm_f32_ex_workspace_bytes(M, N, K, trans_a, trans_b, DH_GEMM_TILE_AUTO);
 }
 
 extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
                            const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                            int64_t ldc, int accumulate, void* workspace, size_t workspace_bytes,
                            dh_stream_t stream) {
+  return dh_gemm_f32_ex(M, N, K, trans_a, trans_b, A, lda, B, ldb, C, ldc, accumulate, workspace, workspace_bytes, DH_GEMM_TILE_AUTO, stream);
+}
+
+extern "C" int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
+                              const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                              int64_t ldc, int accumulate, void* workspace, size_t workspace_bytes,
+                              int tile, dh_stream_t stream) {
+  if (tile != DH_GEMM_TILE_AUTO && tile != DH_GEMM_TILE_128 && tile != DH_GEMM_TILE_256)
+    return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: bad tile request %d", tile);
   if (M < 0 || N < 0 || K < 0) return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: negative size");
   if (M == 0 || N == 0) return DH_OK;
   if (!C || (K > 0 && (!A || !B))) return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: null operand");
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N)
     return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: leading dimension too small");
   hipStream_t st = dh::as_stream(stream);
-  if (K > 0 && dh::skinny_applies(M, N, K, trans_a))  // narrow layers: HBM-bound streaming kernel (gemm_skinny.hip)
+  if (tile == DH_GEMM_TILE_AUTO && K > 0 && dh::skinny_applies(M, N, K, trans_a))  // narrow layers: HBM-bound streaming kernel (gemm_skinny.hip)
     return dh::skinny_launch(M, N, K, trans_b, A, lda, B, ldb, C, ldc, accumulate, st);
-  Plan p = make_plan(M, N, K);
+  Plan p = make_plan(M, N, K, tile);
   float* slabs = nullptr;
   if (p.S > 1) {
     const size_t need = (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);

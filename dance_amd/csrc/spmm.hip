@@ -281,9 +281,10 @@ template <bool MIN, bool MOUT>
 void launch_slices(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
                    const float* rowscale, const float* colscale, const float* Z, int64_t ldz, float* Y, int64_t ldy,
                    const float* bias, int act, int reduce, const int32_t* row_ids, const uint32_t* in_mask, uint32_t* out_mask,
-                   hipStream_t st) {
+                   hipStream_t st, int64_t slice_begin = 0, int64_t slice_end = -1) {
   const bool idx32 = n_cols >= 0 && (double)n_cols * (double)ldz < 4294967296.0;
-  for (int64_t c = 0; c < width; c += 128) {
+  const int64_t c_end = slice_end < 0 ? width : slice_end * 128;
+  for (int64_t c = slice_begin * 128; c < c_end; c += 128) {
     const ReluMask mask{out_mask, in_mask, (int)(width / 128), (int)(c / 128)};
     dim3 grid((unsigned)dh::ceil_div(n_rows, 8), 1);
     if (idx32)
@@ -385,8 +386,22 @@ extern "C" int dh_spmm_csr_relu_rows_f32(int64_t n_list, const int32_t* row_ids,
                                          const int32_t* col, const float* val, const float* Z, int64_t ldz, float* Y,
                                          int64_t ldy, const float* bias, int act, void* out_mask, const void* in_mask,
                                          dh_stream_t stream) {
+  return dh_spmm_csr_relu_slices_f32(n_list, row_ids, n_cols, width, 0, width / 128, rowptr, col, val, Z, ldz, Y, ldy, bias, act, out_mask,
+                                     in_mask, stream);
+}
+
+// Column slices [slice_begin, slice_end) (units of 128 columns) of the fused-ReLU SpMM over a width-wide layer: Z, Y, bias and
+// the masks are those of the WHOLE layer.  One call per slice range lets a caller aggregate slice c on one stream while the
+// GEMM that produces slice c + 1 runs on another (autograd.py: the software-pipelined layer).
+extern "C" int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width, int64_t slice_begin,
+                                           int64_t slice_end, const int32_t* rowptr, const int32_t* col, const float* val, const float* Z,
+                                           int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, void* out_mask,
+                                           const void* in_mask, dh_stream_t stream) {
+  if (slice_begin < 0 || slice_end < slice_begin || slice_end * 128 > width)
+    return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: slice range [%lld, %lld) outside width %lld", (long long)slice_begin,
+                    (long long)slice_end, (long long)width);
   if (n_list < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: negative size");
-  if (n_list == 0 || width == 0) return DH_OK;
+  if (n_list == 0 || width == 0 || slice_end == slice_begin) return DH_OK;
   if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: null rowptr/Z/Y");
   if (width % 128 != 0 || ldz % 4 != 0 || ldy % 4 != 0 || !dh::aligned16(Z) || !dh::aligned16(Y) || (bias && !dh::aligned16(bias)) ||
       (in_mask && !dh::aligned16(in_mask)))
@@ -399,7 +414,7 @@ extern "C" int dh_spmm_csr_relu_rows_f32(int64_t n_list, const int32_t* row_ids,
   uint32_t* mo = static_cast<uint32_t*>(out_mask);
 #define DH_SLICES(MIN, MOUT)                                                                                                        \
   launch_slices<MIN, MOUT>(n_list, n_cols, width, rowptr, col, val, nullptr, nullptr, Z, ldz, Y, ldy, bias, act, DH_REDUCE_SUM, row_ids, \
-                           mi, mo, st)
+                           mi, mo, st, slice_begin, slice_end)
   if (mi && mo) DH_SLICES(true, true);
   else if (mi) DH_SLICES(true, false);
   else if (mo) DH_SLICES(false, true);

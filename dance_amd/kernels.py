@@ -141,15 +141,24 @@ def spmm_csr_relu(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
                   n_cols: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                   out_mask: Optional[torch.Tensor] = None, in_mask: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None,
-                  tag: str = "spmm_csr_f32") -> torch.Tensor:
+                  slices: Optional[Tuple[int, int]] = None, tag: str = "spmm_csr_f32") -> torch.Tensor:
     """dh_spmm_csr_relu_f32: forward records the ReLU sign mask (out_mask), backward applies it to the gathered
-    rows (in_mask).  Masks are uint8 tensors of ``relu_mask_bytes`` bytes.  ``rows``: as in ``spmm_csr``."""
+    rows (in_mask).  Masks are uint8 tensors of ``relu_mask_bytes`` bytes.  ``rows``: as in ``spmm_csr``.
+    ``slices`` = (begin, end) in units of 128 columns: only those column slices of the layer are computed
+    (dh_spmm_csr_relu_slices_f32; Z, out and the masks are the whole layer's)."""
     lib = _lib_ready()
     n_rows = rowptr.numel() - 1
     width = Z.shape[1]
     n_cols = Z.shape[0] if n_cols is None else n_cols
     if out is None:
         out = torch.empty((n_rows, width), dtype=torch.float32, device=Z.device)
+    if slices is not None:
+        _call(tag, lib.dh_spmm_csr_relu_slices_f32, n_rows if rows is None else rows.numel(), _dev(rows, torch.int32, "rows", 1), n_cols, width,
+              int(slices[0]), int(slices[1]), _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),
+              _dev(val, torch.float32, "val", 1), _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(out, torch.float32, "out", 2), _ld(out),
+              _dev(bias, torch.float32, "bias", 1), act, None if out_mask is None else out_mask.data_ptr(),
+              None if in_mask is None else in_mask.data_ptr(), _stream())
+        return out
     if rows is not None:
         _call(tag, lib.dh_spmm_csr_relu_rows_f32, rows.numel(), _dev(rows, torch.int32, "rows", 1), n_cols, width,
               _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
@@ -197,12 +206,14 @@ def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
 # split, 6 partial products, fp32 accumulation; fp32-level accuracy), "exact" = v_mfma_f32_32x32x2_f32 (dh_gemm_f32, a
 # bit-exact k-ordered fmaf chain).  Set with DANCE_AMD_GEMM or per call.
 GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "exact")
+GEMM_TILE_AUTO, GEMM_TILE_256, GEMM_TILE_128 = 0, 1, 2
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          out: Optional[torch.Tensor] = None, accumulate: bool = False, tag: Optional[str] = None,
-         mode: Optional[str] = None) -> torch.Tensor:
-    """C (+)= op(A) @ op(B), fp32 in / fp32 out, on the matrix cores; see dh_gemm_f32x3 / dh_gemm_f32 and GEMM_MODE."""
+         mode: Optional[str] = None, tile: int = GEMM_TILE_AUTO) -> torch.Tensor:
+    """C (+)= op(A) @ op(B), fp32 in / fp32 out, on the matrix cores; see dh_gemm_f32x3 / dh_gemm_f32 and GEMM_MODE.
+    ``tile`` (exact mode): macro-tile request of dh_gemm_f32_ex."""
     lib = _lib_ready()
     mode = mode or GEMM_MODE
     if mode not in ("x3", "exact"):
@@ -217,10 +228,17 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
         if accumulate:
             raise ValueError("gemm: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+    tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
+    if mode == "exact" and tile != GEMM_TILE_AUTO:
+        ws_bytes = lib.dh_gemm_f32_ex_workspace_bytes(M, N, K, int(trans_a), int(trans_b), tile)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None
+        _call(tag, lib.dh_gemm_f32_ex, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A),
+              _dev(B, torch.float32, "B", 2), _ld(B), _dev(out, torch.float32, "out", 2), _ld(out), int(accumulate),
+              None if ws is None else ws.data_ptr(), ws_bytes, tile, _stream())
+        return out
     size_fn, fn = (lib.dh_gemm_f32x3_workspace_bytes, lib.dh_gemm_f32x3) if mode == "x3" else (lib.dh_gemm_f32_workspace_bytes, lib.dh_gemm_f32)
     ws_bytes = size_fn(M, N, K, int(trans_a), int(trans_b))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None
-    tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
     _call(tag, fn, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A),
           _dev(B, torch.float32, "B", 2), _ld(B), _dev(out, torch.float32, "out", 2), _ld(out), int(accumulate),
           None if ws is None else ws.data_ptr(), ws_bytes, _stream())

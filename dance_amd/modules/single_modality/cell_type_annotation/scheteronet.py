@@ -382,6 +382,102 @@ class scHeteroNet(nn.Module, BaseClassificationMethod):
               save_path=None, batch=None) -> Union[float, Tuple[float, Any]]:
         from ...base import resolve_score_func
         y_pred = self.predict_proba(x, save_path=save_path)
+        if save_path is not None and batch is not None:
+            np.savez_compressed(save_path + "_predictions.npz", predictions=y.cpu().numpy(), batch=batch)
         func = partial(eval_acc, acc=resolve_score_func(score_func or self._DEFAULT_METRIC))
         score = func(y[idx], y_pred[idx])
         return (score, y_pred) if return_pred else score
+
+    def evaluate(self, dataset_ind, dataset_ood_te, criterion, eval_func, display_step, run, results, epoch, loss, dataset, T, use_prop,
+                 use_2hop, oodprop, oodalpha):
+        """scheteronet.py:714-734: one evaluation round of the training script — OOD detection measures + test score +
+        validation loss appended to ``results[run]``; ``min_loss`` tracks the best validation loss seen."""
+        result, test_ind_score, test_ood_score, representations = self.evaluate_detect(
+            dataset_ind, dataset_ood_te, criterion, eval_func, self.device, return_score=True, dataset=dataset, T=T, use_prop=use_prop,
+            use_2hop=use_2hop, oodprop=oodprop, oodalpha=oodalpha)
+        results[run].append(result)
+        if result[-1] < self.min_loss:
+            self.min_loss = result[-1]
+        if epoch % display_step == 0:
+            print(f"Epoch: {epoch:02d}, Loss: {loss:.4f}, AUROC: {100 * result[0]:.2f}%, AUPR: {100 * result[1]:.2f}%, "
+                  f"FPR95: {100 * result[2]:.2f}%, Test Score: {100 * result[-2]:.2f}%")
+        return result
+
+    def evaluate_detect(self, dataset_ind, dataset_ood, criterion, eval_func, device, return_score, dataset, T, use_prop, use_2hop,
+                        oodprop, oodalpha, score_func: Optional[Union[str, Mapping[Any, float]]] = None):
+        """scheteronet.py:747-788: negative-energy scores of the in-distribution test nodes against those of the OOD nodes
+        (one dataset or a list) -> [auroc, aupr, fpr95] per OOD set, then the test score and the validation loss of the
+        classifier.  The encoder passes and the energy propagation run on the device; the measures are host code."""
+        from ...base import resolve_score_func
+        self.eval()
+
+        def energy(d, idx):
+            with torch.no_grad():
+                return self.detect(d, idx, device, T, use_prop, use_2hop, oodprop, oodalpha).cpu()
+
+        test_ind_score = energy(dataset_ind, dataset_ind.splits["test"])
+        result = []
+        for d in (dataset_ood if isinstance(dataset_ood, list) else [dataset_ood]):
+            test_ood_score = energy(d, d.node_idx)
+            auroc, aupr, fpr, _ = get_measures(test_ind_score, test_ood_score)
+            result += [auroc] + [aupr] + [fpr]
+        with torch.no_grad():
+            out = self(dataset_ind).cpu()
+            test_idx = dataset_ind.splits["test"]
+            test_score = eval_func(dataset_ind.y[test_idx], out[test_idx], acc=resolve_score_func(score_func or self._DEFAULT_METRIC))
+            valid_idx = dataset_ind.splits["valid"]
+            if dataset in ("proteins", "ppi"):
+                valid_loss = criterion(out[valid_idx], dataset_ind.y[valid_idx].to(torch.float))
+            else:
+                valid_loss = criterion(F.log_softmax(out[valid_idx], dim=1), dataset_ind.y[valid_idx].squeeze(1))
+            result += [test_score] + [valid_loss]
+        if return_score:
+            return result, test_ind_score, test_ood_score, out.detach().cpu().numpy()
+        return result
+
+
+def stable_cumsum(arr, rtol=1e-05, atol=1e-08):
+    """float64 cumulative sum whose last element is checked against the plain sum (scheteronet.py:1034-1052)."""
+    out = np.cumsum(arr, dtype=np.float64)
+    if not np.allclose(out[-1], np.sum(arr, dtype=np.float64), rtol=rtol, atol=atol):
+        raise RuntimeError("cumsum was found to be unstable: its last element does not correspond to sum")
+    return out
+
+
+def fpr_and_fdr_at_recall(y_true, y_score, recall_level=0.95, pos_label=None):
+    """False-positive rate (and the score threshold) at the operating point whose recall is closest to ``recall_level``
+    (scheteronet.py:1055-1094).  Thresholds sit at the last sample of every run of tied scores, walked from the first one
+    reaching full recall towards the highest score, with a (recall 1, no false positives) sentinel at the end — the order
+    matters for argmin's tie-breaking, so it is kept."""
+    classes = np.unique(y_true)
+    binary = any(np.array_equal(classes, c) for c in ([0, 1], [-1, 1], [0], [-1], [1]))
+    if pos_label is None and not binary:
+        raise ValueError("Data is not binary and pos_label is not specified")
+    if pos_label is None:
+        pos_label = 1.
+    positive = (y_true == pos_label)
+    order = np.argsort(y_score, kind="mergesort")[::-1]
+    y_score, positive = y_score[order], positive[order]
+    run_ends = np.r_[np.where(np.diff(y_score))[0], positive.size - 1]
+    tps = stable_cumsum(positive)[run_ends]
+    fps = 1 + run_ends - tps
+    thresholds = y_score[run_ends]
+    recall = tps / tps[-1]
+    back = slice(tps.searchsorted(tps[-1]), None, -1)
+    recall, fps, thresholds = np.r_[recall[back], 1], np.r_[fps[back], 0], thresholds[back]
+    cutoff = np.argmin(np.abs(recall - recall_level))
+    if np.array_equal(classes, [1]):
+        return thresholds[cutoff]
+    return fps[cutoff] / (np.sum(np.logical_not(positive))), thresholds[cutoff]
+
+
+def get_measures(_pos, _neg, recall_level=0.95):
+    """(auroc, aupr, fpr@recall, threshold) of "positive = in-distribution" from two score vectors (scheteronet.py:1097-1108)."""
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    pos = np.array(_pos[:]).reshape((-1, 1))
+    neg = np.array(_neg[:]).reshape((-1, 1))
+    examples = np.squeeze(np.vstack((pos, neg)))
+    labels = np.zeros(len(examples), dtype=np.int32)
+    labels[:len(pos)] += 1
+    fpr, threshold = fpr_and_fdr_at_recall(labels, examples, recall_level)
+    return roc_auc_score(labels, examples), average_precision_score(labels, examples), fpr, threshold

@@ -233,6 +233,41 @@ class SimpleGCDEC(nn.Module):
                 logger.info(f"delta_label {delta_label} < tol {tol}; total epoch: {epoch}")
                 break
 
+    def fit_with_init(self, X, adj, init_y, lr=0.001, epochs=5000, update_interval=1, weight_decay=5e-4, opt="sgd"):
+        """spagcn.py:541-584: cluster centres = per-group means of the initial embedding under the GIVEN labels ``init_y``
+        (``groupby("Group").mean()``: groups in sorted label order), then the DEC loop without early stopping.  The
+        optimiser is created before ``mu`` receives its values but — unlike ``fit`` — over an existing ``mu`` parameter when
+        the model has one, exactly as ``self.parameters()`` yields it there."""
+        self.to(self.device)
+        X = _to_device_f32(X, self.device)
+        adj = self._adj(adj)
+        if opt == "sgd":
+            optimizer = optim.SGD(self.parameters(), lr=lr, momentum=0.9)
+        elif opt == "admin":
+            optimizer = optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay)
+        else:
+            raise ValueError(f"Unknown optimizer {opt!r}")
+        with torch.no_grad():
+            features = self.gc(X, adj)
+        labels = np.asarray(init_y)
+        groups = np.unique(labels)  # pandas groupby sorts its keys
+        yt = torch.from_numpy(np.searchsorted(groups, labels)).to(self.device)
+        centers = torch.stack([features[yt == c].mean(0) for c in range(len(groups))])
+        if getattr(self, "mu", None) is None:  # the reference copies into an existing self.mu (set by an earlier fit)
+            self.n_clusters = len(groups)
+            self.mu = Parameter(torch.empty(self.n_clusters, self.nhid, device=self.device))
+        self.mu.data.copy_(centers)
+        self.train()
+        for epoch in range(epochs):
+            if epoch % update_interval == 0:
+                _, q = self.forward(X, adj)
+                p = self.target_distribution(q).data
+            optimizer.zero_grad()
+            z, q = self(X, adj)
+            loss = self.loss_function(p, q)
+            loss.backward()
+            optimizer.step()
+
     @torch.no_grad()
     def predict(self, X, adj):
         X, adj = _to_device_f32(X, self.device), self._adj(adj)
@@ -296,6 +331,40 @@ class SpaGCN(BaseClusteringMethod):
 
     def set_l(self, l):
         self.l = l
+
+    def search_set_res(self, x, l, target_num, start=0.4, step=0.1, tol=5e-3, lr=0.05, epochs=10, max_run=10):
+        """spagcn.py:771-805: search the clustering resolution that yields ``target_num`` clusters — short fits of fresh models
+        at res +- step, halving the step when the direction flips.  (``self.res`` is only set on the path that falls out of the
+        loop, as in the reference.)"""
+        res = start
+        logger.info(f"Start at {res = :.4f}, {step = :.4f}")
+        fit_kw = dict(init_spa=True, init="louvain", tol=tol, lr=lr, epochs=epochs)
+        old_num = len(set(SpaGCN(l, device=self.device).fit_predict(x, res=res, **fit_kw)))
+        logger.info(f"Res = {res:.4f}, Num of clusters = {old_num}")
+        run = 0
+        while old_num != target_num:
+            old_sign = 1 if (old_num < target_num) else -1
+            new_num = len(set(SpaGCN(l, device=self.device).fit_predict(x, res=res + step * old_sign, **fit_kw)))
+            logger.info(f"Res = {res + step * old_sign:.3e}, Num of clusters = {new_num}")
+            if new_num == target_num:
+                res = res + step * old_sign
+                logger.info(f"recommended res = {res:.4f}")
+                return res
+            new_sign = 1 if (new_num < target_num) else -1
+            if new_sign == old_sign:
+                res = res + step * old_sign
+                logger.info(f"Res changed to {res}")
+                old_num = new_num
+            else:
+                step = step / 2
+                logger.info(f"Step changed to {step:.4f}")
+            if run > max_run:
+                logger.info(f"Exact resolution not found. Recommended res = {res:.4f}")
+                return res
+            run += 1
+        logger.info(f"Recommended res = {res:.4f}")
+        self.res = res
+        return res
 
     def calc_adj_exp(self, adj):
         """exp(-adj^2 / (2 l^2)) on the device; a ``CSRGraph`` of distances keeps its sparsity pattern."""

@@ -98,6 +98,14 @@ DH_API int dh_spmm_csr_relu_rows_f32(int64_t n_list, const int32_t* row_ids, int
                          const int32_t* rowptr, const int32_t* col, const float* val,
                          const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
                          void* out_mask, const void* in_mask, dh_stream_t stream);
+/* Column slices [slice_begin, slice_end) (units of 128 columns) of dh_spmm_csr_relu_rows_f32 over a width-wide layer; Z, Y,
+ * bias and both masks are those of the WHOLE layer.  The pipelined layer (dance_amd/autograd.py) aggregates slice c on one
+ * stream while the GEMM producing slice c + 1 (torch.mm, scdsc.py:497) runs on another.                              */
+DH_API int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width,
+                         int64_t slice_begin, int64_t slice_end,
+                         const int32_t* rowptr, const int32_t* col, const float* val,
+                         const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
+                         void* out_mask, const void* in_mask, dh_stream_t stream);
 DH_API int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx,
                        const void* relu_mask, float* out, int64_t ldo, dh_stream_t stream);
 
@@ -123,6 +131,17 @@ DH_API int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b
                 const float* A, int64_t lda, const float* B, int64_t ldb,
                 float* C, int64_t ldc, int accumulate,
                 void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* dh_gemm_f32 with an explicit macro-tile: 256x256 (one block of 8 wavefronts per CU, ~250 VGPRs: fewest bytes per flop) or
+ * 128x128 (two blocks of 4 wavefronts per CU at ~170 VGPRs, which leaves a third of every SIMD's register file to the
+ * wavefronts of an HBM-bound kernel running next to it on another stream: the pipelined layer's torch.mm, scdsc.py:497).
+ * AUTO is what dh_gemm_f32 does.                                                                                   */
+enum dh_gemm_tile { DH_GEMM_TILE_AUTO = 0, DH_GEMM_TILE_256 = 1, DH_GEMM_TILE_128 = 2 };
+DH_API size_t dh_gemm_f32_ex_workspace_bytes(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, int tile);
+DH_API int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
+                const float* A, int64_t lda, const float* B, int64_t ldb,
+                float* C, int64_t ldc, int accumulate,
+                void* workspace, size_t workspace_bytes, int tile, dh_stream_t stream);
 
 /* Same contract as dh_gemm_f32 (operands, result and accumulation in fp32), computed on the bf16 matrix cores: each fp32
  * operand is split exactly into three bf16 terms and six of the nine partial products are accumulated in fp32 (the dropped

@@ -10,7 +10,7 @@ ACT_NONE, ACT_RELU = 0, 1
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 
 
-def gemm(A, B, *, trans_a=False, trans_b=False, out=None, accumulate=False, tag=None):
+def gemm(A, B, *, trans_a=False, trans_b=False, out=None, accumulate=False, tag=None, mode=None, tile=0):
     r = torch.mm(A.t() if trans_a else A, B.t() if trans_b else B)
     if out is not None:
         out.copy_(out + r if accumulate else r)
@@ -73,8 +73,19 @@ def _bool_to_mask(b):
 
 
 def spmm_csr_relu(rowptr, col, val, Z, *, n_cols=None, bias=None, act=ACT_NONE, out_mask=None, in_mask=None, out=None, rows=None,
-                  tag=None):
+                  slices=None, tag=None):
     n_rows, width = rowptr.numel() - 1, Z.shape[1]
+    if slices is not None:  # column slices [begin, end) x 128 of the layer: every other column (and mask word) is left untouched
+        c0, c1 = slices[0] * 128, slices[1] * 128
+        full = spmm_csr_relu(rowptr, col, val, Z, n_cols=n_cols, bias=bias, act=act, in_mask=in_mask, rows=None)
+        out = torch.empty_like(full) if out is None else out
+        sel = slice(None) if rows is None else rows.long()
+        out[sel, c0:c1] = full[sel, c0:c1]
+        if out_mask is not None:
+            m = _bool_to_mask((full > 0).numpy()).reshape(n_rows, -1)
+            view = out_mask[:n_rows * m.shape[1]].reshape(n_rows, -1)
+            view[sel, c0 // 8:c1 // 8] = m[sel, c0 // 8:c1 // 8]
+        return out
     if in_mask is not None:
         Z = torch.where(torch.from_numpy(_mask_to_bool(in_mask, Z.shape[0], width)), Z, torch.zeros_like(Z))
     y = _spmm_full(rowptr, col, val, Z, n_cols, None, None, bias, act, REDUCE_SUM)
@@ -320,8 +331,17 @@ def gram_listed_backward(Z, O, us, vs, xe, pos_weight, scale):
     return (dz * scale.double().reshape(())).float()
 
 
+def umap_connectivities(knn_idx, knn_dist):
+    """(rowptr, col, val), (sigma, rho) of the fuzzy simplicial set — oracle.graphs restatement of umap-learn."""
+    from oracle import graphs as og
+    conn, sig, rho = og.fuzzy_simplicial_set(knn_idx.numpy().astype(np.int64), knn_dist.numpy(), knn_idx.shape[1])
+    t = torch.from_numpy
+    return ((t(conn.indptr.astype(np.int32)), t(conn.indices.astype(np.int32)), t(conn.data.astype(np.float32))),
+            (t(np.asarray(sig, dtype=np.float32)), t(np.asarray(rho, dtype=np.float32))))
+
+
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
+STAND_INS = ("umap_connectivities", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
              "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward")

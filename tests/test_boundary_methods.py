@@ -1,0 +1,162 @@
+"""Methods the reference's call sites use that round 2 had left out (VERDICT r2 "missing" 3): ``SpaGCN.search_set_res``
+(spagcn.py:771-805, called by examples/spatial/spatial_domain/spagcn.py:48), ``SimpleGCDEC.fit_with_init`` (:541-584),
+``scHeteroNet.evaluate`` / ``evaluate_detect`` + the OOD measures (scheteronet.py:714-789, 1034-1108).
+
+Each is checked against the REFERENCE'S OWN method lifted out of /root/reference (oracle.ref_extract) and run with our model
+object as ``self`` — so the comparison isolates the host logic: same kernels (CPU stand-ins) underneath on both sides."""
+import functools
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import cpu_ops
+from conftest import rel_err
+from oracle import ref_extract
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+needs_ref = pytest.mark.skipif(not ref_extract.available(), reason="/root/reference not present")
+SH = "dance/modules/single_modality/cell_type_annotation/scheteronet.py"
+SP = "dance/modules/spatial/spatial_domain/spagcn.py"
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    from dance_amd import kernels
+    for name in cpu_ops.STAND_INS:
+        monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
+    return kernels
+
+
+def _ref_measures():
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    cs = ref_extract.extract(SH, "stable_cumsum")
+    fpr = ref_extract.extract(SH, "fpr_and_fdr_at_recall", {"stable_cumsum": cs})
+    return ref_extract.extract(SH, "get_measures", {"fpr_and_fdr_at_recall": fpr, "roc_auc_score": roc_auc_score,
+                                                    "average_precision_score": average_precision_score})
+
+
+@needs_ref
+def test_ood_measures_vs_reference():
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import get_measures
+    ref = _ref_measures()
+    rng = np.random.default_rng(0)
+    for n_pos, n_neg, ties in ((50, 70, False), (200, 30, True), (5, 5, True), (300, 300, False)):
+        pos, neg = rng.normal(1.0, 1.0, n_pos), rng.normal(0.0, 1.0, n_neg)
+        if ties:
+            pos, neg = np.round(pos, 1), np.round(neg, 1)
+        for level in (0.95, 0.5):
+            got, want = get_measures(torch.from_numpy(pos), torch.from_numpy(neg), level), ref(torch.from_numpy(pos), torch.from_numpy(neg), level)
+            assert np.allclose(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64), rtol=0, atol=0), (n_pos, n_neg, ties, level)
+
+
+def test_ood_measures_known_answers():
+    """Separable scores: AUROC = AUPR = 1, no false positives at any recall; identical distributions: fpr@0.95 ~ 0.95."""
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import fpr_and_fdr_at_recall, get_measures
+    auroc, aupr, fpr, thr = get_measures(np.arange(10, 20.0), np.arange(0, 10.0))
+    assert auroc == 1.0 and abs(aupr - 1.0) < 1e-12 and fpr == 0.0 and 10.0 <= thr <= 11.0
+    s = np.linspace(0, 1, 2001)
+    lab = (np.arange(2001) % 2).astype(np.int32)
+    fpr, _ = fpr_and_fdr_at_recall(lab, s, 0.95)
+    assert abs(fpr - 0.95) < 0.01
+    with pytest.raises(ValueError):
+        fpr_and_fdr_at_recall(np.array([0, 1, 2]), np.array([0.1, 0.2, 0.3]))
+
+
+def _scheteronet_model():
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import scHeteroNet
+    gold = np.load(os.path.join(GOLDEN, "scheteronet.npz"))
+    n, d, c, hid = (int(v) for v in gold["sh_dims"])
+    ei = torch.from_numpy(gold["sh_edge_index"])
+    sd = {k.split("::", 1)[1]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sh_sd0::")}
+    m = scHeteroNet(d, c, ei, n, hid, 2, 0.0, True, "cpu", 1e9)
+    m.load_state_dict(sd)
+    idx = torch.arange(n)
+    ds = types.SimpleNamespace(x=torch.from_numpy(gold["sh_x"]), edge_index=ei, y=torch.from_numpy(gold["sh_y"])[:, None],
+                               splits={"train": idx[0::3], "valid": idx[1::3], "test": idx[2::3]}, node_idx=idx[: n // 2])
+    ood = types.SimpleNamespace(x=ds.x, edge_index=ei, y=ds.y, node_idx=idx[n // 2:])
+    return m, ds, ood
+
+
+@needs_ref
+def test_scheteronet_evaluate_detect_vs_reference_method(cpu_kernels):
+    from dance_amd.modules.base import resolve_score_func
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import eval_acc
+    m, ds, ood = _scheteronet_model()
+    import typing
+    ns = {"get_measures": _ref_measures(), "resolve_score_func": resolve_score_func, "Optional": typing.Optional, "Union": typing.Union,
+          "Mapping": typing.Mapping, "Any": typing.Any}
+    ref_detect = ref_extract.extract_method(SH, "scHeteroNet", "evaluate_detect", ns)
+    crit = torch.nn.NLLLoss()
+    for ood_arg in (ood, [ood, ood]):
+        for use_prop, use_2hop in ((False, False), (True, False), (True, True)):
+            kw = dict(return_score=True, dataset="x", T=1.0, use_prop=use_prop, use_2hop=use_2hop, oodprop=2, oodalpha=0.5)
+            want = ref_detect(m, ds, ood_arg, crit, eval_acc, "cpu", **kw)
+            got = m.evaluate_detect(ds, ood_arg, crit, eval_acc, "cpu", **kw)
+            assert len(got[0]) == len(want[0]) == (3 * (2 if isinstance(ood_arg, list) else 1) + 2)
+            assert np.allclose([float(v) for v in got[0]], [float(v) for v in want[0]], rtol=1e-6, atol=1e-7)
+            assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    # evaluate(): appends to results[run], tracks the best validation loss, returns the same list
+    results = {0: []}
+    res = m.evaluate(ds, ood, crit, eval_acc, display_step=100, run=0, results=results, epoch=1, loss=0.0, dataset="x", T=1.0, use_prop=True,
+                     use_2hop=False, oodprop=2, oodalpha=0.5)
+    assert results[0] == [res] and float(m.min_loss) == float(res[-1])
+    assert m.evaluate_detect(ds, ood, crit, eval_acc, "cpu", False, "x", 1.0, True, False, 2, 0.5)[:3] == res[:3]
+
+
+def _planted_spots(side=14, d=10, seed=1):
+    from oracle import matrix as om
+    rng = np.random.default_rng(seed)
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    xy = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    dom = (xy[:, 0] >= side / 2).astype(int) + 2 * (xy[:, 1] >= side / 2).astype(int)
+    embed = (np.eye(4)[dom] @ rng.standard_normal((4, d)) * 2 + rng.standard_normal((xy.shape[0], d))).astype(np.float32)
+    return embed, om.pairwise_distance(xy, 0), dom
+
+
+@needs_ref
+def test_simple_gcdec_fit_with_init_vs_reference_method(cpu_kernels):
+    from torch import optim
+    from dance_amd.modules.spatial.spatial_domain.spagcn import SimpleGCDEC
+    embed, adj, dom = _planted_spots()
+    adj_exp = np.exp(-adj**2 / (2 * 1.5**2)).astype(np.float32)
+    init_y = np.where(dom == 3, 7, dom)  # non-contiguous labels: groupby sorts them (0, 1, 2, 7)
+    ref_fit = ref_extract.extract_method(SP, "SimpleGCDEC", "fit_with_init", {"optim": optim})
+
+    def fresh():
+        torch.manual_seed(3)
+        m = SimpleGCDEC(embed.shape[1], embed.shape[1], device="cpu")
+        m.mu = torch.nn.Parameter(torch.zeros(4, embed.shape[1]))
+        return m
+
+    for opt, lr in (("sgd", 0.01), ("admin", 0.005)):
+        a, b = fresh(), fresh()
+        ref_fit(a, embed, adj_exp, init_y, lr=lr, epochs=6, update_interval=2, opt=opt)
+        b.fit_with_init(embed, adj_exp, init_y, lr=lr, epochs=6, update_interval=2, opt=opt)
+        for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+            assert ka == kb and rel_err(vb.numpy(), va.numpy()) < 1e-5, (opt, ka)
+    # without an earlier fit the centres parameter is created (the reference would fail on the missing attribute)
+    torch.manual_seed(3)
+    c = SimpleGCDEC(embed.shape[1], embed.shape[1], device="cpu")
+    c.fit_with_init(embed, adj_exp, init_y, epochs=2)
+    assert c.mu.shape == (4, embed.shape[1]) and c.n_clusters == 4
+    _, q = c.predict(embed, adj_exp)
+    assert np.allclose(q.sum(1).numpy(), 1, atol=1e-5)
+
+
+@needs_ref
+def test_spagcn_search_set_res_vs_reference_method(cpu_kernels):
+    from dance_amd.modules.spatial.spatial_domain import spagcn
+    embed, adj, dom = _planted_spots()
+    l = spagcn.SpaGCN(device="cpu").search_l(0.5, adj)
+    cpu_model = functools.partial(spagcn.SpaGCN, device="cpu")
+    ref_search = ref_extract.extract_method(SP, "SpaGCN", "search_set_res", {"SpaGCN": cpu_model})
+    for target, kw in ((4, {}), (2, dict(start=0.6, step=0.2)), (50, dict(max_run=1))):
+        a, b = spagcn.SpaGCN(l, device="cpu"), spagcn.SpaGCN(l, device="cpu")
+        torch.manual_seed(0)
+        want = ref_search(a, (embed, adj), l, target, epochs=3, **kw)
+        torch.manual_seed(0)
+        got = b.search_set_res((embed, adj), l, target, epochs=3, **kw)
+        assert got == want and a.res == b.res, (target, got, want)
