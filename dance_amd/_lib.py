@@ -31,6 +31,7 @@ def _declare(lib):
         "dh_spmm_csr_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, P, P, i64, P, i64, P, i32, i32, P]),
         "dh_spmm_csr_relu_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_spmm_csr_relu_slices_f32": (c_int, [i64, P, i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
+        "dh_relu_mask_apply_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
         "dh_gather_rows_f32": (c_int, [i64, i64, P, P, i64, P, P, i64, P]),
         "dh_csr_transpose_workspace_bytes": (c_size_t, [i64, i64, i64]),
         "dh_csr_transpose": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
@@ -89,6 +90,7 @@ def _declare(lib):
         "dh_spatial_gaussian_knn_workspace_bytes": (c_size_t, [i64, i64, i32]),
         "dh_spatial_gaussian_knn": (c_int, [i64, i64, P, i64, i32, c_double, P, P, P, P, c_size_t, P]),
         "dh_edge_softmax_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P]),
+        "dh_edge_softmax_shift_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P, P]),
         "dh_edge_softmax_backward_f32": (c_int, [i64, P, P, P, P, i32, c_float, P, P, P, P, P]),
         "dh_csr_two_hop_count": (c_int, [i64, P, P, P, P, P]),
         "dh_csr_two_hop_workspace_bytes": (c_size_t, [i64, i64]),

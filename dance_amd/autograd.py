@@ -22,9 +22,12 @@ from . import kernels
 from .graph import CSRGraph
 
 
-# ReLU mask in the backward SpMM of the fused layer: "fused" = applied to every gathered row inside dh_spmm_csr_relu_f32 (the
-# measured default), "premask" = dy masked once into a scratch matrix, then the plain SpMM (A/B switch, scripts/bwd_mask_ab.py)
-BWD_MASK_MODE = os.environ.get("DANCE_AMD_BWD_MASK", "fused")
+# ReLU mask in the backward SpMM of the fused layer: "premask" (default) = dy masked once into a scratch matrix by the streaming
+# dh_relu_mask_apply_f32, then the plain SpMM — 4 requests per gathered neighbour instead of 5; measured 0.70 + 4.53 = 5.23 ms
+# against 5.58 ms at the headline shape although it moves 4 GB more (profiles/r03a_bwd_mask_ab.json), bit-identical;
+# "fused" = the mask applied to every gathered row inside dh_spmm_csr_relu_f32 (what the sharded halo path still does,
+# where the masked rows go straight into the send buffer).
+BWD_MASK_MODE = os.environ.get("DANCE_AMD_BWD_MASK", "premask")
 
 
 # Software pipeline of the wide fused layer (relu(A (X W)), width % 128 == 0).  The GEMM is bound by the matrix cores and the
@@ -36,7 +39,7 @@ BWD_MASK_MODE = os.environ.get("DANCE_AMD_BWD_MASK", "fused")
 # slice c + 1; backward the same way round (A^T slice c, then dW[:, c] = X^T dS[:, c] next to the gather of slice c + 1).
 # Arithmetic, summation order and therefore every output bit are those of the unpipelined layer.
 #   DANCE_AMD_LAYER_PIPELINE = "off" | "auto" | comma-separated slice widths (multiples of 128 that sum to the layer width)
-PIPELINE = os.environ.get("DANCE_AMD_LAYER_PIPELINE", "auto")
+PIPELINE = os.environ.get("DANCE_AMD_LAYER_PIPELINE", "off")
 PIPELINE_MIN_ROWS = 1 << 17  # below this a layer is a handful of waves of tiles: nothing to overlap
 PIPELINE_TILE = kernels.GEMM_TILE_128
 PIPELINE_SIDE_PRIORITY = 0   # torch stream priority of the aggregation stream (0 = default, -1 = high)
@@ -159,14 +162,9 @@ class _GCNLayerFn(torch.autograd.Function):
                     _, dw = _pipelined_backward(x, dy, gt, mask, ctx.slices)
                     return None, dw, None, None, None, None, None, None
                 if BWD_MASK_MODE == "premask":
-                    # A/B variant (not the default): G = dy * [out > 0] written once (one streaming pass), then the plain
-                    # gather — four requests per neighbour instead of five, at the price of 2 x N x D x 4 bytes of traffic
-                    ident = getattr(ctx.graph, "_row_ids", None)
-                    if ident is None or ident.numel() != dy.shape[0]:
-                        ident = torch.arange(dy.shape[0], dtype=torch.int32, device=dy.device)
-                        ctx.graph._row_ids = ident
-                    g = kernels.gather_rows(dy, ident, relu_mask=mask)
-                    ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols, tag="spmm_csr_f32[bwd-premasked]")
+                    g = kernels.relu_mask_apply(dy, mask)
+                    ds = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, g, n_cols=gt.n_cols, tag="spmm_csr_f32[bwd]")
+                    del g
                 else:
                     ds = kernels.spmm_csr_relu(gt.rowptr, gt.col, gt.val, dy, n_cols=gt.n_cols, in_mask=mask, tag="spmm_csr_f32[bwd]")
                 if need_w:
@@ -237,18 +235,19 @@ class _GATAggregateFn(torch.autograd.Function):
     source ids (d a_src) and the SpMM on the transposed CSR with the attention values carried along (d x)."""
 
     @staticmethod
-    def forward(ctx, x, a_src, a_dst, graph: CSRGraph, act: int, slope: float):
+    def forward(ctx, x, a_src, a_dst, graph: CSRGraph, act: int, slope: float, shift=None, edge_scale=None):
         x, a_src, a_dst = x.contiguous(), a_src.contiguous(), a_dst.contiguous()
-        att = kernels.edge_softmax(graph.rowptr, graph.col, a_src, a_dst, act=act, negative_slope=slope)
-        out = kernels.spmm_csr(graph.rowptr, graph.col, att, x, n_cols=graph.n_cols)
+        att = kernels.edge_softmax(graph.rowptr, graph.col, a_src, a_dst, act=act, negative_slope=slope, shift=shift)
+        # edge_scale [E] (CSR order): dropout on the attention coefficients (0 or 1 / (1 - p)), applied between softmax and sum
+        out = kernels.spmm_csr(graph.rowptr, graph.col, att if edge_scale is None else att * edge_scale, x, n_cols=graph.n_cols)
         ctx.graph, ctx.act, ctx.slope = graph, act, slope
-        ctx.save_for_backward(x, a_src, a_dst, att)
+        ctx.save_for_backward(x, a_src, a_dst, att, edge_scale)
         ctx.mark_non_differentiable(att)
         return out, att
 
     @staticmethod
     def backward(ctx, dout, _datt_unused):
-        x, a_src, a_dst, att = ctx.saved_tensors
+        x, a_src, a_dst, att, edge_scale = ctx.saved_tensors
         g = ctx.graph
         dout = dout.contiguous()
         dx = da_src = da_dst = None
@@ -257,7 +256,7 @@ class _GATAggregateFn(torch.autograd.Function):
             if x.shape[1] % 4:  # the SDDMM moves 16 bytes per lane: zero-pad the inner dimension (the products are unchanged)
                 pad = 4 - x.shape[1] % 4
                 u, v = torch.nn.functional.pad(dout, (0, pad)), torch.nn.functional.pad(x, (0, pad))
-            datt = kernels.sddmm_csr(g.rowptr, g.col, u, v)
+            datt = kernels.sddmm_csr(g.rowptr, g.col, u, v, scale=edge_scale)
             dt, da_dst = kernels.edge_softmax_backward(g.rowptr, g.col, a_src, a_dst, att, datt, act=ctx.act, negative_slope=ctx.slope)
             da_src = torch.zeros_like(a_src).index_add_(0, g.col.long(), dt)
         if ctx.needs_input_grad[0]:
@@ -265,13 +264,17 @@ class _GATAggregateFn(torch.autograd.Function):
                 g._t_struct = kernels.csr_transpose(g.rowptr, g.col, None, g.n_rows, g.n_cols)
                 g._t_perm = g._t_struct[3].long()
             rp_t, col_t = g._t_struct[0], g._t_struct[1]
-            dx = kernels.spmm_csr(rp_t, col_t, att[g._t_perm].contiguous(), dout, n_cols=g.n_rows)
-        return dx, da_src, da_dst, None, None, None
+            val = att if edge_scale is None else att * edge_scale
+            dx = kernels.spmm_csr(rp_t, col_t, val[g._t_perm].contiguous(), dout, n_cols=g.n_rows)
+        return dx, da_src, da_dst, None, None, None, None, None
 
 
-def gat_aggregate(x, a_src, a_dst, graph: CSRGraph, *, act: int = kernels.ATT_SIGMOID, negative_slope: float = 0.2):
-    """(out, att): attention-weighted aggregation over the in-edges of every row and the per-edge coefficients (CSR order)."""
-    return _GATAggregateFn.apply(x, a_src, a_dst, graph, act, negative_slope)
+def gat_aggregate(x, a_src, a_dst, graph: CSRGraph, *, act: int = kernels.ATT_SIGMOID, negative_slope: float = 0.2, shift=None,
+                  edge_scale=None):
+    """(out, att): attention-weighted aggregation over the in-edges of every row and the per-edge coefficients (CSR order).
+    ``shift``: one-element tensor subtracted from the scores before exp instead of each row's maximum (treated as a constant:
+    its gradient is eps / (row sum + eps) of an attention, i.e. nothing)."""
+    return _GATAggregateFn.apply(x, a_src, a_dst, graph, act, negative_slope, shift, edge_scale)
 
 
 class _DenseAdjLayerFn(torch.autograd.Function):

@@ -38,15 +38,23 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __global__ __launch_bounds__(256) void edge_softmax_kernel(int64_t n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const float* __restrict__ a_src, const float* __restrict__ a_dst, int act, float slope,
-                                                           float* __restrict__ att) {
+                                                           const float* __restrict__ shift, float* __restrict__ att) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int s = rowptr[row], t = rowptr[row + 1];
   const float ad = a_dst ? a_dst[row] : 0.f;
-  float m = -INFINITY;
-  for (int e = s + lane; e < t; e += 64) m = fmaxf(m, act_fwd(a_src[col[e]] + ad, act, slope));
-  m = wave_max(m);
+  float m;
+  if (shift) {
+    // scGNN2's GATLayer (scgnn2.py:1071-1085) subtracts the GLOBAL maximum of all edge scores, not the row's: together with
+    // the + 1e-16 of the denominator that is a different function for rows whose scores sit far below the global maximum
+    // (their attentions shrink towards 0), so the caller hands that maximum in
+    m = *shift;
+  } else {
+    m = -INFINITY;
+    for (int e = s + lane; e < t; e += 64) m = fmaxf(m, act_fwd(a_src[col[e]] + ad, act, slope));
+    m = wave_max(m);
+  }
   float sum = 0.f;
   for (int e = s + lane; e < t; e += 64) {
     const float p = expf(act_fwd(a_src[col[e]] + ad, act, slope) - m);
@@ -84,12 +92,17 @@ __global__ __launch_bounds__(256) void edge_softmax_bwd_kernel(int64_t n_rows, c
 
 extern "C" int dh_edge_softmax_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst, int act,
                                    float negative_slope, float* att, dh_stream_t stream) {
+  return dh_edge_softmax_shift_f32(n_rows, rowptr, col, a_src, a_dst, act, negative_slope, nullptr, att, stream);
+}
+
+extern "C" int dh_edge_softmax_shift_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
+                                         int act, float negative_slope, const float* shift, float* att, dh_stream_t stream) {
   if (n_rows < 0) return dh::fail(DH_ERR_INVALID, "dh_edge_softmax_f32: negative size");
   if (n_rows == 0) return DH_OK;
   if (!rowptr || !col || !a_src || !att) return dh::fail(DH_ERR_INVALID, "dh_edge_softmax_f32: null pointer");
   if (act != 0 && act != 1) return dh::fail(DH_ERR_INVALID, "dh_edge_softmax_f32: act must be 0 (sigmoid) or 1 (leaky_relu)");
   hipLaunchKernelGGL(edge_softmax_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream), n_rows, rowptr, col, a_src, a_dst,
-                     act, negative_slope, att);
+                     act, negative_slope, shift, att);
   return dh::check_launch("dh_edge_softmax_f32");
 }
 

@@ -10,6 +10,8 @@
 // ds_bpermute inside sub-wave groups) while every lane streams its VEC-wide column slice of
 // the neighbour rows.  Accumulation is sequential in CSR order per output element — no
 // atomics, bit-reproducible.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -81,6 +83,7 @@ struct ReluMask {
   const uint32_t* in;  // backward: applied to the gathered rows of Z when non-null [n_cols][slices][4]
   int slices;          // width / 128 of the whole layer
   int slice0;          // 128-column slice of this launch (column-sliced passes)
+  int xcd_blocks;      // > 0: blocks per XCD of the XCD-contiguous row mapping (see spmm_slice128_kernel); 0: block b = rows 8 b ..
 };
 
 // G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart).
@@ -178,7 +181,12 @@ __global__ __launch_bounds__(256) void spmm_slice128_kernel(
     float* __restrict__ Y, int64_t ldy, const float* __restrict__ bias, int act, int reduce,
     const int32_t* __restrict__ row_ids, ReluMask mask) {
   const int g = threadIdx.x & 31;
-  const int64_t slot = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  // The dispatcher places block b on XCD b % 8.  With xcd_blocks > 0 XCD x walks its OWN contiguous eighth of the rows
+  // (blocks x * xcd_blocks ...): on a locality-ordered graph (CSRGraph.permute) the rows gathered by neighbouring
+  // destination rows overlap, and this way they overlap inside one XCD's private L2 instead of being spread over all eight.
+  int64_t blk = blockIdx.x;
+  if (mask.xcd_blocks > 0) blk = (int64_t)(blockIdx.x & 7) * mask.xcd_blocks + (blockIdx.x >> 3);
+  const int64_t slot = blk * 8 + (threadIdx.x >> 5);
   if (slot >= n_rows) return;  // whole 32-lane groups exit together
   const int64_t row = row_ids ? (int64_t)row_ids[slot] : slot;
   const float* zc = Z + g * 4;
@@ -284,9 +292,12 @@ void launch_slices(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t*
                    hipStream_t st, int64_t slice_begin = 0, int64_t slice_end = -1) {
   const bool idx32 = n_cols >= 0 && (double)n_cols * (double)ldz < 4294967296.0;
   const int64_t c_end = slice_end < 0 ? width : slice_end * 128;
+  static const int xcd_map = [] { const char* e = getenv("DH_SPMM_XCDMAP"); return e ? atoi(e) : 0; }();
+  const int64_t blocks = dh::ceil_div(n_rows, 8);
+  const int xcd_blocks = xcd_map ? (int)dh::ceil_div(blocks, 8) : 0;
   for (int64_t c = slice_begin * 128; c < c_end; c += 128) {
-    const ReluMask mask{out_mask, in_mask, (int)(width / 128), (int)(c / 128)};
-    dim3 grid((unsigned)dh::ceil_div(n_rows, 8), 1);
+    const ReluMask mask{out_mask, in_mask, (int)(width / 128), (int)(c / 128), xcd_blocks};
+    dim3 grid((unsigned)(xcd_blocks ? (int64_t)xcd_blocks * 8 : blocks), 1);
     if (idx32)
       hipLaunchKernelGGL((spmm_slice128_kernel<MIN, MOUT, true>), grid, dim3(256), 0, st, n_rows, rowptr, col, val, rowscale, colscale,
                          Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, row_ids, mask);
@@ -401,11 +412,12 @@ extern "C" int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_id
     return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: slice range [%lld, %lld) outside width %lld", (long long)slice_begin,
                     (long long)slice_end, (long long)width);
   if (n_list < 0 || n_cols < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: negative size");
-  if (n_list == 0 || width == 0 || slice_end == slice_begin) return DH_OK;
+  if (n_list == 0 || width == 0) return DH_OK;
   if (!rowptr || !Z || !Y) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: null rowptr/Z/Y");
   if (width % 128 != 0 || ldz % 4 != 0 || ldy % 4 != 0 || !dh::aligned16(Z) || !dh::aligned16(Y) || (bias && !dh::aligned16(bias)) ||
       (in_mask && !dh::aligned16(in_mask)))
     return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: needs width %% 128 == 0 and 16-byte aligned rows / masks");
+  if (slice_end == slice_begin) return DH_OK;
   if (ldz < width || ldy < width) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: leading dimension < width");
   if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: bad act %d", act);
   if (n_list >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: n_rows >= 2^31");
@@ -454,6 +466,38 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(int64_t n, int64_t wid
   }
 }
 }  // namespace
+
+// G = X * [mask bit]: the streaming form of the ReLU backward when the sign mask of the layer output (not the output
+// itself) was kept: one 16-byte load + one mask word per 8 lanes, one non-temporal 16-byte store.
+namespace {
+__global__ __launch_bounds__(256) void relu_mask_apply_kernel(int64_t n_rows, int vec_per_row, const float* __restrict__ X, int64_t ldx,
+                                                              const uint32_t* __restrict__ mask, float* __restrict__ out, int64_t ldo) {
+  const int64_t total = n_rows * vec_per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / vec_per_row;
+    const int c = (int)(i - r * vec_per_row) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+    const uint32_t m = mask[r * (vec_per_row / 8) + (c >> 5)] >> (c & 31);  // the row's bitmap is width / 32 words
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = __uint_as_float(__float_as_uint(v[j]) & (uint32_t)__builtin_amdgcn_sbfe((int)m, j, 1u));
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(out + r * ldo + c));
+  }
+}
+}  // namespace
+
+extern "C" int dh_relu_mask_apply_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, const void* relu_mask, float* out,
+                                      int64_t ldo, dh_stream_t stream) {
+  if (n_rows < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_relu_mask_apply_f32: negative size");
+  if (n_rows == 0 || width == 0) return DH_OK;
+  if (!X || !out || !relu_mask) return dh::fail(DH_ERR_INVALID, "dh_relu_mask_apply_f32: null pointer");
+  if (width % 128 || ldx % 4 || ldo % 4 || ldx < width || ldo < width || !dh::aligned16(X) || !dh::aligned16(out))
+    return dh::fail(DH_ERR_INVALID, "dh_relu_mask_apply_f32: needs width %% 128 == 0 and 16-byte aligned rows");
+  const int64_t total = n_rows * (width / 4);
+  const unsigned grid = (unsigned)(dh::ceil_div(total, 256) < 16384 ? dh::ceil_div(total, 256) : 16384);
+  hipLaunchKernelGGL(relu_mask_apply_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), n_rows, (int)(width / 4), X, ldx,
+                     static_cast<const uint32_t*>(relu_mask), out, ldo);
+  return dh::check_launch("dh_relu_mask_apply_f32");
+}
 
 extern "C" int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx, const void* relu_mask,
                                   float* out, int64_t ldo, dh_stream_t stream) {

@@ -80,11 +80,60 @@ class CSRGraph:
             self._t._t = self
         return self._t
 
+    def permute(self, perm: torch.Tensor) -> "CSRGraph":
+        """P A P^T for ``perm[new] = old`` (square graphs): node ``perm[i]`` becomes node ``i``.
+
+        Within every row the edges KEEP their order (ascending OLD column id), so each output element of an SpMM on the
+        renumbered graph is the same fmaf chain as on the original: results are bit-identical after un-permutation.  The
+        cached transpose is renumbered the same way (not rebuilt), so the backward sums keep their order as well.  Torch
+        index ops on the device; set-up only."""
+        if self.n_rows != self.n_cols:
+            raise ValueError("permute needs a square graph")
+        perm = perm.to(device=self.rowptr.device, dtype=torch.int64)
+        n = self.n_rows
+        if perm.numel() != n:
+            raise ValueError(f"perm has {perm.numel()} entries for {n} nodes")
+        inv = torch.empty(n, dtype=torch.int64, device=perm.device)
+        inv[perm] = torch.arange(n, device=perm.device)
+
+        def renumber(g):
+            rp = g.rowptr.long()
+            deg = (rp[1:] - rp[:-1])[perm]
+            new_rp = torch.zeros(n + 1, dtype=torch.int64, device=perm.device)
+            new_rp[1:] = torch.cumsum(deg, 0)
+            nnz = int(new_rp[-1])
+            src = torch.repeat_interleave(rp[:-1][perm] - new_rp[:-1], deg, output_size=nnz) + torch.arange(nnz, device=perm.device)
+            col = inv[g.col.long()[src]].to(torch.int32)
+            val = None if g.val is None else g.val[src].contiguous()
+            return CSRGraph(new_rp.to(torch.int32), col.contiguous(), val, n, n, symmetric=g.symmetric)
+
+        out = renumber(self)
+        if self._t is not None and not self.symmetric:
+            out._t = renumber(self._t)
+            out._t._t = out
+        return out
+
     def to_scipy(self):
         import scipy.sparse as sp
         val = self.val.cpu().numpy() if self.val is not None else np.ones(self.nnz, dtype=np.float32)
         return sp.csr_matrix((val, self.col.cpu().numpy(), self.rowptr.cpu().numpy()),
                              shape=(self.n_rows, self.n_cols))
+
+
+def locality_order(graph: CSRGraph, method: str = "rcm") -> torch.Tensor:
+    """A renumbering ``perm[new] = old`` under which neighbouring rows of a kNN-like graph gather mostly nearby rows, so that
+    the SpMM's random 512-byte row reads hit L2 / the Infinity Cache instead of HBM (SURVEY.md §8e: "cluster / kNN-BFS order";
+    the same renumbering keeps halos small when the graph is sharded).  ``rcm``: reverse Cuthill-McKee of the symmetrised
+    pattern (scipy on the host, O(nnz), set-up only, like the graph construction it follows)."""
+    if method != "rcm":
+        raise ValueError(f"unknown locality order {method!r}")
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    import scipy.sparse as sp
+    n = graph.n_rows
+    a = sp.csr_matrix((np.ones(graph.nnz, dtype=np.int8), graph.col.cpu().numpy(), graph.rowptr.cpu().numpy()), shape=(n, graph.n_cols))
+    if not graph.symmetric:
+        a = (a + a.T).tocsr()
+    return torch.from_numpy(np.ascontiguousarray(reverse_cuthill_mckee(a, symmetric_mode=True)).astype(np.int64))
 
 
 # Keyed by IDENTITY (id + a finalizer that evicts the entry when the tensor dies).  A WeakKeyDictionary would compare

@@ -183,6 +183,16 @@ def gather_rows(X: torch.Tensor, idx: torch.Tensor, *, relu_mask: Optional[torch
     return out
 
 
+def relu_mask_apply(X: torch.Tensor, relu_mask: torch.Tensor, *, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = X * [Y > 0] from the sign mask recorded by the forward SpMM (dh_relu_mask_apply_f32), one streaming pass."""
+    lib = _lib_ready()
+    if out is None:
+        out = torch.empty_like(X)
+    _call("relu_mask_apply_f32", lib.dh_relu_mask_apply_f32, X.shape[0], X.shape[1], _dev(X, torch.float32, "X", 2), _ld(X),
+          relu_mask.data_ptr(), _dev(out, torch.float32, "out", 2), _ld(out), _stream())
+    return out
+
+
 def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tensor], n_rows: int,
                   n_cols: int) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], torch.Tensor]:
     """CSR of A^T (stable by input position); returns (rowptr_t, col_t, val_t, perm)."""
@@ -607,12 +617,15 @@ def spatial_gaussian_knn(X: torch.Tensor, k: int, l: float = 0.0):
 ATT_SIGMOID, ATT_LEAKY_RELU = 0, 1
 
 
-def edge_softmax(rowptr, col, a_src, a_dst, *, act: int = ATT_SIGMOID, negative_slope: float = 0.2) -> torch.Tensor:
-    """att[e] = softmax over each row's in-edges of act(a_src[col[e]] + a_dst[row]) (dh_edge_softmax_f32)."""
+def edge_softmax(rowptr, col, a_src, a_dst, *, act: int = ATT_SIGMOID, negative_slope: float = 0.2,
+                 shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """att[e] = softmax over each row's in-edges of act(a_src[col[e]] + a_dst[row]) (dh_edge_softmax_f32).  ``shift``: a
+    one-element device tensor subtracted before exp instead of the row maximum (dh_edge_softmax_shift_f32, scGNN2's GAT)."""
     lib = _lib_ready()
     att = torch.empty(col.numel(), dtype=torch.float32, device=col.device)
-    _call("edge_softmax_f32", lib.dh_edge_softmax_f32, rowptr.numel() - 1, _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),
-          _dev(a_src, torch.float32, "a_src", 1), _dev(a_dst, torch.float32, "a_dst", 1), act, float(negative_slope), att.data_ptr(), _stream())
+    _call("edge_softmax_f32", lib.dh_edge_softmax_shift_f32, rowptr.numel() - 1, _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(a_src, torch.float32, "a_src", 1), _dev(a_dst, torch.float32, "a_dst", 1), act,
+          float(negative_slope), _dev(shift, torch.float32, "shift"), att.data_ptr(), _stream())
     return att
 
 

@@ -108,6 +108,11 @@ DH_API int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_ids, i
                          void* out_mask, const void* in_mask, dh_stream_t stream);
 DH_API int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx,
                        const void* relu_mask, float* out, int64_t ldo, dh_stream_t stream);
+/* out = X * [Y > 0] from the recorded sign mask of Y (dh_relu_mask_bytes layout; width % 128 == 0): autograd's ReluBackward
+ * (scdsc.py:499-500) as ONE streaming pass when the masked matrix is wanted as such — the default backward of the fused layer
+ * masks dY once with this kernel and then runs the plain gather (4 requests per neighbour instead of 5).                 */
+DH_API int dh_relu_mask_apply_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, const void* relu_mask,
+                       float* out, int64_t ldo, dh_stream_t stream);
 
 /* ---- K2: deterministic CSR transpose (CSR of A^T) ------------------------------------------
  * out_perm[p] = index into the input nnz arrays of output entry p; output rows are ordered by
@@ -296,6 +301,11 @@ DH_API int dh_spatial_gaussian_knn(int64_t n, int64_t d, const float* X, int64_t
  * d_a_dst[i] = sum_e dt[e] (may be NULL); d a_src is the column-wise sum of dt (caller: scatter-add over col).      */
 DH_API int dh_edge_softmax_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col, const float* a_src,
                         const float* a_dst, int act, float negative_slope, float* att, dh_stream_t stream);
+/* Same with the exponent shifted by *shift (a device scalar) instead of each row's own maximum: scGNN2's GATLayer subtracts the
+ * GLOBAL maximum of all edge scores before exp (scgnn2.py:1071-1085), which with the + 1e-16 denominator is not the same
+ * function as the row-shifted softmax.  shift == NULL: identical to dh_edge_softmax_f32.                                  */
+DH_API int dh_edge_softmax_shift_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col, const float* a_src,
+                        const float* a_dst, int act, float negative_slope, const float* shift, float* att, dh_stream_t stream);
 DH_API int dh_edge_softmax_backward_f32(int64_t n_rows, const int32_t* rowptr, const int32_t* col,
                                  const float* a_src, const float* a_dst, int act, float negative_slope,
                                  const float* att, const float* datt, float* dt, float* d_a_dst,

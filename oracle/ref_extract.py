@@ -314,6 +314,54 @@ def dgl_tagconv_stub():
     return TAGConv
 
 
+def dgl_graphconv_stub():
+    """``dgl.nn.GraphConv`` (dgl 1.1.3) restated from its documentation / source [3P-memory], over DGLStubGraph: optional
+    D_out^-1/2 (norm "both") or 1/D_out ("left") on the source features, ``W`` before the sum-aggregation when
+    in_feats > out_feats and after it otherwise, D_in^-1/2 ("both") or 1/D_in ("right") on the result, degrees clamped at 1,
+    bias, activation; xavier-uniform weight, zero bias.  Test infrastructure only."""
+    import torch
+    import torch.nn as nn
+
+    class GraphConv(nn.Module):
+        def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None, allow_zero_in_degree=False):
+            super().__init__()
+            self._in_feats, self._out_feats, self._norm = in_feats, out_feats, norm
+            self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats)) if weight else None
+            self.bias = nn.Parameter(torch.Tensor(out_feats)) if bias else None
+            if self.weight is not None:
+                nn.init.xavier_uniform_(self.weight)
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+            self._activation = activation
+
+        def forward(self, graph, feat, weight=None, edge_weight=None):
+            src, dst = graph.edges()
+            n = graph.number_of_nodes()
+            w = self.weight if weight is None else weight
+            if self._norm in ("left", "both"):
+                degs = torch.bincount(src, minlength=n).to(feat).clamp(min=1)
+                feat = feat * (degs.pow(-0.5) if self._norm == "both" else 1.0 / degs)[:, None]
+
+            def aggregate(h):
+                m = h[src] if edge_weight is None else h[src] * edge_weight.reshape(-1, 1)
+                return torch.zeros((n, h.shape[1]), dtype=h.dtype).index_add_(0, dst, m)
+
+            if self._in_feats > self._out_feats:
+                rst = aggregate(feat @ w if w is not None else feat)
+            else:
+                rst = aggregate(feat)
+                if w is not None:
+                    rst = rst @ w
+            if self._norm in ("right", "both"):
+                degs = torch.bincount(dst, minlength=n).to(feat).clamp(min=1)
+                rst = rst * (degs.pow(-0.5) if self._norm == "both" else 1.0 / degs)[:, None]
+            if self.bias is not None:
+                rst = rst + self.bias
+            return rst if self._activation is None else self._activation(rst)
+
+    return GraphConv
+
+
 def pyg_message_passing_stub():
     """``torch_geometric.nn.conv.MessagePassing`` (aggr="add", node_dim=0, flow source_to_target) and
     ``torch_geometric.utils.softmax / add_self_loops / remove_self_loops`` as STAGATE's GATConv uses them (stagate.py:19-20):

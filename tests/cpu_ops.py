@@ -100,6 +100,14 @@ def spmm_csr_relu(rowptr, col, val, Z, *, n_cols=None, bias=None, act=ACT_NONE, 
     return out
 
 
+def relu_mask_apply(X, relu_mask, *, out=None):
+    g = torch.where(torch.from_numpy(_mask_to_bool(relu_mask, X.shape[0], X.shape[1])), X, torch.zeros_like(X))
+    if out is not None:
+        out.copy_(g)
+        return out
+    return g
+
+
 def gather_rows(X, idx, *, relu_mask=None, out=None):
     r = X[idx.long()]
     if relu_mask is not None:
@@ -196,10 +204,14 @@ def _att_act(t, act, slope):
     return torch.sigmoid(t) if act == ATT_SIGMOID else torch.nn.functional.leaky_relu(t, slope)
 
 
-def edge_softmax(rowptr, col, a_src, a_dst, *, act=ATT_SIGMOID, negative_slope=0.2):
+def edge_softmax(rowptr, col, a_src, a_dst, *, act=ATT_SIGMOID, negative_slope=0.2, shift=None):
     """att[e] = softmax over each row's in-edges of act(a_src[col[e]] + a_dst[row]) (dh_edge_softmax_f32), in float64."""
     rows, n = _edge_rows(rowptr), rowptr.numel() - 1
     e = _att_act(a_src.double()[col.long()] + a_dst.double()[rows], act, negative_slope)
+    if shift is not None:  # scGNN2's global shift; the 1e-16 of the denominator matters there
+        ex = (e - shift.double().reshape(())).exp()
+        den = torch.zeros(n, dtype=torch.float64).index_add_(0, rows, ex)
+        return (ex / (den[rows] + 1e-16)).float()
     mx = torch.full((n, ), -float("inf"), dtype=torch.float64).scatter_reduce(0, rows, e, reduce="amax", include_self=True)
     ex = (e - mx[rows]).exp()
     den = torch.zeros(n, dtype=torch.float64).index_add_(0, rows, ex)
@@ -341,7 +353,7 @@ def umap_connectivities(knn_idx, knn_dist):
 
 
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("umap_connectivities", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
+STAND_INS = ("umap_connectivities", "relu_mask_apply", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
              "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward")

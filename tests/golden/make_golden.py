@@ -611,6 +611,118 @@ def make_stagate():
     print("stagate.npz:", len(out), "arrays")
 
 
+def make_free_riders():
+    """free_riders.npz — the layers SURVEY.md §8(f)4 names as re-users of the GCN / attention kernels, each produced by the
+    reference's OWN class lifted from /root/reference and run on torch-CPU: scGNN2's ``GraphConvolution`` (scgnn2.py:479-505),
+    ``GATLayer`` / ``GAT`` (:883-1189) and ``Graph_AE`` (:373-415); DSTG's ``GraphConvolution`` / ``GCN`` (dstg.py:37-143);
+    STdGCN's ``conGraphConvolutionlayer`` (stdgcn.py:63-92); GraphSCI's ``GNNModel`` (graphsci.py:107-124) over the DGL graph stub
+    and the restated dgl.nn.GraphConv.  Dropout rates are 0 so every run is deterministic."""
+    import types
+
+    import torch.nn as nn
+    import torch.nn.functional as F
+    rng = np.random.default_rng(2025)
+    out = {}
+    n, fin, fout = 72, 20, 12
+    x = rng.standard_normal((n, fin)).astype(np.float32)
+    adj = sp.random(n, n, density=0.1, random_state=3, format="csr", dtype=np.float32)
+    adj.data = rng.uniform(0.1, 1.0, adj.nnz).astype(np.float32)
+    adj = (adj + sp.eye(n, dtype=np.float32)).tocsr()
+    adj.sort_indices()
+    dy = rng.standard_normal((n, fout)).astype(np.float32)
+    out.update(fr_x=x, fr_dy=dy, fr_adj_indptr=adj.indptr.astype(np.int32), fr_adj_indices=adj.indices.astype(np.int32), fr_adj_data=adj.data)
+    a_coo = scipy_to_torch_coo(adj)
+
+    def run_layer(tag, layer, act_on=None):
+        for k, v in layer.state_dict().items():
+            out[f"{tag}_sd::{k}"] = v.numpy().copy()
+        xt = torch.from_numpy(x.copy()).requires_grad_(True)
+        y = layer(xt, a_coo)
+        y.backward(torch.from_numpy(dy))
+        out[f"{tag}_out"] = y.detach().numpy()
+        out[f"{tag}_dX"] = xt.grad.numpy().copy()
+        for k, p_ in layer.named_parameters():
+            out[f"{tag}_grad::{k}"] = p_.grad.numpy().copy()
+
+    s2 = "dance/modules/single_modality/imputation/scgnn2.py"
+    GC2 = ref_extract.extract(s2, "GraphConvolution", {"Module": nn.Module})
+    torch.manual_seed(11)
+    run_layer("s2gc_relu", GC2(fin, fout, 0., act=F.relu))
+    run_layer("s2gc_lin", GC2(fin, fout, 0., act=lambda t: t))
+    GC_d = ref_extract.extract("dance/modules/spatial/cell_type_deconvo/dstg.py", "GraphConvolution")
+    run_layer("dstg_nobias", GC_d(fin, fout, None, bias=False))
+    run_layer("dstg_bias", GC_d(fin, fout, None, bias=True))
+    dl = ref_extract.extract("dance/modules/spatial/cell_type_deconvo/dstg.py", "dropout_layer", {"sparse_dropout": None})
+    GCN_d = ref_extract.extract("dance/modules/spatial/cell_type_deconvo/dstg.py", "GCN", {"GraphConvolution": GC_d, "dropout_layer": dl})
+    run_layer("dstg_gcn", GCN_d(fin, 16, fout, bias=False, dropout=0.))
+    CG = ref_extract.extract("dance/modules/spatial/cell_type_deconvo/stdgcn.py", "conGraphConvolutionlayer", {"Module": nn.Module})
+    run_layer("stdgcn", CG(fin, fout, bias=True))
+
+    # ---- scGNN2 graph attention: one layer (2 heads, concat, skip projection) with gradients, then the 2-layer GAT and Graph_AE
+    src, dst = adj.nonzero()[1], adj.nonzero()[0]      # edge j -> i for every stored A[i, j]
+    edge_index = np.stack((src, dst)).astype(np.int64)
+    out["fr_edge_index"] = edge_index
+    GATLayer = ref_extract.extract(s2, "GATLayer")
+    GAT = ref_extract.extract(s2, "GAT", {"GATLayer": GATLayer})
+    torch.manual_seed(12)
+    for tag, kw, width in (("gat_concat", dict(num_of_heads=2, concat=True, activation=nn.ELU()), 2 * 7),
+                           ("gat_mean", dict(num_of_heads=3, concat=False, activation=None), 7),
+                           ("gat_same", dict(num_of_heads=2, concat=True, activation=None, num_out=fin), 2 * fin)):
+        fo = kw.pop("num_out", 7)
+        layer = GATLayer(fin, fo, dropout_prob=0.0, add_skip_connection=True, bias=True, log_attention_weights=True, **kw)
+        with torch.no_grad():
+            layer.bias.copy_(torch.from_numpy(rng.standard_normal(layer.bias.shape).astype(np.float32) * 0.1))
+            layer.scoring_fn_source.mul_(4.0)   # spread the scores: the global-max shift then matters
+            layer.scoring_fn_target.mul_(4.0)
+        for k, v in layer.state_dict().items():
+            out[f"{tag}_sd::{k}"] = v.numpy().copy()
+        xt = torch.from_numpy(x.copy()).requires_grad_(True)
+        y, _ = layer((xt, torch.from_numpy(edge_index)))
+        g = torch.from_numpy(rng.standard_normal((n, width)).astype(np.float32))
+        y.backward(g)
+        out.update({f"{tag}_out": y.detach().numpy(), f"{tag}_dy": g.numpy(), f"{tag}_dX": xt.grad.numpy().copy(),
+                    f"{tag}_att": layer.attention_weights.detach().numpy().copy()})
+        for k, p_ in layer.named_parameters():
+            if p_.grad is not None:
+                out[f"{tag}_grad::{k}"] = p_.grad.numpy().copy()
+    IPD = ref_extract.extract(s2, "InnerProductDecoder")
+    GAE = ref_extract.extract(s2, "Graph_AE", {"GAT": GAT, "GraphConvolution": GC2, "InnerProductDecoder": IPD})
+    torch.manual_seed(13)
+    gae = GAE(fin, 6, gat_dropout=0, multi_heads=2, gat_hid_embed=8)
+    gae.eval()
+    for k, v in gae.state_dict().items():
+        out[f"gae_sd::{k}"] = v.numpy().copy()
+    with torch.no_grad():
+        z, _, rec = gae(torch.from_numpy(x), torch.from_numpy(edge_index), use_GAT=True)
+        z2, info, rec2 = gae(torch.from_numpy(x), a_coo, use_GAT=False)
+    out.update(gae_gat_z=z.numpy(), gae_gat_recon=rec.numpy(), gae_gcn_z=z2.numpy(), gae_gcn_logvar=info[1].numpy(), gae_gcn_recon=rec2.numpy())
+
+    # ---- GraphSCI GNNModel over the DGL stub graph (pattern of adj, edge j -> i) ----------------------------------------------
+    GraphConv = ref_extract.dgl_graphconv_stub()
+    GNNModel = ref_extract.extract("dance/modules/single_modality/imputation/graphsci.py", "GNNModel",
+                                   {"dglnn": types.SimpleNamespace(GraphConv=GraphConv)})
+    torch.manual_seed(14)
+    gm = GNNModel(in_feats=fin, out_feats=9, dropout=0., n_hidden1=16, n_hidden2=10)
+    for k, v in gm.state_dict().items():
+        out[f"gsci_sd::{k}"] = v.numpy().copy()
+    g = ref_extract.DGLStubGraph(src, dst)
+    g.ndata["feat"] = torch.from_numpy(x)
+    h = gm.conv2(g, gm.conv1(g, g.ndata["feat"]))
+    mean = gm.dec_mean(g, h)
+    gdy = torch.from_numpy(rng.standard_normal(mean.shape).astype(np.float32))
+    mean.backward(gdy)
+    out.update(gsci_h=h.detach().numpy(), gsci_mean=mean.detach().numpy(), gsci_dy=gdy.numpy())
+    for k, p_ in gm.named_parameters():
+        if p_.grad is not None:
+            out[f"gsci_grad::{k}"] = p_.grad.numpy().copy()
+    torch.manual_seed(15)
+    with torch.no_grad():
+        z_adj, log_std, z_mean = gm(g)
+    out.update(gsci_fwd_log_std=log_std.numpy(), gsci_fwd_mean=z_mean.numpy())
+    np.savez_compressed(os.path.join(HERE, "free_riders.npz"), **out)
+    print("free_riders.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -624,3 +736,4 @@ if __name__ == "__main__":
     make_scdsc_fit()
     make_sctag()
     make_stagate()
+    make_free_riders()

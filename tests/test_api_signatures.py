@@ -41,6 +41,16 @@ PAIRS = [
     ("dance/modules/spatial/spatial_domain/spagcn.py", "SpaGCN", "dance_amd.modules.spatial.spatial_domain.spagcn"),
     ("dance/modules/spatial/spatial_domain/stagate.py", "GATConv", "dance_amd.modules.spatial.spatial_domain.stagate"),
     ("dance/modules/spatial/spatial_domain/stagate.py", "Stagate", "dance_amd.modules.spatial.spatial_domain.stagate"),
+    ("dance/modules/single_modality/imputation/scgnn2.py", "GraphConvolution", "dance_amd.modules.single_modality.imputation.scgnn2"),
+    ("dance/modules/single_modality/imputation/scgnn2.py", "GATLayer", "dance_amd.modules.single_modality.imputation.scgnn2"),
+    ("dance/modules/single_modality/imputation/scgnn2.py", "GAT", "dance_amd.modules.single_modality.imputation.scgnn2"),
+    ("dance/modules/single_modality/imputation/scgnn2.py", "Graph_AE", "dance_amd.modules.single_modality.imputation.scgnn2"),
+    ("dance/modules/single_modality/imputation/scgnn2.py", "GCNModelVAE", "dance_amd.modules.single_modality.imputation.scgnn2"),
+    ("dance/modules/single_modality/imputation/scgnn2.py", "GCNModelAE", "dance_amd.modules.single_modality.imputation.scgnn2"),
+    ("dance/modules/single_modality/imputation/graphsci.py", "GNNModel", "dance_amd.modules.single_modality.imputation.graphsci"),
+    ("dance/modules/spatial/cell_type_deconvo/dstg.py", "GraphConvolution", "dance_amd.modules.spatial.cell_type_deconvo.dstg"),
+    ("dance/modules/spatial/cell_type_deconvo/dstg.py", "GCN", "dance_amd.modules.spatial.cell_type_deconvo.dstg"),
+    ("dance/modules/spatial/cell_type_deconvo/stdgcn.py", "conGraphConvolutionlayer", "dance_amd.modules.spatial.cell_type_deconvo.stdgcn"),
 ]
 
 # Reference methods deliberately absent from the mirror (outside SURVEY.md §8, or torch_geometric plumbing that has no
@@ -50,6 +60,9 @@ ABSENT = {
     ("GATConv", "message"): "torch_geometric MessagePassing hook: the per-edge message tensor is never built (dh_edge_softmax_f32 + SpMM)",
     ("AdaptiveSAGE", "message_func"): "DGL user-defined message function over an EdgeBatch: its arithmetic (gnn.py:62-82) is fused into "
                                       "dh_sage_aggregate_f32 / dh_sage_window_mfma, no [E, D] message tensor exists to hand to a UDF",
+    **{("GATLayer", m): "helper of the reference's scatter formulation over [E, NH, FOUT] tensors (scgnn2.py:1049-1142); the mirror "
+                        "computes the same attention with dh_edge_softmax_shift_f32 + SpMM and never builds those tensors"
+       for m in ("neighborhood_aware_softmax", "sum_edge_scores_neighborhood_aware", "aggregate_neighbors", "lift", "explicit_broadcast")},
     ("WeightedGraphConv", "edge_selection_simple"): "DGL user-defined message function (graphsc.py:417-426): h_src * w_e is the edge value "
                                                     "of the fused SpMM, there is no EdgeBatch",
 }
@@ -139,7 +152,7 @@ def _same_default(name, ref, ours):
 
 
 @needs_ref
-@pytest.mark.parametrize("rel_path,cls,module", PAIRS, ids=[p[1] for p in PAIRS])
+@pytest.mark.parametrize("rel_path,cls,module", PAIRS, ids=[f"{p[2].rsplit('.', 1)[1]}.{p[1]}" for p in PAIRS])
 def test_public_method_signatures_match_reference_ast(rel_path, cls, module):
     import importlib
     ours = getattr(importlib.import_module(module), cls)

@@ -41,3 +41,37 @@ def test_node_count_is_part_of_the_key():
     g5, _ = edge_index_graph(a, 5)
     assert g2.n_rows == 2 and g5.n_rows == 5 and g5.rowptr.numel() == 6
     assert len(_EDGE_CACHE) >= 1
+
+
+def test_permute_keeps_row_order_and_renumbers_the_cached_transpose():
+    import numpy as np
+    import scipy.sparse as sp
+    from dance_amd.graph import CSRGraph, locality_order
+    rng = np.random.default_rng(0)
+    n = 40
+    a = sp.random(n, n, density=0.15, random_state=1, format="csr", dtype=np.float32)
+    a.sort_indices()
+    g = CSRGraph.from_scipy(a, "cpu")
+    at = a.T.tocsr()
+    at.sort_indices()
+    g._t = CSRGraph.from_scipy(at, "cpu")
+    g._t._t = g
+    perm = torch.from_numpy(rng.permutation(n))
+    h = g.permute(perm)
+    p = perm.numpy()
+    want = a[p][:, p].tocsr()
+    assert np.array_equal(h.to_scipy().toarray(), want.toarray())
+    assert np.array_equal(h.transpose().to_scipy().toarray(), want.T.toarray())
+    assert h.transpose().transpose() is h
+    inv = np.argsort(p)
+    for i in range(n):  # edges of new row i = edges of old row perm[i], same order, columns relabelled
+        lo, hi = a.indptr[p[i]], a.indptr[p[i] + 1]
+        assert np.array_equal(h.col[h.rowptr[i]:h.rowptr[i + 1]].numpy(), inv[a.indices[lo:hi]])
+        assert np.array_equal(h.val[h.rowptr[i]:h.rowptr[i + 1]].numpy(), a.data[lo:hi])
+    order = locality_order(g)
+    assert sorted(order.tolist()) == list(range(n))
+    band = lambda m: max(abs(i - j) for i, j in zip(*m.nonzero()))
+    ring = sp.diags([1, 1], [1, -1], shape=(n, n), format="csr", dtype=np.float32)
+    shuffled = ring[p][:, p].tocsr()
+    gs = CSRGraph.from_scipy(shuffled, "cpu", symmetric=True)
+    assert band(gs.permute(locality_order(gs)).to_scipy()) <= 2 < band(shuffled)

@@ -269,7 +269,7 @@ def test_graphsc_golden_regenerates_from_reference(tmp_path, monkeypatch):
             assert np.array_equal(new[k], old[k]), k
 
 
-@pytest.mark.parametrize("maker,fname", [("make_scheteronet", "scheteronet.npz"), ("make_scdsc_fit", "scdsc_fit.npz"), ("make_sctag", "sctag.npz"), ("make_stagate", "stagate.npz")])
+@pytest.mark.parametrize("maker,fname", [("make_scheteronet", "scheteronet.npz"), ("make_scdsc_fit", "scdsc_fit.npz"), ("make_sctag", "sctag.npz"), ("make_stagate", "stagate.npz"), ("make_free_riders", "free_riders.npz")])
 def test_model_goldens_regenerate_from_reference(tmp_path, monkeypatch, maker, fname):
     """scheteronet.npz / scdsc_fit.npz are what the reference's own classes produce NOW (build container only)."""
     import importlib.util
