@@ -19,7 +19,8 @@ Prints ONE JSON line on rank 0.  Besides the headline (rand-k15)
 * ``gemm_f32x3_row`` (1 GPU): a separately labelled row, NOT the headline — the same layer with the GEMMs on the bf16
   matrix cores via an exact three-way operand split (dh_gemm_f32x3);
 * ``knn_k15`` (1 GPU): the same layer timed on the metric's literal graph — exact kNN (k = 15, self included) of a
-  clustered 50-d embedding + UMAP connectivities, built by NeighborGraph's own kernels inside this script;
+  clustered 50-d embedding + UMAP connectivities, built by NeighborGraph's own kernels inside this script, with the cells
+  renumbered by a locality order at graph set-up (``unordered``: the same graph as built; outputs identical row for row);
 * N > 1: ``exchange`` — every exchange mode timed with the same K steps (halo all-to-all-v, dense all-gather, feature-sliced
   all-to-all), bytes on the wire per step and the exchange alone timed without compute; the headline is the fastest mode.
 """
@@ -56,19 +57,29 @@ def synth_features(n_rows, n_genes, device, seed):
 
 
 def synth_rand_graph(n, k, device, seed):
-    """'rand-k15' (SURVEY.md §8d): k uniformly random in-neighbours per row, sorted, value 1/k; same on all ranks."""
+    """'rand-k15' (SURVEY.md §8d): k DISTINCT uniformly random in-neighbours != i per row i, sorted, value 1/k; same on all ranks.
+    Drawn from [0, n - 1) and shifted past the diagonal; the (rare) rows with a repeated draw are redrawn until none is left."""
     g = torch.Generator(device=device).manual_seed(seed)
-    col = torch.randint(0, n, (n, k), device=device, generator=g, dtype=torch.int64).sort(dim=1).values
+    col = torch.randint(0, n - 1, (n, k), device=device, generator=g, dtype=torch.int64).sort(dim=1).values
+    while True:
+        bad = (col[:, 1:] == col[:, :-1]).any(dim=1).nonzero().reshape(-1)
+        if bad.numel() == 0:
+            break
+        col[bad] = torch.randint(0, n - 1, (bad.numel(), k), device=device, generator=g, dtype=torch.int64).sort(dim=1).values
+    col = col + (col >= torch.arange(n, device=device)[:, None]).to(torch.int64)  # skip the diagonal (order is preserved)
     rowptr = torch.arange(0, n * k + 1, k, device=device, dtype=torch.int32)
     val = torch.full((n * k,), 1.0 / k, dtype=torch.float32, device=device)
     return rowptr, col.to(torch.int32).reshape(-1).contiguous(), val
 
 
-def synth_knn_graph(n, k, device, seed):
+def synth_knn_graph(n, k, device, seed, reorder=True):
     """'knn-k15' (SURVEY.md §8d): cells from 20 Gaussian clusters in a 50-d latent space; exact kNN (self included) and
-    UMAP connectivities by the NeighborGraph kernels (dh_knn_bruteforce_f32, dh_umap_membership_f32, ...)."""
+    UMAP connectivities by the NeighborGraph kernels (dh_knn_bruteforce_f32, dh_umap_membership_f32, ...).  With ``reorder`` the
+    cells are then renumbered by a locality order (reverse Cuthill-McKee, dance_amd.graph.locality_order — graph set-up, like the
+    kNN search itself) and the graph permuted with the edge order inside every row kept, so the layer's outputs are those of
+    the unordered graph row for row, bit for bit.  Returns (graph as built, renumbered graph or None, perm, build s, order s)."""
     from dance_amd import kernels
-    from dance_amd.graph import CSRGraph
+    from dance_amd.graph import CSRGraph, locality_order
     g = torch.Generator(device=device).manual_seed(seed)
     centers = torch.randn((20, 50), device=device, generator=g) * 4.0
     emb = centers[torch.randint(0, 20, (n, ), device=device, generator=g)] + torch.randn((n, 50), device=device, generator=g)
@@ -77,7 +88,15 @@ def synth_knn_graph(n, k, device, seed):
     idx, dist_ = kernels.knn(emb, k)
     (rowptr, col, val), _ = kernels.umap_connectivities(idx, dist_.contiguous())
     torch.cuda.synchronize()
-    return CSRGraph(rowptr, col, val, n, n, symmetric=True), time.perf_counter() - t0
+    build_s = time.perf_counter() - t0
+    graph = CSRGraph(rowptr, col, val, n, n, symmetric=True)
+    if not reorder:
+        return graph, None, None, build_s, 0.0
+    t0 = time.perf_counter()
+    perm = locality_order(graph).to(device)
+    ordered = graph.permute(perm)
+    torch.cuda.synchronize()
+    return graph, ordered, perm, build_s, time.perf_counter() - t0
 
 
 def layer_bytes(n, nnz, f=N_GENES, h=N_HIDDEN, s=4):
@@ -281,15 +300,32 @@ def main():
     knn_out = None
     if world == 1 and not args.no_knn_workload:
         del sg
-        kg, build_s = synth_knn_graph(n, K_NEIGH, dev, seed=7)
+        kg, kg_ordered, perm, build_s, order_s = synth_knn_graph(n, K_NEIGH, dev, seed=7)
         sgk = sharding.ShardedGCNGraph.from_global_csr(kg)
         k_elapsed, _ = time_steps(make_step(sgk), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
         k_ms = k_elapsed / args.steps * 1e3
+        y_plain = sharding.sharded_gcn_layer(x, w, sgk, None, True).detach()
+        del sgk
+        # the same cells renumbered by locality: X and dY are permuted ONCE (set-up, like the graph build), the layer is unchanged
+        x_saved, dy_saved = x, dy
+        x, dy = x_saved[perm].contiguous(), dy_saved[perm].contiguous()
+        sgo = sharding.ShardedGCNGraph.from_global_csr(kg_ordered)
+        o_elapsed, o_timer = time_steps(make_step(sgo), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
+        o_ms = o_elapsed / args.steps * 1e3
+        y_ord = sharding.sharded_gcn_layer(x, w, sgo, None, True).detach()
+        same = bool(torch.equal(y_ord, y_plain[perm]))
+        x, dy = x_saved, dy_saved
+        del y_ord, y_plain, sgo
         knn_out = {"workload": f"same layer on knn-k15: exact kNN (k={K_NEIGH}, self included) of a 20-cluster 50-d embedding + UMAP "
-                               f"connectivities, built on the device by the NeighborGraph kernels",
-                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "ms_per_step": k_ms, "value": n / (k_elapsed / args.steps),
-                   "unit": "cells/s", "layer_hbm_frac": round(layer_bytes(n, kg.nnz) / (k_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4)}
-        del sgk, kg
+                               f"connectivities, built on the device by the NeighborGraph kernels; cells renumbered by reverse "
+                               f"Cuthill-McKee (graph set-up), X permuted once, outputs identical row for row",
+                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "locality_order_s": round(order_s, 4),
+                   "ms_per_step": o_ms, "value": n / (o_elapsed / args.steps), "unit": "cells/s",
+                   "layer_hbm_frac": round(layer_bytes(n, kg.nnz) / (o_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
+                   "y_bit_identical_to_unordered": same,
+                   "kernels_ms": {k_: round(v[1], 4) for k_, v in sorted(o_timer.summary().items())},
+                   "unordered": {"ms_per_step": k_ms, "value": n / (k_elapsed / args.steps)}}
+        del kg, kg_ordered
         sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
 
     if rank == 0:
@@ -317,6 +353,8 @@ def main():
                 e.update(bound="hbm", achieved=round(b / ms / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s")
             elif name.startswith("relu_backward"):
                 e.update(bound="hbm", achieved=round(3.0 * n_local * N_HIDDEN * 4 / ms / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s")
+            elif name.startswith("relu_mask_apply"):  # dY in, masked dY out, one bit per element of mask
+                e.update(bound="hbm", achieved=round((2.0 * 4 + 0.125) * n_local * N_HIDDEN / ms / 1e6, 1), peak=PEAK_HBM_GBS, unit="GB/s")
             if "achieved" in e:
                 e["frac"] = round(e["achieved"] / e["peak"], 4)
             kernels_out[name] = e

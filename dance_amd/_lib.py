@@ -99,6 +99,15 @@ def _declare(lib):
         "dh_block_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_block_plan": (c_int, [i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_block_fill": (c_int, [i64, i64, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+        "dh_comm_unique_id": (c_int, [P]),
+        "dh_comm_init": (c_int, [P, i32, i32, P]),
+        "dh_comm_destroy": (c_int, [P]),
+        "dh_comm_world": (c_int, [P]),
+        "dh_comm_rank": (c_int, [P]),
+        "dh_comm_allgather_rows_f32": (c_int, [P, P, i64, i64, P, P]),
+        "dh_comm_allreduce_f32": (c_int, [P, P, i64, P]),
+        "dh_comm_halo_exchange_f32": (c_int, [P, P, P, P, P, i64, P]),
+        "dh_comm_halo_spmm_f32": (c_int, [P, i64, i64, i64, P, P, P, P, i64, P, P, P, P, P, i64, P, i64, P, i64, P, i32, P, P, P]),
         "dh_sage_alpha_grad_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, P]),
     }
     for name, (res, args) in sig.items():

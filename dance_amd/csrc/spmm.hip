@@ -10,8 +10,6 @@
 // ds_bpermute inside sub-wave groups) while every lane streams its VEC-wide column slice of
 // the neighbour rows.  Accumulation is sequential in CSR order per output element — no
 // atomics, bit-reproducible.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -292,9 +290,10 @@ void launch_slices(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t*
                    hipStream_t st, int64_t slice_begin = 0, int64_t slice_end = -1) {
   const bool idx32 = n_cols >= 0 && (double)n_cols * (double)ldz < 4294967296.0;
   const int64_t c_end = slice_end < 0 ? width : slice_end * 128;
-  static const int xcd_map = [] { const char* e = getenv("DH_SPMM_XCDMAP"); return e ? atoi(e) : 0; }();
+  // XCD-contiguous rows (see the kernel): measured at 1M rows on knn-k15, unordered 7.81 -> 7.39 ms, RCM-ordered 5.80 -> 5.73 ms,
+  // rand-k15 unchanged (4.55 ms) — profiles/r03c_locality_map{0,1}.json
   const int64_t blocks = dh::ceil_div(n_rows, 8);
-  const int xcd_blocks = xcd_map ? (int)dh::ceil_div(blocks, 8) : 0;
+  const int xcd_blocks = blocks >= 64 ? (int)dh::ceil_div(blocks, 8) : 0;
   for (int64_t c = slice_begin * 128; c < c_end; c += 128) {
     const ReluMask mask{out_mask, in_mask, (int)(width / 128), (int)(c / 128), xcd_blocks};
     dim3 grid((unsigned)(xcd_blocks ? (int64_t)xcd_blocks * 8 : blocks), 1);

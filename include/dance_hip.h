@@ -42,7 +42,8 @@ enum dh_status {
   DH_ERR_INVALID = -1,   /* bad argument (null pointer, negative size, unsupported combo) */
   DH_ERR_LAUNCH = -2,    /* hipGetLastError() after a launch */
   DH_ERR_WORKSPACE = -3, /* workspace too small */
-  DH_ERR_NO_DEVICE = -4  /* no gfx950 device visible */
+  DH_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
+  DH_ERR_COMM = -5       /* RCCL missing or a collective failed (dh_comm_*) */
 };
 
 enum dh_act { DH_ACT_NONE = 0, DH_ACT_RELU = 1 };
@@ -499,6 +500,40 @@ DH_API int dh_relu_backward_bf16(int64_t n_rows, int64_t width, const uint16_t* 
                           const uint16_t* dY, int64_t lddy, uint16_t* G, int64_t ldg, dh_stream_t stream);
 DH_API int dh_colsum_bf16(int64_t n_rows, int64_t width, const uint16_t* X, int64_t ldx, float* out,
                    void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* ---- multi-GPU: RCCL over xGMI, one process per GPU ------------------------------------------------
+ * The reference has no multi-GPU path for these models; the sharded layer replaces the single-process torch.spmm / autograd
+ * pair of scdsc.py:498 + :286-288 (spagcn.py:359 + :521) with a destination-range shard per rank and ONE exchange per SpMM.
+ * RCCL is bound at run time (dlopen) on the first call: no link-time dependency, and inside a PyTorch process the RCCL torch
+ * already loaded is the one used.  Bootstrap: rank 0 calls dh_comm_unique_id and ships the 128 bytes to the other ranks by any
+ * host channel (a file, MPI, torch.distributed's store); every rank then calls dh_comm_init.  Collectives are asynchronous on
+ * the given stream.  Row counts of the halo exchange are HOST arrays of `world` entries (this rank's entry 0).
+ *   dh_comm_allgather_rows_f32: out[r * rows_per_rank ...] = rank r's `local` [rows_per_rank, width] (dense exchange of S / G).
+ *   dh_comm_allreduce_f32:      buf <- sum over ranks (dW, db: 4 MB at the headline shape).
+ *   dh_comm_halo_exchange_f32:  all-to-all-v of contiguous row blocks, `width` floats per row, ordered by peer rank: grouped
+ *                               ncclSend / ncclRecv, every pair in flight at once on the point-to-point xGMI links.
+ *   dh_comm_halo_spmm_f32:      Y[rows] = act(A_local * operand + bias) for a shard whose column ids are [own rows | halo rows]:
+ *                               packs operand[send_idx] (times the ReLU sign mask of those rows if send_relu_mask != NULL) into
+ *                               send_buf, exchanges on comm_stream while the interior rows run on compute_stream, then the
+ *                               boundary rows; `operand` is [n_local + n_halo, ldz], its tail receives the halo.  No host sync. */
+#define DH_COMM_UNIQUE_ID_BYTES 128
+typedef struct dh_comm* dh_comm_t;
+DH_API int dh_comm_unique_id(void* id_host /* DH_COMM_UNIQUE_ID_BYTES */);
+DH_API int dh_comm_init(dh_comm_t* comm, int world, int rank, const void* unique_id_host);
+DH_API int dh_comm_destroy(dh_comm_t comm);
+DH_API int dh_comm_world(dh_comm_t comm);
+DH_API int dh_comm_rank(dh_comm_t comm);
+DH_API int dh_comm_allgather_rows_f32(dh_comm_t comm, const float* local, int64_t rows_per_rank, int64_t width, float* out,
+                               dh_stream_t stream);
+DH_API int dh_comm_allreduce_f32(dh_comm_t comm, float* buf, int64_t count, dh_stream_t stream);
+DH_API int dh_comm_halo_exchange_f32(dh_comm_t comm, const float* send, const int64_t* send_rows_host, float* recv,
+                               const int64_t* recv_rows_host, int64_t width, dh_stream_t stream);
+DH_API int dh_comm_halo_spmm_f32(dh_comm_t comm, int64_t n_local, int64_t n_halo, int64_t width,
+                               const int32_t* rowptr, const int32_t* col, const float* val, float* operand, int64_t ldz,
+                               const int32_t* send_idx, const int64_t* send_rows_host, const int64_t* recv_rows_host, float* send_buf,
+                               const int32_t* interior_rows, int64_t n_interior, const int32_t* boundary_rows, int64_t n_boundary,
+                               float* Y, int64_t ldy, const float* bias, int act, const void* send_relu_mask,
+                               dh_stream_t compute_stream, dh_stream_t comm_stream);
 
 #ifdef __cplusplus
 }

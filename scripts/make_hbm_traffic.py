@@ -11,7 +11,8 @@ names = {  # bench.py kernel key -> (device kernel name, launches per C-ABI call
     "gemm_f32_tn": ("gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, false, true>", 1),
     # the 512-wide SpMM runs as four 128-column passes (spmm.hip): bytes per call = 4 x bytes per launch
     "spmm_csr_f32[fwd]": ("spmm_slice128_kernel<false, true, true>", 4),   # records the ReLU bitmap
-    "spmm_csr_f32[bwd]": ("spmm_slice128_kernel<true, false, true>", 4),   # applies it to the gathered dY rows
+    "spmm_csr_f32[bwd]": ("spmm_slice128_kernel<false, false, true>", 4),  # plain gather of the pre-masked dY (round 3 default)
+    "relu_mask_apply_f32": ("relu_mask_apply_kernel", 1),                  # dY * [Y > 0] from the bitmap, one streaming pass
 }
 out = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                    "scripts/refresh_round.sh, bench.py at 1M cells); bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024: on "
