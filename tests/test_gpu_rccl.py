@@ -126,3 +126,44 @@ def test_spagcn_sharded_equals_single_process_world1(nccl_world1):
         m.fit((embed, adj), init="kmeans", n_clusters=2, epochs=15, lr=0.01, tol=0.0)
         outs.append((m.predict_proba((embed, adj)).cpu().numpy(), m.model.gc.weight.detach().cpu().numpy()))
     assert rel_err(outs[1][0], outs[0][0]) < 1e-4 and rel_err(outs[1][1], outs[0][1]) < 1e-4
+
+
+def test_dh_comm_entry_points_world1(cuda_device):
+    """The C-ABI communicator (dh_comm_*: RCCL bound by dlopen, no torch.distributed) at world size 1: bootstrap from a unique
+    id, every collective on device buffers of the layer's shapes, and the halo-overlapped SpMM against the plain kernel (with no
+    peers the halo is empty: interior + boundary rows must reproduce dh_spmm_csr_f32 bit for bit, masked send path included)."""
+    from dance_amd import kernels
+    from dance_amd.comm import UNIQUE_ID_BYTES, Communicator
+    dev = cuda_device
+    uid = Communicator.unique_id()
+    assert len(uid) == UNIQUE_ID_BYTES and any(uid)
+    comm = Communicator(1, 0, uid)
+    assert (comm.world, comm.rank) == (1, 0)
+    n, h, k = 5000, 256, 9
+    g = torch.Generator(device="cpu").manual_seed(1)
+    s = torch.randn(n, h, generator=g).to(dev)
+    assert torch.equal(comm.allgather_rows(s), s)
+    t = s[:16].clone()
+    assert torch.equal(comm.allreduce_(t), s[:16])
+    empty = torch.empty((0, h), device=dev)
+    comm.halo_exchange(empty, [0], empty, [0])
+    with pytest.raises(Exception):
+        comm.halo_exchange(s[:3].contiguous(), [3], torch.empty((3, h), device=dev), [3])  # no exchange with oneself
+    with pytest.raises(ValueError):
+        comm.halo_exchange(empty, [0, 0], empty, [0, 0])
+    col = torch.randint(0, n, (n, k), generator=g).sort(dim=1).values.reshape(-1).to(torch.int32).to(dev)
+    rowptr = (torch.arange(n + 1, dtype=torch.int32) * k).to(dev)
+    val = torch.rand(n * k, generator=g).to(dev)
+    bias = torch.randn(h, generator=g).to(dev)
+    perm = torch.randperm(n, generator=g).to(torch.int32).to(dev)
+    interior, boundary = perm[: n // 3].contiguous(), perm[n // 3:].contiguous()
+    y = comm.halo_spmm(rowptr, col, val, s, n, torch.empty(0, dtype=torch.int32, device=dev), [0], [0], interior, boundary, bias=bias,
+                       act=kernels.ACT_RELU)
+    torch.cuda.synchronize()
+    assert torch.equal(y, kernels.spmm_csr(rowptr, col, val, s, bias=bias, act=kernels.ACT_RELU))
+    with pytest.raises(Exception):  # receive counts must add up to the halo rows of the operand
+        comm.halo_spmm(rowptr, col, val, s, n - 5, torch.empty(0, dtype=torch.int32, device=dev), [0], [0], interior, boundary)
+    comm.close()
+    comm.close()  # idempotent
+    c2 = Communicator.single()
+    assert torch.equal(c2.allgather_rows(s[:8].contiguous()), s[:8])
