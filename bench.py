@@ -212,7 +212,15 @@ def main():
     ap.add_argument("--no-x3-row", action="store_true", help="skip the separately labelled split-bf16 GEMM row at 1 GPU")
     ap.add_argument("--exchange", choices=["auto", "halo", "allgather", "alltoall"], default="auto",
                     help="multi-GPU exchange (dance_amd/sharding.py); auto = time every mode, headline = the fastest")
+    ap.add_argument("--emulate-rank", type=int, default=None, metavar="p",
+                    help="with --of P: time rank p's shard of a P-GPU run on this one GPU and PROJECT the step time "
+                         "(scripts/emulate_rank.py; prints its own JSON line, labelled a projection)")
+    ap.add_argument("--of", type=int, default=8, metavar="P")
     args = ap.parse_args()
+    if args.emulate_rank is not None:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import emulate_rank
+        return emulate_rank.main(["--cells", str(args.cells), "--ranks-of", str(args.of), "--rank", str(args.emulate_rank)])
 
     from dance_amd import _lib, kernels, sharding
     from dance_amd.graph import CSRGraph

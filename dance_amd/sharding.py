@@ -23,8 +23,9 @@ Three exchange modes (``ShardedGCNGraph.mode``), same inputs / outputs / numeric
   rows into INTERIOR rows (all columns local) and BOUNDARY rows.  Per layer: the GEMM writes S_p straight into the head
   of the operand buffer, the requested rows are packed (dh_gather_rows_f32) and exchanged with one
   ``all_to_all_single`` (variable split sizes = all-to-all-v) that runs asynchronously while the interior rows are
-  aggregated (dh_spmm_csr[_relu]_rows_f32); the boundary rows follow when the halo has landed.  The fused ReLU mask is
-  kept at P > 1: halo rows of G = dY * [Y > 0] are masked while they are packed, local rows inside the backward SpMM.
+  aggregated (dh_spmm_csr[_relu]_rows_f32); the boundary rows follow when the halo has landed.  The ReLU sign mask is
+  kept at P > 1: backward turns dY_p into G_p = dY_p * [Y_p > 0] with one streaming pass (dh_relu_mask_apply_f32) that writes
+  straight into the head of the operand buffer — where a plain copy would otherwise be needed — before rows are packed.
   Optional: ``halo_dtype="bf16"`` halves the bytes on the wire (halo rows rounded to bf16: not bit-identical any more),
   ``reorder="rcm"`` renumbers the nodes by reverse Cuthill-McKee first so that kNN-like graphs reference mostly local rows.
 * ``"allgather"`` — the dense form of the above: the graph itself is sharded by destination range and every
@@ -98,8 +99,27 @@ class HaloPlan:
         return int(self.remote_ids.numel())
 
 
-def build_halo_plan(shard: "GraphShard", ranges, chunk: int, rank: int, world: int, group=None) -> HaloPlan:
-    """Set-up collective (once per graph): every rank tells the owners which of their rows it needs."""
+def peer_requests_from_global(rowptr: torch.Tensor, col: torch.Tensor, ranges, rank: int):
+    """What the OTHER ranks would ask rank ``rank`` for, computed from the whole CSR instead of by a collective: for every
+    peer q the distinct columns in this rank's range among q's rows.  Returns (send_idx int32 local row ids grouped by peer,
+    send_counts).  Used when one process plans (or emulates, bench.py --emulate-rank) the shard of a rank of a larger world."""
+    lo, hi = ranges[rank]
+    n = rowptr.numel() - 1
+    dev = col.device
+    c = col.to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), (rowptr[1:] - rowptr[:-1]).to(torch.int64), output_size=c.numel())
+    starts = torch.tensor([r[0] for r in ranges], dtype=torch.int64, device=dev)
+    owner = torch.searchsorted(starts, rows, right=True) - 1
+    sel = (c >= lo) & (c < hi) & (owner != rank)
+    key = torch.unique(owner[sel] * n + c[sel])  # ascending: grouped by peer, then by column
+    send_idx = (key % n - lo).to(torch.int32).contiguous()
+    send_counts = torch.bincount(key // n, minlength=len(ranges)).tolist()
+    return send_idx, send_counts
+
+
+def build_halo_plan(shard: "GraphShard", ranges, chunk: int, rank: int, world: int, group=None, peer_requests=None) -> HaloPlan:
+    """Set-up collective (once per graph): every rank tells the owners which of their rows it needs.  ``peer_requests`` =
+    (send_idx, send_counts) from ``peer_requests_from_global`` replaces the collective (single-process planning / emulation)."""
     lo, hi = ranges[rank]
     n_local = hi - lo
     col = shard.col.to(torch.int64)
@@ -120,7 +140,9 @@ def build_halo_plan(shard: "GraphShard", ranges, chunk: int, rank: int, world: i
     # ask the owners: counts first, then the row ids (relative to the owner's range)
     owner_lo = torch.repeat_interleave(bounds[:-1], cuts[1:] - cuts[:-1], output_size=uniq.numel())
     want = (uniq - owner_lo).to(torch.int32)
-    if world > 1:
+    if peer_requests is not None:
+        send_idx, send_counts = peer_requests
+    elif world > 1:
         send_counts_t = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_to_all_single(send_counts_t, torch.tensor(recv_counts, dtype=torch.int64, device=dev), group=group)
         send_counts = send_counts_t.tolist()
@@ -132,32 +154,24 @@ def build_halo_plan(shard: "GraphShard", ranges, chunk: int, rank: int, world: i
 
 
 def rcm_order(graph) -> torch.Tensor:
-    """Reverse Cuthill-McKee order of the symmetrised pattern (host, scipy; set-up only): ``perm[new] = old``.  kNN-like
-    graphs renumbered this way reference mostly nearby — hence local — rows, which is what makes the halo small."""
-    import numpy as np
-    import scipy.sparse as sp
-    from scipy.sparse.csgraph import reverse_cuthill_mckee
-    n = graph.n_rows
-    a = sp.csr_matrix((np.ones(graph.nnz, dtype=np.int8), graph.col.cpu().numpy(), graph.rowptr.cpu().numpy()), shape=(n, graph.n_cols))
-    return torch.from_numpy(np.ascontiguousarray(reverse_cuthill_mckee((a + a.T).tocsr(), symmetric_mode=True)).astype(np.int64))
+    """Reverse Cuthill-McKee order (``perm[new] = old``; dance_amd.graph.locality_order): kNN-like graphs renumbered this way
+    reference mostly nearby — hence local — rows, which is what makes the halo small."""
+    from .graph import locality_order
+    return locality_order(graph, "rcm")
 
 
 def permute_graph(graph, perm: torch.Tensor):
-    """P A P^T for ``perm[new] = old`` as a new CSRGraph on the same device (host scipy; set-up only)."""
-    import numpy as np
-    from .graph import CSRGraph
-    a = graph.to_scipy()
-    p = perm.cpu().numpy()
-    b = a[p][:, p].tocsr()
-    b.sort_indices()
-    return CSRGraph.from_scipy(b, graph.device, symmetric=graph.symmetric)
+    """P A P^T for ``perm[new] = old`` (CSRGraph.permute: on the device, the order of the edges inside every row kept, so the
+    per-row sums of the renumbered graph are those of the original, bit for bit)."""
+    return graph.permute(perm)
 
 
 class ShardedGCNGraph:
     """This rank's destination-range shard of A and of A^T (+ optionally the replicated graph for "alltoall")."""
 
     def __init__(self, a_shard: GraphShard, at_shard: GraphShard, n_nodes: int, group=None, *, mode: str = "allgather",
-                 full: Optional[Tuple[GraphShard, GraphShard]] = None, halo_dtype: str = "f32", perm: Optional[torch.Tensor] = None):
+                 full: Optional[Tuple[GraphShard, GraphShard]] = None, halo_dtype: str = "f32", perm: Optional[torch.Tensor] = None,
+                 emulate: Optional[Tuple[int, int, object]] = None):
         if mode not in ("allgather", "alltoall", "halo"):
             raise ValueError(f"unknown exchange mode {mode!r}")
         if halo_dtype not in ("f32", "bf16"):
@@ -172,23 +186,34 @@ class ShardedGCNGraph:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.emulated = emulate is not None
+        if emulate is not None:  # (rank, world, global graph): the shard of one rank of a larger world, planned without collectives
+            self.rank, self.world = int(emulate[0]), int(emulate[1])
         self.ranges, self.chunk = row_ranges(n_nodes, self.world)
         lo, hi = self.ranges[self.rank]
         if (a_shard.lo, a_shard.hi) != (lo, hi) or (at_shard.lo, at_shard.hi) != (lo, hi):
             raise ValueError(f"rank {self.rank} must own rows [{lo}, {hi})")
         self.halo = self.halo_t = None
         if mode == "halo":
-            self.halo = build_halo_plan(a_shard, self.ranges, self.chunk, self.rank, self.world, group)
-            self.halo_t = build_halo_plan(at_shard, self.ranges, self.chunk, self.rank, self.world, group)
+            req = req_t = None
+            if emulate is not None:
+                g = emulate[2]
+                gt = g.transpose()
+                req = peer_requests_from_global(g.rowptr, g.col, self.ranges, self.rank)
+                req_t = peer_requests_from_global(gt.rowptr, gt.col, self.ranges, self.rank)
+            self.halo = build_halo_plan(a_shard, self.ranges, self.chunk, self.rank, self.world, group, req)
+            self.halo_t = build_halo_plan(at_shard, self.ranges, self.chunk, self.rank, self.world, group, req_t)
 
     @classmethod
     def from_global_csr(cls, graph, group=None, *, mode: str = "allgather", halo_dtype: str = "f32",
-                        reorder: Optional[str] = None) -> "ShardedGCNGraph":
+                        reorder: Optional[str] = None, emulate: Optional[Tuple[int, int]] = None) -> "ShardedGCNGraph":
         """Slice this rank's rows out of a full ``CSRGraph`` (and its transpose) replicated on every rank.
         ``reorder="rcm"`` first renumbers the nodes (``self.perm[new] = old``: callers feed X / read Y in the new order, i.e.
         ``X_new = X[perm]``, and map results back with ``Y[inv]`` where ``inv[perm] = arange``)."""
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if emulate is not None:  # (rank, world): plan that rank's shard in this single process; the exchanges themselves cannot run
+            rank, world = emulate
         perm = None
         if reorder is not None:
             if reorder != "rcm":
@@ -204,7 +229,7 @@ class ShardedGCNGraph:
                     GraphShard(gt.rowptr, gt.col, gt.val, 0, gt.n_rows, gt.n_cols))
         return cls(slice_rows(graph.rowptr, graph.col, graph.val, lo, hi, graph.n_cols),
                    slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group, mode=mode, full=full,
-                   halo_dtype=halo_dtype, perm=perm)
+                   halo_dtype=halo_dtype, perm=perm, emulate=None if emulate is None else (rank, world, graph))
 
     # ---- halo exchange ("halo" mode) ------------------------------------------------------------------------
     def halo_exchange(self, plan: HaloPlan, send_rows: torch.Tensor, recv_into: torch.Tensor):
@@ -410,11 +435,10 @@ def _halo_forward(ctx, x_local, w, bias, sg, active, ops, rowscale, colscale, re
     act = ops.ACT_RELU if active else ops.ACT_NONE
     row_bytes = ops.relu_mask_bytes(1, h) if hasattr(ops, "relu_mask_bytes") else 0
     fused = (active and bias is None and rowscale is None and colscale is None and reduce == ops.REDUCE_SUM and row_bytes > 0
-             and hasattr(ops, "spmm_csr_relu"))
+             and hasattr(ops, "spmm_csr_relu") and hasattr(ops, "relu_mask_apply"))
     mask = None
-    if fused:  # sign mask of Y_p (head) + all-ones words for the rows of G that will arrive already masked (tail)
-        mask = torch.empty((n_loc + plan_t.n_halo) * row_bytes, dtype=torch.uint8, device=dev)
-        mask[n_loc * row_bytes:].fill_(255)
+    if fused:  # sign mask of Y_p: backward turns dY_p into G_p with it before anything is gathered or sent
+        mask = torch.empty(n_loc * row_bytes, dtype=torch.uint8, device=dev)
         _run_split(lambda rows: ops.spmm_csr_relu(sg.a.rowptr, plan.col, sg.a.val, buf, n_cols=buf.shape[0], act=act, out_mask=mask,
                                                   out=out, rows=rows, tag="spmm_csr_f32[fwd]"), plan, work)
     else:
@@ -440,15 +464,17 @@ def _halo_backward(ctx, dy, x_local, w, out, mask):
     if ctx.has_bias and ctx.needs_input_grad[2]:
         db = sg.all_reduce_sum(ops.colsum(g_local))
     if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-        buf = torch.empty((n_loc + plan_t.n_halo, h), dtype=torch.float32, device=dev)  # operand: [G_p (or dY_p + mask) | halo rows of G]
-        buf[:n_loc].copy_(g_local)
-        send = (ops.gather_rows(g_local, plan_t.send_idx, relu_mask=mask) if fused else ops.gather_rows(g_local, plan_t.send_idx)) \
-            if plan_t.send_idx.numel() else buf[:0]
+        buf = torch.empty((n_loc + plan_t.n_halo, h), dtype=torch.float32, device=dev)  # operand: [G_p | halo rows of G]
+        if fused:  # G_p = dY_p * [Y_p > 0] from the sign mask, written straight into the head of the operand (this pass replaces
+            ops.relu_mask_apply(g_local, mask, out=buf[:n_loc])  # the plain copy; the gather below then needs no mask: 4 requests
+        else:                                                    # per neighbour instead of 5, as on one GPU)
+            buf[:n_loc].copy_(g_local)
+        send = ops.gather_rows(buf[:n_loc], plan_t.send_idx) if plan_t.send_idx.numel() else buf[:0]
         work = sg.halo_exchange(plan_t, send, buf[n_loc:])
         ds = torch.empty((n_loc, h), dtype=torch.float32, device=dev)
         if fused:
-            _run_split(lambda rows: ops.spmm_csr_relu(sg.at.rowptr, plan_t.col, sg.at.val, buf, n_cols=buf.shape[0], in_mask=mask, out=ds,
-                                                      rows=rows, tag="spmm_csr_f32[bwd]"), plan_t, work)
+            _run_split(lambda rows: ops.spmm_csr(sg.at.rowptr, plan_t.col, sg.at.val, buf, n_cols=buf.shape[0], out=ds, rows=rows,
+                                                 tag="spmm_csr_f32[bwd]"), plan_t, work)
         else:
             m = ctx.rowscale
             if ctx.reduce == ops.REDUCE_MEAN:

@@ -65,6 +65,15 @@ def _worker(rank, world, port, n, fin, fout, k, seed, use_bias, active, q, mode=
             assert np.array_equal(sg.halo.remote_ids.numpy(), need(adj)) and np.array_equal(sg.halo_t.remote_ids.numpy(), need(at))
             assert sorted(sg.halo.interior.tolist() + sg.halo.boundary.tolist()) == list(range(hi - lo))
             assert sg.stats["exchanges"] == (2 if world > 1 else 0)
+            # the single-process (emulated) plan of this rank = the plan the collective produced
+            from dance_amd.graph import CSRGraph
+            g_all = CSRGraph(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), n, n)
+            g_all._t = CSRGraph(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), n, n)
+            emu = sharding.ShardedGCNGraph.from_global_csr(g_all, mode="halo", emulate=(rank, world))
+            for real, fake in ((sg.halo, emu.halo), (sg.halo_t, emu.halo_t)):
+                assert torch.equal(real.send_idx, fake.send_idx) and list(real.send_counts) == list(fake.send_counts)
+                assert torch.equal(real.col, fake.col) and list(real.recv_counts) == list(fake.recv_counts)
+                assert torch.equal(real.interior, fake.interior) and torch.equal(real.boundary, fake.boundary)
             extra = (sg.stats["exchanged_bytes"], (sg.halo.n_halo + sg.halo_t.n_halo) * fout * (2 if halo_dtype == "bf16" else 4))
         q.put((rank, lo, hi, y.detach().numpy(), wt.grad.numpy(), xl.grad.numpy(), None if bt is None else bt.grad.numpy(), extra))
     finally:
