@@ -68,8 +68,6 @@ def _declare(lib):
         "dh_relu_backward_bf16": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
         "dh_colsum_bf16": (c_int, [i64, i64, P, i64, P, P, c_size_t, P]),
         "dh_sage_aggregate_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, P, i64, P, i64, P]),
-        "dh_sage_cells_workspace_bytes": (c_size_t, [i64, i64, i64, i32]),
-        "dh_sage_aggregate_cells": (c_int, [i64, i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P, c_size_t, i32, P]),
         "dh_csr_densify_window": (c_int, [i64, i64, P, P, P, P, P, i32, i64, i64, P, i64, i32, P]),
         "dh_sage_window_mfma_supported": (c_int, [i64, i64, i32]),
         "dh_sage_window_mfma_workspace_bytes": (c_size_t, [i64, i64, i32]),

@@ -91,6 +91,9 @@ class CellGeneGraph:
         """G if the nodes are laid out as CellFeatureGraph builds them — genes (cell_id >= 0) are nodes [0, G), every later
         node is a cell (cell_id == -1) — else -1.  One device read per graph, cached."""
         if getattr(self, "_gene_prefix", None) is None:
+            if "cell_id" not in self.ndata:  # a graph without the CellFeatureGraph id columns: no known layout
+                self._gene_prefix = -1
+                return -1
             cid = self.ndata["cell_id"]
             g = int((cid >= 0).sum())
             self._gene_prefix = g if bool((cid[:g] >= 0).all()) else -1
@@ -301,7 +304,17 @@ class DataLoader:
         # seeds that are all cells of a CellFeatureGraph-layout graph: a one-layer block then is [seed cells | their genes,
         # ascending], which lets AdaptiveSAGE aggregate on the matrix cores (one device read per loader, not per batch)
         g = graph.gene_prefix() if hasattr(graph, "gene_prefix") else -1
-        self.cells_only = bool(g >= 0 and self.indices.numel() > 0 and int(self.indices.min()) >= g)
+        self.cells_only = bool(g >= 0 and self.indices.numel() > 0 and self._min_seed(graph) >= g)
+
+    def _min_seed(self, graph) -> int:
+        """min(indices), read from the device once per (graph, seed tensor): ScDeepSort builds a new loader every epoch over
+        the same ids."""
+        cache = graph.__dict__.setdefault("_min_seed_cache", {})
+        key = (self.indices.data_ptr(), self.indices.numel())
+        if key not in cache:
+            cache.clear()
+            cache[key] = int(self.indices.min())
+        return cache[key]
 
     def __len__(self):
         n = self.indices.numel()
@@ -339,19 +352,25 @@ class DataLoader:
                 ev.record(side)
             return out, ev
 
-        nxt = build(0)
-        for i in range(n):
-            (inp, outn, blocks), ev = nxt
-            if i + 1 < n:
-                nxt = build(i + 1)
-            main.wait_event(ev)
-            for blk in blocks:  # allocated on the side stream, consumed on the caller's
-                hook_out = getattr(blk, "hook_out", None)
-                extra = tuple(t for t in hook_out if torch.is_tensor(t) and t.is_cuda) if isinstance(hook_out, (tuple, list)) else ()
-                for t in (blk.rowptr, blk.col, blk.val, blk.srcdata["_ID"]) + extra:
-                    if t is not None:
-                        t.record_stream(main)
-            yield inp, outn, blocks
+        try:
+            nxt = build(0)
+            for i in range(n):
+                (inp, outn, blocks), ev = nxt
+                if i + 1 < n:
+                    nxt = build(i + 1)
+                main.wait_event(ev)
+                for blk in blocks:  # allocated on the side stream, consumed on the caller's
+                    hook_out = getattr(blk, "hook_out", None)
+                    extra = tuple(t for t in hook_out if torch.is_tensor(t) and t.is_cuda) if isinstance(hook_out, (tuple, list)) else ()
+                    for t in (blk.rowptr, blk.col, blk.val, blk.srcdata["_ID"]) + extra:
+                        if t is not None:
+                            t.record_stream(main)
+                yield inp, outn, blocks
+        finally:
+            # a consumer that stops early (break, exception) leaves the batch built ahead pending on the side stream, and the
+            # builder's per-graph scratch (mark / lut, "all zero between calls") possibly in use: order the caller's stream after
+            # it, so that a later build on the main stream (prefetch=False, a one-batch loader) neither races nor sees it dirty
+            main.wait_stream(side)
 
 
 _SIDE_STREAMS = {}

@@ -1,7 +1,7 @@
 // Densified-operand form of the AdaptiveSAGE aggregation (dance/models/nn/gnn.py:62-90).
 //
 // The cell-gene graph is 10 % dense (200 expressed genes of 2000 per cell).  On the vector ALUs the aggregation is bound by
-// operand delivery, not by HBM (sage_lds.hip: LDS staging measured no faster than the L2 gather).  The matrix cores are
+// operand delivery, not by HBM (an LDS-staged gather measured no faster than the L2 gather in round 2: 13.8 vs 13.5 ms, profiles/r02_sage_lds_pmc.json).  The matrix cores are
 // 16x faster than the vector ALUs, so at 10 % density a DENSE product wins: write the weighted adjacency window as a dense
 // bf16 (or fp32) matrix once (one streaming pass, HBM-bound) and let the MFMA GEMM do  neigh = A_dense * H  — for the
 // cell <- gene direction (A: cells x genes) and, even more so, for the gene <- cell direction (A: genes x cells), whose

@@ -709,28 +709,6 @@ def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H) -> torch.
     return out
 
 
-def sage_aggregate_cells(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, gene_begin: int, gene_rows: int, *,
-                         out_dtype=None, workspace: Optional[torch.Tensor] = None, reuse_segments: bool = False):
-    """dh_sage_aggregate_cells: the LDS-staged cell <- gene form of ``sage_aggregate`` (fp32 or bf16 features).
-    Returns (neigh, workspace); hand the workspace back with ``reuse_segments=True`` for further calls on the same graph."""
-    lib = _lib_ready()
-    n_dst, n_src, width = rowptr.numel() - 1, H.shape[0], H.shape[1]
-    out_dtype = out_dtype or H.dtype
-    out = torch.empty((n_dst, width), dtype=out_dtype, device=H.device)
-    ws_bytes = lib.dh_sage_cells_workspace_bytes(n_dst, width, gene_rows, _out_dtype(out_dtype))
-    if workspace is None or workspace.numel() < ws_bytes:
-        if reuse_segments:
-            raise ValueError("reuse_segments=True needs the workspace of the previous call")
-        workspace = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=H.device)
-    _call(f"sage_aggregate_cells_{'bf16' if H.dtype == _BF16 else 'f32'}", lib.dh_sage_aggregate_cells, n_dst, n_src, col.numel(), width,
-          alpha.numel() - 2, gene_begin, gene_rows, _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),
-          _dev(w, torch.float32, "w", 1), _dev(src_cell_id, torch.int32, "src_cell_id", 1),
-          _dev(dst_cell_id, torch.int32, "dst_cell_id", 1), _dev(alpha.reshape(-1), torch.float32, "alpha", 1),
-          _dev(H, H.dtype, "H", 2), _ld(H), _out_dtype(H.dtype), out.data_ptr(), _ld(out), _out_dtype(out_dtype),
-          workspace.data_ptr(), workspace.numel(), int(reuse_segments), _stream())
-    return out, workspace
-
-
 def csr_densify_window(rowptr, col, val, col_begin: int, n_cols: int, *, rowscale=None, colscale=None, mean: bool = False,
                        dtype=torch.float32, ld: Optional[int] = None, max_row_nnz: int = 0) -> torch.Tensor:
     """dh_csr_densify_window: dense [n_rows, n_cols] copy (fp32 / bf16) of the columns [col_begin, col_begin + n_cols) of a

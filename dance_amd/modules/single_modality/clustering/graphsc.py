@@ -176,40 +176,10 @@ class _GramListedBCE(torch.autograd.Function):
     """mean(binary_cross_entropy_with_logits(z z^T, y, pos_weight=p)) for a target y that is 1 at the listed (us[e], vs[e])
     (each at most once) and 0 elsewhere, as a function of z and without the B x B logits: the dense part (sum of
     softplus(<z_i, z_j>) and its gradient 2 sum_j sigmoid(<z_i, z_j>) z_j) is ONE matrix-core kernel that keeps every logit
-    tile in registers (dh_gram_sigmoid_f32); the y = 1 corrections need the logits of the listed entries only, which are
-    recomputed as dot products.  Replaces the z z^T GEMM, the two passes over the logits and the two B x B x d GEMMs of
-    the backward of graphsc.py:208-216 / :405-411.  ``p``: python float or 1-element tensor."""
-
-    @staticmethod
-    def forward(ctx, z, us, vs, p):
-        n = z.shape[0]
-        rowloss, o = kernels.gram_sigmoid(z)
-        xe = (z[us] * z[vs]).sum(1)
-        dense = rowloss.sum(dtype=torch.float64)
-        corr = (p * F.softplus(-xe) - F.softplus(xe)).sum(dtype=torch.float64)
-        ctx.save_for_backward(z, o, us, vs, xe)
-        ctx.p = p
-        return ((dense + corr) / float(n * n)).to(torch.float32)
-
-    @staticmethod
-    def backward(ctx, g):
-        z, o, us, vs, xe = ctx.saved_tensors
-        p = ctx.p
-        scale = (g / float(z.shape[0]**2)).to(torch.float32)
-        dz = o * (2.0 * scale)
-        sig = torch.sigmoid(xe)
-        c = ((p * (sig - 1) - sig) * scale)[:, None]
-        # x_e = <z_u, z_v>: both end points receive c_e times the other one (sorted accumulation: deterministic)
-        dz.index_put_((us, ), c * z[vs], accumulate=True)
-        dz.index_put_((vs, ), c * z[us], accumulate=True)
-        return dz, None, None, None
-
-
-class _GramListedKernelBCE(torch.autograd.Function):
-    """_GramListedBCE with the listed entries handled by two small kernels instead of ~40 torch launches (gathers, softplus,
-    two sorted ``index_put_``): dh_gram_listed_forward_f32 / _backward_f32.  ``us`` / ``vs`` int32, ``p`` a python float.
-    Written at the end of round 2 and validated against the kernel stand-ins only (DANCE_AMD_GRAPHSC_DECODER=fused-listed);
-    not the default until it has run on the hardware."""
+    tile in registers (dh_gram_sigmoid_f32); the y = 1 corrections need the logits of the listed entries only, recomputed as dot
+    products by dh_gram_listed_forward_f32 / _backward_f32 (two launches; fixed accumulation order).  Replaces the z z^T GEMM,
+    the two passes over the logits and the two B x B x d GEMMs of the backward of graphsc.py:208-216 / :405-411.
+    ``us`` / ``vs`` int32, ``p`` a python float."""
 
     @staticmethod
     def forward(ctx, z, us, vs, p):
@@ -227,17 +197,8 @@ class _GramListedKernelBCE(torch.autograd.Function):
         return kernels.gram_listed_backward(z, o, us, vs, xe, ctx.p, scale), None, None, None
 
 
-def gram_listed_bce(z, us, vs, pos_weight, *, listed_kernels: bool = False):
-    if listed_kernels:
-        return _GramListedKernelBCE.apply(z.contiguous(), us.to(torch.int32), vs.to(torch.int32), float(pos_weight))
-    return _GramListedBCE.apply(z.contiguous(), us, vs, pos_weight)
-
-
-def gram_target_bce(z, u, v, m, pos_weight):
-    """``sparse_target_bce(z z^T, u, v, m, p)`` with 0 / 1 weights m, as a function of z (see _GramListedBCE).  Selecting the
-    entries with m = 1 is a host round trip (nonzero); GraphSC.fit gets them without one (``_dst_edge_hook``)."""
-    sel = torch.nonzero(m).reshape(-1)
-    return gram_listed_bce(z, u[sel], v[sel], pos_weight)
+def gram_listed_bce(z, us, vs, pos_weight):
+    return _GramListedBCE.apply(z.contiguous(), us.to(torch.int32), vs.to(torch.int32), float(pos_weight))
 
 
 class _PinnedCounts:
@@ -276,11 +237,12 @@ def _dst_edge_hook(blocks):
     return order, cnt, ev
 
 
-# "fused": GraphSC.fit evaluates the decoder loss by dh_gram_sigmoid_f32 (no B x B logits), the listed target entries come
-# from the loader's block hook (no host round trip on the model's stream); "fused-sync": same kernel, entries selected by
-# nonzero(); "dense": z z^T GEMM + passes over the logits; "fused-listed": as "fused" with the listed entries handled by
-# dh_gram_listed_* (written at the end of round 2, not yet run on the hardware — opt-in)
+# "fused" (default): GraphSC.fit evaluates the decoder loss by dh_gram_sigmoid_f32 + dh_gram_listed_* (no B x B logits); the listed
+# target entries come from the loader's block hook (no host round trip on the model's stream).  "dense": the reference-shaped
+# path (z z^T GEMM + passes over the logits), also taken when the fused kernel does not support the shape.
 DECODER_MODE = os.environ.get("DANCE_AMD_GRAPHSC_DECODER", "fused")
+if DECODER_MODE not in ("fused", "dense"):
+    raise ValueError(f"DANCE_AMD_GRAPHSC_DECODER must be 'fused' or 'dense', got {DECODER_MODE!r}")
 
 
 class GraphSC(BaseClusteringMethod):
@@ -333,9 +295,10 @@ class GraphSC(BaseClusteringMethod):
             sharding.broadcast_parameters(self.model)
             train_ids = sharding.shard_seed_ids(torch.from_numpy(train_ids)).numpy()
         sampler = MultiLayerFullNeighborSampler(self.n_layers)
-        can_fuse = (DECODER_MODE in ("fused", "fused-sync", "fused-listed") and getattr(self.model.decoder, "linear_logits", False)
-                    and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
-        fused, fused_sync = can_fuse and DECODER_MODE in ("fused", "fused-listed"), can_fuse and DECODER_MODE == "fused-sync"
+        if DECODER_MODE not in ("fused", "dense"):
+            raise ValueError(f"unknown decoder mode {DECODER_MODE!r} ('fused' or 'dense')")
+        fused = (DECODER_MODE == "fused" and getattr(self.model.decoder, "linear_logits", False)
+                 and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr)
@@ -366,8 +329,7 @@ class GraphSC(BaseClusteringMethod):
                     norm = total / (factor if factor != 0 else 1.0)
                     # second forward, fresh dropout (:215); the decoder's own dropout (:409) is the last draw, as in the reference
                     _, emb2 = self.model.forward(blocks, input_features, decode=False)
-                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), us, vs, pos_weight,
-                                                  listed_kernels=DECODER_MODE == "fused-listed")
+                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), us, vs, pos_weight)
                     if not n_listed:  # the reference's 0 * inf (pos_weight = inf against an all-zero target)
                         loss = loss * float("nan")
                 else:
@@ -379,12 +341,8 @@ class GraphSC(BaseClusteringMethod):
                     pos_weight = ((total - s_) / s_).reshape(1)
                     factor = (total - s_) * 2
                     norm = total / torch.where(factor == 0, torch.ones_like(factor), factor)
-                    if fused_sync:  # fused decoder, listed entries selected by nonzero() (one host round trip per batch)
-                        _, emb2 = self.model.forward(blocks, input_features, decode=False)
-                        loss = norm * gram_target_bce(F.dropout(emb2, self.model.decoder.dropout), eu, ev_, em, pos_weight)
-                    else:
-                        adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
-                        loss = norm * sparse_target_bce(adj_logits, eu, ev_, em, pos_weight)
+                    adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
+                    loss = norm * sparse_target_bce(adj_logits, eu, ev_, em, pos_weight)
                 optim.zero_grad()
                 loss.backward()
                 sharding.allreduce_gradients(self.model)

@@ -546,20 +546,21 @@ def world_info(group=None):
 
 
 def shard_seed_ids(ids: torch.Tensor, group=None) -> torch.Tensor:
-    """This rank's share of the seed cells: contiguous slices of ceil(n / P) ids; short slices are padded by repeating the
-    slice's own ids so that every rank runs the same number of batches (the all-reduce of every step needs all of them).
-    Padded duplicates only re-visit cells the rank already owns; ``gather_embeddings`` drops them again."""
+    """This rank's share of the seed cells: contiguous slices of ceil(n / P) ids.  A short (last) slice is padded so that every
+    rank runs the same number of batches (the all-reduce of every step needs all of them) — with ids from the FRONT of the list,
+    i.e. cells of another rank, never with repeats of its own: all ids of a rank stay distinct, so no batch can contain a seed
+    twice whatever the shuffle (dh_block_plan requires unique seeds).  The padded cells are visited by two ranks in an epoch;
+    ``gather_embeddings`` keeps one copy per cell."""
     rank, world = world_info(group)
     if world == 1:
         return ids
     n = ids.numel()
     per = -(-n // world)
     mine = ids[rank * per:min(n, (rank + 1) * per)]
-    if mine.numel() == 0:
-        mine = ids[:1]
-    if mine.numel() < per:
-        reps = -(-per // mine.numel())
-        mine = mine.repeat(reps)[:per]
+    short = per - mine.numel()
+    if short > 0:  # per <= n, and the front ids belong to rank 0 (a short rank is never rank 0 unless world > n)
+        pad = ids[:short] if rank > 0 else ids[n - short:]
+        mine = torch.cat((mine, pad))
     return mine.contiguous()
 
 

@@ -393,23 +393,6 @@ DH_API int dh_sage_aggregate_f32(int64_t n_dst, int64_t n_src, int64_t width, in
                           const int32_t* src_cell_id, const int32_t* dst_cell_id,
                           const float* alpha, const float* H, int64_t ldh,
                           float* neigh, int64_t ldn, dh_stream_t stream);
-/* LDS-staged cell <- gene form of the same aggregation (sage_lds.hip) for destination rows that are CELLS of the
- * cell-gene graph / of a block sampled from it (dance/models/nn/gnn.py:62-90; blocks of scdeepsort.py:183,233):
- * source rows [gene_begin, gene_begin + gene_rows) of H are the gene nodes; every destination row lists its gene
- * in-edges first, by ascending column, followed by its other in-edges (the cell's self loop) — the layout
- * CellFeatureGraph / the block builder produce.  A tile of alpha-scaled gene features stays resident in each CU's LDS
- * while the cells stream past; gene edges reach the ALUs as scalar operands.  H and neigh may be fp32 or bf16
- * (dh_dtype) independently; sums are fp32 in CSR order (bit-reproducible).  Needs even width and leading dimensions.
- * nnz = number of entries of col / w (= rowptr[n_dst] when the rows are the whole graph).
- * The workspace holds the per-row gene-block boundaries (binary search, skipped when reuse_segments != 0 and the
- * workspace still holds them from a previous call on the same graph) and, for a bf16 output, fp32 running sums.  */
-DH_API size_t dh_sage_cells_workspace_bytes(int64_t n_dst, int64_t width, int64_t gene_rows, int out_dtype);
-DH_API int dh_sage_aggregate_cells(int64_t n_dst, int64_t n_src, int64_t nnz, int64_t width, int64_t n_genes,
-                            int64_t gene_begin, int64_t gene_rows,
-                            const int32_t* rowptr, const int32_t* col, const float* w,
-                            const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha,
-                            const void* H, int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype,
-                            void* workspace, size_t workspace_bytes, int reuse_segments, dh_stream_t stream);
 /* Densified-operand form of the same aggregation (densify.hip): at 10 % density the MFMA GEMM over a dense copy of the
  * weighted adjacency beats every vector-ALU gather (measurements in DESIGN.md), most of all for the gene <- cell rows of
  * ~1e5 in-edges.  dh_csr_densify_window writes out[r][c - col_begin] = val_e * rowscale[r] * colscale[c - col_begin]

@@ -58,7 +58,7 @@ n_nodes = n_cells + n_genes
 cid = torch.cat((torch.arange(n_genes, dtype=torch.int32), -torch.ones(n_cells, dtype=torch.int32))).to(dev)
 fid = torch.cat((-torch.ones(n_genes, dtype=torch.int32), torch.arange(n_cells, dtype=torch.int32))).to(dev)
 cg = CellGeneGraph(rowptr, gcol, gval, eid, n_nodes, {"cell_id": cid, "feat_id": fid, "features": torch.randn(n_nodes, din, device=dev, generator=g)})
-for mode in ("fused", "fused-sync", "dense", "fused-listed"):
+for mode in ("fused", "dense"):
     graphsc.DECODER_MODE = mode
     torch.manual_seed(0)
     m = graphsc.GraphSC(in_feats=din, n_clusters=10, device="cuda")

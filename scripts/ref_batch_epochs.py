@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Epoch times of ScDeepSort.fit / GraphSC.fit at the REFERENCE's batch sizes (500, scdeepsort.py:115; 128, graphsc.py:155) next to
+the throughput batch sizes of profiles/r02d_rows.json, on the synthetic cell-gene graph (10 % density, 2000 genes).
+    python scripts/ref_batch_epochs.py [n_cells=100000]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from dance_amd import kernels  # noqa: E402
+from dance_amd.cellgraph import CellGeneGraph  # noqa: E402
+
+n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+dev, n_genes, per = "cuda", 2000, 200
+out = {"cells": n_cells, "genes": n_genes, "edges_per_cell": per}
+
+
+def graph(d, seed):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    col = torch.rand(n_cells, n_genes, device=dev, generator=g).topk(per, dim=1).indices.sort(dim=1).values.to(torch.int32).reshape(-1)
+    rp_x = torch.arange(0, n_cells * per + 1, per, dtype=torch.int32, device=dev)
+    val_x = torch.rand(n_cells * per, device=dev, generator=g) + 0.5
+    rp_t, col_t, val_t, perm_t = kernels.csr_transpose(rp_x, col, val_x, n_cells, n_genes)
+    rowptr, gcol, gval, eid = kernels.cellgene_graph_assemble(rp_x, col, val_x, rp_t, col_t, val_t, perm_t, n_cells, n_genes)
+    n_nodes = n_cells + n_genes
+    cid = torch.cat((torch.arange(n_genes, dtype=torch.int32), -torch.ones(n_cells, dtype=torch.int32))).to(dev)
+    fid = torch.cat((-torch.ones(n_genes, dtype=torch.int32), torch.arange(n_cells, dtype=torch.int32))).to(dev)
+    return CellGeneGraph(rowptr, gcol, gval, eid, n_nodes, {"cell_id": cid, "feat_id": fid, "features": torch.randn(n_nodes, d, device=dev, generator=g)})
+
+
+def timed(fn):
+    fn()  # warm-up epoch (allocator, caches)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+from dance_amd.modules.single_modality.clustering.graphsc import GraphSC  # noqa: E402
+cg = graph(50, 0)
+for bs in (128, 8192):
+    m = GraphSC(in_feats=50, n_clusters=10, device="cuda")
+    s = timed(lambda: m.fit(cg, epochs=1, batch_size=bs))
+    out[f"GraphSC.fit epoch batch={bs}"] = {"s": s, "batches": -(-n_cells // bs), "ms_per_batch": s / -(-n_cells // bs) * 1e3, "last_loss": m.losses[-1]}
+    print(bs, out[f"GraphSC.fit epoch batch={bs}"], file=sys.stderr, flush=True)
+del cg
+from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort  # noqa: E402
+cg = graph(400, 1)
+labels = torch.from_numpy(np.random.default_rng(0).integers(0, 12, n_cells))
+import tempfile  # noqa: E402
+for bs in (500, 65536):
+    with tempfile.TemporaryDirectory() as td:
+        m = ScDeepSort(400, 200, 1, "mouse", "Brain", batch_size=bs, device="cuda", save_root=td, verbose=False)
+        s = timed(lambda: m.fit(cg, labels, epochs=1, lr=1e-3, val_ratio=0.2))
+    nb = -(-int(n_cells * 0.8) // bs)
+    out[f"ScDeepSort.fit epoch (train + 2 eval passes) batch={bs}"] = {"s": s, "train_batches": nb, "ms_per_train_batch_incl_eval": s / nb * 1e3}
+    print(bs, s, file=sys.stderr, flush=True)
+print(json.dumps(out, indent=1))

@@ -214,3 +214,81 @@ def test_sage_mfma_matches_gather_at_scale(cuda_device):
     ref16 = kernels.sage_aggregate(*args, f16.float())
     got16 = kernels.sage_aggregate_mfma(*args, f16, 0, n_genes, out_dtype=torch.float32)
     assert float((got16 - ref16).abs().max() / ref16.abs().max()) < 1e-5
+
+
+def _cellgene_graph(n_cells, n_genes, per, d, seed):
+    from dance_amd import kernels
+    from dance_amd.cellgraph import CellGeneGraph
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    col = torch.rand(n_cells, n_genes, device=DEV, generator=g).topk(per, dim=1).indices.sort(dim=1).values.to(torch.int32).reshape(-1)
+    rp_x = torch.arange(0, n_cells * per + 1, per, dtype=torch.int32, device=DEV)
+    val_x = torch.rand(n_cells * per, device=DEV, generator=g) + 0.5
+    rp_t, col_t, val_t, perm_t = kernels.csr_transpose(rp_x, col, val_x, n_cells, n_genes)
+    rowptr, gcol, gval, eid = kernels.cellgene_graph_assemble(rp_x, col, val_x, rp_t, col_t, val_t, perm_t, n_cells, n_genes)
+    n_nodes = n_cells + n_genes
+    cid = torch.cat((torch.arange(n_genes, dtype=torch.int32), -torch.ones(n_cells, dtype=torch.int32))).to(DEV)
+    fid = torch.cat((-torch.ones(n_genes, dtype=torch.int32), torch.arange(n_cells, dtype=torch.int32))).to(DEV)
+    feats = torch.randn(n_nodes, d, device=DEV, generator=g)
+    return CellGeneGraph(rowptr, gcol, gval, eid, n_nodes, {"cell_id": cid, "feat_id": fid, "features": feats})
+
+
+@pytest.mark.parametrize("batch", [128, 8192])
+def test_graphsc_batch_full_size(cuda_device, batch):
+    """config 4: graph-sc on the 1M-cell x 2k-gene cell-gene graph (nnz 2e8, D = 50 -> 200 -> 300).  One mini-batch at the
+    reference's batch size (128, graphsc.py:155) and at the throughput batch (8192): the block of the full-neighbour sampler,
+    WeightedGraphConv on it (sampled destination rows against the float64 restatement of graphsc.py:428-484: block-local
+    D_out^-1/2, W before the weighted sum, D_in^-1/2, bias, ReLU), and the decoder loss of GraphSC.fit (fused, no B x B logits)
+    against the float64 BCE-with-logits of graphsc.py:208-216 on the same embedding."""
+    import torch.nn.functional as F
+    from dance_amd.cellgraph import DataLoader, MultiLayerFullNeighborSampler
+    from dance_amd.modules.single_modality.clustering import graphsc
+    n_cells, n_genes, per, d = 1_000_000, 2000, 200, 50
+    cg = _cellgene_graph(n_cells, n_genes, per, d, seed=4)
+    cg.ndata["order"] = cg.ndata["label"] = cg.ndata["feat_id"]
+    torch.manual_seed(0)
+    model = graphsc.GCNAE(agg="sum", activation="relu", in_feats=d, n_hidden=1, hidden_dim=200, hidden_1=300, hidden_2=0, dropout=0.0,
+                          n_layers=1, hidden_relu=False, hidden_bn=False).to(DEV)
+    seeds = np.arange(n_genes, n_genes + n_cells)
+    loader = DataLoader(cg, seeds, MultiLayerFullNeighborSampler(1), batch_size=batch, shuffle=True, drop_last=False,
+                        generator=torch.Generator().manual_seed(9), block_hook=graphsc._dst_edge_hook)
+    input_nodes, output_nodes, blocks = next(iter(loader))
+    blk = blocks[0]
+    b = blk.number_of_dst_nodes()
+    assert b == batch and blk.number_of_src_nodes() <= n_genes + batch and blk.number_of_edges() == batch * (per + 1)
+    x = blk.srcdata["features"]
+    h = model.layer1(blk, x, agg="sum")
+    # float64 restatement on sampled destination rows, from the block's own CSR
+    rp, col, val = blk.rowptr.cpu().numpy(), blk.col.cpu().numpy().astype(np.int64), blk.val.cpu().numpy().astype(np.float64)
+    out_deg = np.maximum(np.bincount(col, minlength=blk.number_of_src_nodes()), 1).astype(np.float64)
+    w64, b64 = model.layer1.weight.detach().double().cpu().numpy(), model.layer1.bias.detach().double().cpu().numpy()
+    x64 = x.double().cpu().numpy()
+    rows = np.random.default_rng(0).choice(b, 48, replace=False)
+    ref = []
+    for i in rows:
+        e = slice(rp[i], rp[i + 1])
+        src = col[e]
+        msg = ((x64[src] * out_deg[src, None]**-0.5) @ w64) * val[e, None]
+        ref.append(np.maximum(msg.sum(0) * max(rp[i + 1] - rp[i], 1)**-0.5 + b64, 0))
+    assert rel_err(h[torch.from_numpy(rows).to(DEV)].detach().cpu().numpy(), np.stack(ref)) < 1e-4
+    # decoder loss: fused path of GraphSC.fit vs float64 dense BCE-with-logits with pos_weight / norm of graphsc.py:208-216
+    _, emb = model.forward(blocks, x, decode=False)
+    order_e, cnt, ev = blk.hook_out
+    if ev is not None:
+        ev.synchronize()
+    n_listed = int(cnt)
+    sel = order_e[:n_listed]
+    us = blk.col[sel].to(torch.int64)
+    vs = torch.searchsorted(blk.rowptr, sel.to(blk.rowptr.dtype), right=True).to(torch.int64) - 1
+    assert n_listed == b  # cell-gene graph: the only edges among the batch's cells are their self loops
+    total = float(b)**2
+    pos_weight, norm = (total - n_listed) / n_listed, total / ((total - n_listed) * 2)
+    emb = emb.detach().requires_grad_(True)
+    loss = norm * graphsc.gram_listed_bce(emb, us, vs, pos_weight)
+    loss.backward()
+    z64 = emb.detach().double().requires_grad_(True)
+    adj = torch.zeros((b, b), dtype=torch.float64, device=DEV)
+    adj[us, vs] = 1.0
+    ref_loss = norm * F.binary_cross_entropy_with_logits(z64 @ z64.T, adj, pos_weight=torch.tensor(pos_weight, dtype=torch.float64, device=DEV))
+    ref_loss.backward()
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
+    assert rel_err(emb.grad.cpu().numpy(), z64.grad.cpu().numpy()) < 1e-4

@@ -137,12 +137,12 @@ def test_gram_sigmoid_kernel_vs_float64(cuda_device, n, d, ld):
     assert not kernels.gram_sigmoid_supported(n, 321)
 
 
-def test_gram_target_bce_matches_torch_dense(cuda_device):
+def test_gram_listed_bce_matches_torch_dense(cuda_device):
     """The decoder loss as a function of z without the logit matrix == F.binary_cross_entropy_with_logits(z z^T, adj,
-    pos_weight) (value and gradient wrt z), with repeated end points and zero-weight listed entries."""
+    pos_weight) (value and gradient wrt z), with repeated end points among the listed entries."""
     import torch.nn.functional as F
 
-    from dance_amd.modules.single_modality.clustering.graphsc import gram_target_bce
+    from dance_amd.modules.single_modality.clustering.graphsc import gram_listed_bce
     torch.manual_seed(0)
     b, d = 300, 40
     z = (torch.randn(b, d, device=cuda_device) * 0.5).requires_grad_(True)
@@ -150,14 +150,13 @@ def test_gram_target_bce_matches_torch_dense(cuda_device):
     u, v = torch.randint(0, b, (e, ), device=cuda_device), torch.randint(0, b, (e, ), device=cuda_device)
     key = torch.unique(u * b + v)                      # listed at most once
     u, v = key // b, key % b
-    m = (torch.rand(u.numel(), device=cuda_device) < 0.7).float()
     adj = torch.zeros(b, b, device=cuda_device, dtype=torch.float64)
-    adj[u, v] = m.double()
-    p = torch.tensor([7.5], device=cuda_device)
+    adj[u, v] = 1.0
+    p = 7.5
     zd = z.detach().double().requires_grad_(True)
-    ref = F.binary_cross_entropy_with_logits(zd @ zd.t(), adj, pos_weight=p.double())
+    ref = F.binary_cross_entropy_with_logits(zd @ zd.t(), adj, pos_weight=torch.tensor([p], device=cuda_device, dtype=torch.float64))
     gref, = torch.autograd.grad(ref * 3.0, zd)
-    got = gram_target_bce(z, u, v, m, p)
+    got = gram_listed_bce(z, u, v, p)
     ggot, = torch.autograd.grad(got * 3.0, z)
     assert abs(float(got) - float(ref)) < 2e-6 * abs(float(ref))
     assert rel_err(ggot.cpu().numpy(), gref.cpu().numpy()) < 1e-5
@@ -176,7 +175,8 @@ def test_graphsc_fit_dense_decoder_mode_vs_reference(cuda_device, gold, monkeypa
     assert np.allclose(m.losses, gold["gsc_mb_losses"], rtol=2e-4, atol=0)
 
 
-# dh_gram_listed_forward_f32 / _backward_f32: first run on the hardware in round 3 (profiles/r03a_gram_listed_tests.log), un-gated since
+# dh_gram_listed_forward_f32 / _backward_f32: first run on the hardware in round 3 (profiles/r03a_gram_listed_tests.log); since then
+# the listed-entry path of the default decoder mode
 def test_gram_listed_kernels_vs_float64(cuda_device):
     from dance_amd import kernels
     torch.manual_seed(3)
@@ -201,13 +201,3 @@ def test_gram_listed_kernels_vs_float64(cuda_device):
         ref.index_add_(0, vs.long(), ce * zz[us.long()])
         assert rel_err(dz.cpu().numpy(), (ref * 0.37).cpu().numpy()) < 1e-5
         assert torch.equal(dz, kernels.gram_listed_backward(z, o, us, vs, xe, p, scale))   # fixed order
-
-
-def test_graphsc_fit_fused_listed_mode_vs_reference(cuda_device, gold, monkeypatch):
-    from dance_amd.modules.single_modality.clustering import graphsc
-    monkeypatch.setattr(graphsc, "DECODER_MODE", "fused-listed")
-    g = _graph(gold)
-    m = _model(gold, "mb", "sum")
-    m.shuffle_generator = torch.Generator().manual_seed(123)
-    m.fit(g, epochs=3, lr=1e-2, batch_size=16)
-    assert np.allclose(m.losses, gold["gsc_mb_losses"], rtol=2e-4, atol=0)

@@ -6,10 +6,40 @@ import pytest
 import torch
 
 from conftest import rel_err
-from test_gpu_sage_lds import _bipartite
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
+
+
+def _bipartite(n_cells, n_genes, density, seed, layout):
+    """CSR rows = cells; returns rowptr, col, w, src_cell_id, dst_cell_id, gene_begin, n_src."""
+    rng = np.random.default_rng(seed)
+    x = (rng.random((n_cells, n_genes)) < density)
+    x[rng.integers(0, n_cells, 3)] = False          # cells with no gene edge at all
+    x[0] = True                                     # a cell expressing every gene
+    x[1] = False                                    # ... and a fully isolated one (no gene edge, no self loop)
+    gene_begin = 0 if layout == "graph" else n_cells
+    self_col = (n_genes + np.arange(n_cells)) if layout == "graph" else np.arange(n_cells)
+    has_self = rng.random(n_cells) < 0.9            # a few cells without self loop; one fully isolated
+    has_self[1] = False
+    deg = x.sum(1)
+    rows, cols = np.nonzero(x)
+    rowptr = np.zeros(n_cells + 1, np.int64)
+    rowptr[1:] = np.cumsum(deg + has_self)
+    col = np.empty(rowptr[-1], np.int32)
+    pos = rowptr[:-1].copy()
+    start = np.concatenate(([0], np.cumsum(deg)))
+    for i in range(n_cells):
+        g = cols[start[i]:start[i + 1]] + gene_begin
+        col[pos[i]:pos[i] + len(g)] = g
+        if has_self[i]:
+            col[pos[i] + len(g)] = self_col[i]
+    w = (rng.random(col.size) + 0.25).astype(np.float32)
+    n_src = n_genes + n_cells
+    cid = -np.ones(n_src, np.int32)
+    cid[gene_begin:gene_begin + n_genes] = rng.permutation(n_genes)  # alpha index of a gene row is its cell_id, not its position
+    dst_cid = -np.ones(n_cells, np.int32)
+    return rowptr.astype(np.int32), col, w, cid, dst_cid, gene_begin, n_src
 
 
 def _ref(rowptr, col, w, cid_src, cid_dst, alpha, h, n_genes):

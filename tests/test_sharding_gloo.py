@@ -321,6 +321,7 @@ def test_data_parallel_helpers(world):
         assert p.exitcode == 0
     per = -(-23 // world)
     assert all(r[1].size == per for r in res)                                     # every rank runs the same number of steps
+    assert all(np.unique(r[1]).size == per for r in res)                          # ... over DISTINCT seeds (dh_block_plan's contract)
     assert set(np.concatenate([r[1] for r in res])) == set(range(10, 33))         # every cell is somebody's
     for r in res[1:]:
         for a, b in zip(r[3], res[0][3]):
