@@ -59,6 +59,8 @@ def _declare(lib):
         "dh_exclusive_scan_i32": (c_int, [i64, P, P, P, c_size_t, P]),
         "dh_csr_row_normalize_f32": (c_int, [i64, P, P, P, P]),
         "dh_cellgene_graph_assemble": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, P, P, P, P]),
+        "dh_dense_nnz_count_f32": (c_int, [i64, i64, P, i64, P, P]),
+        "dh_dense_to_csr_f32": (c_int, [i64, i64, P, i64, P, P, P, P]),
         "dh_sddmm_csr_f32": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, P]),
         "dh_sddmm_csr_bf16": (c_int, [i64, i64, i64, P, P, P, P, i64, P, i64, P, P]),
         "dh_spmm_csr_bf16": (c_int, [i64, i64, i64, P, P, P, P, P, P, i64, P, i64, i32, P, i32, i32, P]),

@@ -168,3 +168,66 @@ extern "C" int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int6
                      out_val, out_eid);
   return dh::check_launch("dh_cellgene_graph_assemble");
 }
+
+// ---- dense -> CSR in row-major non-zero order: ``row, col = np.nonzero(feat)`` of cell_feature_graph.py:38 for an expression
+// matrix that is already resident on the device (the on-device preprocessing pipeline).  One wavefront per row,
+// 64 columns per step; the position of a non-zero inside its row is the popcount of the lower lanes' ballot bits, so the
+// column order of np.nonzero is preserved exactly.
+namespace {
+__global__ __launch_bounds__(256) void dense_nnz_count_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                              int32_t* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* x = X + row * ldx;
+  int n = 0;
+  for (int64_t c = lane; c < n_cols; c += 64) n += (x[c] != 0.f) ? 1 : 0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+  if (lane == 0) counts[row] = n;
+}
+
+__global__ __launch_bounds__(256) void dense_to_csr_fill_kernel(int64_t n_rows, int64_t n_cols, const float* __restrict__ X, int64_t ldx,
+                                                                const int32_t* __restrict__ rowptr, int32_t* __restrict__ col,
+                                                                float* __restrict__ val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const float* x = X + row * ldx;
+  int base = rowptr[row];
+  const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int64_t c0 = 0; c0 < n_cols; c0 += 64) {
+    const int64_t c = c0 + lane;
+    const float v = (c < n_cols) ? x[c] : 0.f;
+    const bool nz = v != 0.f;
+    const uint64_t mask = __ballot(nz);
+    if (nz) {
+      const int pos = base + __popcll(mask & below);
+      col[pos] = (int32_t)c;
+      val[pos] = v;
+    }
+    base += __popcll(mask);
+  }
+}
+}  // namespace
+
+extern "C" int dh_dense_nnz_count_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, int32_t* counts, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_dense_nnz_count_f32: negative size");
+  if (n_rows == 0) return DH_OK;
+  if (!counts || (n_cols > 0 && !X)) return dh::fail(DH_ERR_INVALID, "dh_dense_nnz_count_f32: null pointer");
+  if (ldx < n_cols) return dh::fail(DH_ERR_INVALID, "dh_dense_nnz_count_f32: leading dimension < n_cols");
+  hipLaunchKernelGGL(dense_nnz_count_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X, ldx,
+                     counts);
+  return dh::check_launch("dh_dense_nnz_count_f32");
+}
+
+extern "C" int dh_dense_to_csr_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const int32_t* rowptr, int32_t* col,
+                                   float* val, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_dense_to_csr_f32: negative size");
+  if (n_rows == 0 || n_cols == 0) return DH_OK;
+  if (!X || !rowptr || !col || !val) return dh::fail(DH_ERR_INVALID, "dh_dense_to_csr_f32: null pointer");
+  if (ldx < n_cols) return dh::fail(DH_ERR_INVALID, "dh_dense_to_csr_f32: leading dimension < n_cols");
+  hipLaunchKernelGGL(dense_to_csr_fill_kernel, dim3((unsigned)dh::ceil_div(n_rows, 4)), dim3(256), 0, dh::as_stream(stream), n_rows, n_cols, X,
+                     ldx, rowptr, col, val);
+  return dh::check_launch("dh_dense_to_csr_f32");
+}

@@ -13,6 +13,78 @@ import scipy.sparse as sp
 import torch
 
 
+class DeviceArray:
+    """A matrix that LIVES ON THE DEVICE, stored in an AnnData slot (``X``, ``obsm[...]``, ``varm[...]``, ``layers[...]``).
+
+    Device transforms write these instead of numpy arrays and read them back without a copy, so a chain
+    ``NormalizeTotal -> Log1P -> Scale -> WeightedFeaturePCA(device=...) -> CellFeatureGraph / NeighborGraph`` moves nothing
+    over PCIe between its steps.  Host code that reads the slot still works: ``np.asarray`` / indexing /
+    ``toarray()`` materialise a numpy copy on first use (cached; ``host_copies`` counts them).  Read-only by convention: a
+    transform replaces the slot, it does not write into the old array."""
+
+    host_copies = 0  # class-wide count of device -> host materialisations (the zero-round-trip tests watch it)
+
+    def __init__(self, tensor: torch.Tensor):
+        if tensor.dim() != 2:
+            raise ValueError("DeviceArray wraps a 2-d matrix")
+        self.tensor = tensor
+        self._host = None
+
+    @property
+    def shape(self):
+        return tuple(self.tensor.shape)
+
+    @property
+    def ndim(self):
+        return 2
+
+    @property
+    def dtype(self):
+        return np.dtype(str(self.tensor.dtype).replace("torch.", ""))
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def numpy(self) -> np.ndarray:
+        if self._host is None:
+            self._host = self.tensor.detach().cpu().numpy()
+            DeviceArray.host_copies += 1
+        return self._host
+
+    toarray = numpy  # Data.get_feature densifies through .toarray()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
+
+    @property
+    def T(self):
+        return self.numpy().T
+
+    def astype(self, dtype, **kw):
+        return self.numpy().astype(dtype, **kw)
+
+    def __repr__(self):
+        return f"DeviceArray(shape={self.shape}, dtype={self.tensor.dtype}, device={self.tensor.device})"
+
+
+def to_device_matrix(x, device) -> torch.Tensor:
+    """The fp32 device tensor of an AnnData slot value: a ``DeviceArray`` hands over its tensor (no copy when it already lives
+    on ``device``); numpy / scipy / DataFrame values are uploaded (one H2D)."""
+    if isinstance(x, DeviceArray):
+        return x.tensor.to(device=device, dtype=torch.float32)
+    if isinstance(x, torch.Tensor):
+        return x.to(device=device, dtype=torch.float32)
+    if sp.issparse(x):
+        x = x.toarray()
+    elif hasattr(x, "to_numpy"):
+        x = x.to_numpy()
+    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+
+
 class AnnDataLite:
     """Attribute container with AnnData's channel names (no views, no backing file)."""
 
@@ -197,6 +269,15 @@ class Data:
                     channel: Optional[str] = None, channel_type: Optional[str] = "obsm", mod: Optional[str] = None):
         feature = self._get_feature(channel, channel_type, mod)
         channel_type = channel_type or "obsm"
+        if isinstance(return_type, (torch.device, str)) and str(return_type).split(":")[0] in ("cuda", "cpu", "device"):
+            # return_type = a torch device (or "device" = cuda): the fp32 matrix on that device, without a host round trip when
+            # the slot already holds a DeviceArray; split rows are selected on the device
+            dev = "cuda" if return_type == "device" else return_type
+            t = to_device_matrix(feature, dev)
+            if split_name is not None and channel_type in ["X", "raw_X", "obs", "obsm", "obsp", "layers"]:
+                idx = torch.as_tensor([i for i in self.get_split_idx(split_name, error_on_miss=True) if i < t.shape[0]], device=t.device)
+                t = t[idx][:, idx] if channel_type == "obsp" else t[idx]
+            return t
         if return_type == "default":
             if split_name is not None:
                 raise ValueError(f"split_name is not supported when return_type is 'default', got {split_name=!r}")

@@ -544,6 +544,22 @@ def umap_connectivities(knn_idx: torch.Tensor, knn_dist: torch.Tensor):
     return (rp, col, val), (sigma, rho)
 
 
+def dense_to_csr(X: torch.Tensor):
+    """(rowptr, col, val) of the non-zeros of a dense device matrix in row-major order (np.nonzero order): dh_dense_nnz_count_f32,
+    dh_exclusive_scan_i32, dh_dense_to_csr_f32.  One host read (the total count, to size col / val)."""
+    lib = _lib_ready()
+    n, m = X.shape
+    counts = torch.empty(n, dtype=torch.int32, device=X.device)
+    _call("dense_nnz_count_f32", lib.dh_dense_nnz_count_f32, n, m, _dev(X, torch.float32, "X", 2), _ld(X), counts.data_ptr(), _stream())
+    rowptr = exclusive_scan(counts)
+    nnz = int(rowptr[-1])
+    col = torch.empty(nnz, dtype=torch.int32, device=X.device)
+    val = torch.empty(nnz, dtype=torch.float32, device=X.device)
+    _call("dense_to_csr_f32", lib.dh_dense_to_csr_f32, n, m, _dev(X, torch.float32, "X", 2), _ld(X), rowptr.data_ptr(), col.data_ptr(),
+          val.data_ptr(), _stream())
+    return rowptr, col, val
+
+
 def csr_row_normalize(rowptr: torch.Tensor, val: torch.Tensor) -> torch.Tensor:
     """out[e] = deg(row) * val[e] / sum(val[row])."""
     lib = _lib_ready()

@@ -264,6 +264,14 @@ DH_API int dh_cellgene_graph_assemble(int64_t n_cells, int64_t n_genes, int64_t 
                                const int32_t* perm_t, int32_t* out_rowptr, int32_t* out_col,
                                float* out_val, int32_t* out_eid, dh_stream_t stream);
 
+/* Dense expression matrix -> CSR in row-major non-zero order, i.e. ``row, col = np.nonzero(feat)`` of
+ * dance/transforms/graph/cell_feature_graph.py:38 for a matrix that is already on the device (on-device preprocessing
+ * pipeline): dh_dense_nnz_count_f32 gives the per-row counts, the caller scans them (dh_exclusive_scan_i32) and
+ * dh_dense_to_csr_f32 fills col / val (ascending columns inside a row).                                             */
+DH_API int dh_dense_nnz_count_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, int32_t* counts, dh_stream_t stream);
+DH_API int dh_dense_to_csr_f32(int64_t n_rows, int64_t n_cols, const float* X, int64_t ldx, const int32_t* rowptr,
+                        int32_t* col, float* val, dh_stream_t stream);
+
 /* ---- count-matrix normalisation feeding the graph builders (scanpy normalize_total / log1p / scale as the reference
  * pipelines call them: scdsc.py:113-131, sctag.py:119-139, transforms/normalize.py:531-679) --------------------------
  * dh_rowsum_masked_f32: out[r] = sum of X[r,c] over columns with colmask[c] != 0 (NULL = all), f64 accumulation;

@@ -343,6 +343,53 @@ def gram_listed_backward(Z, O, us, vs, xe, pos_weight, scale):
     return (dz * scale.double().reshape(())).float()
 
 
+def dense_to_csr(X):
+    m = sp.csr_matrix(X.numpy())
+    m.eliminate_zeros()
+    m.sort_indices()
+    t = torch.from_numpy
+    return t(m.indptr.astype(np.int32)), t(m.indices.astype(np.int32)), t(m.data.astype(np.float32))
+
+
+def rowsum_masked(X, colmask=None):
+    x = X.double() if colmask is None else X.double() * colmask.double()[None, :]
+    return x.sum(1).float()
+
+
+def col_any_gt(X, thresh):
+    return (X > thresh[:, None]).any(0).to(torch.uint8)
+
+
+def rowscale_log1p(X, divisor, *, log1p, base=None, inplace=False):
+    y = X if divisor is None else X / divisor[:, None]
+    if log1p:
+        y = torch.log1p(y)
+        if base is not None:
+            y = y / float(np.log(base))
+    if inplace:
+        X.copy_(y)
+        return X
+    return y
+
+
+def col_moments(X, rows_per_block=512):
+    return X.double().sum(0), (X.double()**2).sum(0)
+
+
+def col_standardize(X, mean, std, max_value=None, inplace=False):
+    y = X.double()
+    if mean is not None:
+        y = y - mean[None, :]
+    y = y / std[None, :]
+    if max_value is not None:
+        y = y.clamp(max=max_value) if mean is None else y.clamp(min=-max_value, max=max_value)
+    y = y.float()
+    if inplace:
+        X.copy_(y)
+        return X
+    return y
+
+
 def umap_connectivities(knn_idx, knn_dist):
     """(rowptr, col, val), (sigma, rho) of the fuzzy simplicial set — oracle.graphs restatement of umap-learn."""
     from oracle import graphs as og
@@ -353,7 +400,8 @@ def umap_connectivities(knn_idx, knn_dist):
 
 
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("umap_connectivities", "relu_mask_apply", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
+STAND_INS = ("umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
+             "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
              "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward")
