@@ -67,6 +67,11 @@ class DeviceArray:
     def astype(self, dtype, **kw):
         return self.numpy().astype(dtype, **kw)
 
+    def __getattr__(self, name):  # anything else an ndarray offers (sum, max, mean, reshape ...): on the materialised copy
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.numpy(), name)
+
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, dtype={self.tensor.dtype}, device={self.tensor.device})"
 
@@ -278,6 +283,8 @@ class Data:
                 idx = torch.as_tensor([i for i in self.get_split_idx(split_name, error_on_miss=True) if i < t.shape[0]], device=t.device)
                 t = t[idx][:, idx] if channel_type == "obsp" else t[idx]
             return t
+        if isinstance(feature, DeviceArray) and return_type != "default":
+            feature = feature.numpy()  # host consumers get a plain ndarray (materialised once)
         if return_type == "default":
             if split_name is not None:
                 raise ValueError(f"split_name is not supported when return_type is 'default', got {split_name=!r}")

@@ -120,6 +120,41 @@ class CSRGraph:
                              shape=(self.n_rows, self.n_cols))
 
 
+class LazyScipyCSR:
+    """What a graph transform leaves in ``obsp[...]`` next to the device graph: behaves as the scipy CSR matrix the reference
+    stores there (attribute access, indexing, ``toarray`` ... are forwarded), but the device -> host copy happens on first use —
+    a pipeline whose consumers take the device graph (``uns["<name>.hip"]``) never pays for it."""
+
+    host_copies = 0
+
+    def __init__(self, graph: "CSRGraph"):
+        object.__setattr__(self, "graph", graph)
+        object.__setattr__(self, "_m", None)
+
+    def materialize(self):
+        if self._m is None:
+            object.__setattr__(self, "_m", self.graph.to_scipy())
+            LazyScipyCSR.host_copies += 1
+        return self._m
+
+    @property
+    def shape(self):
+        return (self.graph.n_rows, self.graph.n_cols)
+
+    @property
+    def nnz(self):
+        return self.graph.nnz
+
+    def __getattr__(self, name):
+        return getattr(self.materialize(), name)
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __repr__(self):
+        return f"LazyScipyCSR(shape={self.shape}, nnz={self.nnz}, materialised={self._m is not None})"
+
+
 def locality_order(graph: CSRGraph, method: str = "rcm") -> torch.Tensor:
     """A renumbering ``perm[new] = old`` under which neighbouring rows of a kNN-like graph gather mostly nearby rows, so that
     the SpMM's random 512-byte row reads hit L2 / the Infinity Cache instead of HBM (SURVEY.md §8e: "cluster / kNN-BFS order";

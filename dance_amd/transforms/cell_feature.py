@@ -1,5 +1,6 @@
 """Cell / gene PCA features feeding the graph builders (dance/transforms/cell_feature.py:19-75,146-194).
-Host-side scikit-learn, as in the reference (GPU PCA is a later row)."""
+``device=None``: scikit-learn on the host, as in the reference.  ``device="cuda"``: the decomposition on the GPU
+(dance_amd/utils/pca.py) with inputs and outputs kept on the device as ``DeviceArray``s."""
 import numpy as np
 from sklearn.decomposition import PCA
 
@@ -34,6 +35,8 @@ class WeightedFeaturePCA(BaseTransform):
         self.device = device
 
     def __call__(self, data):
+        if self.device is not None:
+            return self._call_on_device(data)
         feat = data.get_x(self.split_name)  # cells x genes
         if self.feat_norm_mode is not None:
             feat = normalize(feat, mode=self.feat_norm_mode, axis=self.feat_norm_axis)
@@ -41,8 +44,6 @@ class WeightedFeaturePCA(BaseTransform):
             self.logger.warning(f"n_components={self.n_components} must be between 0 and "
                                 f"min(n_samples, n_features)={min(feat.shape)} with svd_solver='full'")
             self.n_components = min(feat.shape)
-        if self.device is not None:
-            return self._call_on_device(data, feat)
         gene_pca = PCA(n_components=self.n_components)
         gene_feat = gene_pca.fit_transform(feat.T)  # genes x components
         x = data.get_x()
@@ -57,16 +58,26 @@ class WeightedFeaturePCA(BaseTransform):
         return data
 
 
-    def _call_on_device(self, data, feat):
+    def _call_on_device(self, data):
+        """Same transform with every matrix on the device: X is read as a device tensor (no copy if an earlier device
+        transform left a DeviceArray there), the results are DeviceArrays in obsm / varm — nothing crosses PCIe."""
         import torch
 
         from .. import kernels
+        from ..data import DeviceArray
         from ..utils.pca import pca_scores, pca_scores_randomized
         if self.device_solver not in ("full", "randomized"):
             raise ValueError(f"device_solver must be 'full' or 'randomized', got {self.device_solver!r}")
         if self.save_info and self.device_solver == "full":
             raise NotImplementedError("save_info needs the cell-space components, which the exact device path never forms")
-        ft = torch.as_tensor(np.ascontiguousarray(feat.T, dtype=np.float32)).to(self.device)   # genes x cells
+        feat = data.get_x(self.split_name, return_type=self.device)  # cells x genes, on the device
+        if self.feat_norm_mode is not None:
+            feat = normalize(feat, mode=self.feat_norm_mode, axis=self.feat_norm_axis)
+        if self.n_components > min(feat.shape):
+            self.logger.warning(f"n_components={self.n_components} must be between 0 and "
+                                f"min(n_samples, n_features)={min(feat.shape)} with svd_solver='full'")
+            self.n_components = min(feat.shape)
+        ft = feat.t().contiguous()  # genes x cells
         if self.device_solver == "randomized":
             gene_feat, comps, var = pca_scores_randomized(ft, self.n_components, self.device_random_state)
             if self.save_info:
@@ -77,10 +88,10 @@ class WeightedFeaturePCA(BaseTransform):
                 data.data.uns["pca_explained_variance_ratio"] = (var / total).cpu().numpy()
         else:
             gene_feat, _, _ = pca_scores(ft, self.n_components)                                  # genes x components
-        x = torch.as_tensor(np.ascontiguousarray(data.get_x(), dtype=np.float32)).to(self.device)
+        x = data.get_x(return_type=self.device)
         cell_feat = kernels.gemm(normalize(x, mode="normalize", axis=1).contiguous(), gene_feat.contiguous())
-        data.data.obsm[self.out] = cell_feat.cpu().numpy()
-        data.data.varm[self.out] = gene_feat.cpu().numpy()
+        data.data.obsm[self.out] = DeviceArray(cell_feat)
+        data.data.varm[self.out] = DeviceArray(gene_feat.contiguous())
         return data
 
 
@@ -102,27 +113,28 @@ class CellPCA(BaseTransform):
         self.device_random_state = None
 
     def __call__(self, data):
-        feat = data.get_feature(return_type="numpy", channel=self.channel, channel_type="obsm" if self.channel else "X")
-        if self.n_components > min(feat.shape):
-            self.n_components = min(feat.shape)
         if self.device is not None:
-            import torch
-
+            from ..data import DeviceArray
             from ..utils.pca import pca_scores, pca_scores_randomized
-            xd = torch.as_tensor(np.ascontiguousarray(feat, dtype=np.float32)).to(self.device)
+            xd = data.get_feature(return_type=self.device, channel=self.channel, channel_type="obsm" if self.channel else "X").contiguous()
+            if self.n_components > min(xd.shape):
+                self.n_components = min(xd.shape)
             if self.svd_solver == "randomized":
                 scores, comps, _ = pca_scores_randomized(xd, self.n_components, self.device_random_state)
             elif self.svd_solver in ("auto", "full", "covariance_eigh"):
                 scores, comps, _ = pca_scores(xd, self.n_components)
             else:
                 raise ValueError(f"svd_solver={self.svd_solver!r} has no device path (use 'auto', 'full' or 'randomized')")
-            data.data.obsm[self.out] = scores.cpu().numpy()
+            data.data.obsm[self.out] = DeviceArray(scores.contiguous())
             if self.save_info:
                 if comps is None:
                     raise NotImplementedError("save_info with more features than samples: components are not formed on the device")
                 data.data.uns["pca_components"] = comps.cpu().numpy()
-                data.data.uns["pca_mean"] = feat.mean(0)
+                data.data.uns["pca_mean"] = xd.mean(0).cpu().numpy()
             return data
+        feat = data.get_feature(return_type="numpy", channel=self.channel, channel_type="obsm" if self.channel else "X")
+        if self.n_components > min(feat.shape):
+            self.n_components = min(feat.shape)
         pca = PCA(n_components=self.n_components, svd_solver=self.svd_solver)
         data.data.obsm[self.out] = pca.fit_transform(feat)
         if self.save_info:

@@ -33,17 +33,27 @@ class CellFeatureGraph(BaseTransform):
         self.device = device
 
     def __call__(self, data):
+        from ...data import DeviceArray
         feat = data.get_feature(return_type="default", channel_type="X", mod=self.mod)
-        x = sp.csr_matrix(feat, dtype=np.float32)
-        x.eliminate_zeros()  # np.nonzero semantics (:38)
-        x.sort_indices()  # row-major nonzero order
-        num_cells, num_feats = x.shape
-        self.logger.info(f"Number of nonzero entries: {x.nnz:,}")
-        self.logger.info(f"Nonzero rate = {x.nnz / num_cells / num_feats:.1%}")
         dev = self.device
-        rp_x = torch.from_numpy(x.indptr.astype(np.int32)).to(dev)
-        col_x = torch.from_numpy(x.indices.astype(np.int32)).to(dev)
-        val_x = torch.from_numpy(x.data.astype(np.float32)).to(dev)
+        if isinstance(feat, DeviceArray):
+            # the expression matrix is already on the device (on-device preprocessing): its non-zeros in np.nonzero order (:38)
+            # come from dh_dense_nnz_count_f32 / dh_dense_to_csr_f32 — no host copy of X
+            xd = feat.tensor.to(device=dev, dtype=torch.float32)
+            num_cells, num_feats = xd.shape
+            rp_x, col_x, val_x = kernels.dense_to_csr(xd)
+            nnz = int(col_x.numel())
+        else:
+            x = sp.csr_matrix(feat, dtype=np.float32)
+            x.eliminate_zeros()  # np.nonzero semantics (:38)
+            x.sort_indices()  # row-major nonzero order
+            num_cells, num_feats = x.shape
+            nnz = x.nnz
+            rp_x = torch.from_numpy(x.indptr.astype(np.int32)).to(dev)
+            col_x = torch.from_numpy(x.indices.astype(np.int32)).to(dev)
+            val_x = torch.from_numpy(x.data.astype(np.float32)).to(dev)
+        self.logger.info(f"Number of nonzero entries: {nnz:,}")
+        self.logger.info(f"Nonzero rate = {nnz / num_cells / num_feats:.1%}")
         rp_t, col_t, val_t, perm_t = kernels.csr_transpose(rp_x, col_x, val_x, num_cells, num_feats)
         if self.normalize_edges:  # in-degree rescale before the self loops are added (:62-68)
             val_x = kernels.csr_row_normalize(rp_x, val_x)  # cells' in-edges (gene -> cell)
@@ -52,11 +62,11 @@ class CellFeatureGraph(BaseTransform):
                                                                 num_cells, num_feats)
         cell_id = torch.cat((torch.arange(num_feats, dtype=torch.int32), -torch.ones(num_cells, dtype=torch.int32)))
         feat_id = torch.cat((-torch.ones(num_feats, dtype=torch.int32), torch.arange(num_cells, dtype=torch.int32)))
-        gene_feature = data.get_feature(return_type="torch", channel=self.gene_feature_channel, mod=self.mod, channel_type="varm")
-        cell_feature = data.get_feature(return_type="torch", channel=self.cell_feature_channel, mod=self.mod, channel_type="obsm")
-        features = torch.vstack((gene_feature, cell_feature)).to(torch.float32)
+        gene_feature = data.get_feature(return_type=dev, channel=self.gene_feature_channel, mod=self.mod, channel_type="varm")
+        cell_feature = data.get_feature(return_type=dev, channel=self.cell_feature_channel, mod=self.mod, channel_type="obsm")
+        features = torch.vstack((gene_feature, cell_feature))  # fp32 on the device (DeviceArray slots: no upload)
         g = CellGeneGraph(rowptr, col, val, eid, num_cells + num_feats,
-                          {"cell_id": cell_id.to(dev), "feat_id": feat_id.to(dev), "features": features.to(dev)})
+                          {"cell_id": cell_id.to(dev), "feat_id": feat_id.to(dev), "features": features})
         data.data.uns[self.out] = g
         return data
 

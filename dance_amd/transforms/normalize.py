@@ -13,9 +13,11 @@ third-party dependency that is not vendored, so the arithmetic below restates it
   scale           : per gene mean and unbiased variance in float64, std 0 -> 1, X = (X - mean) / std, clipped to +-max_value
                     (upper clip only without zero_center)
 
-The matrix is uploaded once, all passes run as HIP kernels (dh_rowsum_masked_f32, dh_col_any_gt_f32, dh_rowscale_log1p_f32,
-dh_col_moments_f32, dh_col_standardize_f32) and the result is written back to ``data.data.X`` (numpy, float32) — or kept on
-the device in ``data.data.uns[device_key]`` for a following device transform when ``keep_on_device`` is set.
+All passes run as HIP kernels (dh_rowsum_masked_f32, dh_col_any_gt_f32, dh_rowscale_log1p_f32, dh_col_moments_f32,
+dh_col_standardize_f32).  The result STAYS ON THE DEVICE: the slot (``X`` / layer / obsm) receives a ``dance_amd.data.DeviceArray``,
+which the next device transform reads without a copy and which turns into a numpy array only if host code asks for one — a chain
+of these transforms in front of the device PCA and the graph builders does no host round trip between its steps.  A host matrix
+(numpy / scipy) found in the slot is uploaded once, by the first transform of the chain.
 """
 from typing import Optional
 
@@ -24,17 +26,18 @@ import scipy.sparse as sp
 import torch
 
 from .. import kernels
+from ..data import DeviceArray, to_device_matrix
 from ..registry import register_preprocessor
 from ..utils.matrix import normalize
 from .base import BaseTransform
 
 
 def _upload(x, device) -> torch.Tensor:
-    if isinstance(x, torch.Tensor):
-        return x.to(device=device, dtype=torch.float32).contiguous()
-    if sp.issparse(x):
-        x = x.toarray()  # the reference densifies as well (normalize.py:622-625)
-    return torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(device)
+    """Device fp32 matrix of a slot value.  A DeviceArray is cloned (the kernels below run in place and the old slot value must
+    stay what it was); host values are uploaded (sparse ones densified, as the reference does at normalize.py:622-625)."""
+    if isinstance(x, DeviceArray):
+        return x.tensor.to(device=device, dtype=torch.float32).clone(memory_format=torch.contiguous_format)
+    return to_device_matrix(x, device).contiguous()
 
 
 def normalize_total(X: torch.Tensor, target_sum: Optional[float] = None, *, exclude_highly_expressed: bool = False,
@@ -85,7 +88,7 @@ class _DeviceMatrixTransform(BaseTransform):
         return _upload(x, self.device)
 
     def _write(self, data, x: torch.Tensor):
-        arr = x.cpu().numpy()
+        arr = DeviceArray(x)  # stays on the device; numpy on demand
         ad = data.data
         if self.layer is not None:
             ad.layers[self.layer] = arr
@@ -147,7 +150,7 @@ class NormalizeTotalLog1P(BaseTransform):
     def __call__(self, data):
         x = _upload(data.data.X, self.device)
         x, _ = normalize_total(x, self.target_sum, exclude_highly_expressed=True, max_fraction=self.max_fraction, inplace=True)
-        data.data.X = log1p(x, self.base, inplace=True).cpu().numpy()
+        data.data.X = DeviceArray(log1p(x, self.base, inplace=True))
         data.data.uns["log1p"] = {"base": self.base}
         return data
 

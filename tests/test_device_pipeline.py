@@ -1,0 +1,93 @@
+"""The on-device preprocessing pipeline: normalisation -> scaling -> gene PCA / cell features -> CellFeatureGraph and
+NeighborGraph with every intermediate kept on the device as a ``DeviceArray`` — ZERO device->host materialisations and ZERO
+host->device uploads after the first one — and results equal to the host path's (same arithmetic, numpy slots).
+CPU: kernel stand-ins (tests/cpu_ops.py) on CPU tensors; the GPU twin (test_gpu_transforms.py) runs the same checks on the kernels."""
+import numpy as np
+import pytest
+import torch
+
+import cpu_ops
+from conftest import rel_err
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    from dance_amd import kernels
+    for name in cpu_ops.STAND_INS:
+        monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
+    return kernels
+
+
+def _counts(n_cells, n_genes, seed):
+    rng = np.random.default_rng(seed)
+    x = ((rng.random((n_cells, n_genes)) < 0.3) * rng.integers(1, 9, (n_cells, n_genes))).astype(np.float32)
+    x[np.arange(n_cells), rng.integers(0, n_genes, n_cells)] += 1  # no empty cell
+    return x
+
+
+def run_pipeline(device, device_in: bool):
+    from dance_amd import data as dd
+    from dance_amd.graph import LazyScipyCSR
+    from dance_amd.transforms import CellPCA, Compose, WeightedFeaturePCA
+    from dance_amd.transforms.graph import CellFeatureGraph, NeighborGraph
+    from dance_amd.transforms.normalize import Log1P, NormalizeTotal
+    x = _counts(240, 60, 0)
+    slot = dd.DeviceArray(torch.from_numpy(x.copy()).to(device)) if device_in else x.copy()
+    data = dd.Data(dd.AnnDataLite(slot), train_size=-1, val_size=0, test_size=0)
+    data.set_config(feature_channel=None, feature_channel_type="X")
+    uploads = {"n": 0}
+    real = dd.to_device_matrix
+
+    def counting(v, dev):
+        if not isinstance(v, (dd.DeviceArray, torch.Tensor)):
+            uploads["n"] += 1
+        return real(v, dev)
+
+    dd.to_device_matrix = counting
+    import dance_amd.transforms.normalize as nz
+    nz_real, nz.to_device_matrix = nz.to_device_matrix, counting
+    copies0, lazy0 = dd.DeviceArray.host_copies, LazyScipyCSR.host_copies
+    try:
+        pipe = Compose(NormalizeTotal(target_sum=1e4, device=device), Log1P(device=device),
+                       WeightedFeaturePCA(n_components=12, split_name="train", device=device),
+                       CellFeatureGraph(cell_feature_channel="WeightedFeaturePCA", device=device),
+                       CellPCA(n_components=8, device=device), NeighborGraph(n_neighbors=10, device=device))
+        pipe(data)
+        stats = dict(uploads=uploads["n"], host_copies=dd.DeviceArray.host_copies - copies0, lazy_graph_copies=LazyScipyCSR.host_copies - lazy0)
+    finally:
+        dd.to_device_matrix, nz.to_device_matrix = real, nz_real
+    return data, stats
+
+
+def check_pipeline(device):
+    from dance_amd.data import DeviceArray
+    from dance_amd.graph import LazyScipyCSR
+    d_dev, st_dev = run_pipeline(device, device_in=True)
+    assert st_dev == dict(uploads=0, host_copies=0, lazy_graph_copies=0), st_dev  # steady state: nothing crosses PCIe
+    ad = d_dev.data
+    assert all(isinstance(v, DeviceArray) for v in (ad.X, ad.obsm["WeightedFeaturePCA"], ad.varm["WeightedFeaturePCA"], ad.obsm["CellPCA"]))
+    assert isinstance(ad.obsp["NeighborGraph"], LazyScipyCSR)
+    d_host, st_host = run_pipeline(device, device_in=False)
+    assert st_host["uploads"] == 1 and st_host["host_copies"] == 0  # a host matrix is uploaded once, by the first transform
+    # same results whichever way the matrix came in
+    assert np.array_equal(np.asarray(ad.X), np.asarray(d_host.data.X))
+    for k in ("WeightedFeaturePCA", "CellPCA"):
+        assert rel_err(np.asarray(ad.obsm[k]), np.asarray(d_host.data.obsm[k])) < 1e-6, k
+    g_dev, g_host = ad.uns["CellFeatureGraph"], d_host.data.uns["CellFeatureGraph"]
+    assert torch.equal(g_dev.rowptr, g_host.rowptr) and torch.equal(g_dev.col, g_host.col) and torch.equal(g_dev.val, g_host.val)
+    assert torch.equal(g_dev.eid, g_host.eid)
+    a, b = ad.obsp["NeighborGraph"], d_host.data.obsp["NeighborGraph"]
+    assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.allclose(a.data, b.data, rtol=1e-6)
+    # ... and the lazy host views behave as the arrays host code expects
+    assert LazyScipyCSR.host_copies >= 1 and a.toarray().shape == (240, 240)
+    x_host = d_dev.get_feature(channel_type="X", return_type="numpy", split_name="train")
+    assert isinstance(x_host, np.ndarray) and x_host.shape == (240, 60) and float(ad.X.max()) == float(x_host.max())
+    # the device normalisation equals the oracle restatement of scanpy's
+    from oracle import normalize as on
+    out = on.normalize_total(_counts(240, 60, 0), 1e4, exclude_highly_expressed=True, max_fraction=0.05)
+    ref = np.log1p(out[0] if isinstance(out, tuple) else out)
+    assert rel_err(np.asarray(ad.X), ref) < 1e-6
+
+
+def test_on_device_pipeline_has_no_host_round_trips(cpu_kernels):
+    check_pipeline("cpu")

@@ -218,3 +218,28 @@ def test_device_randomized_pca_matches_sklearn(cuda_device):
     same_up_to_sign(d_dev.data.obsm["CellPCA"], PCA(n_components=10, svd_solver="randomized", random_state=5).fit_transform(x), 5e-4)
     with pytest.raises(ValueError):
         CellPCA(10, svd_solver="arpack", device="cuda")(d_host)
+
+
+def test_on_device_pipeline_has_no_host_round_trips_gpu(cuda_device):
+    """(f)3 on the kernels: NormalizeTotal -> Log1P -> WeightedFeaturePCA(device) -> CellFeatureGraph -> CellPCA(device) ->
+    NeighborGraph with DeviceArray slots: zero uploads, zero device->host copies, results equal to the host-slot path
+    (dh_dense_nnz_count_f32 / dh_dense_to_csr_f32 give the np.nonzero edge order)."""
+    import test_device_pipeline as tdp
+    tdp.check_pipeline("cuda")
+
+
+def test_dense_to_csr_matches_numpy_nonzero(cuda_device):
+    from dance_amd import kernels
+    rng = np.random.default_rng(5)
+    for n, m, dens in ((1, 1, 1.0), (7, 63, 0.5), (130, 64, 0.1), (257, 2000, 0.1), (33, 129, 0.0)):
+        x = ((rng.random((n, m)) < dens) * rng.standard_normal((n, m))).astype(np.float32)
+        xt = torch.from_numpy(x).to(cuda_device)
+        rp, col, val = kernels.dense_to_csr(xt)
+        r, c = np.nonzero(x)
+        assert np.array_equal(col.cpu().numpy(), c) and np.array_equal(val.cpu().numpy(), x[r, c])
+        assert np.array_equal(rp.cpu().numpy(), np.concatenate(([0], np.cumsum(np.bincount(r, minlength=n)))))
+        # strided rows (a column window of a wider matrix)
+        if m > 8:
+            rp2, col2, val2 = kernels.dense_to_csr(xt[:, 3:m - 2])
+            r2, c2 = np.nonzero(x[:, 3:m - 2])
+            assert np.array_equal(col2.cpu().numpy(), c2) and np.array_equal(val2.cpu().numpy(), x[:, 3:m - 2][r2, c2])
