@@ -102,6 +102,7 @@ class AnnDataLite:
         self.obsm, self.varm = dict(obsm or {}), dict(varm or {})
         self.obsp, self.varp = dict(obsp or {}), dict(varp or {})
         self.layers, self.uns = dict(layers or {}), dict(uns or {})
+        self.raw = None  # set by SaveRaw: a frozen copy of X / var (AnnData.raw)
 
     @property
     def shape(self):
@@ -114,6 +115,39 @@ class AnnDataLite:
     @property
     def n_vars(self):
         return self.X.shape[1]
+
+    # ---- in-place subsetting (AnnData._inplace_subset_var / _inplace_subset_obs): every aligned slot follows ---------------
+    @staticmethod
+    def _take(v, idx, axis):
+        if isinstance(v, DeviceArray):
+            t = v.tensor
+            i = torch.as_tensor(idx, device=t.device)
+            return DeviceArray(t.index_select(axis, i).contiguous())
+        if sp.issparse(v):
+            return v.tocsr()[idx] if axis == 0 else v.tocsc()[:, idx].tocsr()
+        if hasattr(v, "iloc"):
+            return v.iloc[idx]
+        v = np.asarray(v) if not isinstance(v, (np.ndarray, torch.Tensor)) else v
+        return v[idx] if axis == 0 else v[:, idx]
+
+    def _inplace_subset_var(self, mask):
+        idx = np.flatnonzero(np.asarray(mask, dtype=bool))
+        self.X = self._take(self.X, idx, 1)
+        self.var = self.var.iloc[idx]
+        self.varm = {k: self._take(v, idx, 0) for k, v in self.varm.items()}
+        self.varp = {k: self._take(self._take(v, idx, 0), idx, 1) for k, v in self.varp.items()}
+        self.layers = {k: self._take(v, idx, 1) for k, v in self.layers.items()}
+
+    def _inplace_subset_obs(self, mask):
+        idx = np.flatnonzero(np.asarray(mask, dtype=bool))
+        if self.raw is not None:  # AnnData.raw follows the observations (not the variables)
+            self.raw.X = self._take(self.raw.X, idx, 0)
+            self.raw.shape = tuple(self.raw.X.shape)
+        self.X = self._take(self.X, idx, 0)
+        self.obs = self.obs.iloc[idx]
+        self.obsm = {k: self._take(v, idx, 0) for k, v in self.obsm.items()}
+        self.obsp = {k: self._take(self._take(v, idx, 0), idx, 1) for k, v in self.obsp.items()}
+        self.layers = {k: self._take(v, idx, 0) for k, v in self.layers.items()}
 
     def __repr__(self):
         return (f"AnnDataLite object with n_obs x n_vars = {self.n_obs} x {self.n_vars}\n"
@@ -173,6 +207,19 @@ class Data:
         for i, name in enumerate(("train", "val", "test")):
             if edges[i + 1] - edges[i] > 0:
                 self._split_idx_dict[name] = list(range(edges[i], edges[i + 1]))
+
+    def filter_by_mask(self, mask, update_splits: bool = True):
+        """Keep the cells where ``mask`` is True (dance/data/base.py:694-790); split indices are remapped to the new positions."""
+        mask = np.asarray(mask, dtype=bool)
+        if mask.ndim != 1 or len(mask) != self.shape[0]:
+            raise ValueError(f"Mask length ({len(mask)}) must match number of cells ({self.shape[0]})")
+        if mask.all():
+            return self
+        self._data._inplace_subset_obs(mask)
+        if update_splits:
+            new_pos = np.cumsum(mask) - 1
+            self._split_idx_dict = {k: [int(new_pos[i]) for i in v if mask[i]] for k, v in self._split_idx_dict.items()}
+        return self
 
     # ---- basic views ---------------------------------------------------------------------------------------
     @property

@@ -269,17 +269,29 @@ class GraphSC(BaseClusteringMethod):
     @staticmethod
     def preprocessing_pipeline(n_top_genes: int = 3000, normalize_weights: str = "log_per_cell", n_components: int = 50,
                                normalize_edges: bool = False, log_level="INFO"):
-        """Graph part of the reference pipeline (:134-146).  The scanpy gene filtering / HVG / normalisation steps
-        (:111-131) are CPU count-matrix preprocessing outside the hot path: feed a matrix that
-        already went through them."""
-        if normalize_weights not in ("log_per_cell", "per_cell", "none"):
+        """graphsc.py:110-146 with every step on the device (DeviceArray slots): filter genes / cells, normalize_total, log1p,
+        cell_ranger HVG (n_top_genes), the optional second log1p + per-cell normalisation of the edge weights, then the PCA
+        cell-gene graph.  ``PCACellFeatureGraph.pca_device`` decides where the gene PCA runs (host sklearn by default)."""
+        from ....transforms import FilterCellsScanpy, FilterGenesScanpy, HighlyVariableGenesLogarithmizedByTopGenes, Log1P, NormalizeTotal
+        transforms = [
+            FilterGenesScanpy(min_counts=3),
+            FilterCellsScanpy(min_counts=1),
+            NormalizeTotal(max_fraction=1.0),
+            Log1P(),
+            HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=n_top_genes, flavor="cell_ranger", subset=True),
+        ]
+        if normalize_weights == "log_per_cell":
+            transforms.extend([Log1P(), NormalizeTotal(target_sum=1, max_fraction=1.0)])
+        elif normalize_weights == "per_cell":
+            transforms.append(NormalizeTotal(target_sum=1, max_fraction=1.0))
+        elif normalize_weights != "none":
             raise ValueError(f"Unknown normalization option {normalize_weights!r}."
                              "Available options are: 'none', 'log_per_cell', 'per_cell'")
-        return Compose(
+        transforms.extend([
             PCACellFeatureGraph(n_components=n_components, normalize_edges=normalize_edges, feat_norm_mode="standardize"),
             SetConfig({"feature_channel": "CellFeatureGraph", "feature_channel_type": "uns", "label_channel": "Group"}),
-            log_level=log_level,
-        )
+        ])
+        return Compose(*transforms, log_level=log_level)
 
     def fit(self, g, y: Optional[Any] = None, *, epochs: int = 100, lr: float = 1e-5, batch_size: int = 128,
             show_epoch_ari: bool = False, eval_epoch: bool = False):

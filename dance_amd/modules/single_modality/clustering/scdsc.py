@@ -166,9 +166,24 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
 
     @staticmethod
     def preprocessing_pipeline(n_top_genes: int = 2000, n_neighbors: int = 50, log_level="INFO"):
-        """Graph part of scdsc.py:113-138 (the scanpy filtering / normalisation / HVG steps are CPU count-matrix preprocessing
-        outside the hot path: feed a matrix that already went through them, with ``raw_X`` and ``n_counts`` set)."""
+        """scdsc.py:113-138, every step on the device (DeviceArray slots, no host round trip between steps): filter genes / cells,
+        per-cell normalisation to the median count (``sc.pp.normalize_per_cell``: = normalize_total without the highly-expressed
+        exclusion, ``n_counts`` recorded), log1p, cell_ranger HVG, second filter, SaveRaw, normalize_total, log1p, scale, and the
+        correlation kNN graph on the scaled matrix."""
+        from ....transforms import (FilterCellsScanpy, FilterGenesScanpy, HighlyVariableGenesLogarithmizedByTopGenes, Log1P, NormalizeTotal,
+                                    SaveRaw, Scale)
         return Compose(
+            FilterGenesScanpy(min_counts=3),
+            FilterCellsScanpy(min_counts=1),
+            NormalizeTotal(max_fraction=1.0, key_added="n_counts"),
+            Log1P(),
+            HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=n_top_genes, flavor="cell_ranger", subset=True),
+            FilterGenesScanpy(min_counts=1),
+            FilterCellsScanpy(min_counts=1),
+            SaveRaw(),
+            NormalizeTotal(max_fraction=1.0),
+            Log1P(),
+            Scale(),
             NeighborGraph(n_neighbors=n_neighbors, metric="correlation", channel=None),
             SetConfig({"feature_channel": ["NeighborGraph", None, None, "n_counts"],
                        "feature_channel_type": ["obsp", "X", "raw_X", "obs"], "label_channel": "Group"}),

@@ -1,7 +1,10 @@
 from .base import BaseTransform
 from .cell_feature import CellPCA, WeightedFeaturePCA
-from .misc import Compose, SetConfig
+from .filter import (FilterCellsScanpy, FilterGenesScanpy, HighlyVariableGenesLogarithmizedByMeanAndDisp,
+                     HighlyVariableGenesLogarithmizedByTopGenes)
+from .misc import Compose, SaveRaw, SetConfig
 from .normalize import ColumnSumNormalize, Log1P, NormalizeTotal, NormalizeTotalLog1P, Scale
 
-__all__ = ["BaseTransform", "CellPCA", "WeightedFeaturePCA", "Compose", "SetConfig", "ColumnSumNormalize", "Log1P", "NormalizeTotal",
-           "NormalizeTotalLog1P", "Scale"]
+__all__ = ["BaseTransform", "CellPCA", "WeightedFeaturePCA", "Compose", "SaveRaw", "SetConfig", "ColumnSumNormalize", "Log1P", "NormalizeTotal",
+           "NormalizeTotalLog1P", "Scale", "FilterCellsScanpy", "FilterGenesScanpy", "HighlyVariableGenesLogarithmizedByMeanAndDisp",
+           "HighlyVariableGenesLogarithmizedByTopGenes"]

@@ -1,0 +1,255 @@
+"""Gene / cell filtering and highly-variable-gene selection in front of the graph builders, on the device: the
+steps the clustering pipelines run through scanpy before they normalise (graphsc.py:111-119, scdsc.py:113-121) —
+``sc.pp.filter_genes`` / ``sc.pp.filter_cells`` (here ``FilterGenesScanpy`` / ``FilterCellsScanpy``, dance/transforms/filter.py:55-280)
+and ``sc.pp.highly_variable_genes`` with the dispersion flavours (``HighlyVariableGenesLogarithmizedByTopGenes`` /
+``...ByMeanAndDisp``, filter.py:1219-1372).
+
+The per-gene / per-cell statistics (sums, counts of expressing cells, means and variances) are reductions over the N x G matrix and
+run on the device, on a ``DeviceArray`` slot without a host copy; what is left — quantile bins, medians and a top-k over the G-long
+statistic vectors — is host numpy / pandas on kilobytes.  Subsetting keeps the matrix on the device (index_select).
+
+scanpy (pin 1.10.1) is not vendored and not installable here: the selection rules restate its published algorithm
+(scanpy/preprocessing/_simple.py filter_genes / filter_cells, _highly_variable_genes.py _highly_variable_genes_single_batch) —
+parity unpinned by reference output, pinned to oracle/normalize.py's numpy restatement and hand-computed cases.
+"""
+from typing import Optional, Union
+
+import numpy as np
+import torch
+
+from ..data import DeviceArray, to_device_matrix
+from ..registry import register_preprocessor
+from .base import BaseTransform
+
+
+def get_count(count_or_ratio: Optional[Union[float, int]], total: int) -> Optional[int]:
+    """A count, or a ratio of ``total`` turned into one (filter.py:28-52)."""
+    if count_or_ratio is None:
+        return None
+    if isinstance(count_or_ratio, float):
+        if count_or_ratio > 1.:
+            raise ValueError(f"{count_or_ratio=} is greater than 1. Ratio cannot be greater than 1.")
+        return int(count_or_ratio * total)
+    if isinstance(count_or_ratio, int):
+        if count_or_ratio > total:
+            raise ValueError(f"{count_or_ratio=} is greater than {total=}")
+        return count_or_ratio
+    raise TypeError(f"count_or_ratio must be either float or int, got {type(count_or_ratio)}")
+
+
+def filter_mask(x: torch.Tensor, axis: int, *, min_counts=None, min_number=None, max_counts=None, max_number=None):
+    """scanpy's filter_genes (axis 0: per gene over cells) / filter_cells (axis 1): exactly one threshold; ``*_counts`` compare the
+    sum of the values, ``*_number`` the number of non-zero... positive entries.  Returns (keep mask, the statistic) as host arrays."""
+    given = [v is not None for v in (min_counts, min_number, max_counts, max_number)]
+    if sum(given) != 1:
+        raise ValueError("Only provide one of the optional parameters `min_counts`, `min_genes`/`min_cells`, `max_counts`, "
+                         "`max_genes`/`max_cells` per call.")
+    if min_counts is not None or max_counts is not None:
+        stat = x.sum(dim=axis, dtype=torch.float64).to(torch.float32)  # float32 sums like numpy's on a float32 matrix, to fp32 rounding
+    else:
+        stat = (x > 0).sum(dim=axis)
+    lo = min_counts if min_counts is not None else min_number
+    hi = max_counts if max_counts is not None else max_number
+    keep = stat >= lo if lo is not None else stat <= hi
+    return keep.cpu().numpy(), stat.cpu().numpy()
+
+
+class FilterScanpy(BaseTransform):
+    """Scanpy filtering transformation with additional options (ratios instead of counts)."""
+
+    _FILTER_TARGET = None
+
+    def __init__(self, min_counts=None, min_genes_or_cells=None, max_counts=None, max_genes_or_cells=None, split_name: Optional[str] = None,
+                 channel: Optional[str] = None, channel_type: Optional[str] = "X", key_n_counts: Optional[str] = None,
+                 key_n_genes_or_cells: Optional[str] = None, inplace=True, device="cuda", **kwargs):
+        super().__init__(**kwargs)
+        self.min_counts, self.min_genes_or_cells = min_counts, min_genes_or_cells
+        self.max_counts, self.max_genes_or_cells = max_counts, max_genes_or_cells
+        self.split_name, self.channel, self.channel_type = split_name, channel, channel_type
+        self.key_n_counts, self.key_n_genes_or_cells, self.inplace, self.device = key_n_counts, key_n_genes_or_cells, inplace, device
+        if self._FILTER_TARGET is None:
+            raise NotImplementedError("Use FilterCellsScanpy or FilterGenesScanpy instead")
+
+    def prepCounts(self, x: torch.Tensor, axis: int):
+        """Thresholds given as a ratio in (0, 1) are percentiles of the per-gene / per-cell sums (filter.py:147-163)."""
+        is_ratio = lambda v: isinstance(v, float) and 0 < v < 1
+        if not (is_ratio(self.min_counts) or is_ratio(self.max_counts)):
+            return self.min_counts, self.max_counts
+        n_counts = x.sum(dim=axis, dtype=torch.float64).cpu().numpy()
+        if isinstance(self.min_counts, float) and 0 <= self.min_counts <= 1:
+            return np.percentile(n_counts, self.min_counts * 100), None
+        return None, np.percentile(n_counts, self.max_counts * 100)
+
+    def __call__(self, data):
+        x = data.get_feature(return_type=self.device, split_name=self.split_name, channel=self.channel, channel_type=self.channel_type)
+        total_cells, total_features = x.shape
+        genes = self._FILTER_TARGET == "genes"
+        axis = 0 if genes else 1
+        min_counts, max_counts = self.prepCounts(x, axis)
+        basis = total_cells if genes else total_features
+        keep, _ = filter_mask(x, axis, min_counts=min_counts, max_counts=max_counts, min_number=get_count(self.min_genes_or_cells, basis),
+                              max_number=get_count(self.max_genes_or_cells, basis))
+        frame = data.data.var if genes else data.data.obs
+        if self.key_n_counts is not None:
+            frame[self.key_n_counts] = x.sum(dim=axis, dtype=torch.float64).to(torch.float32).cpu().numpy()
+            if self.key_n_genes_or_cells is not None:
+                frame[self.key_n_genes_or_cells] = (x > 0).sum(dim=axis).cpu().numpy()
+        if not keep.all():
+            self.logger.info(f"Subsetting {self._FILTER_TARGET} ({int((~keep).sum()):,} removed) due to {self}")
+            if self.inplace:
+                if genes:
+                    data.data._inplace_subset_var(keep)
+                else:
+                    data.filter_by_mask(keep)
+            else:
+                kept = x[:, torch.as_tensor(np.flatnonzero(keep), device=x.device)] if genes else None
+                if genes:
+                    data.data.obsm[self.out] = DeviceArray(kept.contiguous())
+                else:  # the reference stores x[:, subset].T here as well (filter.py:143); cells and genes swapped, kept as written
+                    data.data.varm[self.out] = DeviceArray(x[:, torch.as_tensor(np.flatnonzero(keep), device=x.device)].t().contiguous())
+        return data
+
+
+@register_preprocessor("filter", "cell")
+class FilterCellsScanpy(FilterScanpy):
+    _DISPLAY_ATTRS = ("min_counts", "min_genes", "max_counts", "max_genes", "split_name")
+    _FILTER_TARGET = "cells"
+
+    def __init__(self, min_counts=None, min_genes=None, max_counts=None, max_genes=None, split_name: Optional[str] = None,
+                 channel: Optional[str] = None, channel_type: Optional[str] = "X", key_n_counts: Optional[str] = None,
+                 key_n_genes: Optional[str] = None, inplace=True, **kwargs):
+        super().__init__(min_counts, min_genes, max_counts, max_genes, split_name, channel, channel_type, key_n_counts, key_n_genes, inplace,
+                         **kwargs)
+        self.min_genes, self.max_genes = min_genes, max_genes
+
+
+@register_preprocessor("filter", "gene")
+class FilterGenesScanpy(FilterScanpy):
+    _DISPLAY_ATTRS = ("min_counts", "min_cells", "max_counts", "max_cells", "split_name")
+    _FILTER_TARGET = "genes"
+
+    def __init__(self, min_counts=None, min_cells=None, max_counts=None, max_cells=None, split_name: Optional[str] = None,
+                 channel: Optional[str] = None, channel_type: Optional[str] = "X", key_n_counts: Optional[str] = None,
+                 key_n_cells: Optional[str] = None, inplace=True, **kwargs):
+        super().__init__(min_counts, min_cells, max_counts, max_cells, split_name, channel, channel_type, key_n_counts, key_n_cells, inplace,
+                         **kwargs)
+        self.min_cells, self.max_cells = min_cells, max_cells
+
+
+def gene_mean_var(x: torch.Tensor, *, undo_log: bool, base: Optional[float] = None):
+    """Per-gene mean and unbiased variance (float64 accumulation) of x, or of expm1(x) for the "seurat" flavour — in row chunks, so
+    the un-logged matrix never exists as a whole."""
+    n, g = x.shape
+    s = torch.zeros(g, dtype=torch.float64, device=x.device)
+    q = torch.zeros(g, dtype=torch.float64, device=x.device)
+    step = max(1, (1 << 27) // max(g, 1))
+    for lo in range(0, n, step):
+        c = x[lo:lo + step]
+        if undo_log:
+            c = torch.expm1(c * float(np.log(base)) if base is not None else c)
+        c = c.double()
+        s += c.sum(0)
+        q += (c * c).sum(0)
+    mean = s / n
+    var = (q / n - mean * mean) * (n / max(n - 1, 1))
+    return mean.cpu().numpy(), var.cpu().numpy()
+
+
+def dispersion_hvg(mean: np.ndarray, var: np.ndarray, *, flavor: str = "seurat", n_top_genes: Optional[int] = None, n_bins: int = 20,
+                   min_mean: float = 0.0125, max_mean: float = 3, min_disp: float = 0.5, max_disp: float = np.inf):
+    """scanpy's dispersion-based selection from per-gene (mean, variance): returns (highly_variable mask, means, dispersions,
+    dispersions_norm) as scanpy writes them to ``.var``.  [3P-memory: scanpy 1.10.1 _highly_variable_genes_single_batch]"""
+    import pandas as pd
+    if flavor not in ("seurat", "cell_ranger"):
+        raise ValueError('`flavor` needs to be "seurat" or "cell_ranger" (the dispersion-based flavours)')
+    mean = mean.astype(np.float64).copy()
+    mean[mean == 0] = 1e-12
+    dispersion = var / mean
+    if flavor == "seurat":
+        dispersion[dispersion == 0] = np.nan
+        dispersion = np.log(dispersion)
+        mean = np.log1p(mean)
+    df = pd.DataFrame({"means": mean, "dispersions": dispersion})
+    if flavor == "seurat":
+        df["mean_bin"] = pd.cut(df["means"], bins=n_bins)
+        grouped = df.groupby("mean_bin", observed=False)["dispersions"]
+        centre, spread = grouped.mean(), grouped.std(ddof=1)
+        single = spread.isnull()  # one gene in the bin: its normalised dispersion becomes 1
+        spread[single.values] = centre[single.values].values
+        centre[single.values] = 0
+    else:
+        df["mean_bin"] = pd.cut(df["means"], np.r_[-np.inf, np.percentile(df["means"], np.arange(10, 105, 5)), np.inf])
+        grouped = df.groupby("mean_bin", observed=False)["dispersions"]
+        centre = grouped.median()
+        with np.errstate(invalid="ignore"):  # statsmodels.robust.mad: median(|x - median(x)|) / 0.6744897501960817
+            spread = grouped.apply(lambda v: np.median(np.abs(v - np.median(v))) / 0.6744897501960817 if len(v) else np.nan)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        norm = (df["dispersions"].values - centre[df["mean_bin"].values].values) / spread[df["mean_bin"].values].values
+    norm = norm.astype(np.float32)
+    if n_top_genes is not None:
+        ok = np.sort(norm[~np.isnan(norm)])[::-1]
+        n_top = min(int(n_top_genes), len(mean))
+        if n_top > ok.size:
+            n_top = ok.size
+        cut = ok[n_top - 1] if n_top > 0 else np.inf
+        hv = np.nan_to_num(norm) >= cut
+    else:
+        z = norm.copy()
+        z[np.isnan(z)] = 0
+        hv = np.logical_and.reduce((mean > min_mean, mean < max_mean, z > min_disp, z < max_disp))
+    return hv, mean, dispersion, norm
+
+
+class _HVGBase(BaseTransform):
+
+    def __init__(self, channel, channel_type, subset, inplace, batch_key, device, **kwargs):
+        super().__init__(**kwargs)
+        if batch_key is not None:
+            raise NotImplementedError("batch_key (per-batch selection and merging) is not implemented on the device path")
+        self.channel, self.channel_type, self.subset, self.inplace, self.device = channel, channel_type, subset, inplace, device
+        self.logger.info("Expects logarithmized data")
+
+    def _select(self, data, **rule):
+        kw = dict(channel=self.channel, channel_type=self.channel_type) if self.channel_type == "layers" else dict(channel_type="X")
+        x = data.get_feature(return_type=self.device, **kw)
+        base = data.data.uns.get("log1p", {}).get("base") if isinstance(data.data.uns.get("log1p"), dict) else None
+        mean, var = gene_mean_var(x, undo_log=self.flavor == "seurat", base=base)
+        hv, means, disp, norm = dispersion_hvg(mean, var, flavor=self.flavor, n_bins=self.n_bins, **rule)
+        if self.inplace:
+            v = data.data.var
+            v["highly_variable"], v["means"], v["dispersions"], v["dispersions_norm"] = hv, means, disp, norm
+            data.data.uns["hvg"] = {"flavor": self.flavor}
+        if self.subset:
+            data.data._inplace_subset_var(hv)
+        return data
+
+
+@register_preprocessor("filter", "gene")
+class HighlyVariableGenesLogarithmizedByTopGenes(_HVGBase):
+    """``sc.pp.highly_variable_genes(n_top_genes=...)`` on logarithmized data (filter.py:1219-1268), dispersion flavours."""
+
+    _DISPLAY_ATTRS = ("n_top_genes", "n_bins", "flavor", "subset")
+
+    def __init__(self, channel: Optional[str] = None, channel_type: Optional[str] = None, n_top_genes: Optional[int] = 1000, n_bins: int = 20,
+                 flavor: str = "seurat", subset: bool = True, inplace: bool = True, batch_key: Optional[str] = None, device="cuda", **kwargs):
+        super().__init__(channel, channel_type, subset, inplace, batch_key, device, **kwargs)
+        self.n_top_genes, self.n_bins, self.flavor = n_top_genes, n_bins, flavor
+
+    def __call__(self, data):
+        return self._select(data, n_top_genes=self.n_top_genes)
+
+
+@register_preprocessor("filter", "gene")
+class HighlyVariableGenesLogarithmizedByMeanAndDisp(_HVGBase):
+    """``sc.pp.highly_variable_genes`` with mean / dispersion cut-offs (filter.py:1314-1372), dispersion flavours."""
+
+    _DISPLAY_ATTRS = ("min_disp", "max_disp", "min_mean", "max_mean", "n_bins", "flavor", "subset")
+
+    def __init__(self, channel: Optional[str] = None, channel_type: Optional[str] = None, min_disp: Optional[float] = 0.5,
+                 max_disp: Optional[float] = np.inf, min_mean: Optional[float] = 0.0125, max_mean: Optional[float] = 3, n_bins: int = 20,
+                 flavor: str = "seurat", subset: bool = True, inplace: bool = True, batch_key: Optional[str] = None, device="cuda", **kwargs):
+        super().__init__(channel, channel_type, subset, inplace, batch_key, device, **kwargs)
+        self.min_disp, self.max_disp, self.min_mean, self.max_mean, self.n_bins, self.flavor = min_disp, max_disp, min_mean, max_mean, n_bins, flavor
+
+    def __call__(self, data):
+        return self._select(data, min_mean=self.min_mean, max_mean=self.max_mean, min_disp=self.min_disp, max_disp=self.max_disp)

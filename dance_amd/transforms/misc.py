@@ -43,3 +43,30 @@ class SetConfig(BaseTransform):
 
     def __call__(self, data):
         data.set_config_from_dict(self.config_dict, overwrite=True)
+
+
+@register_preprocessor("misc")
+class SaveRaw(BaseTransform):
+    """Save the current matrix (and var) to ``data.data.raw`` (dance/transforms/misc.py:126-151).  A ``DeviceArray`` X is cloned
+    on the device: ``raw.X`` stays there until host code reads it."""
+
+    def __init__(self, exist_ok: bool = False, **kwargs):
+        super().__init__(**kwargs)
+        self.exist_ok = exist_ok
+
+    def __call__(self, data):
+        import copy
+        import types
+
+        from ..data import DeviceArray
+        self.logger.info("Saving data to ``.raw``")
+        if getattr(data.data, "raw", None) is not None:
+            if self.exist_ok:
+                self.logger.warning("Overwriting raw content...")
+            else:
+                raise AttributeError(f"Raw data attribute already exist and cannot be overwritten.\n{data}"
+                                     f"If you wish to overwrite, set 'exist_ok' to True.")
+        x = data.data.X
+        x = DeviceArray(x.tensor.clone()) if isinstance(x, DeviceArray) else copy.deepcopy(x)
+        data.data.raw = types.SimpleNamespace(X=x, var=data.data.var.copy(), shape=tuple(x.shape))
+        return data

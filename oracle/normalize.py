@@ -47,3 +47,70 @@ def scale(X, zero_center=True, max_value=None):
         else:
             X[X > max_value] = max_value
     return X, mean, np.sqrt(var)
+
+
+def filter_genes(X, min_counts=None, min_cells=None, max_counts=None, max_cells=None):
+    """scanpy.pp.filter_genes(X, inplace=False): (gene_subset, number_per_gene); exactly one threshold."""
+    if sum(v is not None for v in (min_counts, min_cells, max_counts, max_cells)) != 1:
+        raise ValueError("Only provide one of the optional parameters")
+    X = np.asarray(X)
+    number = X.sum(0) if (min_counts is not None or max_counts is not None) else (X > 0).sum(0)
+    lo = min_counts if min_counts is not None else min_cells
+    hi = max_counts if max_counts is not None else max_cells
+    return (number >= lo if lo is not None else number <= hi), number
+
+
+def filter_cells(X, min_counts=None, min_genes=None, max_counts=None, max_genes=None):
+    """scanpy.pp.filter_cells(X, inplace=False): (cell_subset, number_per_cell)."""
+    s, n = filter_genes(np.asarray(X).T, min_counts, min_genes, max_counts, max_genes)
+    return s, n
+
+
+def highly_variable_genes(X, flavor="seurat", n_top_genes=None, n_bins=20, min_mean=0.0125, max_mean=3, min_disp=0.5, max_disp=np.inf):
+    """scanpy.pp.highly_variable_genes on logarithmized X, dispersion flavours, single batch — a plain numpy loop per bin
+    (no pandas), restating _highly_variable_genes_single_batch [3P-memory, scanpy 1.10.1].  Returns (highly_variable, means,
+    dispersions, dispersions_norm)."""
+    X = np.asarray(X, dtype=np.float64)
+    if flavor == "seurat":
+        X = np.expm1(X)
+    n = X.shape[0]
+    mean = X.mean(0)
+    var = ((X * X).mean(0) - mean**2) * (n / (n - 1))
+    mean[mean == 0] = 1e-12
+    disp = var / mean
+    if flavor == "seurat":
+        disp[disp == 0] = np.nan
+        disp = np.log(disp)
+        mean = np.log1p(mean)
+        lo, hi = mean.min(), mean.max()
+        edges = np.linspace(lo, hi, n_bins + 1)
+        edges[0] = lo - (hi - lo) * 0.001                # pandas.cut(bins=int): left edge pushed out by 0.1 % of the range
+        which = np.clip(np.searchsorted(edges, mean, side="left") - 1, 0, n_bins - 1)   # right-closed intervals
+    else:
+        edges = np.r_[-np.inf, np.percentile(mean, np.arange(10, 105, 5)), np.inf]
+        which = np.searchsorted(edges, mean, side="left") - 1
+    norm = np.full(mean.shape, np.nan)
+    for b in np.unique(which):
+        sel = which == b
+        d = disp[sel]
+        if flavor == "seurat":
+            c = np.nanmean(d) if np.isfinite(d).any() else np.nan
+            # pandas std(ddof=1) skips NaN; a single (non-NaN) gene gives NaN -> replaced by (mean, 0)
+            k = np.isfinite(d).sum()
+            s = np.nanstd(d, ddof=1) if k > 1 else np.nan
+            if np.isnan(s):
+                s, c = c, 0.0
+        else:
+            c = np.median(d)
+            s = np.median(np.abs(d - c)) / 0.6744897501960817
+        with np.errstate(divide="ignore", invalid="ignore"):
+            norm[sel] = (d - c) / s
+    norm = norm.astype(np.float32)
+    if n_top_genes is not None:
+        ok = np.sort(norm[~np.isnan(norm)])[::-1]
+        n_top = min(n_top_genes, len(mean), ok.size)
+        hv = np.nan_to_num(norm) >= ok[n_top - 1]
+    else:
+        z = np.where(np.isnan(norm), 0, norm)
+        hv = (mean > min_mean) & (mean < max_mean) & (z > min_disp) & (z < max_disp)
+    return hv, mean, disp, norm

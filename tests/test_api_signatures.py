@@ -22,6 +22,10 @@ PAIRS = [
     ("dance/transforms/graph/spatial_graph.py", "StagateGraph", "dance_amd.transforms.graph"),
     ("dance/transforms/cell_feature.py", "WeightedFeaturePCA", "dance_amd.transforms"),
     ("dance/transforms/cell_feature.py", "CellPCA", "dance_amd.transforms"),
+    ("dance/transforms/filter.py", "FilterCellsScanpy", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenesScanpy", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByTopGenes", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByMeanAndDisp", "dance_amd.transforms.filter"),
     ("dance/models/nn/gnn.py", "AdaptiveSAGE", "dance_amd.nn.gnn"),
     ("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "GNN", "dance_amd.modules.single_modality.cell_type_annotation.scdeepsort"),
     ("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "ScDeepSort", "dance_amd.modules.single_modality.cell_type_annotation.scdeepsort"),
@@ -86,6 +90,8 @@ EXTRA_PARAMS_OK = {
     ("CellFeatureGraph", "__init__"): {"device"},
     ("PCACellFeatureGraph", "__init__"): {"device"},
     ("WeightedFeaturePCA", "__init__"): {"device", "solver"},
+    ("HighlyVariableGenesLogarithmizedByTopGenes", "__init__"): {"device"},
+    ("HighlyVariableGenesLogarithmizedByMeanAndDisp", "__init__"): {"device"},
     ("CellPCA", "__init__"): {"device", "solver"},
 }
 

@@ -91,3 +91,52 @@ def check_pipeline(device):
 
 def test_on_device_pipeline_has_no_host_round_trips(cpu_kernels):
     check_pipeline("cpu")
+
+
+def check_model_pipelines(device):
+    """ScDSC.preprocessing_pipeline() and GraphSC.preprocessing_pipeline() end to end on DeviceArray input: the reference's step list
+    (scdsc.py:113-138, graphsc.py:110-146) with nothing crossing PCIe between the steps, and shapes / invariants of what comes out."""
+    import torch
+    from dance_amd import data as dd
+    from dance_amd.graph import LazyScipyCSR
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSC
+    rng = np.random.default_rng(3)
+    lam = rng.gamma(0.5, 2.0, 300)
+    x = rng.poisson(lam[None, :] * rng.uniform(0.3, 2.0, (400, 1))).astype(np.float32)
+    x[7] = 0  # a cell without counts: filtered
+
+    def run(pipe, slot):
+        for t in pipe.transforms:
+            if hasattr(t, "device"):
+                t.device = device
+            if hasattr(t, "pca_device"):
+                t.pca_device = device
+        data = dd.Data(dd.AnnDataLite(slot), train_size=-1, val_size=0, test_size=0)
+        c0, l0 = dd.DeviceArray.host_copies, LazyScipyCSR.host_copies
+        pipe(data)
+        return data, dd.DeviceArray.host_copies - c0, LazyScipyCSR.host_copies - l0
+
+    data, copies, lazy = run(ScDSC.preprocessing_pipeline(n_top_genes=60, n_neighbors=12), dd.DeviceArray(torch.from_numpy(x.copy()).to(device)))
+    assert copies == 0 and lazy == 0
+    ad = data.data
+    assert ad.X.shape == (399, 60) and ad.raw.X.shape == (399, 60) and isinstance(ad.X, dd.DeviceArray) and isinstance(ad.raw.X, dd.DeviceArray)
+    xs = ad.X.tensor
+    assert float(xs.mean(0).abs().max()) < 1e-4 and float((xs.std(0, unbiased=True) - 1).abs().max()) < 1e-3   # sc.pp.scale
+    assert np.allclose(np.asarray(ad.obs["n_counts"]), x[np.arange(400) != 7][:, np.asarray(x.sum(0) >= 3)].sum(1), rtol=1e-6)
+    g = ad.uns["NeighborGraph.hip"]
+    assert g.n_rows == 399 and g.symmetric
+    adj, xx, raw, n_counts = data.get_x()           # what ScDSC.fit receives (host views materialise here, once each)
+    assert adj.shape == (399, 399) and xx.shape == raw.shape == (399, 60) and n_counts.shape == (399, )
+    data, copies, lazy = run(GraphSC.preprocessing_pipeline(n_top_genes=80, n_components=10), dd.DeviceArray(torch.from_numpy(x.copy()).to(device)))
+    assert copies == 0
+    cg = data.data.uns["CellFeatureGraph"]
+    n_cells, n_genes = data.data.X.shape
+    assert (n_cells, n_genes) == (399, 80) and cg.number_of_nodes() == 399 + 80 and cg.ndata["features"].shape == (479, 10)
+    assert np.allclose(data.data.X.tensor.sum(1).cpu().numpy(), 1.0, rtol=1e-5)     # normalize_total(target_sum=1) of the edge weights
+    with pytest.raises(ValueError):
+        GraphSC.preprocessing_pipeline(normalize_weights="bogus")
+
+
+def test_model_pipelines_on_device_arrays(cpu_kernels):
+    check_model_pipelines("cpu")

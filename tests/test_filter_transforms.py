@@ -1,0 +1,77 @@
+"""Device gene / cell filtering and dispersion-based HVG selection (dance_amd/transforms/filter.py) against the numpy restatement
+of scanpy's rules (oracle/normalize.py; scanpy itself is not installable: parity unpinned by reference output) and hand-computed
+cases; DeviceArray slots stay on the device through subsetting.  CPU tensors here, the GPU twin runs the same body on cuda."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import normalize as on
+
+
+def _counts(n, g, seed):
+    rng = np.random.default_rng(seed)
+    lam = rng.gamma(0.6, 2.0, g)
+    x = rng.poisson(lam[None, :] * rng.uniform(0.3, 2.0, (n, 1))).astype(np.float32)
+    x[:, :3] = 0            # never expressed
+    x[5] = 0                # an empty cell
+    return x
+
+
+def check_filters(device):
+    from dance_amd.data import AnnDataLite, Data, DeviceArray
+    from dance_amd.transforms.filter import (FilterCellsScanpy, FilterGenesScanpy, HighlyVariableGenesLogarithmizedByMeanAndDisp,
+                                             HighlyVariableGenesLogarithmizedByTopGenes, dispersion_hvg, get_count)
+    x = _counts(300, 120, 0)
+    for kw, okw in ((dict(min_counts=3), dict(min_counts=3)), (dict(min_cells=10), dict(min_cells=10)), (dict(max_cells=0.5), dict(max_cells=150)),
+                    (dict(max_counts=200), dict(max_counts=200))):
+        d = Data(AnnDataLite(DeviceArray(torch.from_numpy(x.copy()).to(device)), obsm={"e": x[:, :4].copy()}), train_size=200, val_size=0, test_size=-1)
+        FilterGenesScanpy(device=device, key_n_counts="n_counts", key_n_cells="n_cells", **kw)(d)
+        keep, num = on.filter_genes(x, **okw)
+        assert isinstance(d.data.X, DeviceArray) and d.data.X.shape == (300, int(keep.sum())) and DeviceArray.host_copies >= 0
+        assert np.array_equal(np.asarray(d.data.X), x[:, keep]) and list(d.data.var.index) == [str(i) for i in np.flatnonzero(keep)]
+        assert d.data.obsm["e"].shape == (300, 4)
+    d = Data(AnnDataLite(DeviceArray(torch.from_numpy(x.copy()).to(device)), obsm={"e": DeviceArray(torch.from_numpy(x[:, :4].copy()).to(device))}),
+             train_size=200, val_size=0, test_size=-1)
+    FilterCellsScanpy(min_counts=1, device=device)(d)
+    keep, _ = on.filter_cells(x, min_counts=1)
+    assert not keep[5] and d.shape == (int(keep.sum()), 120) and np.array_equal(np.asarray(d.data.obsm["e"]), x[keep][:, :4])
+    assert d.train_idx == list(range(199)) and d.test_idx == list(range(199, 299))   # cell 5 left the train split, the rest shifted
+    with pytest.raises(ValueError):
+        FilterGenesScanpy(min_counts=1, min_cells=1, device=device)(d)
+    assert get_count(0.25, 200) == 50 and get_count(7, 200) == 7 and get_count(None, 3) is None
+    with pytest.raises(ValueError):
+        get_count(1.5, 10)
+    # ---- HVG on logarithmized data, both dispersion flavours, top-k and cut-off rules -------------------------------------------
+    xl = np.log1p(on.normalize_total(x[np.arange(300) != 5][:, 3:], 1e4))
+    for flavor in ("seurat", "cell_ranger"):
+        for rule in (dict(n_top_genes=30), dict(min_mean=0.05, max_mean=4, min_disp=0.3)):
+            d = Data(AnnDataLite(DeviceArray(torch.from_numpy(xl.copy()).to(device))))
+            cls = HighlyVariableGenesLogarithmizedByTopGenes if "n_top_genes" in rule else HighlyVariableGenesLogarithmizedByMeanAndDisp
+            cls(flavor=flavor, subset=False, device=device, **rule)(d)
+            hv, mean, disp, norm = on.highly_variable_genes(xl, flavor=flavor, **rule)
+            v = d.data.var
+            assert np.allclose(v["means"].values, mean, rtol=1e-5, atol=1e-9) and np.allclose(v["dispersions"].values, disp, rtol=1e-4, equal_nan=True)
+            assert np.allclose(v["dispersions_norm"].values, norm, rtol=2e-3, atol=2e-4, equal_nan=True), (flavor, rule)
+            agree = (v["highly_variable"].values == hv).mean()
+            assert agree >= 0.98, (flavor, rule, agree)       # a rank boundary may fall between two fp32-equal scores
+            if "n_top_genes" in rule:
+                assert abs(int(v["highly_variable"].sum()) - 30) <= 1
+            cls(flavor=flavor, subset=True, device=device, **rule)(d)
+            assert isinstance(d.data.X, DeviceArray) and d.data.X.shape[1] == int(d.data.var["highly_variable"].sum()) == d.data.var.shape[0]
+    # hand-computed: 40 genes with means 1..40 and dispersion = mean.  cell_ranger bins by the 10th..100th percentiles (step 5) of the
+    # means; a bin holding exactly two genes (d, d + 1) has median d + 1/2 and MAD (1/2) / 0.6745, so their normalised dispersions
+    # are -0.6745 and +0.6745 whatever d is; the top-2 rule then keeps ties at the maximum
+    mean = np.arange(1.0, 41.0)
+    hv, m, dsp, nrm = dispersion_hvg(mean, mean * mean, flavor="cell_ranger", n_top_genes=2)
+    assert np.allclose(dsp, mean)
+    edges = np.r_[-np.inf, np.percentile(mean, np.arange(10, 105, 5)), np.inf]
+    which = np.searchsorted(edges, mean, side="left") - 1
+    pairs = [b for b in np.unique(which) if (which == b).sum() == 2]
+    assert len(pairs) >= 10
+    for b in pairs:
+        assert np.allclose(nrm[which == b], [-0.6744897501960817, 0.6744897501960817], rtol=1e-6)
+    assert hv.sum() >= 2 and np.all(nrm[hv] >= np.sort(nrm[~np.isnan(nrm)])[-2])
+
+
+def test_filter_and_hvg_on_cpu_tensors():
+    check_filters("cpu")

@@ -243,3 +243,13 @@ def test_dense_to_csr_matches_numpy_nonzero(cuda_device):
             rp2, col2, val2 = kernels.dense_to_csr(xt[:, 3:m - 2])
             r2, c2 = np.nonzero(x[:, 3:m - 2])
             assert np.array_equal(col2.cpu().numpy(), c2) and np.array_equal(val2.cpu().numpy(), x[:, 3:m - 2][r2, c2])
+
+
+def test_filter_and_hvg_on_device(cuda_device):
+    import test_filter_transforms as tft
+    tft.check_filters("cuda")
+
+
+def test_model_pipelines_on_device_arrays_gpu(cuda_device):
+    import test_device_pipeline as tdp
+    tdp.check_model_pipelines("cuda")
