@@ -80,6 +80,7 @@ def _declare(lib):
         "dh_gram_sigmoid_supported": (c_int, [i64, i64]),
         "dh_gram_sigmoid_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_gram_sigmoid_f32": (c_int, [i64, i64, P, i64, P, i64, P, P, c_size_t, P]),
+        "dh_gram_pairwise_f32": (c_int, [i32, i64, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_gram_listed_forward_f32": (c_int, [i64, i64, i64, P, i64, P, P, c_float, P, P, P]),
         "dh_gram_listed_backward_f32": (c_int, [i64, i64, i64, P, i64, P, i64, P, P, P, c_float, P, P, i64, P]),
         "dh_rowsum_masked_f32": (c_int, [i64, i64, P, i64, P, P, P]),
@@ -99,6 +100,8 @@ def _declare(lib):
         "dh_block_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_block_plan": (c_int, [i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_block_fill": (c_int, [i64, i64, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+        "dh_zinb_nll_forward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P]),
+        "dh_zinb_nll_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P, P, P, i64, P]),
         "dh_comm_unique_id": (c_int, [P]),
         "dh_comm_init": (c_int, [P, i32, i32, P]),
         "dh_comm_destroy": (c_int, [P]),

@@ -277,6 +277,83 @@ def gat_aggregate(x, a_src, a_dst, graph: CSRGraph, *, act: int = kernels.ATT_SI
     return _GATAggregateFn.apply(x, a_src, a_dst, graph, act, negative_slope, shift, edge_scale)
 
 
+class _ZINBNLL(torch.autograd.Function):
+    """``ZINBLoss.forward`` (dance/utils/loss.py:780-829) as two fused kernels instead of ~25 elementwise passes over the N x G
+    matrices: dh_zinb_nll_forward_f32 (float64 row sums of the element loss) and dh_zinb_nll_backward_f32 (recomputes the element
+    terms, writes d mean / d disp / d pi).  The result is a float64 scalar, as the reference's (its size factors are float64 and
+    promote the expression)."""
+
+    @staticmethod
+    def forward(ctx, x, mean, disp, pi, scale_factor, ridge_lambda: float):
+        x, mean, disp, pi = (t.contiguous() if t.stride(-1) != 1 else t for t in (x.float(), mean, disp, pi))
+        sf = None if scale_factor is None else scale_factor.detach().to(torch.float64).contiguous()
+        rowloss = kernels.zinb_nll_forward(x, mean, disp, pi, sf, ridge_lambda)
+        ctx.ridge = float(ridge_lambda)
+        ctx.save_for_backward(x, mean, disp, pi, sf)
+        return rowloss.sum() / float(x.shape[0] * x.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, mean, disp, pi, sf = ctx.saved_tensors
+        up = (g.to(torch.float64) / float(x.shape[0] * x.shape[1])).reshape(1).contiguous()
+        dm, dd, dp = kernels.zinb_nll_backward(x, mean, disp, pi, sf, ctx.ridge, up)
+        return None, dm, dd, dp, None, None
+
+
+def zinb_nll(x, mean, disp, pi, scale_factor=None, ridge_lambda: float = 0.0) -> torch.Tensor:
+    """mean over all (cell, gene) of the ZINB negative log-likelihood; float64 scalar (see _ZINBNLL)."""
+    return _ZINBNLL.apply(x, mean, disp, pi, scale_factor, ridge_lambda)
+
+
+class _AdjReconstructionMSE(torch.autograd.Function):
+    """mean_ij (sigmoid(<z_i, z_j>) - a_ij)^2 over ALL n^2 pairs for a sparse target a (CSR, stored entries only), as a function of z
+    and without any n x n matrix — scTAG's adjacency-decoder loss ``F.mse_loss(sigmoid(z0 z0^T), adj)`` (sctag.py:470-471, :254):
+
+        sum_ij (s_ij - a_ij)^2 = sum_ij s_ij^2  -  2 sum_{(i,j) in A} a_ij s_ij  +  sum_A a_ij^2,      s = sigmoid(z z^T)
+
+    The first sum and its gradient 2 sum_j 2 s^2 (1 - s) z_j are one pass on the fp32 matrix cores that keeps every logit tile in
+    registers (dh_gram_pairwise_f32, DH_GRAM_SIGMOID_SQ); the second needs the logits of the stored entries only (dh_sddmm_csr_f32)
+    and its gradient is an SpMM over A and one over A^T with the per-edge coefficients as values."""
+
+    @staticmethod
+    def forward(ctx, z, graph: CSRGraph):
+        z = z.contiguous()
+        n = z.shape[0]
+        rowloss, o = kernels.gram_pairwise(z, kernels.GRAM_SIGMOID_SQ)
+        u, v = z, z
+        if z.shape[1] % 4:  # the SDDMM moves 16 bytes per lane
+            u = v = torch.nn.functional.pad(z, (0, 4 - z.shape[1] % 4))
+        xe = kernels.sddmm_csr(graph.rowptr, graph.col, u, v)
+        a = graph.val if graph.val is not None else torch.ones_like(xe)
+        se = torch.sigmoid(xe)
+        total = rowloss.sum(dtype=torch.float64) + (a * (a - 2 * se)).sum(dtype=torch.float64)
+        ctx.graph = graph
+        ctx.save_for_backward(z, o, se, a)
+        return (total / float(n) / float(n)).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, o, se, a = ctx.saved_tensors
+        graph = ctx.graph
+        n = z.shape[0]
+        scale = (g / float(n) / float(n)).to(torch.float32)
+        ce = (-2.0 * a * se * (1 - se)).contiguous()  # d/dx of -2 a sigmoid(x); entry (i, j) contributes ce z_j to row i and ce z_i to row j
+        dz = 2.0 * o + kernels.spmm_csr(graph.rowptr, graph.col, ce, z, n_cols=graph.n_cols)
+        if graph.symmetric:  # same pattern and, for a symmetric target, the same coefficients: A^T's pass is A's
+            dz = dz + kernels.spmm_csr(graph.rowptr, graph.col, ce, z, n_cols=graph.n_cols)
+        else:
+            if getattr(graph, "_t_perm", None) is None:
+                graph._t_struct = kernels.csr_transpose(graph.rowptr, graph.col, None, graph.n_rows, graph.n_cols)
+                graph._t_perm = graph._t_struct[3].long()
+            dz = dz + kernels.spmm_csr(graph._t_struct[0], graph._t_struct[1], ce[graph._t_perm].contiguous(), z, n_cols=graph.n_rows)
+        return dz * scale, None
+
+
+def adj_reconstruction_mse(z: torch.Tensor, graph: CSRGraph) -> torch.Tensor:
+    """mean((sigmoid(z z^T) - A)^2) over all n^2 entries for a sparse A, in O(n d) memory (see _AdjReconstructionMSE)."""
+    return _AdjReconstructionMSE.apply(z, graph)
+
+
 class _DenseAdjLayerFn(torch.autograd.Function):
     """Same op for a DENSE adjacency (SpaGCN passes a dense N x N FloatTensor, spagcn.py:497,359)."""
 

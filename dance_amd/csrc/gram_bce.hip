@@ -43,7 +43,11 @@ constexpr int MAX_D = 320;
 __host__ __device__ constexpr int lds_stride(int dp) { return dp + 4; }  // == 4 (mod 64): the 32 rows of a tile start 4 banks apart
 
 // DP: d padded to a multiple of 64.  VEC: ldz % 4 == 0, d % 4 == 0 and Z 16-byte aligned (float4 loads), else scalar loads.
-template <int DP, bool VEC>
+// MODE: the pair (f, g = f') evaluated on every logit x = <z_i, z_j>: rowloss[i] = sum_j f(x_ij), O[i] = sum_j g(x_ij) z_j.
+//   0: f = softplus, g = sigmoid                       graph-sc's BCE-with-logits against a (nearly) all-zero target
+//   1: f = sigmoid^2, g = 2 sigmoid^2 (1 - sigmoid)    scTAG's MSE(sigmoid(z z^T), adj) (sctag.py:470-471, :254): the dense part
+//                                                      sum_ij sigmoid(x_ij)^2 of sum_ij (sigmoid(x_ij) - a_ij)^2
+template <int DP, bool VEC, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void gram_sigmoid_kernel(int n, int d, const float* __restrict__ Z, int64_t ldz, int j_per_split, int n_pad,
                          float* __restrict__ Opart, double* __restrict__ Lpart) {
@@ -157,10 +161,17 @@ void gram_sigmoid_kernel(int n, int d, const float* __restrict__ Z, int64_t ldz,
       const float e = __expf(-fabsf(x));
       const float inv = __builtin_amdgcn_rcpf(1.f + e);
       const float sig = x >= 0.f ? inv : e * inv;
-      const float sp = fmaxf(x, 0.f) + __logf(1.f + e);
+      float fval, gval;
+      if constexpr (MODE == 0) {
+        fval = fmaxf(x, 0.f) + __logf(1.f + e);
+        gval = sig;
+      } else {
+        fval = sig * sig;
+        gval = 2.f * fval * (x >= 0.f ? e * inv : inv);  // 1 - sigmoid(x) without cancellation
+      }
       const bool valid = j < j_end;
-      sg[r] = valid ? sig : 0.f;
-      tile_loss += valid ? sp : 0.f;
+      sg[r] = valid ? gval : 0.f;
+      tile_loss += valid ? fval : 0.f;
     };
 
     // O[i][:] += sum_j sigmoid(S[i][j]) Z[j0 + j][:]: A = sigmoid(c) (row i = lane % 32, k = the j of register r in this lane
@@ -311,19 +322,30 @@ Plan make_plan(int64_t n, int64_t d) {
   return p;
 }
 
-template <int DP>
+template <int DP, int MODE>
 int launch(const Plan& p, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
   const bool vec = (ldz % 4 == 0) && (d % 4 == 0) && dh::aligned16(Z);
   const size_t lds_bytes = (size_t)2 * BJ * lds_stride(DP) * sizeof(float);
   const dim3 grid((unsigned)p.i_blocks, (unsigned)p.splits);
   if (vec) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, true>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, true, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, true, MODE>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
   } else {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, false>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, false, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, false, MODE>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
   }
-  return dh::check_launch("dh_gram_sigmoid_f32");
+  return dh::check_launch("dh_gram_pairwise_f32");
+}
+
+template <int MODE>
+int launch_dp(const Plan& p, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
+  switch (p.dp) {
+    case 64: return launch<64, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
+    case 128: return launch<128, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
+    case 192: return launch<192, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
+    case 256: return launch<256, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
+    default: return launch<320, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
+  }
 }
 
 }  // namespace
@@ -338,6 +360,12 @@ extern "C" size_t dh_gram_sigmoid_workspace_bytes(int64_t n, int64_t d) {
 
 extern "C" int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
                                    void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  return dh_gram_pairwise_f32(DH_GRAM_SOFTPLUS, n, d, Z, ldz, O, ldo, rowloss, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_gram_pairwise_f32(int mode, int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
+                                    void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  if (mode != DH_GRAM_SOFTPLUS && mode != DH_GRAM_SIGMOID_SQ) return dh::fail(DH_ERR_INVALID, "dh_gram_pairwise_f32: bad mode %d", mode);
   if (n < 0 || d < 0) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: negative size");
   if (n == 0) return DH_OK;
   if (!dh_gram_sigmoid_supported(n, d))
@@ -350,14 +378,8 @@ extern "C" int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t
   hipStream_t st = dh::as_stream(stream);
   double* Lpart = reinterpret_cast<double*>(workspace);                      // doubles first: keeps both parts aligned
   float* Opart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.lpart_bytes);
-  int rc;
-  switch (p.dp) {
-    case 64: rc = launch<64>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
-    case 128: rc = launch<128>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
-    case 192: rc = launch<192>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
-    case 256: rc = launch<256>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
-    default: rc = launch<320>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st); break;
-  }
+  const int rc = mode == DH_GRAM_SOFTPLUS ? launch_dp<0>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st)
+                                          : launch_dp<1>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st);
   if (rc != DH_OK) return rc;
   const int64_t work = n * d;
   const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 65536 ? dh::ceil_div(work, 256) : 65536);

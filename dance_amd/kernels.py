@@ -319,18 +319,51 @@ def gram_sigmoid_supported(n: int, d: int) -> bool:
     return bool(_lib_ready().dh_gram_sigmoid_supported(int(n), int(d)))
 
 
-def gram_sigmoid(Z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(rowloss, O) with rowloss[i] = sum_j softplus(<z_i, z_j>) and O[i] = sum_j sigmoid(<z_i, z_j>) z_j: the dense part of
-    graph-sc's inner-product decoder loss and (x2) its gradient, without the B x B logits (dh_gram_sigmoid_f32)."""
+def zinb_nll_forward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float = 0.0) -> torch.Tensor:
+    """rowloss [n] float64 of the zero-inflated negative-binomial NLL (dh_zinb_nll_forward_f32); the loss is its sum / (n g)."""
+    lib = _lib_ready()
+    n, g = X.shape
+    rowloss = torch.empty(n, dtype=torch.float64, device=X.device)
+    _call("zinb_nll_forward_f32", lib.dh_zinb_nll_forward_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean, torch.float32, "mean", 2),
+          _ld(mean), _dev(disp, torch.float32, "disp", 2), _ld(disp), _dev(pi, torch.float32, "pi", 2), _ld(pi),
+          _dev(scale_factor, torch.float64, "scale_factor", 1), float(ridge_lambda), rowloss.data_ptr(), _stream())
+    return rowloss
+
+
+def zinb_nll_backward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float, upstream: torch.Tensor):
+    """(d mean, d disp, d pi) fp32 of ``zinb_nll_forward`` times the float64 device scalar ``upstream`` (dh_zinb_nll_backward_f32)."""
+    lib = _lib_ready()
+    n, g = X.shape
+    dm, dd, dp = (torch.empty((n, g), dtype=torch.float32, device=X.device) for _ in range(3))
+    _call("zinb_nll_backward_f32", lib.dh_zinb_nll_backward_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean, torch.float32, "mean", 2),
+          _ld(mean), _dev(disp, torch.float32, "disp", 2), _ld(disp), _dev(pi, torch.float32, "pi", 2), _ld(pi),
+          _dev(scale_factor, torch.float64, "scale_factor", 1), float(ridge_lambda), _dev(upstream, torch.float64, "upstream"), dm.data_ptr(),
+          dd.data_ptr(), dp.data_ptr(), g, _stream())
+    return dm, dd, dp
+
+
+GRAM_SOFTPLUS, GRAM_SIGMOID_SQ = 0, 1
+
+
+def gram_pairwise(Z: torch.Tensor, mode: int = GRAM_SOFTPLUS) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowloss, O) with rowloss[i] = sum_j f(<z_i, z_j>) and O[i] = sum_j f'(<z_i, z_j>) z_j over ALL pairs, without the n x n
+    logits (dh_gram_pairwise_f32): f = softplus (GRAM_SOFTPLUS, graph-sc's decoder) or sigmoid^2 (GRAM_SIGMOID_SQ, scTAG's)."""
     lib = _lib_ready()
     n, d = Z.shape
     out = torch.empty((n, d), dtype=torch.float32, device=Z.device)
     rowloss = torch.empty(n, dtype=torch.float32, device=Z.device)
     ws_bytes = lib.dh_gram_sigmoid_workspace_bytes(n, d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Z.device) if ws_bytes else None
-    _call("gram_sigmoid_f32", lib.dh_gram_sigmoid_f32, n, d, _dev(Z, torch.float32, "Z", 2), _ld(Z), out.data_ptr(), _ld(out),
-          rowloss.data_ptr(), None if ws is None else ws.data_ptr(), ws_bytes, _stream())
+    _call("gram_sigmoid_f32" if mode == GRAM_SOFTPLUS else "gram_sigmoid_sq_f32", lib.dh_gram_pairwise_f32, int(mode), n, d,
+          _dev(Z, torch.float32, "Z", 2), _ld(Z), out.data_ptr(), _ld(out), rowloss.data_ptr(), None if ws is None else ws.data_ptr(), ws_bytes,
+          _stream())
     return rowloss, out
+
+
+def gram_sigmoid(Z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowloss, O) with rowloss[i] = sum_j softplus(<z_i, z_j>) and O[i] = sum_j sigmoid(<z_i, z_j>) z_j: the dense part of
+    graph-sc's inner-product decoder loss and (x2) its gradient, without the B x B logits (dh_gram_sigmoid_f32)."""
+    return gram_pairwise(Z, GRAM_SOFTPLUS)
 
 
 def gram_listed_forward(Z: torch.Tensor, us: torch.Tensor, vs: torch.Tensor, pos_weight: float) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -32,7 +32,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import kernels
-from ....autograd import HipLinear, spmm
+from ....autograd import HipLinear, spmm, zinb_nll
 from ....graph import CSRGraph, TensorKeyedCache
 from ....transforms import Compose, SetConfig
 from ....transforms.graph import HeteronetGraph
@@ -76,19 +76,10 @@ def contrastive_loss(z1, z2, temperature=0.5):
 
 
 class ZINBLoss(nn.Module):
+    """scheteronet.py:289-336 (the same ZINB NLL as dance/utils/loss.py:780-829) on the fused kernels (autograd.zinb_nll)."""
 
     def forward(self, x, mean, disp, pi, scale_factor, ridge_lambda=0.0):
-        eps = 1e-10
-        mean = mean * scale_factor[:, None]
-        t1 = torch.lgamma(disp + eps) + torch.lgamma(x + 1.0) - torch.lgamma(x + disp + eps)
-        t2 = (disp + x) * torch.log(1.0 + (mean / (disp + eps))) + (x * (torch.log(disp + eps) - torch.log(mean + eps)))
-        nb_case = t1 + t2 - torch.log(1.0 - pi + eps)
-        zero_nb = torch.pow(disp / (disp + mean + eps), disp)
-        zero_case = -torch.log(pi + ((1.0 - pi) * zero_nb) + eps)
-        result = torch.where(torch.le(x, 1e-8), zero_case, nb_case)
-        if ridge_lambda > 0:
-            result = result + ridge_lambda * torch.square(pi)
-        return torch.mean(result)
+        return zinb_nll(x, mean, disp, pi, scale_factor, ridge_lambda)
 
 
 class MLP(nn.Module):

@@ -23,7 +23,7 @@ import torch.optim as optim
 from torch.nn import Parameter
 
 from .... import kernels
-from ....autograd import HipLinear, linear, spmm
+from ....autograd import HipLinear, adj_reconstruction_mse, linear, spmm
 from ....graph import CSRGraph
 from ....transforms import CellPCA, Compose, SetConfig
 from ....transforms.graph import NeighborGraph
@@ -41,8 +41,8 @@ class WeightedGraph:
     """What the reference keeps as ``dgl.graph((src, dst))`` + ``edata["weight"]`` (:95-97): a device CSR by DESTINATION
     (row v lists the sources u of its in-edges, ascending) with the edge weights, plus the TAGConv degree factor."""
 
-    def __init__(self, adj: np.ndarray, device):
-        a = sp.csr_matrix(np.asarray(adj, dtype=np.float32))
+    def __init__(self, adj, device):
+        a = sp.csr_matrix(adj, dtype=np.float32) if sp.issparse(adj) else sp.csr_matrix(np.asarray(adj, dtype=np.float32))
         a.eliminate_zeros()  # np.nonzero(adj)
         at = a.T.tocsr()     # edge (src = row, dst = col): aggregate at the destination
         at.sort_indices()
@@ -105,8 +105,10 @@ class DecoderAdj(nn.Module):
         self.activation = activation
         self.dec_1 = HipLinear(latent_dim, adj_dim)
 
-    def forward(self, z):
+    def forward(self, z, factor_only: bool = False):
         z0 = F.dropout(self.dec_1(z), self.dropout)  # training=True always, as in the reference (:470)
+        if factor_only:  # the scalable loss works on the factor: sigmoid(z0 z0^T) is never formed (autograd.adj_reconstruction_mse)
+            return z0
         return self.activation(linear(z0, z0))        # z0 z0^T on the matrix cores
 
 
@@ -131,8 +133,14 @@ class DecoderX(nn.Module):
 class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
 
     def __init__(self, n_clusters: int, k: int = 3, hidden_dim: int = 128, latent_dim: int = 15, dec_dim: Optional[int] = None,
-                 dropout: float = 0.2, device: str = "cuda", alpha: float = 1.0, pretrain_path: Optional[str] = None):
+                 dropout: float = 0.2, device: str = "cuda", alpha: float = 1.0, pretrain_path: Optional[str] = None, *,
+                 adj_dim: Optional[int] = None):
         super().__init__()
+        # adj_dim=None: the reference's adjacency decoder — a Linear(latent_dim -> N) followed by an N x N x N product and an N x N
+        # target (sctag.py:302, :433-472): parameters, memory and flops grow with the number of cells.  adj_dim=d (<= 320): the same
+        # decoder with a width that does not depend on N, and the loss mean((sigmoid(z0 z0^T) - adj)^2) over ALL N^2 pairs evaluated
+        # without any N x N matrix (dh_gram_pairwise_f32 + dh_sddmm_csr_f32, autograd.adj_reconstruction_mse): O(N d) memory.
+        self.adj_dim = adj_dim
         self._is_pretrained = False
         self._in_dim = None
         self.pretrain_path = pretrain_path
@@ -145,19 +153,32 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
         self.alpha = alpha
         self.k = k
 
-    def init_model(self, adj: np.ndarray, x: np.ndarray):
+    def init_model(self, adj, x: np.ndarray):
         self._in_dim = x.shape[1]
-        adj = np.asarray(adj, dtype=np.float32)
-        deg = adj.sum(1, keepdims=True)
-        deg[deg == 0] = 1
-        normalized_deg = deg**-0.5
-        adj_n = adj * normalized_deg * normalized_deg.T
-        self.g = WeightedGraph((adj != 0).astype(np.float32), self.device)
-        self.g_n = WeightedGraph(adj_n, self.device)
+        if self.adj_dim is not None:  # scalable mode: the adjacency stays sparse from here on
+            a = sp.csr_matrix(adj, dtype=np.float32)
+            deg = np.asarray(a.sum(1)).ravel()
+            deg[deg == 0] = 1
+            dis = sp.diags((deg**-0.5).astype(np.float32))
+            adj_n = (dis @ a @ dis).tocsr()
+            self.g = WeightedGraph((a != 0).astype(np.float32), self.device)
+            self.g_n = WeightedGraph(adj_n, self.device)
+            a.sort_indices()
+            self.adj_target = CSRGraph.from_scipy(a, self.device, symmetric=(abs(a - a.T) > 0).nnz == 0)
+        else:
+            adj = np.asarray(adj, dtype=np.float32)
+            deg = adj.sum(1, keepdims=True)
+            deg[deg == 0] = 1
+            normalized_deg = deg**-0.5
+            adj_n = adj * normalized_deg * normalized_deg.T
+            self.g = WeightedGraph((adj != 0).astype(np.float32), self.device)
+            self.g_n = WeightedGraph(adj_n, self.device)
+            self.adj_target = None
         self.mu = Parameter(torch.empty(self.n_clusters, self.latent_dim, device=self.device))
         self.encoder1 = TAGConv(self.in_dim, self.hidden_dim, k=self.k)
         self.encoder2 = TAGConv(self.hidden_dim, self.latent_dim, k=self.k)
-        self.decoder_adj = DecoderAdj(latent_dim=self.latent_dim, adj_dim=adj.shape[0], activation=torch.sigmoid, dropout=self.dropout)
+        self.decoder_adj = DecoderAdj(latent_dim=self.latent_dim, adj_dim=self.adj_dim or adj.shape[0], activation=torch.sigmoid,
+                                      dropout=self.dropout)
         self.decoder_x = DecoderX(self.in_dim, self.latent_dim, n_dec_1=self.dec_dim[0], n_dec_2=self.dec_dim[1], n_dec_3=self.dec_dim[2])
         self.zinb_loss = ZINBLoss().to(self.device)
         self.to(self.device)
@@ -184,9 +205,16 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
     def forward(self, g, x_input):
         enc_h = self.encoder1(g, x_input, edge_weight=g.edata["weight"])
         z = self.encoder2(g, enc_h, edge_weight=g.edata["weight"])
-        adj_out = self.decoder_adj(z)
+        adj_out = self.decoder_adj(z, factor_only=self.adj_dim is not None)  # scalable mode: the factor z0 [N, adj_dim], not N x N
         _mean, _disp, _pi = self.decoder_x(z)
         return adj_out, z, self.soft_assign(z), _mean, _disp, _pi
+
+    def adj_loss(self, adj_out, adj_t):
+        """``torch.mean(F.mse_loss(adj_out, adj))`` of sctag.py:254 / :347; in scalable mode from the decoder's factor and the sparse
+        target, over the same N^2 entries."""
+        if self.adj_dim is not None:
+            return adj_reconstruction_mse(adj_out, self.adj_target)
+        return torch.mean(F.mse_loss(adj_out, adj_t))
 
     def pretrain(self, adj, x, x_raw, n_counts, *, epochs: int = 1000, info_step: int = 10, lr: float = 5e-4, w_a: float = 0.3,
                  w_x: float = 1, w_d: float = 0, min_dist: float = 0.5, max_dist: float = 20, force_pretrain: bool = False):
@@ -194,12 +222,12 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
         x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(self.device)
         n_counts = np.asarray(n_counts, dtype=np.float64)
         scale_factor = torch.as_tensor(n_counts / np.median(n_counts)).to(self.device)
-        adj_t = torch.as_tensor(np.asarray(adj), dtype=torch.float32).to(self.device)
+        adj_t = None if self.adj_dim is not None else torch.as_tensor(np.asarray(adj), dtype=torch.float32).to(self.device)
         self.train()
         optimizer = optim.Adam(filter(lambda p: p.requires_grad, self.parameters()), lr=lr, amsgrad=True)
         for _ in range(epochs):
             adj_out, z, _, mean, disp, pi = self.forward(self.g_n, x)
-            loss = w_a * torch.mean(F.mse_loss(adj_out, adj_t)) + w_x * self.zinb_loss(x_raw, mean, disp, pi, scale_factor)
+            loss = w_a * self.adj_loss(adj_out, adj_t) + w_x * self.zinb_loss(x_raw, mean, disp, pi, scale_factor)
             if w_d:
                 loss = loss + w_d * torch.mean(dist_loss(z, min_dist, max_dist=max_dist))
             optimizer.zero_grad()
@@ -217,7 +245,9 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
             info_step: int = 1, max_dist: float = 20, min_dist: float = 0.5, force_pretrain: bool = False):
         from sklearn.cluster import KMeans
         adj, x, x_raw, n_counts = inputs
-        if sp.issparse(adj):
+        if hasattr(adj, "materialize"):  # LazyScipyCSR left by an on-device NeighborGraph
+            adj = adj.materialize()
+        if sp.issparse(adj) and self.adj_dim is None:
             adj = np.asarray(adj.todense())
         self.init_model(adj, x)
         self._pretrain(adj, x, x_raw, n_counts, epochs=pretrain_epochs, info_step=info_step, lr=lr, w_a=w_a, w_x=w_x, w_d=w_d,
@@ -226,7 +256,7 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
         x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(self.device)
         n_counts = np.asarray(n_counts, dtype=np.float64)
         scale_factor = torch.as_tensor(n_counts / np.median(n_counts)).to(self.device)
-        adj_t = torch.as_tensor(np.asarray(adj), dtype=torch.float32).to(self.device)
+        adj_t = None if self.adj_dim is not None else torch.as_tensor(np.asarray(adj), dtype=torch.float32).to(self.device)
         # cluster centres from kmeans on the embedding — computed WITHOUT edge weights, as the reference does (:313-314)
         kmeans = KMeans(self.n_clusters, n_init=20)
         z = self.encoder2(self.g_n, self.encoder1(self.g_n, x))
@@ -245,7 +275,7 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
             # the "cluster loss" of :343-346 is a KL between two constant label vectors: it carries no gradient, but its value
             # (possibly nan / inf) is added to the loss exactly as the reference does
             cluster_loss = torch.mean(F.kl_div(torch.as_tensor(self.y_pred, dtype=torch.float32).to(self.device), y_t, reduction="batchmean"))
-            loss = w_a * torch.mean(F.mse_loss(adj_out, adj_t)) + w_x * self.zinb_loss(x_raw, mean, disp, pi, scale_factor) + w_c * cluster_loss
+            loss = w_a * self.adj_loss(adj_out, adj_t) + w_x * self.zinb_loss(x_raw, mean, disp, pi, scale_factor) + w_c * cluster_loss
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()

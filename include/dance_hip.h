@@ -358,6 +358,13 @@ DH_API int dh_gram_sigmoid_supported(int64_t n, int64_t d);
 DH_API size_t dh_gram_sigmoid_workspace_bytes(int64_t n, int64_t d);
 DH_API int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
                         void* workspace, size_t workspace_bytes, dh_stream_t stream);
+/* The same pass for another element function f of the logits (rowloss[i] = sum_j f(x_ij), O[i] = sum_j f'(x_ij) z_j):
+ * DH_GRAM_SOFTPLUS = dh_gram_sigmoid_f32; DH_GRAM_SIGMOID_SQ: f = sigmoid^2 — the dense part sum_ij sigmoid(x_ij)^2 of scTAG's
+ * adjacency reconstruction loss mean((sigmoid(z0 z0^T) - adj)^2) (sctag.py:470-471, :254), whose sparse part
+ * (-2 a_ij sigmoid(x_ij) + a_ij^2 on the edges) is an SDDMM (dh_sddmm_csr_f32): the N x N matrix never exists.          */
+enum dh_gram_mode { DH_GRAM_SOFTPLUS = 0, DH_GRAM_SIGMOID_SQ = 1 };
+DH_API int dh_gram_pairwise_f32(int mode, int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
+                         void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 /* The y = 1 entries of the same loss (graphsc.py:208-214: the non-zeros of adj[dst][:, dst]), listed as (us[e], vs[e]), each at
  * most once: forward xe[e] = <z_us, z_vs>, term[e] = pos_weight * softplus(-xe) - softplus(xe) (add sum(term) to sum(rowloss));
@@ -491,6 +498,21 @@ DH_API int dh_relu_backward_bf16(int64_t n_rows, int64_t width, const uint16_t* 
                           const uint16_t* dY, int64_t lddy, uint16_t* G, int64_t ldg, dh_stream_t stream);
 DH_API int dh_colsum_bf16(int64_t n_rows, int64_t width, const uint16_t* X, int64_t ldx, float* out,
                    void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
+/* ---- fused zero-inflated negative-binomial NLL (zinb.hip) ---------------------------------------------------------------
+ * ZINBLoss.forward of dance/utils/loss.py:780-829 (scTAG sctag.py:254,347; scDSC scdsc.py:279-283; scHeteroNet
+ * scheteronet.py:289-336): ~25 elementwise torch passes over four N x G matrices, in float64 after the size factors promote
+ * the expression.  forward: one read of X (raw counts), mean, disp, pi (fp32, row-major) -> rowloss[i] = sum_g loss(i, g) in
+ * float64 (the caller takes sum / (n g)); backward: recomputes the element terms and writes d mean, d disp, d pi (fp32,
+ * leading dimension ldo) times *upstream (a DEVICE float64 scalar = grad_output / (n g)).  scale_factor: float64 [n] or NULL (= 1);
+ * element arithmetic in float64 (lgamma / digamma / log / pow), as the reference's promoted expression.                     */
+DH_API int dh_zinb_nll_forward_f32(int64_t n, int64_t n_genes, const float* X, int64_t ldx, const float* mean, int64_t ldm,
+                            const float* disp, int64_t ldd, const float* pi, int64_t ldp, const double* scale_factor,
+                            double ridge_lambda, double* rowloss, dh_stream_t stream);
+DH_API int dh_zinb_nll_backward_f32(int64_t n, int64_t n_genes, const float* X, int64_t ldx, const float* mean, int64_t ldm,
+                             const float* disp, int64_t ldd, const float* pi, int64_t ldp, const double* scale_factor,
+                             double ridge_lambda, const double* upstream, float* d_mean, float* d_disp, float* d_pi, int64_t ldo,
+                             dh_stream_t stream);
 
 /* ---- multi-GPU: RCCL over xGMI, one process per GPU ------------------------------------------------
  * The reference has no multi-GPU path for these models; the sharded layer replaces the single-process torch.spmm / autograd

@@ -195,6 +195,43 @@ def gram_sigmoid(Z):
 ATT_SIGMOID, ATT_LEAKY_RELU = 0, 1
 
 
+def _zinb_elements(x, mean, disp, pi, sf, ridge):
+    """The reference's formula (dance/utils/loss.py:814-826) in float64, per element."""
+    eps = 1e-10
+    x, mean, disp, pi = x.double(), mean.double(), disp.double(), pi.double()
+    if sf is not None:
+        mean = mean * sf.double()[:, None]
+    lg = torch.lgamma
+    t1 = lg(disp + eps) + lg(x + 1.0) - lg(x + disp + eps)
+    t2 = (disp + x) * torch.log(1.0 + (mean / (disp + eps))) + (x * (torch.log(disp + eps) - torch.log(mean + eps)))
+    nb_case = t1 + t2 - torch.log(1.0 - pi + eps)
+    zero_nb = torch.pow(disp / (disp + mean + eps), disp)
+    zero_case = -torch.log(pi + ((1.0 - pi) * zero_nb) + eps)
+    out = torch.where(x <= 1e-8, zero_case, nb_case)
+    return out + ridge * pi * pi if ridge > 0 else out
+
+
+def zinb_nll_forward(X, mean, disp, pi, scale_factor, ridge_lambda=0.0):
+    return _zinb_elements(X, mean, disp, pi, scale_factor, ridge_lambda).sum(1)
+
+
+def zinb_nll_backward(X, mean, disp, pi, scale_factor, ridge_lambda, upstream):
+    m, d, p = (t.detach().double().requires_grad_(True) for t in (mean, disp, pi))
+    with torch.enable_grad():
+        total = _zinb_elements(X, m, d, p, scale_factor, ridge_lambda).sum()
+    gm, gd, gp = torch.autograd.grad(total, (m, d, p))
+    up = upstream.reshape(())
+    return (gm * up).float(), (gd * up).float(), (gp * up).float()
+
+
+def gram_pairwise(Z, mode=0):
+    x = Z.double() @ Z.double().t()
+    sig = torch.sigmoid(x)
+    if mode == 0:
+        return torch.nn.functional.softplus(x).sum(1).float(), (sig @ Z.double()).float()
+    return (sig * sig).sum(1).float(), ((2 * sig * sig * (1 - sig)) @ Z.double()).float()
+
+
 def _edge_rows(rowptr):
     n = rowptr.numel() - 1
     return torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).to(torch.int64))
@@ -400,7 +437,7 @@ def umap_connectivities(knn_idx, knn_dist):
 
 
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
+STAND_INS = ("zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
              "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
