@@ -100,6 +100,10 @@ def _declare(lib):
         "dh_block_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_block_plan": (c_int, [i64, i64, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_block_fill": (c_int, [i64, i64, P, P, P, P, P, P, P, P, P, P, P, c_size_t, P]),
+        "dh_gcn_narrow_supported": (c_int, [i64, i64]),
+        "dh_gcn_narrow_forward_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, i64, P]),
+        "dh_gcn_narrow_backward_workspace_bytes": (c_size_t, [i64]),
+        "dh_gcn_narrow_backward_f32": (c_int, [i64, i64, i64, P, P, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_zinb_nll_forward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P]),
         "dh_zinb_nll_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P, P, P, i64, P]),
         "dh_comm_unique_id": (c_int, [P]),

@@ -1,0 +1,273 @@
+// The narrow GCN layer as two fused kernels (BASELINE config 5: SpaGCN's GraphConvolution 50 -> 50,
+// spagcn.py:357-363 ``spmm(adj, mm(input, weight)) + bias``; also any layer with in, out <= 64).
+//
+// At these widths a row is 200 bytes: the transform-then-aggregate chain of the wide layer (skinny GEMM, SpMM, and in backward
+// colsum, SpMM, split-K GEMM) is five launches of latency-bound kernels that together moved 1.85 GB of algorithmic traffic in
+// 2.40 ms (0.10 of the HBM roofline, round 2).  Here the layer is evaluated AGGREGATE-FIRST — (A X) W instead of A (X W): the same
+// function; fp32 rounding differs in the last bits, parity bar 1e-4 as for every layer (stated in DESIGN.md §3, SURVEY.md §8d
+// "D = F only if the builder chooses aggregate-first") — which makes the forward ONE gather kernel and the weight gradient ONE
+// streaming kernel:
+//
+//   forward : agg_i = sum_e a_e X[col_e, :]   (16 lanes x float4 per row, 4 rows per wavefront, 4 neighbours in flight per lane)
+//             y_i   = act(agg_i W + b)        (W in LDS; agg values broadcast inside the 16-lane group by ds_bpermute)
+//             agg is kept ([N, 64] fp32, column 63 = 1) for the backward.
+//   backward: [dW; db] = [agg | 1]^T (dY * [y > 0])   one pass over agg and dY on the fp32 matrix cores (v_mfma_f32_32x32x2_f32,
+//             K = rows: every wavefront owns a contiguous run of rows and a 64 x 64 accumulator), partial tiles reduced in fixed
+//             order: deterministic.  The ones column makes db row 63 of the same product.
+//   (dX = A^T ((dY * mask) W^T), needed only when the layer's input requires a gradient, stays on the generic kernels.)
+#include "common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int NW = 64;        // padded width of agg / W rows
+constexpr int LDW = NW + 4;   // LDS row stride of W (float4-aligned, rows 4 banks apart)
+
+// VEC = 4: 16 lanes per row (X rows 16-byte aligned); VEC = 2: 32 lanes per row (8-byte aligned rows, e.g. ld = 50)
+template <int VEC>
+__global__ __launch_bounds__(256) void gcn_narrow_forward_kernel(int64_t n_rows, int F, int H, const int32_t* __restrict__ rowptr,
+                                                                 const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                                 const float* __restrict__ X, int64_t ldx, const float* __restrict__ W, int64_t ldw,
+                                                                 const float* __restrict__ bias, int act, float* __restrict__ AGG,
+                                                                 float* __restrict__ Y, int64_t ldy) {
+  constexpr int G = NW / VEC;            // lanes per row
+  constexpr int RPB = 256 / G;           // rows per block
+  using V = typename std::conditional<VEC == 4, f32x4, f32x2>::type;
+  __shared__ __attribute__((aligned(16))) float Ws[NW * LDW];
+  for (int i = threadIdx.x; i < NW * LDW; i += 256) {
+    const int f = i / LDW, j = i - f * LDW;
+    Ws[i] = (f < F && j < H) ? W[(int64_t)f * ldw + j] : 0.f;
+  }
+  __syncthreads();
+  const int g = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  if (row >= n_rows) return;  // whole groups leave together (after the only barrier)
+  const int c0 = g * VEC;
+  V acc = V(0.f);
+  const int s = rowptr[row], t = rowptr[row + 1];
+  auto xrow = [&](int ck) -> V {
+    V v = V(0.f);
+    if (c0 < F) {  // lanes beyond the row's width hold zeros; a partial vector at the end is masked below
+      v = *reinterpret_cast<const V*>(X + (int64_t)ck * ldx + c0);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i)
+        if (c0 + i >= F) v[i] = 0.f;
+    }
+    return v;
+  };
+  for (int base = s; base < t; base += G) {
+    const int e = base + g;
+    int c = 0;
+    float w = 0.f;
+    if (e < t) {
+      c = col[e];
+      w = val ? val[e] : 1.f;
+    }
+    const int cnt = min(G, t - base);
+    int k = 0;
+    for (; k + 4 <= cnt; k += 4) {
+      int ck[4];
+      float wk[4];
+      V z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ck[u] = __shfl(c, k + u, G);
+        wk[u] = __shfl(w, k + u, G);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[u] = xrow(ck[u]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk[u], z[u][i], acc[i]);
+    }
+    for (; k < cnt; ++k) {
+      const int ck = __shfl(c, k, G);
+      const float wk = __shfl(w, k, G);
+      const V z = xrow(ck);
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk, z[i], acc[i]);
+    }
+  }
+  if (AGG) {  // [n_rows, 64]: the aggregated row, zero padded, with a 1 in column 63 (the bias row of the backward product)
+    V a = acc;
+    if (F < NW && c0 + VEC == NW) a[VEC - 1] = 1.f;
+    *reinterpret_cast<V*>(AGG + row * NW + c0) = a;
+  }
+  // y[c0 .. c0 + VEC) = sum_f agg_f W[f][c0 ..] + b: agg_f lives in lane f / VEC of the group, component f % VEC
+  V y = V(0.f);
+#pragma unroll
+  for (int fq = 0; fq < NW / VEC; ++fq) {
+    if (fq * VEC >= F) break;  // uniform
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      const float a = __shfl(acc[i], fq, G);
+      const V wv = *reinterpret_cast<const V*>(Ws + (fq * VEC + i) * LDW + c0);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) y[j] = fmaf(a, wv[j], y[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    const int cj = c0 + j;
+    if (cj < H) {
+      float v = y[j] + (bias ? bias[cj] : 0.f);
+      if (act == DH_ACT_RELU) v = fmaxf(v, 0.f);
+      Y[row * ldy + cj] = v;
+    }
+  }
+}
+
+// partial[b] (64 x 64) = sum over the block's rows of agg_r^T g_r,  g = dY (* [y > 0]); see the file header
+__global__ __launch_bounds__(256) void gcn_narrow_backward_kernel(int64_t n_rows, int H, int64_t rows_per_wave, const float* __restrict__ AGG,
+                                                                  const float* __restrict__ dY, int64_t ldd, const float* __restrict__ Yact,
+                                                                  int64_t ldy, float* __restrict__ partial) {
+  __shared__ float red[3][NW * NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i32 = lane & 31, h = lane >> 5;
+  const int64_t w_global = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t r_begin = w_global * rows_per_wave;
+  const int64_t r_end = min(n_rows, r_begin + rows_per_wave);
+  f32x16 c[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[a][b][r] = 0.f;
+  const bool j1 = i32 + 32 < H, j0 = i32 < H;
+  auto gload = [&](int64_t r, int j, bool ok) -> float {
+    if (r >= r_end || !ok) return 0.f;
+    float v = dY[r * ldd + j];
+    if (Yact && !(Yact[r * ldy + j] > 0.f)) v = 0.f;
+    return v;
+  };
+  constexpr int U = 8;  // k-steps (of 2 rows) in flight
+  for (int64_t r0 = r_begin; r0 < r_end; r0 += 2 * U) {
+    float a0[U], a1[U], g0[U], g1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = r0 + 2 * u + h;
+      const bool in = r < r_end;
+      a0[u] = in ? AGG[r * NW + i32] : 0.f;
+      a1[u] = in ? AGG[r * NW + 32 + i32] : 0.f;
+      g0[u] = gload(r, i32, j0);
+      g1[u] = gload(r, i32 + 32, j1);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      c[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], g0[u], c[0][0], 0, 0, 0);
+      c[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], g1[u], c[0][1], 0, 0, 0);
+      c[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], g0[u], c[1][0], 0, 0, 0);
+      c[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], g1[u], c[1][1], 0, 0, 0);
+    }
+  }
+  // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Waves 1..3 park their tile in
+  // LDS, wave 0 adds them in order and writes the block's partial: fixed summation order.
+  auto at = [&](int a, int b, int r) -> int { return (32 * a + (r & 3) + 8 * (r >> 2) + 4 * h) * NW + 32 * b + i32; };
+  if (wave > 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][at(a, b, r)] = c[a][b][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* out = partial + (int64_t)blockIdx.x * NW * NW;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = at(a, b, r);
+          out[p] = ((c[a][b][r] + red[0][p]) + red[1][p]) + red[2][p];
+        }
+  }
+}
+
+__global__ __launch_bounds__(256) void gcn_narrow_reduce_kernel(int n_blocks, int F, int H, const float* __restrict__ partial, float* __restrict__ dW,
+                                                                int64_t ldw, float* __restrict__ db) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= NW * NW) return;
+  const int f = p / NW, j = p - f * NW;
+  const bool is_w = f < F && j < H, is_b = db && f == NW - 1 && j < H;
+  if (!is_w && !is_b) return;
+  float acc = 0.f;
+  for (int b = 0; b < n_blocks; ++b) acc += partial[(int64_t)b * NW * NW + p];
+  if (is_w) dW[(int64_t)f * ldw + j] = acc;
+  if (is_b) db[j] = acc;
+}
+
+int plan_blocks(int64_t n_rows) {  // one block per 2048 rows, at most 1024 blocks (16 MB of partial tiles)
+  int64_t b = dh::ceil_div(n_rows, 2048);
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+}  // namespace
+
+extern "C" int dh_gcn_narrow_supported(int64_t in_features, int64_t out_features) {
+  return in_features >= 1 && in_features < NW && out_features >= 1 && out_features <= NW;  // column 63 of agg carries the bias row
+}
+
+extern "C" int dh_gcn_narrow_forward_f32(int64_t n_rows, int64_t n_cols, int64_t in_features, int64_t out_features, const int32_t* rowptr,
+                                         const int32_t* col, const float* val, const float* X, int64_t ldx, const float* W, int64_t ldw,
+                                         const float* bias, int act, float* agg, float* Y, int64_t ldy, dh_stream_t stream) {
+  if (n_rows < 0 || n_cols < 0) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: negative size");
+  if (!dh_gcn_narrow_supported(in_features, out_features))
+    return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: widths %lld -> %lld outside [1, 63] x [1, 64]", (long long)in_features, (long long)out_features);
+  if (n_rows == 0) return DH_OK;
+  if (!rowptr || !X || !W || !Y) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: null pointer");
+  if (ldx < in_features || ldw < out_features || ldy < out_features) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: leading dimension too small");
+  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: bad act %d", act);
+  if (agg && !dh::aligned16(agg)) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: agg must be 16-byte aligned");
+  hipStream_t st = dh::as_stream(stream);
+  // a float4 lane may read up to 3 floats past column F - 1 of a row: inside the row's stride when ldx >= round_up(F, 4)
+  const bool v4 = dh::aligned16(X) && ldx % 4 == 0 && ldx >= ((in_features + 3) & ~(int64_t)3);
+  const bool v2 = ((uintptr_t)X % 8 == 0) && ldx % 2 == 0 && ldx >= ((in_features + 1) & ~(int64_t)1);
+  if (v4)
+    hipLaunchKernelGGL(gcn_narrow_forward_kernel<4>, dim3((unsigned)dh::ceil_div(n_rows, 16)), dim3(256), 0, st, n_rows, (int)in_features,
+                       (int)out_features, rowptr, col, val, X, ldx, W, ldw, bias, act, agg, Y, ldy);
+  else if (v2)
+    hipLaunchKernelGGL(gcn_narrow_forward_kernel<2>, dim3((unsigned)dh::ceil_div(n_rows, 8)), dim3(256), 0, st, n_rows, (int)in_features,
+                       (int)out_features, rowptr, col, val, X, ldx, W, ldw, bias, act, agg, Y, ldy);
+  else
+    return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: X rows must be 8-byte aligned with an even leading dimension >= round_up(in, 2)");
+  return dh::check_launch("dh_gcn_narrow_forward_f32");
+}
+
+extern "C" size_t dh_gcn_narrow_backward_workspace_bytes(int64_t n_rows) {
+  return n_rows <= 0 ? 0 : (size_t)plan_blocks(n_rows) * NW * NW * sizeof(float);
+}
+
+extern "C" int dh_gcn_narrow_backward_f32(int64_t n_rows, int64_t in_features, int64_t out_features, const float* agg, const float* dY, int64_t ldd,
+                                          const float* Y_act, int64_t ldy, float* dW, int64_t ldw, float* db, void* workspace,
+                                          size_t workspace_bytes, dh_stream_t stream) {
+  if (n_rows < 0) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_backward_f32: negative size");
+  if (!dh_gcn_narrow_supported(in_features, out_features)) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_backward_f32: unsupported widths");
+  if (!dW || ldw < out_features) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_backward_f32: bad dW");
+  hipStream_t st = dh::as_stream(stream);
+  if (n_rows == 0) {
+    (void)hipMemset2DAsync(dW, ldw * sizeof(float), 0, out_features * sizeof(float), in_features, st);
+    if (db) (void)hipMemsetAsync(db, 0, out_features * sizeof(float), st);
+    return DH_OK;
+  }
+  if (!agg || !dY || ldd < out_features || (Y_act && ldy < out_features)) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_backward_f32: bad operand");
+  const int blocks = plan_blocks(n_rows);
+  if (!workspace || workspace_bytes < (size_t)blocks * NW * NW * sizeof(float))
+    return dh::fail(DH_ERR_WORKSPACE, "dh_gcn_narrow_backward_f32: workspace too small (dh_gcn_narrow_backward_workspace_bytes)");
+  int64_t rows_per_wave = dh::ceil_div(n_rows, (int64_t)blocks * 4);
+  rows_per_wave = (rows_per_wave + 1) & ~(int64_t)1;  // a k-step is two rows
+  float* partial = static_cast<float*>(workspace);
+  hipLaunchKernelGGL(gcn_narrow_backward_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_rows, (int)out_features, rows_per_wave, agg, dY, ldd,
+                     Y_act, ldy, partial);
+  int rc = dh::check_launch("dh_gcn_narrow_backward_f32");
+  if (rc != DH_OK) return rc;
+  hipLaunchKernelGGL(gcn_narrow_reduce_kernel, dim3(NW * NW / 256), dim3(256), 0, st, blocks, (int)in_features, (int)out_features, partial, dW, ldw, db);
+  return dh::check_launch("dh_gcn_narrow_backward_f32 (reduce)");
+}

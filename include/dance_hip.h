@@ -499,6 +499,25 @@ DH_API int dh_relu_backward_bf16(int64_t n_rows, int64_t width, const uint16_t* 
 DH_API int dh_colsum_bf16(int64_t n_rows, int64_t width, const uint16_t* X, int64_t ldx, float* out,
                    void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* ---- the narrow GCN layer fused (gcn_narrow.hip): in < 64, out <= 64 -----------------------------------------------------
+ * SpaGCN's GraphConvolution 50 -> 50 (spagcn.py:357-363: spmm(adj, mm(input, weight)) + bias) and any layer of that size,
+ * evaluated aggregate-first — (A X) W + b, the same function as A (X W) + b — so that the forward is ONE gather kernel and the
+ * weight / bias gradient ONE streaming kernel on the fp32 matrix cores (instead of skinny GEMM + SpMM, resp. colsum + SpMM +
+ * split-K GEMM).  forward: Y = act((A X) W + bias); if agg != NULL it receives [n_rows, 64] fp32 (16-byte aligned): the
+ * aggregated rows, zero padded, column 63 = 1 — the operand of the backward.  X rows 8-byte aligned (16-byte: four rows per
+ * wavefront instead of two).  backward: dW [in, out] = agg^T G, db [out] = 1^T G (db may be NULL) with G = dY, or
+ * dY * [Y_act > 0] when Y_act (the layer's ReLU output) is given; deterministic.  workspace: dh_gcn_narrow_backward_workspace_bytes.
+ * The input gradient A^T (G W^T), when needed, is dh_gemm_f32 + dh_spmm_csr_f32.                                          */
+DH_API int dh_gcn_narrow_supported(int64_t in_features, int64_t out_features);
+DH_API int dh_gcn_narrow_forward_f32(int64_t n_rows, int64_t n_cols, int64_t in_features, int64_t out_features,
+                              const int32_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t ldx,
+                              const float* W, int64_t ldw, const float* bias, int act, float* agg, float* Y, int64_t ldy,
+                              dh_stream_t stream);
+DH_API size_t dh_gcn_narrow_backward_workspace_bytes(int64_t n_rows);
+DH_API int dh_gcn_narrow_backward_f32(int64_t n_rows, int64_t in_features, int64_t out_features, const float* agg,
+                               const float* dY, int64_t ldd, const float* Y_act, int64_t ldy, float* dW, int64_t ldw, float* db,
+                               void* workspace, size_t workspace_bytes, dh_stream_t stream);
+
 /* ---- fused zero-inflated negative-binomial NLL (zinb.hip) ---------------------------------------------------------------
  * ZINBLoss.forward of dance/utils/loss.py:780-829 (scTAG sctag.py:254,347; scDSC scdsc.py:279-283; scHeteroNet
  * scheteronet.py:289-336): ~25 elementwise torch passes over four N x G matrices, in float64 after the size factors promote

@@ -81,6 +81,8 @@ EXTRA_PARAMS_OK = {
     ("GNN", "__init__"): {"compute_dtype"},                   # bf16 storage mode of BASELINE config 3 (default fp32)
     ("HeteroNet", "__init__"): {"remove_self_loops"},         # the discarded remove_diag of scheteronet.py:522 (default: as written)
     ("HetConv", "__init__"): {"args", "kwargs"},
+    ("ScTAG", "__init__"): {"adj_dim"},                       # scalable adjacency decoder width (default None = the reference's N)
+    ("ScTAG", "init_model"): set(),
     ("GCNAE", "forward"): {"decode"},                         # fused decoder loss path skips the B x B logits (default: build them)
     ("NeighborGraph", "__init__"): {"device", "reorder"},
     ("HeteronetGraph", "__init__"): {"device"},
