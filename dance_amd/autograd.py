@@ -30,6 +30,12 @@ from .graph import CSRGraph
 BWD_MASK_MODE = os.environ.get("DANCE_AMD_BWD_MASK", "premask")
 
 
+# Narrow layers (in < 64, out <= 64: SpaGCN's 50 -> 50 GraphConvolution, BASELINE config 5) run aggregate-first on two fused
+# kernels (csrc/gcn_narrow.hip) from NARROW_MIN_ROWS rows on; DANCE_AMD_NARROW_FUSED=0 keeps the generic transform-first chain.
+NARROW_FUSED = os.environ.get("DANCE_AMD_NARROW_FUSED", "1") != "0"
+NARROW_MIN_ROWS = 4096
+
+
 # Software pipeline of the wide fused layer (relu(A (X W)), width % 128 == 0).  The GEMM is bound by the matrix cores and the
 # aggregation by HBM, and they saturate different units of a CU — but run one after the other they add up (the serial floor
 # of the headline: 26.0 ms of MFMA time + 8.2 ms of HBM time).  The aggregation is column-sliced anyway (128-column passes,
@@ -120,6 +126,17 @@ class _GCNLayerFn(torch.autograd.Function):
                 active: bool, rowscale: Optional[torch.Tensor], colscale: Optional[torch.Tensor], reduce: int):
         x = x.contiguous() if x.stride(-1) != 1 else x
         w = weight.contiguous()
+        ctx.narrow = False
+        if (NARROW_FUSED and rowscale is None and colscale is None and reduce == kernels.REDUCE_SUM and graph.n_rows >= NARROW_MIN_ROWS
+                and kernels.gcn_narrow_supported(w.shape[0], w.shape[1]) and x.stride(0) % 2 == 0 and x.data_ptr() % 8 == 0):
+            # narrow layer (in < 64, out <= 64): aggregate-first, one gather kernel forward, one streaming kernel for dW / db
+            out, agg = kernels.gcn_narrow_forward(graph.rowptr, graph.col, graph.val, x, w, bias, kernels.ACT_RELU if active else kernels.ACT_NONE,
+                                                  n_cols=graph.n_cols, want_agg=weight.requires_grad or (bias is not None and bias.requires_grad))
+            ctx.narrow, ctx.slices = True, None
+            ctx.graph, ctx.active, ctx.has_bias = graph, active, bias is not None
+            ctx.rowscale, ctx.colscale, ctx.reduce = None, None, reduce
+            ctx.save_for_backward(x, w, out if active else None, agg)
+            return out
         # ReLU fused into both SpMMs (sign mask instead of G = dY*[Y>0] in HBM) for the plain wide-layer case
         mask = None
         fused = (active and bias is None and rowscale is None and colscale is None and reduce == kernels.REDUCE_SUM
@@ -153,6 +170,16 @@ class _GCNLayerFn(torch.autograd.Function):
         need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         dy = dy.contiguous() if dy.stride(-1) != 1 else dy
         dx = dw = db = None
+        if ctx.narrow:
+            agg = mask  # fourth saved slot: the aggregated rows [n, 64]
+            if need_w or need_b:
+                dw, db = kernels.gcn_narrow_backward(agg, dy, w.shape[0], y_act=out if ctx.active else None, want_bias=need_b)
+                dw = dw if need_w else None
+            if need_x:  # d x = A^T ((dy * [y > 0]) W^T): the generic kernels at width `in`
+                g = kernels.relu_backward(out, dy) if ctx.active else dy
+                gt = ctx.graph.transpose()
+                dx = kernels.spmm_csr(gt.rowptr, gt.col, gt.val, kernels.gemm(g, w, trans_b=True), n_cols=gt.n_cols, tag="spmm_csr_f32[bwd]")
+            return dx, dw, db, None, None, None, None, None
         if mask is not None:  # fused ReLU backward: dS = A^T (dy * [out > 0]) in one gather
             if need_x or need_w:
                 gt = ctx.graph.transpose()

@@ -319,6 +319,39 @@ def gram_sigmoid_supported(n: int, d: int) -> bool:
     return bool(_lib_ready().dh_gram_sigmoid_supported(int(n), int(d)))
 
 
+def gcn_narrow_supported(in_features: int, out_features: int) -> bool:
+    return bool(_lib_ready().dh_gcn_narrow_supported(int(in_features), int(out_features)))
+
+
+def gcn_narrow_forward(rowptr, col, val, X, W, bias=None, act: int = ACT_NONE, *, n_cols: Optional[int] = None, want_agg: bool = True):
+    """(Y, agg): Y = act((A X) W + bias) in one gather kernel (dh_gcn_narrow_forward_f32); agg [n_rows, 64] = the aggregated rows
+    (zero padded, column 63 = 1), the operand of ``gcn_narrow_backward``."""
+    lib = _lib_ready()
+    n_rows = rowptr.numel() - 1
+    f, h = W.shape
+    y = torch.empty((n_rows, h), dtype=torch.float32, device=X.device)
+    agg = torch.empty((n_rows, 64), dtype=torch.float32, device=X.device) if want_agg else None
+    _call("gcn_narrow_forward_f32", lib.dh_gcn_narrow_forward_f32, n_rows, X.shape[0] if n_cols is None else n_cols, f, h,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
+          _dev(X, torch.float32, "X", 2), _ld(X), _dev(W, torch.float32, "W", 2), _ld(W), _dev(bias, torch.float32, "bias", 1), act,
+          None if agg is None else agg.data_ptr(), y.data_ptr(), _ld(y), _stream())
+    return y, agg
+
+
+def gcn_narrow_backward(agg, dY, in_features: int, *, y_act: Optional[torch.Tensor] = None, want_bias: bool = True):
+    """(dW [in, out], db [out] or None) = [agg | 1]^T (dY * [y_act > 0]) in one streaming pass (dh_gcn_narrow_backward_f32)."""
+    lib = _lib_ready()
+    n_rows, h = dY.shape
+    dw = torch.empty((in_features, h), dtype=torch.float32, device=dY.device)
+    db = torch.empty(h, dtype=torch.float32, device=dY.device) if want_bias else None
+    ws_bytes = lib.dh_gcn_narrow_backward_workspace_bytes(n_rows)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dY.device)
+    _call("gcn_narrow_backward_f32", lib.dh_gcn_narrow_backward_f32, n_rows, in_features, h, _dev(agg, torch.float32, "agg", 2),
+          _dev(dY, torch.float32, "dY", 2), _ld(dY), _dev(y_act, torch.float32, "y_act", 2), 0 if y_act is None else _ld(y_act), dw.data_ptr(),
+          _ld(dw), None if db is None else db.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+    return dw, db
+
+
 def zinb_nll_forward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float = 0.0) -> torch.Tensor:
     """rowloss [n] float64 of the zero-inflated negative-binomial NLL (dh_zinb_nll_forward_f32); the loss is its sum / (n g)."""
     lib = _lib_ready()

@@ -195,6 +195,31 @@ def gram_sigmoid(Z):
 ATT_SIGMOID, ATT_LEAKY_RELU = 0, 1
 
 
+def gcn_narrow_supported(in_features, out_features):
+    return 1 <= in_features < 64 and 1 <= out_features <= 64
+
+
+def gcn_narrow_forward(rowptr, col, val, X, W, bias=None, act=ACT_NONE, *, n_cols=None, want_agg=True):
+    n = rowptr.numel() - 1
+    agg = _spmm_full(rowptr, col, val, X.contiguous(), n_cols, None, None, None, ACT_NONE, REDUCE_SUM)
+    y = agg.double() @ W.double()
+    if bias is not None:
+        y = y + bias.double()
+    y = (torch.relu(y) if act == ACT_RELU else y).float()
+    if not want_agg:
+        return y, None
+    pad = torch.zeros((n, 64), dtype=torch.float32)
+    pad[:, :agg.shape[1]] = agg
+    pad[:, 63] = 1.0
+    return y, pad
+
+
+def gcn_narrow_backward(agg, dY, in_features, *, y_act=None, want_bias=True):
+    g = dY.double() if y_act is None else torch.where(y_act > 0, dY, torch.zeros_like(dY)).double()
+    full = agg.double().t() @ g
+    return full[:in_features].float(), (full[63].float() if want_bias else None)
+
+
 def _zinb_elements(x, mean, disp, pi, sf, ridge):
     """The reference's formula (dance/utils/loss.py:814-826) in float64, per element."""
     eps = 1e-10
@@ -437,7 +462,7 @@ def umap_connectivities(knn_idx, knn_dist):
 
 
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
+STAND_INS = ("gcn_narrow_supported", "gcn_narrow_forward", "gcn_narrow_backward", "zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
              "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
