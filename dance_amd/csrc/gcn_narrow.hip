@@ -84,12 +84,25 @@ __global__ __launch_bounds__(256) void gcn_narrow_forward_kernel(int64_t n_rows,
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk[u], z[u][i], acc[i]);
     }
-    for (; k < cnt; ++k) {
-      const int ck = __shfl(c, k, G);
-      const float wk = __shfl(w, k, G);
-      const V z = xrow(ck);
+    const int rem = cnt - k;  // 0..3 neighbours left: their loads go out together as well (one memory round trip, not three)
+    if (rem > 0) {
+      int ck[3];
+      float wk[3];
+      V z[3];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk, z[i], acc[i]);
+      for (int u = 0; u < 3; ++u) {
+        ck[u] = __shfl(c, min(k + u, G - 1), G);  // lanes beyond cnt hold c = 0, w = 0
+        wk[u] = __shfl(w, min(k + u, G - 1), G);
+      }
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (u < rem) z[u] = xrow(ck[u]);
+#pragma unroll
+      for (int u = 0; u < 3; ++u)
+        if (u < rem) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk[u], z[u][i], acc[i]);
+        }
     }
   }
   if (AGG) {  // [n_rows, 64]: the aggregated row, zero padded, with a 1 in column 63 (the bias row of the backward product)
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(256) void gcn_narrow_forward_kernel(int64_t n_rows,
 __global__ __launch_bounds__(256) void gcn_narrow_backward_kernel(int64_t n_rows, int H, int64_t rows_per_wave, const float* __restrict__ AGG,
                                                                   const float* __restrict__ dY, int64_t ldd, const float* __restrict__ Yact,
                                                                   int64_t ldy, float* __restrict__ partial) {
-  __shared__ float red[3][NW * NW];
+  __shared__ float red[NW * NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i32 = lane & 31, h = lane >> 5;
   const int64_t w_global = (int64_t)blockIdx.x * 4 + wave;
@@ -168,15 +181,28 @@ __global__ __launch_bounds__(256) void gcn_narrow_backward_kernel(int64_t n_rows
   // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).  Waves 1..3 park their tile in
   // LDS, wave 0 adds them in order and writes the block's partial: fixed summation order.
   auto at = [&](int a, int b, int r) -> int { return (32 * a + (r & 3) + 8 * (r >> 2) + 4 * h) * NW + 32 * b + i32; };
-  if (wave > 0) {
+  // waves 1, 2, 3 hand their tile to wave 0 through ONE 16 KB LDS tile, in that order (fixed summation order; 16 KB instead of
+  // 48 KB keeps ten blocks resident per CU, the first version's three left a half-empty second round of blocks)
+  for (int src = 1; src < 4; ++src) {
+    if (wave == src) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave - 1][at(a, b, r)] = c[a][b][r];
+          for (int r = 0; r < 16; ++r) red[at(a, b, r)] = c[a][b][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) c[a][b][r] += red[at(a, b, r)];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   if (wave == 0) {
     float* out = partial + (int64_t)blockIdx.x * NW * NW;
 #pragma unroll
@@ -184,10 +210,7 @@ __global__ __launch_bounds__(256) void gcn_narrow_backward_kernel(int64_t n_rows
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int p = at(a, b, r);
-          out[p] = ((c[a][b][r] + red[0][p]) + red[1][p]) + red[2][p];
-        }
+        for (int r = 0; r < 16; ++r) out[at(a, b, r)] = c[a][b][r];
   }
 }
 

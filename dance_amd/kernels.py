@@ -621,6 +621,8 @@ def dense_to_csr(X: torch.Tensor):
     nnz = int(rowptr[-1])
     col = torch.empty(nnz, dtype=torch.int32, device=X.device)
     val = torch.empty(nnz, dtype=torch.float32, device=X.device)
+    if nnz == 0:
+        return rowptr, col, val
     _call("dense_to_csr_f32", lib.dh_dense_to_csr_f32, n, m, _dev(X, torch.float32, "X", 2), _ld(X), rowptr.data_ptr(), col.data_ptr(),
           val.data_ptr(), _stream())
     return rowptr, col, val
