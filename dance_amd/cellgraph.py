@@ -246,6 +246,67 @@ class Block:
         return torch.arange(self._num_dst, device=self.rowptr.device)
 
 
+class StaticCellBlock(Block):
+    """The block of ``batch`` seed CELLS of a CellFeatureGraph-layout graph with STATIC shapes (dh_block_cells_static): sources =
+    [the seeds | all genes], exactly ``e_max`` stored entries, one padding destination row (index ``batch``) over the unused tail.
+    The buffers are owned by the block and refilled by ``rebuild()`` — a handful of launches without any host round trip, so a
+    whole training step over it can be captured as ONE hipGraph (``GraphSC.fit`` / ``ScDeepSort.fit``).  Layer outputs equal those
+    of the dgl.to_block-ordered block: the extra source rows (genes no seed expresses) have no edge."""
+
+    def __init__(self, parent: CellGeneGraph, batch: int):
+        from . import kernels
+        g = parent.gene_prefix()
+        if g < 0:
+            raise ValueError("StaticCellBlock needs the CellFeatureGraph node layout (genes first, then cells)")
+        dev = parent.device
+        deg = (parent.rowptr[g + 1:] - parent.rowptr[g:-1])
+        self.n_genes, self.batch = g, int(batch)
+        self.e_max = int(batch) * int(deg.max()) if deg.numel() else 0   # one host read per (graph, batch size), at set-up
+        self.seeds = torch.zeros(batch, dtype=torch.int64, device=dev)
+        self.seeds.copy_(torch.arange(g, g + batch, device=dev) if parent.number_of_nodes() >= g + batch else torch.full((batch, ), g, device=dev))
+        self.src_ids = torch.cat((self.seeds, torch.arange(g, dtype=torch.int64, device=dev)))  # tail constant, head = seeds (rebuild)
+        self.rowptr = torch.zeros(batch + 2, dtype=torch.int32, device=dev)
+        self.col = torch.zeros(self.e_max, dtype=torch.int32, device=dev)
+        self.val = torch.zeros(self.e_max, dtype=torch.float32, device=dev)
+        self.bad = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._ws = torch.empty(max(kernels.block_cells_static_workspace_bytes(batch), 1), dtype=torch.uint8, device=dev)
+        self._num_src, self._num_dst = batch + g, int(batch)
+        self.parent, self.dst_offset = parent, 0
+        self.gene_window = (batch, g)
+        self.pad_row = True  # CSR rows = num_dst + 1; consumers slice their output to num_dst rows
+        self.srcdata = _GatherFrame(parent.ndata, self.src_ids)
+        self.srcdata["_ID"] = self.src_ids
+        self.dstdata = _GatherFrame(parent.ndata, self.seeds)
+        self.dstdata["_ID"] = self.seeds
+        self.edata = _Frame(weight=self.val[:, None])
+
+    def rebuild(self):
+        """Refill the buffers for the ids currently in ``self.seeds`` (device only; capturable)."""
+        from . import kernels
+        self.src_ids[:self.batch].copy_(self.seeds)
+        kernels.block_cells_static(self.parent.rowptr, self.parent.col, self.parent.val, self.seeds, self.n_genes, self.rowptr, self.col, self.val,
+                                   self.bad, self._ws)
+        self.__dict__.pop("_wgc_scales", None)  # per-batch caches of the layers
+        self.__dict__.pop("_csr", None)
+        for frame in (self.srcdata, self.dstdata):  # gathered node data of the previous batch
+            for k in [k for k in dict.keys(frame) if k != "_ID"]:
+                dict.__delitem__(frame, k)
+        return self
+
+    def number_of_edges(self) -> int:
+        return self.e_max
+
+    def in_degrees(self) -> torch.Tensor:
+        return (self.rowptr[1:self.batch + 1] - self.rowptr[:self.batch]).to(torch.int64)
+
+    def out_degrees(self) -> torch.Tensor:
+        valid = (torch.arange(self.e_max, device=self.col.device) < self.rowptr[self.batch]).to(torch.int64)  # the padding tail counts nothing
+        return torch.zeros(self._num_src, dtype=torch.int64, device=self.col.device).index_add_(0, self.col.to(torch.int64), valid)
+
+    def has_zero_in_degree(self) -> bool:
+        return False  # every cell has its self loop
+
+
 def _full_in_block(g: CellGeneGraph, seeds: torch.Tensor) -> Block:
     """All in-edges of ``seeds``; source nodes = seeds first, then the remaining in-neighbours (ascending id).  Built by
     dh_block_plan / dh_block_fill (block.hip); the node bitmap and the node -> position table live on the graph and are

@@ -16,6 +16,8 @@
 //
 // `mark` (uint8[n_nodes], zero-initialised once) and `lut` (int32[n_nodes], never initialised) persist on the graph.  Seeds
 // must be unique (they are a batch of a permutation in every caller).
+#include <algorithm>
+
 #include "common.h"
 
 extern "C" size_t dh_exclusive_scan_i32_workspace_bytes(int64_t n);
@@ -204,5 +206,88 @@ extern "C" int dh_block_fill(int64_t n_nodes, int64_t n_seeds, const int64_t* se
   hipLaunchKernelGGL(block_others_kernel, dim3((unsigned)l.n_chunks), dim3(256), 0, st, n_nodes, n_seeds, mark, cbase, lut, src_ids);
   hipLaunchKernelGGL(block_fill_kernel, dim3((unsigned)dh::ceil_div(n_seeds, 4)), dim3(256), 0, st, n_seeds, seeds, rowptr, col, val, block_rowptr, lut,
                      block_col, block_val, src_ids);
+  return dh::check_launch(me);
+}
+
+// ---- static-shape block of seed CELLS of a CellFeatureGraph-layout graph (genes are nodes [0, G), every cell's in-edges are its
+// genes, ascending, then its own self loop) ---------------------------------------------------------------------------------------
+// Source list = [the B seeds | ALL G genes]: a superset of dgl.to_block's (genes no seed expresses get no edge, so every layer
+// output is unchanged), but of a size that does not depend on the batch — the block needs no marking / compaction, and no value
+// ever has to reach the host: every buffer has a static shape, so a whole training step on it can be captured as ONE hipGraph
+// (graph-sc / scDeepSort at the reference's batch sizes are launch-bound otherwise).
+//   rows 0 .. B-1 : the seeds' in-edges, column = B + gene id, resp. the row's own index for the self loop
+//   row  B        : a padding row owning the unused tail [nnz, E_max) of the edge arrays (column 0, value 0): the CSR always has
+//                   exactly E_max entries and B + 1 rows, its transpose is well defined, the padding contributes zeros.
+// bad[0] is set when a seed is not a cell of that layout (a non-gene in-neighbour other than the seed itself, or more than E_max
+// edges): the caller checks it once per epoch.
+namespace {
+
+__global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds, int64_t n_genes, int64_t e_max, const int64_t* __restrict__ seeds,
+                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const float* __restrict__ val, int32_t* __restrict__ brp,
+                                                                int32_t* __restrict__ bcol, float* __restrict__ bval, int32_t* __restrict__ bad) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i > n_seeds) return;
+  const int nnz = brp[n_seeds];
+  if (i == n_seeds) {  // the padding row: one wavefront is enough for its bookkeeping, the tail itself is cleared below
+    if (lane == 0) {
+      brp[n_seeds + 1] = (int32_t)e_max;
+      if (nnz > e_max) bad[0] = 1;
+    }
+    return;
+  }
+  const int64_t v = seeds[i];
+  const int s = rowptr[v], t = rowptr[v + 1], o = brp[i];
+  if (o + (t - s) > e_max) return;  // flagged by the padding row's wavefront
+  for (int e = lane; e < t - s; e += 64) {
+    const int c = col[s + e];
+    int bc;
+    if (c < n_genes) bc = (int)n_seeds + c;
+    else {
+      bc = (int)i;
+      if (c != v) bad[0] = 1;
+    }
+    bcol[o + e] = bc;
+    bval[o + e] = val ? val[s + e] : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void cells_static_pad_kernel(int64_t n_seeds, int64_t e_max, const int32_t* __restrict__ brp,
+                                                               int32_t* __restrict__ bcol, float* __restrict__ bval) {
+  const int64_t nnz = brp[n_seeds];
+  for (int64_t e = nnz + (int64_t)blockIdx.x * 256 + threadIdx.x; e < e_max; e += (int64_t)gridDim.x * 256) {
+    bcol[e] = 0;
+    bval[e] = 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t dh_block_cells_static_workspace_bytes(int64_t n_seeds) {
+  if (n_seeds <= 0) return 0;
+  return align256((size_t)n_seeds * 4) + align256(dh_exclusive_scan_i32_workspace_bytes(n_seeds));
+}
+
+extern "C" int dh_block_cells_static(int64_t n_seeds, int64_t n_genes, int64_t e_max, const int64_t* seeds, const int32_t* rowptr,
+                                     const int32_t* col, const float* val, int32_t* block_rowptr, int32_t* block_col, float* block_val,
+                                     int32_t* bad, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  const char* me = "dh_block_cells_static";
+  if (n_seeds <= 0 || n_genes < 0 || e_max < 0) return dh::fail(DH_ERR_INVALID, "%s: bad size", me);
+  if (!seeds || !rowptr || !col || !block_rowptr || !block_col || !block_val || !bad) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  const size_t deg_bytes = align256((size_t)n_seeds * 4);
+  if (!workspace || workspace_bytes < dh_block_cells_static_workspace_bytes(n_seeds))
+    return dh::fail(DH_ERR_WORKSPACE, "%s: workspace too small", me);
+  hipStream_t st = dh::as_stream(stream);
+  char* ws = static_cast<char*>(workspace);
+  int32_t* deg = reinterpret_cast<int32_t*>(ws);
+  hipLaunchKernelGGL(block_deg_kernel, dim3((unsigned)dh::ceil_div(n_seeds, 256)), dim3(256), 0, st, n_seeds, seeds, rowptr, deg);
+  const int rc = dh_exclusive_scan_i32(n_seeds, deg, block_rowptr, ws + deg_bytes, workspace_bytes - deg_bytes, stream);  // block_rowptr[0 .. B]
+  if (rc != DH_OK) return rc;
+  hipLaunchKernelGGL(cells_static_fill_kernel, dim3((unsigned)dh::ceil_div(n_seeds + 1, 4)), dim3(256), 0, st, n_seeds, n_genes, e_max, seeds, rowptr,
+                     col, val, block_rowptr, block_col, block_val, bad);
+  const unsigned pgrid = (unsigned)std::min<int64_t>(dh::ceil_div(e_max, 256), 1024);
+  if (pgrid > 0)
+    hipLaunchKernelGGL(cells_static_pad_kernel, dim3(pgrid), dim3(256), 0, st, n_seeds, e_max, block_rowptr, block_col, block_val);
   return dh::check_launch(me);
 }

@@ -779,6 +779,21 @@ def block_build(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Ten
     return brp, bcol, bval, src_ids
 
 
+def block_cells_static(rowptr, col, val, seeds: torch.Tensor, n_genes: int, brp: torch.Tensor, bcol: torch.Tensor, bval: torch.Tensor,
+                       bad: torch.Tensor, ws: torch.Tensor):
+    """dh_block_cells_static into caller-owned static buffers (brp int32 [B + 2], bcol int32 / bval f32 [E_max], bad int32 [1], ws
+    uint8): the block of seed cells over the sources [seeds | all genes], no host round trip (hipGraph-capturable)."""
+    lib = _lib_ready()
+    _call("block_cells_static", lib.dh_block_cells_static, seeds.numel(), int(n_genes), bcol.numel(), _dev(seeds, torch.int64, "seeds", 1),
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(val, torch.float32, "val", 1),
+          _dev(brp, torch.int32, "brp", 1), _dev(bcol, torch.int32, "bcol", 1), _dev(bval, torch.float32, "bval", 1),
+          _dev(bad, torch.int32, "bad", 1), ws.data_ptr(), ws.numel(), _stream())
+
+
+def block_cells_static_workspace_bytes(n_seeds: int) -> int:
+    return int(_lib_ready().dh_block_cells_static_workspace_bytes(int(n_seeds)))
+
+
 # ---- AdaptiveSAGE ------------------------------------------------------------------------------------------
 def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H) -> torch.Tensor:
     """neigh[v] = mean_e alpha[idx(e)] * w_e * H[src(e)] (dh_sage_aggregate_f32)."""

@@ -63,9 +63,17 @@ class WeightedGraphConv(nn.Module):
             cache[self._norm] = (colscale, rowscale)
         colscale, rowscale = cache[self._norm]
         relu = self._activation in (F.relu, torch.relu) or isinstance(self._activation, nn.ReLU)
-        g = CSRGraph(graph.rowptr, graph.col, graph.val, graph.number_of_dst_nodes(), graph.number_of_src_nodes())
+        n_dst = graph.number_of_dst_nodes()
+        pad = 1 if getattr(graph, "pad_row", False) else 0  # StaticCellBlock: one padding row behind the destinations
+        g = graph.__dict__.get("_csr")  # one CSRGraph (hence one transpose for the backward) per block, shared by both forwards of a batch
+        if g is None:
+            g = graph.__dict__["_csr"] = CSRGraph(graph.rowptr, graph.col, graph.val, n_dst + pad, graph.number_of_src_nodes())
+        if pad and rowscale is not None:
+            rowscale = torch.cat((rowscale, rowscale.new_ones(1)))
         rst = gcn_layer(feat, weight, g, self.bias, relu, rowscale=rowscale, colscale=colscale,
                         reduce=kernels.REDUCE_MEAN if agg == "mean" else kernels.REDUCE_SUM)
+        if pad:
+            rst = rst[:n_dst]
         if self._activation is not None and not relu:
             rst = self._activation(rst)
         return rst
@@ -245,6 +253,75 @@ if DECODER_MODE not in ("fused", "dense"):
     raise ValueError(f"DANCE_AMD_GRAPHSC_DECODER must be 'fused' or 'dense', got {DECODER_MODE!r}")
 
 
+# One hipGraph per training step (GraphSC.fit, single process, fused decoder, one layer, a CellFeatureGraph-layout graph whose seeds
+# are all cells): the static-shape block (cellgraph.StaticCellBlock), both forwards, the decoder loss, the backward and Adam are
+# captured once and replayed per batch — at the reference's batch size (128) a step is ~170 launches of microsecond kernels, i.e.
+# host-bound (1.36 ms / batch eager, profiles/r03e_ref_batch_epochs.json).  DANCE_AMD_HIPGRAPH=0 keeps the eager loop; the last,
+# short batch of an epoch always runs eagerly.
+HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
+HIPGRAPH_MIN_BATCHES = 8  # capturing costs a few eager steps: not worth it for toy runs
+
+
+class _CapturedStep:
+    """The training step of ``GraphSC.fit`` on a ``StaticCellBlock``, captured as one ``torch.cuda.CUDAGraph`` (= hipGraph)."""
+
+    def __init__(self, fit_self, g, batch_size: int, optim):
+        from ....cellgraph import StaticCellBlock
+        self.model, self.optim = fit_self.model, optim
+        self.block = StaticCellBlock(g, batch_size)
+        b = float(batch_size)
+        # the only edges among a batch's own cells are their self loops: adj = I, adj.sum() = B (graphsc.py:208-214)
+        self.pos_weight = (b * b - b) / b
+        self.norm = b * b / ((b * b - b) * 2) if batch_size > 1 else 1.0
+        self.diag = torch.arange(batch_size, dtype=torch.int32, device=g.device)
+        self.graph = None
+        self.emb = self.loss = None
+
+    def _step(self):
+        blk = self.block.rebuild()
+        x = blk.srcdata["features"]
+        _, emb = self.model.forward([blk], x, decode=False)  # :202
+        emb_out = emb.detach().clone()
+        _, emb2 = self.model.forward([blk], x, decode=False)  # :215, fresh dropout
+        loss = self.norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), self.diag, self.diag, self.pos_weight)
+        self.optim.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optim.step()
+        return emb_out, loss.detach()
+
+    def capture(self, first_seeds: torch.Tensor):
+        """Warm up on a side stream (allocator, autotuning-free kernels, Adam state), then record.  The warm-up steps ARE training
+        steps on ``first_seeds``-shaped batches only in effect if the caller wants them to be: parameters and optimiser state are
+        restored afterwards, so capturing leaves the model exactly where it was."""
+        import copy
+        if self.optim.state:
+            raise RuntimeError("capture expects a fresh optimiser (its state tensors are created by the warm-up steps and reset below)")
+        saved_model = copy.deepcopy(self.model.state_dict())
+        self.block.seeds.copy_(first_seeds)
+        side = torch.cuda.Stream(device=first_seeds.device)
+        side.wait_stream(torch.cuda.current_stream(first_seeds.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream(first_seeds.device).wait_stream(side)
+        torch.cuda.synchronize(first_seeds.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.emb, self.loss = self._step()
+        torch.cuda.synchronize(first_seeds.device)
+        self.model.load_state_dict(saved_model)  # copies INTO the captured parameter / buffer tensors
+        for st in self.optim.state.values():      # the graph updates these very tensors: reset them in place (moments 0, step 0)
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        self.block.bad.zero_()
+
+    def run(self, seeds: torch.Tensor):
+        self.block.seeds.copy_(seeds)
+        self.graph.replay()
+        return self.emb, self.loss
+
+
 class GraphSC(BaseClusteringMethod):
 
     # Seed order of the mini-batches: None = shuffled on the device; a (host) torch.Generator makes the order
@@ -313,12 +390,44 @@ class GraphSC(BaseClusteringMethod):
                  and kernels.gram_sigmoid_supported(batch_size, self.model.embedding_dim))
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
-        optim = torch.optim.Adam(self.model.parameters(), lr=lr)
+        n_full = len(train_ids) // batch_size
+        use_graph = (HIPGRAPH and fused and world == 1 and self.n_layers == 1 and dataloader.cells_only and g.device.type == "cuda"
+                     and n_full >= HIPGRAPH_MIN_BATCHES and batch_size > 1)
+        optim = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=use_graph)
+        captured = None
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
             self.model.train()
             z, order, losses = [], [], []
-            for input_nodes, output_nodes, blocks in dataloader:
+            if use_graph:
+                # same seed order as the loader's (``DataLoader.__iter__``): one permutation per epoch from the same generator
+                idx = dataloader.indices
+                perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else
+                        torch.randperm(idx.numel(), generator=self.shuffle_generator).to(idx.device))
+                idx = idx[perm]
+                if captured is None:
+                    captured = _CapturedStep(self, g, batch_size, optim)
+                    captured.capture(idx[:batch_size])
+                z_all = torch.empty((n_full * batch_size, self.model.embedding_dim), dtype=torch.float32, device=g.device)
+                loss_all = torch.empty(n_full, dtype=torch.float32, device=g.device)
+                for i in range(n_full):
+                    emb, loss = captured.run(idx[i * batch_size:(i + 1) * batch_size])
+                    z_all[i * batch_size:(i + 1) * batch_size].copy_(emb)
+                    loss_all[i].copy_(loss)
+                if int(captured.block.bad) != 0:
+                    raise RuntimeError("GraphSC.fit: a seed of the captured step is not a cell of a CellFeatureGraph-layout graph "
+                                       "(set DANCE_AMD_HIPGRAPH=0 for graphs with other in-neighbours)")
+                z.append(z_all)
+                order.append(g.ndata["order"][idx[:n_full * batch_size]])
+                losses.extend(loss_all.unbind(0))
+                batches = []
+                if n_full * batch_size < idx.numel():  # the short last batch runs eagerly
+                    tail = sampler.sample(g, idx[n_full * batch_size:], True)
+                    tail[2][-1].hook_out = _dst_edge_hook(tail[2])
+                    batches = [tail]
+            else:
+                batches = dataloader
+            for input_nodes, output_nodes, blocks in batches:
                 input_features = blocks[0].srcdata["features"]
                 last = blocks[-1]
                 _, emb = self.model.forward(blocks, input_features, decode=False)  # :202 (its adj_logits are never used)

@@ -16,8 +16,9 @@ from dance_amd import kernels  # noqa: E402
 from dance_amd.cellgraph import CellGeneGraph  # noqa: E402
 
 n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
+only = sys.argv[2] if len(sys.argv) > 2 else "all"
 dev, n_genes, per = "cuda", 2000, 200
-out = {"cells": n_cells, "genes": n_genes, "edges_per_cell": per}
+out = {"cells": n_cells, "genes": n_genes, "edges_per_cell": per, "hipgraph": os.environ.get("DANCE_AMD_HIPGRAPH", "1")}
 
 
 def graph(d, seed):
@@ -50,6 +51,9 @@ for bs in (128, 8192):
     out[f"GraphSC.fit epoch batch={bs}"] = {"s": s, "batches": -(-n_cells // bs), "ms_per_batch": s / -(-n_cells // bs) * 1e3, "last_loss": m.losses[-1]}
     print(bs, out[f"GraphSC.fit epoch batch={bs}"], file=sys.stderr, flush=True)
 del cg
+if only == "graphsc":
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort  # noqa: E402
 cg = graph(400, 1)
 labels = torch.from_numpy(np.random.default_rng(0).integers(0, 12, n_cells))

@@ -201,3 +201,27 @@ def test_gram_listed_kernels_vs_float64(cuda_device):
         ref.index_add_(0, vs.long(), ce * zz[us.long()])
         assert rel_err(dz.cpu().numpy(), (ref * 0.37).cpu().numpy()) < 1e-5
         assert torch.equal(dz, kernels.gram_listed_backward(z, o, us, vs, xe, p, scale))   # fixed order
+
+
+def test_graphsc_fit_captured_step_vs_reference(cuda_device, gold, monkeypatch):
+    """GraphSC.fit with every full batch replayed from ONE captured hipGraph (static-shape block, both forwards, fused decoder
+    loss, backward, capturable Adam; forced on at this toy size) reproduces the reference's own fit losses and embedding — the
+    same golden the eager loop is pinned to — and the eager loop's, to fp32 rounding."""
+    from dance_amd.modules.single_modality.clustering import graphsc
+    monkeypatch.setattr(graphsc, "HIPGRAPH_MIN_BATCHES", 1)
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(graphsc, "HIPGRAPH", on)
+        g = _graph(gold)
+        m = _model(gold, "mb", "sum")
+        m.shuffle_generator = torch.Generator().manual_seed(123)
+        m.fit(g, epochs=3, lr=1e-2, batch_size=16)
+        res[on] = (np.asarray(m.losses), m.get_latent().copy(), {k: v.detach().cpu().numpy().copy() for k, v in m.model.state_dict().items()})
+    assert np.allclose(res[True][0], gold["gsc_mb_losses"], rtol=2e-4, atol=0)
+    assert rel_err(res[True][1], gold["gsc_mb_z"]) < 1e-3
+    assert np.allclose(res[True][0], res[False][0], rtol=1e-5) and rel_err(res[True][1], res[False][1]) < 1e-5
+    for k in res[True][2]:
+        assert rel_err(res[True][2][k], res[False][2][k]) < 1e-4, k
+    for k in gold.files:
+        if k.startswith("gsc_mb_sd1::"):
+            assert rel_err(res[True][2][k.split("::", 1)[1]], gold[k]) < 1e-3, k

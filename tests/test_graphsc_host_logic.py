@@ -56,3 +56,66 @@ def test_graphsc_fit_host_logic_vs_reference(monkeypatch, tag, batch_size, agg, 
     for k in gold.files:
         if k.startswith(f"gsc_{tag}_sd1::"):
             assert rel_err(m.model.state_dict()[k.split("::", 1)[1]].numpy(), gold[k]) < 1e-3, k
+
+
+def test_static_cell_block_matches_sampled_block(monkeypatch):
+    """cellgraph.StaticCellBlock (sources = [seeds | all genes], e_max entries, one padding row) gives WeightedGraphConv / GCNAE the
+    outputs and gradients of the dgl.to_block-ordered block of the same seeds; the captured step's body (_CapturedStep._step, run
+    eagerly here) performs the same update as one eager batch of GraphSC.fit."""
+    from dance_amd import kernels
+    from dance_amd.cellgraph import MultiLayerFullNeighborSampler, StaticCellBlock
+    from dance_amd.modules.single_modality.clustering import graphsc
+    for name in STAND_INS:
+        monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
+    gold = np.load(GOLD)
+    g = _graph(gold)
+    g.ndata["order"] = g.ndata["label"] = g.ndata["feat_id"]
+    n_genes = g.gene_prefix()
+    kw = json.loads(str(gold["gsc_kw"]))
+    torch.manual_seed(0)
+    seeds = torch.tensor([n_genes + i for i in (5, 0, 17, 9, 30, 2)])
+    _, _, blocks = MultiLayerFullNeighborSampler(1).sample(g, seeds, True)
+    sb = StaticCellBlock(g, seeds.numel())
+    sb.seeds.copy_(seeds)
+    sb.rebuild()
+    assert int(sb.bad) == 0 and sb.rowptr.numel() == seeds.numel() + 2 and int(sb.rowptr[-1]) == sb.e_max
+    assert torch.equal(sb.in_degrees(), blocks[0].in_degrees())
+    for agg in ("sum", "mean"):
+        m = graphsc.GCNAE(**{**kw, "agg": agg})
+        outs = []
+        for blk in (blocks[0], sb):
+            for p in m.parameters():
+                p.grad = None
+            _, z = m.forward([blk], blk.srcdata["features"], decode=False)
+            z.sum().backward()
+            outs.append((z.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+        assert rel_err(outs[1][0].numpy(), outs[0][0].numpy()) < 1e-6
+        for a, b in zip(outs[1][1], outs[0][1]):
+            assert rel_err(a.numpy(), b.numpy()) < 1e-5
+    # a non-cell seed is flagged
+    sb.seeds[0] = 0
+    sb.rebuild()
+    assert int(sb.bad) == 1
+    # the step body == one eager batch (dropout off): same loss, same updated parameters
+    fit = graphsc.GraphSC(**kw, n_clusters=3, device="cpu")
+    fit.model.dropout = None
+    fit.model.decoder.dropout = 0.0
+    ref = graphsc.GraphSC(**kw, n_clusters=3, device="cpu")
+    ref.model.load_state_dict(fit.model.state_dict())
+    ref.model.dropout, ref.model.decoder.dropout = None, 0.0
+    opt = torch.optim.Adam(fit.model.parameters(), lr=1e-2)
+    step = graphsc._CapturedStep(fit, g, 6, opt)
+    step.block.seeds.copy_(seeds)
+    emb, loss = step._step()
+    ropt = torch.optim.Adam(ref.model.parameters(), lr=1e-2)
+    blk = blocks[0]
+    _, e1 = ref.model.forward([blk], blk.srcdata["features"], decode=False)
+    b = 6.0
+    us = torch.arange(6, dtype=torch.int32)
+    rl = (b * b / ((b * b - b) * 2)) * graphsc.gram_listed_bce(ref.model.forward([blk], blk.srcdata["features"], decode=False)[1], us, us, (b * b - b) / b)
+    ropt.zero_grad()
+    rl.backward()
+    ropt.step()
+    assert abs(float(loss) - float(rl)) < 1e-6 * abs(float(rl)) and rel_err(emb.numpy(), e1.detach().numpy()) < 1e-6
+    for (k, a), (_, c) in zip(fit.model.state_dict().items(), ref.model.state_dict().items()):
+        assert rel_err(a.numpy(), c.numpy()) < 1e-5, k
