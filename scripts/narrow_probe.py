@@ -24,10 +24,13 @@ dy = torch.randn(n, f, device=dev, generator=g)
 x50 = torch.randn(n, f, device=dev, generator=g)
 x52 = torch.zeros(n, 52, device=dev)
 x52[:, :f] = x50
+x64 = torch.zeros(n, 64, device=dev)
+x64[:, :f] = x50
 out = {}
 alg_bytes = 1.85e9  # B_min accounting of the 50 -> 50 layer fwd + bwd
+gather_bytes = n * k * (8 + f * 4) + 4 * n + n * f * 4 + 2 * n * 64 * 4 + n * f * 4  # fwd: edges + gathered rows + Y + agg; bwd: agg + dY
 for label, x, fused in (("fused, X ld=50 (8-byte rows, 2 rows/wave)", x50, True), ("fused, X ld=52 (16-byte rows, 4 rows/wave)", x52[:, :f], True),
-                        ("generic chain (round 2)", x50, False)):
+                        ("fused, X ld=64 (rows = two aligned 128-byte lines)", x64[:, :f], True), ("generic chain (round 2)", x50, False)):
     autograd.NARROW_FUSED = fused
 
     def step():
@@ -45,6 +48,7 @@ for label, x, fused in (("fused, X ld=50 (8-byte rows, 2 rows/wave)", x50, True)
         ms = (time.perf_counter() - t0) / 20 * 1e3
     ksum = {kname: round(v[1], 4) for kname, v in sorted(t.summary().items())}
     out[label] = {"ms_fwd_bwd": ms, "kernels_ms": ksum, "kernel_sum_ms": round(sum(ksum.values()), 4),
-                  "hbm_frac_of_8TBs_on_kernel_sum": round(alg_bytes / (sum(ksum.values()) * 1e-3) / 8e12, 4)}
+                  "hbm_frac_of_8TBs_on_kernel_sum": round(alg_bytes / (sum(ksum.values()) * 1e-3) / 8e12, 4),
+                  "hbm_frac_gather_accounting": round(gather_bytes / (sum(ksum.values()) * 1e-3) / 8e12, 4)}
     print(label, out[label], file=sys.stderr, flush=True)
 print(json.dumps(out, indent=1))
