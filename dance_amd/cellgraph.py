@@ -212,6 +212,11 @@ class Block:
 
     num_dst_nodes = number_of_dst_nodes
 
+    @property
+    def rowptr_dst(self) -> torch.Tensor:
+        """Row pointers of exactly the destination rows (``num_dst + 1`` entries; a StaticCellBlock's CSR has one padding row more)."""
+        return self.rowptr[:self._num_dst + 1]
+
     def number_of_src_nodes(self) -> int:
         return self._num_src
 

@@ -5,6 +5,7 @@
 The training loop is the reference's (full-fan-out in-neighbour blocks of ``batch_size`` cells, Adam, summed CE);
 the per-row ``.item()`` loop of ``evaluate`` (:278-283) is replaced by the equivalent vectorised device ops.
 """
+import os
 import time
 from copy import deepcopy
 from pathlib import Path
@@ -49,6 +50,10 @@ class GNN(nn.Module):
         for block, layer in zip(blocks, self.layers):
             x = layer(block, x)
         return self.linear(x)
+
+
+HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
+HIPGRAPH_MIN_BATCHES = 8
 
 
 class ScDeepSort(BaseClassificationMethod):
@@ -135,7 +140,15 @@ class ScDeepSort(BaseClassificationMethod):
         self.model = GNN(self.dense_dim, self.num_labels, self.hidden_dim, self.n_layers, num_genes, activation=nn.ReLU(),
                          dropout=self.dropout, compute_dtype=self.compute_dtype).to(self.device)
         self.sampler = NeighborSampler(fanouts=[-1] * self.n_layers, edge_dir="in")
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay)
+        # One captured hipGraph per training step (static-shape block of the batch's cells, forward, loss, backward, Adam): at the
+        # reference's batch size (500) a step is a few dozen microsecond kernels and the loop is launch-bound.  Single process, one
+        # layer, CellFeatureGraph node layout, enough full batches to amortise the capture; DANCE_AMD_HIPGRAPH=0 keeps the eager loop.
+        n_full = len(train_idx) // self.batch_size
+        self._use_graph = (HIPGRAPH and sharding.world_info()[1] == 1 and self.n_layers == 1 and graph.gene_prefix() >= 0
+                           and str(self.device).startswith("cuda") and n_full >= HIPGRAPH_MIN_BATCHES and self.batch_size > 1
+                           and not any(layer.use_neigh for layer in self.model.layers))
+        self._captured = None
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph)
         self.loss_fn = nn.CrossEntropyLoss(reduction="sum")
 
         # more than one process: data parallelism over the training cells (the graph is replicated, the model is small):
@@ -165,15 +178,72 @@ class ScDeepSort(BaseClassificationMethod):
         self._print(f"Epoch {_epoch:04d}, Train Acc {_train_acc:.4f}, Val Correct Num {final_val_correct_num}, "
                     f"Val Total Num {len(val_idx)}, Val Unsure Num {final_val_unsure_num}")
 
+    def _captured_step_body(self, block):
+        blk = block.rebuild()
+        loss = self.loss_fn(self.model([blk], blk.srcdata["features"]), blk.dstdata["label"])
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _capture_step(self, graph, first_seeds):
+        """Record one training step on a StaticCellBlock as a hipGraph; the model and the (fresh) optimiser state are put back to
+        where they were, so capturing is not a training step."""
+        from ....cellgraph import StaticCellBlock
+        if self.optimizer.state:
+            raise RuntimeError("capture expects a fresh optimiser")
+        block = StaticCellBlock(graph, self.batch_size)
+        saved = deepcopy(self.model.state_dict())
+        block.seeds.copy_(first_seeds)
+        dev = first_seeds.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._captured_step_body(block)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = self._captured_step_body(block)
+        torch.cuda.synchronize(dev)
+        self.model.load_state_dict(saved)       # in place: the graph keeps pointing at these tensors
+        for st in self.optimizer.state.values():  # moments and step counters back to zero, in place
+            for v in st.values():
+                if torch.is_tensor(v):
+                    v.zero_()
+        block.bad.zero_()
+        return g, block, loss
+
     def cal_loss(self, graph, idx: torch.Tensor):
         self.model.train()
         losses, sizes = [], []
         from .... import sharding
         if getattr(self, "_world", 1) > 1:
             idx = sharding.shard_seed_ids(idx)
-        dataloader = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
-                                generator=self.shuffle_generator)
-        for _, _, blocks in dataloader:
+        if getattr(self, "_use_graph", False) and idx.numel() // self.batch_size >= 1:
+            idx = idx.to(self.device)
+            perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else
+                    torch.randperm(idx.numel(), generator=self.shuffle_generator).to(idx.device))  # the loader's own order
+            idx = idx[perm]
+            n_full = idx.numel() // self.batch_size
+            if self._captured is None:
+                self._captured = self._capture_step(graph, idx[:self.batch_size])
+            cg, block, static_loss = self._captured
+            loss_all = torch.empty(n_full, dtype=torch.float32, device=idx.device)
+            for i in range(n_full):
+                block.seeds.copy_(idx[i * self.batch_size:(i + 1) * self.batch_size])
+                cg.replay()
+                loss_all[i].copy_(static_loss)
+            if int(block.bad) != 0:
+                raise RuntimeError("ScDeepSort.fit: a training seed is not a cell of a CellFeatureGraph-layout graph (set DANCE_AMD_HIPGRAPH=0)")
+            losses, sizes = list(loss_all.unbind(0)), [self.batch_size] * n_full
+            tail = idx[n_full * self.batch_size:]
+            batches = [self.sampler.sample(graph, tail, True)] if tail.numel() else []
+        else:
+            batches = DataLoader(graph=graph, indices=idx, sampler=self.sampler, batch_size=self.batch_size, shuffle=True,
+                                 generator=self.shuffle_generator)
+        for _, _, blocks in batches:
             input_features = blocks[0].srcdata["features"]
             output_labels = blocks[-1].dstdata["label"]
             output_predictions = self.model(blocks, input_features)

@@ -26,11 +26,11 @@ class _SageAggregateFn(torch.autograd.Function):
         if (win is not None and win[1] > 0 and kernels.SAGE_MODE == "mfma" and h.shape[1] % 4 == 0
                 and kernels.sage_mfma_supported(win[1], h.shape[1], h.dtype)):
             # cell destinations whose gene rows are a known window of the sources: the matrix-core kernel (one launch)
-            neigh = kernels.sage_aggregate_mfma(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous(),
+            neigh = kernels.sage_aggregate_mfma(block.rowptr_dst, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous(),
                                                 win[0], win[1])
         else:
             agg = kernels.sage_aggregate_bf16 if h.dtype == torch.bfloat16 else kernels.sage_aggregate  # C3: bf16 storage
-            neigh = agg(block.rowptr, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous())
+            neigh = agg(block.rowptr_dst, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous())
         ctx.block = block
         ctx.save_for_backward(h, alpha)
         return neigh
@@ -39,6 +39,8 @@ class _SageAggregateFn(torch.autograd.Function):
     def backward(ctx, dneigh):
         h, alpha = ctx.saved_tensors
         blk = ctx.block
+        if getattr(blk, "pad_row", False):
+            raise NotImplementedError("the gradient of the aggregation (use_neigh=True) is not defined on a padded static block")
         cid_src, cid_dst = blk.srcdata["cell_id"], blk.dstdata["cell_id"]
         dneigh = dneigh.contiguous()
         n_genes = alpha.numel() - 2

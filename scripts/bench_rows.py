@@ -204,7 +204,7 @@ def main():
     # ---- config C4 on one GPU: GraphSC.fit, one epoch of the GAE (two forwards per batch as in graphsc.py:202,215), 50 -> 200 -> 300 ----
     from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
     cg50 = cg.with_ndata(features=feats[:, :50].contiguous())
-    for bsz in (8192, ):
+    for bsz in (8192, 128):  # 128 = the reference's batch size: one captured hipGraph per step (graphsc._CapturedStep)
         gs = GraphSC(in_feats=50, n_clusters=10, device="cuda")
         gs.fit(cg50, epochs=1, batch_size=bsz)  # warm-up
         torch.cuda.synchronize()
@@ -213,8 +213,9 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         rows[f"GraphSC.fit 1 epoch cells={n_cells} batch={bsz} (reference default batch is 128)"] = dict(
-            ms=dt * 1e3, cells_per_s=n_cells / dt, note="per batch: block sampling, WeightedGraphConv x1, Linear, z z^T, dense "
-            "dst x dst adjacency + weighted BCE, Adam; embeddings of all cells collected on the host as the reference does")
+            ms=dt * 1e3, cells_per_s=n_cells / dt, ms_per_batch=dt * 1e3 / -(-n_cells // bsz),
+            note="per batch: static-shape block, WeightedGraphConv forward x2, Linear, fused decoder loss (no B x B logits), backward, "
+            "Adam — replayed from one captured hipGraph; includes the capture itself (a few eager steps per fit call)")
     del feats, feats16, rowptr, gcol, gval, eid, cg, cg50
 
     # ---- SpaGCN-shape layer 50 -> 50 with bias, k = 15 -----------------------------------------------------
@@ -235,8 +236,67 @@ def main():
 
     ms = gpu_ms(step, iters=5, warm=2)
     byt = 1.85e3 * n
+    byt_gather = n * 15 * (8 + 200.0) + 4 * n + 200.0 * n + 2 * 256.0 * n + 200.0 * n  # what the fused kernels actually have to move
     rows[f"GraphConvolution 50->50 fwd+bwd n={n} k=15"] = dict(ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s",
-                                                              frac=byt / ms / 1e6 / HBM, cells_per_s=n / ms * 1e3)
+                                                              frac=byt / ms / 1e6 / HBM, cells_per_s=n / ms * 1e3,
+                                                              frac_gather_accounting=byt_gather / ms / 1e6 / HBM,
+                                                              note="fused narrow layer (gcn_narrow.hip), X rows at stride 50")
+    x64 = torch.zeros(n, 64, device=dev)
+    x64[:, :50] = x50
+    x50 = x64[:, :50]
+    ms = gpu_ms(step, iters=5, warm=2)
+    rows[f"GraphConvolution 50->50 fwd+bwd n={n} k=15, X rows 256-byte aligned (what SimpleGCDEC.fit feeds)"] = dict(
+        ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s", frac=byt / ms / 1e6 / HBM, cells_per_s=n / ms * 1e3,
+        frac_gather_accounting=byt_gather / ms / 1e6 / HBM)
+    del x64
+    # ---- (f)2: fused ZINB NLL (fwd + bwd) and the all-pairs adjacency loss of scTAG without the N x N matrix -----------------------
+    from dance_amd import autograd
+    nz, gz = (50_000 if q else 1_000_000), 2000
+    xr = torch.poisson(torch.rand(nz, gz, device=dev, generator=g) * 2)
+    mean = (torch.rand(nz, gz, device=dev, generator=g) * 4 + 1e-3).requires_grad_(True)
+    disp = (torch.rand(nz, gz, device=dev, generator=g) * 3 + 1e-3).requires_grad_(True)
+    pi = (torch.rand(nz, gz, device=dev, generator=g) * 0.98 + 0.01).requires_grad_(True)
+    sf = torch.rand(nz, device=dev, dtype=torch.float64) + 0.5
+
+    def zstep():
+        mean.grad = disp.grad = pi.grad = None
+        autograd.zinb_nll(xr, mean, disp, pi, sf).backward()
+
+    with kernels.KernelTimer() as tm:
+        ms = gpu_ms(zstep, iters=3, warm=1)
+    ks = {kname: round(v[1], 3) for kname, v in tm.summary().items()}
+    zb = nz * gz * (16.0 + 28.0)
+    rows[f"ZINB NLL fwd+bwd (dh_zinb_nll_*) cells={nz} genes={gz}"] = dict(ms=ms, kernels_ms=ks, bound="hbm", achieved=zb / ms / 1e6, peak=HBM, unit="GB/s",
+                                                                          frac=zb / ms / 1e6 / HBM, note="float64 element arithmetic (3 lgamma, 2 digamma, 5 log, 1 pow): ALU-bound")
+    ns = 20_000 if q else 100_000  # the unfused torch formula (float64 temporaries) on a sample
+    sl = slice(0, ns)
+    import sys as _sys
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import cpu_ops as _ops
+
+    def zref():
+        m_, d_, p_ = (t[sl].detach().requires_grad_(True) for t in (mean, disp, pi))
+        _ops._zinb_elements(xr[sl], m_, d_, p_, sf[sl], 0.0).mean().backward()
+
+    ms_ref = gpu_ms(zref, iters=2, warm=1)
+    rows[f"ZINB NLL fwd+bwd (dh_zinb_nll_*) cells={nz} genes={gz}"]["torch_unfused_float64_ms_scaled_to_full"] = ms_ref * nz / ns
+    del xr, mean, disp, pi
+    from dance_amd.graph import CSRGraph as _G
+    for na in ([20_000] if q else [100_000, 1_000_000]):
+        colk = torch.randint(0, na, (na, 15), device=dev, generator=g).sort(dim=1).values.to(torch.int32).reshape(-1)
+        ga = _G(torch.arange(0, na * 15 + 1, 15, dtype=torch.int32, device=dev), colk, torch.ones(na * 15, device=dev), na, na)
+        z0 = (torch.randn(na, 32, device=dev, generator=g) * 0.2).requires_grad_(True)
+
+        def astep():
+            z0.grad = None
+            autograd.adj_reconstruction_mse(z0, ga).backward()
+
+        ms = gpu_ms(astep, iters=2, warm=1)
+        fl = 4.0 * na * na * 64
+        rows[f"scTAG adjacency loss over all N^2 pairs, no N x N matrix (adj_dim=32) N={na}"] = dict(
+            ms=ms, bound="mfma", achieved=fl / ms / 1e9, peak=157.3, unit="TFLOP/s (fp32 matrix cores, d padded to 64)", frac=fl / ms / 1e9 / 157.3,
+            note="dense N x N formulation: %.1f GB for the logits alone" % (na * na * 4 / 1e9))
+        del ga, z0, colk
     # ---- A2 preprocessing on the device (opt-in): exact PCA of the gene x cell matrix + the cell-feature projection -------
     from dance_amd.utils.pca import pca_scores
     npc, gpc = (100_000 if q else 1_000_000), 2000

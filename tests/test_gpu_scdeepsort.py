@@ -146,3 +146,43 @@ def test_full_graph_eval_equals_block_eval(cuda_device, tmp_path):
     # the full-graph neigh rows are those of the per-batch blocks (last batch of predict_proba = the last cells)
     last = model.model.layers[0].last_neigh
     assert torch.allclose(neigh_full[-last.shape[0]:], last, rtol=1e-5, atol=1e-6)
+
+
+def test_scdeepsort_captured_step_equals_eager(cuda_device, tmp_path, monkeypatch):
+    """ScDeepSort.fit with every full training batch replayed from ONE captured hipGraph (static-shape cell block, AdaptiveSAGE's
+    discarded aggregation included, loss, backward, capturable Adam) ends with the parameters of the eager loop (same seeds: the
+    split and the batch order come from ``shuffle_generator``), fp32 and bf16 storage; the aggregation of the static block equals
+    the sampled block's."""
+    from dance_amd.cellgraph import NeighborSampler, StaticCellBlock
+    from dance_amd.modules.single_modality.cell_type_annotation import scdeepsort
+    from dance_amd.nn import AdaptiveSAGE
+    n_cells, n_genes, d = 700, 120, 32
+    x, g = _graph(n_cells, n_genes, d, 3, cuda_device)
+    labels = torch.from_numpy(np.random.default_rng(0).integers(0, 5, n_cells))
+    # the static block's discarded aggregation == the sampled block's
+    seeds = n_genes + torch.randperm(n_cells, generator=torch.Generator().manual_seed(0))[:64].to(cuda_device)
+    _, _, blocks = NeighborSampler([-1]).sample(g, seeds, True)
+    sb = StaticCellBlock(g, 64)
+    sb.seeds.copy_(seeds)
+    sb.rebuild()
+    alpha = nn.Parameter(torch.rand(n_genes + 2, 1, device=cuda_device) + 0.5)
+    layer = AdaptiveSAGE(d, 8, alpha, nn.Identity(), nn.ReLU(), nn.Identity()).to(cuda_device)
+    layer(blocks[0], blocks[0].srcdata["features"])
+    ref_neigh = layer.last_neigh.clone()
+    layer(sb, sb.srcdata["features"])
+    assert int(sb.bad) == 0 and rel_err(layer.last_neigh.cpu().numpy(), ref_neigh.cpu().numpy()) < 1e-5
+    monkeypatch.setattr(scdeepsort, "HIPGRAPH_MIN_BATCHES", 1)
+    for cd, tol in (("fp32", 1e-5), ("bf16", 2e-2)):
+        out = {}
+        for on in (True, False):
+            monkeypatch.setattr(scdeepsort, "HIPGRAPH", on)
+            torch.manual_seed(7)
+            m = scdeepsort.ScDeepSort(d, 16, 1, "synthetic", f"cap{on}{cd}", batch_size=64, device="cuda", save_root=tmp_path, verbose=False,
+                                      compute_dtype=cd)
+            m.shuffle_generator = torch.Generator().manual_seed(11)
+            m.fit(g, labels, epochs=3, lr=1e-2, val_ratio=0.2)
+            assert m._use_graph == on and (m._captured is not None) == on
+            out[on] = ({k: v.detach().float().cpu().numpy() for k, v in m.model.state_dict().items()}, m.predict_proba(g))
+        for k in out[True][0]:
+            assert rel_err(out[True][0][k], out[False][0][k]) < tol, (cd, k)
+        assert np.abs(out[True][1] - out[False][1]).max() < tol * 10
