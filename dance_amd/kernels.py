@@ -44,6 +44,8 @@ class KernelTimer:
 def _call(tag: str, fn, *args):
     """Invoke one C-ABI launcher on the current stream; raise on a negative status."""
     timer = KernelTimer.active
+    if timer is not None and torch.cuda.is_current_stream_capturing():
+        timer = None  # events recorded into a hipGraph capture cannot be timed; replays are not visible per launch either
     if timer is not None:
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
