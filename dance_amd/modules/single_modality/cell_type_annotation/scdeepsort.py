@@ -53,7 +53,8 @@ class GNN(nn.Module):
 
 
 HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
-HIPGRAPH_MIN_BATCHES = 8
+HIPGRAPH_MIN_BATCHES = 64   # the capture (two eager steps + instantiation, tens of ms) must be amortised
+HIPGRAPH_MAX_BATCH = 2048    # above this a step is kernel-bound: replaying gains nothing (batch 65536: the capture doubled the epoch)
 
 
 class ScDeepSort(BaseClassificationMethod):
@@ -145,7 +146,7 @@ class ScDeepSort(BaseClassificationMethod):
         # layer, CellFeatureGraph node layout, enough full batches to amortise the capture; DANCE_AMD_HIPGRAPH=0 keeps the eager loop.
         n_full = len(train_idx) // self.batch_size
         self._use_graph = (HIPGRAPH and sharding.world_info()[1] == 1 and self.n_layers == 1 and graph.gene_prefix() >= 0
-                           and str(self.device).startswith("cuda") and n_full >= HIPGRAPH_MIN_BATCHES and self.batch_size > 1
+                           and str(self.device).startswith("cuda") and n_full >= HIPGRAPH_MIN_BATCHES and 1 < self.batch_size <= HIPGRAPH_MAX_BATCH
                            and not any(layer.use_neigh for layer in self.model.layers))
         self._captured = None
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph)

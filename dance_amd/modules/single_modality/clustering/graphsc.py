@@ -259,7 +259,8 @@ if DECODER_MODE not in ("fused", "dense"):
 # host-bound (1.36 ms / batch eager, profiles/r03e_ref_batch_epochs.json).  DANCE_AMD_HIPGRAPH=0 keeps the eager loop; the last,
 # short batch of an epoch always runs eagerly.
 HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
-HIPGRAPH_MIN_BATCHES = 8  # capturing costs a few eager steps: not worth it for toy runs
+HIPGRAPH_MIN_BATCHES = 64  # capturing costs two eager steps + the instantiation (tens of ms): it must be amortised
+HIPGRAPH_MAX_BATCH = 2048   # above this a step is kernel-bound and replaying it gains nothing (measured at 8192: 4.2 vs 4.2 ms)
 
 
 class _CapturedStep:
@@ -392,7 +393,7 @@ class GraphSC(BaseClusteringMethod):
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         n_full = len(train_ids) // batch_size
         use_graph = (HIPGRAPH and fused and world == 1 and self.n_layers == 1 and dataloader.cells_only and g.device.type == "cuda"
-                     and n_full >= HIPGRAPH_MIN_BATCHES and batch_size > 1)
+                     and n_full >= HIPGRAPH_MIN_BATCHES and 1 < batch_size <= HIPGRAPH_MAX_BATCH)
         optim = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=use_graph)
         captured = None
         self.losses, aris, Z = [], [], {}
