@@ -270,19 +270,36 @@ def main():
         modes = ["allgather"]  # one GPU: the shard is the graph, no exchange
     elif args.exchange == "auto":
         modes = ["halo", "allgather"] + (["alltoall"] if N_HIDDEN % world == 0 else [])
-    runs = {}
+    runs, failed = {}, {}
     for mode in modes:
-        sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)  # world == 1: the whole graph
-        elapsed, timer = time_steps(make_step(sg), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
-        runs[mode] = dict(sg=sg, elapsed=elapsed, ksum=timer.summary(), bytes_per_step=sg.stats["exchanged_bytes"] / max(args.steps + args.warmup, 1))
-        if world > 1:
-            ex_ms, ex_bytes = time_exchange_only(sg, N_HIDDEN, max(3, args.steps // 4), fence, dev)
-            runs[mode].update(exchange_only_ms=ex_ms, exchange_only_bytes=ex_bytes)
+        # one exchange mode that raises (on every rank alike: a plan or shape error) must not cost the whole line when several are
+        # being compared; every rank learns of a failure anywhere before the mode's figures are used
+        err = None
+        try:
+            sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)  # world == 1: the whole graph
+            elapsed, timer = time_steps(make_step(sg), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
+            runs[mode] = dict(sg=sg, elapsed=elapsed, ksum=timer.summary(), bytes_per_step=sg.stats["exchanged_bytes"] / max(args.steps + args.warmup, 1))
+            if world > 1:
+                ex_ms, ex_bytes = time_exchange_only(sg, N_HIDDEN, max(3, args.steps // 4), fence, dev)
+                runs[mode].update(exchange_only_ms=ex_ms, exchange_only_bytes=ex_bytes)
+        except Exception as e:  # noqa: BLE001 — reported in the JSON line; re-raised below when no mode is left
+            if len(modes) == 1:
+                raise
+            err = f"{type(e).__name__}: {e}"
+            sg = None
+        if world > 1 and len(modes) > 1:
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if not int(ok.item()):
+                failed[mode] = err or "failed on another rank"
+                runs.pop(mode, None)
         if len(modes) > 1:
             runs[mode]["sg"] = None
             sg_keep = None
             del sg
             torch.cuda.empty_cache()
+    if not runs:
+        raise SystemExit(f"every exchange mode failed: {failed}")
     mode = min(runs, key=lambda m: runs[m]["elapsed"])
     elapsed, ksum = runs[mode]["elapsed"], runs[mode]["ksum"]
     sg = runs[mode]["sg"] or sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
@@ -398,6 +415,8 @@ def main():
                                    "bytes_on_wire_per_step_per_rank": int(r["exchange_only_bytes"]),
                                    "exchange_only_ms_per_step": round(r["exchange_only_ms"], 4)} for m, r in runs.items()}
             out["exchange"]["headline_mode"] = mode
+            if failed:
+                out["exchange"]["failed_modes"] = failed
         if x3_out is not None:
             out["gemm_f32x3_row"] = x3_out
         if knn_out is not None:

@@ -20,10 +20,13 @@ class _SageAggregateFn(torch.autograd.Function):
     """neigh = mean_e alpha[idx(e)] w_e h[src(e)] with gradients for h (transposed gather) and alpha (K7)."""
 
     @staticmethod
-    def forward(ctx, h, alpha, block):
+    def forward(ctx, h, alpha, block, differentiated=False):
         cid_src, cid_dst = block.srcdata["cell_id"], block.dstdata["cell_id"]
         win = getattr(block, "gene_window", None)
-        if (win is not None and win[1] > 0 and kernels.SAGE_MODE == "mfma" and h.shape[1] % 4 == 0
+        # fp32 features whose aggregation enters the output (use_neigh=True) take the exact gather: the matrix-core kernel feeds
+        # fp32 operands as bf16 hi + lo pairs (1e-5 relative per term), which is not the function the backward below differentiates
+        exact = differentiated and h.dtype == torch.float32
+        if (win is not None and win[1] > 0 and kernels.SAGE_MODE == "mfma" and not exact and h.shape[1] % 4 == 0
                 and kernels.sage_mfma_supported(win[1], h.shape[1], h.dtype)):
             # cell destinations whose gene rows are a known window of the sources: the matrix-core kernel (one launch)
             neigh = kernels.sage_aggregate_mfma(block.rowptr_dst, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous(),
@@ -73,7 +76,7 @@ class _SageAggregateFn(torch.autograd.Function):
                 dh = kernels.spmm_csr_bf16(rp_t, col_t, val_t, dneigh.to(torch.bfloat16), n_cols=blk.number_of_dst_nodes())
             else:
                 dh = kernels.spmm_csr(rp_t, col_t, val_t, dneigh, n_cols=blk.number_of_dst_nodes())
-        return dh, dalpha, None
+        return dh, dalpha, None, None
 
 
 class AdaptiveSAGE(nn.Module):
@@ -96,7 +99,7 @@ class AdaptiveSAGE(nn.Module):
 
     def aggregate(self, block, h):
         """``dstdata["neigh"]`` of the reference (gnn.py:90)."""
-        return _SageAggregateFn.apply(h, self.alpha, block)
+        return _SageAggregateFn.apply(h, self.alpha, block, torch.is_grad_enabled() and (h.requires_grad or self.alpha.requires_grad))
 
     def forward(self, block, h):
         off = getattr(block, "dst_offset", 0)  # 0 for sampled blocks (dst nodes lead the sources); G for the full-graph cell rows
