@@ -494,16 +494,27 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
   // Few output tiles and a long K (dW = X^T dZ): split K so that the grid is (just under) a whole number of
   // rounds of the 256 CUs — floor(1024 / tiles) slices: at most 4 full rounds, the last one >= 98 % full —
   // keeping at least 64 K-steps per block.  Measured at 2000 x 512 x 1M: 1024 blocks 138 TFLOP/s, 4096 blocks 135.
+  int64_t S = 1;
   if (p.n_tiles < 512 && K >= 4096) {
     int64_t want = 1024 / p.n_tiles;
     if (want < 1) want = 1;
     int64_t max_s = K / (64 * BK);
     if (max_s < 1) max_s = 1;
-    int64_t S = want < max_s ? want : max_s;
-    if (S > 1) {
-      p.k_chunk = dh::ceil_div(dh::ceil_div(K, S), BK) * BK;
-      p.S = (int)dh::ceil_div(K, p.k_chunk);
-    }
+    S = want < max_s ? want : max_s;
+  }
+  // A handful of tiles and a K of a few thousand rows (the dW of a mini-batch: 50 x 200 from 10 k rows) left most of the chip idle
+  // under the 64-step rule (8 blocks, 0.25 ms for 0.2 GFLOP at batch 8192 of graph-sc): when the grid would not even cover the
+  // 256 CUs once, slices go down to 8 K-steps.  Grids that already fill the chip keep their plan.
+  if (p.n_tiles * S < 256 && K >= 1024) {
+    int64_t want = dh::ceil_div((int64_t)256, (int64_t)p.n_tiles);
+    int64_t max_s = K / (8 * BK);
+    if (max_s < 1) max_s = 1;
+    const int64_t s2 = want < max_s ? want : max_s;
+    if (s2 > S) S = s2;
+  }
+  if (S > 1) {
+    p.k_chunk = dh::ceil_div(dh::ceil_div(K, S), BK) * BK;
+    p.S = (int)dh::ceil_div(K, p.k_chunk);
   }
   return p;
 }

@@ -53,21 +53,28 @@ class WeightedGraphConv(nn.Module):
         weight = self.weight if weight is None else weight
         # degree scalings of this block: computed once per block (graph-sc runs two forwards per batch, graphsc.py:202,215)
         cache = graph.__dict__.setdefault("_wgc_scales", {})
+        n_dst = graph.number_of_dst_nodes()
+        pad = 1 if getattr(graph, "pad_row", False) else 0  # StaticCellBlock: one padding row behind the destinations
+        g = graph.__dict__.get("_csr")  # one CSRGraph (hence one transpose for the backward) per block, shared by both forwards of a batch
+        if g is None:
+            g = graph.__dict__["_csr"] = CSRGraph(graph.rowptr, graph.col, graph.val, n_dst + pad, graph.number_of_src_nodes())
         if self._norm not in cache:
             colscale = rowscale = None
             if self._norm == "both":
-                colscale = graph.out_degrees().float().clamp(min=1).pow(-0.5)  # :444-449
+                if not pad and torch.is_grad_enabled() and (feat.requires_grad or weight.requires_grad):
+                    # training: the backward needs the block's transpose anyway, and its row pointer IS the out-degree count
+                    # (the scatter-add over 1.6 M edges was 0.1 ms of a batch of 8192 cells)
+                    rp_t = g.transpose().rowptr
+                    out_deg = rp_t[1:] - rp_t[:-1]
+                else:
+                    out_deg = graph.out_degrees()
+                colscale = out_deg.float().clamp(min=1).pow(-0.5)  # :444-449
                 rowscale = graph.in_degrees().float().clamp(min=1).pow(-0.5)  # :467-471
             elif self._norm != "none":  # "right" AND "left": the reference only scales the source side for "both" (:444)
                 rowscale = 1.0 / graph.in_degrees().float().clamp(min=1)  # and divides by the in-degree for every other norm (:467-474)
             cache[self._norm] = (colscale, rowscale)
         colscale, rowscale = cache[self._norm]
         relu = self._activation in (F.relu, torch.relu) or isinstance(self._activation, nn.ReLU)
-        n_dst = graph.number_of_dst_nodes()
-        pad = 1 if getattr(graph, "pad_row", False) else 0  # StaticCellBlock: one padding row behind the destinations
-        g = graph.__dict__.get("_csr")  # one CSRGraph (hence one transpose for the backward) per block, shared by both forwards of a batch
-        if g is None:
-            g = graph.__dict__["_csr"] = CSRGraph(graph.rowptr, graph.col, graph.val, n_dst + pad, graph.number_of_src_nodes())
         if pad and rowscale is not None:
             rowscale = torch.cat((rowscale, rowscale.new_ones(1)))
         rst = gcn_layer(feat, weight, g, self.bias, relu, rowscale=rowscale, colscale=colscale,
