@@ -18,6 +18,7 @@
 namespace {
 
 using namespace dh_bf16;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 struct Epilogue {
   const float* bias;  // [N] or null
@@ -101,6 +102,237 @@ __global__ __launch_bounds__(256) void repack_bf16_kernel(int64_t rows, int64_t 
   }
 }
 
+// ---- long-and-narrow products (the dense update of a layer: 1M x 400 -> 200) --------------------------------------------------
+// C[M,N] = A[M,K] · B[N,K]^T with N <= 512 and K <= 512: the tiled kernel above spends such a product in prologues and epilogues
+// (7 K-steps per tile, 36 % of the second column tile empty, A fetched once per column tile: 0.72 ms at 1M x 400 -> 200 for 1.2 GB
+// = 0.21 of HBM).  Here B never moves: wave w of a workgroup keeps the fragments of column tile w (32 output columns x all of K:
+// K / 16 x 4 registers) in registers for the whole kernel, and the workgroup streams row tiles of A through LDS — one coalesced
+// 16-byte load per chunk, issued one tile ahead (registers, then a double-buffered LDS image whose 16-byte fragment reads are
+// conflict-free: row stride = K-steps x 32 B + 16 B, an odd number of 16-byte slots).  The K loop has a compile-time trip count (KSM
+// buckets; the image columns between K and 16 KSM are zero, as are the B fragments there), one barrier per row tile plus two for the
+// output image; every byte of A and C crosses HBM once.  KSM = K-steps of 16 held in registers, MAXW = waves per workgroup (register
+// budget 512 / (MAXW / 4)), RT = rows per tile.
+//
+// Measured (profiles/r03o_gemm_bf16_rows.json): 1M x 400 -> 200 with bias + ReLU 0.39 ms = 3.1 TB/s = 0.38 of HBM (tiled kernel: 0.72
+// ms).  What is left: the B fragments take 104 of 222 registers, so a CU holds ONE workgroup and the three phases of a row tile run
+// one after the other — alone, the loads take 0.14 ms (5.6 TB/s), the MFMAs + fragment reads 0.13 ms, the output 0.17 ms; together 0.39.
+// Reads are in flight only for the first third of an iteration; a DMA ring of 32-row images (global_load_lds, no staging registers,
+// three tiles ahead) would keep them in flight throughout and is the next step (expected 0.29 ms = compute + output).
+// Workgroup barrier that orders LDS traffic only (__syncthreads() is a workgroup-scope fence: the compiler may drain vmcnt in front of
+// it, which would make every barrier of the tile loop wait for the output stores just issued and for the prefetch of the next tile).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int KSM, int MAXW, int RT>
+__global__ __launch_bounds__(64 * MAXW) void gemm_bf16_rows_kernel(int64_t M, int N, int kp, const uint16_t* __restrict__ A, int64_t lda,
+                                                                   const uint16_t* __restrict__ B, int64_t ldb, void* __restrict__ C, int64_t ldc,
+                                                                   Epilogue ep, int n_waves_cols, int vec_ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rows_lds[];
+  constexpr int MT = RT / 32;
+  constexpr int MINW = MAXW >= 8 ? 8 : 4;                                 // the host launches at least this many waves
+  constexpr int SCM = (RT * KSM * 2 + 64 * MINW - 1) / (64 * MINW) + 1;   // staging passes (rows are covered by whole groups of `cpr` threads)
+  constexpr int STRIDE = KSM * 32 + 16;                                   // LDS bytes per row: an odd number of 16-byte slots
+  constexpr int BUF = RT * STRIDE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+  const int r32 = lane & 31, kh = lane >> 5;
+  const int cpr = kp / 8;  // 16-byte chunks of a row that exist (kp is a multiple of 8)
+
+  // B fragments of this wave's column tile: lane = (column r32, k half kh) holds B[n][16 s + 8 kh .. + 8]; zero beyond kp, so the
+  // K loop below always runs its KSM steps without a branch (a guarded step cost a copy of every accumulator per step)
+  bf16x8 bfrag[KSM];
+  {
+    const int n = wave * 32 + r32;
+    const bool live_n = wave < n_waves_cols && n < N;
+    const uint16_t* bp = B + (int64_t)(live_n ? n : 0) * ldb + 8 * kh;
+#pragma unroll
+    for (int s = 0; s < KSM; ++s) {
+      u32x4 v = u32x4(0u);
+      if (live_n && 16 * s + 8 * kh < kp) v = *reinterpret_cast<const u32x4*>(bp + 16 * s);
+      bfrag[s] = __builtin_bit_cast(bf16x8, v);
+    }
+  }
+  // both A images start as zeros: the chunks between kp and 16 KSM are never written again and multiply the zero B fragments
+  for (int i = tid; i < 2 * BUF / 16; i += nthreads) reinterpret_cast<u32x4*>(rows_lds)[i] = u32x4(0u);
+  __syncthreads();
+
+  // staging: a pass covers rpp = nthreads / cpr whole rows, thread (r0, c0) takes chunk c0 of row r0 + pass * rpp
+  const int rpp = nthreads / cpr;
+  const int r0 = tid / cpr, c0 = tid - r0 * cpr;
+  const bool stager = r0 < rpp;
+  u32x4 stage[SCM];
+  // The loads are unconditional — out-of-range rows / idle threads read a clamped (valid) address and the value is dropped or never
+  // stored (behind a divergent guard every load sits in its own basic block with a full vmcnt(0) wait)
+  const int c0c = stager ? c0 : 0;
+  auto load_tile = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t m0 = tile * RT;
+#pragma unroll
+    for (int q = 0; q < SCM; ++q) {
+      const int64_t m = min(m0 + r0 + q * rpp, M - 1);
+      stage[q] = *reinterpret_cast<const u32x4*>(A + m * lda + c0c * 8);
+    }
+  };
+  auto stage_to_lds = [&](int buf) __attribute__((always_inline)) {
+    unsigned char* lp = rows_lds + buf * BUF + r0 * STRIDE + c0 * 16;
+#pragma unroll
+    for (int q = 0; q < SCM; ++q)
+      if (stager && r0 + q * rpp < RT) *reinterpret_cast<u32x4*>(lp + q * rpp * STRIDE) = stage[q];
+  };
+
+  // Per row tile: barrier (image `buf` complete) -> issue the loads of the next tile -> MFMAs on this tile -> wait for the loads and
+  // write them into the other image -> store this tile's C.  The output stores are issued AFTER the wait, so the only vmcnt wait of
+  // an iteration never sits behind a store that was just issued (stores count in vmcnt on gfx9: waiting at the top of the loop
+  // exposed the write latency of every tile).
+  const int64_t n_tiles = (M + RT - 1) / RT;
+  int64_t tile = blockIdx.x;
+  if (tile >= n_tiles) return;
+  const float bias_col = (ep.bias && wave * 32 + r32 < N) ? ep.bias[wave * 32 + r32] : 0.f;  // of this lane's accumulator column (loaded once)
+  load_tile(tile);
+  stage_to_lds(0);
+  // Nothing may be pending when the loop is entered: with the bias (or a B fragment) still in flight the compiler put a counted vmcnt
+  // wait in front of the MFMAs of EVERY iteration (ISA), and since vmcnt retires in order that wait also covers the output stores of the
+  // previous tile.
+  asm volatile("" ::"v"(bias_col));
+#pragma unroll
+  for (int s = 0; s < KSM; ++s) asm volatile("" ::"v"(bfrag[s]));
+  int buf = 0;
+  for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+    lds_barrier();  // image `buf` is complete; image `buf ^ 1` is no longer read by anyone
+    const int64_t next = tile + gridDim.x;
+    if (next < n_tiles) load_tile(next);
+    f32x16 acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+    if (wave < n_waves_cols) {
+      const unsigned char* img = rows_lds + buf * BUF + r32 * STRIDE + kh * 16;
+      // fragments are read two K-steps ahead of their MFMAs (scheduling barriers keep the compiler from hoisting ALL reads of the tile)
+      bf16x8 af[3][MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[0][m] = *reinterpret_cast<const bf16x8*>(img + m * 32 * STRIDE);
+      if (KSM > 1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) af[1][m] = *reinterpret_cast<const bf16x8*>(img + m * 32 * STRIDE + 32);
+      }
+#pragma unroll
+      for (int s = 0; s < KSM; ++s) {
+        if (s + 2 < KSM) {
+#pragma unroll
+          for (int m = 0; m < MT; ++m) af[(s + 2) % 3][m] = *reinterpret_cast<const bf16x8*>(img + m * 32 * STRIDE + (s + 2) * 32);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s % 3][m], bfrag[s], acc[m], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (next < n_tiles) stage_to_lds(buf ^ 1);
+    // Epilogue, 32 rows at a time, through ONE fp32 image [32][32 n_waves_cols] shared by the workgroup: every wave drops its accumulators
+    // (+ bias, ReLU) at their (row, column), then all threads stream the image out in row-major order, 16 bytes per lane.  A wave's own
+    // 32 columns are only 64 bytes of a bf16 row (half a line per store); streamed in row-major order the stores cover whole lines, and
+    // bias / ReLU / rounding / accumulate need no per-element guards (element-wise stores from the accumulators made the compiler keep 32
+    // guarded address computations alive across the tile loop and spill the B fragments).
+    float* ct = reinterpret_cast<float*>(rows_lds + 2 * BUF);
+    const int NC = 32 * n_waves_cols;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (wave < n_waves_cols) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float v = acc[m][i] + bias_col;
+          if (ep.act == DH_ACT_RELU) v = fmaxf(v, 0.f);
+          ct[((i & 3) + 8 * (i >> 2) + 4 * kh) * NC + wave * 32 + r32] = v;
+        }
+      }
+      lds_barrier();
+      const int64_t row0 = tile * RT + m * 32;
+      const int rows_here = (int)min((int64_t)32, M - row0);
+      if (rows_here > 0) {
+        if (vec_ok) {  // N a multiple of the chunk, C and its rows 16-byte aligned
+          const int per = ep.c_bf16 ? 8 : 4, cprc = N / per;
+          for (int idx = tid; idx < rows_here * cprc; idx += nthreads) {
+            const int row = idx / cprc, c = (idx - row * cprc) * per;
+            const float* src = ct + row * NC + c;
+            f32x4_t lo = *reinterpret_cast<const f32x4_t*>(src);
+            if (ep.c_bf16) {
+              f32x4_t hi = *reinterpret_cast<const f32x4_t*>(src + 4);
+              uint16_t* q = static_cast<uint16_t*>(C) + (row0 + row) * ldc + c;
+              if (ep.accumulate) {
+                const u32x4 o = *reinterpret_cast<const u32x4*>(q);
+                lo[0] += __uint_as_float(o[0] << 16); lo[1] += __uint_as_float(o[0] & 0xffff0000u);
+                lo[2] += __uint_as_float(o[1] << 16); lo[3] += __uint_as_float(o[1] & 0xffff0000u);
+                hi[0] += __uint_as_float(o[2] << 16); hi[1] += __uint_as_float(o[2] & 0xffff0000u);
+                hi[2] += __uint_as_float(o[3] << 16); hi[3] += __uint_as_float(o[3] & 0xffff0000u);
+              }
+              u32x4 o;
+              o[0] = f32_to_bf16(lo[0]) | (f32_to_bf16(lo[1]) << 16);
+              o[1] = f32_to_bf16(lo[2]) | (f32_to_bf16(lo[3]) << 16);
+              o[2] = f32_to_bf16(hi[0]) | (f32_to_bf16(hi[1]) << 16);
+              o[3] = f32_to_bf16(hi[2]) | (f32_to_bf16(hi[3]) << 16);
+              *reinterpret_cast<u32x4*>(q) = o;
+            } else {
+              float* q = static_cast<float*>(C) + (row0 + row) * ldc + c;
+              if (ep.accumulate) lo += *reinterpret_cast<const f32x4_t*>(q);
+              *reinterpret_cast<f32x4_t*>(q) = lo;
+            }
+          }
+        } else {
+          for (int idx = tid; idx < rows_here * N; idx += nthreads) {
+            const int row = idx / N, c = idx - row * N;
+            float v = ct[row * NC + c];
+            if (ep.c_bf16) {
+              uint16_t* q = static_cast<uint16_t*>(C) + (row0 + row) * ldc + c;
+              if (ep.accumulate) v += __uint_as_float((unsigned int)*q << 16);
+              *q = (uint16_t)f32_to_bf16(v);
+            } else {
+              float* q = static_cast<float*>(C) + (row0 + row) * ldc + c;
+              if (ep.accumulate) v += *q;
+              *q = v;
+            }
+          }
+        }
+      }
+      if (m + 1 < MT) lds_barrier();  // (after the last block the barrier at the top of the tile loop protects the image)
+    }
+  }
+}
+
+bool rows_applies(int64_t M, int64_t N, int64_t kp, int slices) {
+  return slices == 1 && M >= 2048 && ((N <= 256 && kp <= 512) || (N <= 512 && kp <= 208));
+}
+
+template <int KSM, int MAXW, int RT>
+int rows_launch(int64_t M, int64_t N, int64_t kp, const uint16_t* a, int64_t la, const uint16_t* b, int64_t lb, void* C, int64_t ldc, const Epilogue& ep,
+                hipStream_t st) {
+  constexpr int MINW = MAXW >= 8 ? 8 : 4;
+  const int nwc = (int)((N + 31) / 32);
+  const int waves = nwc < MINW ? MINW : nwc;  // the staging plan is sized for at least this many threads
+  const size_t lds = (size_t)2 * RT * (KSM * 32 + 16) + (size_t)32 * 32 * nwc * sizeof(float);  // two A images + the fp32 output image of 32 rows
+  const int vec_ok = dh::aligned16(C) && ldc % (ep.c_bf16 ? 8 : 4) == 0 && N % (ep.c_bf16 ? 8 : 4) == 0;
+  static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_rows_kernel<KSM, MAXW, RT>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+  if (!lds_ok) return dh::fail(DH_ERR_LAUNCH, "dh_gemm_bf16: cannot raise the dynamic LDS limit");
+  const int64_t n_tiles = dh::ceil_div(M, (int64_t)RT);
+  const int per_cu = lds <= 76 * 1024 && waves <= 8 && KSM <= 4 ? 2 : 1;  // 2 workgroups per CU where LDS and registers (<= 128) allow
+  const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
+  hipLaunchKernelGGL((gemm_bf16_rows_kernel<KSM, MAXW, RT>), dim3(grid), dim3(64 * waves), lds, st, M, (int)N, (int)kp, a, la, b, lb, C, ldc, ep, nwc, vec_ok);
+  return dh::check_launch("dh_gemm_bf16(rows)");
+}
+
+int rows_dispatch(int64_t M, int64_t N, int64_t kp, const uint16_t* a, int64_t la, const uint16_t* b, int64_t lb, void* C, int64_t ldc, const Epilogue& ep,
+                  hipStream_t st) {
+  const int ks = (int)((kp + 15) / 16);
+  if (N > 256) {  // up to 16 column tiles: 1024 threads, 128 registers
+    if (ks <= 4) return rows_launch<4, 16, 32>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+    if (ks <= 8) return rows_launch<8, 16, 32>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+    return rows_launch<13, 16, 32>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+  }
+  if (ks <= 4) return rows_launch<4, 8, 64>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+  if (ks <= 8) return rows_launch<8, 8, 64>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+  if (ks <= 13) return rows_launch<13, 8, 64>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+  if (ks <= 16) return rows_launch<16, 8, 64>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+  if (ks <= 26) return rows_launch<26, 8, 64>(M, N, kp, a, la, b, lb, C, ldc, ep, st);
+  return rows_launch<32, 8, 32>(M, N, kp, a, la, b, lb, C, ldc, ep, st);  // (two 64-row images of 1 KB rows + the patches exceed 160 KB)
+}
+
 struct Plan {
   bool repack_a, repack_b;
   int64_t kp;           // padded K (leading dimension of repacked operands)
@@ -181,6 +413,8 @@ extern "C" int dh_gemm_bf16(int64_t M, int64_t N, int64_t K, int trans_a, int tr
     hipLaunchKernelGGL(repack_bf16_kernel, grid, dim3(256), 0, st, rows, cols, B, ldb, bp, p.kp, trans_b ? 0 : 1);
     b = bp; lb = p.kp;
   }
+  if (rows_applies(M, N, p.kp, p.slices))  // long and narrow: B stationary in registers, A streamed once
+    return rows_dispatch(M, N, p.kp, a, la, b, lb, C, ldc, ep, st);
   float* slabs = p.slices > 1 ? reinterpret_cast<float*>(ws + p.a_bytes + p.b_bytes) : nullptr;
   dim3 grid((unsigned)(dh::ceil_div(M, BM) * dh::ceil_div(N, BN)), 1, (unsigned)p.slices);
   constexpr size_t kTileLds = (size_t)TILE_LDS_ELEMS * sizeof(uint16_t);  // 72 KB: above the 64 KB default limit of dynamic LDS

@@ -102,6 +102,17 @@ GEMM_CASES = [  # M, N, K, trans_a, trans_b
     (64, 513, 72, True, True),
     (1000, 128, 128, False, True),
     (5, 3, 8, False, False),
+    # long and narrow (gemm_bf16_rows_kernel: B stationary in registers, A streamed through LDS once)
+    (5000, 200, 400, False, True),    # the C3 dense update: 26 K-steps, 7 column tiles, last one 8 columns wide
+    (4099, 400, 200, False, False),   # its dX: 13 K-steps (the last one half empty), 13 column tiles, ragged last row tile
+    (3000, 64, 512, False, True),     # 32 K-steps
+    (2500, 256, 256, False, True),
+    (2100, 7, 50, False, True),       # padded copies, one column tile of 7
+    (2049, 33, 8, False, True),
+    (2200, 96, 128, False, True),     # the remaining register buckets of that kernel: 8 / 13 K-steps, and 4 / 8 with more than 8 column tiles
+    (2300, 100, 200, False, True),
+    (2400, 300, 64, False, True),
+    (2400, 320, 120, False, True),
 ]
 
 
@@ -127,6 +138,33 @@ def test_gemm_bf16(cuda_device, M, N, K, ta, tb):
     acc = torch.ones((M, N), dtype=torch.float32, device=cuda_device)
     kernels.gemm_bf16(ad, bd, trans_a=ta, trans_b=tb, out=acc, accumulate=True)
     assert rel_err(acc.cpu().numpy(), ref.numpy() + 1.0) < 1e-5
+
+
+def test_gemm_bf16_rows_unaligned_output(cuda_device):
+    """The long-and-narrow kernel with an output it cannot store 16 bytes at a time (odd leading dimension, offset view),
+    bf16 accumulate, and NaN / Inf confined to their own rows."""
+    from dance_amd import kernels
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 3000, 200, 400
+    a = torch.randn((M, K), generator=g).to(BF16)
+    a[17, 3] = float("inf")
+    a[1999, 399] = float("nan")
+    w = torch.randn((N, K), generator=g).to(BF16)
+    ref = a.to(torch.float64) @ w.to(torch.float64).T
+    ad, wd = a.to(cuda_device), w.to(cuda_device)
+    big = torch.zeros((M, N + 3), dtype=torch.float32, device=cuda_device)
+    out = big[:, 1:N + 1]
+    kernels.gemm_bf16(ad, wd, trans_b=True, out=out)
+    got = out.cpu().numpy()
+    ok = np.ones(M, dtype=bool)
+    ok[[17, 1999]] = False
+    assert rel_err(got[ok], ref.numpy()[ok]) < 1e-5
+    assert not np.isfinite(got[17]).any() and np.isnan(got[1999]).all()
+    assert float(big[:, 0].abs().max()) == 0 and float(big[:, N + 1:].abs().max()) == 0
+    c16 = torch.ones((M, N), dtype=BF16, device=cuda_device)
+    kernels.gemm_bf16(ad, wd, trans_b=True, out=c16, accumulate=True)
+    want = (torch.from_numpy(ref.numpy()[ok]).float() + 1.0).to(BF16)
+    assert torch.equal(c16.cpu()[torch.from_numpy(ok)], want) or rel_err(c16.cpu()[torch.from_numpy(ok)].float().numpy(), want.float().numpy()) < 4e-3
 
 
 def test_gemm_bf16_strided_rows(cuda_device):
