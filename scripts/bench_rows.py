@@ -191,13 +191,17 @@ def main():
             m = ScDeepSort(dfeat, 200, 1, "synthetic", "c3", batch_size=bs, device="cuda", save_root=tmp, verbose=False, compute_dtype=cd)
             torch.manual_seed(0)
             m.fit(cg, labels, epochs=1, lr=1e-3, val_ratio=0.2)  # warm-up epoch (allocator, lazy init)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with kernels.KernelTimer() as tm:
-                m.fit(cg, labels, epochs=1, lr=1e-3, val_ratio=0.2)
+            dt = None
+            for _ in range(2):  # best of two: a fit call also writes a checkpoint to a temporary directory (one run in ten is 2x off)
                 torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            ks = {kname: [v[0], round(v[0] * v[1], 2)] for kname, v in tm.summary().items()}
+                t0 = time.perf_counter()
+                with kernels.KernelTimer() as tm:
+                    m.fit(cg, labels, epochs=1, lr=1e-3, val_ratio=0.2)
+                    torch.cuda.synchronize()
+                t = time.perf_counter() - t0
+                if dt is None or t < dt:
+                    dt = t
+                    ks = {kname: [v[0], round(v[0] * v[1], 2)] for kname, v in tm.summary().items()}
         rows[f"ScDeepSort.fit 1 epoch (train + 2 eval passes) cells={n_cells} batch={bs} compute_dtype={cd}"] = dict(
             ms=dt * 1e3, cells_per_s=n_cells / dt, hip_kernels_calls_total_ms=ks,
             note="includes the block sampler (torch index ops) and checkpoint save per the reference's fit loop")
