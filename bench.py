@@ -231,11 +231,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     _lib.require_device()
+    # Development switches (never set by the driver): DANCE_AMD_BENCH_ONE_GPU=1 puts every rank on GPU 0 and DANCE_AMD_BENCH_BACKEND=gloo
+    # replaces RCCL (which refuses two ranks on one device) — the only way to run the P > 1 code path, with the real kernels, streams and
+    # events, on a one-GPU box.  Such a line is labelled "backend": "gloo ..." and is a functional check, not a measurement.
+    backend = os.environ.get("DANCE_AMD_BENCH_BACKEND", "nccl")
+    if os.environ.get("DANCE_AMD_BENCH_ONE_GPU"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
 
     n = args.cells
 
@@ -410,6 +416,8 @@ def main():
                        "parallelism": f"dst-range x{world}, {mode} exchange" if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels_out,
         }
+        if backend != "nccl":
+            out["backend"] = f"{backend} (development run, all ranks on one GPU: NOT a measurement)"
         if world > 1:
             out["exchange"] = {m: {"ms_per_step": round(r["elapsed"] / args.steps * 1e3, 4), "value": n / (r["elapsed"] / args.steps),
                                    "bytes_on_wire_per_step_per_rank": int(r["exchange_only_bytes"]),
