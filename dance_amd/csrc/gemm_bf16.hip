@@ -116,8 +116,11 @@ __global__ __launch_bounds__(256) void repack_bf16_kernel(int64_t rows, int64_t 
 // Measured (profiles/r03o_gemm_bf16_rows.json): 1M x 400 -> 200 with bias + ReLU 0.39 ms = 3.1 TB/s = 0.38 of HBM (tiled kernel: 0.72
 // ms).  What is left: the B fragments take 104 of 222 registers, so a CU holds ONE workgroup and the three phases of a row tile run
 // one after the other — alone, the loads take 0.14 ms (5.6 TB/s), the MFMAs + fragment reads 0.13 ms, the output 0.17 ms; together 0.39.
-// Reads are in flight only for the first third of an iteration; a DMA ring of 32-row images (global_load_lds, no staging registers,
-// three tiles ahead) would keep them in flight throughout and is the next step (expected 0.29 ms = compute + output).
+// Keeping reads in flight throughout was tried and is NOT the lever: a ring of four 32-row images filled by LDS DMA three tiles ahead
+// (global_load_lds_dwordx4, no staging registers, counted vmcnt so that output stores never block the wait; parity-green) measured
+// 0.42 ms — the MFMA + output phases of the one 8-wave workgroup run in lockstep behind their own LDS round trips and barriers (0.29
+// ms without any load), and 32-row tiles double that per-tile cost.  The next step is more waves per CU: two waves per column tile,
+// each holding half of K (52 registers of B instead of 104 -> four waves per SIMD), partial sums combined in the output image.
 // Workgroup barrier that orders LDS traffic only (__syncthreads() is a workgroup-scope fence: the compiler may drain vmcnt in front of
 // it, which would make every barrier of the tile loop wait for the output stores just issued and for the prefetch of the next tile).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
