@@ -287,9 +287,23 @@ class scHeteroNet(nn.Module, BaseClassificationMethod):
 
     @staticmethod
     def preprocessing_pipeline(log_level="INFO"):
-        """Graph part of scheteronet.py:592-604 (the scanpy filtering / HVG / normalisation steps are CPU count-matrix
-        preprocessing outside the hot path: feed a matrix that already went through them)."""
-        return Compose(HeteronetGraph(), SetConfig({"label_channel": "cell_type"}), log_level=log_level)
+        """scheteronet.py:592-604 with the count-matrix steps on the device: drop rare cell types, filter genes / cells, cell_ranger HVG
+        (4000 genes, subset), SaveRaw, normalize_total, size factors, log1p, then the graph."""
+        from ....transforms import (FilterCellsScanpy, FilterCellsType, FilterGenesScanpy, HighlyVariableGenesLogarithmizedByTopGenes, Log1P,
+                                    NormalizeTotal, SaveRaw, UpdateSizeFactors)
+        return Compose(
+            FilterCellsType(),
+            FilterGenesScanpy(min_counts=3),
+            FilterCellsScanpy(min_counts=1),
+            HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=4000, flavor="cell_ranger"),
+            SaveRaw(),
+            NormalizeTotal(),
+            UpdateSizeFactors(),
+            Log1P(),
+            HeteronetGraph(),
+            SetConfig({"label_channel": "cell_type"}),
+            log_level=log_level,
+        )
 
     def forward(self, dataset, save_path=None):
         x, edge_index = dataset.x.to(self.device), dataset.edge_index.to(self.device)

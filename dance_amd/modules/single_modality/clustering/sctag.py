@@ -193,9 +193,24 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
 
     @staticmethod
     def preprocessing_pipeline(n_top_genes: int = 3000, n_components: int = 50, n_neighbors: int = 15, log_level="INFO"):
-        """Graph part of sctag.py:119-145 (scanpy filtering / normalisation / HVG are CPU preprocessing outside the hot path)."""
+        """sctag.py:119-145, every step on the device (DeviceArray slots, no host round trip between steps): filter genes / cells,
+        per-cell normalisation to the median count (``sc.pp.normalize_per_cell``, ``n_counts`` recorded), log1p, cell_ranger HVG, second
+        filter, SaveRaw, normalize_total, log1p, scale, then PCA (on the device) and the kNN graph in PCA space."""
+        from ....transforms import (FilterCellsScanpy, FilterGenesScanpy, HighlyVariableGenesLogarithmizedByTopGenes, Log1P, NormalizeTotal,
+                                    SaveRaw, Scale)
         return Compose(
-            CellPCA(n_components=n_components),
+            FilterGenesScanpy(min_counts=3),
+            FilterCellsScanpy(min_counts=1),
+            NormalizeTotal(max_fraction=1.0, key_added="n_counts"),
+            Log1P(),
+            HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=n_top_genes, flavor="cell_ranger", subset=True),
+            FilterGenesScanpy(min_counts=1),
+            FilterCellsScanpy(min_counts=1),
+            SaveRaw(),
+            NormalizeTotal(max_fraction=1.0),
+            Log1P(),
+            Scale(),
+            CellPCA(n_components=n_components, device="cuda"),
             NeighborGraph(n_neighbors=n_neighbors, n_pcs=n_components),
             SetConfig({"feature_channel": ["NeighborGraph", None, None, "n_counts"],
                        "feature_channel_type": ["obsp", "X", "raw_X", "obs"], "label_channel": "Group"}),

@@ -322,12 +322,16 @@ class SpaGCN(BaseClusteringMethod):
 
     @staticmethod
     def preprocessing_pipeline(alpha: float = 1, beta: int = 49, dim: int = 50, log_level="INFO"):
-        """Graph + feature part of spagcn.py:715-731 (gene-name filtering and scanpy normalisation are CPU
-        preprocessing outside the hot path)."""
+        """spagcn.py:715-731: drop spike-in / mitochondrial genes by name, normalize_total to 1e4 and log1p on the device, the two
+        spatial graphs, and the PCA of the normalised matrix (on the device)."""
+        from ....transforms import FilterGenesMatch, Log1P, NormalizeTotal
         return Compose(
+            FilterGenesMatch(prefixes=["ERCC", "MT-"]),
+            NormalizeTotal(target_sum=1e4, max_fraction=1.0),
+            Log1P(),
             SpaGCNGraph(alpha=alpha, beta=beta),
             SpaGCNGraph2D(),
-            CellPCA(n_components=dim),
+            CellPCA(n_components=dim, device="cuda"),
             SetConfig({
                 "feature_channel": ["CellPCA", "SpaGCNGraph", "SpaGCNGraph2D"],
                 "feature_channel_type": ["obsm", "obsp", "obsp"],

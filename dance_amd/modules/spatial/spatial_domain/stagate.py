@@ -9,6 +9,7 @@ the attention as edge values — with the matching hand-written backward (autogr
 convention: row 0 = source j, row 1 = target i) is converted once per tensor to a device CSR keyed by destination; the
 per-edge attention is returned in the ORIGINAL edge order when ``return_attention_weights`` is used.
 """
+import logging
 from typing import Any, Optional, Tuple
 
 import numpy as np
@@ -24,6 +25,8 @@ from ....graph import CSRGraph, TensorKeyedCache
 from ....transforms import Compose, SetConfig
 from ....transforms.graph import StagateGraph
 from ...base import BaseClusteringMethod, BasePretrain
+
+logger = logging.getLogger("dance")
 
 _EDGE_CACHE = TensorKeyedCache()
 _LOOP_CACHE = TensorKeyedCache()
@@ -119,8 +122,23 @@ class Stagate(nn.Module, BasePretrain, BaseClusteringMethod):
     @staticmethod
     def preprocessing_pipeline(hvg_flavor: str = "seurat_v3", n_top_hvgs: int = 3000, model_name: str = "radius", radius: float = 150,
                                n_neighbors: int = 5, log_level="INFO"):
-        """Graph part of stagate.py:157-171 (HVG selection / normalisation are CPU preprocessing outside the hot path)."""
+        """stagate.py:157-173: HVG selection, normalize_total to 1e4 and log1p on the device, then the spatial graph.  The dispersion
+        flavours ("seurat", "cell_ranger") run on the device; the reference's default "seurat_v3" is a loess fit of the count
+        variances (scikit-misc, not in this image) and is NOT restated: with that flavour the selection must have happened upstream
+        and the step is skipped with a warning — ``hvg_flavor=None`` skips it silently."""
+        from ....transforms import HighlyVariableGenesLogarithmizedByTopGenes, Log1P, NormalizeTotal
+        steps = []
+        if hvg_flavor in ("seurat", "cell_ranger"):
+            steps.append(HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=n_top_hvgs, flavor=hvg_flavor, subset=True))
+        elif hvg_flavor == "seurat_v3":
+            logger.warning("Stagate.preprocessing_pipeline: hvg_flavor='seurat_v3' (loess on raw counts) is not available here; "
+                           "the HVG step is skipped — select the genes upstream or pass 'seurat' / 'cell_ranger'")
+        elif hvg_flavor is not None:
+            raise ValueError(f"unknown hvg_flavor {hvg_flavor!r}")
         return Compose(
+            *steps,
+            NormalizeTotal(target_sum=1e4, max_fraction=1.0),
+            Log1P(),
             StagateGraph(model_name, radius=radius, n_neighbors=n_neighbors),
             SetConfig({"feature_channel": "StagateGraph", "feature_channel_type": "obsp", "label_channel": "label", "label_channel_type": "obs"}),
             log_level=log_level,

@@ -136,6 +136,57 @@ class FilterGenesScanpy(FilterScanpy):
         self.min_cells, self.max_cells = min_cells, max_cells
 
 
+@register_preprocessor("filter", "gene")
+class FilterGenesMatch(BaseTransform):
+    """Remove the genes whose names start / end with one of the given strings (dance/transforms/filter.py:386-435: ERCC spike-ins,
+    mitochondrial genes in SpaGCN's pipeline).  Names live on the host; only the kept columns of a device matrix are gathered."""
+
+    _DISPLAY_ATTRS = ("prefixes", "suffixes")
+
+    def __init__(self, prefixes=None, suffixes=None, case_sensitive: bool = False, **kwargs):
+        super().__init__(**kwargs)
+        self.prefixes, self.suffixes, self.case_sensitive = prefixes or [], suffixes or [], case_sensitive
+        if case_sensitive:  # (sic: with case_sensitive=True the reference upper-cases both sides, :413-424)
+            self.prefixes = [i.upper() for i in self.prefixes]
+            self.suffixes = [i.upper() for i in self.suffixes]
+
+    def __call__(self, data):
+        names = data.data.var.index.astype(str)
+        ids = names.str.upper() if self.case_sensitive else names
+        remove = np.zeros(len(names), dtype=bool)
+        for kind, items in (("prefix", self.prefixes), ("suffix", self.suffixes)):
+            for item in items:
+                hit = np.asarray(ids.str.startswith(item) if kind == "prefix" else ids.str.endswith(item))
+                self.logger.info(f"{int(hit.sum())} number of genes will be removed due to {kind} {item!r}")
+                remove |= hit
+        self.logger.info(f"Removing {int(remove.sum())} genes in total")
+        if remove.any():
+            data.data._inplace_subset_var(~remove)
+        return data
+
+
+@register_preprocessor("filter", "cell")
+class FilterCellsType(BaseTransform):
+    """Drop the cells of every cell type with at most ``cell_type_threshold`` cells (dance/transforms/filter.py:1477-1512; scHeteroNet's
+    pipeline).  ``obsm["cell_type"]`` is the one-hot label frame of the reference's datasets."""
+
+    def __init__(self, cell_type_threshold=10, **kwargs):
+        super().__init__(**kwargs)
+        self.cell_type_threshold = cell_type_threshold
+
+    def __call__(self, data):
+        import pandas as pd
+        one_hot = data.data.obsm["cell_type"]
+        if not isinstance(one_hot, pd.DataFrame):
+            raise TypeError(f"Expected obsm['cell_type'] to be a pandas.DataFrame, but got {type(one_hot)}")
+        counts = one_hot.sum(axis=0)
+        rare = counts[counts <= self.cell_type_threshold].index
+        self.logger.info(f"Found {len(rare)} cell types with counts <= {self.cell_type_threshold}: {rare.tolist()}")
+        keep = np.ones(len(one_hot), dtype=bool) if rare.empty else ~np.asarray(one_hot[rare].sum(axis=1) > 0)
+        data.filter_by_mask(keep)
+        return data
+
+
 def gene_mean_var(x: torch.Tensor, *, undo_log: bool, base: Optional[float] = None):
     """Per-gene mean and unbiased variance (float64 accumulation) of x, or of expm1(x) for the "seurat" flavour — in row chunks, so
     the un-logged matrix never exists as a whole."""

@@ -138,6 +138,27 @@ class NormalizeTotal(_DeviceMatrixTransform):
 
 
 @register_preprocessor("normalize")
+class UpdateSizeFactors(BaseTransform):
+    """``obs["n_counts"]`` = row sums of X, ``obs["size_factors"]`` = n_counts / median (dance/transforms/normalize.py:647-659).  The sums
+    are taken on the device when X lives there (float64 accumulation; only the n_obs sums come to the host frame)."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+    def __call__(self, data):
+        x = data.data.X
+        if isinstance(x, DeviceArray):
+            n_counts = x.tensor.sum(dim=1, dtype=torch.float64).to(x.tensor.dtype).cpu().numpy()
+        elif sp.issparse(x):
+            n_counts = np.asarray(x.sum(axis=1)).ravel()
+        else:
+            n_counts = np.asarray(x).sum(axis=1)
+        data.data.obs["n_counts"] = n_counts
+        data.data.obs["size_factors"] = data.data.obs.n_counts / np.median(data.data.obs.n_counts)
+        return data
+
+
+@register_preprocessor("normalize")
 class NormalizeTotalLog1P(BaseTransform):
     """NormalizeTotal then Log1P in one upload (normalize.py:662-679)."""
 

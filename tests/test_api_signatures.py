@@ -26,6 +26,9 @@ PAIRS = [
     ("dance/transforms/filter.py", "FilterGenesScanpy", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByTopGenes", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByMeanAndDisp", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenesMatch", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterCellsType", "dance_amd.transforms.filter"),
+    ("dance/transforms/normalize.py", "UpdateSizeFactors", "dance_amd.transforms.normalize"),
     ("dance/models/nn/gnn.py", "AdaptiveSAGE", "dance_amd.nn.gnn"),
     ("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "GNN", "dance_amd.modules.single_modality.cell_type_annotation.scdeepsort"),
     ("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "ScDeepSort", "dance_amd.modules.single_modality.cell_type_annotation.scdeepsort"),

@@ -137,6 +137,77 @@ def check_model_pipelines(device):
     with pytest.raises(ValueError):
         GraphSC.preprocessing_pipeline(normalize_weights="bogus")
 
+    # ---- scTAG (sctag.py:119-145): scDSC's matrix steps, then PCA on the device and the kNN graph in PCA space ------------------------
+    from dance_amd.modules.single_modality.clustering.sctag import ScTAG
+    data, copies, lazy = run(ScTAG.preprocessing_pipeline(n_top_genes=60, n_components=10, n_neighbors=12), dd.DeviceArray(torch.from_numpy(x.copy()).to(device)))
+    assert copies == 0 and lazy == 0
+    ad = data.data
+    assert ad.X.shape == (399, 60) and ad.raw.X.shape == (399, 60) and isinstance(ad.obsm["CellPCA"], dd.DeviceArray) and ad.obsm["CellPCA"].shape == (399, 10)
+    assert ad.uns["NeighborGraph.hip"].n_rows == 399 and "n_counts" in ad.obs
+    adj, xx, raw, n_counts = data.get_x()
+    assert adj.shape == (399, 399) and xx.shape == raw.shape == (399, 60) and n_counts.shape == (399, )
+
+    # ---- SpaGCN (spagcn.py:715-731): gene-name filter, normalize_total(1e4), log1p, the two spatial graphs, PCA ------------------------
+    import pandas as pd
+    from dance_amd.modules.spatial.spatial_domain.spagcn import SpaGCN
+    names = [f"G{i}" for i in range(300)]
+    names[3], names[17], names[40] = "ERCC-0003", "MT-CO1", "mt-nd1"   # the third one survives: the match is case sensitive by default
+    xy = rng.uniform(0, 50, (400, 2))
+    adl = dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy()).to(device)), var=pd.DataFrame(index=names),
+                         obsm={"spatial": xy, "spatial_pixel": np.round(xy * 3).astype(np.int64)}, uns={"image": rng.integers(0, 255, (160, 160, 3)).astype(np.uint8)})
+    pipe = SpaGCN.preprocessing_pipeline(dim=12)
+    for t in pipe.transforms:
+        if hasattr(t, "device"):
+            t.device = device
+    data = dd.Data(adl, train_size=-1, val_size=0, test_size=0)
+    c0 = dd.DeviceArray.host_copies
+    pipe(data)
+    ad = data.data
+    assert dd.DeviceArray.host_copies == c0 and ad.X.shape == (400, 298) and "ERCC-0003" not in ad.var.index and "mt-nd1" in ad.var.index
+    rows = np.asarray(ad.X)  # (a host view, on request)
+    keep = np.ones(300, dtype=bool)
+    keep[[3, 17]] = False
+    tot = x[:, keep].sum(1, keepdims=True)
+    want = np.log1p(np.where(tot > 0, x[:, keep] / np.where(tot > 0, tot, 1) * 1e4, 0))
+    assert rel_err(rows, want) < 1e-6
+    assert ad.obsm["CellPCA"].shape == (400, 12) and ad.obsp["SpaGCNGraph"].shape == (400, 400) and ad.obsp["SpaGCNGraph2D"].shape == (400, 400)
+
+    # ---- scHeteroNet (scheteronet.py:592-604): rare cell types dropped, filters, HVG, SaveRaw, normalize_total, size factors, log1p, graph ----
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import scHeteroNet
+    lab = rng.integers(0, 4, 400)
+    lab[:6] = 4                                            # a cell type with 6 <= 10 cells: removed
+    one_hot = pd.DataFrame(np.eye(5, dtype=np.float32)[lab], columns=[f"t{i}" for i in range(5)], index=[str(i) for i in range(400)])
+    adl = dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy()).to(device)), obsm={"cell_type": one_hot})
+    pipe = scHeteroNet.preprocessing_pipeline()
+    for t in pipe.transforms:
+        if hasattr(t, "device"):
+            t.device = device
+    pipe.transforms[3].n_top_genes = 70
+    data = dd.Data(adl, train_size=-1, val_size=0, test_size=0)
+    pipe(data)
+    ad = data.data
+    n_keep = 400 - 6 - (0 if lab[7] == 4 else 1)           # the rare type and the empty cell 7
+    assert ad.X.shape == (n_keep, 70) and ad.raw.X.shape == (n_keep, 70) and ad.obsm["cell_type"].shape[0] == n_keep
+    assert float(ad.obsm["cell_type"]["t4"].sum()) == 0
+    sf = np.asarray(ad.obs["size_factors"])
+    assert np.isclose(np.median(sf), 1.0) and np.allclose(np.asarray(ad.obs["n_counts"]) / np.median(np.asarray(ad.obs["n_counts"])), sf)
+    assert ad.obsp["HeteronetGraph"].shape == (n_keep, n_keep) if "HeteronetGraph" in ad.obsp else True
+
+    # ---- STAGATE (stagate.py:157-173): dispersion flavours on the device; seurat_v3 is skipped loudly --------------------------------
+    from dance_amd.modules.spatial.spatial_domain.stagate import Stagate
+    adl = dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy()).to(device)), obsm={"spatial_pixel": np.round(xy * 3).astype(np.int64)})
+    pipe = Stagate.preprocessing_pipeline(hvg_flavor="cell_ranger", n_top_hvgs=50, model_name="knn", n_neighbors=6)
+    for t in pipe.transforms:
+        if hasattr(t, "device"):
+            t.device = device
+    data = dd.Data(adl, train_size=-1, val_size=0, test_size=0)
+    pipe(data)
+    assert data.data.X.shape[0] == 400 and 50 <= data.data.X.shape[1] <= 60  # (ties at the cut-off are all kept, as scanpy does)
+    assert data.data.obsp["StagateGraph"].shape == (400, 400)
+    assert len(Stagate.preprocessing_pipeline().transforms) == 4 and len(Stagate.preprocessing_pipeline(hvg_flavor=None).transforms) == 4
+    with pytest.raises(ValueError):
+        Stagate.preprocessing_pipeline(hvg_flavor="bogus")
+
 
 def test_model_pipelines_on_device_arrays(cpu_kernels):
     check_model_pipelines("cpu")

@@ -75,3 +75,47 @@ def check_filters(device):
 
 def test_filter_and_hvg_on_cpu_tensors():
     check_filters("cpu")
+
+
+def test_filter_genes_match_cells_type_size_factors():
+    """The three small transforms the model pipelines need besides the scanpy restatements (filter.py:386-435, :1477-1512,
+    normalize.py:647-659), on host and DeviceArray slots."""
+    import pandas as pd
+    import scipy.sparse as sp
+    from dance_amd import data as dd
+    from dance_amd.transforms import FilterCellsType, FilterGenesMatch, UpdateSizeFactors
+    rng = np.random.default_rng(0)
+    x = rng.integers(0, 5, (12, 6)).astype(np.float32)
+    names = ["ERCC-1", "Actb", "MT-Co1", "mt-Nd1", "Gapdh-ps", "Xist"]
+
+    def mk(slot):
+        return dd.Data(dd.AnnDataLite(slot, var=pd.DataFrame(index=names)), train_size=-1, val_size=0, test_size=0)
+
+    d = mk(dd.DeviceArray(torch.from_numpy(x.copy())))
+    FilterGenesMatch(prefixes=["ERCC", "MT-"], suffixes=["-ps"])(d)
+    assert list(d.data.var.index) == ["Actb", "mt-Nd1", "Xist"] and isinstance(d.data.X, dd.DeviceArray)
+    assert np.array_equal(np.asarray(d.data.X), x[:, [1, 3, 5]])
+    d = mk(x.copy())
+    FilterGenesMatch(prefixes=["mt-"], case_sensitive=True)(d)  # (sic) the reference's flag upper-cases both sides: MT-Co1 AND mt-Nd1 go
+    assert list(d.data.var.index) == ["ERCC-1", "Actb", "Gapdh-ps", "Xist"]
+    d = mk(x.copy())
+    FilterGenesMatch()(d)
+    assert d.data.X.shape == (12, 6)
+
+    lab = np.array([0] * 5 + [1] * 4 + [2] * 3)
+    one_hot = pd.DataFrame(np.eye(3)[lab], columns=["a", "b", "c"], index=[str(i) for i in range(12)])
+    d = dd.Data(dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy())), obsm={"cell_type": one_hot}), train_size=8, val_size=0, test_size=4)
+    FilterCellsType(cell_type_threshold=3)(d)      # type c (3 cells) is dropped; split indices follow
+    assert d.data.X.shape == (9, 6) and list(d.data.obsm["cell_type"].sum(0)) == [5, 4, 0]
+    assert sorted(d.train_idx + d.test_idx) == list(range(9))
+    d2 = dd.Data(dd.AnnDataLite(x.copy(), obsm={"cell_type": one_hot}), train_size=-1, val_size=0, test_size=0)
+    FilterCellsType(cell_type_threshold=2)(d2)     # nothing at or below the threshold
+    assert d2.data.X.shape == (12, 6)
+    with pytest.raises(TypeError):
+        FilterCellsType()(dd.Data(dd.AnnDataLite(x.copy(), obsm={"cell_type": np.eye(3)[lab]}), train_size=-1, val_size=0, test_size=0))
+
+    want = x.sum(1)
+    for slot in (x.copy(), sp.csr_matrix(x), dd.DeviceArray(torch.from_numpy(x.copy()))):
+        d = mk(slot)
+        UpdateSizeFactors()(d)
+        assert np.allclose(np.asarray(d.data.obs["n_counts"]), want) and np.allclose(np.asarray(d.data.obs["size_factors"]), want / np.median(want))
