@@ -35,6 +35,11 @@ class CSRGraph:
     def from_scipy(cls, mat, device="cuda", *, symmetric: bool = False) -> "CSRGraph":
         """Host scipy sparse matrix -> device CSR (index order preserved after canonical CSR conversion)."""
         import scipy.sparse as sp
+        if isinstance(mat, LazyScipyCSR):  # left in obsp by an on-device graph transform: the device graph is already there
+            g = mat.graph
+            if torch.device(device).type == g.device.type:
+                return g
+            mat = mat.materialize()
         csr = sp.csr_matrix(mat)
         csr.sum_duplicates()
         csr.sort_indices()

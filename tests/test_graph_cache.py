@@ -75,3 +75,16 @@ def test_permute_keeps_row_order_and_renumbers_the_cached_transpose():
     shuffled = ring[p][:, p].tocsr()
     gs = CSRGraph.from_scipy(shuffled, "cpu", symmetric=True)
     assert band(gs.permute(locality_order(gs)).to_scipy()) <= 2 < band(shuffled)
+
+
+def test_from_scipy_takes_the_device_graph_of_a_lazy_obsp_slot():
+    """``obsp["NeighborGraph"]`` of an on-device pipeline is a LazyScipyCSR; a model that calls ``CSRGraph.from_scipy`` on it (ScDSC.fit)
+    gets the device graph itself — no host copy, no re-upload."""
+    import numpy as np
+    import torch
+    from dance_amd.graph import CSRGraph, LazyScipyCSR
+    g = CSRGraph(torch.tensor([0, 1, 3], dtype=torch.int32), torch.tensor([1, 0, 1], dtype=torch.int32), torch.tensor([1.0, 2.0, 3.0]), 2, 2)
+    lazy = LazyScipyCSR(g)
+    c0 = LazyScipyCSR.host_copies
+    assert CSRGraph.from_scipy(lazy, "cpu") is g and LazyScipyCSR.host_copies == c0
+    assert np.array_equal(lazy.toarray(), [[0, 1], [2, 3]]) and LazyScipyCSR.host_copies == c0 + 1
