@@ -262,6 +262,33 @@ __global__ __launch_bounds__(256) void cells_static_pad_kernel(int64_t n_seeds, 
   }
 }
 
+// ---- degree scalings of a block (dgl GraphConv norm="both" / "right"; graphsc.py:444-474) -----------------------------------------------
+// rowscale[i] = f(in-degree of row i), colscale[j] = max(out-degree of column j, 1)^-1/2 counted over the entries of rows [0, n_rows) only
+// (a static block's padding tail lies behind them).  One memset + two launches; the torch formulation was 14 (arange / compare / casts /
+// zeros / index_add / clamp / rsqrt ...), i.e. 14 of the ~100 five-microsecond kernels of a captured batch-128 step.
+__global__ __launch_bounds__(256) void degree_count_kernel(int64_t n_rows, int64_t n_pad, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           int mode, float* __restrict__ rowscale, int32_t* __restrict__ count) {
+  const int64_t nnz = rowptr[n_rows];
+  if (blockIdx.x == 0 && threadIdx.x < n_pad) rowscale[n_rows + threadIdx.x] = 1.f;  // padding rows scale by one
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * 256) {
+    if (count) atomicAdd(count + col[e], 1);
+    if (e < n_rows) {
+      const float d = fmaxf((float)(rowptr[e + 1] - rowptr[e]), 1.f);
+      rowscale[e] = mode == DH_DEGREE_BOTH ? 1.f / sqrtf(d) : 1.f / d;
+    }
+  }
+  // (rows outnumber entries only for blocks without edges: finish the row scales)
+  for (int64_t i = max(nnz, (int64_t)0) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256) {
+    const float d = fmaxf((float)(rowptr[i + 1] - rowptr[i]), 1.f);
+    rowscale[i] = mode == DH_DEGREE_BOTH ? 1.f / sqrtf(d) : 1.f / d;
+  }
+}
+
+__global__ __launch_bounds__(256) void degree_colscale_kernel(int64_t n_cols, const int32_t* __restrict__ count, float* __restrict__ colscale) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n_cols) colscale[j] = 1.f / sqrtf(fmaxf((float)count[j], 1.f));  // correctly rounded sqrt and divide (within one rounding of pow(d, -0.5))
+}
+
 }  // namespace
 
 extern "C" size_t dh_block_cells_static_workspace_bytes(int64_t n_seeds) {
@@ -289,5 +316,23 @@ extern "C" int dh_block_cells_static(int64_t n_seeds, int64_t n_genes, int64_t e
   const unsigned pgrid = (unsigned)std::min<int64_t>(dh::ceil_div(e_max, 256), 1024);
   if (pgrid > 0)
     hipLaunchKernelGGL(cells_static_pad_kernel, dim3(pgrid), dim3(256), 0, st, n_seeds, e_max, block_rowptr, block_col, block_val);
+  return dh::check_launch(me);
+}
+
+extern "C" int dh_csr_degree_scales_f32(int64_t n_rows, int64_t n_pad, int64_t n_cols, const int32_t* rowptr, const int32_t* col, int mode,
+                                        float* rowscale, float* colscale, int32_t* count, dh_stream_t stream) {
+  const char* me = "dh_csr_degree_scales_f32";
+  if (n_rows < 0 || n_cols < 0 || n_pad < 0 || n_pad > 256) return dh::fail(DH_ERR_INVALID, "%s: bad size (n_pad <= 256)", me);
+  if (mode != DH_DEGREE_BOTH && mode != DH_DEGREE_MEAN) return dh::fail(DH_ERR_INVALID, "%s: bad mode %d", me, mode);
+  if (n_rows == 0 && n_cols == 0) return DH_OK;
+  if (!rowptr || (n_rows > 0 && !rowscale)) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  const bool cols = mode == DH_DEGREE_BOTH;
+  if (cols && n_cols > 0 && (!colscale || !count)) return dh::fail(DH_ERR_INVALID, "%s: mode BOTH needs colscale and the count buffer [n_cols]", me);  // (col may be null for a block without entries)
+  hipStream_t st = dh::as_stream(stream);
+  if (cols && n_cols > 0) (void)hipMemsetAsync(count, 0, (size_t)n_cols * sizeof(int32_t), st);
+  hipLaunchKernelGGL(degree_count_kernel, dim3(1024), dim3(256), 0, st, n_rows, n_pad, rowptr, col, mode, rowscale, cols && n_cols > 0 ? count : nullptr);
+  int rc = dh::check_launch(me);
+  if (rc != DH_OK || !cols || n_cols == 0) return rc;
+  hipLaunchKernelGGL(degree_colscale_kernel, dim3((unsigned)dh::ceil_div(n_cols, 256)), dim3(256), 0, st, n_cols, count, colscale);
   return dh::check_launch(me);
 }

@@ -792,6 +792,27 @@ def block_cells_static(rowptr, col, val, seeds: torch.Tensor, n_genes: int, brp:
           _dev(bad, torch.int32, "bad", 1), ws.data_ptr(), ws.numel(), _stream())
 
 
+DEGREE_BOTH, DEGREE_MEAN = 0, 1
+
+
+def degree_scales(rowptr: torch.Tensor, col: torch.Tensor, n_rows: int, n_cols: int, mode: int = DEGREE_BOTH, *, n_pad: int = 0):
+    """(rowscale [n_rows + n_pad], colscale [n_cols] or None): dh_csr_degree_scales_f32 over the entries of rows [0, n_rows) (``rowptr`` may
+    be longer: a static block's padding row, whose scale — the last ``n_pad`` entries — is 1).  DEGREE_BOTH: D_in^-1/2, D_out^-1/2
+    (degrees clamped at 1); DEGREE_MEAN: 1 / D_in."""
+    lib = _lib_ready()
+    dev = rowptr.device
+    rowscale = torch.empty(n_rows + n_pad, dtype=torch.float32, device=dev)
+    both = mode == DEGREE_BOTH
+    colscale = torch.empty(n_cols, dtype=torch.float32, device=dev) if both else None
+    count = torch.empty(n_cols, dtype=torch.int32, device=dev) if both else None
+    if rowptr.numel() < n_rows + 1:
+        raise ValueError("degree_scales: rowptr shorter than n_rows + 1")
+    _call("csr_degree_scales_f32", lib.dh_csr_degree_scales_f32, int(n_rows), int(n_pad), int(n_cols), _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), int(mode), rowscale.data_ptr(), None if colscale is None else colscale.data_ptr(),
+          None if count is None else count.data_ptr(), _stream())
+    return rowscale, colscale
+
+
 def block_cells_static_workspace_bytes(n_seeds: int) -> int:
     return int(_lib_ready().dh_block_cells_static_workspace_bytes(int(n_seeds)))
 

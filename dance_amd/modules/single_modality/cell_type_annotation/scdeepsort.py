@@ -149,7 +149,8 @@ class ScDeepSort(BaseClassificationMethod):
                            and str(self.device).startswith("cuda") and n_full >= HIPGRAPH_MIN_BATCHES and 1 < self.batch_size <= HIPGRAPH_MAX_BATCH
                            and not any(layer.use_neigh for layer in self.model.layers))
         self._captured = None
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph)
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph,
+                                          fused=str(self.device).startswith("cuda"))  # one kernel per step instead of ~14
         self.loss_fn = nn.CrossEntropyLoss(reduction="sum")
 
         # more than one process: data parallelism over the training cells (the graph is replicated, the model is small):

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from _synthetic import as_data, spots  # noqa: E402
 
-from dance_amd.modules.spatial.spatial_domain.spagcn import SpaGCN  # noqa: E402
+from dance_amd.modules.spatial.spatial_domain.spagcn import SpaGCN, refine  # noqa: E402
 
 
 def main(argv=None):
@@ -43,9 +43,12 @@ def main(argv=None):
     res = model.search_set_res((xf, adj), l=l, target_num=args.n_clusters, start=0.4, step=0.1, tol=args.tol, lr=args.lr, epochs=args.epochs,
                                max_run=args.max_run)
     pred = model.fit_predict((xf, adj), init_spa=True, init="louvain", tol=args.tol, lr=args.lr, epochs=args.epochs, res=res)
-    score = model.default_score_func(np.asarray(y).ravel(), pred)
-    print(f"SpaGCN l = {l:.4f}, res = {res}, ARI: {score:.4f}")
-    return score
+    y = np.asarray(y).ravel()
+    score = model.default_score_func(y, pred)
+    refined = refine(sample_id=data.data.obs.index.tolist(), pred=pred.tolist(), dis=adj_2d, shape="square")
+    score_refined = model.default_score_func(y, refined)
+    print(f"SpaGCN l = {l:.4f}, res = {res}, ARI: {score:.4f}, refined: {score_refined:.4f}")
+    return score_refined
 
 
 if __name__ == "__main__":

@@ -407,6 +407,15 @@ DH_API int dh_block_cells_static(int64_t n_seeds, int64_t n_genes, int64_t e_max
                           const int32_t* col, const float* val, int32_t* block_rowptr, int32_t* block_col, float* block_val,
                           int32_t* bad, void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* Degree scalings of a block for dgl.nn.GraphConv's norms as graph-sc's WeightedGraphConv applies them (dance graphsc.py:444-474):
+ * DH_DEGREE_BOTH: rowscale[i] = max(indeg(i), 1)^-1/2, colscale[j] = max(outdeg(j), 1)^-1/2; DH_DEGREE_MEAN: rowscale[i] = 1 / max(indeg(i), 1)
+ * (colscale, col, count unused).  Degrees are counted over the entries of rows [0, n_rows) — rowptr has at least n_rows + 1 entries; a
+ * static block's padding row and tail lie behind them; rowscale has n_rows + n_pad entries, the last n_pad (<= 256) are set to 1.
+ * count: caller-owned int32 [n_cols] scratch.  Three stream operations, no host read. */
+enum { DH_DEGREE_BOTH = 0, DH_DEGREE_MEAN = 1 };
+DH_API int dh_csr_degree_scales_f32(int64_t n_rows, int64_t n_pad, int64_t n_cols, const int32_t* rowptr, const int32_t* col, int mode,
+                             float* rowscale, float* colscale, int32_t* count, dh_stream_t stream);
+
 /* ---- K4/K7: AdaptiveSAGE message + mean aggregation -----------------------------------------
  * neigh[v,:] = mean_{e=(u->v)} alpha[idx(e)] * w_e * H[u,:], idx(e) chosen from the src/dst
  * "cell_id" arrays exactly as dance/models/nn/gnn.py:72-76 (gene->cell: src id; cell->gene:

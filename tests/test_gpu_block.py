@@ -51,3 +51,35 @@ def test_block_build_empty_and_sampler(cuda_device):
     assert torch.equal(out, seeds) and torch.equal(blocks[1].dstdata["_ID"], seeds)
     assert torch.equal(blocks[0].dstdata["_ID"], blocks[1].srcdata["_ID"]) and torch.equal(inp, blocks[0].srcdata["_ID"])
     assert torch.equal(blocks[1].srcdata["features"][:, 0].long(), blocks[1].srcdata["_ID"])
+
+
+def test_degree_scales_kernel(cuda_device):
+    """dh_csr_degree_scales_f32 against the torch formulation it replaced (in-degree from the row pointer, out-degree by scatter-add,
+    clamp at 1, pow(-0.5) / reciprocal) and against float64; the entries behind row n_rows (a static block's padding tail) are not counted."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_ops
+    from dance_amd import kernels
+    g = torch.Generator().manual_seed(0)
+    n_rows, n_cols = 777, 300
+    deg = torch.randint(0, 9, (n_rows, ), generator=g)
+    deg[5] = 0
+    rowptr = torch.zeros(n_rows + 2, dtype=torch.int32)
+    rowptr[1:n_rows + 1] = torch.cumsum(deg, 0).to(torch.int32)
+    nnz = int(rowptr[n_rows])
+    rowptr[n_rows + 1] = nnz + 50                                    # a padding row over 50 tail entries
+    col = torch.randint(0, n_cols, (nnz + 50, ), generator=g).to(torch.int32)
+    col[nnz:] = 0
+    for mode, pad in ((kernels.DEGREE_BOTH, 1), (kernels.DEGREE_BOTH, 0), (kernels.DEGREE_MEAN, 1)):
+        want_r, want_c = cpu_ops.degree_scales(rowptr, col, n_rows, n_cols, mode, n_pad=pad)
+        got_r, got_c = kernels.degree_scales(rowptr.to(cuda_device), col.to(cuda_device), n_rows, n_cols, mode, n_pad=pad)
+        assert got_r.shape == (n_rows + pad, ) and float((got_r.cpu() - want_r).abs().max()) <= 1e-7
+        if mode == kernels.DEGREE_BOTH:
+            # 1 / sqrt(d) with correctly rounded operations vs pow(d, -0.5) on the host: one rounding apart at most
+            assert float((got_c.cpu() / want_c - 1).abs().max()) <= 2e-7
+            exact = (torch.bincount(col[:nnz].long(), minlength=n_cols).double().clamp(min=1)**-0.5)
+            assert float((got_c.cpu().double() / exact - 1).abs().max()) <= 1.2e-7
+        else:
+            assert got_c is None
+    r0, c0 = kernels.degree_scales(torch.zeros(4, dtype=torch.int32, device=cuda_device), torch.zeros(0, dtype=torch.int32, device=cuda_device), 3, 5)
+    assert torch.equal(r0, torch.ones(3, device=cuda_device)) and torch.equal(c0, torch.ones(5, device=cuda_device))
