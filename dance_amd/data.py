@@ -75,6 +75,28 @@ class DeviceArray:
     def __repr__(self):
         return f"DeviceArray(shape={self.shape}, dtype={self.tensor.dtype}, device={self.tensor.device})"
 
+    def __iter__(self):
+        return iter(self.numpy())
+
+    __hash__ = object.__hash__  # (identity; __eq__ below is element-wise, as for an ndarray)
+
+
+def _forward_operators():
+    """Arithmetic / comparison operators of host code that treats the slot as an ndarray (``x / x.sum(1, keepdims=True)``, ``x > 0``):
+    evaluated on the materialised host copy — operators are looked up on the type, ``__getattr__`` never sees them."""
+    import operator
+    binary = ["add", "sub", "mul", "truediv", "floordiv", "mod", "pow", "matmul", "lt", "le", "gt", "ge", "eq", "ne", "and", "or", "xor"]
+    for name in binary:
+        op = getattr(operator, name if name not in ("and", "or") else name + "_")
+        setattr(DeviceArray, f"__{name}__", (lambda op: lambda self, other: op(self.numpy(), np.asarray(other) if isinstance(other, DeviceArray) else other))(op))
+        if name in ("add", "sub", "mul", "truediv", "floordiv", "mod", "pow", "matmul", "and", "or", "xor"):
+            setattr(DeviceArray, f"__r{name}__", (lambda op: lambda self, other: op(other, self.numpy()))(op))
+    for name, op in (("neg", operator.neg), ("pos", operator.pos), ("abs", operator.abs), ("invert", operator.invert)):
+        setattr(DeviceArray, f"__{name}__", (lambda op: lambda self: op(self.numpy()))(op))
+
+
+_forward_operators()
+
 
 def to_device_matrix(x, device) -> torch.Tensor:
     """The fp32 device tensor of an AnnData slot value: a ``DeviceArray`` hands over its tensor (no copy when it already lives

@@ -151,7 +151,18 @@ class LazyScipyCSR:
         return self.graph.nnz
 
     def __getattr__(self, name):
+        # only reached when normal lookup fails; private / dunder names are never forwarded (copy and pickle probe ``__deepcopy__``,
+        # ``__getstate__``, ``_m`` ... on an instance whose __init__ has not run: forwarding those recursed)
+        if name.startswith("_") or name == "graph":
+            raise AttributeError(name)
         return getattr(self.materialize(), name)
+
+    def __reduce__(self):
+        return (LazyScipyCSR, (self.graph, ))
+
+    def __deepcopy__(self, memo):
+        import copy
+        return LazyScipyCSR(copy.deepcopy(self.graph, memo))
 
     def __getitem__(self, idx):
         return self.materialize()[idx]

@@ -88,3 +88,36 @@ def test_from_scipy_takes_the_device_graph_of_a_lazy_obsp_slot():
     c0 = LazyScipyCSR.host_copies
     assert CSRGraph.from_scipy(lazy, "cpu") is g and LazyScipyCSR.host_copies == c0
     assert np.array_equal(lazy.toarray(), [[0, 1], [2, 3]]) and LazyScipyCSR.host_copies == c0 + 1
+
+
+def test_lazy_wrappers_survive_copy_and_pickle():
+    """``copy.deepcopy(data)`` / pickling a Data object whose slots hold the lazy device wrappers (a LazyScipyCSR used to recurse
+    without end in ``__getattr__``)."""
+    import copy
+    import pickle
+    import numpy as np
+    import torch
+    from dance_amd.data import DeviceArray
+    from dance_amd.graph import CSRGraph, LazyScipyCSR
+    g = CSRGraph(torch.tensor([0, 1, 3], dtype=torch.int32), torch.tensor([1, 0, 1], dtype=torch.int32), torch.tensor([1.0, 2.0, 3.0]), 2, 2)
+    for clone in (copy.deepcopy, lambda o: pickle.loads(pickle.dumps(o))):
+        lz = clone(LazyScipyCSR(g))
+        assert isinstance(lz, LazyScipyCSR) and lz.shape == (2, 2) and np.array_equal(lz.toarray(), [[0, 1], [2, 3]])
+        da = clone(DeviceArray(torch.arange(6.0).reshape(2, 3)))
+        assert isinstance(da, DeviceArray) and np.array_equal(np.asarray(da), np.arange(6.0).reshape(2, 3))
+    with __import__("pytest").raises(AttributeError):
+        LazyScipyCSR(g)._not_there
+
+
+def test_device_array_behaves_like_an_ndarray_for_host_code():
+    import numpy as np
+    import torch
+    from dance_amd.data import DeviceArray
+    a = np.arange(12.0, dtype=np.float32).reshape(3, 4)
+    d, e = DeviceArray(torch.from_numpy(a.copy())), DeviceArray(torch.ones(3, 4))
+    c0 = DeviceArray.host_copies
+    assert np.array_equal(d * 2, a * 2) and np.array_equal(2 * d, a * 2) and np.array_equal(d + e, a + 1) and np.array_equal(1 - d, 1 - a)
+    assert np.allclose(d / d.sum(1, keepdims=True), a / a.sum(1, keepdims=True)) and bool((d == d).all()) and int((d > 3).sum()) == 8
+    assert np.array_equal(-d, -a) and np.array_equal(abs(d), a) and (d @ np.ones((4, 2), dtype=np.float32)).shape == (3, 2) and np.array_equal(d**2, a**2)
+    assert [r.shape for r in d] == [(4, )] * 3 and hash(d) == hash(d)
+    assert DeviceArray.host_copies == c0 + 2  # one materialisation per array, however many expressions
