@@ -105,6 +105,8 @@ def to_device_matrix(x, device) -> torch.Tensor:
         return x.tensor.to(device=device, dtype=torch.float32)
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.float32)
+    if hasattr(x, "materialize"):  # graph.LazyScipyCSR (an obsp slot written by an on-device graph transform): densified like any sparse slot
+        x = x.materialize()
     if sp.issparse(x):
         x = x.toarray()
     elif hasattr(x, "to_numpy"):
@@ -145,6 +147,8 @@ class AnnDataLite:
             t = v.tensor
             i = torch.as_tensor(idx, device=t.device)
             return DeviceArray(t.index_select(axis, i).contiguous())
+        if hasattr(v, "materialize"):  # graph.LazyScipyCSR: subset the scipy matrix it stands for (the device graph is not re-indexed)
+            v = v.materialize()
         if sp.issparse(v):
             return v.tocsr()[idx] if axis == 0 else v.tocsc()[:, idx].tocsr()
         if hasattr(v, "iloc"):
@@ -354,6 +358,8 @@ class Data:
             return t
         if isinstance(feature, DeviceArray) and return_type != "default":
             feature = feature.numpy()  # host consumers get a plain ndarray (materialised once)
+        elif hasattr(feature, "materialize") and return_type != "default":
+            feature = feature.materialize()  # graph.LazyScipyCSR -> the scipy matrix the reference keeps in obsp
         if return_type == "default":
             if split_name is not None:
                 raise ValueError(f"split_name is not supported when return_type is 'default', got {split_name=!r}")

@@ -121,3 +121,32 @@ def test_device_array_behaves_like_an_ndarray_for_host_code():
     assert np.array_equal(-d, -a) and np.array_equal(abs(d), a) and (d @ np.ones((4, 2), dtype=np.float32)).shape == (3, 2) and np.array_equal(d**2, a**2)
     assert [r.shape for r in d] == [(4, )] * 3 and hash(d) == hash(d)
     assert DeviceArray.host_copies == c0 + 2  # one materialisation per array, however many expressions
+
+
+def test_get_feature_return_types_on_lazy_graph_slot():
+    """Every return type of Data.get_feature on an obsp slot that holds a LazyScipyCSR ("sparse" and the device types used to fail)."""
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    from dance_amd.data import AnnDataLite, Data, DeviceArray
+    from dance_amd.graph import CSRGraph, LazyScipyCSR
+    g = CSRGraph(torch.tensor([0, 1, 2, 3, 4, 5], dtype=torch.int32), torch.tensor([1, 0, 3, 2, 4], dtype=torch.int32), torch.ones(5), 5, 5)
+    d = Data(AnnDataLite(DeviceArray(torch.zeros(5, 4)), obsp={"G": LazyScipyCSR(g)}), train_size=3, val_size=0, test_size=2)
+    want = np.array([[0, 1, 0], [1, 0, 0], [0, 0, 0]], dtype=np.float32)
+    kw = dict(split_name="train", channel="G", channel_type="obsp")
+    assert np.array_equal(d.get_feature(return_type="numpy", **kw), want) and torch.equal(d.get_feature(return_type="torch", **kw), torch.from_numpy(want))
+    s = d.get_feature(return_type="sparse", **kw)
+    assert sp.issparse(s) and np.array_equal(s.toarray(), want) and torch.equal(d.get_feature(return_type="cpu", **kw), torch.from_numpy(want))
+    assert isinstance(d.get_feature(return_type="default", channel="G", channel_type="obsp"), LazyScipyCSR)
+
+
+def test_cell_filter_after_a_lazy_graph_slot():
+    """filter_by_mask on a Data object whose obsp holds a LazyScipyCSR (cells filtered after an on-device graph transform)."""
+    import numpy as np
+    import torch
+    from dance_amd.data import AnnDataLite, Data, DeviceArray
+    from dance_amd.graph import CSRGraph, LazyScipyCSR
+    g = CSRGraph(torch.tensor([0, 1, 2, 3, 4], dtype=torch.int32), torch.tensor([1, 0, 3, 2], dtype=torch.int32), torch.tensor([1.0, 2.0, 3.0, 4.0]), 4, 4)
+    d = Data(AnnDataLite(DeviceArray(torch.arange(8.0).reshape(4, 2)), obsp={"G": LazyScipyCSR(g)}), train_size="all")
+    d.filter_by_mask(np.array([True, False, True, True]))
+    assert d.data.X.shape == (3, 2) and np.array_equal(d.data.obsp["G"].toarray(), [[0, 0, 0], [0, 0, 3], [0, 4, 0]])
