@@ -174,6 +174,8 @@ class AnnDataLite:
         self.obsm = {k: self._take(v, idx, 0) for k, v in self.obsm.items()}
         self.obsp = {k: self._take(self._take(v, idx, 0), idx, 1) for k, v in self.obsp.items()}
         self.layers = {k: self._take(v, idx, 0) for k, v in self.layers.items()}
+        for k in [k for k in self.uns if isinstance(k, str) and k.endswith(".hip")]:
+            del self.uns[k]  # device graphs over the old set of cells (written next to obsp by the graph transforms) are stale now
 
     def __repr__(self):
         return (f"AnnDataLite object with n_obs x n_vars = {self.n_obs} x {self.n_vars}\n"

@@ -147,6 +147,7 @@ def test_cell_filter_after_a_lazy_graph_slot():
     from dance_amd.data import AnnDataLite, Data, DeviceArray
     from dance_amd.graph import CSRGraph, LazyScipyCSR
     g = CSRGraph(torch.tensor([0, 1, 2, 3, 4], dtype=torch.int32), torch.tensor([1, 0, 3, 2], dtype=torch.int32), torch.tensor([1.0, 2.0, 3.0, 4.0]), 4, 4)
-    d = Data(AnnDataLite(DeviceArray(torch.arange(8.0).reshape(4, 2)), obsp={"G": LazyScipyCSR(g)}), train_size="all")
+    d = Data(AnnDataLite(DeviceArray(torch.arange(8.0).reshape(4, 2)), obsp={"G": LazyScipyCSR(g)}, uns={"G.hip": g, "other": 1}), train_size="all")
     d.filter_by_mask(np.array([True, False, True, True]))
+    assert "G.hip" not in d.data.uns and d.data.uns["other"] == 1   # the device graph over the old cells is dropped, not left stale
     assert d.data.X.shape == (3, 2) and np.array_equal(d.data.obsp["G"].toarray(), [[0, 0, 0], [0, 0, 3], [0, 4, 0]])
