@@ -98,6 +98,11 @@ def _forward_operators():
 _forward_operators()
 
 
+def _is_lazy_graph(x) -> bool:
+    """graph.LazyScipyCSR, by name: ``hasattr`` would run DeviceArray.__getattr__ (= a host copy) and graph.py imports this module."""
+    return type(x).__name__ == "LazyScipyCSR"
+
+
 def to_device_matrix(x, device) -> torch.Tensor:
     """The fp32 device tensor of an AnnData slot value: a ``DeviceArray`` hands over its tensor (no copy when it already lives
     on ``device``); numpy / scipy / DataFrame values are uploaded (one H2D)."""
@@ -105,7 +110,7 @@ def to_device_matrix(x, device) -> torch.Tensor:
         return x.tensor.to(device=device, dtype=torch.float32)
     if isinstance(x, torch.Tensor):
         return x.to(device=device, dtype=torch.float32)
-    if hasattr(x, "materialize"):  # graph.LazyScipyCSR (an obsp slot written by an on-device graph transform): densified like any sparse slot
+    if _is_lazy_graph(x):  # graph.LazyScipyCSR (an obsp slot written by an on-device graph transform): densified like any sparse slot
         x = x.materialize()
     if sp.issparse(x):
         x = x.toarray()
@@ -147,7 +152,7 @@ class AnnDataLite:
             t = v.tensor
             i = torch.as_tensor(idx, device=t.device)
             return DeviceArray(t.index_select(axis, i).contiguous())
-        if hasattr(v, "materialize"):  # graph.LazyScipyCSR: subset the scipy matrix it stands for (the device graph is not re-indexed)
+        if _is_lazy_graph(v):  # graph.LazyScipyCSR: subset the scipy matrix it stands for (the device graph is not re-indexed)
             v = v.materialize()
         if sp.issparse(v):
             return v.tocsr()[idx] if axis == 0 else v.tocsc()[:, idx].tocsr()
@@ -360,7 +365,7 @@ class Data:
             return t
         if isinstance(feature, DeviceArray) and return_type != "default":
             feature = feature.numpy()  # host consumers get a plain ndarray (materialised once)
-        elif hasattr(feature, "materialize") and return_type != "default":
+        elif _is_lazy_graph(feature) and return_type != "default":
             feature = feature.materialize()  # graph.LazyScipyCSR -> the scipy matrix the reference keeps in obsp
         if return_type == "default":
             if split_name is not None:
