@@ -304,6 +304,42 @@ def gat_aggregate(x, a_src, a_dst, graph: CSRGraph, *, act: int = kernels.ATT_SI
     return _GATAggregateFn.apply(x, a_src, a_dst, graph, act, negative_slope, shift, edge_scale)
 
 
+class _EdgeWeightedSumFn(torch.autograd.Function):
+    """out[i] = sum_{e=(j->i)} w[e] x[j] with gradients for x AND for the per-edge weights w (CSR order): dh_spmm_csr_f32 forward, the
+    SpMM over the transposed structure with the weights carried along for dx, dh_sddmm_csr_f32 for dw[e] = <dout[i], x[j]>."""
+
+    @staticmethod
+    def forward(ctx, x, w, graph: CSRGraph):
+        x, w = x.contiguous(), w.contiguous()
+        ctx.graph = graph
+        ctx.save_for_backward(x, w)
+        return kernels.spmm_csr(graph.rowptr, graph.col, w, x, n_cols=graph.n_cols)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w = ctx.saved_tensors
+        g = ctx.graph
+        dout = dout.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            u, v = dout, x
+            if x.shape[1] % 4:  # the SDDMM moves 16 bytes per lane: zero-pad the inner dimension (the products are unchanged)
+                pad = 4 - x.shape[1] % 4
+                u, v = torch.nn.functional.pad(dout, (0, pad)), torch.nn.functional.pad(x, (0, pad))
+            dw = kernels.sddmm_csr(g.rowptr, g.col, u, v)
+        if ctx.needs_input_grad[0]:
+            if getattr(g, "_t_perm", None) is None:  # structure of A^T + where each of its entries sits in A: once per graph
+                g._t_struct = kernels.csr_transpose(g.rowptr, g.col, None, g.n_rows, g.n_cols)
+                g._t_perm = g._t_struct[3].long()
+            dx = kernels.spmm_csr(g._t_struct[0], g._t_struct[1], w[g._t_perm].contiguous(), dout, n_cols=g.n_rows)
+        return dx, dw, None
+
+
+def edge_weighted_sum(x, w, graph: CSRGraph):
+    """Aggregation with learnable per-edge weights (``w`` in CSR order of ``graph``): see _EdgeWeightedSumFn."""
+    return _EdgeWeightedSumFn.apply(x, w, graph)
+
+
 class _ZINBNLL(torch.autograd.Function):
     """``ZINBLoss.forward`` (dance/utils/loss.py:780-829) as two fused kernels instead of ~25 elementwise passes over the N x G
     matrices: dh_zinb_nll_forward_f32 (float64 row sums of the element loss) and dh_zinb_nll_backward_f32 (recomputes the element

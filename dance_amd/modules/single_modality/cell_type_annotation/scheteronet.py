@@ -23,6 +23,7 @@ tensor), so the reference's adjacencies KEEP their self loops (HeteronetGraph li
 despite the docstring; ``adj_t2 = (A A - A > 0)`` is evaluated on those.  ``remove_self_loops=False`` (the default)
 reproduces the code as written; ``True`` gives what the docstring says.
 """
+import logging
 from functools import partial
 from typing import Any, Mapping, Optional, Tuple, Union
 
@@ -37,6 +38,8 @@ from ....graph import CSRGraph, TensorKeyedCache
 from ....transforms import Compose, SetConfig
 from ....transforms.graph import HeteronetGraph
 from ...base import BaseClassificationMethod
+
+logger = logging.getLogger("dance")
 
 
 def eval_acc(true_labels, model_output, acc):
@@ -361,9 +364,12 @@ class scHeteroNet(nn.Module, BaseClassificationMethod):
         if use_zinb:
             import scipy.sparse
             x_raw = adata.raw.X
-            if scipy.sparse.issparse(x_raw):
-                x_raw = x_raw.toarray()
-            x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(self.device)[train_idx]
+            if isinstance(getattr(x_raw, "__dict__", {}).get("tensor"), torch.Tensor):  # DeviceArray left by the device pipeline: no host trip
+                x_raw = x_raw.tensor.to(device=self.device, dtype=torch.float32)[train_idx]
+            else:
+                if scipy.sparse.issparse(x_raw):
+                    x_raw = x_raw.toarray()
+                x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(self.device)[train_idx]
             size_factors = torch.as_tensor(np.asarray(adata.obs["size_factors"]), device=self.device)[train_idx]
             loss = loss + zinb_weight * ZINBLoss()(x_raw, _mean, _disp, _pi, size_factors)
         if cl_weight != 0:
@@ -439,6 +445,75 @@ class scHeteroNet(nn.Module, BaseClassificationMethod):
         if return_score:
             return result, test_ind_score, test_ood_score, out.detach().cpu().numpy()
         return result
+
+
+# ---- data plumbing of the reference's training script (scheteronet.py:155-225, :791-827): host-side bookkeeping, no kernels -----------
+class OODData:
+    """The fields of the ``torch_geometric.data.Data`` objects the reference hands to ``fit`` / ``detect`` for the out-of-distribution
+    nodes (x, edge_index, y, node_idx, num_nodes) — PyG itself is not needed for them."""
+
+    def __init__(self, x, edge_index, y):
+        self.x, self.edge_index, self.y = x, edge_index, y
+        self.node_idx = None
+
+    @property
+    def num_nodes(self):
+        return self.x.shape[0]
+
+
+def get_genename(raw_adata):
+    """:791-798."""
+    for key in ("gene_id", "symbol"):
+        if key in raw_adata.var.keys():
+            return raw_adata.var[key].values
+    return raw_adata.var.index
+
+
+def set_split(data, train_idx=[], val_idx=[], test_idx=[]):
+    """:801-827: the rarest cell type becomes the out-of-distribution class; its cells leave the train / val / test index lists, which
+    are stored in ``uns`` next to ``ood_idx`` / ``id_idx``; labels, gene names and per-cell counts are written to ``obs`` / ``var``."""
+    from collections import Counter
+
+    import pandas as pd
+    adata = data.data
+    adata.obs["assay"] = "10x 3' v2"
+    ct = adata.obsm["cell_type"]
+    y = np.argmax(ct.values if isinstance(ct, pd.DataFrame) else np.asarray(ct), axis=1)
+    adata.obs["cell_type_raw"] = y
+    for key in list(adata.obsm.keys()):
+        if isinstance(adata.obsm[key], pd.DataFrame):
+            adata.obsm[key] = adata.obsm[key].values
+    adata.obs["cell"] = y
+    adata.var["gene_name"] = get_genename(adata)
+    ood_class = min(Counter(y.tolist()).items(), key=lambda kv: kv[1])[0]
+    ood = set(np.flatnonzero(y == ood_class).tolist())
+    adata.uns["train_idx"] = [int(i) for i in train_idx if i not in ood]
+    adata.uns["val_idx"] = [int(i) for i in val_idx if i not in ood]
+    adata.uns["test_idx"] = [int(i) for i in test_idx if i not in ood]
+    adata.uns["ood_idx"] = sorted(ood)
+    adata.uns["id_idx"] = [int(i) for i in np.flatnonzero(y != ood_class)]
+    x = adata.X
+    adata.obs["n_counts"] = np.asarray(x.sum(axis=1)).ravel() if not hasattr(x, "tensor") else x.tensor.sum(1).cpu().numpy()
+
+
+def convert_dgl_to_original_format(g, adata, ref_adata_name: str):
+    """:155-225 for the graph ``HeteronetGraph`` leaves in ``uns`` (a CellGeneGraph with ``feat`` / ``label`` node data instead of a
+    DGLGraph): the in-distribution ``NCDataset`` and the two out-of-distribution views over the same nodes and edges."""
+    features, labels = g.ndata["feat"], g.ndata["label"]
+    src, dst = g.edges()
+    edge_index = torch.stack([src, dst], dim=0)
+    dataset_ind = NCDataset(ref_adata_name)
+    dataset_ind.graph = {"edge_index": edge_index, "edge_feat": None, "node_feat": features, "num_nodes": g.number_of_nodes()}
+    dataset_ind.label = labels
+    dataset_ind.num_nodes = g.number_of_nodes()
+    dataset_ind.edge_index, dataset_ind.x, dataset_ind.y = edge_index, features, labels
+    dataset_ind.batch = g.ndata["batch_id"] if "batch_id" in g.ndata else None
+    dataset_ind.node_idx = adata.uns["id_idx"]
+    dataset_ind.splits = {"train": adata.uns["train_idx"], "valid": adata.uns["val_idx"], "test": adata.uns["test_idx"]}
+    dataset_ood_tr, dataset_ood_te = OODData(features, edge_index, labels), OODData(features, edge_index, labels)
+    dataset_ood_tr.node_idx = dataset_ood_te.node_idx = adata.uns["ood_idx"]
+    logger.info(f"NCDataset (ID): Nodes={dataset_ind.num_nodes}, Edges={edge_index.shape[1]}; OOD nodes referenced={len(adata.uns['ood_idx'])}")
+    return dataset_ind, dataset_ood_tr, dataset_ood_te, adata
 
 
 def stable_cumsum(arr, rtol=1e-05, atol=1e-08):

@@ -78,6 +78,51 @@ class WeightedGraphConv(nn.Module):
         return rst
 
 
+class WeightedGraphConvAlpha(WeightedGraphConv):
+    """graphsc.py:487-566: the GraphConv variant whose messages are scaled by a learnable ``alpha`` per edge TYPE instead of the edge
+    weight — ``alpha[gene id]`` for gene -> cell and cell -> gene edges, ``alpha[gene_num]`` between two genes, ``alpha[gene_num + 1]``
+    otherwise (self loops of cells; the rule of scDeepSort's AdaptiveSAGE), node ids in ``srcdata["id"]`` / ``dstdata["id"]`` (genes >= 0,
+    cells < 0).  Defined but not instantiated by the reference's GCNAE; evaluated here as one SpMM with per-edge values (and an SDDMM
+    for alpha's gradient) instead of an [E, D] message tensor.  As in the reference, the module's own ``weight`` is never applied — only
+    an external one is (:534-542)."""
+
+    def forward(self, graph, feat, weight=None, alpha=None, gene_num=None):
+        from ....autograd import edge_weighted_sum, linear
+        if not self._allow_zero_in_degree and graph.has_zero_in_degree():
+            raise RuntimeError("There are 0-in-degree nodes in the graph, output for those nodes will be invalid. "
+                               "Adding self-loop on the input graph will resolve the issue.")
+        feat_src = feat[0] if isinstance(feat, tuple) else feat
+        n_dst, n_src = graph.number_of_dst_nodes(), graph.number_of_src_nodes()
+        rowscale = colscale = None
+        if self._norm != "none":
+            rowscale, colscale = kernels.degree_scales(graph.rowptr, graph.col, n_dst, n_src,
+                                                       kernels.DEGREE_BOTH if self._norm == "both" else kernels.DEGREE_MEAN)
+        if colscale is not None:
+            feat_src = feat_src * colscale[:, None]
+        if weight is not None:
+            if self.weight is not None:
+                raise RuntimeError("External weight is provided while at the same time the module has defined its own weight parameter. "
+                                   "Please create the module with flag weight=False.")
+            feat_src = linear(feat_src, weight.t())
+        src_id, dst_id = graph.srcdata["id"].to(torch.int64), graph.dstdata["id"].to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(n_dst, device=graph.col.device), (graph.rowptr[1:n_dst + 1] - graph.rowptr[:n_dst]).to(torch.int64),
+                                       output_size=graph.col.numel())
+        sid, did = src_id[graph.col.to(torch.int64)], dst_id[rows]
+        idx = torch.full_like(sid, gene_num + 1)
+        idx = torch.where((sid >= 0) & (did < 0), sid, idx)       # gene -> cell
+        idx = torch.where((did >= 0) & (sid < 0), did, idx)       # cell -> gene
+        idx = torch.where((did >= 0) & (sid >= 0), torch.full_like(idx, gene_num), idx)  # gene - gene
+        g = CSRGraph(graph.rowptr, graph.col, None, n_dst, n_src)
+        rst = edge_weighted_sum(feat_src, alpha.reshape(-1)[idx], g)
+        if rowscale is not None:
+            rst = rst * rowscale[:, None]
+        if self.bias is not None:
+            rst = rst + self.bias
+        if self._activation is not None:
+            rst = self._activation(rst)
+        return rst
+
+
 class InnerProductDecoder(nn.Module):
 
     def __init__(self, activation=torch.sigmoid, dropout=0.1):

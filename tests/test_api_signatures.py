@@ -39,6 +39,7 @@ PAIRS = [
     ("dance/modules/single_modality/clustering/graphsc.py", "GCNAE", "dance_amd.modules.single_modality.clustering.graphsc"),
     ("dance/modules/single_modality/clustering/graphsc.py", "WeightedGraphConv", "dance_amd.modules.single_modality.clustering.graphsc"),
     ("dance/modules/single_modality/clustering/graphsc.py", "InnerProductDecoder", "dance_amd.modules.single_modality.clustering.graphsc"),
+    ("dance/modules/single_modality/clustering/graphsc.py", "WeightedGraphConvAlpha", "dance_amd.modules.single_modality.clustering.graphsc"),
     ("dance/modules/single_modality/clustering/scdsc.py", "ScDSC", "dance_amd.modules.single_modality.clustering.scdsc"),
     ("dance/modules/single_modality/clustering/scdsc.py", "ScDSCModel", "dance_amd.modules.single_modality.clustering.scdsc"),
     ("dance/modules/single_modality/clustering/scdsc.py", "GNNLayer", "dance_amd.modules.single_modality.clustering.scdsc"),
@@ -72,6 +73,8 @@ ABSENT = {
        for m in ("neighborhood_aware_softmax", "sum_edge_scores_neighborhood_aware", "aggregate_neighbors", "lift", "explicit_broadcast")},
     ("WeightedGraphConv", "edge_selection_simple"): "DGL user-defined message function (graphsc.py:417-426): h_src * w_e is the edge value "
                                                     "of the fused SpMM, there is no EdgeBatch",
+    ("WeightedGraphConvAlpha", "edge_selection_simple"): "DGL user-defined message function (graphsc.py:491-507): alpha[idx(e)] is the edge value "
+                                                         "of the SpMM, there is no EdgeBatch",
 }
 
 # Parameter-level differences that are intended: the mirror's default device is the GPU (there is no CPU path), and a few

@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 LIGHT = {  # script -> (light options, lowest acceptable score: the synthetic programmes are well separated)
     "single_modality/cell_type_annotation/scdeepsort.py": (["--cells", "3000", "--genes", "400", "--dense_dim", "64", "--n_epochs", "12", "--batch_size", "256", "--lr", "0.01"], 0.85),
+    "single_modality/cell_type_annotation/scheteronet.py": (["--cells", "1500", "--genes", "500", "--epochs", "25", "--use_zinb", "--cl_weight", "0.1"], 0.8),
     "single_modality/clustering/graphsc.py": (["--cells", "3000", "--genes", "600", "--nb_genes", "400", "--epochs", "2", "--batch_size", "128", "--in_feats", "30"], -1.0),
     "single_modality/clustering/scdsc.py": (["--cells", "1200", "--genes", "600", "--nb_genes", "300", "--topk", "15", "--epochs", "10", "--pretrain_epochs", "10"], 0.3),
     "single_modality/clustering/sctag.py": (["--cells", "1000", "--genes", "600", "--n_top_genes", "300", "--epochs", "10", "--pretrain_epochs", "15"], 0.3),

@@ -225,3 +225,9 @@ def test_graphsc_fit_captured_step_vs_reference(cuda_device, gold, monkeypatch):
     for k in gold.files:
         if k.startswith("gsc_mb_sd1::"):
             assert rel_err(res[True][2][k.split("::", 1)[1]], gold[k]) < 1e-3, k
+
+
+def test_weighted_graph_conv_alpha_gpu(cuda_device):
+    """The alpha-weighted GraphConv variant (graphsc.py:487-566) on the kernels: SpMM with per-edge alpha values, SDDMM for alpha's gradient."""
+    import test_graphsc_host_logic as gh
+    gh.check_weighted_graph_conv_alpha("cuda")
