@@ -73,6 +73,7 @@ def _declare(lib):
         "dh_csr_densify_window": (c_int, [i64, i64, P, P, P, P, P, i32, i64, i64, P, i64, i32, P]),
         "dh_sage_window_mfma_supported": (c_int, [i64, i64, i32]),
         "dh_sage_window_mfma_workspace_bytes": (c_size_t, [i64, i64, i32]),
+        "dh_sage_window_mfma_split_workspace_bytes": (c_size_t, [i64, i64, i64, i32]),
         "dh_sage_window_mfma": (c_int, [i64, i64, i64, i64, i64, P, P, P, P, P, i64, i32, P, i64, i32, i64, P, P, P, i64, P, c_size_t, P]),
         "dh_sage_tail": (c_int, [i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P]),
         "dh_softplus_rowsum_f32": (c_int, [i64, i64, P, i64, P, P]),

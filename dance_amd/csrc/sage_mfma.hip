@@ -27,6 +27,11 @@
 //     planes), then 8 steps of [A fragments 2 x 2 ds_read_b128, per column tile B fragments + 4 or 6 MFMAs]; the prepared
 //     feature blocks (K-permuted, fragment order, contiguous 13 / 27 KB per step) arrive by LDS DMA in a three-slot ring.
 //
+//   * few destination rows (a mini-batch: scDeepSort's reference batch is 500 cells = 4 workgroups, each walking all 125 K-steps: 217 us):
+//     the gene window is split over blockIdx.y — up to 256 / row-blocks splits of whole densify chunks —, every split writes its fp32
+//     share (scaled by 1 / deg; split 0 adds the out-of-window edges) and sage_mfma_reduce_kernel sums the shares in split order:
+//     ~30 us, bit-reproducible; ScDeepSort.fit at batch 500 (100k cells): 0.092 -> 0.067 s per epoch.
+//
 // Precondition (the layouts CellFeatureGraph and the block builder produce): inside a row the in-window edges are
 // contiguous and ascending by column; out-of-window edges sit at the row's ends.
 #include <type_traits>
@@ -111,7 +116,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     int64_t n_dst, int64_t width, int col_begin, int n_cols, int Gh, int J, int Dp, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ colscale, const uint16_t* __restrict__ HsP,
     void* __restrict__ neigh, int64_t ldn, int64_t nnz, int nbp, const void* __restrict__ Hraw, int64_t ldh,
-    const int32_t* __restrict__ src_id, const int32_t* __restrict__ dst_id, const float* __restrict__ alpha, int n_genes) {
+    const int32_t* __restrict__ src_id, const int32_t* __restrict__ dst_id, const float* __restrict__ alpha, int n_genes,
+    float* __restrict__ partial, int chunks_per_split) {
+  // partial != null: the gene window is split over blockIdx.y (chunks_per_split densify chunks each) — few destination rows, e.g. a
+  // mini-batch of 500 cells, would otherwise occupy ceil(n_dst / 128) of the 256 CUs for the whole 125-step K loop (217 us at 4
+  // workgroups).  A split block writes its fp32 share (already scaled by 1 / deg; the out-of-window edges are added by split 0) to
+  // partial[blockIdx.y][cell][Dp]; sage_mfma_reduce_kernel sums the shares in split order.
   constexpr int P = HBF16 ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // A image: [2 groups][2 planes][JC][2 halves][64 cells][8] bf16 = JC * 8 KB;  B ring: [3 slots][P][2][Dp][8] bf16 (padded);  cs: [n_cols] f32
@@ -150,6 +160,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     p = half ? lo : s0;
     pend = half ? e0 : lo;
+    if (partial && blockIdx.y > 0) {  // first edge of this half at or behind the split's first chunk
+      const int target = half * Gh + (int)blockIdx.y * chunks_per_split * (JC * 8);
+      int a = p, b = pend;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (col[mid] - col_begin < target) a = mid + 1; else b = mid;
+      }
+      p = a;
+    }
     if (half == 0) {
       ends[2 * (grp * 64 + 32 * nh + r)] = s0;
       ends[2 * (grp * 64 + 32 * nh + r) + 1] = e0;
@@ -215,16 +234,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       default: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
     }
   };
-  if (J > 0) b_dma(0);
-  if (J > 1) b_dma(1);
+  const int n_chunks_all = (J + JC - 1) / JC;
+  const int chunk_lo = partial ? (int)blockIdx.y * chunks_per_split : 0;
+  const int chunk_hi = partial ? min(n_chunks_all, chunk_lo + chunks_per_split) : n_chunks_all;
+  const int j_lo = chunk_lo * JC, j_stop = min(J, chunk_hi * JC);  // this block's MFMA steps [j_lo, j_stop)
+  if (j_lo < j_stop) b_dma(j_lo);
+  if (j_lo + 1 < j_stop) b_dma(j_lo + 1);
 
   uint16_t* const a_grp = a_img + grp * A_GROUP;
   const int my_cell_local = 32 * nh + r;  // position of my stream's cell inside the group
-  const int n_chunks = (J + JC - 1) / JC;
   __syncthreads();  // the colscale table is complete; the first two feature blocks have landed (vmcnt is drained here)
   PROF_T(t_pro);
   PROF_ADD(0, t_start, t_pro);
-  for (int chunk = 0; chunk < n_chunks; ++chunk) {
+  for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
     PROF_T(t_c0);
     // ---- densify this chunk's window genes of the group's 64 cells into fragment order -----------------------------
     {
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     PROF_ADD(3, t_c2, t_c3);
 
     // ---- the chunk's MFMA steps ---------------------------------------------------------------------------------------
-    const int j_end = min(J, (chunk + 1) * JC);
+    const int j_end = min(j_stop, (chunk + 1) * JC);
     bf16x8_t fa[2][2];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl)
@@ -284,7 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int j = chunk * JC; j < j_end; ++j) {
       const int jl = j - chunk * JC;
       PROF_T(t_s0);
-      if (j + 2 < J) b_dma(j + 2);  // slot (j + 2) % 3 was last read in step j - 1, before that step's barrier
+      if (j + 2 < j_stop) b_dma(j + 2);  // slot (j + 2) % 3 was last read in step j - 1, before that step's barrier
       // tile slots beyond the real columns read a clamped (valid) LDS position and feed accumulators nobody stores
       const uint16_t* bb = b_img + (j % 3) * b_tile + (half * Dp + r) * 8;
       // B fragments in two batches: the second batch's reads are issued before the first batch's MFMAs and have landed when
@@ -339,7 +361,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       // (any younger register load only makes the wait longer); then the workgroup meets, without draining vmcnt
       PROF_T(t_s2);
       PROF_ADD(5, t_s1, t_s2);
-      wait_vm(j + 2 < J ? nbp : 0);
+      wait_vm(j + 2 < j_stop ? nbp : 0);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       PROF_T(t_s3);
       PROF_ADD(6, t_s2, t_s3);
@@ -371,7 +393,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         inv = d > 0 ? 1.f / (float)d : 0.f;
         if (FOLD) {
           const int s0 = ends[2 * (grp * 64 + 32 * m + rr)], e0 = ends[2 * (grp * 64 + 32 * m + rr) + 1];
-          n_tail = (s0 - rs) + (re - e0);
+          n_tail = (partial && blockIdx.y != 0) ? 0 : (s0 - rs) + (re - e0);  // split blocks: the out-of-window edges belong to split 0
           t_skip = e0 - s0;  // tail edge q lives at rs + q (q < s0 - rs) or rs + q + (e0 - s0)
           const int did = dst_id[cell];
 #pragma unroll
@@ -460,7 +482,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
               for (int e = 0; e < 16; ++e) v[e] = fmaf(tfk[q], hv[e], v[e]);
             }
-          if (OBF16) {
+          if (partial) {  // this split's share, fp32, rows Dp wide (16-byte aligned for every c0)
+            float* o = partial + ((int64_t)blockIdx.y * n_dst + cell) * Dp + c0;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              f32x4_t t4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t4[e] = v[4 * q4 + e] * inv;
+              *reinterpret_cast<f32x4_t*>(o + 4 * q4) = t4;
+            }
+          } else if (OBF16) {
             uint16_t* o = static_cast<uint16_t*>(neigh) + cell * ldn + c0;
             if (c0 + 16 <= width && ((reinterpret_cast<uintptr_t>(o) & 15u) == 0)) {
 #pragma unroll
@@ -493,7 +524,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
           }
         } else if (!FOLD && cell < n_dst && c0 < width) {
-          if (OBF16) {
+          if (partial) {
+            float* o = partial + ((int64_t)blockIdx.y * n_dst + cell) * Dp + c0;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              f32x4_t t4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t4[e] = v[4 * q4 + e] * inv;
+              *reinterpret_cast<f32x4_t*>(o + 4 * q4) = t4;
+            }
+          } else if (OBF16) {
             uint16_t* o = static_cast<uint16_t*>(neigh) + cell * ldn + c0;
             if (c0 + 16 <= width && ((reinterpret_cast<uintptr_t>(o) & 15u) == 0)) {
 #pragma unroll
@@ -544,7 +584,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       const int rs = rowptr[cell], re = rowptr[cell + 1];
       const int s0 = ends[2 * (grp * 64 + 32 * m + rr)], e0 = ends[2 * (grp * 64 + 32 * m + rr) + 1];
       const int n_tail = (s0 - rs) + (re - e0);
-      if (n_tail <= 4 || nh != 0) continue;  // one wave per cell group does the whole row
+      if (n_tail <= 4 || nh != 0 || (partial && blockIdx.y != 0)) continue;  // one wave per cell group (of split 0) does the whole row
       const float inv = 1.f / (float)(re - rs);
       const int did = dst_id[cell];
       for (int q = 4; q < n_tail; ++q) {
@@ -558,7 +598,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         const float f = w[e1] * alpha[idx] * inv;
         for (int64_t c = (lane & 1); c < width; c += 2) {
           const float hvv = HBF16 ? widen(static_cast<const uint16_t*>(Hraw)[(int64_t)u * ldh + c]) : static_cast<const float*>(Hraw)[(int64_t)u * ldh + c];
-          if (OBF16) {
+          if (partial) {
+            float* o = partial + cell * Dp + c;  // split 0's share
+            *o = fmaf(f, hvv, *o);
+          } else if (OBF16) {
             uint16_t* o = static_cast<uint16_t*>(neigh) + cell * ldn + c;
             *o = (uint16_t)f32_to_bf16(fmaf(f, hvv, widen(*o)));
           } else {
@@ -577,6 +620,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int i = 0; i < 8; ++i) atomicAdd(&dh_sm_prof_cycles[i], prof[i]);
   }
 #endif
+}
+
+// neigh[cell][c] (+)= sum over the splits, in split order (deterministic); accumulate = the non-folded form adds to what dh_sage_tail wrote
+template <bool OBF16>
+__global__ __launch_bounds__(256) void sage_mfma_reduce_kernel(int64_t n_dst, int64_t width, int Dp, int S, const float* __restrict__ partial,
+                                                               void* __restrict__ neigh, int64_t ldn, int accumulate) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_dst * Dp) return;
+  const int64_t cell = i / Dp;
+  const int c = (int)(i - cell * Dp);
+  if (c >= width) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += partial[((int64_t)s * n_dst + cell) * Dp + c];
+  if (OBF16) {
+    uint16_t* o = static_cast<uint16_t*>(neigh) + cell * ldn + c;
+    *o = (uint16_t)f32_to_bf16(accumulate ? v + widen(*o) : v);
+  } else {
+    float* o = static_cast<float*>(neigh) + cell * ldn + c;
+    *o = accumulate ? v + *o : v;
+  }
 }
 
 struct Geo {
@@ -618,6 +681,27 @@ extern "C" size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t wi
   return geometry(n_cols, width, h_dtype == DH_DTYPE_BF16).prep_bytes;
 }
 
+namespace {
+// how many ways the gene window is split for a launch of n_dst rows: 1 when the row blocks alone fill a quarter of the chip
+int split_factor(int64_t n_dst, const Geo& g) {
+  const int64_t blocks = dh::ceil_div(n_dst, 128);
+  const int n_chunks = (g.J + JC - 1) / JC;
+  if (blocks >= 64 || n_chunks < 2) return 1;
+  const int64_t want = 256 / blocks;
+  return (int)(want < n_chunks ? want : n_chunks);
+}
+}  // namespace
+
+/* prep buffer + the fp32 shares of a split launch: hand this many bytes to dh_sage_window_mfma and few-row launches (mini-batches) split
+ * the gene window over the otherwise idle CUs; with only dh_sage_window_mfma_workspace_bytes the unsplit kernel runs. */
+extern "C" size_t dh_sage_window_mfma_split_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype) {
+  if (n_dst <= 0 || n_cols <= 0 || width <= 0) return 0;
+  const Geo g = geometry(n_cols, width, h_dtype == DH_DTYPE_BF16);
+  const int S = split_factor(n_dst, g);
+  const size_t prep = (g.prep_bytes + 255) / 256 * 256;
+  return S > 1 ? prep + (size_t)S * n_dst * g.Dp * sizeof(float) : g.prep_bytes;
+}
+
 extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,
                                    const int32_t* rowptr, const int32_t* col, const float* w, const float* colscale, const void* H,
                                    int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
@@ -646,6 +730,13 @@ extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, 
   if (hb) hipLaunchKernelGGL(sage_mfma_prep_kernel<true>, dim3(pgrid), dim3(256), 0, st, n_cols, width, g.Gh, g.J, g.Dp, Hw, ldh, HsP, step_stride);
   else hipLaunchKernelGGL(sage_mfma_prep_kernel<false>, dim3(pgrid), dim3(256), 0, st, n_cols, width, g.Gh, g.J, g.Dp, Hw, ldh, HsP, step_stride);
   const unsigned grid = (unsigned)dh::ceil_div(n_dst, 128);
+  int S = split_factor(n_dst, g);
+  const size_t prep_aligned = (g.prep_bytes + 255) / 256 * 256;
+  if (S > 1 && workspace_bytes < prep_aligned + (size_t)S * n_dst * g.Dp * sizeof(float)) S = 1;  // caller did not provide room for the shares
+  float* partial = S > 1 ? reinterpret_cast<float*>(static_cast<char*>(workspace) + prep_aligned) : nullptr;
+  const int n_chunks = (g.J + JC - 1) / JC;
+  const int cps = S > 1 ? (n_chunks + S - 1) / S : n_chunks;
+  if (S > 1) S = (n_chunks + cps - 1) / cps;  // no empty split
   const int tiles_total = g.Dp / 32;
   const int nt = tiles_total <= 4 ? 2 : tiles_total <= 8 ? 4 : MAX_TILES;
 #define DH_SM4(HB, OB, NTV, FD)                                                                                                    \
@@ -653,9 +744,9 @@ extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, 
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_mfma_kernel<HB, OB, NTV, FD>),                   \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;              \
     if (!ok) return dh::fail(DH_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", me);                                         \
-    hipLaunchKernelGGL((sage_mfma_kernel<HB, OB, NTV, FD>), dim3(grid), dim3(256), g.lds_bytes, st, n_dst, width, (int)col_begin,  \
-                       (int)n_cols, g.Gh, g.J, g.Dp, rowptr, col, w, colscale, HsP, neigh, ldn, nnz, g.nbp, H, ldh, src_cell_id,  \
-                       dst_cell_id, alpha, (int)n_genes);                                                                          \
+    hipLaunchKernelGGL((sage_mfma_kernel<HB, OB, NTV, FD>), dim3(grid, (unsigned)S), dim3(256), g.lds_bytes, st, n_dst, width,     \
+                       (int)col_begin, (int)n_cols, g.Gh, g.J, g.Dp, rowptr, col, w, colscale, HsP, neigh, ldn, nnz, g.nbp, H, ldh, \
+                       src_cell_id, dst_cell_id, alpha, (int)n_genes, partial, cps);                                               \
   } while (0)
 #define DH_SM3(HB, OB, NTV)                                                                                                        \
   do {                                                                                                                             \
@@ -675,5 +766,10 @@ extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, 
 #undef DH_SM
 #undef DH_SM3
 #undef DH_SM4
+  int rc = dh::check_launch(me);
+  if (rc != DH_OK || S == 1) return rc;
+  const unsigned rgrid = (unsigned)dh::ceil_div(n_dst * g.Dp, 256);
+  if (ob) hipLaunchKernelGGL(sage_mfma_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, st, n_dst, width, g.Dp, S, partial, neigh, ldn, fold ? 0 : 1);
+  else hipLaunchKernelGGL(sage_mfma_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, st, n_dst, width, g.Dp, S, partial, neigh, ldn, fold ? 0 : 1);
   return dh::check_launch(me);
 }

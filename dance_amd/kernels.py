@@ -910,7 +910,8 @@ def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_
     a = alpha.reshape(-1)
     colscale = a[src_cell_id[col_begin:col_begin + n_cols].clamp(min=0).to(torch.int64)].contiguous()  # gnn.py:73
     out = torch.empty((rowptr.numel() - 1, H.shape[1]), dtype=out_dtype, device=H.device)
-    ws_bytes = lib.dh_sage_window_mfma_workspace_bytes(n_cols, H.shape[1], _out_dtype(H.dtype))
+    # (the larger size also holds the fp32 shares of a split launch: mini-batches spread over the chip instead of ceil(rows / 128) CUs)
+    ws_bytes = lib.dh_sage_window_mfma_split_workspace_bytes(rowptr.numel() - 1, n_cols, H.shape[1], _out_dtype(H.dtype))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=H.device)
     # src / dst ids + alpha given: the kernel adds the out-of-window edges (self loops) itself and writes the mean
     _call("sage_window_mfma", lib.dh_sage_window_mfma, rowptr.numel() - 1, H.shape[0], H.shape[1], col_begin, n_cols,
