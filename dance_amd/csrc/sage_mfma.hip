@@ -682,12 +682,13 @@ extern "C" size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t wi
 }
 
 namespace {
-// how many ways the gene window is split for a launch of n_dst rows: 1 when the row blocks alone fill a quarter of the chip
+// how many ways the gene window is split for a launch of n_dst rows: 1 when the row blocks alone cover the 256 CUs, else enough splits
+// for about two workgroups per CU
 int split_factor(int64_t n_dst, const Geo& g) {
   const int64_t blocks = dh::ceil_div(n_dst, 128);
   const int n_chunks = (g.J + JC - 1) / JC;
-  if (blocks >= 64 || n_chunks < 2) return 1;
-  const int64_t want = 256 / blocks;
+  if (blocks >= 256 || n_chunks < 2) return 1;
+  const int64_t want = dh::ceil_div((int64_t)512, blocks);
   return (int)(want < n_chunks ? want : n_chunks);
 }
 }  // namespace

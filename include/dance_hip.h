@@ -456,7 +456,7 @@ DH_API int dh_sage_tail(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_g
 DH_API int dh_sage_window_mfma_supported(int64_t n_cols, int64_t width, int h_dtype);  /* 1 if the shape fits the kernel's LDS plan */
 DH_API size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t width, int h_dtype);
 /* Workspace that also holds the fp32 shares of a SPLIT launch: with this many bytes a launch of few destination rows (a mini-batch: fewer
- * than 64 blocks of 128 rows) splits the gene window over up to 256 / blocks workgroups per row block and sums the shares in a second,
+ * than 256 blocks of 128 rows) splits the gene window over up to 512 / blocks workgroups per row block and sums the shares in a second,
  * deterministic kernel (scDeepSort's batch of 500 cells: 217 -> ~30 us); with the smaller size above the unsplit kernel runs. */
 DH_API size_t dh_sage_window_mfma_split_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype);
 DH_API int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,

@@ -103,9 +103,9 @@ def test_dense_cells(cuda_device, dtype, layout, n_cells, n_genes, width):
 @pytest.mark.parametrize("layout", ["graph", "block"])
 @pytest.mark.parametrize("n_cells,n_genes,width,density", [(700, 90, 400, 0.12), (300, 1203, 104, 0.12), (1000, 500, 200, 0.12),
                                                            (260, 2000, 400, 0.10), (130, 300, 448, 0.6),
-                                                           # >= 64 row blocks: the unsplit kernel (the cases above split the gene window over
+                                                           # >= 256 row blocks: the unsplit kernel (the cases above split the gene window over
                                                            # blockIdx.y — except 90 genes, a single chunk — and sum the shares)
-                                                           (8300, 400, 104, 0.05)])
+                                                           (33000, 400, 104, 0.02)])
 def test_mfma_cells(cuda_device, dtype, layout, n_cells, n_genes, width, density):
     """dh_sage_window_mfma (adjacency densified per workgroup in LDS, bf16 hi + lo splits on the matrix cores) against the
     float64 restatement of gnn.py:62-90 and the gather kernel; the dense 0.6 case overflows the 16-entry stream prefetch."""
