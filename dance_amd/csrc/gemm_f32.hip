@@ -483,7 +483,7 @@ struct Plan {
   int64_t k_chunk;
 };
 
-Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
+Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn, bool rows_reduced) {
   Plan p;
   p.large = bm == CfgLarge::BM;
   p.tiles_m = (int)dh::ceil_div(M, bm);
@@ -504,10 +504,14 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
   }
   // A handful of tiles and a K of a few thousand rows (the dW of a mini-batch: 50 x 200 from 10 k rows) left most of the chip idle
   // under the 64-step rule (8 blocks, 0.25 ms for 0.2 GFLOP at batch 8192 of graph-sc): when the grid would not even cover the
-  // 256 CUs once, slices go down to 8 K-steps.  Grids that already fill the chip keep their plan.
-  if (p.n_tiles * S < 256 && K >= 1024) {
+  // 256 CUs once, slices go down to 2 K-steps.  Grids that already fill the chip keep their plan.  (One CU needs 1.7 us per 128 x 128
+  // x 32 step of exact-fp32 MFMAs: the 500 x 400 -> 200 Linear of a scDeepSort batch was 8 workgroups x 13 steps = 28 us, launch excluded.)
+  // Only for products that reduce over ROWS (trans_a: dW = X^T dZ): their summation order depends on the number of rows anyway.  A
+  // forward product (K = features) must not change its K order with M — the layer's outputs are bit-identical on 1 and P GPUs
+  // because every rank runs the same K order on its rows (tests/test_gpu_sharded_one_gpu.py).
+  if (rows_reduced && p.n_tiles * S < 256 && K >= 256) {
     int64_t want = dh::ceil_div((int64_t)256, (int64_t)p.n_tiles);
-    int64_t max_s = K / (8 * BK);
+    int64_t max_s = K / (2 * BK);
     if (max_s < 1) max_s = 1;
     const int64_t s2 = want < max_s ? want : max_s;
     if (s2 > S) S = s2;
@@ -524,17 +528,17 @@ Plan plan_for(int64_t M, int64_t N, int64_t K, int bm, int bn) {
 // tile: DH_GEMM_TILE_AUTO, or a request for one configuration (dh_gemm_f32_ex).  AUTO also avoids 256-wide tiles that
 // would be at most half full in N or in M (a 128-column slice of a layer, dh_gcn_layer_*: the large tile computed
 // twice the flops there).
-Plan make_plan(int64_t M, int64_t N, int64_t K, int tile = DH_GEMM_TILE_AUTO) {
-  Plan big = plan_for(M, N, K, CfgLarge::BM, CfgLarge::BN);
+Plan make_plan(int64_t M, int64_t N, int64_t K, int tile, bool rows_reduced) {
+  Plan big = plan_for(M, N, K, CfgLarge::BM, CfgLarge::BN, rows_reduced);
 #ifdef DH_GEMM_FORCE_SMALL
-  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
+  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN, rows_reduced);
 #endif
-  if (tile == DH_GEMM_TILE_128) return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
+  if (tile == DH_GEMM_TILE_128) return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN, rows_reduced);
   if (tile == DH_GEMM_TILE_256) return big;
   const bool half_empty = (N % CfgLarge::BN != 0 && N % CfgLarge::BN <= CfgSmall::BN && N < 4 * CfgLarge::BN) ||
                           (M % CfgLarge::BM != 0 && M % CfgLarge::BM <= CfgSmall::BM && M < 4 * CfgLarge::BM);
   if ((int64_t)big.n_tiles * big.S >= 512 && !half_empty) return big;
-  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN);
+  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN, rows_reduced);
 }
 
 }  // namespace
@@ -543,7 +547,7 @@ extern "C" size_t dh_gemm_f32_ex_workspace_bytes(int64_t M, int64_t N, int64_t K
   (void)trans_b;
   if (M <= 0 || N <= 0 || K <= 0) return 0;
   if (tile == DH_GEMM_TILE_AUTO && dh::skinny_applies(M, N, K, trans_a)) return 0;
-  Plan p = make_plan(M, N, K, tile);
+  Plan p = make_plan(M, N, K, tile, trans_a != 0);
   return p.S > 1 ? (size_t)p.S * (size_t)M * (size_t)N * sizeof(float) : 0;
 }
 
@@ -572,7 +576,7 @@ extern "C" int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int 
   hipStream_t st = dh::as_stream(stream);
   if (tile == DH_GEMM_TILE_AUTO && K > 0 && dh::skinny_applies(M, N, K, trans_a))  // narrow layers: HBM-bound streaming kernel (gemm_skinny.hip)
     return dh::skinny_launch(M, N, K, trans_b, A, lda, B, ldb, C, ldc, accumulate, st);
-  Plan p = make_plan(M, N, K, tile);
+  Plan p = make_plan(M, N, K, tile, trans_a != 0);
   float* slabs = nullptr;
   if (p.S > 1) {
     const size_t need = (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);
