@@ -10,6 +10,7 @@ import logging
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 from torch import nn, optim
 from torch.nn.parameter import Parameter
 
@@ -287,6 +288,97 @@ class SimpleGCDEC(nn.Module):
             z, q = self(X[lo:hi].contiguous() if X.shape[0] == adj.n_nodes else X, adj)
             return adj.all_gather_rows(z)[:adj.n_nodes], adj.all_gather_rows(q)[:adj.n_nodes]
         return self(X, adj)
+
+
+class GC_DEC(SimpleGCDEC):
+    """spagcn.py:588-697: the DEC model with TWO graph convolutions (ReLU + dropout in between) — defined next to SimpleGCDEC in the
+    reference, not instantiated by ``SpaGCN``.  Each convolution is the fused GCN layer (ReLU in the SpMM epilogue, bitmap-masked
+    backward); the Student-t head, the losses and the two training loops are SimpleGCDEC's (the reference's GC_DEC restates them with
+    ``1e-6`` instead of ``1e-8`` in the kernel's denominator, :605).  ``mu`` exists from construction, as in the reference."""
+
+    def __init__(self, nfeat, nhid1, nhid2, n_clusters=None, dropout=0.5, alpha=0.2, device="cuda"):
+        nn.Module.__init__(self)
+        self.gc1 = GraphConvolution(nfeat, nhid1)
+        self.gc2 = GraphConvolution(nhid1, nhid2)
+        self.dropout = dropout
+        self.mu = Parameter(torch.empty(n_clusters, nhid2))
+        self.n_clusters, self.nhid, self.alpha, self.device = n_clusters, nhid2, alpha, device
+
+    def gc(self, x, adj):
+        """The embedding both training loops start from (SimpleGCDEC calls its single layer ``gc``)."""
+        x = F.relu(self.gc1(x, adj))
+        x = F.dropout(x, self.dropout, training=True)  # training=True always, as in the reference (:602)
+        return self.gc2(x, adj)
+
+    def forward(self, x, adj):
+        x = self.gc(x, adj)
+        q = 1.0 / ((1.0 + torch.sum((x.unsqueeze(1) - self.mu)**2, dim=2) / self.alpha) + 1e-6)
+        q = q**(self.alpha + 1.0) / 2.0
+        q = q / torch.sum(q, dim=1, keepdim=True)
+        return x, q
+
+    def fit(self, X, adj, lr=0.001, epochs=10, update_interval=5, weight_decay=5e-4, opt="sgd", init="louvain", n_neighbors=10, res=0.4):
+        """:622-670: initial clustering of the embedding (k-means with ``n_clusters`` centres, or the community detection), centres =
+        group means, then the DEC loop without early stopping, the prediction of every epoch kept in ``trajectory``."""
+        self.to(self.device)
+        X, adj = _to_device_f32(X, self.device), self._adj(adj)
+        self.trajectory = []
+        optimizer = self._optimizer(opt, lr, weight_decay)
+        with torch.no_grad():
+            features = self.gc(X, adj)
+        if init == "kmeans":
+            from sklearn.cluster import KMeans
+            y_pred = KMeans(self.n_clusters, n_init=20).fit_predict(features.cpu().numpy())
+        elif init == "louvain":
+            from ....utils.community import leiden_like
+            y_pred = np.asarray(leiden_like(features, n_neighbors, resolution=res, device=self.device))
+        else:
+            raise ValueError(f"Unknown init {init!r}")
+        self.trajectory.append(y_pred)
+        self._centres_from(features, y_pred)
+        self.train()
+        for epoch in range(epochs):
+            if epoch % update_interval == 0:
+                _, q = self.forward(X, adj)
+                p = self.target_distribution(q).data
+            optimizer.zero_grad()
+            z, q = self(X, adj)
+            loss = self.loss_function(p, q)
+            loss.backward()
+            optimizer.step()
+            self.trajectory.append(torch.argmax(q, dim=1).data.cpu().numpy())
+
+    def _optimizer(self, opt, lr, weight_decay):
+        if opt == "sgd":
+            return optim.SGD(self.parameters(), lr=lr, momentum=0.9)
+        if opt == "admin":
+            return optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay)
+        raise ValueError(f"Unknown optimizer {opt!r}")
+
+    def _centres_from(self, features, labels):
+        labels = np.asarray(labels)
+        groups = np.unique(labels)  # pandas groupby sorts its keys
+        yt = torch.from_numpy(np.searchsorted(groups, labels)).to(features.device)
+        self.mu.data.copy_(torch.stack([features[yt == c].mean(0) for c in range(len(groups))]))
+
+    def fit_with_init(self, X, adj, init_y, lr=0.001, epochs=10, update_interval=1, weight_decay=5e-4, opt="sgd"):
+        """:672-697."""
+        self.to(self.device)
+        X, adj = _to_device_f32(X, self.device), self._adj(adj)
+        optimizer = self._optimizer(opt, lr, weight_decay)
+        with torch.no_grad():
+            features = self.gc(X, adj)
+        self._centres_from(features, init_y)
+        self.train()
+        for epoch in range(epochs):
+            if epoch % update_interval == 0:
+                _, q = self.forward(X, adj)
+                p = self.target_distribution(q).data
+            optimizer.zero_grad()
+            z, q = self(X, adj)
+            loss = self.loss_function(p, q)
+            loss.backward()
+            optimizer.step()
 
 
 def refine(sample_id, pred, dis, shape="hexagon"):

@@ -723,6 +723,48 @@ def make_free_riders():
     print("free_riders.npz:", len(out), "arrays")
 
 
+def make_gc_dec():
+    """gc_dec.npz — the two-layer DEC model of spagcn.py:588-697 (``GC_DEC``: not instantiated by ``SpaGCN``, which uses SimpleGCDEC),
+    lifted from /root/reference with the reference's own GraphConvolution and run on torch-CPU with dropout 0: forward (z, q), the KL
+    loss against its own target distribution with the gradients of every parameter, and ``fit_with_init`` (5 SGD epochs)."""
+    import logging
+
+    import pandas as pd
+    import torch.optim as optim
+    spa = "dance/modules/spatial/spatial_domain/spagcn.py"
+    GC = ref_extract.extract(spa, "GraphConvolution")
+    GCDEC = ref_extract.extract(spa, "GC_DEC", {"GraphConvolution": GC, "optim": optim, "pd": pd, "logger": logging.getLogger("reference")})
+    rng = np.random.default_rng(77)
+    n, fin, h1, h2, k = 60, 14, 10, 6, 3
+    x = rng.standard_normal((n, fin)).astype(np.float32)
+    adj = np.exp(-rng.uniform(0, 3, (n, n))).astype(np.float32) * (rng.random((n, n)) < 0.2)
+    adj = ((adj + adj.T) / 2 + np.eye(n, dtype=np.float32)).astype(np.float32)
+    torch.manual_seed(21)
+    m = GCDEC(fin, h1, h2, n_clusters=k, dropout=0.0, alpha=0.2)
+    with torch.no_grad():
+        m.mu.copy_(torch.from_numpy(rng.standard_normal((k, h2)).astype(np.float32)))
+    out = {"gd_x": x, "gd_adj": adj, "gd_dims": np.array([fin, h1, h2, k])}
+    for kk, v in m.state_dict().items():
+        out[f"gd_sd::{kk}"] = v.numpy().copy()
+    z, q = m(torch.from_numpy(x), torch.from_numpy(adj))
+    p = m.target_distribution(q).data
+    loss = m.loss_function(p, q)
+    loss.backward()
+    out.update(gd_z=z.detach().numpy(), gd_q=q.detach().numpy(), gd_p=p.numpy(), gd_loss=np.float64(loss.item()))
+    for kk, p_ in m.named_parameters():
+        out[f"gd_grad::{kk}"] = p_.grad.numpy().copy()
+    init_y = rng.integers(0, k, n)
+    init_y[:k] = np.arange(k)
+    m.zero_grad()
+    m.fit_with_init(x, adj, init_y, lr=0.01, epochs=5, update_interval=2, opt="sgd")
+    zf, qf = m.predict(x, adj)
+    out.update(gd_init_y=init_y, gd_fit_z=zf.detach().numpy(), gd_fit_q=qf.detach().numpy())
+    for kk, v in m.state_dict().items():
+        out[f"gd_fit_sd::{kk}"] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "gc_dec.npz"), **out)
+    print("gc_dec.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -737,3 +779,4 @@ if __name__ == "__main__":
     make_sctag()
     make_stagate()
     make_free_riders()
+    make_gc_dec()

@@ -193,3 +193,9 @@ def test_scdsc_model_matches_reference_golden(cuda_device, heads):
         assert rel_err(val.cpu().numpy(), h[f"scdsc_{name}"]) < TOL, name
     loss = zinb(torch.rand(n, kw["n_input"], device=cuda_device).round(), _mean, _disp, _pi, torch.ones(n, device=cuda_device))
     assert torch.isfinite(loss)
+
+
+def test_gc_dec_vs_reference_gpu(cuda_device):
+    """SpaGCN's two-layer DEC model (spagcn.py:588-697) on the kernels vs the reference's own class (tests/golden/gc_dec.npz)."""
+    import test_models_host_logic as mh
+    mh.check_gc_dec("cuda")

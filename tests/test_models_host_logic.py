@@ -370,3 +370,34 @@ def test_sctag_scalable_adjacency_decoder_on_cpu(cpu_kernels):
     m = ScTAG(n_clusters=3, k=3, hidden_dim=16, latent_dim=6, dec_dim=[12, 16, 20], dropout=0.1, device="cpu", adj_dim=8)
     m.fit((sp.csr_matrix(adj), x, g["tg_counts"], g["tg_n_counts"].astype(np.float64)), g["tg_y"], epochs=3, pretrain_epochs=3, lr=5e-3)
     assert m.predict().shape == (adj.shape[0], ) and np.isfinite(m.predict_proba()).all()
+
+
+def check_gc_dec(device):
+    """GC_DEC (spagcn.py:588-697, the two-layer DEC model) against the reference's own class run on torch-CPU (tests/golden/gc_dec.npz):
+    forward, target distribution, KL loss, every gradient, and ``fit_with_init`` (5 SGD epochs, centres from given labels)."""
+    from dance_amd.modules.spatial.spatial_domain.spagcn import GC_DEC
+    g = np.load(os.path.join(GOLDEN, "gc_dec.npz"))
+    fin, h1, h2, k = (int(v) for v in g["gd_dims"])
+    m = GC_DEC(fin, h1, h2, n_clusters=k, dropout=0.0, alpha=0.2, device=device)
+    m.load_state_dict({key.split("::", 1)[1]: torch.from_numpy(g[key]) for key in g.files if key.startswith("gd_sd::")})
+    m.to(device)
+    x, adj = torch.from_numpy(g["gd_x"]).to(device), torch.from_numpy(g["gd_adj"]).to(device)
+    z, q = m(x, adj)
+    p = m.target_distribution(q).data
+    loss = m.loss_function(p, q)
+    loss.backward()
+    assert rel_err(z.detach().cpu().numpy(), g["gd_z"]) < 1e-5 and rel_err(q.detach().cpu().numpy(), g["gd_q"]) < 1e-5
+    assert rel_err(p.cpu().numpy(), g["gd_p"]) < 1e-5 and abs(loss.item() - float(g["gd_loss"])) < 1e-5 * max(1.0, abs(float(g["gd_loss"])))
+    for name, par in m.named_parameters():
+        assert rel_err(par.grad.cpu().numpy(), g[f"gd_grad::{name}"]) < 1e-3, name
+    m.zero_grad()
+    m.fit_with_init(g["gd_x"], g["gd_adj"], g["gd_init_y"], lr=0.01, epochs=5, update_interval=2, opt="sgd")
+    zf, qf = m.predict(g["gd_x"], g["gd_adj"])
+    assert rel_err(zf.detach().cpu().numpy(), g["gd_fit_z"]) < 1e-4 and rel_err(qf.detach().cpu().numpy(), g["gd_fit_q"]) < 1e-4
+    for key in g.files:
+        if key.startswith("gd_fit_sd::"):
+            assert rel_err(m.state_dict()[key.split("::", 1)[1]].cpu().numpy(), g[key]) < 1e-4, key
+
+
+def test_gc_dec_vs_reference_on_cpu(cpu_kernels):
+    check_gc_dec("cpu")
