@@ -84,8 +84,11 @@ struct ReluMask {
   int xcd_blocks;      // > 0: blocks per XCD of the XCD-contiguous row mapping (see spmm_slice128_kernel); 0: block b = rows 8 b ..
 };
 
-// G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart).
-template <int G, int VEC, int NACC, bool SAGE>
+// G lanes per row, VEC floats per lane per slice, NACC slices per lane (slices G*VEC apart), BATCH neighbour rows requested before the
+// first is used.  BATCH = 4 is the setting of the HBM-bound graphs; a block of a mini-batch (129 rows of 201 entries) is a chain of
+// dependent round trips instead — 50 batches of 4 = 21 us per launch — and runs with BATCH = 16.  The accumulation order, hence every
+// bit of the result, is the same for any BATCH.
+template <int G, int VEC, int NACC, bool SAGE, int BATCH>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(
     int64_t n_rows, int64_t width, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, const float* __restrict__ val,
@@ -124,12 +127,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
     }
     const int cnt = min(G, t - base);
     int k = 0;
-    // 4 neighbour rows in flight per lane per slice
-    for (; k + 4 <= cnt; k += 4) {
-      V z[4][NACC];
-      float wk[4];
+    // BATCH neighbour rows in flight per lane per slice
+    for (; k + BATCH <= cnt; k += BATCH) {
+      V z[BATCH][NACC];
+      float wk[BATCH];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < BATCH; ++u) {
         const int ck = bcast_i<G>(c, k + u);
         wk[u] = bcast_f<G>(w, k + u);
         const float* zr = Z + (int64_t)ck * ldz + c0;
@@ -138,9 +141,28 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(
           z[u][a] = live[a] ? *reinterpret_cast<const V*>(zr + a * G * VEC) : V(0.f);
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < BATCH; ++u)
 #pragma unroll
         for (int a = 0; a < NACC; ++a) fma_vec<VEC>(acc[a], wk[u], z[u][a]);
+    }
+    if constexpr (BATCH > 4) {  // what is left of the 64-entry chunk: batches of 4, then singles
+      for (; k + 4 <= cnt; k += 4) {
+        V z[4][NACC];
+        float wk[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ck = bcast_i<G>(c, k + u);
+          wk[u] = bcast_f<G>(w, k + u);
+          const float* zr = Z + (int64_t)ck * ldz + c0;
+#pragma unroll
+          for (int a = 0; a < NACC; ++a)
+            z[u][a] = live[a] ? *reinterpret_cast<const V*>(zr + a * G * VEC) : V(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) fma_vec<VEC>(acc[a], wk[u], z[u][a]);
+      }
     }
     for (; k < cnt; ++k) {
       const int ck = bcast_i<G>(c, k);
@@ -312,13 +334,19 @@ int launch_vec(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* row
                int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, int reduce,
                SageScale sage, const int32_t* row_ids, hipStream_t st) {
   const int64_t vecs = dh::ceil_div(width, VEC);
+  const bool few_rows = n_rows <= 2048;  // a mini-batch block: latency-bound, deeper request batches (same arithmetic)
 #define DH_SPMM_LAUNCH(G, NACC)                                                                  \
   do {                                                                                           \
     dim3 grid((unsigned)dh::ceil_div(n_rows, 256 / G),                                           \
               (unsigned)dh::ceil_div(vecs, (int64_t)G * NACC));                                  \
-    hipLaunchKernelGGL((spmm_csr_kernel<G, VEC, NACC, SAGE>), grid, dim3(256), 0, st, n_rows,    \
-                       width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act,   \
-                       reduce, sage, row_ids);                                                   \
+    if (few_rows && G >= 16)                                                                     \
+      hipLaunchKernelGGL((spmm_csr_kernel<G, VEC, NACC, SAGE, 16>), grid, dim3(256), 0, st, n_rows, \
+                         width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act,   \
+                         reduce, sage, row_ids);                                                   \
+    else                                                                                          \
+      hipLaunchKernelGGL((spmm_csr_kernel<G, VEC, NACC, SAGE, 4>), grid, dim3(256), 0, st, n_rows,  \
+                         width, rowptr, col, val, rowscale, colscale, Z, ldz, Y, ldy, bias, act,   \
+                         reduce, sage, row_ids);                                                   \
   } while (0)
   if (VEC == 4 && !SAGE && vecs >= 64 && vecs % 32 == 0) {
     // Wide rows: one pass per 128-column slice instead of one launch over the whole width.  Every pass gathers from a
