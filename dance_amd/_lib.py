@@ -119,6 +119,7 @@ def _declare(lib):
         "dh_block_cells_static_workspace_bytes": (c_size_t, [i64]),
         "dh_block_cells_static": (c_int, [i64, i64, i64, P, P, P, P, P, P, P, P, P, c_size_t, P]),
         "dh_csr_degree_scales_f32": (c_int, [i64, i64, i64, P, P, i32, P, P, P, P]),
+        "dh_adam_step_f32": (c_int, [i32, P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
         "dh_sage_alpha_grad_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, P]),
     }
     for name, (res, args) in sig.items():

@@ -817,6 +817,47 @@ def block_cells_static_workspace_bytes(n_seeds: int) -> int:
     return int(_lib_ready().dh_block_cells_static_workspace_bytes(int(n_seeds)))
 
 
+# ---- optimiser ---------------------------------------------------------------------------------------------
+def adam_step(optimizer) -> bool:
+    """One step of a ``torch.optim.Adam`` through dh_adam_step_f32 (two launches per 8 tensors; the state tensors the optimiser owns —
+    exp_avg, exp_avg_sq, step — are updated in place, so checkpoints and ``state_dict`` stay what torch would have written).  Returns
+    False without touching anything when the configuration is outside what the kernel covers (amsgrad / maximize / host-side step
+    counters / non-fp32 or strided tensors / a state that the first ``optimizer.step()`` has not created yet): call ``optimizer.step()``."""
+    import ctypes
+    if type(optimizer) is not torch.optim.Adam:
+        return False
+    plans = []
+    for grp in optimizer.param_groups:
+        if grp.get("amsgrad") or grp.get("maximize") or grp.get("differentiable") or not isinstance(grp["lr"], (int, float)):
+            return False
+        ps = [p for p in grp["params"] if p.grad is not None]
+        for p in ps:
+            st = optimizer.state.get(p)
+            if not st or "exp_avg" not in st or not torch.is_tensor(st.get("step")) or st["step"].device != p.device or st["step"].dtype != torch.float32:
+                return False
+            for t in (p, p.grad, st["exp_avg"], st["exp_avg_sq"]):
+                if t.dtype != torch.float32 or not t.is_contiguous() or t.device.type != p.device.type:
+                    return False
+        if ps and ps[0].device.type == "cpu" and _cpu_adam is None:
+            return False
+        plans.append((grp, ps))
+    lib = _lib_ready()
+    for grp, ps in plans:
+        if not ps:
+            continue
+        n = len(ps)
+        tab = lambda f: (ctypes.c_void_p * n)(*[f(p) for p in ps])
+        b1, b2 = grp["betas"]
+        _call("adam_step_f32", lib.dh_adam_step_f32, n, tab(lambda p: p.data_ptr()), tab(lambda p: p.grad.data_ptr()),
+              tab(lambda p: optimizer.state[p]["exp_avg"].data_ptr()), tab(lambda p: optimizer.state[p]["exp_avg_sq"].data_ptr()),
+              tab(lambda p: optimizer.state[p]["step"].data_ptr()), (ctypes.c_int64 * n)(*[p.numel() for p in ps]), float(grp["lr"]), float(b1),
+              float(b2), float(grp["eps"]), float(grp["weight_decay"]), _stream())
+    return True
+
+
+_cpu_adam = None  # (tests/cpu_ops.py patches adam_step itself; nothing here runs on CPU tensors)
+
+
 # ---- AdaptiveSAGE ------------------------------------------------------------------------------------------
 def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H) -> torch.Tensor:
     """neigh[v] = mean_e alpha[idx(e)] * w_e * H[src(e)] (dh_sage_aggregate_f32)."""

@@ -13,6 +13,7 @@ from pathlib import Path
 import torch
 import torch.nn as nn
 
+from .... import kernels
 from ....autograd import HipLinear
 from ....cellgraph import DataLoader, NeighborSampler
 from ....nn import AdaptiveSAGE
@@ -185,7 +186,8 @@ class ScDeepSort(BaseClassificationMethod):
         loss = self.loss_fn(self.model([blk], blk.srcdata["features"]), blk.dstdata["label"])
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        self.optimizer.step()
+        if not kernels.adam_step(self.optimizer):  # dh_adam_step_f32 once the optimiser's state exists
+            self.optimizer.step()
         return loss.detach()
 
     def _capture_step(self, graph, first_seeds):

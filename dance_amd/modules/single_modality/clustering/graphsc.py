@@ -331,7 +331,8 @@ class _CapturedStep:
         loss = self.norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), self.diag, self.diag, self.pos_weight)
         self.optim.zero_grad(set_to_none=True)
         loss.backward()
-        self.optim.step()
+        if not kernels.adam_step(self.optim):  # dh_adam_step_f32 once the optimiser's state exists (created by the first torch step)
+            self.optim.step()
         return emb_out, loss.detach()
 
     def capture(self, first_seeds: torch.Tensor):

@@ -591,6 +591,15 @@ DH_API int dh_comm_halo_spmm_f32(dh_comm_t comm, int64_t n_local, int64_t n_halo
                                float* Y, int64_t ldy, const float* bias, int act, const void* send_relu_mask,
                                dh_stream_t compute_stream, dh_stream_t comm_stream);
 
+/* ---- optimiser step of the captured mini-batch loops --------------------------------------------------------------------------------
+ * torch.optim.Adam (amsgrad = False) over n fp32 tensors given as HOST arrays of device pointers (params, grads, exp_avg, exp_avg_sq, the
+ * per-tensor step counters — one float each, incremented here — and element counts): two launches per 8 tensors instead of the ~14
+ * multi-tensor launches (or one 38 us fused launch) of the framework optimiser; arithmetic in torch's single-tensor order, every
+ * operation rounded separately in fp32.  dance: scdeepsort.py:160, graphsc.py:180 (Adam for every mini-batch model).                      */
+DH_API int dh_adam_step_f32(int n, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                     float* const* step, const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     dh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -488,7 +488,7 @@ def umap_connectivities(knn_idx, knn_dist):
 
 
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("degree_scales", "block_cells_static", "block_cells_static_workspace_bytes", "gcn_narrow_supported", "gcn_narrow_forward", "gcn_narrow_backward", "zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
+STAND_INS = ("adam_step", "degree_scales", "block_cells_static", "block_cells_static_workspace_bytes", "gcn_narrow_supported", "gcn_narrow_forward", "gcn_narrow_backward", "zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
              "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
@@ -505,3 +505,9 @@ def degree_scales(rowptr, col, n_rows, n_cols, mode=0, *, n_pad=0):
     nnz = int(rp[n_rows])
     outdeg = torch.zeros(n_cols, dtype=torch.int64).index_add_(0, col[:nnz].to(torch.int64), torch.ones(nnz, dtype=torch.int64))
     return torch.cat((indeg.pow(-0.5), pad)), outdeg.float().clamp(min=1).pow(-0.5)
+
+
+def adam_step(optimizer):
+    """Stand-in of kernels.adam_step: the framework's own step (what the kernel reproduces)."""
+    optimizer.step()
+    return True

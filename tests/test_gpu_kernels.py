@@ -321,3 +321,39 @@ def test_sddmm_bf16_and_spatial_gaussian_knn(cuda_device):
         assert np.array_equal(rowptr.cpu().numpy(), np.arange(0, 1500 * 12 + 1, 12)) and np.array_equal(col.cpu().numpy().reshape(1500, 12), ref_col)
         want = ref_d if l <= 0 else np.exp(-(ref_d * ref_d) / np.float32(2 * l * l))
         assert rel_err(val.cpu().numpy().reshape(1500, 12), want) < 1e-6
+
+
+def test_adam_step_kernel_vs_torch(cuda_device):
+    """dh_adam_step_f32 (two launches for the whole parameter set) against torch.optim.Adam's single-tensor implementation on the same
+    tensors, 6 steps, with and without weight decay: parameters and moments agree to fp32 rounding, the step counters are ticked."""
+    from dance_amd import kernels
+    for wd in (0.0, 1e-2):
+        torch.manual_seed(3)
+        shapes = [(37, 19), (19, ), (400, 200), (200, ), (5, 3, 2), (1, ), (1025, ), (64, 64), (3, ), (7, 11)]  # 10 tensors: two launches of <= 8
+        ps = [torch.randn(s, device=cuda_device).requires_grad_(True) for s in shapes]
+        qs = [p.detach().clone().requires_grad_(True) for p in ps]
+        opt_k = torch.optim.Adam(ps, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd, capturable=True, foreach=False)
+        opt_t = torch.optim.Adam(qs, lr=3e-3, betas=(0.9, 0.98), eps=1e-8, weight_decay=wd, capturable=True, foreach=False)
+        for it in range(6):
+            gs = [torch.randn_like(p) * (0.1 + it) for p in ps]
+            for p, q, g in zip(ps, qs, gs):
+                p.grad, q.grad = g.clone(), g.clone()
+            used = kernels.adam_step(opt_k)
+            assert used == (it > 0)          # the very first step creates the state: torch's own
+            if not used:
+                opt_k.step()
+            opt_t.step()
+        for p, q in zip(ps, qs):
+            assert float((p.detach() - q.detach()).abs().max()) <= 2e-6 * max(1.0, float(q.detach().abs().max()))
+            sk, st = opt_k.state[p], opt_t.state[q]
+            assert float(sk["step"]) == float(st["step"]) == 6.0
+            assert float((sk["exp_avg"] - st["exp_avg"]).abs().max()) <= 1e-6 * max(1.0, float(st["exp_avg"].abs().max()))
+            assert float((sk["exp_avg_sq"] - st["exp_avg_sq"]).abs().max()) <= 4e-6 * max(1.0, float(st["exp_avg_sq"].abs().max()))  # (1 - b2) g g vs g g (1 - b2)
+    # outside the kernel's coverage: nothing is touched
+    p = torch.randn(4, device=cuda_device, requires_grad=True)
+    p.grad = torch.ones_like(p)
+    o = torch.optim.Adam([p], amsgrad=True, capturable=True)
+    o.step()
+    before = p.detach().clone()
+    assert kernels.adam_step(o) is False and torch.equal(p, before)
+    assert kernels.adam_step(torch.optim.SGD([p], lr=0.1)) is False
