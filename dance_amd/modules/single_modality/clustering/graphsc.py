@@ -104,7 +104,7 @@ class WeightedGraphConvAlpha(WeightedGraphConv):
                 raise RuntimeError("External weight is provided while at the same time the module has defined its own weight parameter. "
                                    "Please create the module with flag weight=False.")
             feat_src = linear(feat_src, weight.t())
-        src_id, dst_id = graph.srcdata["id"].to(torch.int64), graph.dstdata["id"].to(torch.int64)
+        src_id, dst_id = graph.srcdata["id"].reshape(-1).to(torch.int64), graph.dstdata["id"].reshape(-1).to(torch.int64)  # [N] or [N, 1]
         rows = torch.repeat_interleave(torch.arange(n_dst, device=graph.col.device), (graph.rowptr[1:n_dst + 1] - graph.rowptr[:n_dst]).to(torch.int64),
                                        output_size=graph.col.numel())
         sid, did = src_id[graph.col.to(torch.int64)], dst_id[rows]

@@ -765,6 +765,54 @@ def make_gc_dec():
     print("gc_dec.npz:", len(out), "arrays")
 
 
+def make_wgc_alpha():
+    """wgc_alpha.npz — the reference's own ``WeightedGraphConvAlpha`` (graphsc.py:487-566: per-edge-type learnable alpha, not instantiated
+    by the reference's models) lifted from /root/reference and run over the DGL graph stub on torch-CPU: forward and the gradients of
+    features, the external weight and alpha, norm "both", tanh activation, a bias."""
+    import torch.nn as nn
+    gsc = "dance/modules/single_modality/clustering/graphsc.py"
+
+    class GraphConv(nn.Module):  # dgl.nn.pytorch.GraphConv.__init__ / reset_parameters
+        def __init__(self, in_feats, out_feats, norm="both", weight=True, bias=True, activation=None, allow_zero_in_degree=False):
+            super().__init__()
+            self._in_feats, self._out_feats, self._norm, self._allow_zero_in_degree = in_feats, out_feats, norm, allow_zero_in_degree
+            self.weight = nn.Parameter(torch.Tensor(in_feats, out_feats)) if weight else None
+            self.bias = nn.Parameter(torch.Tensor(out_feats)) if bias else None
+            if self.weight is not None:
+                nn.init.xavier_uniform_(self.weight)
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+            self._activation = activation
+
+    dgl = ref_extract.dgl_stub()
+    ns = {"GraphConv": GraphConv, "fn": dgl.function, "DGLError": RuntimeError, "expand_as_pair": lambda feat, g: (feat, feat[:g.number_of_dst_nodes()])}
+    WGCA = ref_extract.extract(gsc, "WeightedGraphConvAlpha", ns)
+    rng = np.random.default_rng(0)
+    n_genes, n_cells, d, h = 5, 7, 6, 4
+    n = n_genes + n_cells
+    ids = np.concatenate([np.arange(n_genes), -np.ones(n_cells)]).astype(np.int64)   # genes: their id, cells: -1
+    dense = (rng.random((n, n)) < 0.35)
+    np.fill_diagonal(dense, True)                                                     # dense[v, u]: edge u -> v
+    dst, src = np.nonzero(dense)                                                      # CSR order of the destination rows
+    g = ref_extract.DGLStubGraph(src, dst)
+    g.ndata["id"] = torch.from_numpy(ids)[:, None]  # [N, 1]: with 1-d ids the reference's np.where broadcasts to [E, E]
+    feat = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy(rng.standard_normal((d, h)).astype(np.float32)).requires_grad_(True)
+    alpha = torch.from_numpy(rng.uniform(0.5, 1.5, (n_genes + 2, 1)).astype(np.float32)).requires_grad_(True)  # [G + 2, 1], as scDeepSort's alpha
+    layer = WGCA(d, h, norm="both", weight=False, bias=True, activation=torch.tanh)
+    bias = rng.standard_normal(h).astype(np.float32)
+    with torch.no_grad():
+        layer.bias.copy_(torch.from_numpy(bias))
+    out_t = layer(g, feat, weight=w, alpha=alpha, gene_num=n_genes)
+    dy = torch.from_numpy(rng.standard_normal((n, h)).astype(np.float32))
+    out_t.backward(dy)
+    out = dict(wa_ids=ids, wa_dense=dense, wa_feat=feat.detach().numpy(), wa_w=w.detach().numpy(), wa_alpha=alpha.detach().numpy(), wa_bias=bias,
+               wa_dy=dy.numpy(), wa_out=out_t.detach().numpy(), wa_dfeat=feat.grad.numpy(), wa_dw=w.grad.numpy(), wa_dalpha=alpha.grad.numpy(),
+               wa_dims=np.array([n_genes, n_cells, d, h]))
+    np.savez_compressed(os.path.join(HERE, "wgc_alpha.npz"), **out)
+    print("wgc_alpha.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -780,3 +828,4 @@ if __name__ == "__main__":
     make_stagate()
     make_free_riders()
     make_gc_dec()
+    make_wgc_alpha()

@@ -122,59 +122,34 @@ def test_static_cell_block_matches_sampled_block(monkeypatch):
 
 
 def check_weighted_graph_conv_alpha(device):
-    """WeightedGraphConvAlpha (graphsc.py:487-566): forward and the gradients of alpha / features / the external weight against a float64
-    restatement of the message rule of :491-507 (per-edge alpha index from the src / dst ids) with dgl's "both" normalisation."""
+    """WeightedGraphConvAlpha (graphsc.py:487-566) against the reference's OWN class run over the DGL graph stub on torch-CPU
+    (tests/golden/wgc_alpha.npz): forward and the gradients of the features, the external weight and alpha — norm "both", tanh, a bias;
+    node ids as [N, 1] tensors (what the reference's np.where needs) and alpha as the [G + 2, 1] parameter of scDeepSort."""
     import types
     from dance_amd.modules.single_modality.clustering.graphsc import WeightedGraphConvAlpha
-    rng = np.random.default_rng(0)
-    n_genes, n_cells, d, h = 5, 7, 6, 4
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wgc_alpha.npz"))
+    n_genes, n_cells, d, h = (int(v) for v in gold["wa_dims"])
     n = n_genes + n_cells
-    ids = np.concatenate([np.arange(n_genes), -np.ones(n_cells)]).astype(np.int64)   # genes: their id, cells: -1
-    dense = (rng.random((n, n)) < 0.35)
-    np.fill_diagonal(dense, True)                                                     # self loops: no zero in-degree
+    dense, ids = gold["wa_dense"], gold["wa_ids"]
     rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
     col = np.concatenate([np.flatnonzero(r) for r in dense]).astype(np.int32)
-    t = lambda a: torch.from_numpy(a).to(device)
-    blk = types.SimpleNamespace(rowptr=t(rowptr), col=t(col), srcdata={"id": t(ids)}, dstdata={"id": t(ids)}, number_of_dst_nodes=lambda: n,
-                                number_of_src_nodes=lambda: n, has_zero_in_degree=lambda: False)
-    feat = t(rng.standard_normal((n, d)).astype(np.float32)).requires_grad_(True)
-    w = t(rng.standard_normal((d, h)).astype(np.float32)).requires_grad_(True)
-    alpha = t(rng.uniform(0.5, 1.5, n_genes + 2).astype(np.float32)).requires_grad_(True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    blk = types.SimpleNamespace(rowptr=t(rowptr), col=t(col), srcdata={"id": t(ids)[:, None]}, dstdata={"id": t(ids)[:, None]},
+                                number_of_dst_nodes=lambda: n, number_of_src_nodes=lambda: n, has_zero_in_degree=lambda: False)
+    feat, w, alpha = (t(gold[k]).requires_grad_(True) for k in ("wa_feat", "wa_w", "wa_alpha"))
     layer = WeightedGraphConvAlpha(d, h, norm="both", weight=False, bias=True, activation=torch.tanh).to(device)
     with torch.no_grad():
-        layer.bias.copy_(t(rng.standard_normal(h).astype(np.float32)))
+        layer.bias.copy_(t(gold["wa_bias"]))
     out = layer(blk, feat, weight=w, alpha=alpha, gene_num=n_genes)
-    dy = t(rng.standard_normal((n, h)).astype(np.float32))
-    out.backward(dy)
-
-    f64, w64, a64 = (x.detach().cpu().double().requires_grad_(True) for x in (feat, w, alpha))
-    outdeg = torch.from_numpy(dense.sum(0).astype(np.float64)).clamp(min=1)
-    indeg = torch.from_numpy(dense.sum(1).astype(np.float64)).clamp(min=1)
-    hsrc = (f64 * outdeg.pow(-0.5)[:, None]) @ w64
-    rows = []
-    for v in range(n):
-        acc = torch.zeros(h, dtype=torch.float64)
-        for u in np.flatnonzero(dense[v]):
-            s_, t_ = ids[u], ids[v]
-            k = n_genes + 1
-            if s_ >= 0 and t_ < 0:
-                k = s_
-            if t_ >= 0 and s_ < 0:
-                k = t_
-            if t_ >= 0 and s_ >= 0:
-                k = n_genes
-            acc = acc + a64[k] * hsrc[u]
-        rows.append(acc)
-    ref = torch.tanh(torch.stack(rows) * indeg.pow(-0.5)[:, None] + layer.bias.detach().cpu().double())
-    ref.backward(dy.cpu().double())
-    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < 1e-5
-    for got, want in ((feat.grad, f64.grad), (w.grad, w64.grad), (alpha.grad, a64.grad)):
-        assert rel_err(got.cpu().numpy(), want.numpy()) < 1e-5
+    out.backward(t(gold["wa_dy"]))
+    assert rel_err(out.detach().cpu().numpy(), gold["wa_out"]) < 1e-5
+    for got, key in ((feat.grad, "wa_dfeat"), (w.grad, "wa_dw"), (alpha.grad, "wa_dalpha")):
+        assert got.shape == gold[key].shape and rel_err(got.cpu().numpy(), gold[key]) < 1e-5, key
     with pytest.raises(RuntimeError):   # the module's own weight and an external one together (:534-539)
         WeightedGraphConvAlpha(d, h).to(device)(blk, feat, weight=w, alpha=alpha, gene_num=n_genes)
 
 
-def test_weighted_graph_conv_alpha_vs_restatement(monkeypatch):
+def test_weighted_graph_conv_alpha_vs_reference(monkeypatch):
     from dance_amd import kernels
     for name in cpu_ops.STAND_INS:
         monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
