@@ -813,6 +813,51 @@ def make_wgc_alpha():
     print("wgc_alpha.npz:", len(out), "arrays")
 
 
+def make_small_transforms():
+    """small_transforms.npz — ``FilterGenesMatch.__call__`` (filter.py:417-435), ``FilterCellsType.__call__`` (:1484-1512) and
+    ``UpdateSizeFactors.__call__`` (normalize.py:653-659) run as the reference wrote them, on stand-in Data objects (pandas frames, a
+    recording ``_inplace_subset_var`` / ``filter_by_mask``): which genes / cells they keep and the size factors they write."""
+    import logging
+    import types
+
+    import pandas as pd
+    import scipy.sparse as sp_
+    rng = np.random.default_rng(5)
+    out = {}
+    names = np.array(["ERCC-1", "Actb", "MT-Co1", "mt-Nd1", "Gapdh-ps", "Xist", "ERCC10", "Malat1-PS"])
+    out["st_names"] = names
+    call = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenesMatch", "__call__")
+    for tag, prefixes, suffixes, cs in (("a", ["ERCC", "MT-"], ["-ps"], False), ("b", ["mt-"], [], True), ("c", [], ["-PS"], True), ("d", [], [], False)):
+        kept = {}
+        var_names = pd.Index(names)
+        data = types.SimpleNamespace(shape=(4, len(names)),
+                                     data=types.SimpleNamespace(var_names=var_names, _inplace_subset_var=lambda keep, kept=kept: kept.update(v=np.asarray(keep))))
+        if cs:
+            prefixes, suffixes = [i.upper() for i in prefixes], [i.upper() for i in suffixes]  # what FilterGenesMatch.__init__ does (:413-415)
+        call(types.SimpleNamespace(prefixes=prefixes, suffixes=suffixes, case_sensitive=cs, logger=logging.getLogger("reference")), data)
+        out[f"st_match_{tag}_kept"] = np.array(kept["v"], dtype=str)
+    call = ref_extract.extract_method("dance/transforms/filter.py", "FilterCellsType", "__call__", {"Data": object})
+    lab = np.array([0] * 12 + [1] * 11 + [2] * 10 + [3] * 3)
+    rng.shuffle(lab)
+    one_hot = pd.DataFrame(np.eye(4)[lab], columns=["a", "b", "c", "d"], index=[str(i) for i in range(len(lab))])
+    out["st_type_labels"] = lab
+    for thr in (2, 3, 10, 11):
+        got = {}
+        data = types.SimpleNamespace(data=types.SimpleNamespace(obsm={"cell_type": one_hot}, n_obs=len(lab), obs_names=one_hot.index),
+                                     filter_by_mask=lambda m, got=got: got.update(m=np.asarray(m, dtype=bool)))
+        call(types.SimpleNamespace(cell_type_threshold=thr), data)
+        out[f"st_type_keep_{thr}"] = got["m"]
+    call = ref_extract.extract_method("dance/transforms/normalize.py", "UpdateSizeFactors", "__call__", {"Data": object, "sp": sp_})
+    x = rng.poisson(2.0, (9, 6)).astype(np.float32)
+    out["st_sf_x"] = x
+    for tag, mat in (("dense", x), ("sparse", sp_.csr_matrix(x))):
+        obs = pd.DataFrame(index=[str(i) for i in range(9)])
+        call(types.SimpleNamespace(), types.SimpleNamespace(data=types.SimpleNamespace(X=mat, obs=obs)))
+        out[f"st_sf_{tag}_n_counts"], out[f"st_sf_{tag}_size_factors"] = np.asarray(obs["n_counts"], dtype=np.float64), np.asarray(obs["size_factors"], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "small_transforms.npz"), **out)
+    print("small_transforms.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -829,3 +874,4 @@ if __name__ == "__main__":
     make_free_riders()
     make_gc_dec()
     make_wgc_alpha()
+    make_small_transforms()

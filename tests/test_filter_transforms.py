@@ -119,3 +119,34 @@ def test_filter_genes_match_cells_type_size_factors():
         d = mk(slot)
         UpdateSizeFactors()(d)
         assert np.allclose(np.asarray(d.data.obs["n_counts"]), want) and np.allclose(np.asarray(d.data.obs["size_factors"]), want / np.median(want))
+
+
+def test_small_transforms_vs_reference_code():
+    """FilterGenesMatch / FilterCellsType / UpdateSizeFactors against what the reference's own ``__call__`` bodies did on the same inputs
+    (tests/golden/small_transforms.npz, generated by running them on stand-in Data objects)."""
+    import os
+    import pandas as pd
+    import scipy.sparse as sp
+    from dance_amd import data as dd
+    from dance_amd.transforms import FilterCellsType, FilterGenesMatch, UpdateSizeFactors
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small_transforms.npz"))
+    names = [str(v) for v in g["st_names"]]
+    x = np.arange(4 * len(names), dtype=np.float32).reshape(4, len(names))
+    for tag, kw in (("a", dict(prefixes=["ERCC", "MT-"], suffixes=["-ps"])), ("b", dict(prefixes=["mt-"], case_sensitive=True)),
+                    ("c", dict(suffixes=["-PS"], case_sensitive=True)), ("d", dict())):
+        d = dd.Data(dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy())), var=pd.DataFrame(index=names)), train_size="all")
+        FilterGenesMatch(**kw)(d)
+        assert list(d.data.var.index) == [str(v) for v in g[f"st_match_{tag}_kept"]], tag
+    lab = g["st_type_labels"]
+    one_hot = pd.DataFrame(np.eye(4)[lab], columns=["a", "b", "c", "d"], index=[str(i) for i in range(len(lab))])
+    for thr in (2, 3, 10, 11):
+        d = dd.Data(dd.AnnDataLite(np.zeros((len(lab), 3), dtype=np.float32), obs=pd.DataFrame({"i": np.arange(len(lab))}, index=one_hot.index),
+                                   obsm={"cell_type": one_hot.copy()}), train_size="all")
+        FilterCellsType(cell_type_threshold=thr)(d)
+        assert np.array_equal(np.asarray(d.data.obs["i"]), np.flatnonzero(g[f"st_type_keep_{thr}"])), thr
+    xs = g["st_sf_x"]
+    for slot, tag in ((xs.copy(), "dense"), (sp.csr_matrix(xs), "sparse"), (dd.DeviceArray(torch.from_numpy(xs.copy())), "dense")):
+        d = dd.Data(dd.AnnDataLite(slot), train_size="all")
+        UpdateSizeFactors()(d)
+        assert np.allclose(np.asarray(d.data.obs["n_counts"], dtype=np.float64), g[f"st_sf_{tag}_n_counts"])
+        assert np.allclose(np.asarray(d.data.obs["size_factors"], dtype=np.float64), g[f"st_sf_{tag}_size_factors"])
