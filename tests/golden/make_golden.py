@@ -858,6 +858,46 @@ def make_small_transforms():
     print("small_transforms.npz:", len(out), "arrays")
 
 
+def make_scheteronet_split():
+    """scheteronet_split.npz — ``set_split`` (scheteronet.py:801-827) of the reference's training script run as written on a stand-in
+    AnnData: which class becomes out-of-distribution, the index lists left in ``uns``, the columns written to ``obs``."""
+    import types
+    from collections import Counter
+
+    import pandas as pd
+    path = "dance/modules/single_modality/cell_type_annotation/scheteronet.py"
+    get_genename = ref_extract.extract(path, "get_genename")
+    set_split = ref_extract.extract(path, "set_split", {"get_genename": get_genename, "Counter": Counter, "pd": pd})
+    rng = np.random.default_rng(9)
+    n, k, g = 50, 4, 6
+    lab = rng.integers(0, k, n)
+    lab[:5] = 3
+    lab[5:][lab[5:] == 3] = 1          # class 3: 5 cells, the rarest
+    x = rng.poisson(1.5, (n, g)).astype(np.float32)
+
+    class Stub:
+        def __init__(self):
+            self.obs = pd.DataFrame(index=[str(i) for i in range(n)])
+            self.var = pd.DataFrame({"symbol": [f"S{i}" for i in range(g)]}, index=[f"g{i}" for i in range(g)])
+            self.obsm = {"cell_type": pd.DataFrame(np.eye(k)[lab], index=self.obs.index, columns=[f"t{i}" for i in range(k)])}
+            self.uns, self.X = {}, x
+
+        def __getitem__(self, mask):
+            assert bool(np.all(mask))
+            return self
+
+    ad = Stub()
+    perm = rng.permutation(n)
+    tr, va, te = perm[:30].tolist(), perm[30:40].tolist(), perm[40:].tolist()
+    set_split(types.SimpleNamespace(data=ad), tr, va, te)
+    out = dict(ss_labels=lab, ss_x=x, ss_train_in=np.array(tr), ss_val_in=np.array(va), ss_test_in=np.array(te),
+               **{f"ss_{key}": np.array(ad.uns[key]) for key in ("train_idx", "val_idx", "test_idx", "ood_idx", "id_idx")},
+               ss_cell=np.asarray(ad.obs["cell"]), ss_n_counts=np.asarray(ad.obs["n_counts"], dtype=np.float64),
+               ss_gene_name=np.asarray(ad.var["gene_name"], dtype=str), ss_cell_type_is_array=np.array(isinstance(ad.obsm["cell_type"], np.ndarray)))
+    np.savez_compressed(os.path.join(HERE, "scheteronet_split.npz"), **out)
+    print("scheteronet_split.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     if not ref_extract.available():
         raise SystemExit("reference tree not found: golden vectors can only be generated in the build container")
@@ -875,3 +915,4 @@ if __name__ == "__main__":
     make_gc_dec()
     make_wgc_alpha()
     make_small_transforms()
+    make_scheteronet_split()

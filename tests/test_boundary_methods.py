@@ -160,3 +160,29 @@ def test_spagcn_search_set_res_vs_reference_method(cpu_kernels):
         torch.manual_seed(0)
         got = b.search_set_res((embed, adj), l, target, epochs=3, **kw)
         assert got == want and a.res == b.res, (target, got, want)
+
+
+def test_scheteronet_set_split_vs_reference_code():
+    """``set_split`` of scHeteroNet's training script (scheteronet.py:801-827) against the reference's own function run on a stand-in
+    AnnData (tests/golden/scheteronet_split.npz): the out-of-distribution class, the index lists, the columns written."""
+    import os
+    import numpy as np
+    import pandas as pd
+    import torch
+    from dance_amd import data as dd
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import get_genename, set_split
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scheteronet_split.npz"))
+    lab, x = g["ss_labels"], g["ss_x"]
+    n, k = len(lab), int(lab.max()) + 1
+    idx = [str(i) for i in range(n)]
+    for slot in (x.copy(), dd.DeviceArray(torch.from_numpy(x.copy()))):
+        ad = dd.AnnDataLite(slot, obs=pd.DataFrame(index=idx), var=pd.DataFrame({"symbol": [f"S{i}" for i in range(x.shape[1])]}, index=[f"g{i}" for i in range(x.shape[1])]),
+                            obsm={"cell_type": pd.DataFrame(np.eye(k)[lab], index=idx, columns=[f"t{i}" for i in range(k)])})
+        data = dd.Data(ad, train_size="all")
+        set_split(data, g["ss_train_in"].tolist(), g["ss_val_in"].tolist(), g["ss_test_in"].tolist())
+        for key in ("train_idx", "val_idx", "test_idx", "ood_idx", "id_idx"):
+            assert list(ad.uns[key]) == g[f"ss_{key}"].tolist(), key
+        assert np.array_equal(np.asarray(ad.obs["cell"]), g["ss_cell"]) and np.allclose(np.asarray(ad.obs["n_counts"], dtype=np.float64), g["ss_n_counts"])
+        assert [str(v) for v in ad.var["gene_name"]] == [str(v) for v in g["ss_gene_name"]]
+        assert isinstance(ad.obsm["cell_type"], np.ndarray) == bool(g["ss_cell_type_is_array"])
+    assert list(get_genename(dd.AnnDataLite(x, var=pd.DataFrame({"gene_id": ["a"] * x.shape[1]})))) == ["a"] * x.shape[1]
