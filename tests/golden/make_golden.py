@@ -894,6 +894,25 @@ def make_scheteronet_split():
                **{f"ss_{key}": np.array(ad.uns[key]) for key in ("train_idx", "val_idx", "test_idx", "ood_idx", "id_idx")},
                ss_cell=np.asarray(ad.obs["cell"]), ss_n_counts=np.asarray(ad.obs["n_counts"], dtype=np.float64),
                ss_gene_name=np.asarray(ad.var["gene_name"], dtype=str), ss_cell_type_is_array=np.array(isinstance(ad.obsm["cell_type"], np.ndarray)))
+    # ---- convert_dgl_to_original_format (:155-225) on the DGL stub graph with the index lists set_split just wrote -----------------
+    NCDataset = ref_extract.extract(path, "NCDataset")
+
+    class PygData:  # the fields torch_geometric.data.Data keeps for these calls
+        def __init__(self, x=None, edge_index=None, y=None):
+            self.x, self.edge_index, self.y = x, edge_index, y
+            self.num_nodes = x.shape[0]
+
+    conv = ref_extract.extract(path, "convert_dgl_to_original_format", {"NCDataset": NCDataset, "Data": PygData, "dgl": types.SimpleNamespace(DGLGraph=object),
+                                                                         "sc": types.SimpleNamespace(AnnData=object)})
+    e_src, e_dst = rng.integers(0, n, 120), rng.integers(0, n, 120)
+    gs = ref_extract.DGLStubGraph(e_src, e_dst, num_src=n, num_dst=None)
+    gs.ndata["feat"], gs.ndata["label"] = torch.from_numpy(x), torch.from_numpy(lab)
+    gs.num_nodes = lambda: n
+    ind, ood_tr, ood_te, _ = conv(gs, ad, "ref")
+    out.update(ss_e_src=e_src, ss_e_dst=e_dst, ss_ind_edge_index=ind.edge_index.numpy(), ss_ind_node_idx=np.array(ind.node_idx),
+               ss_ind_split_train=np.array(ind.splits["train"]), ss_ind_split_valid=np.array(ind.splits["valid"]), ss_ind_split_test=np.array(ind.splits["test"]),
+               ss_ood_node_idx=np.array(ood_tr.node_idx), ss_ind_num_nodes=np.array(ind.num_nodes), ss_ind_y=ind.y.numpy(),
+               ss_same_ood=np.array(ood_tr.node_idx == ood_te.node_idx))
     np.savez_compressed(os.path.join(HERE, "scheteronet_split.npz"), **out)
     print("scheteronet_split.npz:", len(out), "arrays")
 

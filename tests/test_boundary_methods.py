@@ -186,3 +186,32 @@ def test_scheteronet_set_split_vs_reference_code():
         assert [str(v) for v in ad.var["gene_name"]] == [str(v) for v in g["ss_gene_name"]]
         assert isinstance(ad.obsm["cell_type"], np.ndarray) == bool(g["ss_cell_type_is_array"])
     assert list(get_genename(dd.AnnDataLite(x, var=pd.DataFrame({"gene_id": ["a"] * x.shape[1]})))) == ["a"] * x.shape[1]
+
+
+def test_scheteronet_convert_vs_reference_code():
+    """``convert_dgl_to_original_format`` (scheteronet.py:155-225) on the graph object HeteronetGraph produces vs the reference's own
+    function over the DGL stub graph: edge_index in edge-id order, the in-distribution dataset's fields and splits, the OOD node lists."""
+    import os
+    import types
+    import numpy as np
+    import torch
+    from dance_amd.cellgraph import CellGeneGraph
+    from dance_amd.modules.single_modality.cell_type_annotation.scheteronet import NCDataset, OODData, convert_dgl_to_original_format
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scheteronet_split.npz"))
+    src, dst = torch.from_numpy(g["ss_e_src"]), torch.from_numpy(g["ss_e_dst"])
+    n = len(g["ss_labels"])
+    # CSR by destination with edge ids = positions in the edge list (what HeteronetGraph builds, heteronet_graph.py)
+    order = torch.argsort(dst * (len(src) + 1) + torch.arange(len(src)))
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n), 0)
+    cg = CellGeneGraph(rowptr.to(torch.int32), src[order].to(torch.int32), torch.ones(len(src)), order.to(torch.int32), n,
+                       {"feat": torch.from_numpy(g["ss_x"]), "label": torch.from_numpy(g["ss_labels"])})
+    adata = types.SimpleNamespace(uns={k: g[f"ss_{k}"].tolist() for k in ("train_idx", "val_idx", "test_idx", "ood_idx", "id_idx")})
+    ind, ood_tr, ood_te, back = convert_dgl_to_original_format(cg, adata, "ref")
+    assert isinstance(ind, NCDataset) and isinstance(ood_tr, OODData) and back is adata
+    assert np.array_equal(ind.edge_index.numpy(), g["ss_ind_edge_index"]) and ind.num_nodes == int(g["ss_ind_num_nodes"])
+    assert list(ind.node_idx) == g["ss_ind_node_idx"].tolist() and np.array_equal(ind.y.numpy(), g["ss_ind_y"])
+    for ours, key in (("train", "train"), ("valid", "valid"), ("test", "test")):
+        assert list(ind.splits[ours]) == g[f"ss_ind_split_{key}"].tolist()
+    assert list(ood_tr.node_idx) == g["ss_ood_node_idx"].tolist() and list(ood_te.node_idx) == list(ood_tr.node_idx)
+    assert ood_tr.num_nodes == n and torch.equal(ood_tr.edge_index, ind.edge_index) and torch.equal(ind.graph["node_feat"], ind.x)
