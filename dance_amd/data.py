@@ -5,7 +5,9 @@ path touches (``X, obs, var, obsm, varm, obsp, varp, layers, uns``) and ``Data``
 dance/data/base.py (splits :114-184, config :203-271, ``get_feature`` :415-475, ``get_x/get_y/get_train_data``
 :845-888).  A real ``anndata.AnnData`` can be wrapped by ``Data`` just as well — only attribute access is used.
 """
+import copy
 import warnings
+from pprint import pformat
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -182,10 +184,75 @@ class AnnDataLite:
         for k in [k for k in self.uns if isinstance(k, str) and k.endswith(".hip")]:
             del self.uns[k]  # device graphs over the old set of cells (written next to obsp by the graph transforms) are stale now
 
+    def copy(self):
+        return copy.deepcopy(self)
+
+    def __getitem__(self, idx):
+        """Rows ``idx`` (positions or a boolean mask) as a new container — the copy ``AnnData[idx].copy()`` would give."""
+        idx = np.asarray(idx)
+        if idx.dtype == bool:
+            idx = np.flatnonzero(idx)
+        out = AnnDataLite(self._take(self.X, idx, 0), obs=self.obs.iloc[idx], var=self.var.copy(),
+                          obsm={k: self._take(v, idx, 0) for k, v in self.obsm.items()}, varm=dict(self.varm),
+                          obsp={k: self._take(self._take(v, idx, 0), idx, 1) for k, v in self.obsp.items()}, varp=dict(self.varp),
+                          layers={k: self._take(v, idx, 0) for k, v in self.layers.items()},
+                          uns={k: v for k, v in self.uns.items() if not (isinstance(k, str) and k.endswith(".hip"))})
+        if self.raw is not None:
+            out.raw = copy.copy(self.raw)
+            out.raw.X = self._take(self.raw.X, idx, 0)
+            out.raw.shape = tuple(out.raw.X.shape)
+        return out
+
     def __repr__(self):
         return (f"AnnDataLite object with n_obs x n_vars = {self.n_obs} x {self.n_vars}\n"
                 f"    obsm: {list(self.obsm)}\n    varm: {list(self.varm)}\n    obsp: {list(self.obsp)}\n"
                 f"    uns: {list(self.uns)}")
+
+
+def _stack_rows(parts):
+    if any(isinstance(p, DeviceArray) for p in parts):
+        dev = next(p.tensor.device for p in parts if isinstance(p, DeviceArray))
+        return DeviceArray(torch.cat([to_device_matrix(p, dev) for p in parts], 0))
+    parts = [p.materialize() if _is_lazy_graph(p) else p for p in parts]
+    if any(sp.issparse(p) for p in parts):
+        return sp.vstack([sp.csr_matrix(p) for p in parts], format="csr")
+    return np.concatenate([np.asarray(p) for p in parts], 0)
+
+
+def concat(adatas, *, join: str = "inner", label: Optional[str] = None, keys=None, index_unique: Optional[str] = None):
+    """Stack containers along the cells, the slice of ``anndata.concat`` that ``Data.append`` uses (dance/data/base.py:552):
+    variables are matched by name (``join="inner"``: those every part has, in the first part's order), ``X`` / ``layers`` /
+    ``obsm`` slots every part holds are stacked, ``obs`` keeps the columns every part has; pairwise slots, ``varm`` and
+    ``uns`` are dropped, as anndata does with its default ``merge=None`` / ``uns_merge=None``."""
+    import pandas as pd
+    adatas = list(adatas)
+    if join != "inner":
+        raise NotImplementedError(f"join={join!r}: only the inner join is modelled")
+    names = adatas[0].var.index
+    for a in adatas[1:]:
+        names = names[names.isin(a.var.index)]
+
+    def cols(a, v):
+        pos = a.var.index.get_indexer(names)
+        if len(pos) == a.n_vars and (pos == np.arange(a.n_vars)).all():
+            return v
+        return AnnDataLite._take(v, pos, 1)
+
+    obs = pd.concat([a.obs for a in adatas], join="inner")
+    if label is not None:
+        keys = list(range(len(adatas))) if keys is None else list(keys)
+        obs[label] = pd.Categorical(np.repeat([str(k) for k in keys], [a.n_obs for a in adatas]))
+    if index_unique is not None:
+        keys = list(range(len(adatas))) if keys is None else list(keys)
+        obs.index = [f"{i}{index_unique}{k}" for a, k in zip(adatas, keys) for i in a.obs.index]
+    out = AnnDataLite(_stack_rows([cols(a, a.X) for a in adatas]), obs=obs, var=pd.DataFrame(index=names))
+    for k in adatas[0].obsm:
+        if all(k in a.obsm for a in adatas):
+            out.obsm[k] = _stack_rows([a.obsm[k] for a in adatas])
+    for k in adatas[0].layers:
+        if all(k in a.layers for a in adatas):
+            out.layers[k] = _stack_rows([cols(a, a.layers[k]) for a in adatas])
+    return out
 
 
 def _ensure_iter(x):
@@ -272,11 +339,29 @@ class Data:
         return self._data.shape[1]
 
     @property
+    def cells(self) -> List[str]:
+        return self._data.obs.index.tolist()
+
+    @property
+    def x(self):
+        return self.get_x(return_type="default")
+
+    @property
+    def y(self):
+        return self.get_y(return_type="default")
+
+    def __getitem__(self, idx):
+        return self._data[idx]
+
+    def copy(self):
+        return copy.deepcopy(self)
+
+    @property
     def config(self) -> Dict[str, Any]:
         return self._data.uns["dance_config"]
 
     def __getattr__(self, name):  # pass X / obs / obsm ... through, like the reference does with setattr
-        if name in Data._DATA_CHANNELS + ["X"]:
+        if name in Data._DATA_CHANNELS + ["X"] and "_data" in self.__dict__:
             return getattr(self._data, name)
         raise AttributeError(name)
 
@@ -318,6 +403,83 @@ class Data:
 
     def set_split_idx(self, split_name: str, split_idx: Sequence[int]):
         self._split_idx_dict[split_name] = split_idx
+
+    def get_split_mask(self, split_name: str, return_type: str = "numpy"):
+        """Boolean mask over the cells of one split (dance/data/base.py:341-360)."""
+        split_idx = self.get_split_idx(split_name, error_on_miss=True)
+        if return_type == "numpy":
+            mask = np.zeros(self.shape[0], dtype=bool)
+        elif return_type == "torch":
+            mask = torch.zeros(self.shape[0], dtype=torch.bool)
+        else:
+            raise ValueError(f"Unsupported return_type {return_type!r}. Available options are 'numpy' and 'torch'.")
+        mask[split_idx] = True
+        return mask
+
+    def get_split_data(self, split_name: str):
+        return self._data[self.get_split_idx(split_name, error_on_miss=True)]
+
+    def append(self, data, *, mode: Optional[str] = "merge", rename_dict: Optional[Dict[str, str]] = None,
+               new_split_name: Optional[str] = None, label_batch: bool = False, **concat_kwargs):
+        """Stack another data object under this one (dance/data/base.py:477-561).  ``mode`` says what happens to the new
+        cells' splits: ``"merge"`` into the splits of the same name, ``"rename"`` through ``rename_dict``, ``"new_split"`` = all
+        of them under ``new_split_name``, ``None`` = in no split.  ``label_batch`` numbers the appended blocks in
+        ``obs["batch"]``."""
+        import pandas as pd
+        offset = self.shape[0]
+        new_splits = {k: sorted(int(i) + offset for i in v) for k, v in data._split_idx_dict.items()}
+        if mode == "merge":
+            for name, idx in self._split_idx_dict.items():
+                new_splits[name] = list(idx) + new_splits[name] if name in new_splits else idx
+        elif mode == "rename":
+            if rename_dict is None:
+                raise ValueError("Mode 'rename' is selected but 'rename_dict' is not specified.")
+            if common := set(self._split_idx_dict) & set(rename_dict.values()):
+                raise ValueError(f"'rename_dict' cannot caontain split keys present in current data: {common}")
+            if missed := [i for i in data._split_idx_dict if i not in rename_dict]:
+                raise KeyError(f"Missing rename mapping for keys: {missed}")
+            new_splits = {rename_dict[k]: v for k, v in new_splits.items()}
+            new_splits.update(self._split_idx_dict)
+        elif mode == "new_split":
+            if new_split_name is None:
+                raise ValueError("Mode 'new_split' is selected but 'new_split_name' is not specified.")
+            if not isinstance(new_split_name, str):
+                raise TypeError(f"'new_split_name' must be a string, got {type(new_split_name)}: {new_split_name}.")
+            if new_split_name in self._split_idx_dict:
+                raise ValueError(f"{new_split_name!r} is being used in the current splits. Please pick another name.")
+            new_splits = {new_split_name: list(range(offset, offset + data.shape[0]))}
+            new_splits.update(self._split_idx_dict)
+        elif mode is None:
+            new_splits = self._split_idx_dict
+        else:
+            raise ValueError(f"Unknown mode {mode!r}. Available options are: 'merge', 'rename', 'new_split'")
+        new_uns = {k: v for k, v in data.data.uns.items() if not (isinstance(k, str) and k.endswith(".hip"))}
+        new_uns.update({k: v for k, v in self._data.uns.items() if not (isinstance(k, str) and k.endswith(".hip"))})
+        if label_batch:
+            old = self._data.obs["batch"].tolist() if "batch" in self._data.obs.columns else [0] * self.shape[0]
+            batch = list(map(int, old)) + [int(max(old)) + 1] * data.shape[0]
+        if isinstance(self._data, AnnDataLite):
+            self._data = concat((self._data, data.data), **concat_kwargs)
+        else:  # a real AnnData was wrapped
+            import anndata
+            self._data = anndata.concat((self._data, data.data), **concat_kwargs)
+        self._data.uns.update(new_uns)
+        self._split_idx_dict = new_splits
+        if label_batch:
+            self._data.obs["batch"] = pd.Series(batch, dtype="category", index=self._data.obs.index)
+        return self
+
+    def pop(self, *, split_name: str):
+        """Drop the cells of one split; the other splits are renumbered, emptied ones disappear (dance/data/base.py:563-577)."""
+        gone = set(self.get_split_idx(split_name, error_on_miss=True))
+        keep = [i for i in range(self.shape[0]) if i not in gone]
+        new_pos = {j: i for i, j in enumerate(keep)}
+        splits = {}
+        for name, idx in self._split_idx_dict.items():
+            if moved := sorted(new_pos[i] for i in idx if i in new_pos):
+                splits[name] = moved
+        self._data = self._data[keep]
+        self._split_idx_dict = splits
 
     @property
     def train_idx(self):
@@ -398,8 +560,13 @@ class Data:
             mods, channels, channel_types = map(_ensure_iter, info)
             n = max(len(mods), len(channels), len(channel_types))
             mods, channels, channel_types = (list(v) * n if len(v) == 1 and v[0] is None else v for v in (mods, channels, channel_types))
-        out = [self.get_feature(split_name=split_name, return_type=return_type, mod=m, channel=c, channel_type=t, **kwargs)
-               for m, c, t in zip(mods, channels, channel_types)]
+        out = []
+        for m, c, t in zip(mods, channels, channel_types):
+            try:
+                out.append(self.get_feature(split_name=split_name, return_type=return_type, mod=m, channel=c, channel_type=t, **kwargs))
+            except Exception as e:  # base.py:830-839: one error type for "this configured feature cannot be had"
+                settings = dict(split_name=split_name, return_type=return_type, mod=m, channel=c, channel_type=t, kwargs=kwargs)
+                raise RuntimeError(f"Failed to get features for the following settings:\n{pformat(settings)}") from e
         return out[0] if len(out) == 1 else out
 
     def get_x(self, split_name=None, return_type="numpy", **kwargs):
