@@ -122,17 +122,15 @@ class Stagate(nn.Module, BasePretrain, BaseClusteringMethod):
     @staticmethod
     def preprocessing_pipeline(hvg_flavor: str = "seurat_v3", n_top_hvgs: int = 3000, model_name: str = "radius", radius: float = 150,
                                n_neighbors: int = 5, log_level="INFO"):
-        """stagate.py:157-173: HVG selection, normalize_total to 1e4 and log1p on the device, then the spatial graph.  The dispersion
-        flavours ("seurat", "cell_ranger") run on the device; the reference's default "seurat_v3" is a loess fit of the count
-        variances (scikit-misc, not in this image) and is NOT restated: with that flavour the selection must have happened upstream
-        and the step is skipped with a warning — ``hvg_flavor=None`` skips it silently."""
-        from ....transforms import HighlyVariableGenesLogarithmizedByTopGenes, Log1P, NormalizeTotal
+        """stagate.py:157-173: HVG selection, normalize_total to 1e4 and log1p on the device, then the spatial graph.  The
+        reference's default "seurat_v3" (a loess fit of the count variances) and the dispersion flavours ("seurat",
+        "cell_ranger") all run on the device; ``hvg_flavor=None`` skips the selection."""
+        from ....transforms import HighlyVariableGenesLogarithmizedByTopGenes, HighlyVariableGenesRawCount, Log1P, NormalizeTotal
         steps = []
         if hvg_flavor in ("seurat", "cell_ranger"):
             steps.append(HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=n_top_hvgs, flavor=hvg_flavor, subset=True))
         elif hvg_flavor == "seurat_v3":
-            logger.warning("Stagate.preprocessing_pipeline: hvg_flavor='seurat_v3' (loess on raw counts) is not available here; "
-                           "the HVG step is skipped — select the genes upstream or pass 'seurat' / 'cell_ranger'")
+            steps.append(HighlyVariableGenesRawCount(n_top_genes=n_top_hvgs, subset=True))
         elif hvg_flavor is not None:
             raise ValueError(f"unknown hvg_flavor {hvg_flavor!r}")
         return Compose(

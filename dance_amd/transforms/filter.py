@@ -2,7 +2,8 @@
 steps the clustering pipelines run through scanpy before they normalise (graphsc.py:111-119, scdsc.py:113-121) —
 ``sc.pp.filter_genes`` / ``sc.pp.filter_cells`` (here ``FilterGenesScanpy`` / ``FilterCellsScanpy``, dance/transforms/filter.py:55-280)
 and ``sc.pp.highly_variable_genes`` with the dispersion flavours (``HighlyVariableGenesLogarithmizedByTopGenes`` /
-``...ByMeanAndDisp``, filter.py:1219-1372).
+``...ByMeanAndDisp``, filter.py:1219-1372) or, on counts, the ``seurat_v3`` flavour (``HighlyVariableGenesRawCount``, filter.py:1142-1192,
+STAGATE's default: stagate.py:159-162) with the loess trend fitted here.
 
 The per-gene / per-cell statistics (sums, counts of expressing cells, means and variances) are reductions over the N x G matrix and
 run on the device, on a ``DeviceArray`` slot without a host copy; what is left — quantile bins, medians and a top-k over the G-long
@@ -12,6 +13,7 @@ scanpy (pin 1.10.1) is not vendored and not installable here: the selection rule
 (scanpy/preprocessing/_simple.py filter_genes / filter_cells, _highly_variable_genes.py _highly_variable_genes_single_batch) —
 parity unpinned by reference output, pinned to oracle/normalize.py's numpy restatement and hand-computed cases.
 """
+import warnings
 from typing import Optional, Union
 
 import numpy as np
@@ -251,6 +253,72 @@ def dispersion_hvg(mean: np.ndarray, var: np.ndarray, *, flavor: str = "seurat",
     return hv, mean, dispersion, norm
 
 
+def loess_at_points(x: torch.Tensor, y: torch.Tensor, span: float = 0.3, degree: int = 2) -> torch.Tensor:
+    """Cleveland's local regression of ``y`` on ``x`` evaluated at every ``x`` (gaussian family, tricube kernel) — the model
+    ``skmisc.loess.loess(x, y, span=span, degree=degree)`` fits for scanpy's ``seurat_v3`` flavour.  For each point the
+    ``floor(n * span + 1e-5)`` nearest points get the weight (1 - (d / rho)^3)^3, rho = the distance to the farthest of them,
+    and a polynomial in (x - q) / rho is fitted by weighted least squares; the fitted value is its intercept.  Batched in
+    float64 on ``x``'s device: a block of query points against all points at a time -> weighted moment sums; the small normal
+    equations are then solved on the host.  This is loess's DIRECT surface; scikit-misc's default interpolates the same vertex fits through a kd tree."""
+    x, y = x.double(), y.double()
+    n = x.numel()
+    nf = min(n, int(np.floor(n * span + 1e-5)))
+    if nf < 1:
+        raise ValueError(f"span={span} is too small for {n} points")
+    out = torch.empty_like(x)
+    block = max(1, (1 << 24) // max(n, 1))
+    for lo in range(0, n, block):
+        q = x[lo:lo + block]
+        d = (x[None, :] - q[:, None]).abs()
+        rho = torch.kthvalue(d, nf, dim=1).values * max(1.0, span)
+        safe = torch.where(rho > 0, rho, torch.ones_like(rho))
+        r = d / safe[:, None]
+        w = torch.where(r < 1, (1 - r**3)**3, torch.zeros_like(r))
+        w = torch.where((rho > 0)[:, None], w, (d == 0).double())  # the window is one value of x repeated: its plain mean
+        u = (x[None, :] - q[:, None]) / safe[:, None]
+        powers = [torch.ones_like(u)]
+        for _ in range(2 * degree):
+            powers.append(powers[-1] * u)
+        mom = [(w * p).sum(1) for p in powers]
+        rhs = torch.stack([(w * powers[k] * y[None, :]).sum(1) for k in range(degree + 1)], 1)
+        gram = torch.stack([torch.stack([mom[a + b] for b in range(degree + 1)], 1) for a in range(degree + 1)], 1)
+        # the (degree+1)^2 normal equations of each point are solved on the host (bytes per point; pseudo-inverse, so a window
+        # with fewer distinct x than coefficients gets the minimum-norm fit, as loess's own QR does)
+        inv = np.linalg.pinv(gram.cpu().numpy(), hermitian=True)
+        out[lo:lo + block] = torch.from_numpy((inv @ rhs.cpu().numpy()[:, :, None])[:, 0, 0]).to(x.device)
+    return out
+
+
+def seurat_v3_hvg(x: torch.Tensor, *, n_top_genes: int, span: float = 0.3):
+    """scanpy's ``seurat_v3`` selection on a device count matrix, single batch [3P-memory: scanpy 1.10.1
+    _highly_variable_genes_seurat_v3]: per-gene mean / unbiased variance, loess of log10(variance) on log10(mean) over the
+    non-constant genes, counts clipped at mean + sqrt(N) * fitted std, variance of the standardised clipped counts.  Two passes
+    over the matrix in row chunks; returns (highly_variable, means, variances, variances_norm, rank) as scanpy writes them."""
+    n, g = x.shape
+    mean_np, var_np = gene_mean_var(x, undo_log=False)
+    mean = torch.from_numpy(mean_np).to(x.device)
+    var = torch.from_numpy(var_np).to(x.device)
+    est = torch.zeros(g, dtype=torch.float64, device=x.device)
+    ok = var > 0
+    if ok.any():
+        est[ok] = loess_at_points(torch.log10(mean[ok]), torch.log10(var[ok]), span=span, degree=2)
+    reg_std = torch.sqrt(10**est)
+    clip = reg_std * float(np.sqrt(n)) + mean
+    s = torch.zeros(g, dtype=torch.float64, device=x.device)
+    q = torch.zeros(g, dtype=torch.float64, device=x.device)
+    step = max(1, (1 << 27) // max(g, 1))
+    for lo in range(0, n, step):
+        c = torch.minimum(x[lo:lo + step].double(), clip[None, :])
+        s += c.sum(0)
+        q += (c * c).sum(0)
+    norm_var = (n * mean * mean + q - 2 * s * mean) / ((n - 1) * reg_std * reg_std)
+    norm_var = norm_var.cpu().numpy()
+    rank = np.argsort(np.argsort(-norm_var, kind="stable"), kind="stable").astype(np.float32)
+    hv = rank < n_top_genes
+    rank[~hv] = np.nan
+    return hv, mean_np, var_np, norm_var, rank
+
+
 class _HVGBase(BaseTransform):
 
     def __init__(self, channel, channel_type, subset, inplace, batch_key, device, **kwargs):
@@ -304,3 +372,40 @@ class HighlyVariableGenesLogarithmizedByMeanAndDisp(_HVGBase):
 
     def __call__(self, data):
         return self._select(data, min_mean=self.min_mean, max_mean=self.max_mean, min_disp=self.min_disp, max_disp=self.max_disp)
+
+
+@register_preprocessor("filter", "gene")
+class HighlyVariableGenesRawCount(BaseTransform):
+    """``sc.pp.highly_variable_genes(flavor="seurat_v3")`` on a COUNT matrix (filter.py:1142-1192): the loess fit of the
+    variance-mean trend is computed here (``loess_at_points``, the direct surface — scikit-misc is not needed)."""
+
+    _DISPLAY_ATTRS = ("n_top_genes", "span", "subset")
+
+    def __init__(self, channel: Optional[str] = None, channel_type: Optional[str] = None, n_top_genes: Optional[int] = 1000,
+                 span: Optional[float] = 0.3, subset: bool = True, inplace: bool = True, batch_key: Optional[str] = None,
+                 check_values: bool = True, device="cuda", **kwargs):
+        super().__init__(**kwargs)
+        if batch_key is not None:
+            raise NotImplementedError("batch_key (per-batch selection and merging) is not implemented on the device path")
+        if n_top_genes is None:
+            raise ValueError("`n_top_genes` is mandatory if `flavor` is `seurat_v3`.")  # scanpy's own check
+        self.channel, self.channel_type, self.n_top_genes, self.span = channel, channel_type, n_top_genes, span
+        self.subset, self.inplace, self.check_values, self.device = subset, inplace, check_values, device
+        self.logger.info("Expects count data")
+
+    def __call__(self, data):
+        if data.data.X.shape[1] == 0:
+            raise ValueError("Gene dimension is 0")
+        kw = dict(channel=self.channel, channel_type=self.channel_type) if self.channel_type == "layers" else dict(channel_type="X")
+        x = data.get_feature(return_type=self.device, **kw)
+        if self.check_values and not bool((x[:min(len(x), 4096)] % 1 == 0).all()):
+            warnings.warn("`flavor='seurat_v3'` expects raw count data, but non-integers were found.", UserWarning)
+        hv, means, variances, norm_var, rank = seurat_v3_hvg(x, n_top_genes=int(self.n_top_genes), span=self.span)
+        if self.inplace:
+            v = data.data.var
+            v["highly_variable"], v["highly_variable_rank"], v["means"] = hv, rank, means
+            v["variances"], v["variances_norm"] = variances, norm_var
+            data.data.uns["hvg"] = {"flavor": "seurat_v3"}
+        if self.subset:
+            data.data._inplace_subset_var(hv)
+        return data

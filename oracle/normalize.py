@@ -114,3 +114,47 @@ def highly_variable_genes(X, flavor="seurat", n_top_genes=None, n_bins=20, min_m
         z = np.where(np.isnan(norm), 0, norm)
         hv = (mean > min_mean) & (mean < max_mean) & (z > min_disp) & (z < max_disp)
     return hv, mean, disp, norm
+
+
+def loess_direct(x, y, span=0.3, degree=2):
+    """Local regression of y on x evaluated AT every x (Cleveland's loess, gaussian family, tricube kernel, the direct
+    surface): for each point q the ``floor(n * span + 1e-5)`` nearest points are weighted by (1 - (d / rho)^3)^3 with rho the
+    distance to the farthest of them, and a degree-``degree`` polynomial in (x - q) is fitted by weighted least squares; the
+    fitted value is its intercept.  One ``numpy.linalg.lstsq`` per point — the plain form of netlib dloess ``ehg127``
+    (sqrt-weights on the rows, pseudo-inverse for rank-deficient windows).  scikit-misc's default surface is the kd-tree /
+    blending INTERPOLATION of exactly these vertex fits, so its values are close to these, not identical — **parity unpinned**."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    n = len(x)
+    nf = min(n, int(np.floor(n * span + 1e-5)))
+    out = np.empty(n)
+    for i in range(n):
+        d = np.abs(x - x[i])
+        rho = np.partition(d, nf - 1)[nf - 1] * max(1.0, span)
+        w = np.where(d < rho, (1 - (d / rho)**3)**3, 0.0) if rho > 0 else (d == 0).astype(np.float64)
+        sel = w > 0
+        u = (x[sel] - x[i]) / (rho if rho > 0 else 1.0)
+        A = np.stack([u**p for p in range(degree + 1)], 1) * np.sqrt(w[sel])[:, None]
+        out[i] = np.linalg.lstsq(A, y[sel] * np.sqrt(w[sel]), rcond=None)[0][0]
+    return out
+
+
+def highly_variable_genes_seurat_v3(X, n_top_genes=1000, span=0.3):
+    """scanpy.pp.highly_variable_genes(flavor="seurat_v3") on a count matrix, single batch [3P-memory, scanpy 1.10.1
+    _highly_variable_genes_seurat_v3]: loess of log10(variance) on log10(mean) over the non-constant genes, counts clipped at
+    mean + sqrt(N) * fitted std, variance of the standardised clipped counts, the ``n_top_genes`` largest kept.  Returns
+    (highly_variable, means, variances, variances_norm, rank) — rank is NaN outside the selection, as scanpy writes it."""
+    X = np.asarray(X, dtype=np.float64)
+    n = X.shape[0]
+    mean = X.mean(0)
+    var = ((X * X).mean(0) - mean**2) * (n / (n - 1))
+    est = np.zeros(X.shape[1])
+    ok = var > 0
+    est[ok] = loess_direct(np.log10(mean[ok]), np.log10(var[ok]), span=span, degree=2)
+    reg_std = np.sqrt(10**est)
+    clipped = np.minimum(X, (reg_std * np.sqrt(n) + mean)[None, :])
+    norm_var = (n * mean**2 + (clipped**2).sum(0) - 2 * clipped.sum(0) * mean) / ((n - 1) * reg_std**2)
+    rank = np.argsort(np.argsort(-norm_var, kind="stable"), kind="stable").astype(np.float32)
+    hv = rank < n_top_genes
+    rank[~hv] = np.nan
+    return hv, mean, var, norm_var, rank

@@ -26,6 +26,7 @@ PAIRS = [
     ("dance/transforms/filter.py", "FilterGenesScanpy", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByTopGenes", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByMeanAndDisp", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "HighlyVariableGenesRawCount", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "FilterGenesMatch", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "FilterCellsType", "dance_amd.transforms.filter"),
     ("dance/transforms/normalize.py", "UpdateSizeFactors", "dance_amd.transforms.normalize"),
@@ -102,6 +103,7 @@ EXTRA_PARAMS_OK = {
     ("WeightedFeaturePCA", "__init__"): {"device", "solver"},
     ("HighlyVariableGenesLogarithmizedByTopGenes", "__init__"): {"device"},
     ("HighlyVariableGenesLogarithmizedByMeanAndDisp", "__init__"): {"device"},
+    ("HighlyVariableGenesRawCount", "__init__"): {"device"},
     ("CellPCA", "__init__"): {"device", "solver"},
 }
 

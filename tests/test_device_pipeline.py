@@ -193,7 +193,7 @@ def check_model_pipelines(device):
     assert np.isclose(np.median(sf), 1.0) and np.allclose(np.asarray(ad.obs["n_counts"]) / np.median(np.asarray(ad.obs["n_counts"])), sf)
     assert ad.obsp["HeteronetGraph"].shape == (n_keep, n_keep) if "HeteronetGraph" in ad.obsp else True
 
-    # ---- STAGATE (stagate.py:157-173): dispersion flavours on the device; seurat_v3 is skipped loudly --------------------------------
+    # ---- STAGATE (stagate.py:157-173): the dispersion flavours and the default seurat_v3 (loess) on the device --------------------------------
     from dance_amd.modules.spatial.spatial_domain.stagate import Stagate
     adl = dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy()).to(device)), obsm={"spatial_pixel": np.round(xy * 3).astype(np.int64)})
     pipe = Stagate.preprocessing_pipeline(hvg_flavor="cell_ranger", n_top_hvgs=50, model_name="knn", n_neighbors=6)
@@ -204,7 +204,21 @@ def check_model_pipelines(device):
     pipe(data)
     assert data.data.X.shape[0] == 400 and 50 <= data.data.X.shape[1] <= 60  # (ties at the cut-off are all kept, as scanpy does)
     assert data.data.obsp["StagateGraph"].shape == (400, 400)
-    assert len(Stagate.preprocessing_pipeline().transforms) == 4 and len(Stagate.preprocessing_pipeline(hvg_flavor=None).transforms) == 4
+    assert len(Stagate.preprocessing_pipeline().transforms) == 5 and len(Stagate.preprocessing_pipeline(hvg_flavor=None).transforms) == 4
+    # the reference's default flavour works on counts: the same genes as the numpy restatement picks, exactly n_top_hvgs of them
+    from oracle import normalize as on
+    adl = dd.AnnDataLite(dd.DeviceArray(torch.from_numpy(x.copy()).to(device)), obsm={"spatial_pixel": np.round(xy * 3).astype(np.int64)})
+    pipe = Stagate.preprocessing_pipeline(n_top_hvgs=50, model_name="knn", n_neighbors=6)
+    assert type(pipe.transforms[0]).__name__ == "HighlyVariableGenesRawCount"
+    for t in pipe.transforms:
+        if hasattr(t, "device"):
+            t.device = device
+    data = dd.Data(adl, train_size=-1, val_size=0, test_size=0)
+    before = dd.DeviceArray.host_copies
+    pipe(data)
+    assert dd.DeviceArray.host_copies == before
+    want = on.highly_variable_genes_seurat_v3(x, n_top_genes=50)[0]
+    assert data.data.X.shape == (400, 50) and data.data.var.index.tolist() == [str(i) for i in np.flatnonzero(want)]
     with pytest.raises(ValueError):
         Stagate.preprocessing_pipeline(hvg_flavor="bogus")
 

@@ -77,6 +77,63 @@ def test_filter_and_hvg_on_cpu_tensors():
     check_filters("cpu")
 
 
+def check_seurat_v3(device):
+    """The count-based flavour (filter.py:1142-1192 -> scanpy seurat_v3): the loess trend fitted on the device against the numpy
+    restatement (one lstsq per point) and closed forms; the transform's columns and subset against the restated selection."""
+    from dance_amd.data import AnnDataLite, Data, DeviceArray
+    from dance_amd.transforms.filter import HighlyVariableGenesRawCount, loess_at_points
+    rng = np.random.default_rng(4)
+    # (1) a local quadratic fit reproduces a quadratic exactly, whatever the window
+    xs = rng.uniform(0, 3, 300)
+    quad = 1 + 2 * xs - 0.5 * xs * xs
+    for fit in (on.loess_direct(xs, quad), loess_at_points(torch.from_numpy(xs).to(device), torch.from_numpy(quad).to(device)).cpu().numpy()):
+        assert np.abs(fit - quad).max() < 1e-10
+    # (2) hand-computed: five points 0..4, span 1, degree 1, evaluated at 0 — the window reaches 4, so the tricube weights are
+    # 1, (1 - 1/64)^3, (1 - 1/8)^3, (1 - 27/64)^3 and 0; the weighted straight line through (0,0) (1,1) (2,4) (3,9):
+    px, py = np.arange(5.0), np.array([0.0, 1, 4, 9, 20])
+    w = np.array([1.0, (1 - 1 / 64)**3, (1 - 1 / 8)**3, (1 - 27 / 64)**3])
+    sw, sx, sy = w.sum(), (w * px[:4]).sum(), (w * py[:4]).sum()
+    slope = ((w * px[:4] * py[:4]).sum() - sx * sy / sw) / ((w * px[:4]**2).sum() - sx * sx / sw)
+    at0 = sy / sw - slope * sx / sw
+    assert np.isclose(on.loess_direct(px, py, span=1.0, degree=1)[0], at0, rtol=1e-12)
+    assert np.isclose(float(loess_at_points(torch.from_numpy(px).to(device), torch.from_numpy(py).to(device), span=1.0, degree=1)[0]), at0, rtol=1e-12)
+    # (3) noisy data with tied x (a window that is one repeated value included): device == restatement
+    xs = rng.normal(size=400)
+    xs[10:20] = xs[10]
+    ys = np.sin(xs) + 0.1 * rng.normal(size=400)
+    got = loess_at_points(torch.from_numpy(xs).to(device), torch.from_numpy(ys).to(device)).cpu().numpy()
+    assert np.abs(got - on.loess_direct(xs, ys)).max() < 1e-9
+    tied = np.r_[np.zeros(8), np.linspace(1, 2, 12)]
+    yt = rng.normal(size=20)
+    got = loess_at_points(torch.from_numpy(tied).to(device), torch.from_numpy(yt).to(device)).cpu().numpy()   # nf = 6 < 8 ties: rho = 0
+    assert np.isclose(got[0], yt[:8].mean()) and np.abs(got - on.loess_direct(tied, yt)).max() < 1e-9
+    # (4) the transform on counts: constant genes, the written columns, the subset
+    x = _counts(300, 150, 2)
+    x[:, 7] = 3
+    want_hv, mean, var, norm_var, rank = on.highly_variable_genes_seurat_v3(x, n_top_genes=40)
+    d = Data(AnnDataLite(DeviceArray(torch.from_numpy(x.copy()).to(device))))
+    before = DeviceArray.host_copies
+    HighlyVariableGenesRawCount(n_top_genes=40, subset=False, device=device)(d)
+    v = d.data.var
+    assert np.array_equal(v["highly_variable"].values, want_hv) and int(want_hv.sum()) == 40 and not want_hv[:3].any() and not want_hv[7]
+    assert np.allclose(v["means"].values, mean) and np.allclose(v["variances"].values, var, rtol=1e-6)
+    assert np.allclose(v["variances_norm"].values, norm_var, rtol=1e-6) and np.array_equal(v["highly_variable_rank"].values, rank, equal_nan=True)
+    assert v["variances_norm"].values[7] == 0 and d.data.uns["hvg"] == {"flavor": "seurat_v3"}
+    HighlyVariableGenesRawCount(n_top_genes=40, device=device)(d)
+    assert isinstance(d.data.X, DeviceArray) and d.data.X.shape == (300, 40) and DeviceArray.host_copies == before
+    assert np.array_equal(np.asarray(d.data.X), x[:, want_hv])
+    with pytest.warns(UserWarning, match="expects raw count data"):
+        HighlyVariableGenesRawCount(n_top_genes=5, device=device)(Data(AnnDataLite(DeviceArray(torch.from_numpy(x + 0.5).to(device)))))
+    with pytest.raises(ValueError):
+        HighlyVariableGenesRawCount(n_top_genes=None)
+    with pytest.raises(ValueError, match="Gene dimension is 0"):
+        HighlyVariableGenesRawCount(device=device)(Data(AnnDataLite(np.zeros((4, 0), dtype=np.float32))))
+
+
+def test_seurat_v3_hvg_on_cpu_tensors():
+    check_seurat_v3("cpu")
+
+
 def test_filter_genes_match_cells_type_size_factors():
     """The three small transforms the model pipelines need besides the scanpy restatements (filter.py:386-435, :1477-1512,
     normalize.py:647-659), on host and DeviceArray slots."""

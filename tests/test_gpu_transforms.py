@@ -250,6 +250,11 @@ def test_filter_and_hvg_on_device(cuda_device):
     tft.check_filters("cuda")
 
 
+def test_seurat_v3_hvg_on_device(cuda_device):
+    import test_filter_transforms as tft
+    tft.check_seurat_v3("cuda")
+
+
 def test_model_pipelines_on_device_arrays_gpu(cuda_device):
     import test_device_pipeline as tdp
     tdp.check_model_pipelines("cuda")
