@@ -21,7 +21,7 @@ def main(argv=None):
     p.add_argument("--n_clusters", type=int, default=4)
     p.add_argument("--hidden_dims", type=int, nargs=2, default=[128, 30])
     p.add_argument("--high_variable_genes", type=int, default=400)
-    p.add_argument("--hvg_flavor", default="cell_ranger")
+    p.add_argument("--hvg_flavor", default="seurat_v3")
     p.add_argument("--n_neighbors", type=int, default=6)
     p.add_argument("--epochs", type=int, default=60)
     p.add_argument("--device", default="cuda")
