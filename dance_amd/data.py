@@ -147,6 +147,14 @@ class AnnDataLite:
     def n_vars(self):
         return self.X.shape[1]
 
+    @property
+    def obs_names(self):
+        return self.obs.index
+
+    @property
+    def var_names(self):
+        return self.var.index
+
     # ---- in-place subsetting (AnnData._inplace_subset_var / _inplace_subset_obs): every aligned slot follows ---------------
     @staticmethod
     def _take(v, idx, axis):
@@ -163,8 +171,22 @@ class AnnDataLite:
         v = np.asarray(v) if not isinstance(v, (np.ndarray, torch.Tensor)) else v
         return v[idx] if axis == 0 else v[:, idx]
 
+    @staticmethod
+    def _positions(index, sel):
+        """A boolean mask -> the kept positions in order; a list of names -> their positions IN THE LIST'S ORDER (what
+        ``AnnData[:, names]`` gives: dance's gene filters pass sorted names, so the columns come out sorted by name)."""
+        sel = np.asarray(sel)
+        if sel.dtype == bool:
+            return np.flatnonzero(sel)
+        if sel.dtype.kind in "iu":
+            return sel.astype(np.int64)
+        pos = index.get_indexer(sel)
+        if (pos < 0).any():
+            raise KeyError(f"names not in the index: {[str(v) for v in sel[pos < 0][:5]]}")
+        return pos
+
     def _inplace_subset_var(self, mask):
-        idx = np.flatnonzero(np.asarray(mask, dtype=bool))
+        idx = self._positions(self.var.index, mask)
         self.X = self._take(self.X, idx, 1)
         self.var = self.var.iloc[idx]
         self.varm = {k: self._take(v, idx, 0) for k, v in self.varm.items()}
@@ -172,7 +194,7 @@ class AnnDataLite:
         self.layers = {k: self._take(v, idx, 1) for k, v in self.layers.items()}
 
     def _inplace_subset_obs(self, mask):
-        idx = np.flatnonzero(np.asarray(mask, dtype=bool))
+        idx = self._positions(self.obs.index, mask)
         if self.raw is not None:  # AnnData.raw follows the observations (not the variables)
             self.raw.X = self._take(self.raw.X, idx, 0)
             self.raw.shape = tuple(self.raw.X.shape)
@@ -189,9 +211,15 @@ class AnnDataLite:
 
     def __getitem__(self, idx):
         """Rows ``idx`` (positions or a boolean mask) as a new container — the copy ``AnnData[idx].copy()`` would give."""
-        idx = np.asarray(idx)
-        if idx.dtype == bool:
-            idx = np.flatnonzero(idx)
+        if isinstance(idx, tuple):  # adata[rows, columns]
+            rows, cols = idx
+            out = self if isinstance(rows, slice) and rows == slice(None) else self[rows]
+            if isinstance(cols, slice) and cols == slice(None):
+                return out
+            out = out.copy() if out is self else out
+            out._inplace_subset_var(cols)
+            return out
+        idx = self._positions(self.obs.index, idx)
         out = AnnDataLite(self._take(self.X, idx, 0), obs=self.obs.iloc[idx], var=self.var.copy(),
                           obsm={k: self._take(v, idx, 0) for k, v in self.obsm.items()}, varm=dict(self.varm),
                           obsp={k: self._take(self._take(v, idx, 0), idx, 1) for k, v in self.obsp.items()}, varp=dict(self.varp),

@@ -14,7 +14,7 @@ scanpy (pin 1.10.1) is not vendored and not installable here: the selection rule
 parity unpinned by reference output, pinned to oracle/normalize.py's numpy restatement and hand-computed cases.
 """
 import warnings
-from typing import Optional, Union
+from typing import List, Optional, Union
 
 import numpy as np
 import torch
@@ -136,6 +136,205 @@ class FilterGenesScanpy(FilterScanpy):
         super().__init__(min_counts, min_cells, max_counts, max_cells, split_name, channel, channel_type, key_n_counts, key_n_cells, inplace,
                          **kwargs)
         self.min_cells, self.max_cells = min_cells, max_cells
+
+
+@register_preprocessor("filter", "gene")
+class FilterGenesCommon(BaseTransform):
+    """Keep the genes that are expressed (non-zero somewhere) in every batch, or in every named split (filter.py:319-383).  The
+    per-group |x| column sums are device reductions; the kept genes come out sorted by NAME, as the reference's
+    ``_inplace_subset_var(sorted(names))`` leaves them."""
+
+    _DISPLAY_ATTRS = ("batch_key", "split_keys")
+
+    def __init__(self, batch_key: Optional[str] = None, split_keys: Optional[List[str]] = None, **kwargs):
+        self.device = kwargs.pop("device", "cuda")
+        super().__init__(**kwargs)
+        if (batch_key is not None) and (split_keys is not None):
+            raise ValueError("Either batch_key or split_keys can be specified, but not both. "
+                             f"Got {batch_key=!r}, {split_keys=!r}")
+        elif (batch_key is None) and (split_keys is None):
+            raise ValueError("Either one of batch_key or split_keys must be specified.")
+        self.batch_key, self.split_keys = batch_key, split_keys
+
+    def __call__(self, data):
+        x = data.get_feature(return_type=self.device, channel_type="X")
+        if self.batch_key is None:
+            groups = {k: np.asarray(data.get_split_idx(k, error_on_miss=True), dtype=np.int64) for k in self.split_keys}
+        else:
+            groups = {k: np.flatnonzero((data.data.obs[self.batch_key] == k).values) for k in data.data.obs[self.batch_key].unique()}
+        common = None
+        for name, rows in groups.items():
+            hit = x[torch.as_tensor(rows, device=x.device)].abs().sum(0, dtype=torch.float64) > 0
+            self.logger.info(f"{int(hit.sum()):,} genes found in {name!r}")
+            common = hit if common is None else common & hit
+        names = sorted(data.data.var_names[common.cpu().numpy()])
+        self.logger.info(f"Found {len(names):,} common genes out of {data.shape[1]:,} total genes.")
+        data.data._inplace_subset_var(names)
+
+
+def gene_summary(x: torch.Tensor, mode: str) -> np.ndarray:
+    """The per-gene statistic of dance's ``FilterGenes`` family (filter.py:476-487): ``sum``, ``var`` (population variance,
+    mean(x^2) - mean(x)^2), ``cv`` = std / mean, ``rv`` = var / mean (both with 0 where the mean is 0) — float64 column
+    reductions on ``x``'s device, G numbers back to the host."""
+    n = x.shape[0]
+    s = x.sum(0, dtype=torch.float64)
+    if mode == "sum":
+        return s.cpu().numpy()
+    mean = s / n
+    if mode == "var":
+        q = torch.zeros_like(s)
+        step = max(1, (1 << 27) // max(x.shape[1], 1))
+        for lo in range(0, n, step):
+            c = x[lo:lo + step].double()
+            q += (c * c).sum(0)
+        return (q / n - mean * mean).cpu().numpy()
+    if mode in ("cv", "rv"):
+        q = torch.zeros_like(s)
+        step = max(1, (1 << 27) // max(x.shape[1], 1))
+        for lo in range(0, n, step):
+            c = x[lo:lo + step].double() - mean[None, :]  # numpy's var: mean of squared deviations
+            q += (c * c).sum(0)
+        var = q / n
+        out = (var.sqrt() if mode == "cv" else var) / mean
+        return torch.nan_to_num(out, nan=0.0, posinf=0.0, neginf=0.0).cpu().numpy()
+    raise ValueError(f"Unknown summarization mode {mode!r}, available options are ['cv', 'rv', 'sum', 'var']")
+
+
+class FilterGenes(BaseTransform):
+    """Filter genes on a per-gene summary of the expression matrix (filter.py:437-518); subclasses say which genes stay."""
+
+    def __init__(self, *, mode: str = "sum", channel: Optional[str] = None, channel_type: Optional[str] = None,
+                 whitelist_indicators: Optional[Union[str, List[str]]] = None, add_n_counts=True, add_n_cells=True, inplace=True,
+                 device="cuda", **kwargs):
+        super().__init__(**kwargs)
+        if (channel is not None) and (channel_type != "layers"):
+            raise ValueError(f"Only X layers is available for filtering genes, specified {channel_type=!r}")
+        if mode not in (all_modes := ["cv", "rv", "sum", "var"]):
+            raise ValueError(f"Unknown summarization mode {mode!r}, available options are {all_modes}")
+        self.mode, self.channel, self.channel_type, self.whitelist_indicators = mode, channel, channel_type, whitelist_indicators
+        self.add_n_counts, self.add_n_cells, self.inplace, self.device = add_n_counts, add_n_cells, inplace, device
+
+    def _get_preserve_mask(self, gene_summary: np.ndarray) -> np.ndarray:
+        raise NotImplementedError
+
+    def __call__(self, data):
+        kw = dict(channel=self.channel, channel_type="layers") if self.channel is not None else dict(channel_type="X")
+        x = data.get_feature(return_type=self.device, **kw)
+        if self.add_n_counts:
+            data.data.var["n_counts"] = x.sum(0, dtype=torch.float64).to(torch.float32).cpu().numpy()
+        if self.add_n_cells:
+            data.data.var["n_cells"] = (x > 0).sum(0).cpu().numpy()
+        summary = gene_summary(x, self.mode)
+        mask = self._get_preserve_mask(summary)
+        selected = sorted(data.data.var_names[mask])
+        if self.whitelist_indicators is not None:  # genes flagged in any of these .var columns stay whatever their statistic
+            columns = [self.whitelist_indicators] if isinstance(self.whitelist_indicators, str) else self.whitelist_indicators
+            flags = data.data.var[columns]
+            selected = sorted(set(selected) | set(flags[flags.max(1)].index.tolist()))
+        data.data.uns["gene_summary"] = summary
+        self.logger.info(f"{data.shape[1] - len(selected):,} genes removed")
+        if self.inplace:
+            data.data._inplace_subset_var(selected)  # (sic) by sorted name: the columns are reordered
+        else:
+            pos = torch.as_tensor(data.data.var_names.get_indexer(selected), device=x.device)
+            data.data.obsm[self.out] = DeviceArray(x.index_select(1, pos).contiguous())
+
+
+@register_preprocessor("filter", "gene")
+class FilterGenesPercentile(FilterGenes):
+    """Keep the genes whose summary lies between two percentiles of all summaries, ends included (filter.py:521-588)."""
+
+    _DISPLAY_ATTRS = ("min_val", "max_val", "mode")
+
+    def __init__(self, min_val: Optional[float] = 1, max_val: Optional[float] = 99, *, mode: str = "sum", channel: Optional[str] = None,
+                 channel_type: Optional[str] = None, whitelist_indicators: Optional[Union[str, List[str]]] = None, add_n_counts=True,
+                 add_n_cells=True, inplace=True, **kwargs):
+        super().__init__(mode=mode, channel=channel, channel_type=channel_type, whitelist_indicators=whitelist_indicators,
+                         add_n_counts=add_n_counts, add_n_cells=add_n_cells, inplace=inplace, **kwargs)
+        self.min_val, self.max_val = min_val, max_val
+
+    def _get_preserve_mask(self, gene_summary):
+        lo, hi = np.percentile(gene_summary, self.min_val), np.percentile(gene_summary, self.max_val)
+        return np.logical_and(gene_summary >= lo, gene_summary <= hi)
+
+
+@register_preprocessor("filter", "gene")
+class FilterGenesTopK(FilterGenes):
+    """Keep the ``num_genes`` genes with the largest (``top``) or smallest summary (filter.py:590-662)."""
+
+    _DISPLAY_ATTRS = ("num_genes", "top", "mode")
+
+    def __init__(self, num_genes: int = 1000, top: bool = True, *, mode: str = "cv", channel: Optional[str] = None,
+                 channel_type: Optional[str] = "X", whitelist_indicators: Optional[Union[str, List[str]]] = None, add_n_counts=False,
+                 add_n_cells=False, inplace=True, **kwargs):
+        super().__init__(mode=mode, channel=channel, channel_type=channel_type, whitelist_indicators=whitelist_indicators,
+                         add_n_counts=add_n_counts, add_n_cells=add_n_cells, inplace=inplace, **kwargs)
+        self.num_genes, self.top = num_genes, top
+
+    def _get_preserve_mask(self, gene_summary):
+        total = gene_summary.size
+        if self.num_genes >= total:
+            self.logger.warning(f"{self.num_genes=!r} > total number of genes: {total}")
+            self.num_genes = total
+        order = gene_summary.argsort()
+        mask = np.zeros(total, dtype=bool)
+        mask[order[-self.num_genes:] if self.top else order[:self.num_genes]] = True
+        return mask
+
+
+class _ScanpyOrder(BaseTransform):
+    """One scanpy threshold after another, in the order given (filter.py:1048-1139, :1403-1473)."""
+
+    _KEYS: tuple = ()
+    _STEP = None
+
+    def _setup(self, order, thresholds, step_kwargs):
+        self.order = list(self._KEYS) if order is None else list(order)
+        self.logger.info(f"Filter order: {self.order}")
+        if not set(self.order).issubset(thresholds):
+            raise KeyError(f"An order should be in {thresholds.keys()}")
+        self.steps = {key: self._STEP(**{key: thresholds[key]}, **step_kwargs) for key in thresholds if key in self.order}
+        for key in thresholds:
+            if key not in self.order:
+                self.logger.warning(f"{key} not in order,It makes no sense to set {key}")
+
+    def __call__(self, data):
+        for key in self.order:
+            self.steps[key](data)
+
+
+@register_preprocessor("filter", "gene")
+class FilterGenesScanpyOrder(_ScanpyOrder):
+    _KEYS = ("min_counts", "min_cells", "max_counts", "max_cells")
+    _STEP = FilterGenesScanpy
+
+    def __init__(self, order: Optional[List[str]] = None, min_counts=None, min_cells=None, max_counts=None, max_cells=None,
+                 split_name: Optional[str] = None, channel: Optional[str] = None, channel_type: Optional[str] = "X", add_n_counts=True,
+                 add_n_cells=True, inplace=True, params_dict=None, **kwargs):
+        device = kwargs.pop("device", "cuda")
+        super().__init__(**kwargs)
+        self.add_n_counts, self.add_n_cells = add_n_counts, add_n_cells
+        self._setup(order, dict(min_counts=min_counts, min_cells=min_cells, max_counts=max_counts, max_cells=max_cells),
+                    dict(split_name=split_name, channel=channel, channel_type=channel_type, key_n_counts="n_counts" if add_n_counts else None,
+                         key_n_cells="n_cells" if add_n_cells else None, inplace=inplace, device=device, **kwargs))
+        self.filter_genes_order, self.geneScanpyOrderDict = self.order, self.steps
+
+
+@register_preprocessor("filter", "cell")
+class FilterCellsScanpyOrder(_ScanpyOrder):
+    _KEYS = ("min_counts", "min_genes", "max_counts", "max_genes")
+    _STEP = FilterCellsScanpy
+
+    def __init__(self, order: Optional[List[str]] = None, min_counts=None, min_genes=None, max_counts=None, max_genes=None,
+                 split_name: Optional[str] = None, channel: Optional[str] = None, channel_type: Optional[str] = "X", add_n_counts=True,
+                 add_n_genes=True, inplace=True, **kwargs):
+        device = kwargs.pop("device", "cuda")
+        super().__init__(**kwargs)
+        self.add_n_counts, self.add_n_genes = add_n_counts, add_n_genes
+        self._setup(order, dict(min_counts=min_counts, min_genes=min_genes, max_counts=max_counts, max_genes=max_genes),
+                    dict(split_name=split_name, channel=channel, channel_type=channel_type, key_n_counts="n_counts" if add_n_counts else None,
+                         key_n_genes="n_genes" if add_n_genes else None, inplace=inplace, device=device, **kwargs))
+        self.filter_cells_order, self.cellScanpyOrderDict = self.order, self.steps
 
 
 @register_preprocessor("filter", "gene")

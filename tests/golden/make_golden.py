@@ -858,6 +858,87 @@ def make_small_transforms():
     print("small_transforms.npz:", len(out), "arrays")
 
 
+def make_gene_filters():
+    """gene_filters.npz — the reference's own ``FilterGenes.__call__`` (filter.py:466-518) with ``FilterGenesPercentile`` /
+    ``FilterGenesTopK._get_preserve_mask`` (:583-586, :650-662) and ``FilterGenesCommon.__call__`` (:362-383) run as written on
+    stand-in Data objects: the (name-sorted) gene lists they hand to ``_inplace_subset_var``, the summaries and the columns they write."""
+    import logging
+    import types
+    from typing import Dict, Union
+
+    import pandas as pd
+    import scipy.sparse as sp_
+    rng = np.random.default_rng(22)
+    n, g = 60, 40
+    lam = rng.gamma(2.0, 3.0, g)    # expressed well enough that no two genes share a statistic (0/1 genes tie in var / mean exactly, and
+    x = rng.poisson(lam[None, :] * rng.uniform(0.4, 2.0, (n, 1))).astype(np.float32)   # the reference then decides by fp32 rounding noise)
+    x[:, 3] = 0
+    x[:30, 5] = 0          # gene 5: silent in the first half of the cells
+    x[30:, 9] = 0          # gene 9: silent in the second half
+    names = np.array([f"g{i}" for i in range(g)])   # sorted by name != sorted by number
+    out = {"gf_x": x, "gf_names": names}
+    call = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenes", "__call__", {"sp": sp_, "DevError": RuntimeError})
+    pct = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenesPercentile", "_get_preserve_mask")
+    topk = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenesTopK", "_get_preserve_mask")
+    log = logging.getLogger("reference")
+
+    def run(tag, rule, mode, whitelist=None, **rule_kw):
+        var = pd.DataFrame(index=pd.Index(names))
+        if whitelist is not None:
+            var["keep_me"] = np.isin(np.arange(g), whitelist)
+        got = {}
+        inner = types.SimpleNamespace(var=var, var_names=var.index, uns={}, _inplace_subset_var=lambda sel: got.update(sel=list(sel)))
+        data = types.SimpleNamespace(data=inner, shape=x.shape, get_feature=lambda **kw: x.copy())
+        me = types.SimpleNamespace(mode=mode, channel=None, channel_type=None, whitelist_indicators="keep_me" if whitelist is not None else None,
+                                   add_n_counts=True, add_n_cells=True, inplace=True, logger=log, **rule_kw)
+        me._get_preserve_mask = types.MethodType(rule, me)
+        call(me, data)
+        out[f"gf_{tag}_selected"] = np.array(got["sel"], dtype=str)
+        out[f"gf_{tag}_summary"] = np.asarray(inner.uns["gene_summary"], dtype=np.float64)
+        srt = np.sort(out[f"gf_{tag}_summary"])
+        assert (np.diff(srt) > 1e-4 * np.abs(srt[1:])).all(), (tag, "tied summaries: pick another seed")   # (gene 3 alone is silent)
+        out[f"gf_{tag}_n_counts"], out[f"gf_{tag}_n_cells"] = np.asarray(var["n_counts"], dtype=np.float64), np.asarray(var["n_cells"], dtype=np.int64)
+
+    for mode in ("sum", "var", "cv", "rv"):
+        run(f"pct_{mode}", pct, mode, min_val=10, max_val=90)
+        run(f"top_{mode}", topk, mode, num_genes=12, top=True)
+    run("pct_default", pct, "sum", min_val=1, max_val=99)
+    run("bottom_cv", topk, "cv", num_genes=7, top=False)
+    run("top_all", topk, "sum", num_genes=99, top=True)
+    run("pct_whitelist", pct, "sum", whitelist=[3, 17], min_val=10, max_val=90)
+
+    common = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenesCommon", "__call__", {"DevError": RuntimeError})
+    by_split = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenesCommon", "_select_by_splits",
+                                          {"Dict": Dict, "Union": Union, "ad": types.SimpleNamespace(AnnData=object)})
+    by_batch = ref_extract.extract_method("dance/transforms/filter.py", "FilterGenesCommon", "_select_by_batch",
+                                          {"Dict": Dict, "Union": Union, "ad": types.SimpleNamespace(AnnData=object)})
+
+    class Rows:  # the slice of AnnData the method touches: row selection by positions or by obs names, .X, .obs, .var_names
+        def __init__(self, mat, obs):
+            self.X, self.obs, self.var_names = mat, obs, pd.Index(names)
+            self.got = None
+
+        def __getitem__(self, idx):
+            pos = self.obs.index.get_indexer(idx) if len(idx) and isinstance(list(idx)[0], str) else np.asarray(list(idx))
+            return Rows(self.X[pos], self.obs.iloc[pos])
+
+        def _inplace_subset_var(self, sel):
+            self.got = list(sel)
+
+    obs = pd.DataFrame({"batch": np.r_[np.zeros(30, int), np.ones(20, int), np.full(10, 2)]}, index=[f"c{i}" for i in range(n)])
+    for tag, mat in (("dense", x), ("sparse", sp_.csr_matrix(x))):
+        for mode in ("batch", "split"):
+            inner = Rows(mat, obs)
+            splits = {"train": list(range(0, 30)), "test": list(range(30, 60)), "val": list(range(25, 35))}
+            data = types.SimpleNamespace(data=inner, get_split_idx=lambda k, error_on_miss=True: splits[k])
+            me = types.SimpleNamespace(batch_key="batch" if mode == "batch" else None, split_keys=["train", "test"] if mode == "split" else None, logger=log)
+            me._select_by_splits, me._select_by_batch = types.MethodType(by_split, me), types.MethodType(by_batch, me)
+            common(me, data)
+            out[f"gf_common_{mode}_{tag}"] = np.array(inner.got, dtype=str)
+    np.savez_compressed(os.path.join(HERE, "gene_filters.npz"), **out)
+    print("gene_filters.npz:", len(out), "arrays")
+
+
 def make_scheteronet_split():
     """scheteronet_split.npz — ``set_split`` (scheteronet.py:801-827) of the reference's training script run as written on a stand-in
     AnnData: which class becomes out-of-distribution, the index lists left in ``uns``, the columns written to ``obs``."""
@@ -935,3 +1016,4 @@ if __name__ == "__main__":
     make_wgc_alpha()
     make_small_transforms()
     make_scheteronet_split()
+    make_gene_filters()

@@ -28,6 +28,12 @@ PAIRS = [
     ("dance/transforms/filter.py", "HighlyVariableGenesLogarithmizedByMeanAndDisp", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "HighlyVariableGenesRawCount", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "FilterGenesMatch", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenesCommon", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenes", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenesPercentile", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenesTopK", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterGenesScanpyOrder", "dance_amd.transforms.filter"),
+    ("dance/transforms/filter.py", "FilterCellsScanpyOrder", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "FilterCellsType", "dance_amd.transforms.filter"),
     ("dance/transforms/normalize.py", "UpdateSizeFactors", "dance_amd.transforms.normalize"),
     ("dance/models/nn/gnn.py", "AdaptiveSAGE", "dance_amd.nn.gnn"),
@@ -104,6 +110,7 @@ EXTRA_PARAMS_OK = {
     ("HighlyVariableGenesLogarithmizedByTopGenes", "__init__"): {"device"},
     ("HighlyVariableGenesLogarithmizedByMeanAndDisp", "__init__"): {"device"},
     ("HighlyVariableGenesRawCount", "__init__"): {"device"},
+    ("FilterGenes", "__init__"): {"device"},
     ("CellPCA", "__init__"): {"device", "solver"},
 }
 

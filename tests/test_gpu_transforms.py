@@ -250,6 +250,11 @@ def test_filter_and_hvg_on_device(cuda_device):
     tft.check_filters("cuda")
 
 
+def test_gene_filters_on_device(cuda_device):
+    import test_gene_filters as tgf
+    tgf.check_gene_filters("cuda")
+
+
 def test_seurat_v3_hvg_on_device(cuda_device):
     import test_filter_transforms as tft
     tft.check_seurat_v3("cuda")
