@@ -939,6 +939,72 @@ def make_gene_filters():
     print("gene_filters.npz:", len(out), "arrays")
 
 
+def make_feature_feature_graph():
+    """feature_feature_graph.npz — ``FeatureFeatureGraph.__call__`` (feature_feature_graph.py:44-87) run as written, with scipy's
+    ``spearmanr`` / ``coo_matrix``, the reference's ``dist_to_rbf`` and a recording stand-in for ``dgl.graph`` /
+    ``dgl.nn.EdgeWeightNorm`` (norm="both" on positive weights: w / sqrt(weighted out-degree(src) * weighted in-degree(dst))
+    [3P-memory: dgl 1.1.3]): the edge list in the reference's order and the edge weights."""
+    import types
+
+    from scipy.sparse import coo_matrix
+    from scipy.stats import spearmanr
+    rng = np.random.default_rng(31)
+    n, g = 90, 36
+    base = rng.normal(size=(n, 6))
+    x = (base @ rng.normal(size=(6, g)) + 0.8 * rng.normal(size=(n, g))).astype(np.float32)
+    x[:, 4] = -x[:, 2] + 0.1 * rng.normal(size=n).astype(np.float32)     # a strongly negative pair
+    x[:, 7] = np.round(x[:, 7])                                           # ties for the rank correlation
+    out = {"ffg_x": x}
+
+    class Graph:
+        def __init__(self, edges, num_nodes):
+            self.src, self.dst, self.n = edges[0].long(), edges[1].long(), num_nodes
+            self.ndata, self.edata = {}, {}
+
+        def num_edges(self):
+            return len(self.src)
+
+    def edge_weight_norm():
+        def norm(graph, w):
+            out_deg = torch.zeros(graph.n).index_add_(0, graph.src, w)
+            in_deg = torch.zeros(graph.n).index_add_(0, graph.dst, w)
+            return out_deg[graph.src].pow(-0.5) * in_deg[graph.dst].pow(-0.5) * w
+        return norm
+
+    dist_to_rbf = ref_extract.extract("dance/utils/matrix.py", "dist_to_rbf")
+    call = ref_extract.extract_method("dance/transforms/graph/feature_feature_graph.py", "FeatureFeatureGraph", "__call__", {
+        "spearmanr": spearmanr, "coo_matrix": coo_matrix, "dist_to_rbf": dist_to_rbf, "dgl": types.SimpleNamespace(graph=Graph),
+        "dglnn": types.SimpleNamespace(EdgeWeightNorm=edge_weight_norm)})
+    cases = {"pearson": dict(threshold=0.3, positive_only=False, score_func="pearson", kw={}),
+             "pearson_pos": dict(threshold=0.45, positive_only=True, score_func="pearson", kw={}),
+             "pearson_raw": dict(threshold=0.3, positive_only=False, score_func="pearson", kw={}, normalize_edges=False),
+             "spearman": dict(threshold=0.3, positive_only=False, score_func="spearman", kw={}),
+             "rbf": dict(threshold=0.3, positive_only=False, score_func="rbf", kw={}),
+             "rbf_ind": dict(threshold=0.35, positive_only=False, score_func="rbf", kw=dict(scale_mode="ind_med_dist", denom_scale=0.8)),
+             "rbf_scale": dict(threshold=0.2, positive_only=False, score_func="rbf", kw=dict(scale_mode="scale", denom_scale=9.0))}
+    for tag, c in cases.items():
+        inner = types.SimpleNamespace(uns={})
+        data = types.SimpleNamespace(data=inner, get_feature=lambda return_type="numpy": x.copy())
+        me = types.SimpleNamespace(threshold=c["threshold"], positive_only=c["positive_only"], normalize_edges=c.get("normalize_edges", True),
+                                   score_func=c["score_func"], score_func_kwargs=c["kw"], out="FeatureFeatureGraph")
+        call(me, data)
+        gr = inner.uns["FeatureFeatureGraph"]
+        out[f"ffg_{tag}_src"], out[f"ffg_{tag}_dst"] = gr.src.numpy().astype(np.int32), gr.dst.numpy().astype(np.int32)
+        out[f"ffg_{tag}_weight"] = gr.edata["weight"].numpy()
+        assert np.array_equal(gr.ndata["feat"].numpy(), x.T)
+        # the similarity nearest to the threshold, for the record: fp32-vs-fp64 rounding must not be able to move an edge
+        if c["score_func"] == "pearson":
+            s_ = np.abs(np.corrcoef(x.T))
+        elif c["score_func"] == "spearman":
+            s_ = np.abs(spearmanr(x, axis=0)[0])
+        else:
+            s_ = None
+        if s_ is not None:
+            assert np.abs(s_ - c["threshold"]).min() > 1e-4, (tag, np.abs(s_ - c["threshold"]).min())
+    np.savez_compressed(os.path.join(HERE, "feature_feature_graph.npz"), **out)
+    print("feature_feature_graph.npz:", len(out), "arrays;", {k: len(out[f"ffg_{k}_src"]) for k in cases})
+
+
 def make_scheteronet_split():
     """scheteronet_split.npz — ``set_split`` (scheteronet.py:801-827) of the reference's training script run as written on a stand-in
     AnnData: which class becomes out-of-distribution, the index lists left in ``uns``, the columns written to ``obs``."""
@@ -1017,3 +1083,4 @@ if __name__ == "__main__":
     make_small_transforms()
     make_scheteronet_split()
     make_gene_filters()
+    make_feature_feature_graph()

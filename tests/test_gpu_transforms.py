@@ -250,6 +250,11 @@ def test_filter_and_hvg_on_device(cuda_device):
     tft.check_filters("cuda")
 
 
+def test_feature_feature_graph_on_device(cuda_device):
+    import test_feature_feature_graph as tffg
+    tffg.check_feature_feature_graph("cuda")
+
+
 def test_gene_filters_on_device(cuda_device):
     import test_gene_filters as tgf
     tgf.check_gene_filters("cuda")
