@@ -1,6 +1,6 @@
 """Method protocol (mirrors dance/modules/base.py:17-199): preprocessing_pipeline / fit / predict / predict_proba /
-score / fit_predict / fit_score, default metrics ``acc`` (classification, dance/utils/metrics.py:33-58) and ``ari``
-(clustering, :61-70)."""
+score / fit_predict / fit_score, default metrics ``acc`` (classification, dance/utils/metrics.py:33-58), ``ari``
+(clustering, :61-70) and ``mse`` (regression, :71-80)."""
 from abc import ABC, abstractmethod
 from typing import Any, Mapping, Optional, Tuple, Union
 
@@ -22,7 +22,14 @@ def _ari(true, pred) -> float:
     return float(adjusted_rand_score(np.asarray(true).ravel(), np.asarray(pred).ravel()))
 
 
-_METRICS = {"acc": _acc, "ari": _ari}
+def _mse(true, pred) -> float:
+    """utils/metrics.py:71-80 (``sklearn.metrics.mean_squared_error``)."""
+    true = true.cpu().numpy() if isinstance(true, torch.Tensor) else np.asarray(true)
+    pred = pred.cpu().numpy() if isinstance(pred, torch.Tensor) else np.asarray(pred)
+    return float(np.mean((true.astype(np.float64) - pred.astype(np.float64))**2))
+
+
+_METRICS = {"acc": _acc, "ari": _ari, "mse": _mse}
 
 
 def resolve_score_func(score_func):
@@ -158,6 +165,11 @@ class TorchNNPretrain(BasePretrain, ABC):
 
 class BaseClassificationMethod(BaseMethod):
     _DEFAULT_METRIC = "acc"
+
+
+class BaseRegressionMethod(BaseMethod):
+
+    _DEFAULT_METRIC = "mse"
 
 
 class BaseClusteringMethod(BaseMethod):

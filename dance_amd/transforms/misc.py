@@ -1,4 +1,4 @@
-"""Compose / SetConfig (contract of dance/transforms/misc.py:15-151)."""
+"""Compose / SetConfig / SaveRaw / UpdateRaw / RemoveSplit (contract of dance/transforms/misc.py:15-190)."""
 from .base import BaseTransform
 from ..registry import register_preprocessor
 
@@ -70,3 +70,43 @@ class SaveRaw(BaseTransform):
         x = DeviceArray(x.tensor.clone()) if isinstance(x, DeviceArray) else copy.deepcopy(x)
         data.data.raw = types.SimpleNamespace(X=x, var=data.data.var.copy(), shape=tuple(x.shape))
         return data
+
+
+@register_preprocessor("misc")
+class UpdateRaw(BaseTransform):
+    """Cut ``data.data.raw`` down to the genes the matrix has now, in their order (dance/transforms/misc.py:154-174) — after a gene
+    filter that ran past ``SaveRaw``.  A ``DeviceArray`` raw matrix is subset on the device."""
+
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+
+    def __call__(self, data):
+        import types
+
+        from ..data import AnnDataLite
+        raw = getattr(data.data, "raw", None)
+        if raw is None:
+            raise AttributeError(f"Raw data attribute doesn't exist \n{data}"
+                                 f"If you wish to update raw, save raw first.")
+        self.logger.warning("RawData will change.")
+        pos = raw.var.index.get_indexer(data.data.var_names)
+        if (pos < 0).any():
+            raise KeyError("some genes of the current matrix are not in .raw")
+        x = AnnDataLite._take(raw.X, pos, 1)
+        data.data.raw = types.SimpleNamespace(X=x, var=raw.var.iloc[pos], shape=tuple(x.shape))
+        return data
+
+
+@register_preprocessor("misc")
+class RemoveSplit(BaseTransform):
+    """Drop the cells of one split (dance/transforms/misc.py:177-190)."""
+
+    _DISPLAY_ATTRS = ("split_name", )
+
+    def __init__(self, *, split_name: str, **kwargs):
+        super().__init__(**kwargs)
+        self.split_name = split_name
+
+    def __call__(self, data):
+        self.logger.info(f"Popping split: {self.split_name!r}")
+        data.pop(split_name=self.split_name)

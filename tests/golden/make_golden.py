@@ -1005,6 +1005,130 @@ def make_feature_feature_graph():
     print("feature_feature_graph.npz:", len(out), "arrays;", {k: len(out[f"ffg_{k}_src"]) for k in cases})
 
 
+def make_graphsci():
+    """graphsci.npz — the reference's whole ``GraphSCI`` class (graphsci.py:126-560) with its own ``AEModel`` / ``GNNModel``, lifted
+    from /root/reference (dgl.nn.GraphConv and the DGL graph as the stubs of oracle/ref_extract.py, no file writes) and run on torch-CPU
+    with dropout 0: ``get_loss`` on given tensors, three epochs of ``fit`` (masked), ``predict`` and the three scores; plus
+    ``CellwiseMaskData.__call__`` (mask.py:152-290) as written, for both distributions and both mask layouts."""
+    import logging
+    import types
+    from pathlib import Path
+
+    from scipy.sparse import csr_matrix, spmatrix
+    from scipy.stats import expon
+    path = "dance/modules/single_modality/imputation/graphsci.py"
+    rng = np.random.default_rng(41)
+    out = {}
+    # ---- CellwiseMaskData -----------------------------------------------------------------------------------------------------------
+    n, g = 40, 24
+    counts = (rng.random((n, g)) < 0.45) * rng.integers(1, 30, (n, g))
+    counts[3] = 0
+    counts[4, 5:] = 0            # a cell with at most min_gene_counts expressed genes
+    counts = counts.astype(np.float32)
+    out["gs_counts"] = counts
+    call = ref_extract.extract_method("dance/transforms/mask.py", "CellwiseMaskData", "__call__", {"spmatrix": spmatrix})
+    probs = ref_extract.extract_method("dance/transforms/mask.py", "CellwiseMaskData", "_get_probs", {"expon": expon})
+    for tag, distr, rate, test in (("exp_t", "exp", 0.3, True), ("uni_t", "uniform", 0.25, True), ("exp_v", "exp", 0.1, False), ("all", "uniform", 1.0, True)):
+        inner = types.SimpleNamespace(layers={})
+        data = types.SimpleNamespace(data=inner, get_feature=lambda return_type="sparse": csr_matrix(counts))
+        me = types.SimpleNamespace(distr=distr, mask_rate=rate, seed=7, min_gene_counts=5, add_test_mask=test, logger=logging.getLogger("reference"))
+        me._get_probs = types.MethodType(probs, me)
+        call(me, data)
+        for k in ("train_mask", "valid_mask", "test_mask"):
+            out[f"gs_mask_{tag}_{k}"] = inner.layers[k]
+    # ---- the model ------------------------------------------------------------------------------------------------------------------
+    ns = {"dglnn": types.SimpleNamespace(GraphConv=ref_extract.dgl_graphconv_stub())}
+    GNNModel = ref_extract.extract(path, "GNNModel", ns)
+    build = ref_extract.extract(path, "buildNetwork")
+    Disp, Mean = ref_extract.extract(path, "DispActivation"), ref_extract.extract(path, "MeanActivation")
+    Mul = ref_extract.extract(path, "MultiplyLayer")
+    AE = ref_extract.extract(path, "AEModel", {"MultiplyLayer": Mul, "buildNetwork": build, "DispActivation": Disp, "MeanActivation": Mean})
+
+    class NoDisk:
+        """``Path().resolve() / "graphsci"`` that exists already, so the constructor writes nothing."""
+        def __call__(self):
+            return self
+
+        def resolve(self):
+            return self
+
+        def __truediv__(self, other):
+            return self
+
+        def exists(self):
+            return True
+
+    GraphSCI = ref_extract.extract(path, "GraphSCI", {"BaseRegressionMethod": object, "Path": NoDisk(), "GNNModel": GNNModel, "AEModel": AE,
+                                                      "LogLevel": str})
+    GraphSCI.save_model = lambda self: None
+    n, g = 30, 12
+    lam = rng.gamma(2.0, 1.5, g)
+    raw = rng.poisson(lam[None, :] * rng.uniform(0.5, 2.0, (n, 1))).astype(np.float32)
+    raw[np.arange(n), rng.integers(0, g, n)] += 1
+    x = np.log1p(raw)
+    corr = np.corrcoef(x.T)
+    adj = (np.abs(corr) >= 0.12).astype(np.float32)
+    src, dst = np.nonzero(adj)
+    deg = adj.sum(1)
+    w = (1.0 / np.sqrt(deg[src] * deg[dst])).astype(np.float32)
+    mask = rng.random((n, g)) < 0.85
+    out.update(gs_x=x, gs_raw=raw, gs_src=src.astype(np.int32), gs_dst=dst.astype(np.int32), gs_w=w, gs_mask=mask)
+
+    class Graph(ref_extract.DGLStubGraph):
+        def num_nodes(self):
+            return self.number_of_nodes()
+
+        def num_edges(self):
+            return len(self._src)
+
+    def graph():
+        gr = Graph(src, dst, num_src=g, num_dst=None)
+        gr.ndata["feat"] = torch.from_numpy(x.T.copy())
+        gr.edata["weight"] = torch.from_numpy(w)
+        return gr
+
+    torch.manual_seed(42)
+    model = GraphSCI(num_cells=n, num_genes=g, dataset="golden", dropout=0.0, gpu=-1, seed=3)
+    for k, v in model.state_dict().items():
+        out[f"gs_sd::{k}"] = v.numpy().copy()
+    xt, rt = torch.from_numpy(x), torch.from_numpy(raw)
+    x_train, raw_train = xt * torch.from_numpy(mask), rt * torch.from_numpy(mask)
+    # get_loss on fixed tensors
+    model.size_factors = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32))
+    t = lambda *shape, pos=False: torch.from_numpy((rng.random(shape) + 0.05 if pos else rng.standard_normal(shape)).astype(np.float32))
+    args = dict(z_adj=t(g, g), z_adj_log_std=t(g, g) * 0.1, z_adj_mean=t(g, g), z_exp=t(n, g, pos=True), mean=t(n, g, pos=True), disp=t(n, g, pos=True),
+                pi=t(n, g, pos=True) * 0.9)
+    out["gs_loss_sf"] = model.size_factors.numpy()
+    for k, v in args.items():
+        out[f"gs_loss_in_{k}"] = v.numpy()
+    losses = model.get_loss(rt, torch.from_numpy(adj), mask=mask, le=1.0, la=0.7, ke=2.0, ka=0.5, **args)
+    out["gs_loss_out"] = np.array([float(v) for v in losses])
+    # three epochs of fit, predict, scores
+    torch.manual_seed(43)
+    gr = graph()
+    log = []
+    orig_train = GraphSCI.train
+
+    def train(self, *a, **k):
+        r = orig_train(self, *a, **k)
+        log.append([self.train_loss, self.loss_adj, self.loss_exp, self.kl, self.valid_loss])
+        return r
+
+    GraphSCI.train = train
+    model.fit(x_train, raw_train, gr, mask, le=1, la=1e-2, ke=1e2, ka=1, n_epochs=3, lr=1e-3, weight_decay=1e-6, train_idx=list(range(n - 4)))
+    out["gs_fit_log"] = np.array(log)
+    out["gs_fit_size_factors"] = model.size_factors.numpy()
+    for k, v in model.state_dict().items():
+        out[f"gs_fit_sd::{k}"] = v.numpy().copy()
+    torch.manual_seed(44)
+    imputed = model.predict(x_train, raw_train, gr, mask)
+    out["gs_pred"] = imputed.numpy()
+    out["gs_scores"] = np.array([model.score(xt, imputed.clone(), ~mask, m, log1p=False) for m in ("RMSE", "PCC", "MRE")] +
+                                [model.score(xt, imputed.clone(), ~mask, "RMSE", log1p=True, test_idx=list(range(n - 4, n)))])
+    np.savez_compressed(os.path.join(HERE, "graphsci.npz"), **out)
+    print("graphsci.npz:", len(out), "arrays; fit log", np.array(log)[:, 0])
+
+
 def make_scheteronet_split():
     """scheteronet_split.npz — ``set_split`` (scheteronet.py:801-827) of the reference's training script run as written on a stand-in
     AnnData: which class becomes out-of-distribution, the index lists left in ``uns``, the columns written to ``obs``."""
@@ -1084,3 +1208,4 @@ if __name__ == "__main__":
     make_scheteronet_split()
     make_gene_filters()
     make_feature_feature_graph()
+    make_graphsci()

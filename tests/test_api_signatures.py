@@ -37,6 +37,13 @@ PAIRS = [
     ("dance/transforms/filter.py", "FilterCellsScanpyOrder", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "FilterCellsType", "dance_amd.transforms.filter"),
     ("dance/transforms/normalize.py", "UpdateSizeFactors", "dance_amd.transforms.normalize"),
+    ("dance/transforms/misc.py", "UpdateRaw", "dance_amd.transforms.misc"),
+    ("dance/transforms/misc.py", "RemoveSplit", "dance_amd.transforms.misc"),
+    ("dance/transforms/mask.py", "CellwiseMaskData", "dance_amd.transforms.mask"),
+    ("dance/modules/single_modality/imputation/graphsci.py", "GraphSCI", "dance_amd.modules.single_modality.imputation.graphsci"),
+    ("dance/modules/single_modality/imputation/graphsci.py", "AEModel", "dance_amd.modules.single_modality.imputation.graphsci"),
+    ("dance/modules/single_modality/imputation/graphsci.py", "MultiplyLayer", "dance_amd.modules.single_modality.imputation.graphsci"),
+    ("dance/modules/single_modality/imputation/graphsci.py", "GNNModel", "dance_amd.modules.single_modality.imputation.graphsci"),
     ("dance/models/nn/gnn.py", "AdaptiveSAGE", "dance_amd.nn.gnn"),
     ("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "GNN", "dance_amd.modules.single_modality.cell_type_annotation.scdeepsort"),
     ("dance/modules/single_modality/cell_type_annotation/scdeepsort.py", "ScDeepSort", "dance_amd.modules.single_modality.cell_type_annotation.scdeepsort"),
@@ -99,7 +106,8 @@ EXTRA_PARAMS_OK = {
     ("ScTAG", "__init__"): {"adj_dim"},                       # scalable adjacency decoder width (default None = the reference's N)
     ("ScTAG", "init_model"): set(),
     ("GCNAE", "forward"): {"decode"},                         # fused decoder loss path skips the B x B logits (default: build them)
-    ("GC_DEC", "__init__"): {"device"},                       # where the parameters live (the reference is CPU-only)
+    ("GC_DEC", "__init__"): {"device"},
+    ("GraphSCI", "__init__"): {"device"},                     # where the model lives; the reference's gpu=-1 (CPU) has no counterpart here                       # where the parameters live (the reference is CPU-only)
     ("NeighborGraph", "__init__"): {"device", "reorder"},
     ("HeteronetGraph", "__init__"): {"device"},
     ("FeatureFeatureGraph", "__init__"): {"device"},
