@@ -37,6 +37,7 @@ PAIRS = [
     ("dance/transforms/filter.py", "FilterCellsScanpyOrder", "dance_amd.transforms.filter"),
     ("dance/transforms/filter.py", "FilterCellsType", "dance_amd.transforms.filter"),
     ("dance/transforms/normalize.py", "UpdateSizeFactors", "dance_amd.transforms.normalize"),
+    ("dance/transforms/interface.py", "AnnDataTransform", "dance_amd.transforms.interface"),
     ("dance/transforms/misc.py", "UpdateRaw", "dance_amd.transforms.misc"),
     ("dance/transforms/misc.py", "RemoveSplit", "dance_amd.transforms.misc"),
     ("dance/transforms/mask.py", "CellwiseMaskData", "dance_amd.transforms.mask"),

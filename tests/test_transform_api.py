@@ -168,3 +168,29 @@ def test_randomized_pca_host_logic_matches_sklearn():
         pca_scores_randomized(torch.zeros(5, 4), 5, 0, ops=cpu_ops)
     with pytest.raises(TypeError):
         pca_scores_randomized(torch.zeros(5, 4, dtype=torch.float64), 2, 0, ops=cpu_ops)
+
+
+def _scale_in_place(adata, factor=1.0):
+    adata.X = adata.X * factor
+
+
+def test_anndata_transform_interface():
+    """The cases of the reference's tests/transforms/test_interface.py:22-50 with a local in-place function in scanpy's place:
+    a callable and its dotted path do the same thing; a module is not callable; an unknown attribute does not resolve."""
+    from dance_amd.transforms import AnnDataTransform, Compose
+    x = np.random.default_rng(123).random((5, 3)).astype(np.float32)
+    a, b = Data(AnnDataLite(x.copy())), Data(AnnDataLite(x.copy()))
+    AnnDataTransform(_scale_in_place, factor=100)(a)
+    AnnDataTransform("test_transform_api._scale_in_place", factor=100)(b)
+    assert a.data.X.tolist() == b.data.X.tolist() == (x * 100).tolist()
+    t = AnnDataTransform("numpy.log1p")
+    assert repr(t) == "AnnDataTransform(func=numpy.log1p, func_kwargs={})"
+    with pytest.raises(TypeError):
+        AnnDataTransform(np)
+    with pytest.raises(TypeError):
+        AnnDataTransform("numpy.linalg")
+    with pytest.raises(AttributeError):
+        AnnDataTransform("numpy.dosenot_exist")
+    Compose(AnnDataTransform(_scale_in_place, factor=0.5), AnnDataTransform(_scale_in_place, factor=4))(a)
+    assert np.allclose(a.data.X, x * 200)
+    assert resolve_from_registry("AnnDataTransform", "preprocessor.interface") is AnnDataTransform
