@@ -269,9 +269,12 @@ def test_graphsc_golden_regenerates_from_reference(tmp_path, monkeypatch):
             assert np.array_equal(new[k], old[k]), k
 
 
-@pytest.mark.parametrize("maker,fname", [("make_scheteronet", "scheteronet.npz"), ("make_scdsc_fit", "scdsc_fit.npz"), ("make_sctag", "sctag.npz"), ("make_stagate", "stagate.npz"), ("make_free_riders", "free_riders.npz")])
+@pytest.mark.parametrize("maker,fname", [("make_scheteronet", "scheteronet.npz"), ("make_scdsc_fit", "scdsc_fit.npz"), ("make_sctag", "sctag.npz"), ("make_stagate", "stagate.npz"), ("make_free_riders", "free_riders.npz"),
+                                         ("make_gc_dec", "gc_dec.npz"), ("make_wgc_alpha", "wgc_alpha.npz"), ("make_small_transforms", "small_transforms.npz"),
+                                         ("make_scheteronet_split", "scheteronet_split.npz"), ("make_gene_filters", "gene_filters.npz"),
+                                         ("make_feature_feature_graph", "feature_feature_graph.npz"), ("make_graphsci", "graphsci.npz")])
 def test_model_goldens_regenerate_from_reference(tmp_path, monkeypatch, maker, fname):
-    """scheteronet.npz / scdsc_fit.npz are what the reference's own classes produce NOW (build container only)."""
+    """Every model / transform golden is what the reference's own code produces NOW (build container only)."""
     import importlib.util
     import os
 
@@ -288,6 +291,6 @@ def test_model_goldens_regenerate_from_reference(tmp_path, monkeypatch, maker, f
     assert sorted(new.files) == sorted(old.files)
     for k in old.files:
         if old[k].dtype.kind in "fc":
-            assert np.allclose(new[k], old[k], rtol=1e-4, atol=1e-5), k
+            assert np.allclose(new[k], old[k], rtol=1e-4, atol=1e-5, equal_nan=True), k
         else:
             assert np.array_equal(new[k], old[k]), k
