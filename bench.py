@@ -300,8 +300,8 @@ def main():
                 failed[mode] = err or "failed on another rank"
                 runs.pop(mode, None)
         if len(modes) > 1:
-            runs[mode]["sg"] = None
-            sg_keep = None
+            if mode in runs:  # (a failed mode has no entry)
+                runs[mode]["sg"] = None
             del sg
             torch.cuda.empty_cache()
     if not runs:
