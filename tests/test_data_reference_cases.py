@@ -41,7 +41,7 @@ def test_basic():
     assert d.train_idx == [0] and d.get_split_idx("ref") == [0,1] and d.get_split_idx("inf") == [2]
     for bad in ((0,1,2), [0,1], ("0","1")):
         with pytest.raises(TypeError):
-        Data(mk(), split_index_range_dict={"train": bad})
+            Data(mk(), split_index_range_dict={"train": bad})
     d = Data(mk(), full_split_name="inference")
     assert d.train_idx is None and d.get_split_idx("inference") == [0,1,2]
 
