@@ -518,24 +518,71 @@ def seurat_v3_hvg(x: torch.Tensor, *, n_top_genes: int, span: float = 0.3):
     return hv, mean_np, var_np, norm_var, rank
 
 
+def dispersion_hvg_batched(x: torch.Tensor, batches, names, *, flavor: str, base: Optional[float], n_bins: int, **rule):
+    """scanpy's ``batch_key`` mode of the dispersion flavours [3P-memory: scanpy 1.10.1 _highly_variable_genes_batched]: the
+    single-batch selection inside every batch over the genes expressed there (the others count as zeros), then per gene the mean of
+    the statistics over the batches and the number of batches that selected it; with ``n_top_genes`` the genes are ranked by that
+    number, ties by the averaged normalised dispersion (then by name), otherwise the cut-offs apply to the averages.  Per-batch
+    statistics are device reductions over the batch's rows.  Returns a dict of the ``.var`` columns scanpy writes."""
+    import pandas as pd
+    g = x.shape[1]
+    cats = pd.Categorical(np.asarray(batches))
+    stats = {k: [] for k in ("means", "dispersions", "dispersions_norm", "highly_variable")}
+    for code in range(len(cats.categories)):
+        rows = torch.as_tensor(np.flatnonzero(cats.codes == code), device=x.device)
+        xb = x.index_select(0, rows)
+        expressed = ((xb > 0).sum(0) >= 1).cpu().numpy()
+        cols = torch.as_tensor(np.flatnonzero(expressed), device=x.device)
+        mean, var = gene_mean_var(xb.index_select(1, cols), undo_log=flavor == "seurat", base=base)
+        hv, means, disp, norm = dispersion_hvg(mean, var, flavor=flavor, n_bins=n_bins, **rule)
+        for key, val in (("means", means), ("dispersions", disp), ("dispersions_norm", norm), ("highly_variable", hv)):
+            full = np.zeros(g, dtype=np.float64)
+            full[expressed] = val
+            stats[key].append(full)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)  # a gene whose statistic is NaN in every batch stays NaN
+        out = {k: np.nanmean(np.stack(stats[k]), 0) for k in ("means", "dispersions", "dispersions_norm")}
+    nb = np.stack(stats["highly_variable"]).sum(0).astype(np.int64)
+    out["highly_variable_nbatches"] = nb
+    out["highly_variable_intersection"] = nb == len(cats.categories)
+    norm = out["dispersions_norm"]
+    if rule.get("n_top_genes") is not None:
+        by_name = np.argsort(np.asarray(names, dtype=str), kind="stable")            # the order the per-gene aggregation leaves
+        key_norm = np.where(np.isnan(norm[by_name]), -np.inf, norm[by_name])        # NaN last
+        ranked = by_name[np.lexsort((-key_norm, -nb[by_name]))]
+        hv = np.zeros(g, dtype=bool)
+        hv[ranked[:int(rule["n_top_genes"])]] = True
+    else:
+        z = np.nan_to_num(norm)
+        out["dispersions_norm"] = z
+        hv = np.logical_and.reduce((out["means"] > rule["min_mean"], out["means"] < rule["max_mean"], z > rule["min_disp"], z < rule["max_disp"]))
+    out["highly_variable"] = hv
+    return out
+
+
 class _HVGBase(BaseTransform):
 
     def __init__(self, channel, channel_type, subset, inplace, batch_key, device, **kwargs):
         super().__init__(**kwargs)
-        if batch_key is not None:
-            raise NotImplementedError("batch_key (per-batch selection and merging) is not implemented on the device path")
         self.channel, self.channel_type, self.subset, self.inplace, self.device = channel, channel_type, subset, inplace, device
+        self.batch_key = batch_key
         self.logger.info("Expects logarithmized data")
 
     def _select(self, data, **rule):
         kw = dict(channel=self.channel, channel_type=self.channel_type) if self.channel_type == "layers" else dict(channel_type="X")
         x = data.get_feature(return_type=self.device, **kw)
         base = data.data.uns.get("log1p", {}).get("base") if isinstance(data.data.uns.get("log1p"), dict) else None
-        mean, var = gene_mean_var(x, undo_log=self.flavor == "seurat", base=base)
-        hv, means, disp, norm = dispersion_hvg(mean, var, flavor=self.flavor, n_bins=self.n_bins, **rule)
+        if self.batch_key is not None:
+            cols = dispersion_hvg_batched(x, data.data.obs[self.batch_key].values, data.data.var_names, flavor=self.flavor, base=base,
+                                          n_bins=self.n_bins, **rule)
+            hv = cols["highly_variable"]
+        else:
+            mean, var = gene_mean_var(x, undo_log=self.flavor == "seurat", base=base)
+            hv, means, disp, norm = dispersion_hvg(mean, var, flavor=self.flavor, n_bins=self.n_bins, **rule)
+            cols = dict(highly_variable=hv, means=means, dispersions=disp, dispersions_norm=norm)
         if self.inplace:
-            v = data.data.var
-            v["highly_variable"], v["means"], v["dispersions"], v["dispersions_norm"] = hv, means, disp, norm
+            for key, val in cols.items():
+                data.data.var[key] = val
             data.data.uns["hvg"] = {"flavor": self.flavor}
         if self.subset:
             data.data._inplace_subset_var(hv)

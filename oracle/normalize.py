@@ -158,3 +158,42 @@ def highly_variable_genes_seurat_v3(X, n_top_genes=1000, span=0.3):
     hv = rank < n_top_genes
     rank[~hv] = np.nan
     return hv, mean, var, norm_var, rank
+
+
+def highly_variable_genes_batched(X, batch, names, flavor="seurat", n_top_genes=None, n_bins=20, min_mean=0.0125, max_mean=3, min_disp=0.5,
+                                  max_disp=np.inf):
+    """scanpy.pp.highly_variable_genes(batch_key=...) for the dispersion flavours [3P-memory, scanpy 1.10.1
+    _highly_variable_genes_batched], written gene by gene: every batch runs the single-batch rule on the genes it expresses, a gene it
+    does not express contributes zeros; per gene the batch values are averaged (NaN skipped) and the selections counted.  Ranking for
+    ``n_top_genes``: more batches first, then larger mean normalised dispersion (NaN last), then the gene name."""
+    X = np.asarray(X)
+    batch = np.asarray(batch)
+    g = X.shape[1]
+    per_batch = []
+    for b in sorted(set(batch.tolist())):
+        xb = X[batch == b]
+        expressed = (xb > 0).sum(0) >= 1
+        hv, mean, disp, norm = highly_variable_genes(xb[:, expressed], flavor=flavor, n_top_genes=n_top_genes, n_bins=n_bins, min_mean=min_mean,
+                                                     max_mean=max_mean, min_disp=min_disp, max_disp=max_disp)
+        rows = np.zeros((4, g))
+        rows[:, expressed] = np.stack([mean, disp, norm.astype(np.float64), hv.astype(np.float64)])
+        per_batch.append(rows)
+    per_batch = np.stack(per_batch)                       # batches x 4 x genes
+    out = {}
+    for i, key in enumerate(("means", "dispersions", "dispersions_norm")):
+        vals = per_batch[:, i]
+        out[key] = np.array([np.mean(v[~np.isnan(v)]) if (~np.isnan(v)).any() else np.nan for v in vals.T])
+    nb = per_batch[:, 3].sum(0).astype(np.int64)
+    out["highly_variable_nbatches"] = nb
+    out["highly_variable_intersection"] = nb == per_batch.shape[0]
+    if n_top_genes is not None:
+        order = sorted(range(g), key=lambda j: (-nb[j], np.isnan(out["dispersions_norm"][j]),
+                                                -out["dispersions_norm"][j] if not np.isnan(out["dispersions_norm"][j]) else 0.0, str(names[j])))
+        hv = np.zeros(g, dtype=bool)
+        hv[order[:n_top_genes]] = True
+    else:
+        z = np.nan_to_num(out["dispersions_norm"])
+        out["dispersions_norm"] = z
+        hv = (out["means"] > min_mean) & (out["means"] < max_mean) & (z > min_disp) & (z < max_disp)
+    out["highly_variable"] = hv
+    return out

@@ -77,6 +77,50 @@ def test_filter_and_hvg_on_cpu_tensors():
     check_filters("cpu")
 
 
+def check_hvg_batches(device):
+    """``batch_key``: per-batch selection merged as scanpy does, against the gene-by-gene restatement; two copies of one batch must
+    give the single-batch answer with every selected gene counted twice."""
+    import pandas as pd
+    from dance_amd.data import AnnDataLite, Data, DeviceArray
+    from dance_amd.transforms.filter import HighlyVariableGenesLogarithmizedByMeanAndDisp, HighlyVariableGenesLogarithmizedByTopGenes
+    x = _counts(360, 90, 7)
+    x[:120, 10:14] = 0                                   # genes a batch does not express at all
+    xl = np.log1p(on.normalize_total(x[np.arange(360) != 5][:, 3:], 1e4))
+    batch = np.r_[np.zeros(119, int), np.ones(140, int), np.full(100, 2)]
+    names = [f"g{i}" for i in range(xl.shape[1])]
+    for flavor in ("seurat", "cell_ranger"):
+        for rule in (dict(n_top_genes=25), dict(min_mean=0.05, max_mean=4, min_disp=0.3)):
+            d = Data(AnnDataLite(DeviceArray(torch.from_numpy(xl.copy()).to(device)), obs=pd.DataFrame({"batch": batch}, index=[str(i) for i in range(len(xl))]),
+                                 var=pd.DataFrame(index=names)))
+            cls = HighlyVariableGenesLogarithmizedByTopGenes if "n_top_genes" in rule else HighlyVariableGenesLogarithmizedByMeanAndDisp
+            cls(flavor=flavor, subset=False, batch_key="batch", device=device, **rule)(d)
+            want = on.highly_variable_genes_batched(xl, batch, names, flavor=flavor, **rule)
+            v = d.data.var
+            assert np.array_equal(v["highly_variable_nbatches"].values, want["highly_variable_nbatches"]), (flavor, rule)
+            assert np.array_equal(v["highly_variable_intersection"].values, want["highly_variable_intersection"])
+            assert np.allclose(v["means"].values, want["means"], rtol=1e-5, atol=1e-9) and np.allclose(v["dispersions"].values, want["dispersions"], rtol=1e-4, equal_nan=True)
+            assert np.allclose(v["dispersions_norm"].values, want["dispersions_norm"], rtol=2e-3, atol=2e-4, equal_nan=True)
+            assert (v["highly_variable"].values == want["highly_variable"]).mean() >= 0.98, (flavor, rule)
+            if "n_top_genes" in rule:
+                assert int(v["highly_variable"].sum()) == 25
+    # one batch written twice == no batches (over genes expressed somewhere: the batch mode drops a batch's silent genes first)
+    xl = xl[:, (xl > 0).any(0)]
+    names = names[:xl.shape[1]]
+    one = Data(AnnDataLite(DeviceArray(torch.from_numpy(xl.copy()).to(device)), var=pd.DataFrame(index=names)))
+    HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=20, subset=False, device=device)(one)
+    two = Data(AnnDataLite(DeviceArray(torch.from_numpy(np.concatenate([xl, xl])).to(device)), var=pd.DataFrame(index=names),
+                           obs=pd.DataFrame({"b": ["p"] * len(xl) + ["q"] * len(xl)}, index=[str(i) for i in range(2 * len(xl))])))
+    HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=20, subset=False, batch_key="b", device=device)(two)
+    sel = one.data.var["highly_variable"].values
+    assert np.array_equal(two.data.var["highly_variable_nbatches"].values, 2 * sel.astype(int))
+    assert np.allclose(two.data.var["dispersions_norm"].values, one.data.var["dispersions_norm"].values, equal_nan=True)
+    assert set(np.flatnonzero(two.data.var["highly_variable"].values)) <= set(np.flatnonzero(sel)) and int(two.data.var["highly_variable"].sum()) == 20
+
+
+def test_hvg_batch_key_on_cpu_tensors():
+    check_hvg_batches("cpu")
+
+
 def check_seurat_v3(device):
     """The count-based flavour (filter.py:1142-1192 -> scanpy seurat_v3): the loess trend fitted on the device against the numpy
     restatement (one lstsq per point) and closed forms; the transform's columns and subset against the restated selection."""

@@ -260,6 +260,11 @@ def test_gene_filters_on_device(cuda_device):
     tgf.check_gene_filters("cuda")
 
 
+def test_hvg_batch_key_on_device(cuda_device):
+    import test_filter_transforms as tft
+    tft.check_hvg_batches("cuda")
+
+
 def test_seurat_v3_hvg_on_device(cuda_device):
     import test_filter_transforms as tft
     tft.check_seurat_v3("cuda")
