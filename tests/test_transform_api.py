@@ -194,3 +194,16 @@ def test_anndata_transform_interface():
     Compose(AnnDataTransform(_scale_in_place, factor=0.5), AnnDataTransform(_scale_in_place, factor=4))(a)
     assert np.allclose(a.data.X, x * 200)
     assert resolve_from_registry("AnnDataTransform", "preprocessor.interface") is AnnDataTransform
+
+
+def test_utils_seed_and_device():
+    import random
+
+    import torch
+    from dance_amd.utils import default, get_device, hexdigest, set_seed
+    assert get_device("auto") == "cuda" and get_device("cuda:1") == "cuda:1"
+    assert default(None, 3) == 3 and default(0, 3) == 0 and hexdigest("abc") == "900150983cd24fb0d6963f7d28e17f72"
+    set_seed(5, cuda=False)
+    a = (random.random(), float(np.random.rand()), float(torch.rand(1)))
+    set_seed(5, cuda=False)
+    assert a == (random.random(), float(np.random.rand()), float(torch.rand(1)))
