@@ -540,6 +540,6 @@ class GraphSC(BaseClusteringMethod):
 
 def run_leiden(data, device="cuda"):
     """graphsc.py:568-587: ``sc.pp.neighbors(use_rep="X", n_neighbors=300, n_pcs=0)`` + ``sc.tl.leiden``.  Neighbour
-    graph on the GPU; modularity optimisation by the Louvain scheme on the host (dance_amd/utils/community.py)."""
+    graph on the GPU; the Leiden algorithm itself on the host (dance_amd/utils/community.py; seeded-stochastic like leidenalg, not pinned to it)."""
     from ....utils.community import leiden_like
     return [int(x) for x in leiden_like(np.asarray(data, dtype=np.float32), 300, resolution=1.0, device=device)]

@@ -200,8 +200,8 @@ class SimpleGCDEC(nn.Module):
             y_pred = kmeans.fit_predict(feats_all.cpu().numpy() if init_spa else x_all.cpu().numpy())
         elif init == "louvain":
             # spagcn.py:480-492: sc.pp.neighbors(n_neighbors) + sc.tl.leiden(resolution=res).  Neighbour graph on the
-            # GPU (exact kNN + UMAP connectivities); the modularity optimisation itself is the Louvain scheme on the
-            # host (scanpy / leidenalg are not installable — deviation documented in dance_amd/utils/community.py)
+            # GPU (exact kNN + UMAP connectivities); the Leiden algorithm itself runs on the host (dance_amd/utils/community.py:
+            # scanpy / leidenalg are not installable — same algorithm and quality function, not leidenalg's random stream)
             from ....utils.community import leiden_like
             logger.info(f"Initializing cluster centers with louvain, resolution = {res}")
             y_pred = leiden_like(feats_all if init_spa else x_all, n_neighbors, resolution=res, device=self.device)

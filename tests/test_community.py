@@ -35,3 +35,79 @@ def test_louvain_resolution_and_degenerate_graphs():
     two = sp.csr_matrix(np.array([[0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=np.float32))
     got = louvain(two)
     assert got[0] == got[1] != got[2] == got[3]
+
+
+def _connected(a, labels):
+    from scipy.sparse.csgraph import connected_components
+    for c in np.unique(labels):
+        idx = np.flatnonzero(labels == c)
+        if connected_components(a[idx][:, idx], directed=False)[0] != 1:
+            return False
+    return True
+
+
+def _block_model(n, c, p_in, p_out, seed):
+    rng = np.random.default_rng(seed)
+    z = rng.integers(0, c, n)
+    m = rng.random((n, n)) < np.where(z[:, None] == z[None, :], p_in, p_out)
+    m = np.triu(m, 1)
+    return sp.csr_matrix((m | m.T).astype(np.float64)), z
+
+
+def test_leiden_partitions_and_guarantees():
+    """The Leiden scheme (Traag et al. 2019) on the same quality function: planted partitions, the size-ordered labels, seeded
+    determinism, and the property Louvain lacks — every community is a connected subgraph — over sparse noisy graphs and seeds."""
+    from sklearn.metrics import adjusted_rand_score
+    from dance_amd.utils.community import leiden
+    a, lab = _planted(900, 5, 0)
+    got = leiden(a, 1.0)
+    assert adjusted_rand_score(lab, got) > 0.98 and modularity(a, got) >= modularity(a, lab) - 1e-9
+    assert np.all(np.diff(np.bincount(got)) <= 0) and np.array_equal(got, leiden(a, 1.0))
+    # a ring of 8 six-cliques joined by single edges: the cliques, exactly (Q = 0.8125 for this graph)
+    rows, cols = [], []
+    for c in range(8):
+        for i in range(6):
+            for j in range(6):
+                if i != j:
+                    rows.append(6 * c + i), cols.append(6 * c + j)
+        rows += [6 * c, 6 * ((c + 1) % 8) + 1]
+        cols += [6 * ((c + 1) % 8) + 1, 6 * c]
+    ring = sp.csr_matrix((np.ones(len(rows)), (rows, cols)), shape=(48, 48))
+    got = leiden(ring)
+    assert len(np.unique(got)) == 8 and all(len(set(got[6 * c:6 * c + 6])) == 1 for c in range(8))
+    assert abs(modularity(ring, got) - 0.8125) < 1e-12
+    for seed, (n, p_in, p_out) in enumerate([(500, 0.05, 0.004), (500, 0.03, 0.006), (400, 0.25, 0.05), (800, 0.02, 0.002)]):
+        g, z = _block_model(n, 5, p_in, p_out, seed)
+        for rs in (0, 1):
+            lab_l = leiden(g, 1.0, random_state=rs)
+            lone = np.asarray(g.sum(1)).ravel() == 0
+            assert _connected(g[~lone][:, ~lone], lab_l[~lone]), (seed, rs)
+            assert modularity(g, lab_l) >= modularity(g, louvain(g, 1.0, random_state=rs)) - 2e-3, (seed, rs)
+    # iterating to stability never loses quality against a single pass
+    g, _ = _block_model(600, 6, 0.04, 0.006, 9)
+    assert modularity(g, leiden(g, n_iterations=-1)) >= modularity(g, leiden(g, n_iterations=1)) - 1e-9
+
+
+def test_leiden_resolution_degenerate_graphs_and_refinement_invariants():
+    from dance_amd.utils.community import _refine, leiden, leiden_like
+    a, lab = _planted(600, 4, 1)
+    coarse, mid, fine = leiden(a, 0.05), leiden(a, 1.0), leiden(a, 5.0)
+    assert len(np.unique(coarse)) <= len(np.unique(mid)) <= len(np.unique(fine))
+    assert modularity(a, fine, 5.0) > modularity(a, coarse, 5.0)
+    assert leiden(sp.csr_matrix((5, 5))).tolist() == [0] * 5
+    two = sp.csr_matrix(np.array([[0, 1, 0, 0], [1, 0, 0, 0], [0, 0, 0, 1], [0, 0, 1, 0]], dtype=np.float32))
+    got = leiden(two)
+    assert got[0] == got[1] != got[2] == got[3]
+    # refinement: sub-communities stay inside their community and are connected, whatever partition they refine
+    g, z = _block_model(300, 3, 0.08, 0.01, 4)
+    g.sort_indices()
+    k = np.asarray(g.sum(1)).ravel()
+    refined = _refine(g.indptr, g.indices, g.data, k, z.copy(), 1.0, float(g.sum()), np.random.default_rng(0), 0.01)
+    for r in np.unique(refined):
+        assert len(set(z[refined == r])) == 1
+    has_edges = k > 0
+    assert _connected(g[has_edges][:, has_edges], refined[has_edges])
+    assert len(np.unique(refined)) < 300                      # something merged
+    import pytest
+    with pytest.raises(ValueError):
+        leiden_like(np.zeros((4, 2), np.float32), 2, method="bogus")
