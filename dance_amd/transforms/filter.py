@@ -488,11 +488,42 @@ def loess_at_points(x: torch.Tensor, y: torch.Tensor, span: float = 0.3, degree:
     return out
 
 
-def seurat_v3_hvg(x: torch.Tensor, *, n_top_genes: int, span: float = 0.3):
-    """scanpy's ``seurat_v3`` selection on a device count matrix, single batch [3P-memory: scanpy 1.10.1
-    _highly_variable_genes_seurat_v3]: per-gene mean / unbiased variance, loess of log10(variance) on log10(mean) over the
-    non-constant genes, counts clipped at mean + sqrt(N) * fitted std, variance of the standardised clipped counts.  Two passes
-    over the matrix in row chunks; returns (highly_variable, means, variances, variances_norm, rank) as scanpy writes them."""
+def seurat_v3_hvg(x: torch.Tensor, *, n_top_genes: int, span: float = 0.3, batches=None):
+    """scanpy's ``seurat_v3`` selection on a device count matrix [3P-memory: scanpy 1.10.1 _highly_variable_genes_seurat_v3]:
+    per-gene mean / unbiased variance, loess of log10(variance) on log10(mean) over the non-constant genes, counts clipped at
+    mean + sqrt(N) * fitted std, variance of the standardised clipped counts; the genes are ranked by it.  With ``batches`` (one
+    label per cell) all of that runs inside every batch; a gene's rank is the median of its ranks among the batches that have it in
+    their top ``n_top_genes``, ties go to the gene more batches selected, and ``variances_norm`` is the mean over the batches.
+    Returns (highly_variable, means, variances, variances_norm, rank, n_batches) as scanpy writes them (means / variances over all
+    cells)."""
+    if batches is not None:
+        import pandas as pd
+        cats = pd.Categorical(np.asarray(batches))
+        per = []
+        for code in range(len(cats.categories)):
+            rows = torch.as_tensor(np.flatnonzero(cats.codes == code), device=x.device)
+            per.append(_seurat_v3_norm_var(x.index_select(0, rows), span)[2])
+        per = np.stack(per)
+        ranks = np.argsort(np.argsort(-per, axis=1, kind="stable"), axis=1, kind="stable").astype(np.float32)
+        n_batches = (ranks < n_top_genes).sum(0)
+        ranks[ranks >= n_top_genes] = np.nan
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)  # a gene no batch selected: all-NaN column
+            rank = np.nanmedian(ranks, axis=0)
+        order = np.lexsort((-n_batches, np.where(np.isnan(rank), np.inf, rank)))   # rank ascending (NaN last), then more batches first
+        hv = np.zeros(x.shape[1], dtype=bool)
+        hv[order[:n_top_genes]] = True
+        mean_np, var_np = gene_mean_var(x, undo_log=False)
+        return hv, mean_np, var_np, per.mean(0), rank.astype(np.float32), n_batches
+    mean_np, var_np, norm_var = _seurat_v3_norm_var(x, span)
+    rank = np.argsort(np.argsort(-norm_var, kind="stable"), kind="stable").astype(np.float32)
+    hv = rank < n_top_genes
+    rank[~hv] = np.nan
+    return hv, mean_np, var_np, norm_var, rank, None
+
+
+def _seurat_v3_norm_var(x: torch.Tensor, span: float):
+    """(means, variances, variance of the clipped standardised counts) of one batch: two passes over the matrix in row chunks."""
     n, g = x.shape
     mean_np, var_np = gene_mean_var(x, undo_log=False)
     mean = torch.from_numpy(mean_np).to(x.device)
@@ -511,11 +542,7 @@ def seurat_v3_hvg(x: torch.Tensor, *, n_top_genes: int, span: float = 0.3):
         s += c.sum(0)
         q += (c * c).sum(0)
     norm_var = (n * mean * mean + q - 2 * s * mean) / ((n - 1) * reg_std * reg_std)
-    norm_var = norm_var.cpu().numpy()
-    rank = np.argsort(np.argsort(-norm_var, kind="stable"), kind="stable").astype(np.float32)
-    hv = rank < n_top_genes
-    rank[~hv] = np.nan
-    return hv, mean_np, var_np, norm_var, rank
+    return mean_np, var_np, norm_var.cpu().numpy()
 
 
 def dispersion_hvg_batched(x: torch.Tensor, batches, names, *, flavor: str, base: Optional[float], n_bins: int, **rule):
@@ -631,12 +658,10 @@ class HighlyVariableGenesRawCount(BaseTransform):
                  span: Optional[float] = 0.3, subset: bool = True, inplace: bool = True, batch_key: Optional[str] = None,
                  check_values: bool = True, device="cuda", **kwargs):
         super().__init__(**kwargs)
-        if batch_key is not None:
-            raise NotImplementedError("batch_key (per-batch selection and merging) is not implemented on the device path")
         if n_top_genes is None:
             raise ValueError("`n_top_genes` is mandatory if `flavor` is `seurat_v3`.")  # scanpy's own check
         self.channel, self.channel_type, self.n_top_genes, self.span = channel, channel_type, n_top_genes, span
-        self.subset, self.inplace, self.check_values, self.device = subset, inplace, check_values, device
+        self.subset, self.inplace, self.check_values, self.device, self.batch_key = subset, inplace, check_values, device, batch_key
         self.logger.info("Expects count data")
 
     def __call__(self, data):
@@ -646,11 +671,14 @@ class HighlyVariableGenesRawCount(BaseTransform):
         x = data.get_feature(return_type=self.device, **kw)
         if self.check_values and not bool((x[:min(len(x), 4096)] % 1 == 0).all()):
             warnings.warn("`flavor='seurat_v3'` expects raw count data, but non-integers were found.", UserWarning)
-        hv, means, variances, norm_var, rank = seurat_v3_hvg(x, n_top_genes=int(self.n_top_genes), span=self.span)
+        batches = None if self.batch_key is None else data.data.obs[self.batch_key].values
+        hv, means, variances, norm_var, rank, n_batches = seurat_v3_hvg(x, n_top_genes=int(self.n_top_genes), span=self.span, batches=batches)
         if self.inplace:
             v = data.data.var
             v["highly_variable"], v["highly_variable_rank"], v["means"] = hv, rank, means
             v["variances"], v["variances_norm"] = variances, norm_var
+            if n_batches is not None:
+                v["highly_variable_nbatches"] = n_batches
             data.data.uns["hvg"] = {"flavor": "seurat_v3"}
         if self.subset:
             data.data._inplace_subset_var(hv)

@@ -197,3 +197,25 @@ def highly_variable_genes_batched(X, batch, names, flavor="seurat", n_top_genes=
         hv = (out["means"] > min_mean) & (out["means"] < max_mean) & (z > min_disp) & (z < max_disp)
     out["highly_variable"] = hv
     return out
+
+
+def highly_variable_genes_seurat_v3_batched(X, batch, n_top_genes=1000, span=0.3):
+    """scanpy's seurat_v3 flavour with ``batch_key`` [3P-memory, scanpy 1.10.1]: the single-batch statistic of
+    ``highly_variable_genes_seurat_v3`` inside every batch, ranks within the batch, a gene's rank = the median of its in-top ranks,
+    ``highly_variable_nbatches`` = how many batches have it in their top; chosen: the ``n_top_genes`` smallest median ranks, ties to
+    the gene more batches picked.  Gene by gene, no vectorised ranking.  Returns (highly_variable, variances_norm, rank, n_batches)."""
+    X = np.asarray(X, dtype=np.float64)
+    batch = np.asarray(batch)
+    g = X.shape[1]
+    norm_vars = [highly_variable_genes_seurat_v3(X[batch == b], n_top_genes=g, span=span)[3] for b in sorted(set(batch.tolist()))]
+    in_top = [[] for _ in range(g)]
+    for nv in norm_vars:
+        order = sorted(range(g), key=lambda j: (-nv[j], j))
+        for r, j in enumerate(order[:n_top_genes]):
+            in_top[j].append(r)
+    rank = np.array([np.median(r) if r else np.nan for r in in_top])
+    n_batches = np.array([len(r) for r in in_top])
+    chosen = sorted(range(g), key=lambda j: (np.isnan(rank[j]), rank[j] if not np.isnan(rank[j]) else 0.0, -n_batches[j], j))[:n_top_genes]
+    hv = np.zeros(g, dtype=bool)
+    hv[chosen] = True
+    return hv, np.mean(norm_vars, axis=0), rank, n_batches

@@ -174,6 +174,32 @@ def check_seurat_v3(device):
         HighlyVariableGenesRawCount(device=device)(Data(AnnDataLite(np.zeros((4, 0), dtype=np.float32))))
 
 
+def test_seurat_v3_hvg_batch_key():
+    """The count flavour per batch (CPU tensors; the per-batch statistic is the single-batch code the GPU twin runs)."""
+    import pandas as pd
+    from dance_amd.data import AnnDataLite, Data, DeviceArray
+    from dance_amd.transforms.filter import HighlyVariableGenesRawCount
+    x = _counts(330, 100, 11)
+    batch = np.r_[np.zeros(120, int), np.ones(110, int), np.full(100, 2)]
+    d = Data(AnnDataLite(DeviceArray(torch.from_numpy(x.copy())), obs=pd.DataFrame({"lab": batch}, index=[str(i) for i in range(330)])))
+    HighlyVariableGenesRawCount(n_top_genes=30, subset=False, batch_key="lab", device="cpu")(d)
+    hv, norm_var, rank, n_batches = on.highly_variable_genes_seurat_v3_batched(x, batch, n_top_genes=30)
+    v = d.data.var
+    assert np.array_equal(v["highly_variable"].values, hv) and int(hv.sum()) == 30
+    assert np.array_equal(v["highly_variable_nbatches"].values, n_batches) and n_batches.max() <= 3
+    assert np.array_equal(v["highly_variable_rank"].values, rank.astype(np.float32), equal_nan=True)
+    assert np.allclose(v["variances_norm"].values, norm_var, rtol=1e-6)
+    assert np.allclose(v["means"].values, x.mean(0), rtol=1e-6)                  # over all cells, not per batch
+    # one batch twice: the single-batch selection, every chosen gene in both tops
+    one = Data(AnnDataLite(DeviceArray(torch.from_numpy(x.copy()))))
+    HighlyVariableGenesRawCount(n_top_genes=30, subset=False, device="cpu")(one)
+    two = Data(AnnDataLite(DeviceArray(torch.from_numpy(np.concatenate([x, x]))), obs=pd.DataFrame({"lab": ["p"] * 330 + ["q"] * 330}, index=[str(i) for i in range(660)])))
+    HighlyVariableGenesRawCount(n_top_genes=30, batch_key="lab", device="cpu")(two)
+    assert two.data.X.shape == (660, 30)
+    assert list(two.data.var.index) == [str(i) for i in np.flatnonzero(one.data.var["highly_variable"].values)]
+    assert (two.data.var["highly_variable_nbatches"].values == 2).all()
+
+
 def test_seurat_v3_hvg_on_cpu_tensors():
     check_seurat_v3("cpu")
 
