@@ -200,12 +200,12 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
                                     SaveRaw, Scale)
         return Compose(
             FilterGenesScanpy(min_counts=3),
-            FilterCellsScanpy(min_counts=1),
+            FilterCellsScanpy(min_counts=1, key_n_counts="n_counts"),
             NormalizeTotal(max_fraction=1.0, key_added="n_counts"),
             Log1P(),
             HighlyVariableGenesLogarithmizedByTopGenes(n_top_genes=n_top_genes, flavor="cell_ranger", subset=True),
             FilterGenesScanpy(min_counts=1),
-            FilterCellsScanpy(min_counts=1),
+            FilterCellsScanpy(min_counts=1, key_n_counts="n_counts"),
             SaveRaw(),
             NormalizeTotal(max_fraction=1.0),
             Log1P(),

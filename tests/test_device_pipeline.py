@@ -123,7 +123,16 @@ def check_model_pipelines(device):
     assert ad.X.shape == (399, 60) and ad.raw.X.shape == (399, 60) and isinstance(ad.X, dd.DeviceArray) and isinstance(ad.raw.X, dd.DeviceArray)
     xs = ad.X.tensor
     assert float(xs.mean(0).abs().max()) < 1e-4 and float((xs.std(0, unbiased=True) - 1).abs().max()) < 1e-3   # sc.pp.scale
-    assert np.allclose(np.asarray(ad.obs["n_counts"]), x[np.arange(400) != 7][:, np.asarray(x.sum(0) >= 3)].sum(1), rtol=1e-6)
+    # obs["n_counts"] is what the reference ends with: every in-place sc.pp.filter_cells overwrites it, so after the second cell filter
+    # (scdsc.py:124) it holds the row sums of the log1p-normalised HVG matrix — the value ZINB's size factors are built from (:246)
+    xf = x[np.arange(400) != 7].astype(np.float64)
+    xf = xf[:, np.asarray(x.sum(0) >= 3)]
+    tot = xf.sum(1)
+    logn = np.log1p(xf / tot[:, None] * np.median(tot))
+    kept = np.flatnonzero(np.asarray(x.sum(0) >= 3))                      # var names are the original column numbers
+    hvg_cols = np.searchsorted(kept, np.asarray([int(v) for v in ad.var_names]))
+    assert np.allclose(np.asarray(ad.obs["n_counts"]), logn[:, hvg_cols].sum(1), rtol=1e-4)
+    assert not np.allclose(np.asarray(ad.obs["n_counts"]), tot, rtol=1e-3)   # not the raw totals NormalizeTotal recorded first
     g = ad.uns["NeighborGraph.hip"]
     assert g.n_rows == 399 and g.symmetric
     adj, xx, raw, n_counts = data.get_x()           # what ScDSC.fit receives (host views materialise here, once each)
