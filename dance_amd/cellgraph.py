@@ -11,6 +11,7 @@ the reference's order, cell_feature_graph.py:43-69), so ``edges()`` / ``edata`` 
 """
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 
@@ -48,7 +49,96 @@ class _GatherFrame(dict):
         return len(self.keys())
 
 
-class CellGeneGraph:
+class _EdgeView:
+    """``edges.src`` / ``edges.dst`` of an edge batch: node-frame entries gathered per edge on access."""
+
+    def __init__(self, frame, index: torch.Tensor):
+        self._frame, self._index = frame, index
+
+    def __getitem__(self, key):
+        return self._frame[key][self._index]
+
+    def __contains__(self, key):
+        return key in self._frame
+
+
+class EdgeBatch:
+    """What a message UDF receives (``dgl.udf.EdgeBatch``): ``src[k]`` / ``dst[k]`` are the node features of every edge's end
+    points, ``data[k]`` the edge features, all in the CSR slot order of the graph (destination-major)."""
+
+    def __init__(self, src_frame, dst_frame, edata, src_index, dst_index):
+        self.src, self.dst, self.data = _EdgeView(src_frame, src_index), _EdgeView(dst_frame, dst_index), edata
+        self._n = int(src_index.numel())
+
+    def batch_size(self) -> int:
+        return self._n
+
+    def __len__(self):
+        return self._n
+
+
+class _MessagePassing:
+    """``update_all`` / ``adjacency_matrix`` for the graph and its blocks (gnn.py:90, graphsc.py:208,463-465): built-in
+    ``fn.u_mul_e`` / ``fn.copy_u`` messages with ``fn.sum`` / ``fn.mean`` run as ONE dh_spmm_csr_f32 launch on the stored CSR; a Python
+    message UDF (``AdaptiveSAGE.message_func``, ``edge_selection_simple``) gets an ``EdgeBatch`` and its [E, ...] message tensor is
+    reduced per destination by the same kernel (the compatibility path: it materialises the messages, which the model code of this
+    package never does).  Differentiable in the source features / the UDF's message (autograd.spmm), not in built-in edge weights.
+    The frames read / written are ``srcdata`` / ``dstdata`` (= ``ndata`` on a whole graph)."""
+
+    def _mp_parts(self):
+        """(row pointers of the destination rows starting at 0, source index per slot, weights per slot, #dst, #src, frames)."""
+        raise NotImplementedError
+
+    def update_all(self, message_func, reduce_func, apply_node_func=None):
+        from . import autograd, kernels
+        from . import function as fn
+        from .graph import CSRGraph
+        if apply_node_func is not None:
+            raise NotImplementedError("update_all: apply_node_func is not used by the reference's layers")
+        if not isinstance(reduce_func, fn._Reduce):
+            raise TypeError("update_all: the reduce function must be dance_amd.function.sum / mean")
+        rowptr, col, val, n_dst, n_src, srcdata, dstdata, edata = self._mp_parts()
+        reduce = kernels.REDUCE_MEAN if reduce_func.kind == "mean" else kernels.REDUCE_SUM
+        if isinstance(message_func, fn._Message):
+            if message_func.out != reduce_func.msg:
+                raise KeyError(f"update_all: the reduce function reads {reduce_func.msg!r}, the message is {message_func.out!r}")
+            z = srcdata[message_func.lhs]
+            ew = None
+            if message_func.kind == "u_mul_e":
+                ew = edata[message_func.rhs]
+                if ew.numel() != col.numel():
+                    raise ValueError("update_all: u_mul_e needs one scalar per edge")
+                ew = ew.reshape(-1).to(torch.float32).contiguous()
+            shape = z.shape
+            out = autograd.spmm(z.reshape(shape[0], -1).to(torch.float32), CSRGraph(rowptr, col, ew, n_dst, n_src), reduce=reduce)
+            dstdata[reduce_func.out] = out.reshape((n_dst, ) + tuple(shape[1:]))
+            return
+        # message UDF: one EdgeBatch over all stored edges, then a segment reduction of its message tensor
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        dst_index = torch.repeat_interleave(torch.arange(n_dst, device=rowptr.device), deg)
+        msgs = message_func(EdgeBatch(srcdata, dstdata, edata, col.to(torch.int64), dst_index))
+        m = msgs[reduce_func.msg]
+        e = int(col.numel())
+        if m.shape[0] != e:
+            raise ValueError(f"update_all: the message has {m.shape[0]} rows for {e} edges")
+        slot = torch.arange(e, dtype=torch.int32, device=rowptr.device)
+        out = autograd.spmm(m.reshape(e, -1).to(torch.float32), CSRGraph(rowptr, slot, None, n_dst, e), reduce=reduce)
+        dstdata[reduce_func.out] = out.reshape((n_dst, ) + tuple(m.shape[1:]))
+
+    def adjacency_matrix(self, transpose: bool = False):
+        """Sparse [num_src, num_dst] matrix with a 1 per stored edge u -> v at (u, v) (``dgl.DGLGraph.adj`` of DGL 1.x: rows are
+        sources; ``transpose=True`` puts the destinations in the rows); ``.to_dense()`` as graphsc.py:208 calls it."""
+        rowptr, col, _, n_dst, n_src, *_ = self._mp_parts()
+        deg = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+        dst = torch.repeat_interleave(torch.arange(n_dst, device=rowptr.device), deg)
+        src = col.to(torch.int64)
+        idx, shape = (torch.stack((dst, src)), (n_dst, n_src)) if transpose else (torch.stack((src, dst)), (n_src, n_dst))
+        return torch.sparse_coo_tensor(idx, torch.ones(src.numel(), dtype=torch.float32, device=rowptr.device), shape)
+
+    adj = adjacency_matrix
+
+
+class CellGeneGraph(_MessagePassing):
 
     def __init__(self, rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, eid: Optional[torch.Tensor],
                  n_nodes: int, ndata: Optional[Dict[str, torch.Tensor]] = None):
@@ -75,6 +165,54 @@ class CellGeneGraph:
 
     def nodes(self) -> torch.Tensor:
         return torch.arange(self._n_nodes, device=self.device)
+
+    @property
+    def srcdata(self):
+        return self.ndata
+
+    @property
+    def dstdata(self):
+        return self.ndata
+
+    def _mp_parts(self):
+        return self.rowptr, self.col, self.val, self._n_nodes, self._n_nodes, self.ndata, self.ndata, _Frame(weight=self.val[:, None])
+
+    def add_edges(self, u, v, data=None):
+        """Append the edges u[i] -> v[i] IN PLACE (``dgl.DGLGraph.add_edges``; cell_feature_graph.py:69 adds the self loops this way):
+        they get the next edge ids, ``data["weight"]`` ([k] or [k, 1]; 0 when absent, as DGL zero-fills missing edge features)."""
+        dev = self.device
+        u = torch.as_tensor(u, dtype=torch.int64, device=dev).reshape(-1)
+        v = torch.as_tensor(v, dtype=torch.int64, device=dev).reshape(-1)
+        if u.numel() != v.numel():
+            if u.numel() == 1:
+                u = u.expand_as(v)
+            elif v.numel() == 1:
+                v = v.expand_as(u)
+            else:
+                raise ValueError("add_edges: u and v must have the same length (or one of them a single node)")
+        if u.numel() and (int(torch.max(u.max(), v.max())) >= self._n_nodes or int(torch.min(u.min(), v.min())) < 0):
+            raise ValueError("add_edges: node id out of range")
+        extra = set((data or {}).keys()) - {"weight"}
+        if extra:
+            raise KeyError(f"add_edges: this graph stores one edge feature, 'weight' (got {sorted(extra)})")
+        wt = (torch.as_tensor(data["weight"], dtype=torch.float32, device=dev).reshape(-1) if data and "weight" in data
+              else torch.zeros(u.numel(), dtype=torch.float32, device=dev))
+        if wt.numel() != u.numel():
+            raise ValueError("add_edges: one weight per new edge")
+        e_old = int(self.col.numel())
+        eid_old = self.eid.to(torch.int64) if self.eid is not None else torch.arange(e_old, device=dev)
+        src = torch.cat((self.col.to(torch.int64), u))
+        dst = torch.cat((self._dst_of_slots(), v))
+        eid = torch.cat((eid_old, torch.arange(e_old, e_old + u.numel(), device=dev)))
+        val = torch.cat((self.val, wt))
+        order = torch.argsort(dst * (e_old + u.numel() + 1) + eid)  # CSR by destination, a row's slots in edge-id order
+        rowptr = torch.zeros(self._n_nodes + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=self._n_nodes), 0)
+        self.rowptr, self.col, self.val = rowptr.to(torch.int32), src[order].to(torch.int32), val[order].contiguous()
+        self.eid = eid[order].to(torch.int32)
+        self._edge_cache = None
+        for k in ("_zero_in_deg", "_gene_prefix", "_min_seed_cache"):
+            self.__dict__.pop(k, None)
 
     def in_degrees(self) -> torch.Tensor:
         return (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
@@ -191,7 +329,7 @@ class CellGeneGraph:
         return g
 
 
-class Block:
+class Block(_MessagePassing):
     """Bipartite message-flow block: ``num_dst`` destination nodes (= the first ``num_dst`` source nodes) with all
     their in-edges; CSR rows are destinations, columns index ``srcdata`` rows."""
 
@@ -211,6 +349,16 @@ class Block:
         return self._num_dst
 
     num_dst_nodes = number_of_dst_nodes
+
+    def _mp_parts(self):
+        rp = self.rowptr_dst
+        first = int(rp[0]) if rp.numel() else 0  # the full-graph cell block keeps absolute offsets into the graph's col / val
+        if first:
+            last = int(rp[-1])
+            return rp - first, self.col[first:last], self.val[first:last], self._num_dst, self._num_src, self.srcdata, self.dstdata, \
+                _Frame(weight=self.val[first:last, None])
+        e = int(rp[-1]) if rp.numel() else 0
+        return rp, self.col[:e], self.val[:e], self._num_dst, self._num_src, self.srcdata, self.dstdata, _Frame(weight=self.val[:e, None])
 
     @property
     def rowptr_dst(self) -> torch.Tensor:
@@ -370,17 +518,25 @@ class DataLoader:
         # seeds that are all cells of a CellFeatureGraph-layout graph: a one-layer block then is [seed cells | their genes,
         # ascending], which lets AdaptiveSAGE aggregate on the matrix cores (one device read per loader, not per batch)
         g = graph.gene_prefix() if hasattr(graph, "gene_prefix") else -1
-        self.cells_only = bool(g >= 0 and self.indices.numel() > 0 and self._min_seed(graph) >= g)
+        self.cells_only = bool(g >= 0 and self.indices.numel() > 0 and self._min_seed(graph, indices) >= g)
 
-    def _min_seed(self, graph) -> int:
-        """min(indices), read from the device once per (graph, seed tensor): ScDeepSort builds a new loader every epoch over
-        the same ids."""
-        cache = graph.__dict__.setdefault("_min_seed_cache", {})
-        key = (self.indices.data_ptr(), self.indices.numel())
-        if key not in cache:
-            cache.clear()
-            cache[key] = int(self.indices.min())
-        return cache[key]
+    def _min_seed(self, graph, given) -> int:
+        """min(indices).  Host seeds (lists, numpy, CPU tensors) are reduced on the host — no device read at all.  A device tensor
+        is read once per (graph, tensor OBJECT, version): ScDeepSort builds a new loader every epoch over the same ids.  The key is
+        the caller's tensor identity + ``_version`` (graph.TensorKeyedCache), never ``data_ptr()``: ``self.indices`` is a fresh
+        copy per loader and the caching allocator hands a freed block to the next allocation of the same size, so a pointer key
+        could return another seed set's minimum."""
+        if not (torch.is_tensor(given) and given.is_cuda):
+            host = given.detach().cpu().numpy() if torch.is_tensor(given) else np.asarray(given)
+            return int(host.min())
+        from .graph import TensorKeyedCache
+        cache = graph.__dict__.setdefault("_min_seed_cache", None)
+        if not isinstance(cache, TensorKeyedCache):
+            cache = graph.__dict__["_min_seed_cache"] = TensorKeyedCache()
+        hit = cache.get(given)
+        if hit is None:
+            hit = cache.put(given, int(given.min()))
+        return hit
 
     def __len__(self):
         n = self.indices.numel()

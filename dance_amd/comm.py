@@ -101,7 +101,7 @@ class Communicator:
             out = torch.empty((n_local, width), dtype=torch.float32, device=operand.device)
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream(device=operand.device)
-        send_buf = torch.empty((max(int(sum(send_rows)), 1), width), dtype=torch.float32, device=operand.device)
+        send_buf = torch.empty((max(int(sum(send_rows)), 1), _ld(operand)), dtype=torch.float32, device=operand.device)  # rows travel at the operand's stride
         send_buf.record_stream(self._comm_stream)
         operand.record_stream(self._comm_stream)
         _lib.check(self._lib.dh_comm_halo_spmm_f32(

@@ -218,8 +218,8 @@ extern "C" int dh_block_fill(int64_t n_nodes, int64_t n_seeds, const int64_t* se
 //   rows 0 .. B-1 : the seeds' in-edges, column = B + gene id, resp. the row's own index for the self loop
 //   row  B        : a padding row owning the unused tail [nnz, E_max) of the edge arrays (column 0, value 0): the CSR always has
 //                   exactly E_max entries and B + 1 rows, its transpose is well defined, the padding contributes zeros.
-// bad[0] is set when a seed is not a cell of that layout (a non-gene in-neighbour other than the seed itself, or more than E_max
-// edges): the caller checks it once per epoch.
+// bad[0] is set when a seed is not a cell of that layout (a non-gene in-neighbour other than the seed itself, no self loop or more
+// than one, or more than E_max edges): the caller checks it once per epoch.
 namespace {
 
 __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds, int64_t n_genes, int64_t e_max, const int64_t* __restrict__ seeds,
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds,
   const int64_t v = seeds[i];
   const int s = rowptr[v], t = rowptr[v + 1], o = brp[i];
   if (o + (t - s) > e_max) return;  // flagged by the padding row's wavefront
+  int n_self = 0;  // complete in lane 0 (it is active in every trip any lane makes)
   for (int e = lane; e < t - s; e += 64) {
     const int c = col[s + e];
     int bc;
@@ -248,9 +249,13 @@ __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds,
       bc = (int)i;
       if (c != v) bad[0] = 1;
     }
+    n_self += __popcll(__ballot(c >= n_genes));
     bcol[o + e] = bc;
     bval[o + e] = val ? val[s + e] : 1.f;
   }
+  // the captured training steps take the decoder target among a batch's own cells to be the identity (graphsc.py:208-214 on a
+  // CellFeatureGraph: the only cell -> cell edges are the self loops): a seed row without exactly one self loop breaks that
+  if (lane == 0 && n_self != 1) bad[0] = 1;
 }
 
 __global__ __launch_bounds__(256) void cells_static_pad_kernel(int64_t n_seeds, int64_t e_max, const int32_t* __restrict__ brp,

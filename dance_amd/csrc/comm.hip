@@ -197,6 +197,7 @@ extern "C" int dh_comm_halo_spmm_f32(dh_comm_t comm, int64_t n_local, int64_t n_
     return dh::fail(DH_ERR_INVALID, "dh_comm_halo_spmm_f32: negative size");
   if (!send_rows_host || !recv_rows_host) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_spmm_f32: null counts");
   if (ldz % 4 != 0) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_spmm_f32: the operand's rows must be 16-byte aligned (ldz %% 4 == 0)");
+  if (ldz < width) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_spmm_f32: ldz %lld < width %lld", (long long)ldz, (long long)width);
   hipStream_t cs = dh::as_stream(compute_stream), xs = dh::as_stream(comm_stream);
   int64_t n_send = 0, n_recv = 0;
   for (int p = 0; p < comm->world; ++p) {
@@ -206,7 +207,9 @@ extern "C" int dh_comm_halo_spmm_f32(dh_comm_t comm, int64_t n_local, int64_t n_
   if (n_recv != n_halo) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_spmm_f32: receive counts sum to %lld, n_halo = %lld", (long long)n_recv, (long long)n_halo);
   // 1. pack the rows the peers asked for (own rows of the operand; optionally masked: G = dY * [Y > 0] on the way out)
   if (n_send) {
-    if (int rc = dh_gather_rows_f32(n_send, width, send_idx, operand, ldz, send_relu_mask, send_buf, width, compute_stream)) return rc;
+    // packed with the operand's own row stride: the exchange below moves whole ldz-float rows into the operand's tail, so a padded
+    // operand (ldz > width) keeps sender and receiver strides equal (send_buf: n_send * ldz floats)
+    if (int rc = dh_gather_rows_f32(n_send, width, send_idx, operand, ldz, send_relu_mask, send_buf, ldz, compute_stream)) return rc;
   }
   DH_HIP(hipEventRecord(comm->packed, cs), "dh_comm_halo_spmm_f32");
   // 2. exchange on the comm stream: halo rows land behind the own rows of the operand

@@ -43,6 +43,18 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
                       hipStream_t st);
 size_t knn_filter_mean_floats(int64_t d);
 
+// sage_bcm.hip: the two-waves-per-SIMD kernel pair (block-chunk-major plan of the graph + MFMA) behind the unsplit path of dh_sage_window_mfma
+bool sage_bcm_fits(int64_t n_dst, int64_t n_cols, int64_t width, bool hbf16, const void* H, int64_t ldh, int64_t nnz);
+size_t sage_bcm_plan_bytes(int64_t n_dst, int64_t n_cols, int64_t nnz);
+size_t sage_bcm_prep_bytes(int64_t n_cols, int64_t width, bool hbf16);
+size_t sage_bcm_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, bool hbf16, int64_t nnz);
+int sage_bcm_plan(int64_t n_dst, int64_t col_begin, int64_t n_cols, const int32_t* rowptr, const int32_t* col, const float* w, void* plan,
+                  hipStream_t st);
+int sage_bcm_launch(int64_t n_dst, int64_t width, int64_t col_begin, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                    const float* w, const float* colscale, const void* H, int64_t ldh, bool hb, void* neigh, int64_t ldn, bool ob,
+                    int64_t nnz, const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha, int64_t n_genes,
+                    const void* plan, void* workspace, hipStream_t st);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace dh

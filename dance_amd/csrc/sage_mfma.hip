@@ -34,6 +34,8 @@
 //
 // Precondition (the layouts CellFeatureGraph and the block builder produce): inside a row the in-window edges are
 // contiguous and ascending by column; out-of-window edges sit at the row's ends.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -703,6 +705,13 @@ extern "C" size_t dh_sage_window_mfma_split_workspace_bytes(int64_t n_dst, int64
   return S > 1 ? prep + (size_t)S * n_dst * g.Dp * sizeof(float) : g.prep_bytes;
 }
 
+/* workspace of the repack + two-waves-per-SIMD kernel pair (sage_bcm.hip) that unsplit launches run when it is provided: the K-major feature
+ * planes, the chunk pointers of every 64-row group and the packed entries (8 bytes per stored entry of col / w); 0 if the shape does not fit. */
+extern "C" size_t dh_sage_window_mfma_bcm_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype, int64_t nnz) {
+  if (n_dst <= 0 || n_cols <= 0 || width <= 0 || nnz <= 0 || width > 512 || n_cols > 4096) return 0;
+  return dh::sage_bcm_workspace_bytes(n_dst, n_cols, width, h_dtype == DH_DTYPE_BF16, nnz);
+}
+
 extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,
                                    const int32_t* rowptr, const int32_t* col, const float* w, const float* colscale, const void* H,
                                    int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
@@ -724,6 +733,26 @@ extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, 
   if (!workspace || workspace_bytes < g.prep_bytes) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, workspace_bytes, g.prep_bytes);
   if (g.lds_bytes > 160 * 1024) return dh::fail(DH_ERR_INVALID, "%s: needs %zu bytes of LDS (window too wide for this width)", me, g.lds_bytes);
   hipStream_t st = dh::as_stream(stream);
+  {
+    // Unsplit launches (>= 256 row blocks: the full graph, large batches) with the self loops folded in run the repack + two-waves-
+    // per-SIMD kernel pair of sage_bcm.hip when the caller provided its workspace (dh_sage_window_mfma_bcm_workspace_bytes).
+    // DANCE_AMD_SAGE_MFMA = "v1" keeps this file's kernel everywhere (A/B), "bcm" forces the new pair for few-row launches too
+    // (tests: every shape through both).
+    const char* mode = getenv("DANCE_AMD_SAGE_MFMA");
+    const bool v1_only = mode && mode[0] == 'v' && mode[1] == '1';
+    const bool bcm_force = mode && mode[0] == 'b';
+    const int s_try = split_factor(n_dst, g);
+    const bool unsplit = s_try == 1 || workspace_bytes < (g.prep_bytes + 255) / 256 * 256 + (size_t)s_try * n_dst * g.Dp * sizeof(float);
+    if (fold && !v1_only && (unsplit || bcm_force) && dh::sage_bcm_fits(n_dst, n_cols, width, hb, H, ldh, nnz) &&
+        workspace_bytes >= dh::sage_bcm_workspace_bytes(n_dst, n_cols, width, hb, nnz))
+    {  // the plan (graph only) behind the feature planes in the caller's workspace, rebuilt per call; callers that keep a graph use
+       // dh_sage_window_plan once and dh_sage_window_mfma_planned per call
+      char* plan = static_cast<char*>(workspace) + dh::sage_bcm_prep_bytes(n_cols, width, hb);
+      if (int rc = dh::sage_bcm_plan(n_dst, col_begin, n_cols, rowptr, col, w, plan, st)) return rc;
+      return dh::sage_bcm_launch(n_dst, width, col_begin, n_cols, rowptr, col, w, colscale, H, ldh, hb, neigh, ldn, ob, nnz, src_cell_id,
+                                 dst_cell_id, alpha, n_genes, plan, workspace, st);
+    }
+  }
   uint16_t* HsP = static_cast<uint16_t*>(workspace);
   const char* Hw = static_cast<const char*>(H) + (size_t)col_begin * ldh * (hb ? 2 : 4);
   const unsigned pgrid = (unsigned)dh::ceil_div((int64_t)g.J * 2 * g.Dp, 256);
@@ -773,4 +802,51 @@ extern "C" int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, 
   if (ob) hipLaunchKernelGGL(sage_mfma_reduce_kernel<true>, dim3(rgrid), dim3(256), 0, st, n_dst, width, g.Dp, S, partial, neigh, ldn, fold ? 0 : 1);
   else hipLaunchKernelGGL(sage_mfma_reduce_kernel<false>, dim3(rgrid), dim3(256), 0, st, n_dst, width, g.Dp, S, partial, neigh, ldn, fold ? 0 : 1);
   return dh::check_launch(me);
+}
+
+/* ---- the plan interface of the two-waves-per-SIMD path (sage_bcm.hip) ---------------------------------------------------------------- */
+extern "C" size_t dh_sage_window_plan_bytes(int64_t n_dst, int64_t n_cols, int64_t nnz) {
+  if (n_dst <= 0 || n_cols <= 0 || nnz <= 0 || n_cols > 4096) return 0;
+  return dh::sage_bcm_plan_bytes(n_dst, n_cols, nnz);
+}
+
+extern "C" int dh_sage_window_plan(int64_t n_dst, int64_t col_begin, int64_t n_cols, const int32_t* rowptr, const int32_t* col, const float* w,
+                                   int64_t nnz, void* plan, size_t plan_bytes, dh_stream_t stream) {
+  const char* me = "dh_sage_window_plan";
+  if (n_dst < 0 || col_begin < 0 || n_cols <= 0 || nnz < 0) return dh::fail(DH_ERR_INVALID, "%s: bad size", me);
+  if (n_dst == 0) return DH_OK;
+  if (!rowptr || !col || !w || !plan) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (n_cols > 4096 || nnz < 2 || nnz >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "%s: window of %lld columns / %lld entries not supported", me, (long long)n_cols, (long long)nnz);
+  if (plan_bytes < dh::sage_bcm_plan_bytes(n_dst, n_cols, nnz)) return dh::fail(DH_ERR_WORKSPACE, "%s: plan buffer %zu < %zu bytes", me, plan_bytes, dh::sage_bcm_plan_bytes(n_dst, n_cols, nnz));
+  return dh::sage_bcm_plan(n_dst, col_begin, n_cols, rowptr, col, w, plan, dh::as_stream(stream));
+}
+
+extern "C" int dh_sage_window_mfma_planned_supported(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype, const void* H, int64_t ldh, int64_t nnz) {
+  return dh::sage_bcm_fits(n_dst, n_cols, width, h_dtype == DH_DTYPE_BF16, H, ldh, nnz) ? 1 : 0;
+}
+
+extern "C" int dh_sage_window_mfma_planned(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols, const int32_t* rowptr,
+                                           const int32_t* col, const float* w, const float* colscale, const void* H, int64_t ldh, int h_dtype,
+                                           void* neigh, int64_t ldn, int out_dtype, int64_t nnz, const int32_t* src_cell_id,
+                                           const int32_t* dst_cell_id, const float* alpha, int64_t n_genes, const void* plan, size_t plan_bytes,
+                                           void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  const char* me = "dh_sage_window_mfma_planned";
+  if (n_dst < 0 || n_src < 0 || width < 0 || col_begin < 0 || n_cols < 0 || nnz < 0) return dh::fail(DH_ERR_INVALID, "%s: negative size", me);
+  if (n_dst == 0 || width == 0 || n_cols == 0) return DH_OK;
+  if (!rowptr || !col || !w || !H || !neigh || !plan || !workspace) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (!src_cell_id || !dst_cell_id || !alpha) return dh::fail(DH_ERR_INVALID, "%s: src_cell_id, dst_cell_id and alpha are required (the self loops are folded in)", me);
+  if (ldh < width || ldn < width) return dh::fail(DH_ERR_INVALID, "%s: leading dimension < width", me);
+  if ((h_dtype != DH_DTYPE_F32 && h_dtype != DH_DTYPE_BF16) || (out_dtype != DH_DTYPE_F32 && out_dtype != DH_DTYPE_BF16)) return dh::fail(DH_ERR_INVALID, "%s: bad dtype", me);
+  if (col_begin + n_cols > n_src) return dh::fail(DH_ERR_INVALID, "%s: window beyond the source rows", me);
+  const bool hb = h_dtype == DH_DTYPE_BF16;
+  if (!dh::sage_bcm_fits(n_dst, n_cols, width, hb, H, ldh, nnz)) return dh::fail(DH_ERR_INVALID, "%s: shape / alignment not supported (see dh_sage_window_mfma_planned_supported)", me);
+  if (plan_bytes < dh::sage_bcm_plan_bytes(n_dst, n_cols, nnz)) return dh::fail(DH_ERR_WORKSPACE, "%s: plan buffer %zu < %zu bytes", me, plan_bytes, dh::sage_bcm_plan_bytes(n_dst, n_cols, nnz));
+  if (workspace_bytes < dh::sage_bcm_prep_bytes(n_cols, width, hb)) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, workspace_bytes, dh::sage_bcm_prep_bytes(n_cols, width, hb));
+  return dh::sage_bcm_launch(n_dst, width, col_begin, n_cols, rowptr, col, w, colscale, H, ldh, hb, neigh, ldn, out_dtype == DH_DTYPE_BF16, nnz,
+                             src_cell_id, dst_cell_id, alpha, n_genes, plan, workspace, dh::as_stream(stream));
+}
+
+extern "C" size_t dh_sage_window_mfma_planned_workspace_bytes(int64_t n_cols, int64_t width, int h_dtype) {
+  if (n_cols <= 0 || width <= 0) return 0;
+  return dh::sage_bcm_prep_bytes(n_cols, width, h_dtype == DH_DTYPE_BF16);
 }

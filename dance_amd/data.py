@@ -346,7 +346,8 @@ class Data:
         self._data._inplace_subset_obs(mask)
         if update_splits:
             new_pos = np.cumsum(mask) - 1
-            self._split_idx_dict = {k: [int(new_pos[i]) for i in v if mask[i]] for k, v in self._split_idx_dict.items()}
+            # every split comes back SORTED by new position (base.py:780), whatever order it was given in; emptied splits stay as []
+            self._split_idx_dict = {k: sorted(int(new_pos[i]) for i in v if mask[i]) for k, v in self._split_idx_dict.items()}
         return self
 
     # ---- basic views ---------------------------------------------------------------------------------------

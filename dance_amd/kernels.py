@@ -933,6 +933,7 @@ def sage_aggregate_dense(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col
 # layout, blocks of the device block builder): "mfma" = dh_sage_window_mfma where the shape fits, "gather" = always the gather
 # kernels (dh_sage_aggregate_f32 / _bf16).  Set with DANCE_AMD_SAGE.
 SAGE_MODE = os.environ.get("DANCE_AMD_SAGE", "mfma")
+SAGE_BCM_MIN_ROWS = 256 * 128  # from here on dh_sage_window_mfma launches unsplit (>= 256 row blocks)
 
 
 def sage_mfma_supported(n_cols: int, width: int, dtype) -> bool:
@@ -950,18 +951,56 @@ def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_
     out_dtype = out_dtype or H.dtype
     a = alpha.reshape(-1)
     colscale = a[src_cell_id[col_begin:col_begin + n_cols].clamp(min=0).to(torch.int64)].contiguous()  # gnn.py:73
-    out = torch.empty((rowptr.numel() - 1, H.shape[1]), dtype=out_dtype, device=H.device)
+    n_dst = rowptr.numel() - 1
+    out = torch.empty((n_dst, H.shape[1]), dtype=out_dtype, device=H.device)
+    planned = (n_dst >= SAGE_BCM_MIN_ROWS or os.environ.get("DANCE_AMD_SAGE_MFMA", "") == "bcm") and os.environ.get("DANCE_AMD_SAGE_MFMA", "") != "v1"
+    if planned and lib.dh_sage_window_mfma_planned_supported(n_dst, n_cols, H.shape[1], _out_dtype(H.dtype), H.data_ptr(), _ld(H), col.numel()):
+        # unsplit launches (the full graph, large batches): the two-waves-per-SIMD kernel over a repacked ("block-chunk-major") copy of
+        # the rows.  The repack depends on the graph only — kept per (rowptr, col, w) for as long as those tensors live unchanged
+        plan = _sage_plan(rowptr, col, w, col_begin, n_cols)
+        ws_bytes = lib.dh_sage_window_mfma_planned_workspace_bytes(n_cols, H.shape[1], _out_dtype(H.dtype))
+        ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=H.device)
+        _call("sage_window_mfma_planned", lib.dh_sage_window_mfma_planned, n_dst, H.shape[0], H.shape[1], col_begin, n_cols,
+              _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
+              _dev(colscale, torch.float32, "colscale", 1), _dev(H, H.dtype, "H", 2), _ld(H), _out_dtype(H.dtype), out.data_ptr(), _ld(out),
+              _out_dtype(out_dtype), col.numel(), _dev(src_cell_id, torch.int32, "src_cell_id", 1), _dev(dst_cell_id, torch.int32, "dst_cell_id", 1),
+              _dev(a, torch.float32, "alpha", 1), a.numel() - 2, plan.data_ptr(), plan.numel(), ws.data_ptr(), ws_bytes, _stream())
+        return out
     # (the larger size also holds the fp32 shares of a split launch: mini-batches spread over the chip instead of ceil(rows / 128) CUs)
-    ws_bytes = lib.dh_sage_window_mfma_split_workspace_bytes(rowptr.numel() - 1, n_cols, H.shape[1], _out_dtype(H.dtype))
+    ws_bytes = lib.dh_sage_window_mfma_split_workspace_bytes(n_dst, n_cols, H.shape[1], _out_dtype(H.dtype))
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=H.device)
     # src / dst ids + alpha given: the kernel adds the out-of-window edges (self loops) itself and writes the mean
-    _call("sage_window_mfma", lib.dh_sage_window_mfma, rowptr.numel() - 1, H.shape[0], H.shape[1], col_begin, n_cols,
+    _call("sage_window_mfma", lib.dh_sage_window_mfma, n_dst, H.shape[0], H.shape[1], col_begin, n_cols,
           _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
           _dev(colscale, torch.float32, "colscale", 1), _dev(H, H.dtype, "H", 2), _ld(H), _out_dtype(H.dtype), out.data_ptr(),
           _ld(out), _out_dtype(out_dtype), col.numel(), _dev(src_cell_id, torch.int32, "src_cell_id", 1),
           _dev(dst_cell_id, torch.int32, "dst_cell_id", 1), _dev(a, torch.float32, "alpha", 1), a.numel() - 2,
           ws.data_ptr(), ws_bytes, _stream())
     return out
+
+
+_SAGE_PLANS = None  # graph.TensorKeyedCache: col tensor -> (extra key, plan bytes); dies with the tensor
+
+
+def _sage_plan(rowptr, col, w, col_begin: int, n_cols: int) -> torch.Tensor:
+    """dh_sage_window_plan of (rowptr, col, w), cached by the identity + version of the three tensors (never by data_ptr)."""
+    global _SAGE_PLANS
+    from .graph import TensorKeyedCache
+    if _SAGE_PLANS is None:
+        _SAGE_PLANS = TensorKeyedCache()
+    extra = (id(rowptr), rowptr._version, rowptr.numel(), id(w), w._version, int(col_begin), int(n_cols))
+    hit = _SAGE_PLANS.get(col, extra)
+    if hit is not None and hit[0]() is rowptr and hit[1]() is w:
+        return hit[2]
+    import weakref
+    lib = _lib_ready()
+    n_dst = rowptr.numel() - 1
+    nbytes = lib.dh_sage_window_plan_bytes(n_dst, n_cols, col.numel())
+    plan = torch.empty(nbytes, dtype=torch.uint8, device=col.device)
+    _call("sage_window_plan", lib.dh_sage_window_plan, n_dst, col_begin, n_cols, _dev(rowptr, torch.int32, "rowptr", 1),
+          _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1), col.numel(), plan.data_ptr(), nbytes, _stream())
+    _SAGE_PLANS.put(col, (weakref.ref(rowptr), weakref.ref(w), plan), extra)
+    return plan
 
 
 def sage_alpha_grad(rowptr, col, w, src_cell_id, dst_cell_id, n_genes, H, dneigh) -> torch.Tensor:

@@ -462,7 +462,7 @@ class GraphSC(BaseClusteringMethod):
                     z_all[i * batch_size:(i + 1) * batch_size].copy_(emb)
                     loss_all[i].copy_(loss)
                 if int(captured.block.bad) != 0:
-                    raise RuntimeError("GraphSC.fit: a seed of the captured step is not a cell of a CellFeatureGraph-layout graph "
+                    raise RuntimeError("GraphSC.fit: a seed of the captured step is not a cell of a CellFeatureGraph-layout graph with one self loop "
                                        "(set DANCE_AMD_HIPGRAPH=0 for graphs with other in-neighbours)")
                 z.append(z_all)
                 order.append(g.ndata["order"][idx[:n_full * batch_size]])

@@ -459,11 +459,35 @@ DH_API size_t dh_sage_window_mfma_workspace_bytes(int64_t n_cols, int64_t width,
  * than 256 blocks of 128 rows) splits the gene window over up to 512 / blocks workgroups per row block and sums the shares in a second,
  * deterministic kernel (scDeepSort's batch of 500 cells: 217 -> ~30 us); with the smaller size above the unsplit kernel runs. */
 DH_API size_t dh_sage_window_mfma_split_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype);
+/* Workspace of the round-4 kernel pair behind UNSPLIT launches (>= 256 blocks of 128 rows: the full graph, large batches) with the
+ * self loops folded in: a repack of the rows into per-64-row, K-chunk-major entry lists with the entries already scaled and split
+ * (8 bytes per stored entry of col / w: nnz of them), the chunk pointers and the feature planes; then a two-wavefronts-per-SIMD MFMA
+ * kernel whose loop moves one packed entry per lane and chunk.  Give dh_sage_window_mfma at least this many bytes and it takes that
+ * path (same result to fp32 rounding: the K order of the sums differs); with less it runs the single-wave kernel.  0 = shape not
+ * supported (width > 512, n_cols > 4096).  Also needs 16-byte aligned feature rows (H, ldh * size, width * size multiples of 16). */
+DH_API size_t dh_sage_window_mfma_bcm_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype, int64_t nnz);
 DH_API int dh_sage_window_mfma(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,
                         const int32_t* rowptr, const int32_t* col, const float* w, const float* colscale,
                         const void* H, int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
                         const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha, int64_t n_genes,
                         void* workspace, size_t workspace_bytes, dh_stream_t stream);
+/* The plan interface of the same kernel pair, for callers that aggregate over ONE graph many times (ScDeepSort.fit evaluates the full
+ * graph three times per epoch, scdeepsort.py:191-193; alpha changes between calls, the graph does not).  dh_sage_window_plan repacks
+ * the rows [0, n_dst) once — per 64-row group the in-window entries sorted by 32-gene K chunk, 8 bytes each, plus the chunk pointers:
+ * it depends on rowptr / col / w only.  dh_sage_window_mfma_planned then computes what dh_sage_window_mfma computes (self loops folded
+ * in: src_cell_id / dst_cell_id / alpha required) with workspace = dh_sage_window_mfma_planned_workspace_bytes (the feature planes).
+ * Supported shapes: dh_sage_window_mfma_planned_supported (width <= 512, n_cols <= 4096, 16-byte aligned feature rows). */
+DH_API size_t dh_sage_window_plan_bytes(int64_t n_dst, int64_t n_cols, int64_t nnz);
+DH_API int dh_sage_window_plan(int64_t n_dst, int64_t col_begin, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                        const float* w, int64_t nnz, void* plan, size_t plan_bytes, dh_stream_t stream);
+DH_API int dh_sage_window_mfma_planned_supported(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype, const void* H, int64_t ldh,
+                                          int64_t nnz);
+DH_API size_t dh_sage_window_mfma_planned_workspace_bytes(int64_t n_cols, int64_t width, int h_dtype);
+DH_API int dh_sage_window_mfma_planned(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols,
+                                const int32_t* rowptr, const int32_t* col, const float* w, const float* colscale, const void* H,
+                                int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
+                                const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha, int64_t n_genes,
+                                const void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes, dh_stream_t stream);
 DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
                            const int32_t* rowptr, const int32_t* col, const float* w,
                            const int32_t* src_cell_id, const int32_t* dst_cell_id,
@@ -571,7 +595,9 @@ DH_API int dh_zinb_nll_backward_f32(int64_t n, int64_t n_genes, const float* X, 
  *   dh_comm_halo_spmm_f32:      Y[rows] = act(A_local * operand + bias) for a shard whose column ids are [own rows | halo rows]:
  *                               packs operand[send_idx] (times the ReLU sign mask of those rows if send_relu_mask != NULL) into
  *                               send_buf, exchanges on comm_stream while the interior rows run on compute_stream, then the
- *                               boundary rows; `operand` is [n_local + n_halo, ldz], its tail receives the halo.  No host sync. */
+ *                               boundary rows; `operand` is [n_local + n_halo, ldz], its tail receives the halo.  Rows travel with
+ *                               the operand's own stride: send_buf holds sum(send_rows) * ldz floats (ldz >= width; the padding
+ *                               columns of a padded operand ride along so that the halo lands row for row).  No host sync. */
 #define DH_COMM_UNIQUE_ID_BYTES 128
 typedef struct dh_comm* dh_comm_t;
 DH_API int dh_comm_unique_id(void* id_host /* DH_COMM_UNIQUE_ID_BYTES */);

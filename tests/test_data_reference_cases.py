@@ -131,3 +131,12 @@ def test_pop_masks_and_concat_by_name():
     with pytest.raises(TypeError):
          # str with list (base.py:33-41)
         da.set_config(feature_channel=["e"], feature_channel_type="obsm")
+
+
+def test_filter_by_mask_returns_sorted_splits():
+    """dance/data/base.py:780 stores sorted(new_indices) for every split after a cell filter, whatever order the split was
+    given in (the remapped lists used to keep the original order)."""
+    d = Data(AnnData(np.arange(12, dtype=np.float32).reshape(6, 2)))
+    d._split_idx_dict = {"train": [4, 0, 2], "val": [5, 1], "test": [3]}
+    d.filter_by_mask(np.array([True, False, True, False, True, True]))
+    assert d._split_idx_dict == {"train": [0, 1, 2], "val": [3], "test": []}

@@ -83,3 +83,29 @@ def test_degree_scales_kernel(cuda_device):
             assert got_c is None
     r0, c0 = kernels.degree_scales(torch.zeros(4, dtype=torch.int32, device=cuda_device), torch.zeros(0, dtype=torch.int32, device=cuda_device), 3, 5)
     assert torch.equal(r0, torch.ones(3, device=cuda_device)) and torch.equal(c0, torch.ones(5, device=cuda_device))
+
+
+def test_static_cell_block_flags_rows_without_exactly_one_self_loop(cuda_device):
+    """The captured GraphSC / ScDeepSort steps take the decoder target among a batch's own cells to be the identity: every seed
+    row must hold exactly one self loop.  dh_block_cells_static sets ``bad`` otherwise (a CellFeatureGraph-layout
+    graph WITHOUT cell self loops used to train on a wrong target silently)."""
+    from dance_amd.cellgraph import CellGeneGraph, StaticCellBlock
+    n_genes, n_cells = 5, 6
+
+    def build(self_loops):
+        rows = [[] for _ in range(n_genes)]  # gene rows: empty (not used as seeds)
+        for c in range(n_cells):
+            r = [c % n_genes, (c + 2) % n_genes]
+            rows.append(sorted(r) + ([n_genes + c] * self_loops[c]))
+        rowptr = torch.tensor(np.concatenate(([0], np.cumsum([len(r) for r in rows]))), dtype=torch.int32, device=DEV)
+        col = torch.tensor([x for r in rows for x in r], dtype=torch.int32, device=DEV)
+        cid = torch.tensor(list(range(n_genes)) + [-1] * n_cells, dtype=torch.int32, device=DEV)
+        return CellGeneGraph(rowptr, col, torch.ones(col.numel(), device=DEV), None, n_genes + n_cells,
+                             {"cell_id": cid, "features": torch.zeros(n_genes + n_cells, 2, device=DEV)})
+
+    for loops, expect in (([1] * 6, 0), ([1, 1, 0, 1, 1, 1], 1), ([1, 2, 1, 1, 1, 1], 1)):
+        sb = StaticCellBlock(build(loops), 4)
+        sb.bad.zero_()
+        sb.seeds.copy_(torch.tensor([5, 6, 7, 8], device=DEV))  # cells 0 .. 3
+        sb.rebuild()
+        assert int(sb.bad) == expect, loops

@@ -70,7 +70,8 @@ def test_zinb_nll_kernels_vs_float64_formula(cuda_device):
         m64, d64, p64 = (t.detach().double().requires_grad_(True) for t in (mean, disp, pi))
         ref = cpu_ops._zinb_elements(x, m64, d64, p64, sf, ridge).mean()
         rm, rd, rp = torch.autograd.grad(ref * 2.0, (m64, d64, p64))
-        assert abs(float(loss) - float(ref)) < 1e-10 * abs(float(ref)) + 1e-12
+        # (round 4: the x = 0 branch evaluates its log1p / exp / log in fp32, everything else and every sum in float64)
+        assert abs(float(loss) - float(ref)) < 1e-6 * abs(float(ref)) + 1e-12
         for a, b, nm in ((gm, rm, "mean"), (gd, rd, "disp"), (gp, rp, "pi")):
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6, (n, g, nm)
         again = kernels.zinb_nll_forward(x, mean.detach(), disp.detach(), pi.detach(), sf, ridge)

@@ -151,3 +151,30 @@ def test_cell_filter_after_a_lazy_graph_slot():
     d.filter_by_mask(np.array([True, False, True, True]))
     assert "G.hip" not in d.data.uns and d.data.uns["other"] == 1   # the device graph over the old cells is dropped, not left stale
     assert d.data.X.shape == (3, 2) and np.array_equal(d.data.obsp["G"].toarray(), [[0, 0, 0], [0, 0, 3], [0, 4, 0]])
+
+
+def _tiny_cell_gene_graph(device="cpu"):
+    """3 genes (nodes 0..2, cell_id >= 0) + 4 cells (nodes 3..6): self loops only — enough for the loader's layout test."""
+    from dance_amd.cellgraph import CellGeneGraph
+    n = 7
+    rowptr = torch.arange(n + 1, dtype=torch.int32, device=device)
+    col = torch.arange(n, dtype=torch.int32, device=device)
+    cid = torch.tensor([0, 1, 2, -1, -1, -1, -1], dtype=torch.int32, device=device)
+    return CellGeneGraph(rowptr, col, torch.ones(n, device=device), None, n, {"cell_id": cid, "features": torch.zeros(n, 2, device=device)})
+
+
+def test_loader_cells_only_flag_is_not_cached_across_seed_sets():
+    """the flag was cached under (data_ptr, numel) of the loader's private device copy; a later loader whose
+    seeds had the same length but included gene nodes could hit the stale entry and get cells_only=True (wrong block layout for
+    the matrix-core aggregation).  Host seeds are now reduced on the host; device seeds are keyed by identity + version."""
+    from dance_amd.cellgraph import DataLoader, NeighborSampler
+    g = _tiny_cell_gene_graph()
+    sampler = NeighborSampler([-1])
+    cells = [3, 4, 5, 6]
+    for _ in range(3):  # same-sized seed sets back to back, freed in between: the allocator may recycle the block
+        assert DataLoader(g, cells, sampler, batch_size=2).cells_only is True
+        assert DataLoader(g, [0, 4, 5, 6], sampler, batch_size=2).cells_only is False
+    t = torch.tensor(cells)
+    assert DataLoader(g, t, sampler, batch_size=2).cells_only is True
+    t[0] = 1  # in-place edit of the caller's tensor: a gene among the seeds now
+    assert DataLoader(g, t, sampler, batch_size=2).cells_only is False

@@ -15,6 +15,9 @@ LIB = os.path.join(ROOT, "dance_amd", "libdancehip.so")
 KNOWN_VGPR_SPILLS = {
     "gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, true,": "the transposed-transposed GEMM variant: no caller on the model paths",
     "knn_filter_small_kernel<13>": "small-k kNN filter at its widest candidate list (next-round item 6)",
+    "sage_bcm_kernel<false, false, 4>": "fp32 features, 13 - 16 column tiles: 8 dwords of loop-invariant addresses spilled ONCE before the loop "
+                                        "(the allocation is dictated by the 4-tile mover path, which holds 8 feature pieces)",
+    "sage_bcm_kernel<false, true, 4>": "same kernel, bf16 output",
 }
 
 
@@ -32,6 +35,9 @@ def test_no_unexpected_scratch_spills():
     spilled = [n for n, r in own if r["vspill"] > 0]
     unexpected = [n for n in spilled if not any(k in n for k in KNOWN_VGPR_SPILLS)]
     assert not unexpected, f"kernels spilling VGPRs to scratch: {unexpected}"
+    for n, r in own:  # the tolerated sage_bcm spill stays what it is: a handful of dwords, two waves per SIMD
+        if n.startswith("sage_bcm_kernel<"):
+            assert r["vspill"] <= 8 and r["scratch"] <= 64 and r["vgpr"] <= 256, (n, r)
     # the headline kernels keep their occupancy: the fp32 GEMM at most 256 registers (2 waves per SIMD), the SpMM at most 64 (8 waves)
     for n, r in own:
         if n.startswith("gemm_f32_kernel<Cfg<2, 4, 4, 2>"):
