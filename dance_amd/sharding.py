@@ -80,6 +80,43 @@ def slice_rows(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.Tens
     return GraphShard(rp, col[s:e].contiguous(), None if val is None else val[s:e].contiguous(), lo, hi, n_cols)
 
 
+def transpose_shard(a_shard: "GraphShard", ranges, rank: int, world: int, group=None) -> "GraphShard":
+    """Rows [lo, hi) of A^T from every rank's rows of A, by ONE set-up exchange (all-to-all-v of (column, row, value) triples by
+    column owner) — no rank ever holds the whole graph.  Row j of the result lists the sources i of the stored entries A[i, j] in
+    ascending i (ties in A's own order): exactly the rows ``slice_rows(transpose(A))`` would give, bit for bit."""
+    lo, hi = ranges[rank]
+    dev = a_shard.col.device
+    n_local = a_shard.n_rows
+    deg = (a_shard.rowptr[1:] - a_shard.rowptr[:-1]).to(torch.int64)
+    rows = torch.repeat_interleave(torch.arange(a_shard.lo, a_shard.lo + n_local, device=dev), deg, output_size=a_shard.col.numel())
+    cols = a_shard.col.to(torch.int64)
+    vals = a_shard.val if a_shard.val is not None else torch.ones(cols.numel(), dtype=torch.float32, device=dev)
+    starts = torch.tensor([r[0] for r in ranges], dtype=torch.int64, device=dev)
+    owner = torch.searchsorted(starts, cols, right=True) - 1
+    order = torch.argsort(owner, stable=True)  # grouped by destination rank; inside a group still row-major (ascending i)
+    send_counts = torch.bincount(owner, minlength=world).tolist()
+    pack = torch.stack((cols[order], rows[order]), 1).contiguous()  # int64 [m, 2]
+    vsend = vals[order].contiguous()
+    if world > 1:
+        cnt = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_to_all_single(cnt, torch.tensor(send_counts, dtype=torch.int64, device=dev), group=group)
+        recv_counts = cnt.tolist()
+        got = torch.empty((sum(recv_counts), 2), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(got, pack, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+        vgot = torch.empty(sum(recv_counts), dtype=torch.float32, device=dev)
+        dist.all_to_all_single(vgot, vsend, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=group)
+    else:
+        got, vgot = pack, vsend
+    # the pieces arrive grouped by SENDING rank = ascending source row range, each piece row-major: a stable sort by column
+    # (= the row of A^T) leaves every row's sources ascending
+    j = got[:, 0] - lo
+    srt = torch.argsort(j, stable=True)
+    rowptr = torch.zeros(hi - lo + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(j, minlength=hi - lo), 0)
+    return GraphShard(rowptr.to(torch.int32), got[srt, 1].to(torch.int32).contiguous(),
+                      None if a_shard.val is None else vgot[srt].contiguous(), lo, hi, a_shard.n_cols)
+
+
 @dataclass
 class HaloPlan:
     """Halo bookkeeping of one CSR shard (rows of A, or of A^T): which rows this rank receives from / sends to every peer and
@@ -230,6 +267,21 @@ class ShardedGCNGraph:
         return cls(slice_rows(graph.rowptr, graph.col, graph.val, lo, hi, graph.n_cols),
                    slice_rows(gt.rowptr, gt.col, gt.val, lo, hi, gt.n_cols), graph.n_rows, group, mode=mode, full=full,
                    halo_dtype=halo_dtype, perm=perm, emulate=None if emulate is None else (rank, world, graph))
+
+    @classmethod
+    def from_row_shard(cls, a_shard: GraphShard, n_nodes: int, group=None, *, mode: str = "allgather", halo_dtype: str = "f32") -> "ShardedGCNGraph":
+        """From this rank's rows of A alone (every rank calls it with its own range): the rows of A^T the backward needs come from
+        one set-up exchange (``transpose_shard``), the halo plans from the usual request collective.  No rank ever materialises the
+        whole graph — what ``bench.py --gpus N`` and any caller that generates or loads its graph by row range use.  ("alltoall"
+        mode replicates the CSR by design and is only available through ``from_global_csr``.)"""
+        if mode == "alltoall":
+            raise ValueError("mode='alltoall' needs the replicated graph: use from_global_csr")
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        ranges, _ = row_ranges(n_nodes, world)
+        if (a_shard.lo, a_shard.hi) != ranges[rank]:
+            raise ValueError(f"rank {rank} must own rows [{ranges[rank][0]}, {ranges[rank][1]})")
+        return cls(a_shard, transpose_shard(a_shard, ranges, rank, world, group), n_nodes, group, mode=mode, halo_dtype=halo_dtype)
 
     # ---- halo exchange ("halo" mode) ------------------------------------------------------------------------
     def halo_exchange(self, plan: HaloPlan, send_rows: torch.Tensor, recv_into: torch.Tensor):
