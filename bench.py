@@ -41,35 +41,90 @@ PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 PEAK_MFMA_F32_TFLOPS = 157.3  # dense f32-input MFMA peak
 
 
-def synth_features(n_rows, n_genes, device, seed):
-    """Sparse-ish log-normalised expression, standardised per gene and clipped, made on device."""
+def synth_features(n_rows, n_genes, device, seed, kind="expression"):
+    """The layer's input X, made on the device (set-up, untimed).
+    ``expression`` = SURVEY.md §8(d)'s generator: cells from 20 Gaussian clusters in a 50-d latent space pushed through a fixed random
+    50 x G map that modulates per-gene rates lambda_g ~ LogNormal(0, 1); counts ~ Poisson(rate) masked by Bernoulli(0.10); then
+    normalize_total(1e4) -> log1p -> per-gene standardisation (zero mean, unit variance over this rank's rows) clipped at 10, as
+    scdsc.py:124-126 prepares it.  The cluster centres, the map and lambda_g come from a fixed seed (shared by all ranks); the cells
+    from ``seed``.  ``randn`` = standard normal entries: the A/B that shows the matrix-core rate is not an artefact of the ~90 %
+    constant entries of a standardised sparse matrix (MFMA power is data dependent)."""
     g = torch.Generator(device=device).manual_seed(seed)
     out = torch.empty((n_rows, n_genes), dtype=torch.float32, device=device)
     step = 125_000
+    if kind == "randn":
+        for lo in range(0, n_rows, step):
+            hi = min(n_rows, lo + step)
+            out[lo:hi] = torch.randn((hi - lo, n_genes), device=device, generator=g)
+        return out
+    gs = torch.Generator(device=device).manual_seed(20240)  # structure shared by every rank
+    centres = torch.randn((20, 50), device=device, generator=gs) * 2.0
+    proj = torch.randn((50, n_genes), device=device, generator=gs) / 50**0.5
+    lam = torch.exp(torch.randn(n_genes, device=device, generator=gs))
+    s1 = torch.zeros(n_genes, dtype=torch.float64, device=device)
+    s2 = torch.zeros(n_genes, dtype=torch.float64, device=device)
     for lo in range(0, n_rows, step):
         hi = min(n_rows, lo + step)
-        u = torch.rand((hi - lo, n_genes), device=device, generator=g)
-        lam = torch.rand((hi - lo, n_genes), device=device, generator=g)
-        counts = torch.where(u < 0.10, torch.floor(lam * lam * 20.0) + 1.0, torch.zeros_like(u))
-        x = torch.log1p(counts)
-        out[lo:hi] = ((x - 0.16) / 0.55).clamp_(max=10.0)
+        z = centres[torch.randint(0, 20, (hi - lo, ), device=device, generator=g)] + torch.randn((hi - lo, 50), device=device, generator=g)
+        rate = lam[None, :] * torch.exp(0.3 * (z @ proj))
+        counts = torch.poisson(rate, generator=g) * (torch.rand((hi - lo, n_genes), device=device, generator=g) < 0.10)
+        tot = counts.sum(1, keepdim=True).clamp_(min=1.0)
+        x = torch.log1p(counts / tot * 1e4)
+        s1 += x.sum(0, dtype=torch.float64)
+        s2 += (x.double() * x.double()).sum(0)
+        out[lo:hi] = x
+    mean = s1 / n_rows
+    std = (s2 / n_rows - mean * mean).clamp_(min=1e-12).sqrt()
+    mean, inv = mean.float(), (1.0 / std).float()
+    for lo in range(0, n_rows, step):
+        hi = min(n_rows, lo + step)
+        out[lo:hi] = ((out[lo:hi] - mean) * inv).clamp_(max=10.0)
     return out
 
 
+def _mix64(x):
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap-around; logical shifts emulated with masks)."""
+    lsr = lambda z, sh: (z >> sh) & ((1 << (64 - sh)) - 1)
+    z = x + (-7046029254386353131)                # 0x9E3779B97F4A7C15
+    z = (z ^ lsr(z, 30)) * (-4658895280553007687)  # 0xBF58476D1CE4E5B9
+    z = (z ^ lsr(z, 27)) * (-7723592293110705685)  # 0x94D049BB133111EB
+    return z ^ lsr(z, 31)
+
+
+def synth_rand_graph_rows(n, k, lo, hi, device, seed):
+    """Rows [lo, hi) of 'rand-k15' (SURVEY.md §8d): k DISTINCT uniformly random in-neighbours != i per row i, sorted, value 1/k.
+    Counter-based: row i's columns are a pure function of (seed, i) — a rank generates exactly its own destination range and gets the
+    rows the whole graph would have there, so no rank of a P-GPU run ever builds (or stores) the other ranks' rows.  k + 3 hashed
+    candidates in [0, n - 1), the first k distinct ones (in generation order) taken, sorted and shifted past the diagonal; a row with fewer than k distinct
+    candidates (1e-10 at 1M x 15) is re-hashed with the next salt."""
+    rows = torch.arange(lo, hi, device=device, dtype=torch.int64)
+    m = k + 3
+    out = torch.empty((hi - lo, k), dtype=torch.int64, device=device)
+    todo = torch.arange(hi - lo, device=device)
+    salt = 0
+    while todo.numel():
+        ctr = (rows[todo, None] * m + torch.arange(m, device=device)[None, :]) + ((seed * 1024 + salt) << 40)
+        c = ((_mix64(ctr) >> 1) & ((1 << 62) - 1)) % (n - 1)
+        srt = c.sort(dim=1, stable=True)
+        dup_sorted = torch.zeros_like(c, dtype=torch.bool)
+        dup_sorted[:, 1:] = srt.values[:, 1:] == srt.values[:, :-1]
+        dup = torch.zeros_like(dup_sorted).scatter_(1, srt.indices, dup_sorted)  # back in generation order: the later copy is the duplicate
+        # the first k distinct candidates IN GENERATION ORDER (taking the k smallest would bias the columns towards 0), then sorted
+        keep = torch.argsort(dup.to(torch.int8), dim=1, stable=True)[:, :k]
+        ok = ~torch.gather(dup, 1, keep).any(dim=1)
+        c = torch.gather(c, 1, keep).sort(dim=1).values
+        out[todo[ok]] = c[ok]
+        todo = todo[~ok]
+        salt += 1
+    out = out + (out >= rows[:, None]).to(torch.int64)  # skip the diagonal (order is preserved)
+    rowptr = torch.arange(0, (hi - lo) * k + 1, k, device=device, dtype=torch.int32)
+    val = torch.full(((hi - lo) * k,), 1.0 / k, dtype=torch.float32, device=device)
+    return rowptr, out.to(torch.int32).reshape(-1).contiguous(), val
+
+
 def synth_rand_graph(n, k, device, seed):
-    """'rand-k15' (SURVEY.md §8d): k DISTINCT uniformly random in-neighbours != i per row i, sorted, value 1/k; same on all ranks.
-    Drawn from [0, n - 1) and shifted past the diagonal; the (rare) rows with a repeated draw are redrawn until none is left."""
-    g = torch.Generator(device=device).manual_seed(seed)
-    col = torch.randint(0, n - 1, (n, k), device=device, generator=g, dtype=torch.int64).sort(dim=1).values
-    while True:
-        bad = (col[:, 1:] == col[:, :-1]).any(dim=1).nonzero().reshape(-1)
-        if bad.numel() == 0:
-            break
-        col[bad] = torch.randint(0, n - 1, (bad.numel(), k), device=device, generator=g, dtype=torch.int64).sort(dim=1).values
-    col = col + (col >= torch.arange(n, device=device)[:, None]).to(torch.int64)  # skip the diagonal (order is preserved)
-    rowptr = torch.arange(0, n * k + 1, k, device=device, dtype=torch.int32)
-    val = torch.full((n * k,), 1.0 / k, dtype=torch.float32, device=device)
-    return rowptr, col.to(torch.int32).reshape(-1).contiguous(), val
+    """The whole 'rand-k15' graph (one GPU, and the "alltoall" exchange mode, which replicates the CSR by design)."""
+    return synth_rand_graph_rows(n, k, 0, n, device, seed)
 
 
 def synth_knn_graph(n, k, device, seed, reorder=True):
@@ -140,7 +195,12 @@ def cpu_baseline(sample_cells, min_seconds=10.0, max_iters=5):
         step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": n / med, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port",
+    full = None  # the same port on the WHOLE 1M-cell workload: minutes of CPU time, measured once per refresh and kept under profiles/
+    fpath = os.path.join(ROOT, "profiles", "cpu_baseline_1M.json")
+    if os.path.exists(fpath):
+        fj = json.load(open(fpath))
+        full = {"value": fj["value"], "cores": fj["cores"], "source": "profiles/cpu_baseline_1M.json (bench.py --cpu-sample-cells 1000000 on a GPU box)"}
+    return {"value": n / med, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port", "full_workload_value": full,
             "sample": f"{n} cells x {N_GENES} genes -> {N_HIDDEN}, rand k={K_NEIGH} graph, fp32, fwd+bwd, "
                       f"median of {len(times)} iterations ({med * 1e3:.0f} ms each), torch-CPU "
                       f"oracle.layers.GNNLayer",
@@ -210,6 +270,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-knn-workload", action="store_true", help="skip the second (knn-k15) timed workload at 1 GPU")
     ap.add_argument("--no-x3-row", action="store_true", help="skip the separately labelled split-bf16 GEMM row at 1 GPU")
+    ap.add_argument("--no-x-randn", action="store_true", help="skip the A/B leg with standard-normal X at 1 GPU")
     ap.add_argument("--exchange", choices=["auto", "halo", "allgather", "alltoall"], default="auto",
                     help="multi-GPU exchange (dance_amd/sharding.py); auto = time every mode, headline = the fastest")
     ap.add_argument("--emulate-rank", type=int, default=None, metavar="p",
@@ -252,11 +313,26 @@ def main():
             torch.cuda.synchronize()
 
     # ---- inputs resident in HBM before the timed region ---------------------------------------------------
-    rowptr, col, val = synth_rand_graph(n, K_NEIGH, dev, seed=1)
-    graph = CSRGraph(rowptr, col, val, n, n)
     ranges, _ = sharding.row_ranges(n, world)
     lo, hi = ranges[rank]
     n_local = hi - lo
+    # every rank generates ITS destination rows of the graph only (counter-based generator: the rows the whole graph has there); the
+    # rows of A^T come from one set-up exchange (sharding.transpose_shard).  Only the "alltoall" mode, which replicates the CSR by
+    # design, builds the whole graph.
+    graph = None
+
+    def whole_graph():
+        nonlocal graph
+        if graph is None:
+            graph = CSRGraph(*synth_rand_graph(n, K_NEIGH, dev, seed=1), n, n)
+        return graph
+
+    def make_sharded(mode):
+        if world == 1 or mode == "alltoall":
+            return sharding.ShardedGCNGraph.from_global_csr(whole_graph(), mode=mode)
+        rp, cl, vl = synth_rand_graph_rows(n, K_NEIGH, lo, hi, dev, seed=1)
+        return sharding.ShardedGCNGraph.from_row_shard(sharding.GraphShard(rp, cl, vl, lo, hi, n), n, mode=mode)
+
     x = synth_features(n_local, N_GENES, dev, seed=100 + rank)
     gen = torch.Generator(device=dev).manual_seed(2)
     bound = (6.0 / (N_GENES + N_HIDDEN))**0.5  # xavier_uniform, same W on every rank
@@ -267,7 +343,7 @@ def main():
     def make_step(sg):
         def step():
             w.grad = None
-            y = sharding.sharded_gcn_layer(x, w, sg, None, True)
+            y = sharding.sharded_gcn_layer(x, w, sg, None, True)  # (x is read at call time: the randn A/B swaps it)
             y.backward(dy)
         return step
 
@@ -282,7 +358,7 @@ def main():
         # being compared; every rank learns of a failure anywhere before the mode's figures are used
         err = None
         try:
-            sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)  # world == 1: the whole graph
+            sg = make_sharded(mode)  # world == 1: the whole graph
             elapsed, timer = time_steps(make_step(sg), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
             runs[mode] = dict(sg=sg, elapsed=elapsed, ksum=timer.summary(), bytes_per_step=sg.stats["exchanged_bytes"] / max(args.steps + args.warmup, 1))
             if world > 1:
@@ -308,8 +384,8 @@ def main():
         raise SystemExit(f"every exchange mode failed: {failed}")
     mode = min(runs, key=lambda m: runs[m]["elapsed"])
     elapsed, ksum = runs[mode]["elapsed"], runs[mode]["ksum"]
-    sg = runs[mode]["sg"] or sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
-    nnz_total = int(graph.nnz)
+    sg = runs[mode]["sg"] or make_sharded(mode)
+    nnz_total = K_NEIGH * n
 
     x3_out = None
     if world == 1 and not args.no_x3_row:
@@ -327,6 +403,20 @@ def main():
                            "6 products, fp32 accumulate; error vs float64 <= the exact kernel's, tests/test_gpu_gemm_x3.py)",
                   "ms_per_step": x_ms, "value": n / (x_elapsed / args.steps), "unit": "cells/s",
                   "kernels_ms": {k: round(v[1], 4) for k, v in sorted(x_timer.summary().items())}}
+
+    randn_out = None
+    if world == 1 and not args.no_x_randn:
+        # A/B of the input DATA, same shape, same kernels: standard-normal X instead of the standardised expression matrix
+        x_keep = x
+        x = synth_features(n_local, N_GENES, dev, seed=900, kind="randn")
+        try:
+            r_elapsed, r_timer = time_steps(make_step(sg), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
+        finally:
+            x = x_keep
+        randn_out = {"label": "A/B, not the headline: the same layer with X ~ N(0, 1) entries (matrix-core power is data dependent)",
+                     "ms_per_step": r_elapsed / args.steps * 1e3, "value": n / (r_elapsed / args.steps), "unit": "cells/s",
+                     "kernels_ms": {k: round(v[1], 4) for k, v in sorted(r_timer.summary().items())}}
+        del x_keep
 
     knn_out = None
     if world == 1 and not args.no_knn_workload:
@@ -357,7 +447,7 @@ def main():
                    "kernels_ms": {k_: round(v[1], 4) for k_, v in sorted(o_timer.summary().items())},
                    "unordered": {"ms_per_step": k_ms, "value": n / (k_elapsed / args.steps)}}
         del kg, kg_ordered
-        sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode)
+        sg = make_sharded(mode)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -411,7 +501,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"GCN layer (scDSC GNNLayer) fwd+bwd, {n} cells x {N_GENES} genes -> {N_HIDDEN}, "
-                                   f"rand-k{K_NEIGH} graph (nnz={K_NEIGH * n}), fp32",
+                                   f"rand-k{K_NEIGH} graph (nnz={K_NEIGH * n}), fp32; X = SURVEY 8(d) generator (20-cluster latent x "
+                                   f"LogNormal gene rates, Poisson counts at 10 % density, normalize_total / log1p / per-gene scale)",
                        "cells": n, "genes": N_GENES, "hidden": N_HIDDEN, "k": K_NEIGH,
                        "parallelism": f"dst-range x{world}, {mode} exchange" if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels_out,
@@ -427,6 +518,8 @@ def main():
                 out["exchange"]["failed_modes"] = failed
         if x3_out is not None:
             out["gemm_f32x3_row"] = x3_out
+        if randn_out is not None:
+            out["x_randn"] = randn_out
         if knn_out is not None:
             out["knn_k15"] = knn_out
         if world == 1 and not args.no_cpu_baseline:

@@ -534,3 +534,56 @@ def test_model_fit_loops_data_parallel_on_gloo():
     assert np.isfinite(gsc0[0]).all() and np.isfinite(gsc1[0]).all() and len(gsc0[0]) == len(gsc1[0])
     assert all(np.array_equal(a, b) for a, b in zip(sd0, sd1))
     assert prob0.shape[0] == n_cells and np.array_equal(prob0, prob1)
+
+
+def _row_shard_worker(rank, world, port, n, k, seed, q):
+    """from_row_shard (every rank holds ONLY its rows of A; A^T by the set-up exchange) against from_global_csr-style slicing."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from dance_amd import sharding
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _, _, _, _, adj = _problem(n, 4, 4, k, seed)
+        at = adj.T.tocsr()
+        at.sort_indices()
+        ranges, _ = sharding.row_ranges(n, world)
+        lo, hi = ranges[rank]
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
+        a_sh = sharding.slice_rows(t(adj.indptr, np.int32), t(adj.indices, np.int32), t(adj.data, np.float32), lo, hi, n)
+        want = sharding.slice_rows(t(at.indptr, np.int32), t(at.indices, np.int32), t(at.data, np.float32), lo, hi, n)
+        out = {}
+        for mode in ("allgather", "halo"):
+            sg = sharding.ShardedGCNGraph.from_row_shard(a_sh, n, mode=mode)
+            ref = sharding.ShardedGCNGraph(a_sh, want, n, mode=mode)
+            ok = (torch.equal(sg.at.rowptr, want.rowptr) and torch.equal(sg.at.col, want.col) and torch.equal(sg.at.val, want.val)
+                  and (sg.at.lo, sg.at.hi) == (lo, hi))
+            if mode == "halo":
+                for a, b in ((sg.halo, ref.halo), (sg.halo_t, ref.halo_t)):
+                    ok = ok and torch.equal(a.col, b.col) and torch.equal(a.remote_ids, b.remote_ids) and a.recv_counts == b.recv_counts \
+                        and torch.equal(a.send_idx, b.send_idx) and a.send_counts == b.send_counts
+            out[mode] = bool(ok)
+        try:
+            sharding.ShardedGCNGraph.from_row_shard(a_sh, n, mode="alltoall")
+            out["alltoall_rejected"] = False
+        except ValueError:
+            out["alltoall_rejected"] = True
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 101), (3, 50), (4, 37), (1, 23)])
+def test_from_row_shard_builds_the_transposed_shard_by_exchange(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_row_shard_worker, args=(r, world, port, n, 5, 3 + n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in results:
+        assert out == {"allgather": True, "halo": True, "alltoall_rejected": True}
