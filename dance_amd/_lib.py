@@ -80,6 +80,11 @@ def _declare(lib):
         "dh_sage_window_mfma_planned_supported": (c_int, [i64, i64, i64, i32, P, i64, i64]),
         "dh_sage_window_mfma_planned_workspace_bytes": (c_size_t, [i64, i64, i32]),
         "dh_sage_window_mfma_planned": (c_int, [i64, i64, i64, i64, i64, P, P, P, P, P, i64, i32, P, i64, i32, i64, P, P, P, i64, P, c_size_t, P, c_size_t, P]),
+        "dh_sage_window_splitk_plan_bytes": (c_size_t, [i64, i64, i64]),
+        "dh_sage_window_splitk_plan": (c_int, [i64, i64, i64, P, P, P, i64, P, c_size_t, P]),
+        "dh_sage_window_splitk_supported": (c_int, [i64, i64, i64, i32, P, i64, i64]),
+        "dh_sage_window_splitk_workspace_bytes": (c_size_t, [i64, i64, i64, i32]),
+        "dh_sage_window_splitk": (c_int, [i64, i64, i64, i64, i64, P, P, P, P, P, i64, i32, P, i64, i32, i64, P, P, P, i64, P, c_size_t, P, c_size_t, P]),
         "dh_sage_window_mfma": (c_int, [i64, i64, i64, i64, i64, P, P, P, P, P, i64, i32, P, i64, i32, i64, P, P, P, i64, P, c_size_t, P]),
         "dh_sage_tail": (c_int, [i64, i64, i64, i64, i64, i64, P, P, P, P, P, P, P, i64, i32, P, i64, i32, P]),
         "dh_softplus_rowsum_f32": (c_int, [i64, i64, P, i64, P, P]),

@@ -258,6 +258,28 @@ class CellGeneGraph(_MessagePassing):
         blk.edata = _Frame()
         return blk
 
+    def all_rows_block(self) -> "Block":
+        """The full-graph "block" whose destinations are ALL nodes (the CSR as it is): an inner layer of a multi-layer pass over the
+        whole graph — what the sampler's fanout -1 blocks (scdeepsort.py:183 ``[-1] * n_layers``) add up to.  With the genes-first
+        layout the gene rows [0, G) take their in-edges from the cell window [G, G + N) (``cell_window``, the split-K matrix-core
+        kernel) and the cell rows from the gene window [0, G) (``gene_window``); ``gene_rows`` = G."""
+        g = self.gene_prefix()
+        if g < 0:
+            raise ValueError("all_rows_block needs the CellFeatureGraph node layout (genes first, then cells)")
+        n = self._n_nodes
+        blk = Block.__new__(Block)
+        blk.rowptr, blk.col, blk.val = self.rowptr, self.col, self.val
+        blk._num_src, blk._num_dst = n, n
+        blk.parent, blk.dst_offset = self, 0
+        blk.gene_window, blk.cell_window, blk.gene_rows = (0, g), (g, n - g), g
+        ids = torch.arange(n, device=self.device)
+        blk.srcdata = _Frame(self.ndata)
+        blk.srcdata["_ID"] = ids
+        blk.dstdata = _Frame(self.ndata)
+        blk.dstdata["_ID"] = ids
+        blk.edata = _Frame()
+        return blk
+
     def _dst_of_slots(self) -> torch.Tensor:
         deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.int64)
         return torch.repeat_interleave(torch.arange(self._n_nodes, device=self.device), deg)

@@ -107,36 +107,87 @@ __global__ __launch_bounds__(256) void sage_bcm_prep_kernel(int64_t n_cols, int6
   }
 }
 
-// One workgroup (16 wavefronts) per group of 64 destination rows: the in-window entries of the group, sorted by chunk (window gene
-// / 32; order inside a chunk is whatever the LDS atomics give — every entry owns its own slot of the A image, so the product
-// does not depend on it), land at pent[rowptr[first row] ...) and chunk_ptr[group][c] points at chunk c's first entry
-// (chunk_ptr[group][n_chunks] = one past the last).  An entry = {element offset inside the group's A image (plane 0), the
-// weight's bits}, 8 bytes; the window gene of an entry of chunk c is 32 c + 8 (offset >> 9) + (offset & 7).
-//   Fast path (every row <= 256 stored entries, <= 16384 in the group — 10 % of 2000 genes is 200 +- 13): a wavefront owns 4 rows,
-//   a lane the entries lane, lane + 64, ... of each — 16 (column, weight) pairs per lane requested at once and kept in registers
-//   across histogram -> scan -> placement into an LDS image of the sorted list -> one coalesced write-out.  The edge list is
-//   read once, row membership needs no search.  Anything else takes the two-pass path with a row search and direct stores.
+// bounds[row][s] (s = 0 .. S) = the first stored entry of `row` whose column is >= col_begin + s * slice_cols, inside the row's
+// in-window run (the out-of-window entries — self loops — sit at the row's ends and are skipped first); bounds[row][S] = the
+// run's end.  One thread per (row, s): the plan of a sliced window finds every (row, slice) piece without walking the rows.
+__global__ __launch_bounds__(256) void sage_bcm_bounds_kernel(int64_t n_dst, int col_begin, int n_cols, int slice_cols, int S,
+                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                              int32_t* __restrict__ bounds) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_dst * (S + 1)) return;
+  const int64_t row = i / (S + 1);
+  const int sidx = (int)(i - row * (S + 1));
+  int lo = rowptr[row], hi = rowptr[row + 1];
+  while (lo < hi && (unsigned)(col[lo] - col_begin) >= (unsigned)n_cols) ++lo;
+  while (hi > lo && (unsigned)(col[hi - 1] - col_begin) >= (unsigned)n_cols) --hi;
+  if (sidx < S) {
+    const int target = sidx * slice_cols;  // window position
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (col[mid] - col_begin < target) lo = mid + 1; else hi = mid;
+    }
+  } else {
+    lo = hi;
+  }
+  bounds[i] = lo;
+}
+
+// One workgroup (16 wavefronts) per group of 64 destination rows (and, SLICED, per window slice): the group's entries with a
+// column inside the slice, sorted by chunk (position in the slice / 32; order inside a chunk is whatever the LDS atomics give —
+// every entry owns its own slot of the A image, so the product does not depend on it), land at pent[base ...) with
+// base = rowptr[first row] + (the entries of the group's rows that precede the slice), and chunk_ptr[(group, slice)][c] points at
+// chunk c's first entry (the entry behind the last chunk = one past the end).  An entry = {element offset inside the group's A
+// image (plane 0), the weight's bits}, 8 bytes; the window position of an entry of chunk c is 32 c + 8 (offset >> 9) + (offset & 7).
+//   Fast path (every row <= 256 entries in the slice, <= 16384 in the group — 10 % of 2000 columns is 200 +- 13): a wavefront owns
+//   4 rows, a lane the entries lane, lane + 64, ... of each — 16 (column, weight) pairs per lane requested at once and kept in
+//   registers across histogram -> scan -> placement into an LDS image of the sorted list -> one coalesced write-out.  The edge
+//   list is read once.  Anything else takes the two-pass path with direct stores.
 constexpr int PACK_ROWS = 4, PACK_IT = 4;  // rows per wavefront, 64-entry strides per row held in registers
-__global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int col_begin, int n_cols, int n_chunks, const int32_t* __restrict__ rowptr,
-                                                             const int32_t* __restrict__ col, const float* __restrict__ w,
+template <bool SLICED>
+__global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int col_begin, int n_cols, int slice_cols, int S,
+                                                             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                             const float* __restrict__ w, const int32_t* __restrict__ bounds,
                                                              int32_t* __restrict__ chunk_ptr, u32x2* __restrict__ pent) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  int* const rp = reinterpret_cast<int*>(smem);        // [65]
-  int* const hist = rp + 68;                           // [MAX_CHUNKS + 1]: counts, then exclusive offsets
+  int* const rlo = reinterpret_cast<int*>(smem);       // [64] the rows' first entry in the slice
+  int* const rhi = rlo + 64;                           // [64] ... and one past their last
+  int* const hist = rhi + 64;                          // [MAX_CHUNKS + 1]: counts, then exclusive offsets
   int* const cursor = hist + MAX_CHUNKS + 4;           // [MAX_CHUNKS]
-  int* const flag = cursor + MAX_CHUNKS;               // [4]: a row too long for the register path
-  u32x2* const s_ent = reinterpret_cast<u32x2*>(flag + 4);  // [PACK_CAP] {offset in the A image, hi | lo << 16}
+  int* const misc = cursor + MAX_CHUNKS;               // [4]: {a row too long for the register path, entries before the slice, entries in it}
+  u32x2* const s_ent = reinterpret_cast<u32x2*>(misc + 4);  // [PACK_CAP] {offset in the A image, weight bits}
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int sl = SLICED ? (int)blockIdx.y : 0;
   const int64_t c0 = (int64_t)blockIdx.x * 64;
-  if (tid <= 64) rp[tid] = rowptr[min(c0 + tid, n_dst)];
+  const int wbeg = col_begin + sl * slice_cols;                  // first column of the slice
+  const int wn = min(slice_cols, n_cols - sl * slice_cols);      // its width
+  const int n_chunks = (wn + 31) >> 5, cps1 = (slice_cols >> 5) + 1;
   for (int i = tid; i < MAX_CHUNKS + 1; i += 1024) hist[i] = 0;
   for (int i = tid; i < MAX_CHUNKS; i += 1024) cursor[i] = 0;
-  if (tid < 4) flag[tid] = 0;
+  if (tid < 4) misc[tid] = 0;
   __syncthreads();
-  const int base = rp[0], end = rp[64];
-  if (tid < 64 && rp[tid + 1] - rp[tid] > 64 * PACK_IT) flag[0] = 1;
+  if (tid < 64) {
+    const int64_t row = c0 + tid;
+    int lo = 0, hi = 0, before = 0;
+    if (row < n_dst) {
+      const int rs = rowptr[row];
+      if (SLICED) {
+        lo = bounds[row * (S + 1) + sl];
+        hi = bounds[row * (S + 1) + sl + 1];
+      } else {
+        lo = rs;
+        hi = rowptr[row + 1];
+      }
+      before = lo - rs;
+    }
+    rlo[tid] = lo;
+    rhi[tid] = hi;
+    if (hi - lo > 64 * PACK_IT) misc[0] = 1;
+    atomicAdd(&misc[1], before);
+    atomicAdd(&misc[2], hi - lo);
+  }
   __syncthreads();
-  const bool fast = flag[0] == 0 && end - base <= PACK_CAP;  // block-uniform
+  const int base = rowptr[min(c0, n_dst)] + misc[1];
+  const bool fast = misc[0] == 0 && misc[2] <= PACK_CAP;  // block-uniform
 
   auto scan_and_publish = [&]() {
     __syncthreads();
@@ -155,7 +206,8 @@ __global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int 
     }
     __syncthreads();
     const int total = hist[MAX_CHUNKS];
-    for (int i = tid; i <= n_chunks; i += 1024) chunk_ptr[(int64_t)blockIdx.x * (n_chunks + 1) + i] = base + (i < n_chunks ? hist[i] : total);
+    int32_t* cp = chunk_ptr + ((int64_t)blockIdx.x * S + sl) * cps1;
+    for (int i = tid; i < cps1; i += 1024) cp[i] = base + (i < n_chunks ? hist[i] : total);
     return total;
   };
   auto pack = [&](int g, float wv_e, int row, uint32_t& idx, uint32_t& hl) {
@@ -169,12 +221,12 @@ __global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int 
     float wq[PACK_ROWS][PACK_IT];
 #pragma unroll
     for (int rr = 0; rr < PACK_ROWS; ++rr) {
-      const int rs = rp[PACK_ROWS * wv + rr], re = rp[PACK_ROWS * wv + rr + 1];
+      const int rs = rlo[PACK_ROWS * wv + rr], re = rhi[PACK_ROWS * wv + rr];
 #pragma unroll
       for (int it = 0; it < PACK_IT; ++it) {
         const int e = rs + lane + 64 * it;
         const bool ok = e < re;
-        gq[rr][it] = ok ? col[e] - col_begin : -1;
+        gq[rr][it] = ok ? col[e] - wbeg : -1;
         wq[rr][it] = ok ? w[e] : 0.f;
       }
     }
@@ -182,14 +234,14 @@ __global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int 
     for (int rr = 0; rr < PACK_ROWS; ++rr)
 #pragma unroll
       for (int it = 0; it < PACK_IT; ++it)
-        if ((unsigned)gq[rr][it] < (unsigned)n_cols) atomicAdd(&hist[gq[rr][it] >> 5], 1);
+        if ((unsigned)gq[rr][it] < (unsigned)wn) atomicAdd(&hist[gq[rr][it] >> 5], 1);
     const int total = scan_and_publish();
 #pragma unroll
     for (int rr = 0; rr < PACK_ROWS; ++rr)
 #pragma unroll
       for (int it = 0; it < PACK_IT; ++it) {
         const int g = gq[rr][it];
-        if ((unsigned)g >= (unsigned)n_cols) continue;
+        if ((unsigned)g >= (unsigned)wn) continue;
         uint32_t idx, hl;
         pack(g, wq[rr][it], PACK_ROWS * wv + rr, idx, hl);
         const int pos = hist[g >> 5] + atomicAdd(&cursor[g >> 5], 1);
@@ -199,50 +251,109 @@ __global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int 
     for (int i = tid; i < total; i += 1024) pent[(int64_t)base + i] = s_ent[i];
     return;
   }
-  // general path: two passes over the group's entries, the row of an entry by bisection, direct (scattered) stores
-  for (int e = base + tid; e < end; e += 1024) {
-    const int g = col[e] - col_begin;
-    if ((unsigned)g < (unsigned)n_cols) atomicAdd(&hist[g >> 5], 1);
-  }
-  scan_and_publish();
-  for (int e = base + tid; e < end; e += 1024) {
-    const int g = col[e] - col_begin;
-    if ((unsigned)g >= (unsigned)n_cols) continue;
-    int lo = 0, hi = 64;  // the row of entry e: the last r with rp[r] <= e
-    while (hi - lo > 1) {
-      const int mid = (lo + hi) >> 1;
-      if (rp[mid] <= e) lo = mid; else hi = mid;
+  // general path: two passes over the rows' pieces, direct (scattered) stores
+  for (int rr = 0; rr < 64; ++rr)
+    for (int e = rlo[rr] + tid; e < rhi[rr]; e += 1024) {
+      const int g = col[e] - wbeg;
+      if ((unsigned)g < (unsigned)wn) atomicAdd(&hist[g >> 5], 1);
     }
-    uint32_t idx, hl;
-    pack(g, w[e], lo, idx, hl);
-    const int pos = hist[g >> 5] + atomicAdd(&cursor[g >> 5], 1);
-    pent[(int64_t)base + pos] = u32x2{idx, hl};
+  scan_and_publish();
+  for (int rr = 0; rr < 64; ++rr)
+    for (int e = rlo[rr] + tid; e < rhi[rr]; e += 1024) {
+      const int g = col[e] - wbeg;
+      if ((unsigned)g >= (unsigned)wn) continue;
+      uint32_t idx, hl;
+      pack(g, w[e], rr, idx, hl);
+      const int pos = hist[g >> 5] + atomicAdd(&cursor[g >> 5], 1);
+      pent[(int64_t)base + pos] = u32x2{idx, hl};
+    }
+}
+
+// neigh[row, c] = 1 / deg(row) * ( rowscale[row] * sum over the sets of partial[set][row][c]  +  the out-of-window in-edges with the
+// alpha rule of gnn.py:72-76 ), the shares summed in set order (deterministic)
+template <bool HBF16, bool OBF16>
+__global__ __launch_bounds__(256) void sage_bcm_reduce_kernel(int64_t n_dst, int64_t width, int Dp, int n_sets, int col_begin, int n_cols,
+                                                              const float* __restrict__ partial, const float* __restrict__ rowscale,
+                                                              const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                              const float* __restrict__ w, const void* __restrict__ Hraw, int64_t ldh,
+                                                              const int32_t* __restrict__ src_id, const int32_t* __restrict__ dst_id,
+                                                              const float* __restrict__ alpha, int n_genes, void* __restrict__ neigh, int64_t ldn) {
+  const int64_t row = blockIdx.x;
+  const int rs = rowptr[row], re = rowptr[row + 1];
+  int s0 = rs, e0 = re;
+  while (s0 < e0 && (unsigned)(col[s0] - col_begin) >= (unsigned)n_cols) ++s0;
+  while (e0 > s0 && (unsigned)(col[e0 - 1] - col_begin) >= (unsigned)n_cols) --e0;
+  const float inv = re > rs ? 1.f / (float)(re - rs) : 0.f;
+  const float rsc = rowscale ? rowscale[row] : 1.f;
+  const int did = dst_id[row];
+  for (int64_t c = threadIdx.x; c < width; c += 256) {
+    float v = 0.f;
+    for (int s = 0; s < n_sets; ++s) v += partial[((int64_t)s * n_dst + row) * Dp + c];
+    v *= rsc;
+    for (int part = 0; part < 2; ++part)  // the out-of-window entries: [rs, s0) and [e0, re)
+      for (int e = part ? e0 : rs; e < (part ? re : s0); ++e) {
+        const int u = col[e];
+        const int sid = src_id[u];
+        int idx = n_genes + 1;
+        if (sid >= 0 && did < 0) idx = sid;
+        if (did >= 0 && sid < 0) idx = did;
+        if (did >= 0 && sid >= 0) idx = n_genes;
+        const float hv = HBF16 ? widen(static_cast<const uint16_t*>(Hraw)[(int64_t)u * ldh + c]) : static_cast<const float*>(Hraw)[(int64_t)u * ldh + c];
+        v = fmaf(w[e] * alpha[idx], hv, v);
+      }
+    v *= inv;
+    if (OBF16) static_cast<uint16_t*>(neigh)[row * ldn + c] = (uint16_t)f32_to_bf16(v);
+    else static_cast<float*>(neigh)[row * ldn + c] = v;
   }
 }
 
 // NT = ceil(tiles / 4): a wave holds NT or NT - 1 column tiles (wave-uniform; the step loop is instantiated for both)
-template <bool HBF16, bool OBF16, int NT>
+// SPLITK (gene <- cell: few destination rows, a window of up to millions of columns): the window is cut into slices of `slice_cols`
+// = 2048 columns (64 chunks; the plan holds the packed entries and chunk pointers per 64-row group AND slice, a group's slices one
+// behind the other), set s (see set_id) owns `slices_per_set` consecutive slices, runs the loop over them as ONE long K range and
+// writes its fp32 share to partial[set][row][Dp]; sage_bcm_reduce_kernel sums the shares in order and adds the row scale, the mean
+// and the out-of-window edges.  No column scale in this mode (gnn.py:74: a cell -> gene edge takes alpha of the DESTINATION gene).
+// The feature blocks of a set are read by its 16 row blocks in near lockstep: the first one's loads bring a block from HBM, the
+// others find it in the XCD's L2 (the set -> XCD mapping below).  Touching blocks ahead of time and walking the blocks in a different
+// order per row block (to spread simultaneous requests over the L2 channels) were both tried and both cost 3 - 6 %
+// (profiles/r04y_sage_splitk_ab.json): the one-step lead of the movers is enough.  What does matter: every LDS region behind the
+// chunk-pointer table must start on a 16-byte boundary — with an 8-byte offset every 16-byte LDS access of the loop is split and
+// the step takes 8500 cycles instead of 2800.
+template <bool HBF16, bool OBF16, int NT, bool SPLITK>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void sage_bcm_kernel(
-    int64_t n_dst, int64_t width, int col_begin, int n_cols, int J, int n_chunks, int Dp, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ colscale, const int32_t* __restrict__ chunk_ptr,
-    const u32x2* __restrict__ pent,
-    const uint16_t* __restrict__ HsP, void* __restrict__ neigh, int64_t ldn, int64_t nnz, int step_bytes,
-    const void* __restrict__ Hraw, int64_t ldh, const int32_t* __restrict__ src_id, const int32_t* __restrict__ dst_id,
-    const float* __restrict__ alpha, int n_genes) {
+    int64_t n_dst, int64_t width, int col_begin, int n_cols, int slice_cols, int n_slices, int slices_per_set, int cptr_stride, int Dp,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ w, const float* __restrict__ colscale,
+    const int32_t* __restrict__ chunk_ptr, const u32x2* __restrict__ pent, const uint16_t* __restrict__ HsP, void* __restrict__ neigh,
+    int64_t ldn, int64_t nnz, int step_bytes, const void* __restrict__ Hraw, int64_t ldh, const int32_t* __restrict__ src_id,
+    const int32_t* __restrict__ dst_id, const float* __restrict__ alpha, int n_genes, float* __restrict__ partial) {
   constexpr int P = HBF16 ? 1 : 2;
+  const int cps1 = (slice_cols >> 5) + 1;  // chunk pointers per group and slice in the plan
   constexpr int HS = HBF16 ? 2 : 4;  // bytes per feature
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // persistent through the epilogue: rowinfo, ends.  Loop: chunk pointers, staging, A images, B ring; epilogue: the row buffer over them.
   f32x4_t* const rowinfo = reinterpret_cast<f32x4_t*>(smem);                 // [128] {1 / deg, f0, bits(u0), bits(n_tail)}
   int* const ends = reinterpret_cast<int*>(rowinfo + 128);                   // [128][2]: in-window run [s0, e0)
   unsigned char* const scratch = reinterpret_cast<unsigned char*>(ends + 256);
-  int* const cptr = reinterpret_cast<int*>(scratch);                         // [2 groups][MAX_CHUNKS + 4]
-  float* const cs = reinterpret_cast<float*>(cptr + 2 * (MAX_CHUNKS + 4));          // [n_cols rounded to 4]: colscale of the window genes
-  uint16_t* const a_img = reinterpret_cast<uint16_t*>(cs + ((n_cols + 3) & ~3));    // [2 buffers][2 groups][IMG]  // [2 buffers][2 groups][IMG]
+  int* const cptr = reinterpret_cast<int*>(scratch);                         // [2 groups][cptr_stride]: the chunk pointers of this workgroup's slices
+  float* const cs = reinterpret_cast<float*>(cptr + 2 * cptr_stride);        // [slice_cols]: colscale of the window columns (not SPLITK)
+  uint16_t* const a_img = reinterpret_cast<uint16_t*>(cs + (SPLITK ? 0 : slice_cols));  // [2 buffers][2 groups][IMG]
   unsigned char* const b_img = reinterpret_cast<unsigned char*>(a_img + 2 * 2 * IMG);  // [3 slots][step_bytes]
   unsigned char* const rowbuf = scratch;                                     // epilogue: [64 rows][width * HS] (16-byte pieces, row-linear)
 
   PROF_T(t_start);
+  // SPLITK: a 1-D grid whose workgroups i, i + 8, i + 16, ... share an XCD (and its L2): the row blocks of one set are neighbours
+  // THERE, so the set's feature blocks come out of HBM once and are read by its row blocks from L2
+  const int row_blocks = (int)((n_dst + 127) / 128);
+  const int rb_id = SPLITK ? (int)((blockIdx.x >> 3) % row_blocks) : (int)blockIdx.x;
+  const int set_id = SPLITK ? (int)((blockIdx.x >> 3) / row_blocks) * 8 + (int)(blockIdx.x & 7) : 0;
+  if (SPLITK && set_id * slices_per_set >= n_slices) return;  // (the grid rounds the sets up to a multiple of 8)
+  // this workgroup's part of the window: slices [sl0, sl1) = columns [col0, col0 + wn) = J MFMA steps = n_chunks chunks.  A slice has
+  // its own chunk-pointer row in the plan (cps1 entries, the last one = the slice's end), so chunk c's pointer sits at c + c / (cps1 - 1)
+  const int sl0 = set_id * slices_per_set, sl1 = SPLITK ? min(n_slices, sl0 + slices_per_set) : 1;
+  const int wn = SPLITK ? min(n_cols, sl1 * slice_cols) - sl0 * slice_cols : n_cols;
+  const int J = (wn + 15) / 16, n_chunks = (J + JC - 1) / JC;
+  const unsigned char* const hsp = reinterpret_cast<const unsigned char*>(HsP) + (int64_t)sl0 * (slice_cols / 16) * step_bytes;
+  auto ci = [&](int c) __attribute__((always_inline)) { return SPLITK ? c + (c >> 6) : c; };
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wq = wave & 3;
@@ -252,17 +363,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int my_tiles = tbase + extra(wq);
   int tile0 = wq * tbase;
   for (int q = 0; q < wq; ++q) tile0 += extra(q);
-  const int64_t cell0 = (int64_t)blockIdx.x * 128 + grp * 64;  // first cell of the group
+  const int64_t cell0 = (int64_t)rb_id * 128 + grp * 64;  // first cell of the group
   const int li = wq * 64 + lane;                               // this lane's entry slot inside a chunk's list (0 .. 255)
 
   // ---- prologue -----------------------------------------------------------------------------------------------------------
-  {
-    const int64_t grp_id = (int64_t)blockIdx.x * 2 + grp;
-    const bool live_grp = grp_id * 64 < n_dst;
-    for (int i = li; i <= n_chunks; i += 256) cptr[grp * (MAX_CHUNKS + 4) + i] = live_grp ? chunk_ptr[grp_id * (n_chunks + 1) + i] : 0;
-  }
-  for (int i = tid; i < n_cols; i += 512) cs[i] = colscale ? colscale[i] : 1.f;
-  if (wq == 0) {  // per-row table of the group's 64 cells
+  const int64_t grp_id = (int64_t)rb_id * 2 + grp;
+  const bool live_grp = grp_id * 64 < n_dst;
+  for (int i = li; i < (sl1 - sl0) * cps1; i += 256)  // the chunk pointers of (group, slices sl0 .. sl1 - 1)
+    cptr[grp * cptr_stride + i] = live_grp ? chunk_ptr[(grp_id * n_slices + sl0) * cps1 + i] : 0;
+  if (!SPLITK)
+    for (int i = tid; i < wn; i += 512) cs[i] = colscale ? colscale[i] : 1.f;
+  if (!SPLITK && wq == 0) {  // per-row table of the group's 64 cells
     const int cl = grp * 64 + lane;
     const int64_t my_cell = cell0 + lane;
     int s0 = 0, e0 = 0;
@@ -327,7 +438,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const uint32_t voff = (uint32_t)lane * 16;
   auto b_load_part = [&](int j, auto lo_c, auto hi_c) __attribute__((always_inline)) {  // pieces [LO, HI) of this mover's NPM
     constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
-    const unsigned char* blk = reinterpret_cast<const unsigned char*>(HsP) + (int64_t)j * step_bytes;
+    const unsigned char* blk = hsp + (int64_t)j * step_bytes;
 #pragma unroll
     for (int s = LO; s < HI; ++s) {
       const unsigned char* base = blk + (size_t)min(mrank + 4 * s, pieces - 1) * 1024;  // wave-uniform: scalar base + lane offset
@@ -343,15 +454,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int eli = (wq & 1) * 64 + lane;  // entry waves: this lane's first entry slot (the second is eli + 128)
   u32x2 ent[2] = {{0u, 0u}, {0u, 0u}};
   auto ent_load = [&](int c) __attribute__((always_inline)) {  // (lanes beyond the list read a neighbour, unused)
-    const int64_t e = (int64_t)cptr[grp * (MAX_CHUNKS + 4) + c] + eli;
+    const int64_t e = (int64_t)cptr[grp * cptr_stride + ci(c)] + eli;
     ent[0] = __builtin_nontemporal_load(pent + min(e, nnz - 1));
     ent[1] = __builtin_nontemporal_load(pent + min(e + 128, nnz - 1));
   };
   // this lane's entries of chunk c (in `ent`) -> A buffer c & 1 (cleared one step earlier): a = w * colscale[gene] split into bf16
   // hi + lo (the residual 2^-18 |a|), two 2-byte stores each
   auto put = [&](uint16_t* img, int c, u32x2 en) __attribute__((always_inline)) {
-    const int g = min(32 * c + (int)(en[0] >> 9) * 8 + (int)(en[0] & 7), n_cols - 1);
-    const float a = __uint_as_float(en[1]) * cs[g];
+    float a = __uint_as_float(en[1]);
+    if (!SPLITK) a *= cs[min(32 * c + (int)(en[0] >> 9) * 8 + (int)(en[0] & 7), wn - 1)];
     const unsigned int ahi = f32_to_bf16(a);
     const unsigned int alo = f32_to_bf16(a - widen(ahi));
     img[en[0]] = (uint16_t)ahi;
@@ -359,8 +470,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   auto scatter = [&](int c) __attribute__((always_inline)) {
     uint16_t* const img = a_img + (size_t)((c & 1) * 2 + grp) * IMG;
-    const int first = cptr[grp * (MAX_CHUNKS + 4) + c];
-    const int len = cptr[grp * (MAX_CHUNKS + 4) + c + 1] - first;
+    const int first = cptr[grp * cptr_stride + ci(c)];
+    const int len = cptr[grp * cptr_stride + ci(c) + 1] - first;
 #pragma unroll
     for (int q = 0; q < 2; ++q)
       if (eli + 128 * q < len) put(img, c, ent[q]);
@@ -375,22 +486,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     z[li] = u32x4(0u);
     z[li + 256] = u32x4(0u);
   };
-
-  clear(0);
-  clear(1);
-  __syncthreads();  // chunk pointers, row table, cleared images
-  if (!mover && n_chunks > 0) {
-    ent_load(0);
-    scatter(0);
-  }
-  if (mover && J > 0) {  // block 0 straight into its slot; block 1 waits in the registers for step 0's store
-    b_load(0);
-    b_store(0);
-  }
-  if (mover && J > 1) b_load(1);
-  __syncthreads();  // chunk 0 of both groups and feature block 0 are in place
-  PROF_T(t_pro);
-  PROF_ADD(0, t_start, t_pro);
 
   bf16x8_t fa[2][2];
   auto read_a = [&](int j) __attribute__((always_inline)) {  // the A fragments of step j: chunk j / JC -> buffer, j % JC -> slot
@@ -530,8 +625,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       TLP(5);  // fragments read, entries scattered, feature pieces stored and requested: at the barrier
       __syncthreads();
 #ifdef DH_SB_PROF
-      if (blockIdx.x == TL_BLOCK && j >= TL_J0 && j < TL_J0 + TL_STEPS && lane == 0)
-        for (int k = 0; k < TL_PROBES; ++k) dh_sb_timeline[wave][j - TL_J0][k] = tl[k];
+      if (blockIdx.x == (SPLITK ? 100 : TL_BLOCK) && j >= (SPLITK ? 1000 : TL_J0) && j < (SPLITK ? 1000 : TL_J0) + TL_STEPS && lane == 0)
+        for (int k = 0; k < TL_PROBES; ++k) dh_sb_timeline[wave][j - (SPLITK ? 1000 : TL_J0)][k] = tl[k];
 #endif
     };
     using I0 = std::integral_constant<int, 0>;
@@ -554,12 +649,50 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (LAG && J > 0) mma(J - 1, [](auto) {});
   };
-  if (grp == 0) {
-    if (my_tiles == NT) run(std::integral_constant<int, NT>{}, std::integral_constant<int, 0>{});
-    else run(std::integral_constant<int, (NT > 0 ? NT - 1 : 0)>{}, std::integral_constant<int, 0>{});
-  } else {
-    if (my_tiles == NT) run(std::integral_constant<int, NT>{}, std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, (NT > 0 ? NT - 1 : 0)>{}, std::integral_constant<int, 1>{});
+  auto start_slice = [&]() __attribute__((always_inline)) {  // cleared images, chunk 0 scattered, feature block 0 in LDS, block 1 in registers
+    clear(0);
+    clear(1);
+    __syncthreads();  // chunk pointers, column scales, (row table,) cleared images
+    if (!mover && n_chunks > 0) {
+      ent_load(0);
+      scatter(0);
+    }
+    if (mover && J > 0) {  // block 0 straight into its slot; block 1 waits in the registers for step 0's store
+      b_load(0);
+      b_store(0);
+    }
+    if (mover && J > 1) b_load(1);
+    __syncthreads();  // chunk 0 of both groups and feature block 0 are in place
+  };
+  auto run_slice = [&]() __attribute__((always_inline)) {
+    if (grp == 0) {
+      if (my_tiles == NT) run(std::integral_constant<int, NT>{}, std::integral_constant<int, 0>{});
+      else run(std::integral_constant<int, (NT > 0 ? NT - 1 : 0)>{}, std::integral_constant<int, 0>{});
+    } else {
+      if (my_tiles == NT) run(std::integral_constant<int, NT>{}, std::integral_constant<int, 1>{});
+      else run(std::integral_constant<int, (NT > 0 ? NT - 1 : 0)>{}, std::integral_constant<int, 1>{});
+    }
+  };
+  start_slice();
+  run_slice();
+  if (SPLITK) {
+    // this set's share of the window product, fp32, rows Dp wide; scales / mean / out-of-window edges are the reduce kernel's
+    auto store_partial = [&](auto mt_c) __attribute__((always_inline)) {
+      constexpr int MT = decltype(mt_c)::value;
+      static_for<2 * (MT > 0 ? MT : 0)>([&](auto t_c) __attribute__((always_inline)) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int m = t / (MT > 0 ? MT : 1), y = t % (MT > 0 ? MT : 1);
+        const int c = (tile0 + y) * 32 + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t cell = cell0 + 32 * m + (i & 3) + 8 * (i >> 2) + 4 * half;
+          if (cell < n_dst) partial[((int64_t)set_id * n_dst + cell) * Dp + c] = acc[m][y][i];
+        }
+      });
+    };
+    if (my_tiles == NT) store_partial(std::integral_constant<int, NT>{});
+    else store_partial(std::integral_constant<int, (NT > 0 ? NT - 1 : 0)>{});
+    return;
   }
 
   PROF_T(t_epi);
@@ -621,7 +754,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const f32x4_t ri = rowinfo[rl];
     const int n_tail = __float_as_int(ri[3]);
     if (n_tail < 2) continue;  // wave-uniform
-    const int64_t cell = (int64_t)blockIdx.x * 128 + rl;
+    const int64_t cell = (int64_t)rb_id * 128 + rl;
     const int rs = rowptr[cell];
     const int s0 = ends[2 * rl], e0 = ends[2 * rl + 1];
     const int did = dst_id[cell];
@@ -665,12 +798,12 @@ GeoB geometry_b(int64_t n_dst, int64_t n_cols, int64_t width, bool hbf16) {
   g.prep_bytes = ((size_t)g.J * g.step_bytes + 255) / 256 * 256;
   g.cptr_bytes = ((size_t)dh::ceil_div(n_dst, 64) * (g.n_chunks + 1) * 4 + 255) / 256 * 256;
   const int npm = hbf16 ? g.nt : 2 * g.nt;  // pieces per mover wave and step (the kernel's NPM)
-  const size_t loop = (size_t)2 * (MAX_CHUNKS + 4) * 4 + (size_t)((n_cols + 3) / 4 * 4) * 4 + (size_t)2 * 2 * IMG * 2 + (size_t)3 * npm * 4096;
+  const size_t loop = (size_t)2 * (MAX_CHUNKS + 4) * 4 + (size_t)32 * g.n_chunks * 4 + (size_t)2 * 2 * IMG * 2 + (size_t)3 * npm * 4096;
   const size_t epi = (size_t)64 * width * (hbf16 ? 2 : 4) + 1024;
   g.lds_bytes = 128 * 16 + 256 * 4 + (loop > epi ? loop : epi);
   return g;
 }
-constexpr size_t PACK_LDS = (68 + MAX_CHUNKS + 4 + MAX_CHUNKS + 4) * 4 + (size_t)PACK_CAP * 8;
+constexpr size_t PACK_LDS = (64 + 64 + MAX_CHUNKS + 4 + MAX_CHUNKS + 4) * 4 + (size_t)PACK_CAP * 8;
 
 }  // namespace
 
@@ -708,11 +841,11 @@ int sage_bcm_plan(int64_t n_dst, int64_t col_begin, int64_t n_cols, const int32_
   const GeoB g = geometry_b(n_dst, n_cols, 32, false);
   int32_t* chunk_ptr = static_cast<int32_t*>(plan);
   u32x2* pent = reinterpret_cast<u32x2*>(static_cast<char*>(plan) + g.cptr_bytes);
-  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_bcm_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_bcm_pack_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              160 * 1024) == hipSuccess;
   if (!ok) return fail(DH_ERR_LAUNCH, "dh_sage_window_plan: cannot raise the dynamic LDS limit");
-  hipLaunchKernelGGL(sage_bcm_pack_kernel, dim3((unsigned)ceil_div(n_dst, 64)), dim3(1024), PACK_LDS, st, n_dst, (int)col_begin, (int)n_cols,
-                     g.n_chunks, rowptr, col, w, chunk_ptr, pent);
+  hipLaunchKernelGGL(sage_bcm_pack_kernel<false>, dim3((unsigned)ceil_div(n_dst, 64)), dim3(1024), PACK_LDS, st, n_dst, (int)col_begin, (int)n_cols,
+                     32 * g.n_chunks, 1, rowptr, col, w, (const int32_t*)nullptr, chunk_ptr, pent);
   return check_launch("dh_sage_window_plan");
 }
 
@@ -733,13 +866,12 @@ int sage_bcm_launch(int64_t n_dst, int64_t width, int64_t col_begin, int64_t n_c
   const unsigned grid = (unsigned)ceil_div(n_dst, 128);
 #define DH_SB(HB, OB, NTV)                                                                                                         \
   do {                                                                                                                             \
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_bcm_kernel<HB, OB, NTV>),                        \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_bcm_kernel<HB, OB, NTV, false>),                 \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;              \
     if (!ok) return fail(DH_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", me);                                             \
-    hipLaunchKernelGGL((sage_bcm_kernel<HB, OB, NTV>), dim3(grid), dim3(512), g.lds_bytes, st, n_dst, width, (int)col_begin,        \
-                       (int)n_cols, g.J, g.n_chunks, g.Dp, rowptr, col, w, colscale, chunk_ptr, pent, HsP, neigh, ldn, nnz,           \
-                       g.step_bytes,                                                                                               \
-                       H, ldh, src_cell_id, dst_cell_id, alpha, (int)n_genes);                                                     \
+    hipLaunchKernelGGL((sage_bcm_kernel<HB, OB, NTV, false>), dim3(grid), dim3(512), g.lds_bytes, st, n_dst, width, (int)col_begin, \
+                       (int)n_cols, 32 * g.n_chunks, 1, 1, MAX_CHUNKS + 4, g.Dp, rowptr, col, w, colscale, chunk_ptr, pent, HsP, neigh, ldn, nnz,    \
+                       g.step_bytes, H, ldh, src_cell_id, dst_cell_id, alpha, (int)n_genes, (float*)nullptr);                      \
   } while (0)
 #define DH_SBN(HB, OB)                                                                                                             \
   do {                                                                                                                             \
@@ -757,4 +889,153 @@ int sage_bcm_launch(int64_t n_dst, int64_t width, int64_t col_begin, int64_t n_c
   return check_launch(me);
 }
 
+
 }  // namespace dh
+
+/* ---- windows too wide for one pass (gene <- cell: 2000 destination rows, a window of every cell) --------------------------------------
+ * The same loop with the K dimension cut into slices of SPLIT_COLS columns and the slices dealt to `sets` of workgroups; see
+ * sage_bcm_kernel<.., SPLITK>.  Plan = [chunk pointers per (64-row group, slice)] [row bounds per (row, slice)] [packed entries]. */
+namespace {
+
+constexpr int SPLIT_COLS = 2048;  // 64 chunks (the kernel's chunk-pointer index c + c / 64 knows): 10 % density gives a row ~205 entries per slice (the pack kernel's register path holds 256)
+
+struct GeoS {
+  GeoB b;  // of ONE slice: LDS plan, Dp, nt, step_bytes
+  int S, n_sets, slices_per_set, row_blocks, cps1, cptr_stride;
+  int64_t J_total;
+  size_t cptr_bytes, bounds_bytes, prep_bytes, partial_bytes;
+};
+GeoS geometry_s(int64_t n_dst, int64_t n_cols, int64_t width, bool hbf16) {
+  GeoS g;
+  g.b = geometry_b(n_dst, n_cols < SPLIT_COLS ? n_cols : SPLIT_COLS, width, hbf16);
+  g.S = (int)dh::ceil_div(n_cols, (int64_t)SPLIT_COLS);
+  g.row_blocks = (int)dh::ceil_div(n_dst, (int64_t)128);
+  // one workgroup per CU (256 of them), in whole multiples of 8 sets (a set's row blocks share an XCD), no more sets than slices
+  int sets = 256 / g.row_blocks / 8 * 8;
+  if (sets < 8) sets = 8;
+  if (sets > g.S) sets = g.S;
+  g.slices_per_set = (g.S + sets - 1) / sets;
+  g.n_sets = (g.S + g.slices_per_set - 1) / g.slices_per_set;
+  g.cps1 = SPLIT_COLS / 32 + 1;
+  g.J_total = (n_cols + 15) / 16;
+  g.cptr_bytes = ((size_t)dh::ceil_div(n_dst, 64) * g.S * g.cps1 * 4 + 255) / 256 * 256;
+  g.bounds_bytes = ((size_t)n_dst * (g.S + 1) * 4 + 255) / 256 * 256;
+  g.prep_bytes = ((size_t)g.J_total * g.b.step_bytes + 255) / 256 * 256;
+  g.partial_bytes = (size_t)g.n_sets * n_dst * g.b.Dp * 4;
+  g.cptr_stride = (g.slices_per_set * g.cps1 + 4 + 3) / 4 * 4;  // (a multiple of 16 bytes: the A images and feature slots behind the table are read 16 bytes at a time)
+  g.b.lds_bytes = 128 * 16 + 256 * 4 + (size_t)2 * g.cptr_stride * 4 + (size_t)2 * 2 * IMG * 2 +
+                  (size_t)3 * (hbf16 ? g.b.nt : 2 * g.b.nt) * 4096;
+  return g;
+}
+bool splitk_fits(int64_t n_dst, int64_t n_cols, int64_t width, int64_t nnz) {
+  return n_dst > 0 && n_dst <= 65536 && n_cols > 0 && n_cols < ((int64_t)1 << 30) && width > 0 && width <= 512 && nnz >= 2 && nnz < ((int64_t)1 << 31);
+}
+
+}  // namespace
+
+extern "C" size_t dh_sage_window_splitk_plan_bytes(int64_t n_dst, int64_t n_cols, int64_t nnz) {
+  if (!splitk_fits(n_dst, n_cols, 32, nnz)) return 0;
+  const GeoS g = geometry_s(n_dst, n_cols, 32, false);
+  return g.cptr_bytes + g.bounds_bytes + (size_t)nnz * 8;
+}
+
+extern "C" int dh_sage_window_splitk_plan(int64_t n_dst, int64_t col_begin, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                                          const float* w, int64_t nnz, void* plan, size_t plan_bytes, dh_stream_t stream) {
+  const char* me = "dh_sage_window_splitk_plan";
+  if (n_dst < 0 || col_begin < 0 || n_cols <= 0 || nnz < 0) return dh::fail(DH_ERR_INVALID, "%s: bad size", me);
+  if (n_dst == 0) return DH_OK;
+  if (!rowptr || !col || !w || !plan) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (!splitk_fits(n_dst, n_cols, 32, nnz)) return dh::fail(DH_ERR_INVALID, "%s: %lld rows / %lld columns / %lld entries not supported", me, (long long)n_dst, (long long)n_cols, (long long)nnz);
+  const GeoS g = geometry_s(n_dst, n_cols, 32, false);
+  const size_t need = g.cptr_bytes + g.bounds_bytes + (size_t)nnz * 8;
+  if (plan_bytes < need) return dh::fail(DH_ERR_WORKSPACE, "%s: plan buffer %zu < %zu bytes", me, plan_bytes, need);
+  hipStream_t st = dh::as_stream(stream);
+  int32_t* chunk_ptr = static_cast<int32_t*>(plan);
+  int32_t* bounds = reinterpret_cast<int32_t*>(static_cast<char*>(plan) + g.cptr_bytes);
+  u32x2* pent = reinterpret_cast<u32x2*>(static_cast<char*>(plan) + g.cptr_bytes + g.bounds_bytes);
+  const int64_t nb = n_dst * (g.S + 1);
+  hipLaunchKernelGGL(sage_bcm_bounds_kernel, dim3((unsigned)dh::ceil_div(nb, (int64_t)256)), dim3(256), 0, st, n_dst, (int)col_begin, (int)n_cols,
+                     SPLIT_COLS, g.S, rowptr, col, bounds);
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_bcm_pack_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             160 * 1024) == hipSuccess;
+  if (!ok) return dh::fail(DH_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", me);
+  hipLaunchKernelGGL(sage_bcm_pack_kernel<true>, dim3((unsigned)dh::ceil_div(n_dst, (int64_t)64), (unsigned)g.S), dim3(1024), PACK_LDS, st, n_dst,
+                     (int)col_begin, (int)n_cols, SPLIT_COLS, g.S, rowptr, col, w, bounds, chunk_ptr, pent);
+  return dh::check_launch(me);
+}
+
+extern "C" int dh_sage_window_splitk_supported(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype, const void* H, int64_t ldh, int64_t nnz) {
+  (void)H;
+  (void)ldh;
+  if (!splitk_fits(n_dst, n_cols, width, nnz)) return 0;
+  return geometry_s(n_dst, n_cols, width, h_dtype == DH_DTYPE_BF16).b.lds_bytes <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" size_t dh_sage_window_splitk_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype) {
+  if (!splitk_fits(n_dst, n_cols, width, 2)) return 0;
+  const GeoS g = geometry_s(n_dst, n_cols, width, h_dtype == DH_DTYPE_BF16);
+  return g.prep_bytes + g.partial_bytes;
+}
+
+extern "C" int dh_sage_window_splitk(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols, const int32_t* rowptr,
+                                     const int32_t* col, const float* w, const float* rowscale, const void* H, int64_t ldh,
+                                     int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
+                                     const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha, int64_t n_genes,
+                                     const void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  const char* me = "dh_sage_window_splitk";
+  if (n_dst < 0 || n_src < 0 || width < 0 || col_begin < 0 || n_cols < 0 || nnz < 0) return dh::fail(DH_ERR_INVALID, "%s: negative size", me);
+  if (n_dst == 0 || width == 0) return DH_OK;
+  if (!rowptr || !col || !w || !H || !neigh || !plan || !workspace) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (!src_cell_id || !dst_cell_id || !alpha) return dh::fail(DH_ERR_INVALID, "%s: src_cell_id, dst_cell_id and alpha are required (the out-of-window edges are folded in)", me);
+  if (ldh < width || ldn < width) return dh::fail(DH_ERR_INVALID, "%s: leading dimension < width", me);
+  if ((h_dtype != DH_DTYPE_F32 && h_dtype != DH_DTYPE_BF16) || (out_dtype != DH_DTYPE_F32 && out_dtype != DH_DTYPE_BF16)) return dh::fail(DH_ERR_INVALID, "%s: bad dtype", me);
+  if (n_cols <= 0 || col_begin + n_cols > n_src) return dh::fail(DH_ERR_INVALID, "%s: window beyond the source rows", me);
+  const bool hb = h_dtype == DH_DTYPE_BF16, ob = out_dtype == DH_DTYPE_BF16;
+  if (!dh_sage_window_splitk_supported(n_dst, n_cols, width, h_dtype, H, ldh, nnz)) return dh::fail(DH_ERR_INVALID, "%s: shape not supported (see dh_sage_window_splitk_supported)", me);
+  const GeoS g = geometry_s(n_dst, n_cols, width, hb);
+  if (plan_bytes < g.cptr_bytes + g.bounds_bytes + (size_t)nnz * 8) return dh::fail(DH_ERR_WORKSPACE, "%s: plan buffer %zu too small", me, plan_bytes);
+  if (workspace_bytes < g.prep_bytes + g.partial_bytes) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, workspace_bytes, g.prep_bytes + g.partial_bytes);
+  hipStream_t st = dh::as_stream(stream);
+  uint16_t* HsP = static_cast<uint16_t*>(workspace);
+  float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + g.prep_bytes);
+  const int32_t* chunk_ptr = static_cast<const int32_t*>(plan);
+  const u32x2* pent = reinterpret_cast<const u32x2*>(static_cast<const char*>(plan) + g.cptr_bytes + g.bounds_bytes);
+  const char* Hw = static_cast<const char*>(H) + (size_t)col_begin * ldh * (hb ? 2 : 4);
+  const unsigned pgrid = (unsigned)dh::ceil_div(g.J_total * 2 * g.b.Dp, (int64_t)256);
+  const int64_t step_elems = g.b.step_bytes / 2;
+  if (hb) hipLaunchKernelGGL(sage_bcm_prep_kernel<true>, dim3(pgrid), dim3(256), 0, st, n_cols, width, (int)g.J_total, g.b.Dp, Hw, ldh, HsP, step_elems);
+  else hipLaunchKernelGGL(sage_bcm_prep_kernel<false>, dim3(pgrid), dim3(256), 0, st, n_cols, width, (int)g.J_total, g.b.Dp, Hw, ldh, HsP, step_elems);
+  const unsigned grid = (unsigned)(((g.n_sets + 7) / 8) * 8 * g.row_blocks);
+#define DH_SK(HB, NTV)                                                                                                             \
+  do {                                                                                                                             \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(sage_bcm_kernel<HB, false, NTV, true>),               \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;              \
+    if (!ok) return dh::fail(DH_ERR_LAUNCH, "%s: cannot raise the dynamic LDS limit", me);                                         \
+    hipLaunchKernelGGL((sage_bcm_kernel<HB, false, NTV, true>), dim3(grid), dim3(512), g.b.lds_bytes, st, n_dst, width,            \
+                       (int)col_begin, (int)n_cols, SPLIT_COLS, g.S, g.slices_per_set, g.cptr_stride, g.b.Dp, rowptr, col, w, (const float*)nullptr, chunk_ptr, \
+                       pent, HsP, (void*)nullptr, (int64_t)0, nnz, g.b.step_bytes, H, ldh, src_cell_id, dst_cell_id, alpha,         \
+                       (int)n_genes, partial);                                                                                     \
+  } while (0)
+#define DH_SKN(HB)                                                                                                                 \
+  do {                                                                                                                             \
+    if (g.b.nt == 1) DH_SK(HB, 1);                                                                                                 \
+    else if (g.b.nt == 2) DH_SK(HB, 2);                                                                                            \
+    else if (g.b.nt == 3) DH_SK(HB, 3);                                                                                            \
+    else DH_SK(HB, 4);                                                                                                             \
+  } while (0)
+  if (hb) DH_SKN(true);
+  else DH_SKN(false);
+#undef DH_SKN
+#undef DH_SK
+  if (int rc = dh::check_launch(me)) return rc;
+#define DH_RED(HB, OB)                                                                                                             \
+  hipLaunchKernelGGL((sage_bcm_reduce_kernel<HB, OB>), dim3((unsigned)n_dst), dim3(256), 0, st, n_dst, width, g.b.Dp, g.n_sets,     \
+                     (int)col_begin, (int)n_cols, partial, rowscale, rowptr, col, w, H, ldh, src_cell_id, dst_cell_id, alpha,       \
+                     (int)n_genes, neigh, ldn)
+  if (hb && ob) DH_RED(true, true);
+  else if (hb) DH_RED(true, false);
+  else if (ob) DH_RED(false, true);
+  else DH_RED(false, false);
+#undef DH_RED
+  return dh::check_launch(me);
+}

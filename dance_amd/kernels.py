@@ -940,7 +940,7 @@ def sage_mfma_supported(n_cols: int, width: int, dtype) -> bool:
     return bool(_lib_ready().dh_sage_window_mfma_supported(int(n_cols), int(width), _out_dtype(dtype)))
 
 
-def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *, out_dtype=None) -> torch.Tensor:
+def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *, out_dtype=None, out=None) -> torch.Tensor:
     """AdaptiveSAGE mean aggregation for CELL destinations (the result of ``sage_aggregate``) with the gene window
     [col_begin, col_begin + n_cols) of H on the matrix cores and no dense adjacency in HBM (dh_sage_window_mfma: the
     workgroup densifies 128 cells x 128 genes at a time in LDS); the other in-edges (self loops, at the rows' ends) are
@@ -952,7 +952,7 @@ def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_
     a = alpha.reshape(-1)
     colscale = a[src_cell_id[col_begin:col_begin + n_cols].clamp(min=0).to(torch.int64)].contiguous()  # gnn.py:73
     n_dst = rowptr.numel() - 1
-    out = torch.empty((n_dst, H.shape[1]), dtype=out_dtype, device=H.device)
+    out = _sage_out(out, n_dst, H, out_dtype)
     planned = (n_dst >= SAGE_BCM_MIN_ROWS or os.environ.get("DANCE_AMD_SAGE_MFMA", "") == "bcm") and os.environ.get("DANCE_AMD_SAGE_MFMA", "") != "v1"
     if planned and lib.dh_sage_window_mfma_planned_supported(n_dst, n_cols, H.shape[1], _out_dtype(H.dtype), H.data_ptr(), _ld(H), col.numel()):
         # unsplit launches (the full graph, large batches): the two-waves-per-SIMD kernel over a repacked ("block-chunk-major") copy of
@@ -979,28 +979,80 @@ def sage_aggregate_mfma(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_
     return out
 
 
+def _sage_out(out, n_dst, H, out_dtype):
+    """The result buffer of a window aggregation: fresh, or the caller's rows (a slice of a larger result: rows contiguous, any row stride)."""
+    if out is None:
+        return torch.empty((n_dst, H.shape[1]), dtype=out_dtype, device=H.device)
+    if out.shape != (n_dst, H.shape[1]) or out.dtype != out_dtype or out.device != H.device or out.stride(1) != 1:
+        raise ValueError(f"out must be a [{n_dst}, {H.shape[1]}] {out_dtype} tensor on {H.device} with contiguous rows")
+    return out
+
+
 _SAGE_PLANS = None  # graph.TensorKeyedCache: col tensor -> (extra key, plan bytes); dies with the tensor
 
 
-def _sage_plan(rowptr, col, w, col_begin: int, n_cols: int) -> torch.Tensor:
-    """dh_sage_window_plan of (rowptr, col, w), cached by the identity + version of the three tensors (never by data_ptr)."""
+def _sage_plan(rowptr, col, w, col_begin: int, n_cols: int, kind: str = "window") -> torch.Tensor:
+    """dh_sage_window_plan (kind "window") or dh_sage_window_splitk_plan ("splitk") of (rowptr, col, w), cached by the identity +
+    version of the three tensors (never by data_ptr)."""
     global _SAGE_PLANS
     from .graph import TensorKeyedCache
+    import weakref
     if _SAGE_PLANS is None:
         _SAGE_PLANS = TensorKeyedCache()
-    extra = (id(rowptr), rowptr._version, rowptr.numel(), id(w), w._version, int(col_begin), int(n_cols))
-    hit = _SAGE_PLANS.get(col, extra)
-    if hit is not None and hit[0]() is rowptr and hit[1]() is w:
+
+    def ident(t):  # a view (block.rowptr_dst is a fresh slice on every access) is known by its base tensor + offset + length
+        base = t._base if t._base is not None else t
+        return base, (id(base), base._version, t.storage_offset(), t.numel())
+
+    plans = _SAGE_PLANS.get(col)  # the plans made of this col tensor (dropped when it changes or dies): key -> (rowptr base, w base, plan)
+    if plans is None:
+        plans = _SAGE_PLANS.put(col, {})
+    (rbase, rkey), (wbase, wkey) = ident(rowptr), ident(w)
+    key = (kind, rkey, wkey, int(col_begin), int(n_cols))
+    hit = plans.get(key)
+    if hit is not None and hit[0]() is rbase and hit[1]() is wbase:
         return hit[2]
-    import weakref
     lib = _lib_ready()
     n_dst = rowptr.numel() - 1
-    nbytes = lib.dh_sage_window_plan_bytes(n_dst, n_cols, col.numel())
+    size_fn, plan_fn = ((lib.dh_sage_window_plan_bytes, lib.dh_sage_window_plan) if kind == "window" else
+                        (lib.dh_sage_window_splitk_plan_bytes, lib.dh_sage_window_splitk_plan))
+    nbytes = size_fn(n_dst, n_cols, col.numel())
+    if nbytes == 0:
+        raise ValueError(f"sage plan ({kind}): {n_dst} rows x {n_cols} window columns, {col.numel()} entries not supported")
     plan = torch.empty(nbytes, dtype=torch.uint8, device=col.device)
-    _call("sage_window_plan", lib.dh_sage_window_plan, n_dst, col_begin, n_cols, _dev(rowptr, torch.int32, "rowptr", 1),
+    _call(f"sage_{kind}_plan", plan_fn, n_dst, col_begin, n_cols, _dev(rowptr, torch.int32, "rowptr", 1),
           _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1), col.numel(), plan.data_ptr(), nbytes, _stream())
-    _SAGE_PLANS.put(col, (weakref.ref(rowptr), weakref.ref(w), plan), extra)
+    plans[key] = (weakref.ref(rbase), weakref.ref(wbase), plan)
     return plan
+
+
+def sage_splitk_supported(n_dst: int, n_cols: int, width: int, dtype, nnz: int) -> bool:
+    return bool(_lib_ready().dh_sage_window_splitk_supported(int(n_dst), int(n_cols), int(width), _out_dtype(dtype), None, 0, int(nnz)))
+
+
+def sage_aggregate_splitk(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H, col_begin: int, n_cols: int, *, out_dtype=None, out=None) -> torch.Tensor:
+    """AdaptiveSAGE mean aggregation (the result of ``sage_aggregate``) for FEW destinations with very long rows — the gene nodes,
+    ~1e5 cell in-neighbours each — whose CELL sources are the window [col_begin, col_begin + n_cols) of H (dh_sage_window_splitk: the
+    window is the K dimension of the matrix-core loop, split over the chip; no dense adjacency).  The window's sources must all be
+    cells (cell_id < 0): an in-window edge then carries alpha[cell_id of the destination] for a gene destination, the cell-cell
+    alpha otherwise (gnn.py:72-76) — one scale per destination row."""
+    lib = _lib_ready()
+    out_dtype = out_dtype or H.dtype
+    a = alpha.reshape(-1).float().contiguous()
+    n_genes = a.numel() - 2
+    did = dst_cell_id.to(torch.int64)
+    rowscale = torch.where(did >= 0, a[did.clamp(min=0)], a[n_genes + 1]).contiguous()
+    n_dst = rowptr.numel() - 1
+    out = _sage_out(out, n_dst, H, out_dtype)
+    plan = _sage_plan(rowptr, col, w, col_begin, n_cols, "splitk")
+    ws_bytes = lib.dh_sage_window_splitk_workspace_bytes(n_dst, n_cols, H.shape[1], _out_dtype(H.dtype))
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=H.device)
+    _call("sage_window_splitk", lib.dh_sage_window_splitk, n_dst, H.shape[0], H.shape[1], col_begin, n_cols,
+          _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1), _dev(w, torch.float32, "w", 1),
+          _dev(rowscale, torch.float32, "rowscale", 1), _dev(H, H.dtype, "H", 2), _ld(H), _out_dtype(H.dtype), out.data_ptr(), _ld(out),
+          _out_dtype(out_dtype), col.numel(), _dev(src_cell_id, torch.int32, "src_cell_id", 1), _dev(dst_cell_id, torch.int32, "dst_cell_id", 1),
+          _dev(a, torch.float32, "alpha", 1), n_genes, plan.data_ptr(), plan.numel(), ws.data_ptr(), ws_bytes, _stream())
+    return out
 
 
 def sage_alpha_grad(rowptr, col, w, src_cell_id, dst_cell_id, n_genes, H, dneigh) -> torch.Tensor:

@@ -263,13 +263,16 @@ class ScDeepSort(BaseClassificationMethod):
 
     @torch.no_grad()
     def _full_graph_logits(self, graph):
-        """Logits of every cell from ONE pass over the graph (see ``full_graph_eval``); None when that mode does not apply
-        (more than one layer, or a node order other than CellFeatureGraph's genes-first)."""
-        if not self.full_graph_eval or self.n_layers != 1 or graph.gene_prefix() < 0:
+        """Logits of every cell from ONE pass over the graph (see ``full_graph_eval``); None when that mode does not apply (a node
+        order other than CellFeatureGraph's genes-first).  With L layers the inner L - 1 layers update EVERY node (what the
+        sampler's fanout -1 blocks reach from any cell: all its genes, then all their cells, scdeepsort.py:183) — their gene rows
+        aggregate ~1e5 cells each through the split-K matrix-core kernel — and the last layer the cell rows."""
+        if not self.full_graph_eval or graph.gene_prefix() < 0:
             return None
         self.model.eval()
         blk = graph.cell_rows_block()
-        return self.model([blk], blk.srcdata["features"])
+        inner = [graph.all_rows_block()] * (self.n_layers - 1)
+        return self.model(inner + [blk], blk.srcdata["features"])
 
     @torch.no_grad()
     def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0, *, _logits=None):

@@ -26,7 +26,17 @@ class _SageAggregateFn(torch.autograd.Function):
         # fp32 features whose aggregation enters the output (use_neigh=True) take the exact gather: the matrix-core kernel feeds
         # fp32 operands as bf16 hi + lo pairs (1e-5 relative per term), which is not the function the backward below differentiates
         exact = differentiated and h.dtype == torch.float32
-        if (win is not None and win[1] > 0 and kernels.SAGE_MODE == "mfma" and not exact and h.shape[1] % 4 == 0
+        gr = getattr(block, "gene_rows", 0)
+        if (gr and win is not None and kernels.SAGE_MODE == "mfma" and not exact and h.shape[1] % 4 == 0
+                and kernels.sage_mfma_supported(win[1], h.shape[1], h.dtype)
+                and kernels.sage_splitk_supported(gr, block.cell_window[1], h.shape[1], h.dtype, block.col.numel())):
+            # every node is a destination (CellGeneGraph.all_rows_block): the gene rows take the cells as the K dimension of the
+            # split-K matrix-core kernel, the cell rows the gene window — both without a dense adjacency, into one result
+            hc, a32, rp = h.contiguous(), alpha.detach().float(), block.rowptr_dst
+            neigh = torch.empty((block.number_of_dst_nodes(), h.shape[1]), dtype=h.dtype, device=h.device)
+            kernels.sage_aggregate_splitk(rp[:gr + 1], block.col, block.val, cid_src, cid_dst[:gr], a32, hc, *block.cell_window, out=neigh[:gr])
+            kernels.sage_aggregate_mfma(rp[gr:], block.col, block.val, cid_src, cid_dst[gr:], a32, hc, win[0], win[1], out=neigh[gr:])
+        elif (not gr and win is not None and win[1] > 0 and kernels.SAGE_MODE == "mfma" and not exact and h.shape[1] % 4 == 0
                 and kernels.sage_mfma_supported(win[1], h.shape[1], h.dtype)):
             # cell destinations whose gene rows are a known window of the sources: the matrix-core kernel (one launch)
             neigh = kernels.sage_aggregate_mfma(block.rowptr_dst, block.col, block.val, cid_src, cid_dst, alpha.detach().float(), h.contiguous(),

@@ -488,6 +488,30 @@ DH_API int dh_sage_window_mfma_planned(int64_t n_dst, int64_t n_src, int64_t wid
                                 int64_t ldh, int h_dtype, void* neigh, int64_t ldn, int out_dtype, int64_t nnz,
                                 const int32_t* src_cell_id, const int32_t* dst_cell_id, const float* alpha, int64_t n_genes,
                                 const void* plan, size_t plan_bytes, void* workspace, size_t workspace_bytes, dh_stream_t stream);
+/* The other direction of the same layer — GENE destinations (gnn.py:74: a cell -> gene edge carries alpha[cell_id of the destination
+ * gene]; a 2-layer scDeepSort, scdeepsort.py:183 `[-1] * L`, aggregates into its gene nodes every pass): few rows (n_dst <= 65536; 2000
+ * genes), each with ~1e5 in-edges from a window [col_begin, col_begin + n_cols) of up to 2^30 source rows (every cell).  The window
+ * is the K dimension of the matrix-core loop of dh_sage_window_mfma_planned, cut into slices of 2048 columns that are dealt to up to
+ * 256 workgroups (a set of slices per workgroup, the workgroups of one set on one XCD so that they share its L2 for the feature
+ * blocks); the fp32 shares are summed in set order by a second kernel (deterministic), which also applies
+ *     neigh[v,:] = 1/deg(v) * ( rowscale[v] * sum_{in-window e=(u->v)} w_e H[u,:]  +  sum_{other e} alpha[idx(e)] w_e H[u,:] )
+ * with idx(e) the rule of dh_sage_aggregate_f32 for the out-of-window in-edges (the self loops).  rowscale may be NULL (= 1).
+ * No dense copy of the adjacency (2000 x 1e6 fp32 = 8 GB) is ever formed.  fp32 features and the weights enter as bf16 hi + lo pairs
+ * (three products per term, fp32 accumulation: ~1e-5 relative per term); bf16 features exactly.
+ * dh_sage_window_splitk_plan repacks the in-window entries once per graph (8 bytes per stored entry + pointer tables, depends on
+ * rowptr / col / w only); workspace = the feature planes of the window + the shares.  Precondition as above: inside a row the
+ * in-window edges are contiguous and ascending by column. */
+DH_API size_t dh_sage_window_splitk_plan_bytes(int64_t n_dst, int64_t n_cols, int64_t nnz);
+DH_API int dh_sage_window_splitk_plan(int64_t n_dst, int64_t col_begin, int64_t n_cols, const int32_t* rowptr, const int32_t* col,
+                               const float* w, int64_t nnz, void* plan, size_t plan_bytes, dh_stream_t stream);
+DH_API int dh_sage_window_splitk_supported(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype, const void* H, int64_t ldh,
+                                    int64_t nnz);
+DH_API size_t dh_sage_window_splitk_workspace_bytes(int64_t n_dst, int64_t n_cols, int64_t width, int h_dtype);
+DH_API int dh_sage_window_splitk(int64_t n_dst, int64_t n_src, int64_t width, int64_t col_begin, int64_t n_cols, const int32_t* rowptr,
+                          const int32_t* col, const float* w, const float* rowscale, const void* H, int64_t ldh, int h_dtype,
+                          void* neigh, int64_t ldn, int out_dtype, int64_t nnz, const int32_t* src_cell_id,
+                          const int32_t* dst_cell_id, const float* alpha, int64_t n_genes, const void* plan, size_t plan_bytes,
+                          void* workspace, size_t workspace_bytes, dh_stream_t stream);
 DH_API int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t width, int64_t n_genes,
                            const int32_t* rowptr, const int32_t* col, const float* w,
                            const int32_t* src_cell_id, const int32_t* dst_cell_id,

@@ -155,6 +155,21 @@ def main():
             ms=msm, bound="mfma", achieved=fl / msm / 1e9, peak=2500.0, unit="TFLOP/s (bf16 MFMA, dense-equivalent incl. the split planes)",
             frac=fl / msm / 1e9 / 2500.0, cells_per_s=n_cells / msm * 1e3,
             speedup_vs_gather=(ms if tag == "f32" else ms16) / msm)
+    # the other direction: the 2000 gene rows of ~1e5 cell in-edges each (dh_sage_window_splitk: the cells as the K dimension, split
+    # over the chip); the plan (one repack of the rows, graph only) is cached across calls and timed apart
+    rp_genes, cid_genes = rowptr[:n_genes + 1], cid[:n_genes]
+    for tag, ft, planes in (("f32", feats, 3), ("bf16", feats16, 2)):
+        fng = lambda: kernels.sage_aggregate_splitk(rp_genes, gcol, gval, cid, cid_genes, alpha, ft, n_genes, n_cells)
+        msm = gpu_ms(fng, iters=3)
+        fl = 2.0 * n_cells * n_genes * dfeat * planes
+        rows[f"sage_window_splitk {tag} gene<-cell full graph cells={n_cells} D={dfeat} edges={nnz + n_genes}"] = dict(
+            ms=msm, bound="mfma", achieved=fl / msm / 1e9, peak=2500.0, unit="TFLOP/s (bf16 MFMA, dense-equivalent incl. the split planes)",
+            frac=fl / msm / 1e9 / 2500.0, speedup_vs_all_nodes_gather=ms_all / msm,
+            note="round 3: these rows cost 56.9 ms inside the all-nodes gather (one wavefront per row)")
+    ms_all2 = gpu_ms(lambda: (kernels.sage_aggregate_splitk(rp_genes, gcol, gval, cid, cid_genes, alpha, feats, n_genes, n_cells),
+                              kernels.sage_aggregate_mfma(rp_cells, gcol, gval, cid, cid_cells, alpha, feats, 0, n_genes)), iters=3)
+    rows[f"AdaptiveSAGE aggregation of ALL nodes f32 (split-K gene rows + gene-window cell rows) cells={n_cells}"] = dict(
+        ms=ms_all2, speedup_vs_all_nodes_gather=ms_all / ms_all2)
     PEAK_BF16 = 2500.0  # TFLOP/s dense (MI355X_MICROARCH.md)
     hid = 200
     h16 = feats16[n_genes:]  # [n_cells, 400] cell rows

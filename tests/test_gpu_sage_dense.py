@@ -153,6 +153,46 @@ def test_dense_gene_rows(cuda_device, dtype):
         assert rel_err(got.float().cpu().numpy(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n_cells,n_genes,width,density", [
+    (20_000, 60, 128, 0.1),      # 10 slices, one 64-row group
+    (5_000, 203, 400, 0.1),      # ragged last slice (5000 = 2 * 2048 + 904), four groups, a ragged row block, 13 column tiles
+    (1_500, 130, 64, 0.3),       # a window narrower than one slice; rows of ~450 in-window entries: the pack kernel's general path
+    (70_000, 33, 200, 0.05),     # more slices (35) than sets: several slices per workgroup
+    (300, 3, 8, 0.5),            # tiny everything
+])
+def test_splitk_gene_rows(cuda_device, dtype, n_cells, n_genes, width, density):
+    """dh_sage_window_splitk (gene destinations, the cells as the K dimension, no dense adjacency) against the float64 restatement of
+    gnn.py:62-90 and the gather kernel; the plan is cached per graph and the result does not change from call to call."""
+    from dance_amd import kernels
+    rowptr, col, w, cid, dst_cid = _gene_rows(n_cells, n_genes, density, 11)
+    rng = np.random.default_rng(5)
+    h = torch.from_numpy(rng.standard_normal((n_genes + n_cells, width)).astype(np.float32)).to(DEV)
+    alpha = (rng.random(n_genes + 2) + 0.5).astype(np.float32)
+    if dtype == "bf16":
+        h = h.to(torch.bfloat16)
+    t = lambda a: torch.from_numpy(a).to(DEV)
+    args = (t(rowptr), t(col), t(w), t(cid), t(dst_cid), t(alpha), h)
+    assert kernels.sage_splitk_supported(n_genes, n_cells, width, h.dtype, col.size)
+    got = kernels.sage_aggregate_splitk(*args, n_genes, n_cells)
+    ref = _ref(rowptr, col, w, cid, dst_cid, alpha.astype(np.float64), h.float().cpu().numpy(), n_genes)
+    assert got.dtype == h.dtype and got.shape == (n_genes, width)
+    if dtype == "f32":
+        old = kernels.sage_aggregate(*args)
+        assert rel_err(old.cpu().numpy(), ref) < 1e-5
+        assert rel_err(got.cpu().numpy(), ref) < 2e-5
+    else:
+        assert rel_err(got.float().cpu().numpy(), ref) < 1e-2
+    again = kernels.sage_aggregate_splitk(*args, n_genes, n_cells)       # second call: the cached plan, same bits
+    assert torch.equal(got, again)
+    # a window that starts and ends inside the cell rows: the entries outside it are NOT part of this call's sum apart from the
+    # out-of-window rule (they take the alpha of their own index) — compare with the reference on the same graph
+    if n_cells >= 5000 and dtype == "f32":
+        lo, n = n_genes + 777, n_cells - 1500
+        part = kernels.sage_aggregate_splitk(*args, lo, n)
+        assert rel_err(part.cpu().numpy(), ref) < 2e-5
+
+
 def test_densify_window_direct(cuda_device):
     """Row / column scales, mean, padding and window clipping of dh_csr_densify_window against scipy."""
     import scipy.sparse as sp

@@ -148,6 +148,37 @@ def test_full_graph_eval_equals_block_eval(cuda_device, tmp_path):
     assert torch.allclose(neigh_full[-last.shape[0]:], last, rtol=1e-5, atol=1e-6)
 
 
+def test_two_layer_full_graph_eval(cuda_device, tmp_path):
+    """Two AdaptiveSAGE layers (scdeepsort.py:183 ``[-1] * n_layers``): the full-graph pass updates every node in the inner layer —
+    its gene rows through dh_sage_window_splitk, its cell rows through dh_sage_window_mfma — and gives the statistics / probabilities
+    of the batch-by-batch loop over two-hop sampled blocks; the inner layer's aggregation equals the gather kernel on the whole CSR."""
+    from dance_amd import kernels
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    n_cells, n_genes, d = 2600, 90, 24
+    x, g = _graph(n_cells, n_genes, d, 5, cuda_device)
+    labels = torch.from_numpy(np.random.default_rng(1).integers(0, 4, n_cells))
+    model = ScDeepSort(d, 16, 2, "synthetic", "fg2", batch_size=512, device="cuda", save_root=tmp_path, verbose=False)
+    model.shuffle_generator = torch.Generator().manual_seed(0)
+    model.fit(g, labels, epochs=1, lr=1e-2)
+    with torch.no_grad():
+        model.model.alpha.copy_(torch.rand_like(model.model.alpha) + 0.5)  # (never trained in the reference: make the scales visible)
+    gg = g.to("cuda")
+    gg.ndata["label"] = torch.cat((-torch.ones(n_genes, dtype=torch.long), labels)).to(cuda_device)
+    idx = torch.arange(n_genes + 50, n_genes + 2000, device=cuda_device)
+    full = model.evaluate(gg, idx)
+    prob_full = model.predict_proba(g)
+    neigh0 = model.model.layers[0].last_neigh.clone()
+    assert neigh0.shape == (n_genes + n_cells, d)
+    cid = gg.ndata["cell_id"]
+    ref = kernels.sage_aggregate(gg.rowptr, gg.col, gg.val, cid, cid, model.model.alpha.detach().reshape(-1).float(),
+                                 gg.ndata["features"].contiguous())
+    assert rel_err(neigh0[:n_genes].cpu().numpy(), ref[:n_genes].cpu().numpy()) < 2e-5     # gene rows: split-K
+    assert rel_err(neigh0[n_genes:].cpu().numpy(), ref[n_genes:].cpu().numpy()) < 2e-5     # cell rows: gene window
+    model.full_graph_eval = False
+    assert model.evaluate(gg, idx) == full
+    assert np.abs(prob_full - model.predict_proba(g)).max() < 1e-6
+
+
 def test_scdeepsort_captured_step_equals_eager(cuda_device, tmp_path, monkeypatch):
     """ScDeepSort.fit with every full training batch replayed from ONE captured hipGraph (static-shape cell block, AdaptiveSAGE's
     discarded aggregation included, loss, backward, capturable Adam) ends with the parameters of the eager loop (same seeds: the

@@ -15,9 +15,9 @@ LIB = os.path.join(ROOT, "dance_amd", "libdancehip.so")
 KNOWN_VGPR_SPILLS = {
     "gemm_f32_kernel<Cfg<2, 4, 4, 2>, true, true,": "the transposed-transposed GEMM variant: no caller on the model paths",
     "knn_filter_small_kernel<13>": "small-k kNN filter at its widest candidate list (next-round item 6)",
-    "sage_bcm_kernel<false, false, 4>": "fp32 features, 13 - 16 column tiles: 8 dwords of loop-invariant addresses spilled ONCE before the loop "
+    "sage_bcm_kernel<false, false, 4,": "fp32 features, 13 - 16 column tiles: 8 dwords of loop-invariant addresses spilled ONCE before the loop "
                                         "(the allocation is dictated by the 4-tile mover path, which holds 8 feature pieces)",
-    "sage_bcm_kernel<false, true, 4>": "same kernel, bf16 output",
+    "sage_bcm_kernel<false, true, 4,": "same kernel, bf16 output",
 }
 
 
