@@ -9,6 +9,7 @@ from torch import nn
 
 from ....autograd import gcn_layer, zinb_nll
 from ....graph import as_graph
+from ....sharding import ShardedGCNGraph, allreduce_sum_gradients, broadcast_parameters, sharded_batch_norm, sharded_gcn_layer
 
 
 class GNNLayer(nn.Module):
@@ -21,6 +22,8 @@ class GNNLayer(nn.Module):
         torch.nn.init.xavier_uniform_(self.weight)
 
     def forward(self, features, adj, active=True):
+        if isinstance(adj, ShardedGCNGraph):  # destination-range shard of the graph: features = this rank's rows (sharding.py)
+            return sharded_gcn_layer(features, self.weight, adj, None, bool(active), ops=getattr(adj, "ops", None))
         # relu(spmm(adj, mm(features, weight))): MFMA GEMM + fused-ReLU CSR SpMM (dance_amd/autograd.py)
         return gcn_layer(features, self.weight, as_graph(adj, features.device), None, bool(active))
 
@@ -66,16 +69,26 @@ class AE(nn.Module):
             setattr(self, bn, nn.BatchNorm1d(o))
         self.x_bar_layer = HipLinear(n_dec_3, n_input)
 
+    # Row-sharded training (ScDSC.fit over a ShardedGCNGraph): x is this rank's rows of a batch of ``rows_total`` rows; the batch
+    # statistics of every BatchNorm are then those of all rows (sharding.sharded_batch_norm).  None: the modules as they are.
+    rows_total, group = None, None
+
+    def _bn(self, bn, h):
+        if self.rows_total is None:
+            return bn(h)
+        return sharded_batch_norm(bn, h, self.rows_total, self.group)
+
     def forward(self, x):
-        enc_h1 = F.relu(self.BN1(self.enc_1(x)))
-        enc_h2 = F.relu(self.BN2(self.enc_2(enc_h1)))
-        enc_h3 = F.relu(self.BN3(self.enc_3(enc_h2)))
-        z1 = self.BN4(self.z1_layer(enc_h3))
-        z2 = self.BN5(self.z2_layer(z1))
-        z3 = self.BN6(self.z3_layer(z2))
-        dec_h1 = F.relu(self.BN7(self.dec_1(z3)))
-        dec_h2 = F.relu(self.BN8(self.dec_2(dec_h1)))
-        dec_h3 = F.relu(self.BN9(self.dec_3(dec_h2)))
+        bn = self._bn
+        enc_h1 = F.relu(bn(self.BN1, self.enc_1(x)))
+        enc_h2 = F.relu(bn(self.BN2, self.enc_2(enc_h1)))
+        enc_h3 = F.relu(bn(self.BN3, self.enc_3(enc_h2)))
+        z1 = bn(self.BN4, self.z1_layer(enc_h3))
+        z2 = bn(self.BN5, self.z2_layer(z1))
+        z3 = bn(self.BN6, self.z3_layer(z2))
+        dec_h1 = F.relu(bn(self.BN7, self.dec_1(z3)))
+        dec_h2 = F.relu(bn(self.BN8, self.dec_2(dec_h1)))
+        dec_h3 = F.relu(bn(self.BN9, self.dec_3(dec_h2)))
         return self.x_bar_layer(dec_h3), enc_h1, enc_h2, enc_h3, z3, z2, z1, dec_h3
 
 
@@ -110,7 +123,8 @@ class ScDSCModel(nn.Module):
     def forward(self, x, adj):
         x_bar, tra1, tra2, tra3, z3, z2, z1, dec_h3 = self.ae(x)
         sigma = self.sigma
-        adj = as_graph(adj, x.device)  # CSR (+ transpose) built once, reused by all 7 layers and every epoch
+        if not isinstance(adj, ShardedGCNGraph):
+            adj = as_graph(adj, x.device)  # CSR (+ transpose) built once, reused by all 7 layers and every epoch
         h = self.gnn_1(x, adj)
         h = self.gnn_2((1 - sigma) * h + sigma * tra1, adj)
         h = self.gnn_3((1 - sigma) * h + sigma * tra2, adj)
@@ -211,34 +225,76 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
         self._pretrain(x, batch_size=pt_batch_size, epochs=pt_epochs, lr=pt_lr, force_pretrain=True)
         device, model = self.device, self.model
         optimizer = Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=lr)
-        if not isinstance(adj, (CSRGraph, torch.Tensor)):
+        # ``adj`` = a ShardedGCNGraph (one process per GPU, rows sharded by destination range): x / x_raw / n_counts
+        # are the whole arrays and every rank keeps its rows.  The reductions over all cells — BatchNorm statistics, the target
+        # distribution's column sums, the four loss means — are completed with small all-reduces, the GCN weights' gradients inside
+        # the sharded layer, every other parameter's after backward: the arithmetic is the single-process model's up to the order
+        # of those sums.  The AE pre-training above is mini-batch SGD over shuffled cells and runs replicated (same seed, same
+        # result on every rank; rank 0's parameters are broadcast to be sure).
+        sg = adj if isinstance(adj, ShardedGCNGraph) else None
+        sharded = sg is not None and sg.world > 1
+        n_all = x.shape[0]
+        lo, hi = sg.ranges[sg.rank] if sg is not None else (0, n_all)
+        if sg is not None and sg.n_nodes != n_all:
+            raise ValueError(f"the sharded graph has {sg.n_nodes} nodes, x has {n_all} rows")
+        if sharded:
+            broadcast_parameters(model, sg.group)
+            model.ae.rows_total, model.ae.group = n_all, sg.group
+        elif not isinstance(adj, (CSRGraph, ShardedGCNGraph, torch.Tensor)):
             adj = CSRGraph.from_scipy(adj, device)  # one device CSR (+ cached transpose) for all 7 layers of every epoch
-        x_raw = torch.as_tensor(np.asarray(x_raw), dtype=torch.float32).to(device)
+        x_raw = torch.as_tensor(np.asarray(x_raw)[lo:hi], dtype=torch.float32).to(device)
         n_counts = np.asarray(n_counts, dtype=np.float64)
-        sf = torch.as_tensor(n_counts / np.median(n_counts)).to(device)
-        data = torch.from_numpy(x).to(device)
+        sf = torch.as_tensor((n_counts / np.median(n_counts))[lo:hi]).to(device)
+        data = torch.from_numpy(x[lo:hi]).to(device)
+        n_loc, n_genes = data.shape
+
+        def allsum(t):
+            if sharded:
+                import torch.distributed as dist
+                t = t.clone()
+                dist.all_reduce(t, group=sg.group)
+            return t
+
+        def all_rows(t):  # this rank's rows -> all rows, on every rank
+            return sg.all_gather_rows(t.contiguous())[:n_all] if sharded else t
+
+        gcn_weights = {id(getattr(model, f"gnn_{i}").weight) for i in range(1, 8)}
+        others = [p for p in model.parameters() if p.requires_grad and id(p) not in gcn_weights]
         aris, keys, Q = [], [], {}
         p = None
-        with torch.no_grad():  # :253-254 — its result is unused, but the module is in train mode here: this full-batch pass
-            model.ae(data)     # moves the BatchNorm running statistics that the eval-mode passes below read
-        for epoch in range(epochs):
-            if epoch % 10 == 0:
-                model.eval()
-                with torch.no_grad():
-                    _, tmp_q, _, _, _, _, _, _ = model(data, adj)
-                    self.q = tmp_q.data
-                    p = self.target_distribution(self.q)
-                    aris.append(self.score(None, y))  # ARI for model selection (:261-263)
-                    keys.append(key := f"epoch{epoch}")
-                    Q[key] = self.q
-            model.train()
-            x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model(data, adj)
-            loss = (bcl * F.binary_cross_entropy(q, p) + cl * F.kl_div(pred.log(), p, reduction="batchmean") + rl * F.mse_loss(x_bar, data)
-                    + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf))
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
-            self.last_loss = loss.detach()
+        try:
+            with torch.no_grad():  # :253-254 — its result is unused, but the module is in train mode here: this full-batch pass
+                model.ae(data)     # moves the BatchNorm running statistics that the eval-mode passes below read
+            for epoch in range(epochs):
+                if epoch % 10 == 0:
+                    model.eval()
+                    with torch.no_grad():
+                        _, tmp_q, _, _, _, _, _, _ = model(data, adj)
+                        q_loc = tmp_q.data
+                        p = q_loc**2 / allsum(q_loc.sum(0))  # target_distribution with the column sums over ALL cells
+                        p = (p.t() / p.sum(1)).t()
+                        self.q = all_rows(q_loc)
+                        aris.append(self.score(None, y))  # ARI for model selection (:261-263)
+                        keys.append(key := f"epoch{epoch}")
+                        Q[key] = self.q
+                model.train()
+                x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model(data, adj)
+                if sharded:  # this rank's share of the global means: local sum / global count
+                    loss = (bcl * F.binary_cross_entropy(q, p, reduction="sum") / (n_all * q.shape[1])
+                            + cl * F.kl_div(pred.log(), p, reduction="sum") / n_all
+                            + rl * F.mse_loss(x_bar, data, reduction="sum") / (n_all * n_genes)
+                            + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf) * (n_loc / n_all))
+                else:
+                    loss = (bcl * F.binary_cross_entropy(q, p) + cl * F.kl_div(pred.log(), p, reduction="batchmean")
+                            + rl * F.mse_loss(x_bar, data) + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf))
+                optimizer.zero_grad()
+                loss.backward()
+                if sharded:
+                    allreduce_sum_gradients(others, sg.group)
+                optimizer.step()
+                self.last_loss = allsum(loss.detach())
+        finally:
+            model.ae.rows_total, model.ae.group = None, None
         self.q = Q[keys[int(np.argmax(aris))]]
 
     def predict_proba(self, x=None) -> np.ndarray:

@@ -643,6 +643,73 @@ def allreduce_gradients(module: torch.nn.Module, group=None):
         off += g.numel()
 
 
+def allreduce_sum_gradients(params, group=None):
+    """SUM the gradients of ``params`` over the ranks (one flat bucket).  For row-sharded training where every rank's loss is its
+    rows' share of ONE global loss (local sum / global count): the gradient of a replicated parameter is the sum of the ranks'."""
+    _, world = world_info(group)
+    grads = [p.grad for p in params if p.grad is not None]
+    if world == 1 or not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for g in grads:
+        g.copy_(flat[off:off + g.numel()].reshape(g.shape))
+        off += g.numel()
+
+
+class _ShardedBatchNormFn(torch.autograd.Function):
+    """Training-mode BatchNorm1d over rows that are sharded across the ranks: the statistics are those of ALL rows (two small
+    all-reduces forward — sum, then centred sum of squares: the two-pass variance torch computes —, one backward).  Returns the
+    local rows normalised with the global statistics; the gradients of weight / bias are the LOCAL shares (the caller sums the
+    gradients of replicated parameters over the ranks, ``allreduce_sum_gradients``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, n_total, eps, group):
+        s = x.sum(0)
+        dist.all_reduce(s, group=group)
+        mean = s / n_total
+        xc = x - mean
+        v = (xc * xc).sum(0)
+        dist.all_reduce(v, group=group)
+        var = v / n_total                      # biased: what normalises (torch.nn.functional.batch_norm, training=True)
+        invstd = torch.rsqrt(var + eps)
+        xhat = xc * invstd
+        ctx.save_for_backward(xhat, weight, invstd)
+        ctx.n_total, ctx.group = n_total, group
+        ctx.mark_non_differentiable(mean, var)
+        y = xhat * weight + bias if weight is not None else xhat
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, dy, _dmean, _dvar):
+        xhat, weight, invstd = ctx.saved_tensors
+        dxhat = dy * weight if weight is not None else dy
+        sums = torch.stack((dxhat.sum(0), (dxhat * xhat).sum(0)))
+        dweight = (dy * xhat).sum(0) if weight is not None else None
+        dbias = dy.sum(0) if weight is not None else None
+        dist.all_reduce(sums, group=ctx.group)
+        dx = invstd * (dxhat - (sums[0] + xhat * sums[1]) / ctx.n_total)
+        return dx, dweight, dbias, None, None, None
+
+
+def sharded_batch_norm(bn: torch.nn.BatchNorm1d, x_local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """``bn(x)`` for a row shard of a batch of ``n_total`` rows: identical (to summation order) to the module applied to all rows
+    on one device — batch statistics over all rows in training mode, the running statistics updated with them (momentum, unbiased
+    variance, ``num_batches_tracked``), the module's own path in eval mode and at world 1."""
+    _, world = world_info(group)
+    if world == 1 or not (bn.training or not bn.track_running_stats):
+        return bn(x_local)
+    y, mean, var = _ShardedBatchNormFn.apply(x_local, bn.weight, bn.bias, int(n_total), bn.eps, group)
+    if bn.training and bn.track_running_stats:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1 - m).add_(var * (n_total / max(n_total - 1, 1)), alpha=m)
+    return y
+
+
 def gather_embeddings(z: torch.Tensor, order: torch.Tensor, group=None):
     """All ranks' (embedding rows, cell order ids) -> one copy per cell on every rank (padded duplicates dropped, rows sorted
     by order id).  Every rank contributes the same number of rows (``shard_seed_ids`` pads)."""

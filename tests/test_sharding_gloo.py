@@ -587,3 +587,74 @@ def test_from_row_shard_builds_the_transposed_shard_by_exchange(world, n):
         assert p.exitcode == 0
     for _, out in results:
         assert out == {"allgather": True, "halo": True, "alltoall_rejected": True}
+
+
+def _scdsc_worker(rank, world, port, mode, q):
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_ops
+    from dance_amd import kernels, sharding
+    for name in cpu_ops.STAND_INS:  # the dense / elementwise ops of the model on the host (what the cpu_kernels fixture does)
+        setattr(kernels, name, getattr(cpu_ops, name))
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSC
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scdsc_fit.npz"))
+        kw = json.loads(str(g["sf_kw"]))
+        n = g["sf_x"].shape[0]
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            m = ScDSC(pretrain_path=os.path.join(tmp, f"ae{rank}.pt"), device="cpu", **kw)
+            if rank == 0:  # the other ranks start from their own random weights: the fit broadcasts rank 0's after pre-training
+                m.model.load_state_dict({k.split("::", 1)[1]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sf_sd0::")})
+            adj = sp.csr_matrix((g["sf_adj_data"], g["sf_adj_indices"], g["sf_adj_indptr"]), shape=(n, n))
+            adj.sort_indices()
+            at = adj.T.tocsr()
+            at.sort_indices()
+            lo, hi = sharding.row_ranges(n, world)[0][rank]
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
+            sl = lambda mm: sharding.slice_rows(t(mm.indptr, np.int32), t(mm.indices, np.int32), t(mm.data, np.float32), lo, hi, n)
+            sg = sharding.ShardedGCNGraph(sl(adj), sl(at), n, mode=mode)
+            sg.ops = cpu_ops
+            torch.manual_seed(10)
+            if rank > 0:  # pre-training is replicated; ranks other than 0 run it from different weights — and are overwritten
+                with torch.no_grad():
+                    for prm in m.model.parameters():
+                        prm.add_(0.01)
+            m.fit((sg, g["sf_x"], g["sf_counts"], g["sf_n_counts"].astype(np.float64)), g["sf_y"], lr=1e-3, epochs=12, pt_epochs=3,
+                  pt_batch_size=32, pt_lr=1e-3)
+            sd = {k: v.detach().numpy().copy() for k, v in m.model.state_dict().items()}
+            q.put((rank, m.predict_proba(), m.predict(), sd, float(m.last_loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "halo"), (3, "allgather")])
+def test_sharded_scdsc_fit_vs_reference_golden(world, mode):
+    """ScDSC.fit with the cells sharded by destination range over 2 / 3 ranks (7 chained sharded GCN layers, BatchNorm statistics,
+    target distribution and loss means over ALL cells by all-reduce) reproduces the reference's own single-process fit
+    (tests/golden/scdsc_fit.npz) to the tolerance of the single-process test; every rank ends with the same model and the same q."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scdsc_fit.npz"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scdsc_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res[1:]:
+        assert np.array_equal(r[1], res[0][1]) and r[4] == res[0][4]
+        for k, v in r[3].items():
+            assert np.allclose(v, res[0][3][k], rtol=1e-6, atol=1e-7), k
+    qq, pred, sd = res[0][1], res[0][2], res[0][3]
+    assert qq.shape == g["sf_q"].shape and np.allclose(qq.sum(1), 1, atol=1e-5)
+    assert rel_err(qq, g["sf_q"]) < 5e-3
+    assert (pred == g["sf_pred"]).mean() > 0.98
+    for k in g.files:
+        if k.startswith("sf_sd1::") and "num_batches_tracked" not in k:
+            assert np.abs(sd[k.split("::", 1)[1]] - g[k]).max() < 1.5e-2 * max(1.0, np.abs(g[k]).max()), k
