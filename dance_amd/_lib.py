@@ -93,6 +93,8 @@ def _declare(lib):
         "dh_gram_sigmoid_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_gram_sigmoid_f32": (c_int, [i64, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_gram_pairwise_f32": (c_int, [i32, i64, i64, P, i64, P, i64, P, P, c_size_t, P]),
+        "dh_gram_pairwise_rect_workspace_bytes": (c_size_t, [i64, i64, i64]),
+        "dh_gram_pairwise_rect_f32": (c_int, [i32, i64, i64, i64, P, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_gram_listed_forward_f32": (c_int, [i64, i64, i64, P, i64, P, P, c_float, P, P, P]),
         "dh_gram_listed_backward_f32": (c_int, [i64, i64, i64, P, i64, P, i64, P, P, P, c_float, P, P, i64, P]),
         "dh_rowsum_masked_f32": (c_int, [i64, i64, P, i64, P, P, P]),

@@ -49,8 +49,8 @@ __host__ __device__ constexpr int lds_stride(int dp) { return dp + 4; }  // == 4
 //                                                      sum_ij sigmoid(x_ij)^2 of sum_ij (sigmoid(x_ij) - a_ij)^2
 template <int DP, bool VEC, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void gram_sigmoid_kernel(int n, int d, const float* __restrict__ Z, int64_t ldz, int j_per_split, int n_pad,
-                         float* __restrict__ Opart, double* __restrict__ Lpart) {
+void gram_sigmoid_kernel(int n_r, const float* __restrict__ Zr, int64_t ldr, int n, int d, const float* __restrict__ Z, int64_t ldz,
+                         int j_per_split, int n_pad, float* __restrict__ Opart, double* __restrict__ Lpart) {
   constexpr int STRIDE = lds_stride(DP);
   constexpr int HALF = DP / 2;
   constexpr int NT = DP / 32;              // column tiles of the second product
@@ -65,10 +65,11 @@ void gram_sigmoid_kernel(int n, int d, const float* __restrict__ Z, int64_t ldz,
   const int j_end = min(n, j_begin + j_per_split);
   const int n_tiles = (j_end - j_begin + BJ - 1) / BJ;
 
-  auto load4 = [&](int row, int col) -> f32x4 {  // Z[row][col .. col + 3], zero outside the matrix
+  // rows i come from Zr [n_r, d] (the square pass: Zr = Z), columns j from Z [n, d]
+  auto load4_from = [&](const float* M, int64_t ld, int rows, int row, int col) -> f32x4 {  // M[row][col .. col + 3], zero outside the matrix
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < n) {
-      const float* p = Z + (int64_t)row * ldz + col;
+    if (row < rows) {
+      const float* p = M + (int64_t)row * ld + col;
       if (VEC) {
         if (col < d) v = *reinterpret_cast<const f32x4*>(p);
       } else {
@@ -80,13 +81,14 @@ void gram_sigmoid_kernel(int n, int d, const float* __restrict__ Z, int64_t ldz,
     }
     return v;
   };
+  auto load4 = [&](int row, int col) -> f32x4 { return load4_from(Z, ldz, n, row, col); };
 
   // B operand of the first product: lane (m, h) holds Z[i0 + m][h * HALF + t], t = 0 .. HALF - 1 (k is enumerated as
   // (h, t); the A operand read from LDS uses the same enumeration, so any order is a valid K order)
   float zi[HALF];
   static_for<HALF / 4>([&](auto q_c) __attribute__((always_inline)) {
     constexpr int q = decltype(q_c)::value;
-    const f32x4 v = load4(i0 + m, h * HALF + 4 * q);
+    const f32x4 v = load4_from(Zr, ldr, n_r, i0 + m, h * HALF + 4 * q);
     zi[4 * q + 0] = v.x; zi[4 * q + 1] = v.y; zi[4 * q + 2] = v.z; zi[4 * q + 3] = v.w;
   });
 
@@ -306,10 +308,10 @@ struct Plan {
   size_t opart_bytes, lpart_bytes;
 };
 
-Plan make_plan(int64_t n, int64_t d) {
+Plan make_plan(int64_t n_r, int64_t n, int64_t d) {  // n_r rows i against n columns j
   Plan p{};
   p.dp = (int)(dh::ceil_div(d, 64) * 64);
-  p.i_blocks = (int)dh::ceil_div(n, BI);
+  p.i_blocks = (int)dh::ceil_div(n_r, BI);
   p.n_pad = p.i_blocks * BI;
   const int64_t j_tiles = dh::ceil_div(n, BJ);
   int64_t want = dh::ceil_div(512, p.i_blocks);  // two workgroups per CU
@@ -323,28 +325,28 @@ Plan make_plan(int64_t n, int64_t d) {
 }
 
 template <int DP, int MODE>
-int launch(const Plan& p, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
-  const bool vec = (ldz % 4 == 0) && (d % 4 == 0) && dh::aligned16(Z);
+int launch(const Plan& p, int n_r, const float* Zr, int64_t ldr, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
+  const bool vec = (ldz % 4 == 0) && (ldr % 4 == 0) && (d % 4 == 0) && dh::aligned16(Z) && dh::aligned16(Zr);
   const size_t lds_bytes = (size_t)2 * BJ * lds_stride(DP) * sizeof(float);
   const dim3 grid((unsigned)p.i_blocks, (unsigned)p.splits);
   if (vec) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, true, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, true, MODE>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
+    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, true, MODE>), grid, dim3(256), lds_bytes, st, n_r, Zr, ldr, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
   } else {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_sigmoid_kernel<DP, false, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, false, MODE>), grid, dim3(256), lds_bytes, st, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
+    hipLaunchKernelGGL((gram_sigmoid_kernel<DP, false, MODE>), grid, dim3(256), lds_bytes, st, n_r, Zr, ldr, n, d, Z, ldz, p.j_per_split, p.n_pad, Opart, Lpart);
   }
   return dh::check_launch("dh_gram_pairwise_f32");
 }
 
 template <int MODE>
-int launch_dp(const Plan& p, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
+int launch_dp(const Plan& p, int n_r, const float* Zr, int64_t ldr, int n, int d, const float* Z, int64_t ldz, float* Opart, double* Lpart, hipStream_t st) {
   switch (p.dp) {
-    case 64: return launch<64, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
-    case 128: return launch<128, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
-    case 192: return launch<192, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
-    case 256: return launch<256, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
-    default: return launch<320, MODE>(p, n, d, Z, ldz, Opart, Lpart, st);
+    case 64: return launch<64, MODE>(p, n_r, Zr, ldr, n, d, Z, ldz, Opart, Lpart, st);
+    case 128: return launch<128, MODE>(p, n_r, Zr, ldr, n, d, Z, ldz, Opart, Lpart, st);
+    case 192: return launch<192, MODE>(p, n_r, Zr, ldr, n, d, Z, ldz, Opart, Lpart, st);
+    case 256: return launch<256, MODE>(p, n_r, Zr, ldr, n, d, Z, ldz, Opart, Lpart, st);
+    default: return launch<320, MODE>(p, n_r, Zr, ldr, n, d, Z, ldz, Opart, Lpart, st);
   }
 }
 
@@ -354,7 +356,13 @@ extern "C" int dh_gram_sigmoid_supported(int64_t n, int64_t d) { return n >= 0 &
 
 extern "C" size_t dh_gram_sigmoid_workspace_bytes(int64_t n, int64_t d) {
   if (n <= 0 || !dh_gram_sigmoid_supported(n, d)) return 0;
-  const Plan p = make_plan(n, d);
+  const Plan p = make_plan(n, n, d);
+  return p.opart_bytes + p.lpart_bytes;
+}
+
+extern "C" size_t dh_gram_pairwise_rect_workspace_bytes(int64_t n_rows, int64_t n, int64_t d) {
+  if (n_rows <= 0 || n <= 0 || !dh_gram_sigmoid_supported(n, d) || !dh_gram_sigmoid_supported(n_rows, d)) return 0;
+  const Plan p = make_plan(n_rows, n, d);
   return p.opart_bytes + p.lpart_bytes;
 }
 
@@ -365,26 +373,39 @@ extern "C" int dh_gram_sigmoid_f32(int64_t n, int64_t d, const float* Z, int64_t
 
 extern "C" int dh_gram_pairwise_f32(int mode, int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
                                     void* workspace, size_t workspace_bytes, dh_stream_t stream) {
-  if (mode != DH_GRAM_SOFTPLUS && mode != DH_GRAM_SIGMOID_SQ) return dh::fail(DH_ERR_INVALID, "dh_gram_pairwise_f32: bad mode %d", mode);
-  if (n < 0 || d < 0) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: negative size");
-  if (n == 0) return DH_OK;
-  if (!dh_gram_sigmoid_supported(n, d))
-    return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: d = %lld outside [1, %d] (use the unfused decoder)", (long long)d, MAX_D);
-  if (!Z || !O || !rowloss || ldz < d || ldo < d) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: bad pointer / leading dimension");
-  const Plan p = make_plan(n, d);
-  if (!workspace || workspace_bytes < p.opart_bytes + p.lpart_bytes)
-    return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: workspace of %zu bytes needed, %zu given", p.opart_bytes + p.lpart_bytes, workspace_bytes);
-  if (!dh::aligned16(workspace)) return dh::fail(DH_ERR_INVALID, "dh_gram_sigmoid_f32: workspace must be 16-byte aligned");
+  return dh_gram_pairwise_rect_f32(mode, n, n, d, Z, ldz, Z, ldz, O, ldo, rowloss, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dh_gram_pairwise_rect_f32(int mode, int64_t n_rows, int64_t n, int64_t d, const float* Zr, int64_t ldr, const float* Z,
+                                         int64_t ldz, float* O, int64_t ldo, float* rowloss, void* workspace, size_t workspace_bytes,
+                                         dh_stream_t stream) {
+  const char* me = "dh_gram_pairwise_rect_f32";
+  if (mode != DH_GRAM_SOFTPLUS && mode != DH_GRAM_SIGMOID_SQ) return dh::fail(DH_ERR_INVALID, "%s: bad mode %d", me, mode);
+  if (n_rows < 0 || n < 0 || d < 0) return dh::fail(DH_ERR_INVALID, "%s: negative size", me);
+  if (n_rows == 0) return DH_OK;
+  if (!dh_gram_sigmoid_supported(n, d) || !dh_gram_sigmoid_supported(n_rows, d))
+    return dh::fail(DH_ERR_INVALID, "%s: d = %lld outside [1, %d] (use the unfused decoder)", me, (long long)d, MAX_D);
+  if (!Zr || (n > 0 && !Z) || !O || !rowloss || ldz < d || ldr < d || ldo < d) return dh::fail(DH_ERR_INVALID, "%s: bad pointer / leading dimension", me);
   hipStream_t st = dh::as_stream(stream);
+  if (n == 0) {  // no columns: empty sums
+    if (hipMemset2DAsync(O, (size_t)ldo * sizeof(float), 0, (size_t)d * sizeof(float), (size_t)n_rows, st) != hipSuccess ||
+        hipMemsetAsync(rowloss, 0, (size_t)n_rows * sizeof(float), st) != hipSuccess)
+      return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
+    return DH_OK;
+  }
+  const Plan p = make_plan(n_rows, n, d);
+  if (!workspace || workspace_bytes < p.opart_bytes + p.lpart_bytes)
+    return dh::fail(DH_ERR_INVALID, "%s: workspace of %zu bytes needed, %zu given", me, p.opart_bytes + p.lpart_bytes, workspace_bytes);
+  if (!dh::aligned16(workspace)) return dh::fail(DH_ERR_INVALID, "%s: workspace must be 16-byte aligned", me);
   double* Lpart = reinterpret_cast<double*>(workspace);                      // doubles first: keeps both parts aligned
   float* Opart = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.lpart_bytes);
-  const int rc = mode == DH_GRAM_SOFTPLUS ? launch_dp<0>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st)
-                                          : launch_dp<1>(p, (int)n, (int)d, Z, ldz, Opart, Lpart, st);
+  const int rc = mode == DH_GRAM_SOFTPLUS ? launch_dp<0>(p, (int)n_rows, Zr, ldr, (int)n, (int)d, Z, ldz, Opart, Lpart, st)
+                                          : launch_dp<1>(p, (int)n_rows, Zr, ldr, (int)n, (int)d, Z, ldz, Opart, Lpart, st);
   if (rc != DH_OK) return rc;
-  const int64_t work = n * d;
+  const int64_t work = n_rows * d;
   const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 65536 ? dh::ceil_div(work, 256) : 65536);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)n, (int)d, p.dp, p.n_pad, p.splits, Opart, Lpart, O, ldo, rowloss);
-  return dh::check_launch("dh_gram_sigmoid_f32 (reduce)");
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(grid), dim3(256), 0, st, (int)n_rows, (int)d, p.dp, p.n_pad, p.splits, Opart, Lpart, O, ldo, rowloss);
+  return dh::check_launch("dh_gram_pairwise_rect_f32 (reduce)");
 }
 
 extern "C" int dh_gram_listed_forward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const int32_t* us,

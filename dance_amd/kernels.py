@@ -395,6 +395,23 @@ def gram_pairwise(Z: torch.Tensor, mode: int = GRAM_SOFTPLUS) -> Tuple[torch.Ten
     return rowloss, out
 
 
+def gram_pairwise_rect(Zr: torch.Tensor, Z: torch.Tensor, mode: int = GRAM_SOFTPLUS) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rowloss, O) for the rows of ``Zr`` against ALL rows of ``Z``: rowloss[i] = sum_j f(<zr_i, z_j>), O[i] = sum_j f'(<zr_i, z_j>) z_j
+    (dh_gram_pairwise_rect_f32) — a rank's row block of the pairwise pass when the cells are sharded (sharding.py)."""
+    lib = _lib_ready()
+    (nr, d), n = Zr.shape, Z.shape[0]
+    if Z.shape[1] != d:
+        raise ValueError("gram_pairwise_rect: Zr and Z must have the same width")
+    out = torch.empty((nr, d), dtype=torch.float32, device=Z.device)
+    rowloss = torch.empty(nr, dtype=torch.float32, device=Z.device)
+    ws_bytes = lib.dh_gram_pairwise_rect_workspace_bytes(nr, n, d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=Z.device) if ws_bytes else None
+    _call("gram_pairwise_rect_f32", lib.dh_gram_pairwise_rect_f32, int(mode), nr, n, d, _dev(Zr, torch.float32, "Zr", 2), _ld(Zr),
+          _dev(Z, torch.float32, "Z", 2), _ld(Z), out.data_ptr(), _ld(out), rowloss.data_ptr(), None if ws is None else ws.data_ptr(), ws_bytes,
+          _stream())
+    return rowloss, out
+
+
 def gram_sigmoid(Z: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(rowloss, O) with rowloss[i] = sum_j softplus(<z_i, z_j>) and O[i] = sum_j sigmoid(<z_i, z_j>) z_j: the dense part of
     graph-sc's inner-product decoder loss and (x2) its gradient, without the B x B logits (dh_gram_sigmoid_f32)."""

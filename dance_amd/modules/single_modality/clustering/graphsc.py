@@ -173,6 +173,32 @@ class GCNAE(nn.Module):
             x = self.encoder(x)
         return (self.decoder(x) if decode else None), x
 
+    def forward_sharded(self, scg, features):
+        """The embedding of this rank's cells from a pass over the WHOLE graph with the cells sharded by range and the genes replicated
+        (``sharding.ShardedCellGeneGraph``) — the blocks the full-neighbour sampler builds for the seed set "all cells":
+        every node is a destination of the inner layers (their gene rows: partial sums over the rank's cells, completed by an all-reduce
+        of G x D floats), the cells of the last.  ``features``: rows of the local nodes (genes, then this rank's cells).  Dropout
+        draws the replicated gene rows from a generator every rank seeds alike (``scg.gene_rng``), the cell rows from the rank's own."""
+        from ....sharding import sharded_batch_norm, sharded_cellgene_conv
+        x = features
+        g = scg.n_genes
+        n_l = 1 + (1 if hasattr(self, "layer2") else 0)
+        for i in range(n_l):
+            if self.dropout is not None and self.training and self.dropout.p > 0:
+                keep = 1.0 - self.dropout.p
+                mg = (torch.rand((g, x.shape[1]), device=x.device, generator=scg.gene_rng) < keep)
+                mc = (torch.rand((x.shape[0] - g, x.shape[1]), device=x.device) < keep)
+                x = x * torch.cat((mg, mc)).to(x.dtype) / keep
+            layer = self.layer1 if i == 0 else self.layer2
+            relu = layer._activation in (F.relu, torch.relu) or isinstance(layer._activation, nn.ReLU)
+            x = sharded_cellgene_conv(x, layer.weight, layer.bias, scg, "all" if i < n_l - 1 else "cells", norm=layer._norm, agg=self.agg, relu=relu)
+            if layer._activation is not None and not relu:
+                x = layer._activation(x)
+        if self.hidden is not None:
+            for m in self.encoder:  # the rows are cells now: BatchNorm statistics over ALL cells
+                x = sharded_batch_norm(m, x, scg.n_cells, scg.group) if isinstance(m, nn.BatchNorm1d) else m(x)
+        return x
+
 
 def block_dst_adjacency(block) -> torch.Tensor:
     """``g.adjacency_matrix().to_dense()[dst][:, dst]`` of the reference (:208-209): B x B, entry [u, v] = 1 for an
@@ -520,6 +546,68 @@ class GraphSC(BaseClusteringMethod):
             if eval_epoch or epoch == epochs - 1:  # the embedding only leaves the device when somebody reads it
                 zc, oc = sharding.gather_embeddings(torch.cat(z), torch.cat(order))  # one process: a sort by cell order
                 self.z = zc.cpu().numpy()
+            if eval_epoch and y is not None:
+                aris.append(self.score(None, y))
+                Z[f"epoch{epoch}"] = self.z
+        if eval_epoch and aris:
+            self.z = Z[f"epoch{int(np.argmax(aris))}"]
+
+    def fit_full_graph(self, g, y: Optional[Any] = None, *, epochs: int = 100, lr: float = 1e-5, eval_epoch: bool = False):
+        """``fit`` with the whole cell set as ONE batch per epoch (what graphsc.py:148-246 does for ``batch_size >= n_cells``: the blocks
+        of the full-neighbour sampler are then the graph itself), with the cells sharded by contiguous range over the ranks of
+        ``torch.distributed`` and the genes replicated (BASELINE config 4 as stated: destination-sharded).  Per epoch and
+        layer: cell rows aggregate locally, gene rows are partial sums completed by an all-reduce of G x D floats; the decoder loss over
+        all n x n cell pairs is evaluated row block by row block against the all-gathered embedding (no n x n matrix, no gradient
+        exchange); the replicated parameters' gradients are summed over the ranks.  One process: the same arithmetic without the
+        collectives.  ``g``: the whole ``CellGeneGraph`` (genes-first layout) on every rank at set-up."""
+        from .... import sharding
+        g = g.to(self.device)
+        g.ndata["order"] = g.ndata["label"] = g.ndata["feat_id"]
+        rank, world = sharding.world_info()
+        scg = sharding.ShardedCellGeneGraph.from_global(g, ops=getattr(self, "ops", None))
+        if world > 1:
+            sharding.broadcast_parameters(self.model)
+        seed = torch.randint(0, 2**31 - 1, (1, ), device=self.device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.broadcast(seed, src=0)
+        scg.gene_rng = torch.Generator(device=self.device).manual_seed(int(seed))
+        loc, ng = scg.local, scg.n_genes
+        feats = loc.ndata["features"]
+        # the decoder's target: adj[dst][:, dst] over the cells — in a cell - gene graph the cells' self loops (graphsc.py:208-213)
+        rp, col = loc.rowptr.to(torch.int64), loc.col.to(torch.int64)
+        rows = torch.repeat_interleave(torch.arange(loc.number_of_nodes(), device=rp.device), rp[1:] - rp[:-1])
+        cell_edges = (rows >= ng) & (col >= ng)
+        if bool((cell_edges & (rows != col)).any()):
+            raise NotImplementedError("fit_full_graph: edges between different cells (the sharded decoder target lists self loops only)")
+        has_self = torch.zeros(loc.number_of_nodes(), dtype=torch.bool, device=rp.device)
+        has_self[rows[cell_edges]] = True
+        has_self = has_self[ng:]
+        n_listed = int(scg.all_sum(has_self.sum().to(torch.float32).reshape(1)))
+        total = float(scg.n_cells)**2
+        pos_weight = (total - n_listed) / n_listed if n_listed else float("inf")
+        factor = (total - n_listed) * 2
+        norm = total / (factor if factor != 0 else 1.0)
+        optim = torch.optim.Adam(self.model.parameters(), lr=lr)
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        order = loc.ndata["order"][ng:]
+        self.losses, aris, Z = [], [], {}
+        for epoch in range(epochs):
+            self.model.train()
+            emb = self.model.forward_sharded(scg, feats)  # :202 (the embedding that is kept)
+            z_epoch = emb.detach()
+            emb2 = self.model.forward_sharded(scg, feats)  # second forward, fresh dropout (:215)
+            loss = norm * sharding.sharded_selfloop_gram_bce(F.dropout(emb2, self.model.decoder.dropout), has_self, pos_weight, scg)
+            if not n_listed:
+                loss = loss * float("nan")
+            optim.zero_grad()
+            loss.backward()
+            sharding.allreduce_sum_gradients(params)
+            optim.step()
+            self.losses.append(float(scg.all_sum(loss.detach().reshape(1))))
+            if eval_epoch or epoch == epochs - 1:
+                z_all, o_all = scg.all_gather_cells(z_epoch), scg.all_gather_cells(order.reshape(-1, 1).to(torch.float32))
+                self.z = z_all[torch.argsort(o_all.reshape(-1))].cpu().numpy()
             if eval_epoch and y is not None:
                 aris.append(self.score(None, y))
                 Z[f"epoch{epoch}"] = self.z

@@ -724,3 +724,167 @@ def gather_embeddings(z: torch.Tensor, order: torch.Tensor, group=None):
     first = torch.ones_like(order_sorted, dtype=torch.bool)
     first[1:] = order_sorted[1:] != order_sorted[:-1]
     return z[idx[first]], order_sorted[first]
+
+
+# ---- bipartite cell - gene graphs (scDeepSort / graph-sc): cells sharded by range, genes replicated ----------------------
+class _SumLeadingRows(torch.autograd.Function):
+    """rows [0, g) of ``t`` summed over the ranks (the gene rows' partial sums of a cell-sharded aggregation: G x D floats), the other
+    rows untouched.  The adjoint of a sum over ranks whose result every rank uses is the sum of the ranks' gradients."""
+
+    @staticmethod
+    def forward(ctx, t, g, group):
+        ctx.g, ctx.group = g, group
+        out = t.clone()
+        head = out[:g].contiguous()
+        dist.all_reduce(head, group=group)
+        out[:g] = head
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        grad = grad.clone()
+        head = grad[:ctx.g].contiguous()
+        dist.all_reduce(head, group=ctx.group)
+        grad[:ctx.g] = head
+        return grad, None, None
+
+
+class ShardedCellGeneGraph:
+    """This rank's part of a CellFeatureGraph (nodes: genes [0, G), then cells): ALL gene nodes (a few thousand rows, replicated) and
+    the cells [lo, hi) of a contiguous range, with every edge among them.  A cell's in-edges come from genes and its own self loop,
+    so its rows are complete locally; a gene's in-edges come from all cells, so a rank holds a PARTIAL sum of every gene row —
+    completed by one all-reduce of G x D floats per layer (and one more in its backward).  Gene - gene edges (the genes' self loops)
+    are kept on rank 0 only (weight 0 elsewhere) so that the sum over ranks counts them once.  Degrees are those of the whole graph.
+
+    Two message-flow blocks over the local nodes, as the full-neighbour sampler would produce them for the seed set "all cells":
+    ``"all"`` — every node is a destination (inner layers of a multi-layer pass), ``"cells"`` — the cells are (the last layer)."""
+
+    def __init__(self, local, n_genes: int, n_cells: int, cell_range, degrees, group=None, ops=None):
+        self.local, self.n_genes, self.n_cells = local, int(n_genes), int(n_cells)
+        self.lo, self.hi = cell_range
+        self.group, self.ops = group, ops
+        self.rank, self.world = world_info(group)
+        self.in_deg, self.out_deg_all, self.out_deg_cells = degrees  # float32 vectors over the LOCAL nodes, whole-graph counts
+        self._blocks = {}
+
+    @classmethod
+    def from_global(cls, graph, group=None, ops=None) -> "ShardedCellGeneGraph":
+        """From the whole graph (a ``CellGeneGraph`` in the genes-first layout, present on every rank at set-up)."""
+        rank, world = world_info(group)
+        g = graph.gene_prefix()
+        if g < 0:
+            raise ValueError("ShardedCellGeneGraph needs the CellFeatureGraph node layout (genes first, then cells)")
+        n = graph.number_of_nodes()
+        ranges, _ = row_ranges(n - g, world)
+        lo, hi = ranges[rank]
+        dev = graph.device
+        nodes = torch.cat((torch.arange(g, device=dev), g + torch.arange(lo, hi, device=dev)))
+        local = graph.subgraph(nodes)
+        rp, col = graph.rowptr.to(torch.int64), graph.col.to(torch.int64)
+        in_deg = (rp[1:] - rp[:-1]).to(torch.float32)
+        out_all = torch.bincount(col, minlength=n).to(torch.float32)
+        out_cells = torch.bincount(col[int(rp[g]):], minlength=n).to(torch.float32)   # sources of the cell rows only
+        if rank > 0:  # gene <- gene edges (self loops) count once: on rank 0
+            lrp = local.rowptr.to(torch.int64)
+            head = local.col[:int(lrp[g])].to(torch.int64) < g
+            local.val[:int(lrp[g])][head] = 0
+        return cls(local, g, n - g, (lo, hi), (in_deg[nodes], out_all[nodes], out_cells[nodes]), group, ops)
+
+    @property
+    def n_local_cells(self) -> int:
+        return self.hi - self.lo
+
+    def block(self, kind: str):
+        """(CSRGraph of the block over the local nodes, in-degree of its destinations, out-degree of its sources) — degrees of the WHOLE
+        graph's block, which is what the reference's DGL blocks report for the seed set "all cells"."""
+        if kind not in self._blocks:
+            from .graph import CSRGraph
+            loc, g = self.local, self.n_genes
+            n_loc = loc.number_of_nodes()
+            if kind == "all":
+                csr = CSRGraph(loc.rowptr, loc.col, loc.val, n_loc, n_loc)
+                self._blocks[kind] = (csr, self.in_deg, self.out_deg_all)
+            elif kind == "cells":
+                first = int(loc.rowptr[g])
+                csr = CSRGraph((loc.rowptr[g:] - first).contiguous(), loc.col[first:].contiguous(), loc.val[first:].contiguous(), n_loc - g, n_loc)
+                self._blocks[kind] = (csr, self.in_deg[g:], self.out_deg_cells)
+            else:
+                raise ValueError(f"unknown block kind {kind!r}")
+        return self._blocks[kind]
+
+    def all_gather_cells(self, local_rows: torch.Tensor) -> torch.Tensor:
+        """This rank's cell rows [n_local_cells, d] -> the rows of ALL cells [n_cells, d], in cell order, on every rank."""
+        if self.world == 1:
+            return local_rows
+        ranges, chunk = row_ranges(self.n_cells, self.world)
+        d = local_rows.shape[1]
+        pad = torch.zeros((chunk, d), dtype=local_rows.dtype, device=local_rows.device)
+        pad[:local_rows.shape[0]] = local_rows
+        out = torch.empty((self.world * chunk, d), dtype=local_rows.dtype, device=local_rows.device)
+        dist.all_gather_into_tensor(out, pad, group=self.group)
+        return out[:self.n_cells]  # every range but the last is a whole chunk: the gathered rows are already contiguous in cell order
+
+    def all_sum(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            t = t.clone()
+            dist.all_reduce(t, group=self.group)
+        return t
+
+
+def sharded_cellgene_conv(x_local: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], scg: ShardedCellGeneGraph, kind: str, *,
+                          norm: str = "both", agg: str = "sum", relu: bool = False) -> torch.Tensor:
+    """One weighted GraphConv (graphsc.py:434-484: ``rst = act(D_in^-1/2 . agg(A . (D_out^-1/2 X) W) + b)`` for norm "both"; 1 / D_in on
+    the destination side for "right" / "left") over this rank's part of a cell - gene graph.  ``x_local``: features of the local nodes
+    (genes, then this rank's cells).  Returns the block's destination rows: all local nodes (``kind="all"``; the gene rows identical on
+    every rank) or this rank's cells (``kind="cells"``)."""
+    from . import autograd
+    ops = scg.ops or _hip_kernels
+    csr, in_deg, out_deg = scg.block(kind)
+    colscale = rowscale = None
+    if norm == "both":
+        colscale = out_deg.clamp(min=1).pow(-0.5)
+        rowscale = in_deg.clamp(min=1).pow(-0.5)
+    elif norm != "none":
+        rowscale = 1.0 / in_deg.clamp(min=1)
+    if agg == "mean":
+        inv = 1.0 / in_deg.clamp(min=1)
+        rowscale = inv if rowscale is None else rowscale * inv
+    pre = autograd.gcn_layer(x_local, weight, csr, None, False, colscale=colscale, reduce=ops.REDUCE_SUM)
+    if kind == "all" and scg.world > 1:
+        pre = _SumLeadingRows.apply(pre, scg.n_genes, scg.group)
+    if rowscale is not None:
+        pre = pre * rowscale[:, None]
+    if bias is not None:
+        pre = pre + bias
+    return torch.relu(pre) if relu else pre
+
+
+class _ShardedSelfLoopGramBCE(torch.autograd.Function):
+    """This rank's share of mean(binary_cross_entropy_with_logits(Z Z^T, I_self, pos_weight=p)) over ALL n x n cell pairs (graphsc.py:
+    208-216 with the whole cell set as the batch; the target's ones are the cells' self loops), as a function of the rank's own rows
+    z_p: the rows' pass against the all-gathered Z (dh_gram_pairwise_rect_f32) plus the diagonal corrections.  The logits are
+    symmetric, so the gradient of the GLOBAL sum with respect to z_p is 2 O_p (+ the diagonal terms): Z is gathered once, no
+    gradient travels.  The sum of the ranks' values is the loss."""
+
+    @staticmethod
+    def forward(ctx, z, has_self, p, n_total, scg):
+        ops = scg.ops or _hip_kernels
+        z_all = scg.all_gather_cells(z.contiguous())
+        rowloss, o = ops.gram_pairwise_rect(z.contiguous(), z_all.contiguous())
+        xe = (z * z).sum(1)
+        term = torch.where(has_self, p * torch.nn.functional.softplus(-xe) - torch.nn.functional.softplus(xe), torch.zeros_like(xe))
+        ctx.save_for_backward(z, o, xe, has_self)
+        ctx.p, ctx.n_total = p, n_total
+        return ((rowloss.sum(dtype=torch.float64) + term.sum(dtype=torch.float64)) / float(n_total)**2).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, o, xe, has_self = ctx.saved_tensors
+        scale = (g / float(ctx.n_total)**2).to(torch.float32)
+        sig = torch.sigmoid(xe)
+        c = torch.where(has_self, ctx.p * (sig - 1) - sig, torch.zeros_like(xe))
+        return scale * 2.0 * (o + c[:, None] * z), None, None, None, None
+
+
+def sharded_selfloop_gram_bce(z_local: torch.Tensor, has_self: torch.Tensor, pos_weight: float, scg: ShardedCellGeneGraph) -> torch.Tensor:
+    return _ShardedSelfLoopGramBCE.apply(z_local, has_self, float(pos_weight), scg.n_cells, scg)

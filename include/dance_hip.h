@@ -366,6 +366,16 @@ enum dh_gram_mode { DH_GRAM_SOFTPLUS = 0, DH_GRAM_SIGMOID_SQ = 1 };
 DH_API int dh_gram_pairwise_f32(int mode, int64_t n, int64_t d, const float* Z, int64_t ldz, float* O, int64_t ldo, float* rowloss,
                          void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* The rectangular form of the same pass: rows i from Zr [n_rows, d], columns j from Z [n, d] —
+ *   rowloss[i] = sum_{j < n} f(<zr_i, z_j>),   O[i, :] = sum_{j < n} f'(<zr_i, z_j>) z_j        (i < n_rows)
+ * — for the cell-sharded full-graph decoder (dance_amd/sharding.py: a rank's rows of graphsc.py:208-216's loss against the
+ * all-gathered embedding; with x symmetric the gradient of the GLOBAL sum w.r.t. a rank's own rows is still 2 O, so no gradient
+ * travels).  dh_gram_pairwise_f32 is this with Zr = Z.  workspace: dh_gram_pairwise_rect_workspace_bytes.                  */
+DH_API size_t dh_gram_pairwise_rect_workspace_bytes(int64_t n_rows, int64_t n, int64_t d);
+DH_API int dh_gram_pairwise_rect_f32(int mode, int64_t n_rows, int64_t n, int64_t d, const float* Zr, int64_t ldr, const float* Z,
+                              int64_t ldz, float* O, int64_t ldo, float* rowloss, void* workspace, size_t workspace_bytes,
+                              dh_stream_t stream);
+
 /* The y = 1 entries of the same loss (graphsc.py:208-214: the non-zeros of adj[dst][:, dst]), listed as (us[e], vs[e]), each at
  * most once: forward xe[e] = <z_us, z_vs>, term[e] = pos_weight * softplus(-xe) - softplus(xe) (add sum(term) to sum(rowloss));
  * backward dZ = scale[0] * (2 O + sum_e c_e (e_us z_vs^T + e_vs z_us^T)), c_e = pos_weight (sigmoid(xe) - 1) - sigmoid(xe), in list

@@ -283,6 +283,14 @@ def gram_pairwise(Z, mode=0):
     return (sig * sig).sum(1).float(), ((2 * sig * sig * (1 - sig)) @ Z.double()).float()
 
 
+def gram_pairwise_rect(Zr, Z, mode=0):
+    x = Zr.double() @ Z.double().t()
+    sig = torch.sigmoid(x)
+    if mode == 0:
+        return torch.nn.functional.softplus(x).sum(1).float(), (sig @ Z.double()).float()
+    return (sig * sig).sum(1).float(), ((2 * sig * sig * (1 - sig)) @ Z.double()).float()
+
+
 def _edge_rows(rowptr):
     n = rowptr.numel() - 1
     return torch.repeat_interleave(torch.arange(n), (rowptr[1:] - rowptr[:-1]).to(torch.int64))
@@ -488,7 +496,7 @@ def umap_connectivities(knn_idx, knn_dist):
 
 
 # every name above that replaces a function of ``dance_amd.kernels`` (the model host-logic tests patch all of them)
-STAND_INS = ("adam_step", "degree_scales", "block_cells_static", "block_cells_static_workspace_bytes", "gcn_narrow_supported", "gcn_narrow_forward", "gcn_narrow_backward", "zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
+STAND_INS = ("adam_step", "degree_scales", "block_cells_static", "block_cells_static_workspace_bytes", "gcn_narrow_supported", "gcn_narrow_forward", "gcn_narrow_backward", "zinb_nll_forward", "zinb_nll_backward", "gram_pairwise", "gram_pairwise_rect", "umap_connectivities", "relu_mask_apply", "dense_to_csr", "rowsum_masked", "col_any_gt", "rowscale_log1p", "col_moments",
              "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",

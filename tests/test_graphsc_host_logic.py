@@ -58,6 +58,27 @@ def test_graphsc_fit_host_logic_vs_reference(monkeypatch, tag, batch_size, agg, 
             assert rel_err(m.model.state_dict()[k.split("::", 1)[1]].numpy(), gold[k]) < 1e-3, k
 
 
+def test_fit_full_graph_equals_the_reference_fit_with_one_batch(monkeypatch):
+    """GraphSC.fit_full_graph (the cell-sharded full-graph form, here on one process: same arithmetic, no collectives) == the
+    reference's own fit with batch_size >= n_cells (golden tag "full"): losses, embedding, updated parameters."""
+    from dance_amd import kernels
+    from dance_amd.modules.single_modality.clustering import graphsc
+    for name in STAND_INS:
+        monkeypatch.setattr(kernels, name, getattr(cpu_ops, name))
+    gold = np.load(GOLD)
+    kw = json.loads(str(gold["gsc_kw"]))
+    m = graphsc.GraphSC(**kw, n_clusters=3, device="cpu")
+    m.model.decoder.dropout = 0.0
+    m.model.load_state_dict({k.split("::", 1)[1]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("gsc_full_sd0::")})
+    m.ops = cpu_ops
+    m.fit_full_graph(_graph(gold), epochs=3, lr=1e-2)
+    assert np.allclose(m.losses, gold["gsc_full_losses"], rtol=2e-4, atol=0)
+    assert rel_err(m.get_latent(), gold["gsc_full_z"]) < 1e-3
+    for k in gold.files:
+        if k.startswith("gsc_full_sd1::"):
+            assert rel_err(m.model.state_dict()[k.split("::", 1)[1]].numpy(), gold[k]) < 1e-3, k
+
+
 def test_static_cell_block_matches_sampled_block(monkeypatch):
     """cellgraph.StaticCellBlock (sources = [seeds | all genes], e_max entries, one padding row) gives WeightedGraphConv / GCNAE the
     outputs and gradients of the dgl.to_block-ordered block of the same seeds; the captured step's body (_CapturedStep._step, run
