@@ -127,6 +127,7 @@ def _declare(lib):
         "dh_comm_rank": (c_int, [P]),
         "dh_comm_allgather_rows_f32": (c_int, [P, P, i64, i64, P, P]),
         "dh_comm_allreduce_f32": (c_int, [P, P, i64, P]),
+        "dh_comm_halo_offsets": (c_int, [i32, i32, P, P, P, P, P, P]),
         "dh_comm_halo_exchange_f32": (c_int, [P, P, P, P, P, i64, P]),
         "dh_comm_halo_spmm_f32": (c_int, [P, i64, i64, i64, P, P, P, P, i64, P, P, P, P, P, i64, P, i64, P, i64, P, i32, P, P, P]),
         "dh_block_cells_static_workspace_bytes": (c_size_t, [i64]),

@@ -12,6 +12,7 @@
 //   dh_comm_halo_spmm_f32       the layer's aggregation with the exchange hidden behind the interior rows: pack
 //                               (dh_gather_rows_f32) -> exchange on the comm stream || interior rows (dh_spmm_csr_rows_f32) on
 //                               the compute stream -> boundary rows once the halo has landed; events, no host sync.
+#include <vector>
 #include <dlfcn.h>
 #include <string.h>
 #include <rccl/rccl.h>
@@ -157,30 +158,44 @@ extern "C" int dh_comm_allreduce_f32(dh_comm_t comm, float* buf, int64_t count, 
   return DH_OK;
 }
 
+// The plan of one all-to-all-v: where peer p's block starts in the packed send buffer and in the receive buffer (row units, blocks
+// ordered by peer rank), and the validity rules of the counts.  Host arithmetic only — exported so that the plan can be checked without
+// a GPU (tests/test_comm_plan.py simulates the grouped send / receive pairs of a whole world from these offsets).
+extern "C" int dh_comm_halo_offsets(int world, int rank, const int64_t* send_rows_host, const int64_t* recv_rows_host,
+                                    int64_t* send_offset_host, int64_t* recv_offset_host, int64_t* n_send, int64_t* n_recv) {
+  const char* me = "dh_comm_halo_offsets";
+  if (world < 1 || rank < 0 || rank >= world) return dh::fail(DH_ERR_INVALID, "%s: bad world / rank", me);
+  if (!send_rows_host || !recv_rows_host || !send_offset_host || !recv_offset_host) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  int64_t so = 0, ro = 0;
+  for (int p = 0; p < world; ++p) {
+    if (send_rows_host[p] < 0 || recv_rows_host[p] < 0) return dh::fail(DH_ERR_INVALID, "%s: negative count", me);
+    if (p == rank && (send_rows_host[p] || recv_rows_host[p])) return dh::fail(DH_ERR_INVALID, "%s: a rank does not exchange rows with itself", me);
+    send_offset_host[p] = so;
+    recv_offset_host[p] = ro;
+    so += send_rows_host[p];
+    ro += recv_rows_host[p];
+  }
+  if (n_send) *n_send = so;
+  if (n_recv) *n_recv = ro;
+  return DH_OK;
+}
+
 extern "C" int dh_comm_halo_exchange_f32(dh_comm_t comm, const float* send, const int64_t* send_rows_host, float* recv,
                                          const int64_t* recv_rows_host, int64_t width, dh_stream_t stream) {
   if (!comm) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_exchange_f32: null communicator");
   if (!send_rows_host || !recv_rows_host || width < 0) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_exchange_f32: bad argument");
   hipStream_t st = dh::as_stream(stream);
+  std::vector<int64_t> soff((size_t)comm->world), roff((size_t)comm->world);
   int64_t so = 0, ro = 0;
-  for (int p = 0; p < comm->world; ++p) {
-    if (send_rows_host[p] < 0 || recv_rows_host[p] < 0) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_exchange_f32: negative count");
-    if (p == comm->rank && (send_rows_host[p] || recv_rows_host[p]))
-      return dh::fail(DH_ERR_INVALID, "dh_comm_halo_exchange_f32: a rank does not exchange rows with itself");
-    so += send_rows_host[p];
-    ro += recv_rows_host[p];
-  }
+  if (int rc = dh_comm_halo_offsets(comm->world, comm->rank, send_rows_host, recv_rows_host, soff.data(), roff.data(), &so, &ro)) return rc;
   if ((so && !send) || (ro && !recv)) return dh::fail(DH_ERR_INVALID, "dh_comm_halo_exchange_f32: null buffer");
   if (width == 0 || (so == 0 && ro == 0)) return DH_OK;
   DH_NCCL(rccl()->GroupStart(), "dh_comm_halo_exchange_f32");
-  so = ro = 0;
   for (int p = 0; p < comm->world; ++p) {  // one send / receive pair per peer, all in flight at once on the point-to-point links
     if (send_rows_host[p])
-      DH_NCCL(rccl()->Send(send + so * width, (size_t)(send_rows_host[p] * width), ncclFloat, p, comm->nccl, st), "dh_comm_halo_exchange_f32");
+      DH_NCCL(rccl()->Send(send + soff[p] * width, (size_t)(send_rows_host[p] * width), ncclFloat, p, comm->nccl, st), "dh_comm_halo_exchange_f32");
     if (recv_rows_host[p])
-      DH_NCCL(rccl()->Recv(recv + ro * width, (size_t)(recv_rows_host[p] * width), ncclFloat, p, comm->nccl, st), "dh_comm_halo_exchange_f32");
-    so += send_rows_host[p];
-    ro += recv_rows_host[p];
+      DH_NCCL(rccl()->Recv(recv + roff[p] * width, (size_t)(recv_rows_host[p] * width), ncclFloat, p, comm->nccl, st), "dh_comm_halo_exchange_f32");
   }
   DH_NCCL(rccl()->GroupEnd(), "dh_comm_halo_exchange_f32");
   return DH_OK;

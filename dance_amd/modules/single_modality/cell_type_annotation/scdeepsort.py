@@ -66,6 +66,9 @@ class ScDeepSort(BaseClassificationMethod):
     # feature gathers — and indexed; the two evaluate() calls of an epoch share one such pass.  False = the reference's
     # batch-by-batch loop over sampled blocks (scdeepsort.py:272-283,299-330), kept for block-exact parity checks.
     full_graph_eval = True
+    # Captured steps as two graphs with the gradient all-reduce between them (the form used with more than one process); True forces it
+    # on one process too (tests)
+    capture_split = False
 
     def __init__(self, dim_in: int, dim_hid: int, num_layers: int, species: str, tissue: str, *, dropout: int = 0,
                  batch_size: int = 500, device: str = "cuda", save_root=None, verbose: bool = True,
@@ -143,10 +146,12 @@ class ScDeepSort(BaseClassificationMethod):
                          dropout=self.dropout, compute_dtype=self.compute_dtype).to(self.device)
         self.sampler = NeighborSampler(fanouts=[-1] * self.n_layers, edge_dir="in")
         # One captured hipGraph per training step (static-shape block of the batch's cells, forward, loss, backward, Adam): at the
-        # reference's batch size (500) a step is a few dozen microsecond kernels and the loop is launch-bound.  Single process, one
-        # layer, CellFeatureGraph node layout, enough full batches to amortise the capture; DANCE_AMD_HIPGRAPH=0 keeps the eager loop.
-        n_full = len(train_idx) // self.batch_size
-        self._use_graph = (HIPGRAPH and sharding.world_info()[1] == 1 and self.n_layers == 1 and graph.gene_prefix() >= 0
+        # reference's batch size (500) a step is a few dozen microsecond kernels and the loop is launch-bound.  One layer,
+        # CellFeatureGraph node layout, enough full batches (of this rank's share of the cells) to amortise the capture;
+        # DANCE_AMD_HIPGRAPH=0 keeps the eager loop.  More than one process: two graphs per step, the gradient all-reduce between them.
+        self._world = sharding.world_info()[1]
+        n_full = -(-len(train_idx) // self._world) // self.batch_size
+        self._use_graph = (HIPGRAPH and self.n_layers == 1 and graph.gene_prefix() >= 0
                            and str(self.device).startswith("cuda") and n_full >= HIPGRAPH_MIN_BATCHES and 1 < self.batch_size <= HIPGRAPH_MAX_BATCH
                            and not any(layer.use_neigh for layer in self.model.layers))
         self._captured = None
@@ -156,7 +161,6 @@ class ScDeepSort(BaseClassificationMethod):
 
         # more than one process: data parallelism over the training cells (the graph is replicated, the model is small):
         # every rank trains on its share, gradients are averaged with one flat all-reduce per step (dance_amd/sharding.py)
-        self._world = sharding.world_info()[1]
         if self._world > 1:
             sharding.broadcast_parameters(self.model)
         self._print(f"Train Number: {len(train_idx)}, Val Number: {len(val_idx)}")
@@ -181,36 +185,37 @@ class ScDeepSort(BaseClassificationMethod):
         self._print(f"Epoch {_epoch:04d}, Train Acc {_train_acc:.4f}, Val Correct Num {final_val_correct_num}, "
                     f"Val Total Num {len(val_idx)}, Val Unsure Num {final_val_unsure_num}")
 
-    def _captured_step_body(self, block):
+    def _captured_forward_backward(self, block):
         blk = block.rebuild()
         loss = self.loss_fn(self.model([blk], blk.srcdata["features"]), blk.dstdata["label"])
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
-        if not kernels.adam_step(self.optimizer):  # dh_adam_step_f32 once the optimiser's state exists
-            self.optimizer.step()
         return loss.detach()
 
+    def _captured_optimiser_step(self):
+        if not kernels.adam_step(self.optimizer):  # dh_adam_step_f32 once the optimiser's state exists
+            self.optimizer.step()
+
+    def _captured_step_body(self, block):
+        loss = self._captured_forward_backward(block)
+        self._captured_optimiser_step()
+        return loss
+
     def _capture_step(self, graph, first_seeds):
-        """Record one training step on a StaticCellBlock as a hipGraph; the model and the (fresh) optimiser state are put back to
-        where they were, so capturing is not a training step."""
+        """Record one training step on a StaticCellBlock as a hipGraph (dance_amd/capture.py; with more than one process: two graphs
+        and the gradient all-reduce between them); the model and the (fresh) optimiser state are put back to where they were, so
+        capturing is not a training step."""
+        from .... import sharding
+        from ....capture import CapturedStep
         from ....cellgraph import StaticCellBlock
         if self.optimizer.state:
             raise RuntimeError("capture expects a fresh optimiser")
         block = StaticCellBlock(graph, self.batch_size)
         saved = deepcopy(self.model.state_dict())
         block.seeds.copy_(first_seeds)
-        dev = first_seeds.device
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._captured_step_body(block)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = self._captured_step_body(block)
-        torch.cuda.synchronize(dev)
+        g = CapturedStep(lambda: self._captured_forward_backward(block), self._captured_optimiser_step, first_seeds.device,
+                         split=getattr(self, "_world", 1) > 1 or self.capture_split, between=lambda: sharding.allreduce_gradients(self.model))
+        loss = g.outputs
         self.model.load_state_dict(saved)       # in place: the graph keeps pointing at these tensors
         for st in self.optimizer.state.values():  # moments and step counters back to zero, in place
             for v in st.values():

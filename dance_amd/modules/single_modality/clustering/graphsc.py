@@ -348,7 +348,7 @@ class _CapturedStep:
         self.graph = None
         self.emb = self.loss = None
 
-    def _step(self):
+    def _forward_backward(self):
         blk = self.block.rebuild()
         x = blk.srcdata["features"]
         _, emb = self.model.forward([blk], x, decode=False)  # :202
@@ -357,30 +357,32 @@ class _CapturedStep:
         loss = self.norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), self.diag, self.diag, self.pos_weight)
         self.optim.zero_grad(set_to_none=True)
         loss.backward()
-        if not kernels.adam_step(self.optim):  # dh_adam_step_f32 once the optimiser's state exists (created by the first torch step)
-            self.optim.step()
         return emb_out, loss.detach()
 
-    def capture(self, first_seeds: torch.Tensor):
-        """Warm up on a side stream (allocator, autotuning-free kernels, Adam state), then record.  The warm-up steps ARE training
-        steps on ``first_seeds``-shaped batches only in effect if the caller wants them to be: parameters and optimiser state are
-        restored afterwards, so capturing leaves the model exactly where it was."""
+    def _optimiser_step(self):
+        if not kernels.adam_step(self.optim):  # dh_adam_step_f32 once the optimiser's state exists (created by the first torch step)
+            self.optim.step()
+
+    def _step(self):
+        out = self._forward_backward()
+        self._optimiser_step()
+        return out
+
+    def capture(self, first_seeds: torch.Tensor, *, split: bool = False):
+        """Warm up on a side stream (allocator, Adam state), then record (dance_amd/capture.py).  ``split``: two graphs with the
+        gradient all-reduce between them — the data-parallel form.  Parameters and optimiser state are restored afterwards, so
+        capturing leaves the model exactly where it was."""
         import copy
+
+        from .... import sharding
+        from ....capture import CapturedStep
         if self.optim.state:
             raise RuntimeError("capture expects a fresh optimiser (its state tensors are created by the warm-up steps and reset below)")
         saved_model = copy.deepcopy(self.model.state_dict())
         self.block.seeds.copy_(first_seeds)
-        side = torch.cuda.Stream(device=first_seeds.device)
-        side.wait_stream(torch.cuda.current_stream(first_seeds.device))
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._step()
-        torch.cuda.current_stream(first_seeds.device).wait_stream(side)
-        torch.cuda.synchronize(first_seeds.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.emb, self.loss = self._step()
-        torch.cuda.synchronize(first_seeds.device)
+        self.graph = CapturedStep(self._forward_backward, self._optimiser_step, first_seeds.device, split=split,
+                                  between=lambda: sharding.allreduce_gradients(self.model))
+        self.emb, self.loss = self.graph.outputs
         self.model.load_state_dict(saved_model)  # copies INTO the captured parameter / buffer tensors
         for st in self.optim.state.values():      # the graph updates these very tensors: reset them in place (moments 0, step 0)
             for v in st.values():
@@ -400,6 +402,9 @@ class GraphSC(BaseClusteringMethod):
     # reproducible (``torch.randperm(n, generator=...)`` per epoch).  Not a constructor argument: the constructor is
     # the reference's (graphsc.py:70-87).
     shuffle_generator = None
+    # Captured steps as two graphs with the gradient all-reduce between them (the form used with more than one process); True forces
+    # it on one process too (tests)
+    capture_split = False
 
     def __init__(self, agg: str = "sum", activation: str = "relu", in_feats: int = 50, n_hidden: int = 1, hidden_dim: int = 200,
                  hidden_1: int = 300, hidden_2: int = 0, dropout: float = 0.1, n_layers: int = 1, hidden_relu: bool = False,
@@ -463,7 +468,7 @@ class GraphSC(BaseClusteringMethod):
         dataloader = DataLoader(g, train_ids, sampler, batch_size=batch_size, shuffle=True, drop_last=False,
                                 generator=self.shuffle_generator, block_hook=_dst_edge_hook if fused else None)
         n_full = len(train_ids) // batch_size
-        use_graph = (HIPGRAPH and fused and world == 1 and self.n_layers == 1 and dataloader.cells_only and g.device.type == "cuda"
+        use_graph = (HIPGRAPH and fused and self.n_layers == 1 and dataloader.cells_only and g.device.type == "cuda"
                      and n_full >= HIPGRAPH_MIN_BATCHES and 1 < batch_size <= HIPGRAPH_MAX_BATCH)
         # fused: one multi-tensor kernel per step instead of ~14 — inside the captured step of batch 128 that is 0.57 -> 0.47 ms per batch
         optim = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=use_graph, fused=g.device.type == "cuda")
@@ -480,7 +485,7 @@ class GraphSC(BaseClusteringMethod):
                 idx = idx[perm]
                 if captured is None:
                     captured = _CapturedStep(self, g, batch_size, optim)
-                    captured.capture(idx[:batch_size])
+                    captured.capture(idx[:batch_size], split=world > 1 or self.capture_split)
                 z_all = torch.empty((n_full * batch_size, self.model.embedding_dim), dtype=torch.float32, device=g.device)
                 loss_all = torch.empty(n_full, dtype=torch.float32, device=g.device)
                 for i in range(n_full):

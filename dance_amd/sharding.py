@@ -215,6 +215,15 @@ class ShardedGCNGraph:
             raise ValueError(f"halo_dtype must be 'f32' or 'bf16', got {halo_dtype!r}")
         self.halo_dtype, self.perm = halo_dtype, perm
         self.stats = {"exchanged_bytes": 0, "exchanges": 0}
+        # Who carries the exchanges.  "torch" (default): torch.distributed — the process group the launcher initialised ("nccl" IS RCCL
+        # on ROCm; "gloo" in the CPU tests).  "capi" (DANCE_AMD_TRANSPORT=capi; fp32 wire, device tensors): the same three collectives
+        # through the C ABI (dh_comm_halo_exchange_f32 / _allgather_rows_f32 / _allreduce_f32 of csrc/comm.hip on a communicator
+        # bootstrapped over the group) — what a host without torch.distributed calls.  One RCCL underneath either way.
+        import os
+        self.transport = os.environ.get("DANCE_AMD_TRANSPORT", "torch")
+        if self.transport not in ("torch", "capi"):
+            raise ValueError(f"DANCE_AMD_TRANSPORT must be 'torch' or 'capi', got {self.transport!r}")
+        self._comm = self._comm_stream = None
         if mode == "alltoall" and full is None:
             raise ValueError("mode='alltoall' needs the replicated graph (full=(A, A^T) as GraphShards over all rows)")
         self.a, self.at = a_shard, at_shard
@@ -291,6 +300,20 @@ class ShardedGCNGraph:
             return None
         h = send_rows.shape[1]
         self.stats["exchanges"] += 1
+        if self.transport == "capi" and self.halo_dtype == "f32" and send_rows.is_cuda:
+            comm, cs = self._capi(send_rows.device)
+            cur = torch.cuda.current_stream(send_rows.device)
+            cs.wait_stream(cur)  # the packed rows are ready
+            with torch.cuda.stream(cs):
+                comm.halo_exchange(send_rows, plan.send_counts, recv_into, plan.recv_counts)
+            send_rows.record_stream(cs)
+            recv_into.record_stream(cs)
+            self.stats["exchanged_bytes"] += plan.n_halo * h * 4
+
+            class _OnCommStream:
+                def wait(_self):
+                    torch.cuda.current_stream(send_rows.device).wait_stream(cs)
+            return _OnCommStream()
         if self.halo_dtype == "bf16":
             wire_send = send_rows.to(torch.bfloat16)
             wire_recv = torch.empty((plan.n_halo, h), dtype=torch.bfloat16, device=send_rows.device)
@@ -306,6 +329,14 @@ class ShardedGCNGraph:
         self.stats["exchanged_bytes"] += plan.n_halo * h * 4
         return dist.all_to_all_single(recv_into, send_rows, output_split_sizes=plan.recv_counts, input_split_sizes=plan.send_counts,
                                       group=self.group, async_op=True)
+
+    def _capi(self, device):
+        """(Communicator over this group, its stream), created on first use."""
+        if self._comm is None:
+            from .comm import Communicator
+            self._comm = Communicator.from_torch_distributed(self.group)
+            self._comm_stream = torch.cuda.Stream(device=device)
+        return self._comm, self._comm_stream
 
     def halo_vector(self, plan: HaloPlan, v: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
         """A replicated global per-node vector in the operand-buffer order of ``plan``: [own range | received rows]."""
@@ -359,7 +390,10 @@ class ShardedGCNGraph:
             pad[:local.shape[0]] = local
             local = pad
         out = torch.empty((self.world * self.chunk, h), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+        if self.transport == "capi" and local.is_cuda and local.dtype == torch.float32:
+            self._capi(local.device)[0].allgather_rows(local.contiguous(), out)
+        else:
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
         self.stats["exchanges"] += 1
         self.stats["exchanged_bytes"] += (self.world - 1) * self.chunk * h * local.element_size()
         return out
@@ -379,7 +413,10 @@ class ShardedGCNGraph:
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self.transport == "capi" and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous():
+                self._capi(t.device)[0].allreduce_(t)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
 

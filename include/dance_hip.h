@@ -642,6 +642,12 @@ DH_API int dh_comm_rank(dh_comm_t comm);
 DH_API int dh_comm_allgather_rows_f32(dh_comm_t comm, const float* local, int64_t rows_per_rank, int64_t width, float* out,
                                dh_stream_t stream);
 DH_API int dh_comm_allreduce_f32(dh_comm_t comm, float* buf, int64_t count, dh_stream_t stream);
+/* Host arithmetic of one all-to-all-v (no GPU, no communicator): offsets (in rows) of peer p's block in the packed send buffer and in
+ * the receive buffer, blocks ordered by peer rank, totals in *n_send / *n_recv (may be NULL); rejects negative counts and a non-zero
+ * count for `rank` itself.  dh_comm_halo_exchange_f32 issues exactly one ncclSend(send + send_offset[p] * width, send_rows[p] * width)
+ * and one ncclRecv(recv + recv_offset[p] * width, recv_rows[p] * width) per peer with a non-zero count, inside one group. */
+DH_API int dh_comm_halo_offsets(int world, int rank, const int64_t* send_rows_host, const int64_t* recv_rows_host,
+                         int64_t* send_offset_host, int64_t* recv_offset_host, int64_t* n_send, int64_t* n_recv);
 DH_API int dh_comm_halo_exchange_f32(dh_comm_t comm, const float* send, const int64_t* send_rows_host, float* recv,
                                const int64_t* recv_rows_host, int64_t width, dh_stream_t stream);
 DH_API int dh_comm_halo_spmm_f32(dh_comm_t comm, int64_t n_local, int64_t n_halo, int64_t width,

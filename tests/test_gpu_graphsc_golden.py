@@ -210,13 +210,17 @@ def test_graphsc_fit_captured_step_vs_reference(cuda_device, gold, monkeypatch):
     from dance_amd.modules.single_modality.clustering import graphsc
     monkeypatch.setattr(graphsc, "HIPGRAPH_MIN_BATCHES", 1)
     res = {}
-    for on in (True, False):
-        monkeypatch.setattr(graphsc, "HIPGRAPH", on)
+    for on in (True, False, "split"):  # "split": the step as two graphs with the (here: one-rank) gradient all-reduce between them
+        monkeypatch.setattr(graphsc, "HIPGRAPH", bool(on))
         g = _graph(gold)
         m = _model(gold, "mb", "sum")
+        m.capture_split = on == "split"
         m.shuffle_generator = torch.Generator().manual_seed(123)
         m.fit(g, epochs=3, lr=1e-2, batch_size=16)
         res[on] = (np.asarray(m.losses), m.get_latent().copy(), {k: v.detach().cpu().numpy().copy() for k, v in m.model.state_dict().items()})
+    assert np.array_equal(res["split"][0], res[True][0]) and np.array_equal(res["split"][1], res[True][1])  # the same kernels in the same order
+    for k in res[True][2]:
+        assert np.array_equal(res["split"][2][k], res[True][2][k]), k
     assert np.allclose(res[True][0], gold["gsc_mb_losses"], rtol=2e-4, atol=0)
     assert rel_err(res[True][1], gold["gsc_mb_z"]) < 1e-3
     assert np.allclose(res[True][0], res[False][0], rtol=1e-5) and rel_err(res[True][1], res[False][1]) < 1e-5

@@ -205,15 +205,18 @@ def test_scdeepsort_captured_step_equals_eager(cuda_device, tmp_path, monkeypatc
     monkeypatch.setattr(scdeepsort, "HIPGRAPH_MIN_BATCHES", 1)
     for cd, tol in (("fp32", 1e-5), ("bf16", 2e-2)):
         out = {}
-        for on in (True, False):
-            monkeypatch.setattr(scdeepsort, "HIPGRAPH", on)
+        for on in (True, False, "split"):  # "split": two graphs per step with the (here: one-rank) gradient all-reduce between them
+            monkeypatch.setattr(scdeepsort, "HIPGRAPH", bool(on))
             torch.manual_seed(7)
             m = scdeepsort.ScDeepSort(d, 16, 1, "synthetic", f"cap{on}{cd}", batch_size=64, device="cuda", save_root=tmp_path, verbose=False,
                                       compute_dtype=cd)
+            m.capture_split = on == "split"
             m.shuffle_generator = torch.Generator().manual_seed(11)
             m.fit(g, labels, epochs=3, lr=1e-2, val_ratio=0.2)
-            assert m._use_graph == on and (m._captured is not None) == on
+            assert m._use_graph == bool(on) and (m._captured is not None) == bool(on)
             out[on] = ({k: v.detach().float().cpu().numpy() for k, v in m.model.state_dict().items()}, m.predict_proba(g))
+        for k in out[True][0]:
+            assert np.array_equal(out["split"][0][k], out[True][0][k]), (cd, k)
         for k in out[True][0]:
             assert rel_err(out[True][0][k], out[False][0][k]) < tol, (cd, k)
         assert np.abs(out[True][1] - out[False][1]).max() < tol * 10
