@@ -86,6 +86,8 @@ class ZINBLoss(nn.Module):
 
 
 class MLP(nn.Module):
+    # reference: dance/modules/single_modality/cell_type_annotation/scheteronet.py:339-371 — module skeleton transcribed (attribute names =
+    # state_dict keys; layer order); the Linear layers are HipLinear (dh_gemm_f32 with the ReLU in the epilogue)
 
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout=.5):
         super().__init__()
@@ -235,6 +237,8 @@ class HeteroNet(nn.Module):
         self.adj_t2 = NormAdj(rowptr2, col2, n)
 
     def forward(self, x, edge_index, decoder=False, save_path=None):
+        # reference: scheteronet.py:541-566 — the layer sequence transcribed (embed, H2GCN convs with the running concatenation, jump, final
+        # projection); every conv is two HIP SpMMs on the normalised one- and two-hop patterns
         adj_t, adj_t2 = self.adj_t, self.adj_t2
         x = self.feature_embed(x)
         x = self.activation(x)

@@ -306,6 +306,8 @@ class GraphSCI(nn.Module, BaseRegressionMethod):
     def get_loss(self, batch, adj_orig, z_adj, z_adj_log_std, z_adj_mean, z_exp, mean, disp, pi, mask, le=1, la=1, ke=1, ka=1):
         """(loss_adj, loss_exp, log_lik, kl, loss) as graphsci.py:466-505 computes them — weighted soft-target cross entropy of the
         generated adjacency, masked ZINB negative log-likelihood of the raw counts, the two KL terms — on the device."""
+        # reference: dance/modules/single_modality/imputation/graphsci.py:466-505 — the loss expressions transcribed term by term (this file is
+        # out of the hot path's scope beyond GNNModel; kept so that fit() runs end to end)
         mask = self._mask(mask) if not (isinstance(mask, torch.Tensor) and mask.device == batch.device) else mask
         g = adj_orig.shape[0]
         deg = adj_orig.sum(axis=1)

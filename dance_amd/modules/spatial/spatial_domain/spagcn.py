@@ -443,6 +443,8 @@ class SpaGCN(BaseClusteringMethod):
         """spagcn.py:771-805: search the clustering resolution that yields ``target_num`` clusters — short fits of fresh models
         at res +- step, halving the step when the direction flips.  (``self.res`` is only set on the path that falls out of the
         loop, as in the reference.)"""
+        # reference: dance/modules/spatial/spatial_domain/spagcn.py:771-805 — host control flow transcribed (same bisection, stopping rule and log
+        # strings) so that the recommended resolution is the reference's; the fits it launches are this package's
         res = start
         logger.info(f"Start at {res = :.4f}, {step = :.4f}")
         fit_kw = dict(init_spa=True, init="louvain", tol=tol, lr=lr, epochs=epochs)

@@ -64,20 +64,73 @@ class NeighborGraph(BaseTransform):
             rep = np.ascontiguousarray(rep / norm, dtype=np.float32)
         return torch.from_numpy(rep).to(self.device)
 
+    # ---- method="gauss" (scanpy's diffusion-map kernel, Neighbors._compute_connectivities_diffmap; oracle.graphs.gauss_connectivities) ----
+    @staticmethod
+    def _gauss_weight(d2, s2_i, s2_j):
+        den = s2_i + s2_j
+        return torch.sqrt(2 * torch.sqrt(s2_i) * torch.sqrt(s2_j) / den) * torch.exp(-d2 / den)
+
+    def _gauss_knn(self, idx, dist):
+        """knn=True: weights on the kNN entries with sigma_i^2 = median of the point's k - 1 squared neighbour distances, pattern
+        symmetrised by copying W_ij to a missing W_ji (float64 arithmetic on the device, as scanpy's numpy)."""
+        n, k = idx.shape
+        d2 = dist[:, 1:].double()**2
+        srt = torch.sort(d2, dim=1).values
+        m = k - 1
+        s2 = (srt[:, (m - 1) // 2] + srt[:, m // 2]) * 0.5  # np.median
+        i = torch.arange(n, device=idx.device).repeat_interleave(m)
+        j = idx[:, 1:].reshape(-1).to(torch.int64)
+        w = self._gauss_weight(d2.reshape(-1), s2[i], s2[j])
+        # union pattern: (i, j) and (j, i); where both directions are kNN entries each keeps the value computed from its own row
+        key_f, key_b = i * n + j, j * n + i
+        have = torch.isin(key_b, key_f)
+        keys = torch.cat((key_f, key_b[~have]))
+        vals = torch.cat((w, w[~have]))
+        order = torch.argsort(keys)
+        keys, vals = keys[order], vals[order]
+        rowptr = torch.zeros(n + 1, dtype=torch.int64, device=idx.device)
+        rowptr[1:] = torch.cumsum(torch.bincount(keys // n, minlength=n), 0)
+        return rowptr.to(torch.int32), (keys % n).to(torch.int32).contiguous(), vals.to(torch.float32).contiguous()
+
+    def _gauss_dense(self, x):
+        """knn=False: the kernel on ALL pairs (dense n x n distances: meant for a few thousand points, as in scanpy), sigma_i^2 = the
+        squared distance to the n_neighbors-th point (itself included) / 4, entries <= 1e-14 dropped."""
+        n = x.shape[0]
+        if n > 30000:
+            raise ValueError(f"knn=False builds the dense {n} x {n} kernel matrix; use knn=True beyond ~30k points")
+        xd = x.double()
+        sq = (xd * xd).sum(1)
+        d2 = (sq[:, None] + sq[None, :] - 2 * xd @ xd.t()).clamp(min=0)
+        d2.fill_diagonal_(0)
+        if self.metric in ("cosine", "correlation"):
+            d2 = (d2 * 0.5)**2  # distance = 1 - cos = |u - v|^2 / 2 on the normalised rows; the kernel squares the distance
+        s2 = torch.sort(d2, dim=1).values[:, self.n_neighbors - 1] / 4
+        w = self._gauss_weight(d2, s2[:, None], s2[None, :])
+        w = torch.where(w > 1e-14, w, torch.zeros_like(w)).to(torch.float32)
+        return kernels.dense_to_csr(w)[:3]
+
     def __call__(self, data):
-        if self.method != "umap" or not self.knn:
-            raise NotImplementedError("NeighborGraph on HIP implements method='umap', knn=True (the reference defaults)")
+        if self.method not in ("umap", "gauss"):
+            raise ValueError(f"method must be 'umap' or 'gauss' (sc.pp.neighbors; 'rapids' has no meaning here), got {self.method!r}")
+        if self.method == "umap" and not self.knn:
+            raise ValueError("`method = 'umap' only with `knn = True`.")  # scanpy's own check
         self.logger.info("Start computing the kNN connectivity adjacency matrix")
         x = self._representation(data)
-        idx, dist = kernels.knn(x, self.n_neighbors)
-        if self.metric in ("cosine", "correlation"):
-            dist = dist * dist * 0.5  # 1 - cos / 1 - corr
-        (rowptr, col, val), _ = kernels.umap_connectivities(idx, dist.contiguous())
         n = x.shape[0]
+        if self.method == "gauss" and not self.knn:
+            rowptr, col, val = self._gauss_dense(x)
+        else:
+            idx, dist = kernels.knn(x, self.n_neighbors)
+            if self.metric in ("cosine", "correlation"):
+                dist = dist * dist * 0.5  # 1 - cos / 1 - corr
+            if self.method == "umap":
+                (rowptr, col, val), _ = kernels.umap_connectivities(idx, dist.contiguous())
+            else:
+                rowptr, col, val = self._gauss_knn(idx, dist)
         # the device-resident graph is what the GCN layers consume (value-symmetric: no transpose needed in backward).  The obsp slot
         # holds the scipy matrix the reference stores there; inside an on-device pipeline (the representation came from a
         # DeviceArray) it is built on first access only (LazyScipyCSR), so the pipeline itself copies nothing to the host
-        g = CSRGraph(rowptr, col, val, n, n, symmetric=True)
+        g = CSRGraph(rowptr, col, val, n, n, symmetric=self.method == "umap")
         data.data.uns[f"{self.out}.hip"] = g
         data.data.obsp[self.out] = LazyScipyCSR(g) if self._device_in else g.to_scipy()
         return data

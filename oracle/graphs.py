@@ -125,6 +125,40 @@ def neighbor_graph(x, n_neighbors=15):
 
 
 # ---- HeteronetGraph (heteronet_graph.py:27-40) ---------------------------------------------------------------
+def gauss_connectivities(knn_indices, knn_dists, knn=True):
+    """sc.pp.neighbors(method="gauss") connectivities (neighbor_graph.py:37-39,52-55 forward ``method`` / ``knn``): scanpy 1.10.1
+    ``Neighbors._compute_connectivities_diffmap`` [3P-memory], restated with explicit loops.  ``knn_indices`` / ``knn_dists``
+    [n, k] with the point itself in column 0.
+      knn=True : sigma_i^2 = median of the k - 1 squared neighbour distances; W_ij = sqrt(2 s_i s_j / (s_i^2 + s_j^2)) exp(-d_ij^2 /
+                 (s_i^2 + s_j^2)) on the kNN entries, then W_ji = W_ij wherever i is not among j's neighbours (pattern = the union).
+      knn=False: sigma_i^2 = (squared distance to the last of the k neighbours) / 4, W as above on ALL pairs from the dense distance
+                 matrix (``knn_dists`` is then the dense [n, n] matrix and ``knn_indices`` its row-wise argsort), entries <= 1e-14
+                 dropped."""
+    n = knn_indices.shape[0]
+    if not knn:
+        d2 = np.asarray(knn_dists, dtype=np.float64)**2
+        k = knn_indices.shape[1]
+        sig2 = np.sort(d2, axis=1)[:, k - 1] / 4
+        sig = np.sqrt(sig2)
+        w = np.sqrt(2 * np.multiply.outer(sig, sig) / np.add.outer(sig2, sig2)) * np.exp(-d2 / np.add.outer(sig2, sig2))
+        w[w <= 1e-14] = 0
+        return sp.csr_matrix(w)
+    ind = np.asarray(knn_indices)[:, 1:]
+    d2 = np.asarray(knn_dists, dtype=np.float64)[:, 1:]**2
+    sig2 = np.median(d2, axis=1)
+    sig = np.sqrt(sig2)
+    w = sp.lil_matrix((n, n), dtype=np.float64)
+    for i in range(n):
+        for t, j in enumerate(ind[i]):
+            den = sig2[i] + sig2[j]
+            w[i, j] = np.sqrt(2 * sig[i] * sig[j] / den) * np.exp(-d2[i, t] / den)
+    for i in range(n):
+        for j in ind[i]:
+            if i not in set(ind[j]):
+                w[j, i] = w[i, j]
+    return w.tocsr()
+
+
 def heteronet_edges(features, knears=5):
     """edge list [[i, j] for j in indices[i]] with indices = kneighbors of k+1 points INCLUDING self (:36-39)."""
     idx, _ = knn_exact(features, knears + 1)

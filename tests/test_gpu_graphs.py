@@ -166,6 +166,46 @@ def test_neighbor_graph_connectivities(cuda_device, n, d, k):
     assert np.all(np.abs(got - want) <= want * 2.5e-7 * (4 + a) + 1e-12)
 
 
+@pytest.mark.parametrize("metric", ["euclidean", "cosine"])
+def test_neighbor_graph_gauss_branches(cuda_device, metric):
+    """NeighborGraph(method="gauss") with knn=True (weights on the kNN entries, union pattern) and knn=False (dense kernel) —
+    neighbor_graph.py:37-39,52-55 forward both to scanpy — against oracle.graphs.gauss_connectivities; method="umap" with knn=False is
+    scanpy's ValueError."""
+    from dance_amd import data as dd
+    from dance_amd import kernels
+    from dance_amd.transforms.graph.neighbor_graph import NeighborGraph
+    rng = np.random.default_rng(3)
+    n, d, k = 400, 12, 10
+    x = (rng.standard_normal((6, d))[rng.integers(0, 6, n)] * 3 + rng.standard_normal((n, d))).astype(np.float32)
+    for knn in (True, False):
+        dat = dd.Data(dd.AnnDataLite(x.copy(), obsm={"rep": x.copy()}))
+        NeighborGraph(n_neighbors=k, method="gauss", knn=knn, metric=metric, channel="rep", device="cuda")(dat)
+        got = sp.csr_matrix(dat.data.obsp["NeighborGraph"])
+        got.sort_indices()
+        xn = x / np.linalg.norm(x, axis=1, keepdims=True) if metric == "cosine" else x
+        if knn:
+            idx, dist = kernels.knn(_t(np.ascontiguousarray(xn, dtype=np.float32), cuda_device), k)
+            dist = dist.cpu().numpy().astype(np.float64)
+            if metric == "cosine":
+                dist = dist * dist * 0.5
+            want = og.gauss_connectivities(idx.cpu().numpy(), dist, knn=True)
+        else:
+            xd = xn.astype(np.float64)
+            dm = np.sqrt(np.maximum(((xd[:, None, :] - xd[None, :, :])**2).sum(-1), 0))
+            if metric == "cosine":
+                dm = dm * dm * 0.5
+            want = og.gauss_connectivities(np.argsort(dm, axis=1)[:, :k], dm, knn=False)
+        want.sort_indices()
+        if knn:
+            assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+            assert rel_err(got.data, want.data) < 1e-6
+        else:  # entries at the 1e-14 cut may fall on either side: compare as dense matrices
+            assert np.abs(got.toarray() - want.toarray()).max() < 1e-6
+    dat = dd.Data(dd.AnnDataLite(x.copy(), obsm={"rep": x.copy()}))
+    with pytest.raises(ValueError):
+        NeighborGraph(n_neighbors=k, method="umap", knn=False, channel="rep", device="cuda")(dat)
+
+
 def _neighbor_fixture():
     path = os.path.join(GOLDEN, "neighbor_graph.npz")
     return dict(np.load(path)) if os.path.exists(path) else None
