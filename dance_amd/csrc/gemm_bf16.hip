@@ -336,6 +336,145 @@ int rows_dispatch(int64_t M, int64_t N, int64_t kp, const uint16_t* a, int64_t l
   return rows_launch<32, 8, 32>(M, N, kp, a, la, b, lb, C, ldc, ep, st);  // (two 64-row images of 1 KB rows + the patches exceed 160 KB)
 }
 
+// ---- dW = dY^T X with BOTH operands stored K-major (trans_a, row-major B) and a long K: C[M,N] = sum_k A[k][m] B[k][n] ----------------
+// The generic path transposes both operands into K-contiguous copies first (two extra passes over 2 x (M + N) K bytes: 1.6 ms for
+// the 200 x 400 gradient over 1M cells, of which the product itself is 0.15).  Here a workgroup streams 64-row slabs of A and B as
+// they lie (coalesced 16-byte loads, 16-byte LDS stores) and the MFMA fragments — 8 consecutive k of ONE column — are gathered from
+// LDS with 8 two-byte reads each: the LDS rows are padded so that the 32 columns x 2 k-halves of a wave's fragment read fall on
+// distinct banks.  8 waves (two per SIMD); a wave owns all (<= 7) row tiles of C for one column tile of the workgroup's 256 columns.
+// The slabs of the next TWO steps travel in registers while the current one is multiplied.  The K range is split over the
+// workgroups (fp32 slabs, summed in slice order by gemm_bf16_reduce_kernel).  Shapes: M <= 224, M % 8 == 0, N % 8 == 0, 16-byte
+// aligned rows.
+constexpr int TT_KC = 64;         // k rows per step
+constexpr int TT_LDA = 232;       // bf16 per LDS row of the A slab: 464 bytes (16-byte multiple; 8 rows = 928 words = 32 banks apart)
+constexpr int TT_LDB = 264;       // ... of the B slab (256 columns): 528 bytes
+constexpr size_t TT_LDS = (size_t)2 * TT_KC * (TT_LDA + TT_LDB) * sizeof(uint16_t);  // 126 976 B
+
+template <int MT>  // row tiles of C in use: M <= 32 MT
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void gemm_bf16_tn_tall_kernel(int M, int N, int64_t K, const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B,
+                              int64_t ldb, float* __restrict__ slabs, int64_t k_per_slice, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t tt_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, kb = lane >> 5;
+  // workgroups i, i + 8, ... share an XCD: the column blocks of one K slice are neighbours THERE, so the A slab they all read comes
+  // out of HBM once
+  const int j8 = blockIdx.x >> 3;
+  const int slice = (j8 / n_blocks) * 8 + (blockIdx.x & 7);
+  const int n_blk = (j8 % n_blocks) * 256;                  // first column of this workgroup
+  const int64_t k_begin = (int64_t)slice * k_per_slice;
+  if (k_begin >= K) return;                                 // (the grid rounds the slices up to a multiple of 8)
+  const int k_len = (int)((k_begin + k_per_slice < K ? k_begin + k_per_slice : K) - k_begin);  // rows of this slice
+  const int n_steps = (k_len + TT_KC - 1) / TT_KC;
+  const int pa = M / 8, pb_all = N / 8;                      // 16-byte pieces per global row
+  const int pb0 = n_blk / 8, pb = (pb_all - pb0) < 32 ? (pb_all - pb0) : 32;  // pieces of this workgroup's 256 columns
+  // Thread -> piece: 32 threads per slab row (piece tid & 31 of rows (tid >> 5) + 16 q), the same for A and B — one byte offset per
+  // operand in a register, everything else immediates.  The slice's rows go through a wave-uniform base and 32-bit byte offsets (a
+  // slice is a few MB).  Every load is issued unconditionally from a clamped address — no branches between the loads —, and what
+  // lies outside the matrix is zeroed when the registers are STORED: a select right behind a load would make the wave wait for it.
+  constexpr int NQ = TT_KC / 16;                             // passes of 16 rows per step
+  const char* const a_base = reinterpret_cast<const char*>(A + k_begin * lda);
+  const char* const b_base = reinterpret_cast<const char*>(B + k_begin * ldb + (int64_t)pb0 * 8);
+  const unsigned lda_b = (unsigned)lda * 2u, ldb_b = (unsigned)ldb * 2u;
+  const int row0 = tid >> 5, pc = tid & 31;
+  const unsigned a_col = (unsigned)min(pc, pa - 1) * 16u, b_col = (unsigned)min(pc, pb - 1) * 16u;
+  auto load = [&](int k0, u32x4 (&ra)[NQ], u32x4 (&rb)[NQ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const unsigned kr = (unsigned)min(k0 + row0 + 16 * q, k_len - 1);
+      ra[q] = *reinterpret_cast<const u32x4*>(a_base + (kr * lda_b + a_col));
+      rb[q] = *reinterpret_cast<const u32x4*>(b_base + (kr * ldb_b + b_col));
+    }
+  };
+  auto store = [&](int buf, int k0, const u32x4 (&ra)[NQ], const u32x4 (&rb)[NQ]) __attribute__((always_inline)) {
+    uint16_t* a_img = tt_lds + (size_t)buf * TT_KC * (TT_LDA + TT_LDB) + row0 * TT_LDA + pc * 8;
+    uint16_t* b_img = tt_lds + (size_t)buf * TT_KC * (TT_LDA + TT_LDB) + TT_KC * TT_LDA + row0 * TT_LDB + pc * 8;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const bool in_k = k0 + row0 + 16 * q < k_len;
+      if (pc < 4 * MT) *reinterpret_cast<u32x4*>(a_img + 16 * q * TT_LDA) = (in_k && pc < pa) ? ra[q] : u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(b_img + 16 * q * TT_LDB) = (in_k && pc < pb) ? rb[q] : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  f32x16 tacc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tacc[i][e] = 0.f;
+  // A fragment = 8 consecutive k of ONE column = 8 two-byte LDS reads (+ 4 packs).  (Fetching row pairs as dwords — ds_read2_b32 and
+  // a byte permute that picks the lane's half — halves the LDS instructions and was SLOWER, 0.65 against 0.55 ms: the kernel is bound
+  // by the LDS instruction rate either way, ~5 cycles per wave instruction and CU.  What would lift it is an LDS image transposed
+  // in registers on the way in, so that a fragment is one 16-byte read — the loader's 8 x 8 blocks cost 32 permutes per thread.)
+  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+  auto gather = [&](const uint16_t* img, int ld, int krow, int col0) __attribute__((always_inline)) {
+    const uint16_t* src = img + krow * ld + col0 + r;
+    us8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = src[e * ld];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    const uint16_t* a_img = tt_lds + (size_t)buf * TT_KC * (TT_LDA + TT_LDB);
+    const uint16_t* b_img = a_img + TT_KC * TT_LDA;
+#pragma unroll
+    for (int ks = 0; ks < TT_KC / 16; ++ks) {
+      const int krow = 16 * ks + 8 * kb;
+      const bf16x8 fb = gather(b_img, TT_LDB, krow, wave * 32);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) tacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather(a_img, TT_LDA, krow, i * 32), fb, tacc[i], 0, 0, 0);
+    }
+  };
+  // step t multiplies buffer t & 1 while the slabs of steps t + 1 (requested a step ago) and t + 2 (requested now) are in flight
+  u32x4 ra0[NQ], rb0[NQ], ra1[NQ], rb1[NQ];
+  load(0, ra0, rb0);
+  store(0, 0, ra0, rb0);
+  load(TT_KC, ra1, rb1);  // (past the slice: clamped rows, stored as zeros)
+  __syncthreads();
+  for (int t = 0; t < n_steps; t += 2) {
+    const int k0 = t * TT_KC;
+    load(k0 + 2 * TT_KC, ra0, rb0);
+    compute(0);
+    store(1, k0 + TT_KC, ra1, rb1);
+    __syncthreads();
+    load(k0 + 3 * TT_KC, ra1, rb1);
+    compute(1);  // (an odd number of steps: the buffer holds zeros)
+    store(0, k0 + 2 * TT_KC, ra0, rb0);
+    __syncthreads();
+  }
+  // C[m][n] of row tile i: row m = 32 i + (e & 3) + 8 (e >> 2) + 4 kb, column n = n_blk + 32 wave + r
+  float* slab = slabs + (int64_t)slice * M * N;
+  const int n = n_blk + wave * 32 + r;
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kb;
+      if (m < M && n < N) slab[(int64_t)m * N + n] = tacc[i][e];
+    }
+}
+
+bool tn_tall_applies(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const void* A, int64_t lda, const void* B, int64_t ldb) {
+  return trans_a && !trans_b && M <= 224 && M % 8 == 0 && N % 8 == 0 && N <= 4096 && K >= 64 * TT_KC && lda % 8 == 0 && ldb % 8 == 0 &&
+         lda < (1 << 20) && ldb < (1 << 20) && dh::aligned16(A) && dh::aligned16(B);
+}
+struct TallPlan {
+  int n_blocks, slices;
+  int64_t k_per_slice;
+  size_t slab_bytes;
+};
+TallPlan tn_tall_plan(int64_t M, int64_t N, int64_t K) {
+  TallPlan p;
+  p.n_blocks = (int)dh::ceil_div(N, 256);
+  int64_t slices = 256 / p.n_blocks;  // one workgroup per CU
+  const int64_t max_slices = K / (8 * TT_KC);
+  if (slices > max_slices) slices = max_slices;
+  if (slices < 1) slices = 1;
+  p.k_per_slice = dh::ceil_div(dh::ceil_div(K, slices), TT_KC) * TT_KC;
+  p.slices = (int)dh::ceil_div(K, p.k_per_slice);
+  p.slab_bytes = (size_t)p.slices * M * N * sizeof(float);
+  return p;
+}
+
 struct Plan {
   bool repack_a, repack_b;
   int64_t kp;           // padded K (leading dimension of repacked operands)
@@ -391,6 +530,33 @@ extern "C" int dh_gemm_bf16(int64_t M, int64_t N, int64_t K, int trans_a, int tr
   if (K == 0) {  // empty sum: C = act(bias) (+ C)
     hipLaunchKernelGGL(gemm_bf16_reduce_kernel, dim3((unsigned)dh::ceil_div(M * N, 256)), dim3(256), 0, st, M, N, 0, nullptr, C, ldc, ep);
     return dh::check_launch("dh_gemm_bf16");
+  }
+  if (tn_tall_applies(M, N, K, trans_a, trans_b, A, lda, B, ldb)) {
+    const TallPlan tp = tn_tall_plan(M, N, K);
+    if (workspace && workspace_bytes >= tp.slab_bytes && dh::aligned16(workspace)) {  // (the size query covers it: the generic path needs more)
+      float* slabs = static_cast<float*>(workspace);
+      const unsigned grid = (unsigned)((tp.slices + 7) / 8 * 8 * tp.n_blocks);
+#define DH_TT(MTV)                                                                                                                 \
+  do {                                                                                                                             \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_tall_kernel<MTV>),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TT_LDS) == hipSuccess;             \
+    if (!ok) return dh::fail(DH_ERR_LAUNCH, "dh_gemm_bf16: cannot raise the dynamic LDS limit");                                   \
+    hipLaunchKernelGGL(gemm_bf16_tn_tall_kernel<MTV>, dim3(grid), dim3(512), TT_LDS, st, (int)M, (int)N, K, A, lda, B, ldb, slabs,  \
+                       tp.k_per_slice, tp.n_blocks);                                                                               \
+  } while (0)
+      switch ((int)((M + 31) / 32)) {
+        case 1: DH_TT(1); break;
+        case 2: DH_TT(2); break;
+        case 3: DH_TT(3); break;
+        case 4: DH_TT(4); break;
+        case 5: DH_TT(5); break;
+        case 6: DH_TT(6); break;
+        default: DH_TT(7); break;
+      }
+#undef DH_TT
+      hipLaunchKernelGGL(gemm_bf16_reduce_kernel, dim3((unsigned)dh::ceil_div(M * N, 256)), dim3(256), 0, st, M, N, tp.slices, slabs, C, ldc, ep);
+      return dh::check_launch("dh_gemm_bf16");
+    }
   }
   const Plan p = make_plan(M, N, K, trans_a, trans_b, A, lda, B, ldb);
   const size_t need = p.a_bytes + p.b_bytes + p.slab_bytes;

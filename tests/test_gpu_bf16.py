@@ -98,6 +98,11 @@ GEMM_CASES = [  # M, N, K, trans_a, trans_b
     (300, 200, 400, False, True),     # nn.Linear forward: native NT
     (300, 400, 200, False, False),    # dX = dY W: B repacked
     (200, 400, 3000, True, False),    # dW = dY^T X: both repacked, split over K
+    # tall K-major products (gemm_bf16_tn_tall_kernel: both operands read as they lie, fragments gathered from LDS; K >= 4096)
+    (200, 400, 100003, True, False),  # the C3 gradient dW = dY^T X: 7 row tiles, 13 column tiles in two blocks, ragged K
+    (16, 8, 5000, True, False),       # one row tile, one column tile of 8
+    (224, 520, 9000, True, False),    # every row tile, three column blocks (the last 8 columns wide)
+    (72, 264, 4096, True, False),     # the smallest K this path takes
     (129, 7, 50, False, True),        # K % 8 != 0: padded copies
     (64, 513, 72, True, True),
     (1000, 128, 128, False, True),
