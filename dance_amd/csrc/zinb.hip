@@ -22,8 +22,10 @@
 //     factors so that it stays inside the double range, and log1p(m / d)).  Non-integer or large (> 256) counts take the lgamma /
 //     digamma formulas as before.
 //   * the x = 0 branch (the majority of a count matrix) needs no gamma function at all and only contributes log(pi + (1 - pi) zn):
-//     its transcendentals (log1p, exp, log) run in fp32, the combination in float64.  Worst-case 3e-7 relative per element.
-//   Sums stay float64.  The loss equals the float64 formula to ~1e-7 relative, the gradients to 1e-6 of their max-norm.
+//     it runs in fp32 throughout (zero_terms below).  Worst-case ~5e-7 relative per element.
+//   * the two branches run in two PHASES per row (zinb_kernel below) instead of side by side in a divergent wavefront: 151 -> 56 ms
+//     came from the arithmetic above, the rest from no longer executing the count branch on every 64-gene step.
+//   Sums stay float64.  The loss equals the float64 formula to ~1e-7 relative, the gradients to a few 1e-7 of their max-norm.
 #include "common.h"
 
 namespace {
@@ -106,34 +108,49 @@ __device__ __forceinline__ void gamma_terms(double x, double de, double me, doub
   if (GRAD) dg = digamma_pos(de) - digamma_pos(x + de);
 }
 
+// x = 0 (nine elements in ten of an expression matrix): -log(p + (1 - p) r^d + eps) with r = d / (d + m + eps), all in fp32 — the result
+// feeds an fp32 gradient or a float64 sum of ~1e9 terms; the arguments are O(1) after the activations' clamps (mean >= 1e-5, disp in
+// [1e-4, 1e4]) and log r goes through log1p(-u) for small u = m / s, so d * log r loses nothing to cancellation.
+struct ZTerms {
+  float loss, d_m, d_d, d_p;
+};
 template <bool GRAD>
-__device__ __forceinline__ Terms zinb_terms(double x, double m, double d, double p, double ridge) {
+__device__ __forceinline__ ZTerms zero_terms(float m, float d, float p, float ridge) {
+  ZTerms o{0.f, 0.f, 0.f, 0.f};
+  const float s = d + m + 1e-10f;
+  const float rs = 1.f / s;
+  const float u = (m + 1e-10f) * rs;
+  const float lr = u < 0.5f ? log1pf(-u) : logf(d * rs);
+  const float zn = expf(d * lr);
+  const float w = p + (1.f - p) * zn + 1e-10f;
+  o.loss = -logf(w);
+  if (GRAD) {
+    const float rw = 1.f / w;
+    const float dzc_dzn = -(1.f - p) * rw;
+    o.d_p = -(1.f - zn) * rw;
+    o.d_m = dzc_dzn * (-zn * d * rs);
+    o.d_d = dzc_dzn * zn * (lr + u);
+  }
+  if (ridge > 0.f) {
+    o.loss += ridge * p * p;
+    if (GRAD) o.d_p += 2.f * ridge * p;
+  }
+  return o;
+}
+
+// x > 0: float64 (the Gamma-function ratios as products, one logarithm per 16 factors)
+template <bool GRAD>
+__device__ __forceinline__ Terms count_terms(double x, double m, double d, double p, double ridge) {
   Terms o{0.0, 0.0, 0.0, 0.0};
-  if (x <= 1e-8) {
-    // zn = r^d with r = d / s, s = d + m + eps: log r = log1p(-(m + eps) / s) — fp32 transcendentals on float64-prepared arguments
-    const double s = d + m + kEps;
-    const double u = (m + kEps) / s;
-    const float lr = u < 0.5 ? log1pf(-(float)u) : logf((float)(d / s));
-    const double zn = (double)expf((float)(d * (double)lr));
-    const double w = p + (1.0 - p) * zn + kEps;
-    o.loss = -(double)logf((float)w);
-    if (GRAD) {
-      const double dzc_dzn = -(1.0 - p) / w;
-      o.d_p = -(1.0 - zn) / w;
-      o.d_m = dzc_dzn * (-zn * d / s);
-      o.d_d = dzc_dzn * zn * ((double)lr + u);
-    }
-  } else {
-    const double de = d + kEps, me = m + kEps, q = 1.0 - p + kEps;
-    double lg, dg;
-    gamma_terms<GRAD>(x, de, me, q, lg, dg);
-    const double l1 = fast_log1p(m / de);  // log(1 + m / (d + eps))
-    o.loss = lg + (d + x) * l1;
-    if (GRAD) {
-      o.d_p = 1.0 / q;
-      o.d_m = (d + x) / (de + m) - x / me;
-      o.d_d = dg + l1 - (d + x) * m / (de * (de + m)) + x / de;
-    }
+  const double de = d + kEps, me = m + kEps, q = 1.0 - p + kEps;
+  double lg, dg;
+  gamma_terms<GRAD>(x, de, me, q, lg, dg);
+  const double l1 = fast_log1p(m / de);  // log(1 + m / (d + eps))
+  o.loss = lg + (d + x) * l1;
+  if (GRAD) {
+    o.d_p = 1.0 / q;
+    o.d_m = (d + x) / (de + m) - x / me;
+    o.d_d = dg + l1 - (d + x) * m / (de * (de + m)) + x / de;
   }
   if (ridge > 0.0) {
     o.loss += ridge * p * p;
@@ -142,38 +159,82 @@ __device__ __forceinline__ Terms zinb_terms(double x, double m, double d, double
   return o;
 }
 
-// one wavefront per row: rowloss[row] = sum_g loss(row, g) in float64 (fixed lane order + butterfly: deterministic)
-__global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
-                                                           const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
-                                                           const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
-                                                           double* __restrict__ rowloss) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n) return;
-  const double s = sf ? sf[row] : 1.0;
-  double acc = 0.0;
-  for (int64_t c = lane; c < g; c += 64)
-    acc += zinb_terms<false>((double)X[row * ldx + c], (double)M[row * ldm + c] * s, (double)D[row * ldd + c], (double)P[row * ldp + c], ridge).loss;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-  if (lane == 0) rowloss[row] = acc;
-}
+// One wavefront per row, two phases.  Phase 1 walks the row 64 genes at a time: the x = 0 elements are finished on the spot (fp32),
+// the positions of the x > 0 elements are appended to a per-wave list in LDS (ballot + prefix count: deterministic order).  Phase 2
+// evaluates the float64 count terms on the list, 64 at a time with every lane busy — inside phase 1 the one lane in ten with a count
+// would make the whole wavefront execute the product loops and the float64 logarithm on every step (that divergence, not the
+// arithmetic of the zeros, was why round 3's 151 ms did not depend on the density).  A row with more counts than the list holds
+// finishes the overflow inside phase 1.
+constexpr int NZ_CAP = 2048;  // list entries per wave (8 KB; 4 waves per block)
 
-__global__ __launch_bounds__(256) void zinb_backward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
-                                                            const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
-                                                            const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
-                                                            const double* __restrict__ upstream, float* __restrict__ dM, float* __restrict__ dD,
-                                                            float* __restrict__ dP, int64_t ldo) {
-  const double up = upstream[0];  // d(result) / d(element loss) = grad_output / (n g), a device scalar: no host round trip
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+template <bool GRAD>
+__global__ __launch_bounds__(256) void zinb_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx, const float* __restrict__ M,
+                                                   int64_t ldm, const float* __restrict__ D, int64_t ldd, const float* __restrict__ P, int64_t ldp,
+                                                   const double* __restrict__ sf, double ridge, double* __restrict__ rowloss,
+                                                   const double* __restrict__ upstream, float* __restrict__ dM, float* __restrict__ dD,
+                                                   float* __restrict__ dP, int64_t ldo) {
+  __shared__ int nz_list[4][NZ_CAP];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= n) return;
   const double s = sf ? sf[row] : 1.0;
-  for (int64_t c = lane; c < g; c += 64) {
-    const Terms t = zinb_terms<true>((double)X[row * ldx + c], (double)M[row * ldm + c] * s, (double)D[row * ldd + c], (double)P[row * ldp + c], ridge);
-    dM[row * ldo + c] = (float)(up * t.d_m * s);
-    dD[row * ldo + c] = (float)(up * t.d_d);
-    dP[row * ldo + c] = (float)(up * t.d_p);
+  const double up = GRAD ? upstream[0] : 0.0;  // d(result) / d(element loss) = grad_output / (n g), a device scalar: no host round trip
+  const float upf = (float)up, upsf = (float)(up * s), ridge_f = (float)ridge;
+  const float* x_row = X + row * ldx;
+  const float* m_row = M + row * ldm;
+  const float* d_row = D + row * ldd;
+  const float* p_row = P + row * ldp;
+  int* list = nz_list[wave];
+  double acc = 0.0;
+  float acc_z = 0.f;  // the zeros of one 64-gene step are summed in fp32 lanes and folded into the float64 sum every 16 steps
+  int cnt = 0, folded = 0;
+  auto count_element = [&](int64_t c) __attribute__((always_inline)) {
+    const Terms t = count_terms<GRAD>((double)x_row[c], (double)m_row[c] * s, (double)d_row[c], (double)p_row[c], ridge);
+    if (GRAD) {
+      dM[row * ldo + c] = (float)(up * t.d_m * s);
+      dD[row * ldo + c] = (float)(up * t.d_d);
+      dP[row * ldo + c] = (float)(up * t.d_p);
+    } else {
+      acc += t.loss;
+    }
+  };
+  for (int64_t c0 = 0; c0 < g; c0 += 64) {
+    const int64_t c = c0 + lane;
+    const bool in = c < g;
+    const float x = in ? x_row[c] : 0.f;
+    const bool nz = in && x > 1e-8f;
+    if (in && !nz) {
+      const ZTerms t = zero_terms<GRAD>((float)((double)m_row[c] * s), d_row[c], p_row[c], ridge_f);
+      if (GRAD) {
+        dM[row * ldo + c] = upsf * t.d_m;
+        dD[row * ldo + c] = upf * t.d_d;
+        dP[row * ldo + c] = upf * t.d_p;
+      } else {
+        acc_z += t.loss;
+      }
+    }
+    const unsigned long long mask = __ballot(nz);
+    if (mask) {
+      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+      if (nz) {
+        if (pos < NZ_CAP) list[pos] = (int)c;
+        else count_element(c);
+      }
+      cnt += __popcll(mask);
+    }
+    if (!GRAD && ++folded == 16) {
+      acc += (double)acc_z;
+      acc_z = 0.f;
+      folded = 0;
+    }
+  }
+  if (!GRAD) acc += (double)acc_z;
+  const int listed = cnt < NZ_CAP ? cnt : NZ_CAP;
+  for (int i = lane; i < listed; i += 64) count_element(list[i]);  // (a wave reads its own LDS writes: no barrier needed)
+  if (!GRAD) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) rowloss[row] = acc;
   }
 }
 
@@ -194,8 +255,8 @@ extern "C" int dh_zinb_nll_forward_f32(int64_t n, int64_t g, const float* X, int
   const int rc = check("dh_zinb_nll_forward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
   if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
   if (!rowloss) return dh::fail(DH_ERR_INVALID, "dh_zinb_nll_forward_f32: null output");
-  hipLaunchKernelGGL(zinb_forward_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
-                     pi, ldp, scale_factor, ridge_lambda, rowloss);
+  hipLaunchKernelGGL(zinb_kernel<false>, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
+                     pi, ldp, scale_factor, ridge_lambda, rowloss, (const double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0);
   return dh::check_launch("dh_zinb_nll_forward_f32");
 }
 
@@ -205,7 +266,7 @@ extern "C" int dh_zinb_nll_backward_f32(int64_t n, int64_t g, const float* X, in
   const int rc = check("dh_zinb_nll_backward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
   if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
   if (!upstream || !d_mean || !d_disp || !d_pi || ldo < g) return dh::fail(DH_ERR_INVALID, "dh_zinb_nll_backward_f32: bad output / upstream");
-  hipLaunchKernelGGL(zinb_backward_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
-                     pi, ldp, scale_factor, ridge_lambda, upstream, d_mean, d_disp, d_pi, ldo);
+  hipLaunchKernelGGL(zinb_kernel<true>, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
+                     pi, ldp, scale_factor, ridge_lambda, (double*)nullptr, upstream, d_mean, d_disp, d_pi, ldo);
   return dh::check_launch("dh_zinb_nll_backward_f32");
 }
