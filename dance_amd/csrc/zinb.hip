@@ -13,19 +13,20 @@
 //   nb = t1 + t2 - log(1 - pi + eps);   zn = (d / (d + m + eps))^d;   zc = -log(pi + (1 - pi) zn + eps)
 //   loss = (x <= 1e-8 ? zc : nb) + ridge * pi^2,   result = mean over all elements
 //
-// Round 3 evaluated every element with three float64 lgamma and (backward) two digamma calls: 151 ms forward + backward at 1M x 2000,
-// 0.07 of the 14 ms the 88 GB of traffic need.  Round 4:
-//   * counts are integers: Gamma(x + d) / Gamma(d) = prod_{k < x} (d + k), so
-//         t1 = log( x! / prod_{k < x} (d + k) ),    digamma(d) - digamma(x + d) = - P'(d) / P(d),  P(d) = prod_{k < x} (d + k)
-//     — x multiplications (and the derivative by the product rule in the same loop); the integer power x log(d / m) and log(1 - pi)
-//     ride the same product, so the whole negative-binomial branch costs TWO float64 logarithms (that product, in chunks of 16
-//     factors so that it stays inside the double range, and log1p(m / d)).  Non-integer or large (> 256) counts take the lgamma /
-//     digamma formulas as before.
-//   * the x = 0 branch (the majority of a count matrix) needs no gamma function at all and only contributes log(pi + (1 - pi) zn):
-//     it runs in fp32 throughout (zero_terms below).  Worst-case ~5e-7 relative per element.
-//   * the two branches run in two PHASES per row (zinb_kernel below) instead of side by side in a divergent wavefront: 151 -> 56 ms
-//     came from the arithmetic above, the rest from no longer executing the count branch on every 64-gene step.
-//   Sums stay float64.  The loss equals the float64 formula to ~1e-7 relative, the gradients to a few 1e-7 of their max-norm.
+// Round 3 evaluated every element with three float64 lgamma and (backward) two digamma calls: 151 ms forward + backward at 1M x 2000.
+// Round 4, 25 ms (11 forward + 15 backward; 20 ms at 10 % density; profiles/r04zd_zinb_time.json), in the order of what each step bought:
+//   * counts are integers: Gamma(x + d) / Gamma(d) = prod_{k < x} (d + k), so t1 = log( x! / prod_{k < x} (d + k) ) and the integer
+//     power x log(d / m) and log(1 - pi) ride the same product, in chunks of 16 factors so that it stays inside the double range; the
+//     gradient's digamma(d) - digamma(x + d) + x / d — two large terms that cancel — is the sum (1 / d) sum_k k / (d + k).  No
+//     float64 division (rcp_d), logarithms of the float64 products on the fp32 transcendental unit (log_d).      151 -> 56 ms
+//   * the x = 0 branch (the majority of a count matrix) needs no gamma function and runs in fp32 throughout (zero_terms).
+//   * the two branches no longer share a divergent wavefront: the one lane in ten with a count made every 64-gene step execute the
+//     count branch as well.  Forward collects the counts of a row in LDS and evaluates them afterwards, 64 at a time.
+//   * registers: the library's lgamma (rare fallback) alone held the forward kernel at 204 VGPRs = 2 resident waves per SIMD, and a
+//     wave waited out one HBM round trip per 64 genes: own lgamma (92 VGPRs, 5 waves) and the loads of four steps issued together.
+//                                                                                                               forward 29 -> 11 ms
+//   * backward writes whole lines: windows of 256 genes, gradients staged in LDS (see zinb_backward_kernel).    backward 26 -> 15 ms
+//   Sums stay float64.  The loss equals the float64 formula to ~1e-8 relative, the gradients to ~2e-7 of their max-norm.
 #include "common.h"
 
 namespace {
@@ -71,41 +72,53 @@ __device__ __forceinline__ double digamma_pos(double x) {
   }
   const double f = 1.0 / (x * x);
   const double t = f * (-1.0 / 12.0 + f * (1.0 / 120.0 + f * (-1.0 / 252.0 + f * (1.0 / 240.0 + f * (-1.0 / 132.0)))));
-  return r + log(x) - 0.5 / x + t;
+  return r + fast_log(x) - 0.5 / x + t;
+}
+
+// 1 / a for a double inside the fp32 range (every argument here is, after the activations' clamps): the fp32 reciprocal and one Newton
+// step in float64 — ~1e-14 relative for 3 instructions instead of the ~30 of a float64 division
+__device__ __forceinline__ double rcp_d(double a) {
+  const double r = (double)__frcp_rn((float)a);
+  return r * (2.0 - a * r);
+}
+// log of a positive double whose VALUE may lie far outside the fp32 range (products of up to 16 factors): exponent and mantissa apart,
+// the mantissa's logarithm on the fp32 transcendental unit (v_log_f32, ~1 ulp): absolute error ~1e-7, which is what a loss term needs
+__device__ __forceinline__ float log_d(double v) {
+  int e;
+  const double m = frexp(v, &e);  // m in [0.5, 1)
+  return ((float)e + __log2f((float)m)) * 0.69314718055994531f;
+}
+// log(1 + x) in fp32 for x > -1: Kahan's form x log(t) / (t - 1), t = fl(1 + x) — exact in the limit x -> 0 without a series
+__device__ __forceinline__ float log1p_f(float x) {
+  const float t = 1.f + x;
+  const float d = t - 1.f;
+  return d == 0.f ? x : __logf(t) * __fdividef(x, d);
 }
 
 struct Terms {
   double loss, d_m, d_d, d_p;  // d loss / d (scaled mean, disp, pi)
 };
 
-// lg = lgamma(de) + lgamma(x + 1) - lgamma(x + de) + x log(de / me) - log(q)   (me = m + eps, q = 1 - p + eps)
-// dg = digamma(de) - digamma(x + de)
-// For an integer count the whole of lg is ONE logarithm per 16 factors:  lg = log( prod_{k < x} (k + 1) de / ((de + k) me) / q ).
+// lgamma(x), x > 0: upward recurrence to x >= 8 (the shifted-out factors collected in one product, one logarithm), then Stirling's
+// series through x^-7 (next term 1 / (1188 x^9) < 7e-12 there).  Own code instead of the library's: the fallback below is rare, and
+// the library call alone doubled the kernel's register count (4 -> 2 resident waves per SIMD for every element, not just these).
+__device__ __forceinline__ double lgamma_pos(double x) {
+  double prod = 1.0;
+  while (x < 8.0) {
+    prod *= x;
+    x += 1.0;
+  }
+  const double r = 1.0 / x, r2 = r * r;
+  const double series = r * (1.0 / 12.0 + r2 * (-1.0 / 360.0 + r2 * (1.0 / 1260.0 + r2 * (-1.0 / 1680.0))));
+  return (x - 0.5) * fast_log(x) - x + 0.91893853320467274 + series - fast_log(prod);
+}
+
+// The general (non-integer or > 256) count:  lg = lgamma(de) + lgamma(x + 1) - lgamma(x + de) + x log(de / me) - log(q),
+// dg = digamma(de) - digamma(x + de)   (me = m + eps, q = 1 - p + eps)
 template <bool GRAD>
 __device__ __forceinline__ void gamma_terms(double x, double de, double me, double q, double& lg, double& dg) {
-  const int xi = (int)x;
-  if ((double)xi == x && xi <= 256) {  // integer count: finite products (16 factors stay inside the double range for every clamp bound)
-    lg = 0.0;
-    dg = 0.0;
-    double extra = 1.0 / q;
-    for (int k0 = 0; k0 < xi; k0 += 16) {
-      const int k1 = min(xi, k0 + 16);
-      double num = 1.0, den = 1.0, pd = 1.0, dpd = 0.0;  // pd = prod (de + k), dpd = d pd / d de
-      for (int k = k0; k < k1; ++k) {
-        const double f = de + (double)k;
-        if (GRAD) dpd = dpd * f + pd;
-        pd *= f;
-        num *= (double)(k + 1) * de;
-        den *= me;
-      }
-      lg += fast_log(num * extra / (den * pd));
-      extra = 1.0;
-      if (GRAD) dg -= dpd / pd;
-    }
-    return;
-  }
-  lg = lgamma(de) + lgamma(x + 1.0) - lgamma(x + de) + x * log(de / me) - log(q);
-  if (GRAD) dg = digamma_pos(de) - digamma_pos(x + de);
+  lg = lgamma_pos(de) + lgamma_pos(x + 1.0) - lgamma_pos(x + de) + x * fast_log(de / me) - fast_log(q);
+  dg = GRAD ? digamma_pos(de) - digamma_pos(x + de) : 0.0;
 }
 
 // x = 0 (nine elements in ten of an expression matrix): -log(p + (1 - p) r^d + eps) with r = d / (d + m + eps), all in fp32 — the result
@@ -118,14 +131,14 @@ template <bool GRAD>
 __device__ __forceinline__ ZTerms zero_terms(float m, float d, float p, float ridge) {
   ZTerms o{0.f, 0.f, 0.f, 0.f};
   const float s = d + m + 1e-10f;
-  const float rs = 1.f / s;
+  const float rs = __frcp_rn(s);
   const float u = (m + 1e-10f) * rs;
-  const float lr = u < 0.5f ? log1pf(-u) : logf(d * rs);
-  const float zn = expf(d * lr);
+  const float lr = u < 0.5f ? log1p_f(-u) : __logf(d * rs);  // the transcendental unit's log / exp: ~1 ulp of the result
+  const float zn = __expf(d * lr);
   const float w = p + (1.f - p) * zn + 1e-10f;
-  o.loss = -logf(w);
+  o.loss = -__logf(w);
   if (GRAD) {
-    const float rw = 1.f / w;
+    const float rw = __frcp_rn(w);
     const float dzc_dzn = -(1.f - p) * rw;
     o.d_p = -(1.f - zn) * rw;
     o.d_m = dzc_dzn * (-zn * d * rs);
@@ -138,19 +151,49 @@ __device__ __forceinline__ ZTerms zero_terms(float m, float d, float p, float ri
   return o;
 }
 
-// x > 0: float64 (the Gamma-function ratios as products, one logarithm per 16 factors)
+// x > 0.  Integer counts (what a count matrix holds): the Gamma-function ratios are products,
+//     lgamma(de) + lgamma(x + 1) - lgamma(x + de) + x log(de / me) - log q = sum over chunks of 16 factors of log(num) - log(den),
+// float64 products, their logarithms by log_d; and in the gradient digamma(de) - digamma(x + de) + x / de — two large terms that cancel
+// — is the cancellation-free sum (1 / de) sum_{k < x} k / (de + k).  No float64 division anywhere (rcp_d).  Anything else (a
+// non-integer "count", x > 256) takes the lgamma / digamma formulas.
 template <bool GRAD>
 __device__ __forceinline__ Terms count_terms(double x, double m, double d, double p, double ridge) {
   Terms o{0.0, 0.0, 0.0, 0.0};
   const double de = d + kEps, me = m + kEps, q = 1.0 - p + kEps;
-  double lg, dg;
-  gamma_terms<GRAD>(x, de, me, q, lg, dg);
-  const double l1 = fast_log1p(m / de);  // log(1 + m / (d + eps))
-  o.loss = lg + (d + x) * l1;
-  if (GRAD) {
-    o.d_p = 1.0 / q;
-    o.d_m = (d + x) / (de + m) - x / me;
-    o.d_d = dg + l1 - (d + x) * m / (de * (de + m)) + x / de;
+  const int xi = (int)x;
+  if ((double)xi == x && xi <= 256) {
+    float lg = -log_d(q);
+    double ksum = 0.0;  // sum_k k / (de + k)
+    for (int k0 = 0; k0 < xi; k0 += 16) {
+      const int k1 = min(xi, k0 + 16);
+      double num = 1.0, den = 1.0;
+      for (int k = k0; k < k1; ++k) {
+        const double f = de + (double)k;
+        num *= (double)(k + 1) * de;
+        den *= me * f;
+        if (GRAD) ksum += (double)((float)k * __frcp_rn((float)f));
+      }
+      lg += log_d(num) - log_d(den);
+    }
+    const double rde = rcp_d(de), rdm = rcp_d(de + m);
+    const double r = m * rde;
+    const double l1 = r < 1e-5 ? r * (1.0 - r * (0.5 - r * (1.0 / 3.0))) : (double)log_d(1.0 + r);  // log(1 + m / (d + eps))
+    o.loss = (double)lg + (d + x) * l1;
+    if (GRAD) {
+      o.d_p = rcp_d(q);
+      o.d_m = (d + x) * rdm - x * rcp_d(me);
+      o.d_d = ksum * rde + l1 - (d + x) * m * rde * rdm;
+    }
+  } else {
+    double lg, dg;
+    gamma_terms<GRAD>(x, de, me, q, lg, dg);
+    const double l1 = fast_log1p(m / de);
+    o.loss = lg + (d + x) * l1;
+    if (GRAD) {
+      o.d_p = 1.0 / q;
+      o.d_m = (d + x) / (de + m) - x / me;
+      o.d_d = dg + l1 - (d + x) * m / (de * (de + m)) + x / de;
+    }
   }
   if (ridge > 0.0) {
     o.loss += ridge * p * p;
@@ -159,82 +202,144 @@ __device__ __forceinline__ Terms count_terms(double x, double m, double d, doubl
   return o;
 }
 
-// One wavefront per row, two phases.  Phase 1 walks the row 64 genes at a time: the x = 0 elements are finished on the spot (fp32),
+// Forward: one wavefront per row, two phases.  Phase 1 walks the row 64 genes at a time: the x = 0 elements are finished on the spot (fp32),
 // the positions of the x > 0 elements are appended to a per-wave list in LDS (ballot + prefix count: deterministic order).  Phase 2
 // evaluates the float64 count terms on the list, 64 at a time with every lane busy — inside phase 1 the one lane in ten with a count
 // would make the whole wavefront execute the product loops and the float64 logarithm on every step (that divergence, not the
 // arithmetic of the zeros, was why round 3's 151 ms did not depend on the density).  A row with more counts than the list holds
 // finishes the overflow inside phase 1.
-constexpr int NZ_CAP = 2048;  // list entries per wave (8 KB; 4 waves per block)
+constexpr int NZ_CAP = 1024;  // list entries per wave (4 KB; 4 waves per block: 16 KB, so LDS never limits the resident waves)
+constexpr int ZU = 4;          // 64-gene steps whose loads are issued together: a wave keeps 4 x 4 loads per lane in flight
 
-template <bool GRAD>
-__global__ __launch_bounds__(256) void zinb_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx, const float* __restrict__ M,
-                                                   int64_t ldm, const float* __restrict__ D, int64_t ldd, const float* __restrict__ P, int64_t ldp,
-                                                   const double* __restrict__ sf, double ridge, double* __restrict__ rowloss,
-                                                   const double* __restrict__ upstream, float* __restrict__ dM, float* __restrict__ dD,
-                                                   float* __restrict__ dP, int64_t ldo) {
+__global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
+                                                           const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
+                                                           const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
+                                                           double* __restrict__ rowloss) {
   __shared__ int nz_list[4][NZ_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= n) return;
   const double s = sf ? sf[row] : 1.0;
-  const double up = GRAD ? upstream[0] : 0.0;  // d(result) / d(element loss) = grad_output / (n g), a device scalar: no host round trip
-  const float upf = (float)up, upsf = (float)(up * s), ridge_f = (float)ridge;
+  const float ridge_f = (float)ridge;
   const float* x_row = X + row * ldx;
   const float* m_row = M + row * ldm;
   const float* d_row = D + row * ldd;
   const float* p_row = P + row * ldp;
   int* list = nz_list[wave];
   double acc = 0.0;
-  float acc_z = 0.f;  // the zeros of one 64-gene step are summed in fp32 lanes and folded into the float64 sum every 16 steps
+  float acc_z = 0.f;  // the zeros are summed in fp32 lanes and folded into the float64 sum every 16 steps of 64 genes
   int cnt = 0, folded = 0;
   auto count_element = [&](int64_t c) __attribute__((always_inline)) {
-    const Terms t = count_terms<GRAD>((double)x_row[c], (double)m_row[c] * s, (double)d_row[c], (double)p_row[c], ridge);
-    if (GRAD) {
-      dM[row * ldo + c] = (float)(up * t.d_m * s);
-      dD[row * ldo + c] = (float)(up * t.d_d);
-      dP[row * ldo + c] = (float)(up * t.d_p);
-    } else {
-      acc += t.loss;
-    }
+    acc += count_terms<false>((double)x_row[c], (double)m_row[c] * s, (double)d_row[c], (double)p_row[c], ridge).loss;
   };
-  for (int64_t c0 = 0; c0 < g; c0 += 64) {
-    const int64_t c = c0 + lane;
-    const bool in = c < g;
-    const float x = in ? x_row[c] : 0.f;
-    const bool nz = in && x > 1e-8f;
-    if (in && !nz) {
-      const ZTerms t = zero_terms<GRAD>((float)((double)m_row[c] * s), d_row[c], p_row[c], ridge_f);
-      if (GRAD) {
-        dM[row * ldo + c] = upsf * t.d_m;
-        dD[row * ldo + c] = upf * t.d_d;
-        dP[row * ldo + c] = upf * t.d_p;
-      } else {
-        acc_z += t.loss;
+  for (int64_t c0 = 0; c0 < g; c0 += 64 * ZU) {
+    float xv[ZU], mv[ZU], dv[ZU], pv[ZU];
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {  // all loads of the ZU steps first (clamped addresses: no branch between them)
+      const int64_t c = c0 + 64 * u + lane, cc = c < g ? c : g - 1;
+      xv[u] = x_row[cc];
+      mv[u] = m_row[cc];
+      dv[u] = d_row[cc];
+      pv[u] = p_row[cc];
+    }
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int64_t c = c0 + 64 * u + lane;
+      const bool in = c < g;
+      const bool nz = in && xv[u] > 1e-8f;
+      if (in && !nz) acc_z += zero_terms<false>((float)((double)mv[u] * s), dv[u], pv[u], ridge_f).loss;
+      const unsigned long long mask = __ballot(nz);
+      if (mask) {
+        const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (nz) {
+          if (pos < NZ_CAP) list[pos] = (int)c;
+          else count_element(c);
+        }
+        cnt += __popcll(mask);
       }
     }
-    const unsigned long long mask = __ballot(nz);
-    if (mask) {
-      const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-      if (nz) {
-        if (pos < NZ_CAP) list[pos] = (int)c;
-        else count_element(c);
-      }
-      cnt += __popcll(mask);
-    }
-    if (!GRAD && ++folded == 16) {
+    if (++folded == 4) {
       acc += (double)acc_z;
       acc_z = 0.f;
       folded = 0;
     }
   }
-  if (!GRAD) acc += (double)acc_z;
+  acc += (double)acc_z;
   const int listed = cnt < NZ_CAP ? cnt : NZ_CAP;
   for (int i = lane; i < listed; i += 64) count_element(list[i]);  // (a wave reads its own LDS writes: no barrier needed)
-  if (!GRAD) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (lane == 0) rowloss[row] = acc;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) rowloss[row] = acc;
+}
+
+// Backward: the same split of the two branches, but inside WINDOWS of ZU x 64 genes, and every gradient goes through a per-wave LDS
+// stage so that the three outputs are written as whole 256-byte runs.  (With the row-long list of the forward kernel the x = 0 lanes
+// wrote their lines with holes and the counts filled them in much later — after the partly written lines had left L2: the 24 GB of
+// gradient writes turned into read-modify-writes and the kernel took 23 - 26 ms whatever the arithmetic cost.)
+__global__ __launch_bounds__(256) void zinb_backward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
+                                                            const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
+                                                            const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
+                                                            const double* __restrict__ upstream, float* __restrict__ dM, float* __restrict__ dD,
+                                                            float* __restrict__ dP, int64_t ldo) {
+  constexpr int W = 64 * ZU;
+  __shared__ float stage[4][3][W];
+  __shared__ unsigned short wlist[4][W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= n) return;
+  const double s = sf ? sf[row] : 1.0;
+  const double up = upstream[0];  // d(result) / d(element loss) = grad_output / (n g), a device scalar: no host round trip
+  const float upf = (float)up, upsf = (float)(up * s), ridge_f = (float)ridge;
+  const float* x_row = X + row * ldx;
+  const float* m_row = M + row * ldm;
+  const float* d_row = D + row * ldd;
+  const float* p_row = P + row * ldp;
+  float (*st)[W] = stage[wave];
+  unsigned short* wl = wlist[wave];
+  for (int64_t c0 = 0; c0 < g; c0 += W) {
+    float xv[ZU], mv[ZU], dv[ZU], pv[ZU];
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int64_t c = c0 + 64 * u + lane, cc = c < g ? c : g - 1;
+      xv[u] = x_row[cc];
+      mv[u] = m_row[cc];
+      dv[u] = d_row[cc];
+      pv[u] = p_row[cc];
+    }
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int li = 64 * u + lane;
+      const bool in = c0 + li < g;
+      const bool nz = in && xv[u] > 1e-8f;
+      if (in && !nz) {
+        const ZTerms t = zero_terms<true>((float)((double)mv[u] * s), dv[u], pv[u], ridge_f);
+        st[0][li] = upsf * t.d_m;
+        st[1][li] = upf * t.d_d;
+        st[2][li] = upf * t.d_p;
+      }
+      const unsigned long long mask = __ballot(nz);
+      if (nz) wl[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)li;
+      cnt += __popcll(mask);
+    }
+    for (int i = lane; i < cnt; i += 64) {  // the window's counts, every lane busy (a wave reads its own LDS writes: no barrier)
+      const int li = wl[i];
+      const int64_t c = c0 + li;
+      const Terms t = count_terms<true>((double)x_row[c], (double)m_row[c] * s, (double)d_row[c], (double)p_row[c], ridge);
+      st[0][li] = (float)(up * t.d_m * s);
+      st[1][li] = (float)(up * t.d_d);
+      st[2][li] = (float)(up * t.d_p);
+    }
+#pragma unroll
+    for (int u = 0; u < ZU; ++u) {
+      const int li = 64 * u + lane;
+      const int64_t c = c0 + li;
+      if (c < g) {
+        dM[row * ldo + c] = st[0][li];
+        dD[row * ldo + c] = st[1][li];
+        dP[row * ldo + c] = st[2][li];
+      }
+    }
   }
 }
 
@@ -255,8 +360,8 @@ extern "C" int dh_zinb_nll_forward_f32(int64_t n, int64_t g, const float* X, int
   const int rc = check("dh_zinb_nll_forward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
   if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
   if (!rowloss) return dh::fail(DH_ERR_INVALID, "dh_zinb_nll_forward_f32: null output");
-  hipLaunchKernelGGL(zinb_kernel<false>, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
-                     pi, ldp, scale_factor, ridge_lambda, rowloss, (const double*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, (int64_t)0);
+  hipLaunchKernelGGL(zinb_forward_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
+                     pi, ldp, scale_factor, ridge_lambda, rowloss);
   return dh::check_launch("dh_zinb_nll_forward_f32");
 }
 
@@ -266,7 +371,7 @@ extern "C" int dh_zinb_nll_backward_f32(int64_t n, int64_t g, const float* X, in
   const int rc = check("dh_zinb_nll_backward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
   if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
   if (!upstream || !d_mean || !d_disp || !d_pi || ldo < g) return dh::fail(DH_ERR_INVALID, "dh_zinb_nll_backward_f32: bad output / upstream");
-  hipLaunchKernelGGL(zinb_kernel<true>, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
-                     pi, ldp, scale_factor, ridge_lambda, (double*)nullptr, upstream, d_mean, d_disp, d_pi, ldo);
+  hipLaunchKernelGGL(zinb_backward_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp,
+                     ldd, pi, ldp, scale_factor, ridge_lambda, upstream, d_mean, d_disp, d_pi, ldo);
   return dh::check_launch("dh_zinb_nll_backward_f32");
 }

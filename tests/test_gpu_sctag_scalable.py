@@ -57,7 +57,8 @@ def test_zinb_nll_kernels_vs_float64_formula(cuda_device):
     torch.manual_seed(1)
     for n, g, ridge, with_sf in ((64, 50, 0.0, True), (300, 2000, 0.5, True), (1000, 333, 0.0, False)):
         x = torch.poisson(torch.rand(n, g, device=cuda_device) * 2.5)
-        x[:, :5] *= 40  # large counts: lgamma / digamma at big arguments
+        x[:, :5] *= 40  # large counts (> 256): the lgamma / digamma fallback at big arguments
+        x[:, 5:9] *= 0.37  # non-integer "counts" (normalised matrices fed by mistake or on purpose): the same fallback at small ones
         mean = (torch.rand(n, g, device=cuda_device) * 5 + 1e-5).requires_grad_(True)
         disp = (torch.rand(n, g, device=cuda_device) * 4 + 1e-4).requires_grad_(True)
         disp.data[:, 7] = 1e4     # the clamp bounds of DispAct
