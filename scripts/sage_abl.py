@@ -1,5 +1,5 @@
-"""Development: dh_sage_window_mfma (v2 kernel) under the DANCE_AMD_SM2_ABL ablation bits — timing only.
-bits: 1 no stream prefetch, 2 no scatter, 4 no MFMAs, 8 no self-loop feature loads in the epilogue."""
+"""Development: dh_sage_window_mfma at 1M cells x 2000 genes, D = 400 — timing only (VARIANT=<name> loads an A/B build
+dance_amd/libdancehip_<name>.so; the second argument is a list of values for the retired DANCE_AMD_SM2_ABL switch, pass 0)."""
 import json
 import os
 import sys
@@ -7,6 +7,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dance_amd import _lib  # noqa: E402
+if os.environ.get("VARIANT"):  # A/B builds of sage_bcm.hip: dance_amd/libdancehip_<VARIANT>.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libdancehip_{os.environ['VARIANT']}.so")
 from dance_amd import kernels  # noqa: E402
 
 dev = "cuda"
