@@ -292,3 +292,89 @@ def test_graphsc_batch_full_size(cuda_device, batch):
     ref_loss.backward()
     assert abs(float(loss) - float(ref_loss)) < 1e-5 * abs(float(ref_loss))
     assert rel_err(emb.grad.cpu().numpy(), z64.grad.cpu().numpy()) < 1e-4
+
+
+def test_sage_all_nodes_full_size(cuda_device):
+    """Config 3's graph at 1M cells x 2000 genes: the aggregation of EVERY node — gene rows through dh_sage_window_splitk (2000 rows of
+    ~1e5 cell in-edges), cell rows through dh_sage_window_mfma_planned — against the gather kernel on all rows (max-norm 2e-5), and
+    two size-independent properties of the gene rows: linearity in the features and a row-weighted checksum (sum_v deg(v) neigh[v] =
+    sum over edges of alpha w h[src], evaluated independently as one SpMM of the transposed graph)."""
+    from dance_amd import kernels
+    cg = _cellgene_graph(1_000_000, 2000, 200, 400, 5)
+    n_genes = cg.gene_prefix()
+    n_cells = cg.number_of_nodes() - n_genes
+    cid, h = cg.ndata["cell_id"], cg.ndata["features"]
+    alpha = torch.rand(n_genes + 2, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) + 0.5
+    args = (cg.rowptr, cg.col, cg.val, cid, cid, alpha)
+    ref = kernels.sage_aggregate(*args, h)
+    rp_g = cg.rowptr[:n_genes + 1]
+    genes = kernels.sage_aggregate_splitk(rp_g, cg.col, cg.val, cid, cid[:n_genes], alpha, h, n_genes, n_cells)
+    cells = kernels.sage_aggregate_mfma(cg.rowptr[n_genes:], cg.col, cg.val, cid, cid[n_genes:].contiguous(), alpha, h, 0, n_genes)
+    scale = float(ref.abs().max())
+    assert float((genes - ref[:n_genes]).abs().max()) < 2e-5 * scale
+    assert float((cells - ref[n_genes:]).abs().max()) < 2e-5 * scale
+    # linearity: aggregate(2 h + h') = 2 aggregate(h) + aggregate(h')
+    h2 = torch.randn(h.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    lin = kernels.sage_aggregate_splitk(rp_g, cg.col, cg.val, cid, cid[:n_genes], alpha, 2 * h + h2, n_genes, n_cells)
+    g2 = kernels.sage_aggregate_splitk(rp_g, cg.col, cg.val, cid, cid[:n_genes], alpha, h2, n_genes, n_cells)
+    assert float((lin - (2 * genes + g2)).abs().max()) < 4e-5 * float(lin.abs().max())
+    # checksum of the gene rows: sum_v deg(v) neigh[v] == (edge values alpha[.] w as a row vector) . H through the gene rows' own CSR
+    deg = (rp_g[1:] - rp_g[:-1]).double()
+    lhs = (deg[:, None] * genes.double()).sum(0)
+    rows = torch.repeat_interleave(torch.arange(n_genes, device=DEV), (rp_g[1:] - rp_g[:-1]).long())
+    e_hi = int(rp_g[-1])
+    src = cg.col[:e_hi].long()
+    sid, did = cid[src].long(), cid[:n_genes][rows].long()
+    idx = torch.where(sid >= 0, torch.full_like(sid, n_genes), did)   # gene destinations: cell source -> alpha[gene id], gene source -> alpha[G]
+    coef = (alpha.double()[idx] * cg.val[:e_hi].double())
+    colsum = torch.zeros(cg.number_of_nodes(), dtype=torch.float64, device=DEV).index_add_(0, src, coef)
+    rhs = colsum @ h.double()
+    assert float((lhs - rhs).abs().max()) < 2e-5 * float(rhs.abs().max())
+
+
+def test_zinb_full_size_properties(cuda_device):
+    """dh_zinb_nll_* at 1M x 2000 (config 1's scDSC / scTAG loss at the headline's cell count): the loss of the whole matrix equals the
+    row-count-weighted mean of the losses of its two halves (the kernel's float64 row sums are additive), every gradient entry is
+    finite, and sampled rows agree with the float64 formula."""
+    import cpu_ops
+    from dance_amd import autograd
+    n, gz = 1_000_000, 2000
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.poisson(torch.rand(n, gz, device=DEV, generator=g) * 2.0) * (torch.rand(n, gz, device=DEV, generator=g) < 0.2)
+    mean = (torch.rand(n, gz, device=DEV, generator=g) * 4 + 1e-3).requires_grad_(True)
+    disp = (torch.rand(n, gz, device=DEV, generator=g) * 3 + 1e-3).requires_grad_(True)
+    pi = (torch.rand(n, gz, device=DEV, generator=g) * 0.98 + 0.01).requires_grad_(True)
+    sf = torch.rand(n, device=DEV, dtype=torch.float64, generator=g) + 0.5
+    whole = autograd.zinb_nll(x, mean, disp, pi, sf)
+    gm, gd, gp = torch.autograd.grad(whole, (mean, disp, pi))
+    cut = 333_337
+    a = autograd.zinb_nll(x[:cut], mean[:cut].detach(), disp[:cut].detach(), pi[:cut].detach(), sf[:cut])
+    b = autograd.zinb_nll(x[cut:], mean[cut:].detach(), disp[cut:].detach(), pi[cut:].detach(), sf[cut:])
+    assert abs(float(whole) - (float(a) * cut + float(b) * (n - cut)) / n) < 1e-12 * abs(float(whole))
+    for t in (gm, gd, gp):
+        assert bool(torch.isfinite(t).all())
+    rows = torch.randint(0, n, (4000, ), device=DEV, generator=g)
+    m64, d64, p64 = (t[rows].detach().double().requires_grad_(True) for t in (mean, disp, pi))
+    ref = cpu_ops._zinb_elements(x[rows], m64, d64, p64, sf[rows], 0.0).sum() / (n * gz)   # these rows' share of the mean over all elements
+    rm, rd, rp = torch.autograd.grad(ref, (m64, d64, p64))
+    for got, want in ((gm[rows], rm), (gd[rows], rd), (gp[rows], rp)):
+        assert float((got.double() - want).abs().max()) < 1e-6 * float(want.abs().max())
+
+
+def test_bf16_weight_gradient_full_size(cuda_device):
+    """C3's dW = dY^T X over 1M cells (gemm_bf16_tn_tall_kernel): additivity over row ranges — the product over all rows equals the
+    sum of the products over two ragged parts (each through the same kernel) to fp32 rounding — and equality with the float64
+    product on a 20k-row slice."""
+    from dance_amd import kernels
+    g = torch.Generator(device=DEV).manual_seed(3)
+    k = 1_000_003
+    dy = torch.randn(k, 200, device=DEV, generator=g).to(torch.bfloat16)
+    x = torch.randn(k, 400, device=DEV, generator=g).to(torch.bfloat16)
+    whole = kernels.gemm_bf16(dy, x, trans_a=True, out_dtype=torch.float32)
+    cut = 400_001
+    parts = kernels.gemm_bf16(dy[:cut], x[:cut], trans_a=True, out_dtype=torch.float32) + kernels.gemm_bf16(dy[cut:], x[cut:], trans_a=True,
+                                                                                                            out_dtype=torch.float32)
+    assert float((whole - parts).abs().max()) < 2e-6 * float(whole.abs().max()) * 30  # ~sqrt(K) growth of fp32 partial sums
+    small = kernels.gemm_bf16(dy[:20_000], x[:20_000], trans_a=True, out_dtype=torch.float32)
+    ref = dy[:20_000].double().t() @ x[:20_000].double()
+    assert float((small.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
