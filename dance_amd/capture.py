@@ -5,7 +5,15 @@ One process: block rebuild + forward + loss + backward + optimiser are ONE graph
 cells, ``sharding.allreduce_gradients`` per step): a collective cannot sit inside the graph of a step that also owns the optimiser
 update it feeds, so the step is TWO graphs sharing a memory pool — [rebuild, forward, loss, backward] and [optimiser] — with the
 gradient all-reduce issued eagerly on the same stream in between.  The gradients live in the first graph's pool, so both graphs and
-the all-reduce see the same tensors on every replay."""
+the all-reduce see the same tensors on every replay.
+
+The parameters' ``.grad`` tensors — allocated inside the capture, written by every replay — must remain THE gradients for as long as
+the graph is replayed.  An eager step next to a captured one (the short last batch of an epoch) therefore zeroes and accumulates into
+them in place (``optimizer.zero_grad(set_to_none=False)``) instead of replacing them: with ``set_to_none=True`` there, the next
+epoch's replays died with a GPU memory access fault from 100k cells x batch 128 upwards (toy sizes never showed it; holding extra
+references to the tensors — ``keep_alive`` / ``kept`` below, kept as a second line of defence — was not enough by itself, so the
+mechanism is the allocator's treatment of the graph's pool once eager gradients of the same parameters exist, not a plain
+use-after-free).  Regression test: tests/test_gpu_fullsize.py::test_captured_fits_survive_the_eager_last_batch."""
 from typing import Callable, Optional
 
 import torch
@@ -14,7 +22,8 @@ import torch
 class CapturedStep:
 
     def __init__(self, forward_backward: Callable[[], object], optimiser_step: Callable[[], None], device, *,
-                 between: Optional[Callable[[], None]] = None, split: bool = False, warmup: int = 2):
+                 between: Optional[Callable[[], None]] = None, split: bool = False, warmup: int = 2,
+                 keep_alive: Optional[Callable[[], list]] = None):
         """``forward_backward()`` -> the step's static outputs (tensors that every replay refreshes); ``optimiser_step()`` applies the
         gradients; ``between()`` (split mode) runs eagerly between the two graphs — the gradient all-reduce.  The callables run
         ``warmup`` times on a side stream first (allocator, lazily created optimiser state), then are recorded.  The caller restores
@@ -43,6 +52,7 @@ class CapturedStep:
             with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
                 optimiser_step()
         torch.cuda.synchronize(device)
+        self.kept = list(keep_alive()) if keep_alive is not None else []
 
     def replay(self):
         self.graph.replay()

@@ -214,7 +214,8 @@ class ScDeepSort(BaseClassificationMethod):
         saved = deepcopy(self.model.state_dict())
         block.seeds.copy_(first_seeds)
         g = CapturedStep(lambda: self._captured_forward_backward(block), self._captured_optimiser_step, first_seeds.device,
-                         split=getattr(self, "_world", 1) > 1 or self.capture_split, between=lambda: sharding.allreduce_gradients(self.model))
+                         split=getattr(self, "_world", 1) > 1 or self.capture_split, between=lambda: sharding.allreduce_gradients(self.model),
+                         keep_alive=lambda: [p.grad for p in self.model.parameters() if p.grad is not None])
         loss = g.outputs
         self.model.load_state_dict(saved)       # in place: the graph keeps pointing at these tensors
         for st in self.optimizer.state.values():  # moments and step counters back to zero, in place
@@ -257,8 +258,8 @@ class ScDeepSort(BaseClassificationMethod):
             output_labels = blocks[-1].dstdata["label"]
             output_predictions = self.model(blocks, input_features)
             loss = self.loss_fn(output_predictions, output_labels)
-            self.optimizer.zero_grad()
-            loss.backward()
+            self.optimizer.zero_grad(set_to_none=getattr(self, "_captured", None) is None)  # (see dance_amd/capture.py: next to a captured step
+            loss.backward()                                                                # the gradients stay the graph's tensors)
             sharding.allreduce_gradients(self.model)
             self.optimizer.step()
             sizes.append(blocks[-1].num_dst_nodes())

@@ -381,7 +381,8 @@ class _CapturedStep:
         saved_model = copy.deepcopy(self.model.state_dict())
         self.block.seeds.copy_(first_seeds)
         self.graph = CapturedStep(self._forward_backward, self._optimiser_step, first_seeds.device, split=split,
-                                  between=lambda: sharding.allreduce_gradients(self.model))
+                                  between=lambda: sharding.allreduce_gradients(self.model),
+                                  keep_alive=lambda: [p.grad for p in self.model.parameters() if p.grad is not None])
         self.emb, self.loss = self.graph.outputs
         self.model.load_state_dict(saved_model)  # copies INTO the captured parameter / buffer tensors
         for st in self.optim.state.values():      # the graph updates these very tensors: reset them in place (moments 0, step 0)
@@ -542,7 +543,9 @@ class GraphSC(BaseClusteringMethod):
                     norm = total / torch.where(factor == 0, torch.ones_like(factor), factor)
                     adj_logits, _ = self.model.forward(blocks, input_features)  # second forward, fresh dropout (:215)
                     loss = norm * sparse_target_bce(adj_logits, eu, ev_, em, pos_weight)
-                optim.zero_grad()
+                # next to a captured step the gradients stay the tensors the graph writes (zeroed and accumulated into in place): an eager
+                # step that replaced them (set_to_none) made the following replays fault at 100k cells (dance_amd/capture.py)
+                optim.zero_grad(set_to_none=captured is None)
                 loss.backward()
                 sharding.allreduce_gradients(self.model)
                 optim.step()

@@ -378,3 +378,28 @@ def test_bf16_weight_gradient_full_size(cuda_device):
     small = kernels.gemm_bf16(dy[:20_000], x[:20_000], trans_a=True, out_dtype=torch.float32)
     ref = dy[:20_000].double().t() @ x[:20_000].double()
     assert float((small.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+def test_captured_fits_survive_the_eager_last_batch(cuda_device):
+    """Regression (round 4): three epochs of GraphSC.fit at batch 128 and of ScDeepSort.fit at batch 500 on 100k cells, every full
+    batch replayed from a captured hipGraph and the short last batch of each epoch run eagerly.  The eager batch's
+    ``optimizer.zero_grad()`` used to drop the last reference to the gradient tensors the graph writes; at this size the allocator
+    then released their memory and the next epoch's replays died with a GPU memory access fault (toy sizes never released the
+    block).  The captured step now holds those tensors (``capture.CapturedStep.kept``)."""
+    import tempfile
+
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    n_cells = 100_000
+    cg = _cellgene_graph(n_cells, 2000, 200, 50, seed=6)
+    m = GraphSC(in_feats=50, n_clusters=10, device="cuda")
+    m.fit(cg, epochs=3, batch_size=128)                                   # 781 captured steps + a batch of 32 per epoch
+    assert len(m.losses) == 3 * 782 and np.isfinite(m.losses).all() and m.get_latent().shape[0] == n_cells
+    labels = torch.randint(0, 8, (n_cells, ), generator=torch.Generator().manual_seed(0))
+    with tempfile.TemporaryDirectory() as tmp:
+        s = ScDeepSort(50, 32, 1, "synthetic", "reg", batch_size=500, device="cuda", save_root=tmp, verbose=False)
+        s.fit(cg, labels, epochs=3, lr=1e-3, val_ratio=0.2)                # 80 000 training cells: 160 captured steps, no tail ...
+        assert s._captured is not None and len(s._captured[0].kept) > 0
+        s2 = ScDeepSort(50, 32, 1, "synthetic", "reg2", batch_size=500, device="cuda", save_root=tmp, verbose=False)
+        s2.fit(cg, labels, epochs=3, lr=1e-3, val_ratio=0.2037)            # ... and with a short last batch
+        assert np.isfinite(s2.predict_proba(cg)).all()
