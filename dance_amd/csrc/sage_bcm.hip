@@ -910,21 +910,24 @@ GeoS geometry_s(int64_t n_dst, int64_t n_cols, int64_t width, bool hbf16) {
   g.b = geometry_b(n_dst, n_cols < SPLIT_COLS ? n_cols : SPLIT_COLS, width, hbf16);
   g.S = (int)dh::ceil_div(n_cols, (int64_t)SPLIT_COLS);
   g.row_blocks = (int)dh::ceil_div(n_dst, (int64_t)128);
-  // one workgroup per CU (256 of them), in whole multiples of 8 sets (a set's row blocks share an XCD), no more sets than slices
+  // one workgroup per CU (256 of them), in whole multiples of 8 sets (a set's row blocks share an XCD), no more sets than slices;
+  // more sets (= more rounds of workgroups) when a set's chunk-pointer table would not fit LDS next to the images (very wide windows)
+  g.cps1 = SPLIT_COLS / 32 + 1;
+  const size_t lds_fixed = 128 * 16 + 256 * 4 + (size_t)2 * 2 * IMG * 2 + (size_t)3 * (hbf16 ? g.b.nt : 2 * g.b.nt) * 4096;
   int sets = 256 / g.row_blocks / 8 * 8;
   if (sets < 8) sets = 8;
   if (sets > g.S) sets = g.S;
+  auto stride_of = [&](int n_sets) { return (((g.S + n_sets - 1) / n_sets) * g.cps1 + 4 + 3) / 4 * 4; };
+  while (sets < g.S && lds_fixed + (size_t)2 * stride_of(sets) * 4 > 160 * 1024) sets = sets + 8 < g.S ? sets + 8 : g.S;
   g.slices_per_set = (g.S + sets - 1) / sets;
   g.n_sets = (g.S + g.slices_per_set - 1) / g.slices_per_set;
-  g.cps1 = SPLIT_COLS / 32 + 1;
   g.J_total = (n_cols + 15) / 16;
   g.cptr_bytes = ((size_t)dh::ceil_div(n_dst, 64) * g.S * g.cps1 * 4 + 255) / 256 * 256;
   g.bounds_bytes = ((size_t)n_dst * (g.S + 1) * 4 + 255) / 256 * 256;
   g.prep_bytes = ((size_t)g.J_total * g.b.step_bytes + 255) / 256 * 256;
   g.partial_bytes = (size_t)g.n_sets * n_dst * g.b.Dp * 4;
   g.cptr_stride = (g.slices_per_set * g.cps1 + 4 + 3) / 4 * 4;  // (a multiple of 16 bytes: the A images and feature slots behind the table are read 16 bytes at a time)
-  g.b.lds_bytes = 128 * 16 + 256 * 4 + (size_t)2 * g.cptr_stride * 4 + (size_t)2 * 2 * IMG * 2 +
-                  (size_t)3 * (hbf16 ? g.b.nt : 2 * g.b.nt) * 4096;
+  g.b.lds_bytes = lds_fixed + (size_t)2 * g.cptr_stride * 4;
   return g;
 }
 bool splitk_fits(int64_t n_dst, int64_t n_cols, int64_t width, int64_t nnz) {

@@ -403,3 +403,35 @@ def test_captured_fits_survive_the_eager_last_batch(cuda_device):
         s2 = ScDeepSort(50, 32, 1, "synthetic", "reg2", batch_size=500, device="cuda", save_root=tmp, verbose=False)
         s2.fit(cg, labels, epochs=3, lr=1e-3, val_ratio=0.2037)            # ... and with a short last batch
         assert np.isfinite(s2.predict_proba(cg)).all()
+
+
+def test_splitk_window_wider_than_one_round_of_sets(cuda_device):
+    """A cell window of 2.5M columns at D = 400 fp32: the chunk-pointer table of 1/16 of the slices no longer fits LDS next to the
+    images, so the kernel takes more sets than CUs / row blocks (several rounds of workgroups).  Sparse rows (0.2 %) keep it small;
+    checked against the gather kernel."""
+    from dance_amd import kernels
+    n_genes, n_cells, d = 2000, 2_500_000, 400
+    g = torch.Generator(device=DEV).manual_seed(0)
+    per = 5000
+    cols = torch.randint(0, n_cells, (n_genes, per), device=DEV, generator=g).sort(dim=1).values
+    keep = torch.ones_like(cols, dtype=torch.bool)
+    keep[:, 1:] = cols[:, 1:] != cols[:, :-1]                       # distinct columns per row
+    counts = keep.sum(1)
+    rowptr = torch.zeros(n_genes + 1, dtype=torch.int64, device=DEV)
+    rowptr[1:] = torch.cumsum(counts + 1, 0)
+    nnz = int(rowptr[-1])
+    col = torch.empty(nnz, dtype=torch.int32, device=DEV)
+    is_self = torch.zeros(nnz, dtype=torch.bool, device=DEV)
+    is_self[rowptr[:-1]] = True
+    col[is_self] = torch.arange(n_genes, dtype=torch.int32, device=DEV)
+    col[~is_self] = (cols[keep] + n_genes).to(torch.int32)
+    w = torch.rand(nnz, device=DEV, generator=g) + 0.25
+    rowptr = rowptr.to(torch.int32)
+    cid = torch.cat((torch.randperm(n_genes, device=DEV, generator=g).to(torch.int32), -torch.ones(n_cells, dtype=torch.int32, device=DEV)))
+    alpha = torch.rand(n_genes + 2, device=DEV, generator=g) + 0.5
+    h = torch.randn(n_genes + n_cells, d, device=DEV, generator=g)
+    args = (rowptr, col, w, cid, cid[:n_genes].contiguous(), alpha, h)
+    assert kernels.sage_splitk_supported(n_genes, n_cells, d, h.dtype, nnz)
+    got = kernels.sage_aggregate_splitk(*args, n_genes, n_cells)
+    ref = kernels.sage_aggregate(*args)
+    assert float((got - ref).abs().max()) < 2e-5 * float(ref.abs().max())
