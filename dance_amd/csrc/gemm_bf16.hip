@@ -13,6 +13,8 @@
 // fragment reads of 32 consecutive rows fall on distinct 4-bank slots); the next K-step's global loads are issued
 // before the MFMAs of the current one.  Few-tile problems with a long K (dW = dY^T X) are split over K into fp32
 // slabs that a second kernel sums in slice order (deterministic, no atomics) and finishes (bias, act, dtype).
+#include <cstdlib>
+
 #include "gemm_bf16_tile.h"
 
 namespace {
@@ -337,63 +339,70 @@ int rows_dispatch(int64_t M, int64_t N, int64_t kp, const uint16_t* a, int64_t l
 }
 
 // ---- dW = dY^T X with BOTH operands stored K-major (trans_a, row-major B) and a long K: C[M,N] = sum_k A[k][m] B[k][n] ----------------
-// The generic path transposes both operands into K-contiguous copies first (two extra passes over 2 x (M + N) K bytes: 1.6 ms for
+// The generic path transposes both operands into K-contiguous copies first (two extra passes over 2 x (M + N) K bytes: 1.61 ms for
 // the 200 x 400 gradient over 1M cells, of which the product itself is 0.15).  Here a workgroup streams 64-row slabs of A and B as
-// they lie (coalesced 16-byte loads, 16-byte LDS stores) and the MFMA fragments — 8 consecutive k of ONE column — are gathered from
-// LDS with 8 two-byte reads each: the LDS rows are padded so that the 32 columns x 2 k-halves of a wave's fragment read fall on
-// distinct banks.  8 waves (two per SIMD); a wave owns all (<= 7) row tiles of C for one column tile of the workgroup's 256 columns.
-// The slabs of the next TWO steps travel in registers while the current one is multiplied.  The K range is split over the
-// workgroups (fp32 slabs, summed in slice order by gemm_bf16_reduce_kernel).  Shapes: M <= 224, M % 8 == 0, N % 8 == 0, 16-byte
-// aligned rows.
-constexpr int TT_KC = 64;         // k rows per step
-constexpr int TT_LDA = 232;       // bf16 per LDS row of the A slab: 464 bytes (16-byte multiple; 8 rows = 928 words = 32 banks apart)
-constexpr int TT_LDB = 264;       // ... of the B slab (256 columns): 528 bytes
-constexpr size_t TT_LDS = (size_t)2 * TT_KC * (TT_LDA + TT_LDB) * sizeof(uint16_t);  // 126 976 B
+// they lie and TRANSPOSES THEM ON THE WAY INTO LDS: a thread loads an 8 (k) x 8 (columns) block — eight 16-byte loads, rows 8 apart
+// for neighbouring lanes, eight lanes on one 128-byte line —, turns it in registers (32 byte permutes) and stores eight 16-byte runs
+// of k for its eight columns, so that an MFMA fragment (8 consecutive k of one column) is ONE 16-byte LDS read.  LDS image
+// [column][64 k + 8 pad] (144-byte rows: the 16 lanes of a quarter-wave read or write distinct banks).  8 waves, two per SIMD: waves
+// 0 - 3 load A, waves 4 - 7 B; a wave owns all (<= 7) row tiles of C for one column tile of the workgroup's 256 columns.  The slabs of
+// the next TWO steps travel in registers while the current one is multiplied (a streaming kernel with one workgroup per CU lives on
+// the bytes it keeps in flight).  The K range is split over the workgroups, the column blocks of one K slice on one XCD (fp32 slabs,
+// summed in slice order by gemm_bf16_reduce_kernel).  Shapes: M <= 224, M % 8 == 0, N % 8 == 0, 16-byte aligned rows.
+// Measured at 200 x 400 x 1M: 0.405 ms = 3.0 TB/s (profiles/r04zp_gemm_bf16_tn.json).  The first form of this kernel left the slabs
+// untransposed and gathered every fragment with 8 two-byte LDS reads: 0.55 - 0.57 ms, bound by the LDS instruction rate (~5 cycles per
+// wave instruction and CU); fetching row pairs as dwords (ds_read2_b32 + permute) was slower still (0.65).
+constexpr int TT_KC = 64;  // k rows per step
+constexpr int TX_LD = 72;  // bf16 per LDS row: 64 k + 8 pad = 144 bytes
+constexpr size_t TX_LDS = (size_t)2 * (224 + 256) * TX_LD * sizeof(uint16_t);  // 138 240 B
 
-template <int MT>  // row tiles of C in use: M <= 32 MT
+template <int MT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void gemm_bf16_tn_tall_kernel(int M, int N, int64_t K, const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B,
-                              int64_t ldb, float* __restrict__ slabs, int64_t k_per_slice, int n_blocks) {
-  extern __shared__ __attribute__((aligned(16))) uint16_t tt_lds[];
+                               int64_t ldb, float* __restrict__ slabs, int64_t k_per_slice, int n_blocks) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t tx_lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, kb = lane >> 5;
-  // workgroups i, i + 8, ... share an XCD: the column blocks of one K slice are neighbours THERE, so the A slab they all read comes
-  // out of HBM once
   const int j8 = blockIdx.x >> 3;
   const int slice = (j8 / n_blocks) * 8 + (blockIdx.x & 7);
-  const int n_blk = (j8 % n_blocks) * 256;                  // first column of this workgroup
+  const int n_blk = (j8 % n_blocks) * 256;
   const int64_t k_begin = (int64_t)slice * k_per_slice;
-  if (k_begin >= K) return;                                 // (the grid rounds the slices up to a multiple of 8)
-  const int k_len = (int)((k_begin + k_per_slice < K ? k_begin + k_per_slice : K) - k_begin);  // rows of this slice
+  if (k_begin >= K) return;
+  const int k_len = (int)((k_begin + k_per_slice < K ? k_begin + k_per_slice : K) - k_begin);
   const int n_steps = (k_len + TT_KC - 1) / TT_KC;
-  const int pa = M / 8, pb_all = N / 8;                      // 16-byte pieces per global row
-  const int pb0 = n_blk / 8, pb = (pb_all - pb0) < 32 ? (pb_all - pb0) : 32;  // pieces of this workgroup's 256 columns
-  // Thread -> piece: 32 threads per slab row (piece tid & 31 of rows (tid >> 5) + 16 q), the same for A and B — one byte offset per
-  // operand in a register, everything else immediates.  The slice's rows go through a wave-uniform base and 32-bit byte offsets (a
-  // slice is a few MB).  Every load is issued unconditionally from a clamped address — no branches between the loads —, and what
-  // lies outside the matrix is zeroed when the registers are STORED: a select right behind a load would make the wave wait for it.
-  constexpr int NQ = TT_KC / 16;                             // passes of 16 rows per step
-  const char* const a_base = reinterpret_cast<const char*>(A + k_begin * lda);
-  const char* const b_base = reinterpret_cast<const char*>(B + k_begin * ldb + (int64_t)pb0 * 8);
-  const unsigned lda_b = (unsigned)lda * 2u, ldb_b = (unsigned)ldb * 2u;
-  const int row0 = tid >> 5, pc = tid & 31;
-  const unsigned a_col = (unsigned)min(pc, pa - 1) * 16u, b_col = (unsigned)min(pc, pb - 1) * 16u;
-  auto load = [&](int k0, u32x4 (&ra)[NQ], u32x4 (&rb)[NQ]) __attribute__((always_inline)) {
+  const int pa = M / 8, pb_all = N / 8;
+  const int pb0 = n_blk / 8, pb = (pb_all - pb0) < 32 ? (pb_all - pb0) : 32;
+  // loader role: octet o = lane & 7 (k rows 8 o .. 8 o + 7 of the slab), piece pc = 8 (wave & 3) + (lane >> 3); waves 0 - 3: A, 4 - 7: B
+  const bool load_b = wave >= 4;
+  const int o = lane & 7, pc = 8 * (wave & 3) + (lane >> 3);
+  const int p_lim = load_b ? pb : pa;
+  const bool stores = pc < (load_b ? 32 : 4 * MT);  // (pieces beyond the A image are loaded from a clamped address and dropped)
+  const char* const g_base = load_b ? reinterpret_cast<const char*>(B + k_begin * ldb + (int64_t)pb0 * 8) : reinterpret_cast<const char*>(A + k_begin * lda);
+  const unsigned ld_b = (unsigned)(load_b ? ldb : lda) * 2u;
+  const unsigned col_b = (unsigned)min(pc, p_lim - 1) * 16u;
+  auto load = [&](int k0, u32x4 (&rg)[8]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const unsigned kr = (unsigned)min(k0 + row0 + 16 * q, k_len - 1);
-      ra[q] = *reinterpret_cast<const u32x4*>(a_base + (kr * lda_b + a_col));
-      rb[q] = *reinterpret_cast<const u32x4*>(b_base + (kr * ldb_b + b_col));
+    for (int j = 0; j < 8; ++j) {
+      const unsigned kr = (unsigned)min(k0 + 8 * o + j, k_len - 1);
+      rg[j] = *reinterpret_cast<const u32x4*>(g_base + (kr * ld_b + col_b));
     }
   };
-  auto store = [&](int buf, int k0, const u32x4 (&ra)[NQ], const u32x4 (&rb)[NQ]) __attribute__((always_inline)) {
-    uint16_t* a_img = tt_lds + (size_t)buf * TT_KC * (TT_LDA + TT_LDB) + row0 * TT_LDA + pc * 8;
-    uint16_t* b_img = tt_lds + (size_t)buf * TT_KC * (TT_LDA + TT_LDB) + TT_KC * TT_LDA + row0 * TT_LDB + pc * 8;
+  const unsigned sel_lo = 0x05040100u, sel_hi = 0x07060302u;
+  auto store = [&](int buf, int k0, const u32x4 (&rg)[8]) __attribute__((always_inline)) {
+    uint16_t* img = tx_lds + (size_t)buf * (224 + 256) * TX_LD + (load_b ? 224 * TX_LD : 0) + (size_t)(8 * pc) * TX_LD + 8 * o;
+    const int k_left = k_len - (k0 + 8 * o);  // rows of this octet inside the slice (<= 0: none)
+    const bool col_live = pc < p_lim;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const bool in_k = k0 + row0 + 16 * q < k_len;
-      if (pc < 4 * MT) *reinterpret_cast<u32x4*>(a_img + 16 * q * TT_LDA) = (in_k && pc < pa) ? ra[q] : u32x4{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4*>(b_img + 16 * q * TT_LDB) = (in_k && pc < pb) ? rb[q] : u32x4{0u, 0u, 0u, 0u};
+    for (int c = 0; c < 8; ++c) {  // column 8 pc + c: its eight k values, two per dword
+      u32x4 q;
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        unsigned lo = rg[2 * p2][c >> 1], hi = rg[2 * p2 + 1][c >> 1];
+        if (2 * p2 >= k_left) lo = 0u;      // (only the last step of a slice has rows to blank)
+        if (2 * p2 + 1 >= k_left) hi = 0u;
+        q[p2] = __builtin_amdgcn_perm(hi, lo, (c & 1) ? sel_hi : sel_lo);
+      }
+      if (stores) *reinterpret_cast<u32x4*>(img + c * TX_LD) = col_live ? q : u32x4{0u, 0u, 0u, 0u};
     }
   };
   f32x16 tacc[MT];
@@ -401,47 +410,34 @@ void gemm_bf16_tn_tall_kernel(int M, int N, int64_t K, const uint16_t* __restric
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int e = 0; e < 16; ++e) tacc[i][e] = 0.f;
-  // A fragment = 8 consecutive k of ONE column = 8 two-byte LDS reads (+ 4 packs).  (Fetching row pairs as dwords — ds_read2_b32 and
-  // a byte permute that picks the lane's half — halves the LDS instructions and was SLOWER, 0.65 against 0.55 ms: the kernel is bound
-  // by the LDS instruction rate either way, ~5 cycles per wave instruction and CU.  What would lift it is an LDS image transposed
-  // in registers on the way in, so that a fragment is one 16-byte read — the loader's 8 x 8 blocks cost 32 permutes per thread.)
-  typedef unsigned short us8 __attribute__((ext_vector_type(8)));
-  auto gather = [&](const uint16_t* img, int ld, int krow, int col0) __attribute__((always_inline)) {
-    const uint16_t* src = img + krow * ld + col0 + r;
-    us8 v;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = src[e * ld];
-    return __builtin_bit_cast(bf16x8, v);
-  };
   auto compute = [&](int buf) __attribute__((always_inline)) {
-    const uint16_t* a_img = tt_lds + (size_t)buf * TT_KC * (TT_LDA + TT_LDB);
-    const uint16_t* b_img = a_img + TT_KC * TT_LDA;
+    const uint16_t* a_img = tx_lds + (size_t)buf * (224 + 256) * TX_LD;
+    const uint16_t* b_img = a_img + 224 * TX_LD;
 #pragma unroll
     for (int ks = 0; ks < TT_KC / 16; ++ks) {
-      const int krow = 16 * ks + 8 * kb;
-      const bf16x8 fb = gather(b_img, TT_LDB, krow, wave * 32);
+      const int koff = 16 * ks + 8 * kb;
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(b_img + (size_t)(wave * 32 + r) * TX_LD + koff);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) tacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gather(a_img, TT_LDA, krow, i * 32), fb, tacc[i], 0, 0, 0);
+      for (int i = 0; i < MT; ++i)
+        tacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(a_img + (size_t)(i * 32 + r) * TX_LD + koff), fb, tacc[i], 0, 0, 0);
     }
   };
-  // step t multiplies buffer t & 1 while the slabs of steps t + 1 (requested a step ago) and t + 2 (requested now) are in flight
-  u32x4 ra0[NQ], rb0[NQ], ra1[NQ], rb1[NQ];
-  load(0, ra0, rb0);
-  store(0, 0, ra0, rb0);
-  load(TT_KC, ra1, rb1);  // (past the slice: clamped rows, stored as zeros)
+  u32x4 rg0[8], rg1[8];
+  load(0, rg0);
+  store(0, 0, rg0);
+  load(TT_KC, rg1);
   __syncthreads();
   for (int t = 0; t < n_steps; t += 2) {
     const int k0 = t * TT_KC;
-    load(k0 + 2 * TT_KC, ra0, rb0);
+    load(k0 + 2 * TT_KC, rg0);
     compute(0);
-    store(1, k0 + TT_KC, ra1, rb1);
+    store(1, k0 + TT_KC, rg1);
     __syncthreads();
-    load(k0 + 3 * TT_KC, ra1, rb1);
-    compute(1);  // (an odd number of steps: the buffer holds zeros)
-    store(0, k0 + 2 * TT_KC, ra0, rb0);
+    load(k0 + 3 * TT_KC, rg1);
+    compute(1);
+    store(0, k0 + 2 * TT_KC, rg0);
     __syncthreads();
   }
-  // C[m][n] of row tile i: row m = 32 i + (e & 3) + 8 (e >> 2) + 4 kb, column n = n_blk + 32 wave + r
   float* slab = slabs + (int64_t)slice * M * N;
   const int n = n_blk + wave * 32 + r;
 #pragma unroll
@@ -539,9 +535,9 @@ extern "C" int dh_gemm_bf16(int64_t M, int64_t N, int64_t K, int trans_a, int tr
 #define DH_TT(MTV)                                                                                                                 \
   do {                                                                                                                             \
     static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_tn_tall_kernel<MTV>),                       \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TT_LDS) == hipSuccess;             \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)TX_LDS) == hipSuccess;             \
     if (!ok) return dh::fail(DH_ERR_LAUNCH, "dh_gemm_bf16: cannot raise the dynamic LDS limit");                                   \
-    hipLaunchKernelGGL(gemm_bf16_tn_tall_kernel<MTV>, dim3(grid), dim3(512), TT_LDS, st, (int)M, (int)N, K, A, lda, B, ldb, slabs,  \
+    hipLaunchKernelGGL(gemm_bf16_tn_tall_kernel<MTV>, dim3(grid), dim3(512), TX_LDS, st, (int)M, (int)N, K, A, lda, B, ldb, slabs,  \
                        tp.k_per_slice, tp.n_blocks);                                                                               \
   } while (0)
       switch ((int)((M + 31) / 32)) {
