@@ -498,20 +498,69 @@ def _full_in_block(g: CellGeneGraph, seeds: torch.Tensor) -> Block:
     return Block(brp, bcol, bval, src_ids.numel(), seeds.numel(), src_ids, g)
 
 
-class NeighborSampler:
-    """``dgl.dataloading.NeighborSampler(fanouts, edge_dir="in")`` restricted to full fan-out (every entry -1),
-    which is all the reference uses (scdeepsort.py:183, graphsc.py:181 MultiLayerFullNeighborSampler)."""
+def _sampled_in_block(g: CellGeneGraph, seeds: torch.Tensor, fanout: int, generator=None) -> Block:
+    """At most ``fanout`` in-edges per seed, drawn uniformly WITHOUT replacement (``dgl.sampling.sample_neighbors(g, seeds, fanout,
+    edge_dir="in")``; a seed with fewer in-edges keeps them all), as a message-flow block with dgl.to_block's numbering.  A random
+    key per in-edge of the seeds, a sort by (seed, key), the first ``fanout`` of every seed kept, the kept edges put back into the
+    graph's own edge order; the block itself comes from the same builder as the full-neighbour blocks, fed a CSR that holds the kept
+    edges only.  (The draws are torch's, not DGL's: which edges are kept is not comparable with a DGL run, the distribution is.)"""
+    from . import kernels
+    dev = g.device
+    seeds = seeds.to(dev).to(torch.int64).contiguous()
+    n = g.number_of_nodes()
+    rp = g.rowptr.to(torch.int64)
+    start, deg = rp[seeds], rp[seeds + 1] - rp[seeds]
+    seg = torch.repeat_interleave(torch.arange(seeds.numel(), device=dev), deg)
+    first = torch.cumsum(deg, 0) - deg                                   # offset of every seed's run in the concatenated edge list
+    e = start[seg] + (torch.arange(seg.numel(), device=dev) - first[seg])  # positions in g.col / g.val
+    key = seg.to(torch.float64) + torch.rand(seg.numel(), device=dev, generator=generator, dtype=torch.float64)
+    order = torch.argsort(key)
+    rank = torch.arange(seg.numel(), device=dev) - first[seg[order]]
+    kept = order[rank < fanout]
+    # a CSR over ALL nodes with the kept edges in the rows of their seeds (ascending node id, edge order inside a row as in the graph)
+    node = seeds[seg[kept]]
+    srt = torch.argsort(node * g.col.numel() + e[kept])
+    ek = e[kept][srt]
+    counts = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, node, torch.ones_like(node))
+    rowptr = torch.zeros(n + 1, dtype=torch.int32, device=dev)
+    rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    scratch = getattr(g, "_block_scratch", None)
+    if scratch is None:
+        scratch = (torch.zeros(n, dtype=torch.uint8, device=dev), torch.empty(n, dtype=torch.int32, device=dev))
+        g._block_scratch = scratch
+    brp, bcol, bval, src_ids = kernels.block_build(rowptr, g.col[ek].contiguous(), g.val[ek].contiguous(), seeds, *scratch)
+    blk = Block(brp, bcol, bval, src_ids.numel(), seeds.numel(), src_ids, g)
+    # the kept edges in block order (block rows follow the seeds' order, a row's edges the graph's): their ids in the parent graph
+    pos = torch.empty(n, dtype=torch.int64, device=dev)
+    pos[seeds] = torch.arange(seeds.numel(), device=dev)
+    blk.edata["_ID"] = ek[torch.argsort(pos[node[srt]], stable=True)]
+    return blk
 
-    def __init__(self, fanouts: Sequence[int], edge_dir: str = "in"):
-        if any(f != -1 for f in fanouts) or edge_dir != "in":
-            raise NotImplementedError("only full in-neighbour sampling ([-1]*L, edge_dir='in') is used by the hot path")
-        self.num_layers = len(fanouts)
+
+class NeighborSampler:
+    """``dgl.dataloading.NeighborSampler(fanouts, edge_dir="in")``: one block per entry of ``fanouts``, the LAST entry for the hop next
+    to the seeds (DGL walks ``reversed(fanouts)``).  -1 = every in-neighbour — all the reference uses (scdeepsort.py:183,
+    graphsc.py:181 MultiLayerFullNeighborSampler) and the only form the matrix-core aggregation and the captured steps take; a positive
+    entry draws that many in-edges per node uniformly without replacement (``generator``: a torch.Generator on the graph's device for
+    reproducible draws)."""
+
+    def __init__(self, fanouts: Sequence[int], edge_dir: str = "in", prob=None, mask=None, replace: bool = False, generator=None, **_ignored):
+        if edge_dir != "in":
+            raise NotImplementedError("edge_dir='out' is not used by the hot path (every caller aggregates over in-edges)")
+        if prob is not None or mask is not None or replace:
+            raise NotImplementedError("weighted / masked / with-replacement neighbour sampling is not used by the hot path")
+        if any(int(f) == 0 or int(f) < -1 for f in fanouts):
+            raise ValueError(f"fanouts must be -1 (all in-neighbours) or positive, got {list(fanouts)}")
+        self.fanouts = [int(f) for f in fanouts]
+        self.num_layers = len(self.fanouts)
+        self.generator = generator
 
     def sample(self, g: CellGeneGraph, seeds: torch.Tensor, cells_only: bool = False):
         blocks: List[Block] = []
         out_nodes = seeds
         for layer in range(self.num_layers):
-            blk = _full_in_block(g, seeds)
+            fan = self.fanouts[self.num_layers - 1 - layer]
+            blk = _full_in_block(g, seeds) if fan == -1 else _sampled_in_block(g, seeds, fan, self.generator)
             if cells_only and layer == 0:  # destinations = the seed cells, remaining sources = their genes (ascending id)
                 blk.gene_window = (blk.number_of_dst_nodes(), blk.number_of_src_nodes() - blk.number_of_dst_nodes())
             blocks.insert(0, blk)

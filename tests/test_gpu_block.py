@@ -109,3 +109,43 @@ def test_static_cell_block_flags_rows_without_exactly_one_self_loop(cuda_device)
         sb.seeds.copy_(torch.tensor([5, 6, 7, 8], device=DEV))  # cells 0 .. 3
         sb.rebuild()
         assert int(sb.bad) == expect, loops
+
+
+def test_fanout_sampled_blocks_on_device(cuda_device):
+    """NeighborSampler with positive fan-outs on the device builder: per destination min(fanout, degree) distinct in-edges that exist
+    in the graph with their weights; two layers chain (the first block's destinations are the second's sources); -1 entries give the
+    full-neighbour block; AdaptiveSAGE / WeightedGraphConv run on the sampled blocks."""
+    from dance_amd.cellgraph import CellGeneGraph, NeighborSampler
+    rowptr, col, val = _graph(20_000, 30, 7)
+    n = 20_000
+    g = CellGeneGraph(rowptr, col, val, None, n, {"features": torch.randn(n, 16, device=DEV)})
+    seeds = torch.randperm(n, generator=torch.Generator().manual_seed(1))[:3000].to(DEV)
+    gen = torch.Generator(device=DEV).manual_seed(2)
+    inp, out, blocks = NeighborSampler([7, 4], generator=gen).sample(g, seeds)
+    assert len(blocks) == 2 and torch.equal(out, seeds)
+    last, first = blocks[1], blocks[0]
+    rp = rowptr.long()
+    deg = (rp[seeds + 1] - rp[seeds])
+    assert torch.equal((last.rowptr[1:3001] - last.rowptr[:3000]).long(), deg.clamp(max=4))
+    ids = last.srcdata["_ID"]
+    dst = torch.repeat_interleave(seeds, (last.rowptr[1:3001] - last.rowptr[:3000]).long())
+    src = ids[last.col.long()]
+    eid = last.edata["_ID"]
+    assert torch.equal(col[eid].long(), src) and torch.equal(val[eid], last.val)
+    owner = torch.searchsorted(rp, eid, right=True) - 1
+    assert torch.equal(owner, dst)                                      # every kept edge lies in its destination's row of the graph
+    key = dst * n + src
+    assert key.unique().numel() == key.numel()                          # without replacement
+    assert torch.equal(first.srcdata["_ID"][:first.number_of_dst_nodes()], ids) and torch.equal(inp, first.srcdata["_ID"])
+    assert int((first.rowptr[1:first.number_of_dst_nodes() + 1] - first.rowptr[:first.number_of_dst_nodes()]).max()) <= 7
+    full = NeighborSampler([-1]).sample(g, seeds)[2][0]
+    big = NeighborSampler([10_000], generator=gen).sample(g, seeds)[2][0]
+    assert torch.equal(full.rowptr, big.rowptr) and torch.equal(full.col, big.col) and torch.equal(full.val, big.val)
+    # a GraphConv-style layer runs on the sampled block
+    from dance_amd import autograd
+    from dance_amd.graph import CSRGraph
+    w = torch.randn(16, 8, device=DEV, requires_grad=True)
+    blk_g = CSRGraph(last.rowptr, last.col, last.val, last.number_of_dst_nodes(), last.number_of_src_nodes())
+    y = autograd.gcn_layer(last.srcdata["features"], w, blk_g, None, True)
+    y.sum().backward()
+    assert y.shape == (3000, 8) and bool(torch.isfinite(w.grad).all())
