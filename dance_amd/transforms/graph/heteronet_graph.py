@@ -27,9 +27,17 @@ class HeteronetGraph(BaseTransform):
         """Edge list [[i, j] ...] (int64 ndarray) in the reference's order: i ascending, j by (distance, index)."""
         if radius:
             raise NotImplementedError("radius graphs are not used on this path (knears only)")
-        if distance_metrics not in ("l2", "euclidean", "minkowski"):
-            raise NotImplementedError(f"distance metric {distance_metrics!r}: only l2 is implemented on HIP")
-        x = torch.from_numpy(np.ascontiguousarray(features_np, dtype=np.float32)).to(self.device)
+        if distance_metrics not in ("l2", "euclidean", "minkowski", "cosine", "correlation"):
+            raise NotImplementedError(f"distance metric {distance_metrics!r}: the HIP kNN ranks by l2, cosine or correlation distance")
+        feats = np.ascontiguousarray(features_np, dtype=np.float32)
+        if distance_metrics in ("cosine", "correlation"):
+            # 1 - cos(u, v) = |u' - v'|^2 / 2 on the (centred and) l2-normalised rows: the same neighbours in the same order
+            if distance_metrics == "correlation":
+                feats = feats - feats.mean(1, keepdims=True)
+            norm = np.linalg.norm(feats, axis=1, keepdims=True)
+            norm[norm == 0] = 1
+            feats = np.ascontiguousarray(feats / norm, dtype=np.float32)
+        x = torch.from_numpy(feats).to(self.device)
         idx, _ = kernels.knn(x, knears + 1)
         idx = idx.cpu().numpy().astype(np.int64)
         n, k = idx.shape
