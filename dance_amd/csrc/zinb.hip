@@ -14,7 +14,7 @@
 //   loss = (x <= 1e-8 ? zc : nb) + ridge * pi^2,   result = mean over all elements
 //
 // Round 3 evaluated every element with three float64 lgamma and (backward) two digamma calls: 151 ms forward + backward at 1M x 2000.
-// Round 4, 25 ms (11 forward + 15 backward; 20 ms at 10 % density; profiles/r04zd_zinb_time.json), in the order of what each step bought:
+// Round 4, 24 ms (9 forward + 15 backward; 19 ms at 10 % density; profiles/r04zd_zinb_time.json), in the order of what each step bought:
 //   * counts are integers: Gamma(x + d) / Gamma(d) = prod_{k < x} (d + k), so t1 = log( x! / prod_{k < x} (d + k) ) and the integer
 //     power x log(d / m) and log(1 - pi) ride the same product, in chunks of 16 factors so that it stays inside the double range; the
 //     gradient's digamma(d) - digamma(x + d) + x / d — two large terms that cancel — is the sum (1 / d) sum_k k / (d + k).  No
@@ -202,20 +202,20 @@ __device__ __forceinline__ Terms count_terms(double x, double m, double d, doubl
   return o;
 }
 
-// Forward: one wavefront per row, two phases.  Phase 1 walks the row 64 genes at a time: the x = 0 elements are finished on the spot (fp32),
-// the positions of the x > 0 elements are appended to a per-wave list in LDS (ballot + prefix count: deterministic order).  Phase 2
-// evaluates the float64 count terms on the list, 64 at a time with every lane busy — inside phase 1 the one lane in ten with a count
-// would make the whole wavefront execute the product loops and the float64 logarithm on every step (that divergence, not the
-// arithmetic of the zeros, was why round 3's 151 ms did not depend on the density).  A row with more counts than the list holds
-// finishes the overflow inside phase 1.
-constexpr int NZ_CAP = 1024;  // list entries per wave (4 KB; 4 waves per block: 16 KB, so LDS never limits the resident waves)
+// Forward: one wavefront per row, two phases per WINDOW of ZU x 64 genes.  Phase 1 finishes the window's x = 0 elements on the spot
+// (fp32) and appends the positions (and operands) of its x > 0 elements to a per-wave list in LDS (ballot + prefix count:
+// deterministic order); phase 2 evaluates the float64 count terms on that list, 64 at a time with every lane busy — side by side in
+// phase 1 the one lane in ten with a count would make the whole wavefront execute the product loops and the float64 logarithm on
+// every step (that divergence, not the arithmetic of the zeros, was why round 3's 151 ms did not depend on the density).
 constexpr int ZU = 4;          // 64-gene steps whose loads are issued together: a wave keeps 4 x 4 loads per lane in flight
 
 __global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
                                                            const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
                                                            const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
                                                            double* __restrict__ rowloss) {
-  __shared__ int nz_list[4][NZ_CAP];
+  constexpr int W = 64 * ZU;
+  __shared__ float stage[4][4][W];  // the window's x, scaled-mean input, disp, pi: the counts are evaluated from here, not re-read
+  __shared__ unsigned short wlist[4][W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t row = (int64_t)blockIdx.x * 4 + wave;
   if (row >= n) return;
@@ -225,48 +225,44 @@ __global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g,
   const float* m_row = M + row * ldm;
   const float* d_row = D + row * ldd;
   const float* p_row = P + row * ldp;
-  int* list = nz_list[wave];
+  float (*st)[W] = stage[wave];
+  unsigned short* wl = wlist[wave];
   double acc = 0.0;
-  float acc_z = 0.f;  // the zeros are summed in fp32 lanes and folded into the float64 sum every 16 steps of 64 genes
-  int cnt = 0, folded = 0;
-  auto count_element = [&](int64_t c) __attribute__((always_inline)) {
-    acc += count_terms<false>((double)x_row[c], (double)m_row[c] * s, (double)d_row[c], (double)p_row[c], ridge).loss;
-  };
-  for (int64_t c0 = 0; c0 < g; c0 += 64 * ZU) {
+  for (int64_t c0 = 0; c0 < g; c0 += W) {
     float xv[ZU], mv[ZU], dv[ZU], pv[ZU];
 #pragma unroll
-    for (int u = 0; u < ZU; ++u) {  // all loads of the ZU steps first (clamped addresses: no branch between them)
+    for (int u = 0; u < ZU; ++u) {  // all loads of the window first (clamped addresses: no branch between them)
       const int64_t c = c0 + 64 * u + lane, cc = c < g ? c : g - 1;
       xv[u] = x_row[cc];
       mv[u] = m_row[cc];
       dv[u] = d_row[cc];
       pv[u] = p_row[cc];
     }
+    int cnt = 0;
+    float acc_z = 0.f;  // the window's zeros in fp32 lanes, folded into the float64 sum per window
 #pragma unroll
     for (int u = 0; u < ZU; ++u) {
-      const int64_t c = c0 + 64 * u + lane;
-      const bool in = c < g;
+      const int li = 64 * u + lane;
+      const bool in = c0 + li < g;
       const bool nz = in && xv[u] > 1e-8f;
       if (in && !nz) acc_z += zero_terms<false>((float)((double)mv[u] * s), dv[u], pv[u], ridge_f).loss;
       const unsigned long long mask = __ballot(nz);
-      if (mask) {
+      if (nz) {
         const int pos = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-        if (nz) {
-          if (pos < NZ_CAP) list[pos] = (int)c;
-          else count_element(c);
-        }
-        cnt += __popcll(mask);
+        wl[pos] = (unsigned short)li;
+        st[0][li] = xv[u];
+        st[1][li] = mv[u];
+        st[2][li] = dv[u];
+        st[3][li] = pv[u];
       }
+      cnt += __popcll(mask);
     }
-    if (++folded == 4) {
-      acc += (double)acc_z;
-      acc_z = 0.f;
-      folded = 0;
+    acc += (double)acc_z;
+    for (int i = lane; i < cnt; i += 64) {  // the window's counts, every lane busy (a wave reads its own LDS writes: no barrier)
+      const int li = wl[i];
+      acc += count_terms<false>((double)st[0][li], (double)st[1][li] * s, (double)st[2][li], (double)st[3][li], ridge).loss;
     }
   }
-  acc += (double)acc_z;
-  const int listed = cnt < NZ_CAP ? cnt : NZ_CAP;
-  for (int i = lane; i < listed; i += 64) count_element(list[i]);  // (a wave reads its own LDS writes: no barrier needed)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (lane == 0) rowloss[row] = acc;
