@@ -17,6 +17,7 @@
 // list (LDS for k <= 32, else the output arrays themselves).  For random data a query sees only ~k ln(N/k)
 // insertions, so the kernels are bound by the 3 VALU ops per (pair, feature).
 #include "common.h"
+#include "knn_fold.h"
 
 namespace {
 
@@ -290,9 +291,11 @@ struct Layout {
   int algo;                      // resolved: DH_KNN_SCAN or DH_KNN_FILTER
   int P;                         // candidate slices of the scan (of the sample scan in filter mode)
   int dch;                       // padded width of the register kernel (0: d > 64)
-  int64_t S;                     // sample size (filter)
+  bool fold;                     // filter: the fp16 two-pass path (d <= 64)
+  dh::KnnFoldGeom g;             // its geometry
+  int64_t S, stride;             // sample rows j * stride, j < S (filter)
   int cap;                       // survivor list capacity per query (filter)
-  size_t partial, xp, xs, mean, norms, rq, cn, a2, b2, counts, surv, total;
+  size_t partial, xp, xs, mean, scale, norms, rq, cn, a2, b2, counts, surv, total;
 };
 
 Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
@@ -307,19 +310,32 @@ Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
   L.partial = take(L.P > 1 ? (size_t)L.P * nq * k * 8 : 0);
   L.xp = take(L.dch ? (size_t)n * L.dch * sizeof(float) : 0);
   if (algo == DH_KNN_FILTER) {
-    L.S = dh::knn_filter_sample_size(n);
-    int n_seg, seg;
-    dh::knn_filter_geometry(n, d, nq, k, &n_seg, &seg);
-    L.cap = n_seg * seg;
-    const size_t K3 = (size_t)dh::knn_filter_k3(d);
-    L.xs = take((size_t)L.S * (L.dch ? L.dch : d) * sizeof(float));
+    L.fold = dh::knn_fold_applies(d);
     L.mean = take(dh::knn_filter_mean_floats(d) * sizeof(float));
     L.norms = take((size_t)n * sizeof(float));
-    L.rq = take((size_t)nq * sizeof(float));
-    L.cn = take((size_t)n * sizeof(float));
-    L.a2 = take((size_t)n * K3 * 2);
-    L.b2 = take((size_t)n * K3 * 2);
-    L.counts = take((size_t)nq * n_seg * sizeof(int32_t));
+    if (L.fold) {
+      L.g = dh::knn_fold_geom(n, d, nq, k);
+      L.S = L.g.S;
+      L.stride = L.g.stride0;
+      L.cap = L.g.cap;
+      L.scale = take(64);
+      L.a2 = take((size_t)n * L.g.K3 * 2);
+      L.b2 = take((size_t)L.g.n_pos * L.g.K3 * 2);
+      L.counts = take((size_t)nq * (L.g.n_seg1 + L.g.n_seg2) * sizeof(int32_t));
+    } else {
+      L.S = dh::knn_filter_sample_size(n);
+      L.stride = n / L.S;
+      int n_seg, seg;
+      dh::knn_filter_geometry(n, d, nq, k, &n_seg, &seg);
+      L.cap = n_seg * seg;
+      const size_t K3 = (size_t)dh::knn_filter_k3(d);
+      L.rq = take((size_t)nq * sizeof(float));
+      L.cn = take((size_t)n * sizeof(float));
+      L.a2 = take((size_t)n * K3 * 2);
+      L.b2 = take((size_t)n * K3 * 2);
+      L.counts = take((size_t)nq * n_seg * sizeof(int32_t));
+    }
+    L.xs = take((size_t)L.S * (L.dch ? L.dch : d) * sizeof(float));
     L.surv = take((size_t)nq * L.cap * sizeof(int32_t));
   }
   L.total = off;
@@ -400,8 +416,12 @@ extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64
   // filter: (1) exact k-th distance inside a strided sample -> out_dist[:, k-1] (raw d2), (2) + (3) in knn_filter.hip
   float* Xs = reinterpret_cast<float*>(ws + L.xs);
   const int rs = L.dch ? L.dch : (int)d;
-  dh::knn_filter_sample(n, d, X, ldx, rs, Xs, st);
+  dh::knn_filter_sample_strided(L.S, L.stride, d, X, ldx, rs, Xs, st);
   scan_launch(L.S, d, L.dch, Q, ldq, Xs, rs, q_begin, q_end, k, L.P, true, ws + L.partial, out_idx, out_dist, st);
+  if (L.fold)
+    return dh::knn_fold_launch(L.g, n, d, X, ldx, Q, ldq, L.dch, q_begin, nq, k, reinterpret_cast<float*>(ws + L.mean),
+                               reinterpret_cast<unsigned int*>(ws + L.scale), ws + L.a2, ws + L.b2, reinterpret_cast<float*>(ws + L.norms),
+                               reinterpret_cast<int32_t*>(ws + L.counts), reinterpret_cast<int32_t*>(ws + L.surv), out_idx, out_dist, st);
   return dh::knn_filter_launch(n, d, X, ldx, Q, ldq, L.dch ? L.dch : d, q_begin, nq, k, out_dist, reinterpret_cast<float*>(ws + L.mean),
                                reinterpret_cast<uint16_t*>(ws + L.a2), reinterpret_cast<uint16_t*>(ws + L.b2),
                                reinterpret_cast<float*>(ws + L.norms), reinterpret_cast<float*>(ws + L.rq),

@@ -25,9 +25,31 @@
 // are translation invariant (any mu is admissible — its rounding only costs efficiency), the subtraction's own rounding
 // moves d2 by <= 2 |x-y| u (|x'| + |y'|) <= 4 u (|x'|^2 + |y'|^2), well inside the slack above, and embeddings with a
 // large common offset (or non-negative expression rows) no longer inflate the survivor lists.  Inputs must be finite.
+//
+// d <= 64 (what NeighborGraph feeds: PCA embeddings): ONE fp16 term instead of three bf16 terms, thresholds in two passes.
+//   * The centred data are scaled by a power of two (exact) so that max |y| lies in [2^8, 2^9) and every row becomes ONE
+//     fp16 vector yh (11 significant bits, |yh - y| <= 2^-11 |y|, or <= 2^-14 absolute below fp16's normal range — the
+//     bound does not rely on subnormal support).  With sum |q_i c_i| <= (|q|^2 + |c|^2) / 2 and the factor 2 of the dot product:
+//         |d2~ - d2| <= (|q|^2 + |c|^2) (2^-10 (1 + 2^-12) + (K + 10) 5 u) + 2^-13 sqrt(d) (|q| + |c|) + 1/2
+//     (representation; fp32 accumulation over K <= 80 exact products and the threshold columns; flushed elements; the
+//     fp16 splits of the two threshold terms), against the test's slack eps (|q|^2 + |c|^2) + A (|q| + |c|) + 1 with
+//     eps = 2^-10 + 2^-13 + d 2^-20, A = 1.01 * 2^-13 sqrt(d).  The slack is ~9x the three-term form's, the matrix-core
+//     work 2.75x smaller at d = 50 (K = 64 instead of 176); all norms are those of the CENTRED, SCALED rows.
+//   * The whole test rides the matrix cores: A row = [-2 yh | -Rq split in 3 | M M M | 0], B row = [yh | M M M | Cn split in
+//     3 | 0] (M = 2^12), Cn = (1 - eps) |c|^2 - A |c|, Rq = tau - (1 - eps) |q|^2 + A |q| + 1, so the accumulator is
+//     -2 q.c + Cn - Rq and a pair survives iff its SIGN BIT is set: one v_alignbit per pair collects the bits.
+//   * Thresholds in two passes (n >= 32768): tau0 from a strided sample of ~4096 rows (exact scan), then the filter over the
+//     rows r = 0 mod 16 (which contain the sample), an exact re-rank of those survivors -> tau1 = the exact k-th distance
+//     among n / 16 candidates, then the filter over the other 15/16 with tau1: ~16 k survivors per query instead of
+//     k n / S (960 at n = 1M), and a 4x smaller sample scan.  B rows are stored grouped by r mod 16 so that each pass reads
+//     contiguous tiles; the final re-rank merges pass 2's survivors into the k keys pass 1 left (equal keys collapse, so a
+//     query that had to re-scan everything in pass 1 stays exact).
+//   * Data whose scale cannot be normalised (max |x - mu| outside [2^-60, 2^60], or all points identical) pass everything:
+//     every query overflows its list and re-scans all candidates — exact, at the scan's speed.
 #include <type_traits>
 
 #include "gemm_bf16_tile.h"
+#include "knn_fold.h"
 
 namespace {
 
@@ -55,26 +77,10 @@ __global__ __launch_bounds__(256) void knn_mean_kernel(int64_t n, int64_t d, int
   mu[t] = s / (float)n;
 }
 
-// exact three-way split of an fp32 value into bf16 terms (24 = 8 + 8 + 8 significant bits): v == hi + mid + lo
-__device__ __forceinline__ void split3(float v, unsigned int out[3]) {
-  out[0] = f32_to_bf16(v);
-  if (!(fabsf(v) < __int_as_float(0x7f800000))) {  // +-inf thresholds (rows that pass everything / nothing): no inf - inf
-    out[1] = out[2] = 0u;
-    return;
-  }
-  const float r1 = v - widen(out[0]);
-  out[1] = f32_to_bf16(r1);
-  out[2] = f32_to_bf16(r1 - widen(out[1]));
-}
-
 // x' = x - mu; norms[r] = sum_t x'[r][t]^2 (one wavefront per row); A2[r] = [hi | hi | lo | 0], B2[r] = [hi | lo | hi | 0] of
 // x', each part dp wide, rows K3 = roundup(3 dp, 16) long.
-// FOLD (query-stationary kernel, d <= 64): the whole filter test rides the matrix cores.  A2[r] = [-2 hi | -2 hi | -2 lo |
-// -Rq split3 (written by knn_thresholds_kernel) | 1 1 1 | 0], B2[r] = [hi | lo | hi | 1 1 1 | Cn split3 | 0] with
-// Cn = (1 - eps) |x'|^2, so that the accumulator IS  -2 q.c + Cn[c] - Rq[q]  and a pair survives iff it is <= 0.
-template <bool FOLD>
 __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
-                                                        const float* __restrict__ mu, int dp, int64_t K3, float eps,
+                                                        const float* __restrict__ mu, int dp, int64_t K3,
                                                         uint16_t* __restrict__ A2, uint16_t* __restrict__ B2,
                                                         float* __restrict__ norms) {
   const int lane = threadIdx.x & 63;
@@ -83,33 +89,19 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
   const float* x = X + r * ldx;
   uint16_t* a = A2 + r * K3;
   uint16_t* b = B2 + r * K3;
-  for (int t = 3 * dp + (FOLD ? 6 : 0) + lane; t < K3; t += 64) a[t] = b[t] = 0;
+  for (int t = 3 * dp + lane; t < K3; t += 64) a[t] = b[t] = 0;
   float s = 0.f;
   for (int t = lane; t < dp; t += 64) {
     const float v = t < d ? x[t] - mu[t] : 0.f;
     s = fmaf(v, v, s);
     const unsigned int hi = f32_to_bf16(v);
     const unsigned int lo = f32_to_bf16(v - widen(hi));  // exact subtraction: hi is v rounded to 8 bits
-    // -2 x: exponent + 1 and the sign flipped, exact in bf16 (finite inputs; an overflow to inf only widens the test)
-    const unsigned int ahi = FOLD ? f32_to_bf16(-2.f * widen(hi)) : hi, alo = FOLD ? f32_to_bf16(-2.f * widen(lo)) : lo;
-    a[t] = (uint16_t)ahi; a[dp + t] = (uint16_t)ahi; a[2 * dp + t] = (uint16_t)alo;
+    a[t] = (uint16_t)hi; a[dp + t] = (uint16_t)hi; a[2 * dp + t] = (uint16_t)lo;
     b[t] = (uint16_t)hi; b[dp + t] = (uint16_t)lo; b[2 * dp + t] = (uint16_t)hi;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) {
-    norms[r] = s;
-    if (FOLD) {
-      unsigned int c3[3];
-      split3((1.f - eps) * s, c3);
-      for (int i = 0; i < 3; ++i) {
-        a[3 * dp + 3 + i] = 0x3f80;  // 1.0 against Cn
-        b[3 * dp + i] = 0x3f80;      // 1.0 against -Rq
-        b[3 * dp + 3 + i] = (uint16_t)c3[i];
-        a[3 * dp + i] = 0;           // -Rq: knn_thresholds_kernel (query rows only)
-      }
-    }
-  }
+  if (lane == 0) norms[r] = s;
 }
 
 // The filter test  |q|^2 + |c|^2 - 2 dot <= tau + eps (|q|^2 + |c|^2)  rearranged so that the epilogue is one fma and
@@ -117,19 +109,12 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
 // (eps carries a factor 2 of slack over the bound above, which also covers these few extra roundings.)
 __global__ __launch_bounds__(256) void knn_thresholds_kernel(int64_t n, int64_t q_begin, int64_t nq, int k, float eps,
                                                              const float* __restrict__ norms, const float* __restrict__ sample_d2,
-                                                             float* __restrict__ Rq, float* __restrict__ Cn, int32_t* __restrict__ counts,
-                                                             uint16_t* __restrict__ A2_fold, int64_t K3, int dp) {
+                                                             float* __restrict__ Rq, float* __restrict__ Cn, int32_t* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) Cn[i] = (1.f - eps) * norms[i];
   if (i < nq) {
-    const float rq = sample_d2[i * k + (k - 1)] - (1.f - eps) * norms[q_begin + i];  // +inf when the sample held < k points
-    Rq[i] = rq;
+    Rq[i] = sample_d2[i * k + (k - 1)] - (1.f - eps) * norms[q_begin + i];  // +inf when the sample held < k points
     counts[i] = 0;
-    if (A2_fold) {  // the folded filter: -Rq rides three K columns of the query's A row
-      unsigned int r3[3];
-      split3(-rq, r3);
-      for (int j = 0; j < 3; ++j) A2_fold[(q_begin + i) * K3 + 3 * dp + j] = (uint16_t)r3[j];
-    }
   }
 }
 
@@ -170,39 +155,135 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
   }
 }
 
-// d <= 64: "query-stationary" form of the same filter.  The tile kernel above re-reads both operands for every
-// 128 x 128 tile — 5.25 bytes of L2 traffic per pair at K3 = 168, which is what bounds it (counters: 4.6 TB/s of L2
-// requests, matrix cores 13 % busy).  Here a block of 8 waves owns 256 queries for its whole life: each wave keeps the MFMA
-// A-fragments of its 64 queries (all of K3) in REGISTERS, and the block only streams 128-candidate tiles of B2 through a
-// double-buffered LDS image (one barrier per tile) — 1.3 bytes per pair.
-//
-// Round 2: the threshold test itself rides the matrix cores (FOLD layout of knn_split_kernel: the accumulator is
-// -2 q.c + Cn[c] - Rq[q], a pair survives iff it is <= 0), so the epilogue is one compare + one add-with-carry per pair
-// (was fma + compare against an LDS operand + shift/or), and it is ROTATED half a tile against the MFMAs: while the
-// matrix cores work on candidate sub-tile j of tile t the vector ALUs test sub-tile 1-j of the previous half, paired one
-// MFMA with a fixed number of test pairs behind it (order written out and pinned).  Measured at 1M x 50 (profiles/): 388 -> 353 ms;
-// ablation builds (-DDH_KNN_ABL=1: no appends) run 272 ms, i.e. the survivor appends (~960 per query, one returning LDS
-// atomic + one 4-byte global store each) cost 81 ms and the tile loop itself sits at ~59 % matrix-pipe utilisation behind its
-// one barrier per 128-candidate tile.  The six extra K columns cost no K-step at d = 50 (3 * 56 + 6 <= 176); their
-// products are exact and the extra accumulation roundings (<= 7 u (|q|^2 + |c|^2)) sit inside the factor 2 of slack in eps.
-template <int KS>  // 16-wide k steps: K3 = 16 KS
-__global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64_t n, const uint16_t* __restrict__ A2,
-                                                               const uint16_t* __restrict__ B2, int32_t* __restrict__ counts,
-                                                               int32_t* __restrict__ surv, int cap, int seg,
-                                                               int64_t tiles_per_slice) {
+// ---- d <= 64: fp16, "query-stationary", thresholds in two passes (design and error budget: head of this file) ----------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int FOLD_G = 16;                     // pass 1 = every 16th row
+constexpr int64_t FOLD_TWO_PASS_MIN = 32768;   // below this one pass over everything
+constexpr int FOLD_NT = 2;                     // 128-row candidate tiles per LDS image (one barrier per image)
+constexpr float FOLD_MUL = 4096.f;             // the threshold terms ride as MUL * (t0 + t1 + t2), t_i fp16
+constexpr float FOLD_RQ_MAX = 67108864.f;      // 2^26 > any -2 q.c + Cn of scaled rows (<= 3 d 2^18): "everything passes"
+
+// power-of-two scale that puts max |x - mu| into [2^8, 2^9); ok = false when it cannot (then every pair passes)
+struct FoldScale { float s; bool ok; };
+__device__ __forceinline__ FoldScale fold_scale(unsigned int maxbits) {
+  const int e = (int)(maxbits >> 23);  // bits of a non-negative float
+  FoldScale r;
+  r.ok = e >= 127 - 60 && e <= 127 + 60;
+  r.s = r.ok ? __uint_as_float((unsigned int)(127 + 8 - (e - 127)) << 23) : 1.f;
+  return r;
+}
+
+// w ~ t0 + t1 + t2 in fp16 (|w| <= 2^14); residual <= 2^-33 |w|, or 2^-14 where a term falls below the normal range
+__device__ __forceinline__ void split3h(float w, _Float16 out[3]) {
+  out[0] = (_Float16)w;
+  const float r1 = w - (float)out[0];
+  out[1] = (_Float16)r1;
+  out[2] = (_Float16)(r1 - (float)out[1]);
+}
+
+__global__ __launch_bounds__(256) void knn_maxabs_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
+                                                         const float* __restrict__ mu, unsigned int* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  float m = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * 4)
+    for (int64_t t = lane; t < d; t += 64) m = fmaxf(m, fabsf(X[r * ldx + t] - mu[t]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bits
+}
+
+// One wavefront per row p < n_pad of B2: p = class * n1 + index holds candidate r = index * G + class (p < G n1, r < n), every
+// other row is zero (never passes).  y = s (x[r] - mu), norms[r] = |y|^2, A2[r] = [-2 yh | 0 0 0 (-Rq: thresholds kernel) |
+// M M M | 0], B2[p] = [yh | M M M | Cn split | 0].
+__global__ __launch_bounds__(256) void knn_fold_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ mu, const unsigned int* __restrict__ maxabs,
+                                                             int dp, int K3, float eps, float abs_lin, int G, int64_t n1, int64_t n_pad,
+                                                             _Float16* __restrict__ A2, _Float16* __restrict__ B2,
+                                                             float* __restrict__ norms) {
+  const int lane = threadIdx.x & 63;
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_pad) return;
+  _Float16* b = B2 + p * K3;
+  const int64_t r = p < (int64_t)G * n1 ? (p % n1) * G + p / n1 : n;
+  if (r >= n) {
+    for (int t = lane; t < K3; t += 64) b[t] = (_Float16)0.f;
+    return;
+  }
+  const FoldScale sc = fold_scale(*maxabs);
+  const float* x = X + r * ldx;
+  _Float16* a = A2 + r * K3;
+  for (int t = dp + 6 + lane; t < K3; t += 64) a[t] = b[t] = (_Float16)0.f;
+  float s = 0.f;
+  for (int t = lane; t < dp; t += 64) {
+    const float y = (t < d && sc.ok) ? (x[t] - mu[t]) * sc.s : 0.f;
+    s = fmaf(y, y, s);
+    const _Float16 h = (_Float16)y;
+    b[t] = h;
+    a[t] = (_Float16)(-2.f * (float)h);  // exact
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) {
+    norms[r] = s;
+    _Float16 c3[3];
+    split3h(((1.f - eps) * s - abs_lin * sqrtf(s)) * (1.f / FOLD_MUL), c3);
+    for (int i = 0; i < 3; ++i) {
+      a[dp + i] = (_Float16)0.f;
+      a[dp + 3 + i] = (_Float16)FOLD_MUL;
+      b[dp + i] = (_Float16)FOLD_MUL;
+      b[dp + 3 + i] = c3[i];
+    }
+  }
+}
+
+// -Rq of every query into the three threshold columns of its A row; tau[i * k + k - 1] = the raw k-th distance so far
+__global__ __launch_bounds__(256) void knn_fold_thresholds_kernel(int64_t q_begin, int64_t nq, int k, float eps, float abs_lin,
+                                                                  const unsigned int* __restrict__ maxabs,
+                                                                  const float* __restrict__ norms, const float* __restrict__ tau,
+                                                                  int dp, int K3, _Float16* __restrict__ A2,
+                                                                  int32_t* __restrict__ counts, int n_zero_seg) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nq) return;
+  const FoldScale sc = fold_scale(*maxabs);
+  const float tau_s = (tau[i * k + (k - 1)] * sc.s) * sc.s;  // +inf when fewer than k points were seen
+  const float nq2 = norms[q_begin + i];
+  float rq = tau_s * (1.f + 9.5367431640625e-7f) - (1.f - eps) * nq2 + abs_lin * sqrtf(nq2) + 1.f;
+  if (!sc.ok || !(rq < FOLD_RQ_MAX)) rq = FOLD_RQ_MAX;
+  _Float16 r3[3];
+  split3h(-rq * (1.f / FOLD_MUL), r3);
+  _Float16* a = A2 + (q_begin + i) * K3 + dp;
+  for (int j = 0; j < 3; ++j) a[j] = r3[j];
+  for (int sg = 0; sg < n_zero_seg; ++sg) counts[(int64_t)sg * nq + i] = 0;
+}
+
+// A block of 8 waves owns 256 queries for its whole life: each wave keeps the MFMA A-fragments of its 64 queries (all of
+// K3) in REGISTERS and the block streams images of FOLD_NT 128-candidate tiles of B2 through a double-buffered LDS copy (one
+// barrier per image) — 0.5 bytes of L2 traffic per pair at K3 = 64.  The pass test is ROTATED half a tile against the
+// MFMAs: while the matrix cores work on candidate sub-tile j the vector ALUs collect the sign bits of sub-tile 1 - j of
+// the previous half, a fixed number of pairs behind every MFMA (order written out and pinned: left to itself the compiler
+// sinks the bit collection into the rarely taken append branch behind the MFMAs).
+// History (profiles/): three-term bf16 form of this kernel, K3 = 176, v_cmp + v_addc per pair: 353 ms at 1M x 50, of which the
+// survivor appends (~960 per query) cost 81 ms; the tile loop sat at ~59 % matrix-pipe utilisation.
+template <int KS, int NT>  // 16-wide k steps: K3 = 16 KS; NT tiles per LDS image
+__global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_t n, int G, int64_t n1,
+                                                              const _Float16* __restrict__ A2, const _Float16* __restrict__ B2,
+                                                              int32_t* __restrict__ counts, int32_t* __restrict__ surv, int cap, int seg,
+                                                              int64_t t_begin, int64_t t_end, int64_t tiles_per_slice) {
   constexpr int K3 = 16 * KS;
-  constexpr int LD = K3 + 8;               // bf16 per LDS row: (LD / 2) % 8 == 4 -> conflict-free 16-byte fragment reads
+  constexpr int LD = K3 + 8;               // fp16 per LDS row: (LD / 2) % 8 == 4 -> conflict-free 16-byte fragment reads
   constexpr int CPR = 2 * KS;              // 16-byte chunks per row
-  constexpr int NCH = (BN * CPR + 511) / 512;
-  extern __shared__ __attribute__((aligned(16))) uint16_t lds[];  // 2 x [BN][LD]
+  constexpr int GCH = NT * BN * CPR;       // chunks per image (contiguous in B2: a row is exactly CPR chunks)
+  constexpr int NCH = (GCH + 511) / 512;
+  extern __shared__ __attribute__((aligned(16))) _Float16 lds_h[];  // 2 x [NT * BN][LD]
   __shared__ int cnt_s[256];  // survivors appended by THIS block per query: the block owns its 256 queries, so the
-                              // list cursors are LDS atomics (~100 cycles) instead of returning global atomics
+                              // list cursors are LDS atomics instead of returning global atomics
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, lr = lane & 31, kh = (lane >> 5) * 8;
   const int64_t m0 = (int64_t)blockIdx.x * 256 + wr * 64;
 
   if (tid < 256) cnt_s[tid] = 0;
-  bf16x8 a[2][KS];
+  f16x8 a[2][KS];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int64_t row = m0 + i * 32 + lr;
@@ -210,116 +291,103 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
     for (int kk = 0; kk < KS; ++kk) {
       u32x4 v = u32x4(0u);
       if (row < nq) v = *reinterpret_cast<const u32x4*>(A2 + row * K3 + kk * 16 + kh);
-      a[i][kk] = __builtin_bit_cast(bf16x8, v);
+      a[i][kk] = __builtin_bit_cast(f16x8, v);
     }
   }
 
   int* cnt = cnt_s + wr * 64 + 4 * (lane >> 5);
-  const int64_t row0 = m0 + 4 * (lane >> 5);                                      // query of accumulator register (i, r):
+  const int64_t row0 = m0 + 4 * (lane >> 5);                           // query of accumulator register (i, r):
   int32_t* surv_base = surv + row0 * cap + (int64_t)blockIdx.y * seg;  // row0 + i * 32 + (r & 3) + 8 * (r >> 2); this slice's segment
 
-  const int64_t tiles_n = (n + BN - 1) / BN;
-  const int64_t t_lo = (int64_t)blockIdx.y * tiles_per_slice, t_hi = min(tiles_n, t_lo + tiles_per_slice);
+  const int64_t t_lo = t_begin + (int64_t)blockIdx.y * tiles_per_slice, t_hi = min(t_end, t_lo + tiles_per_slice);
   u32x4 stage[NCH];
-  // chunk s of this thread: row c / CPR of the tile, 16-byte column c % CPR (fixed per thread); only the last tile of the
-  // matrix can hold rows >= n, so every other tile is loaded without guards (the per-chunk 64-bit compares and branches of
-  // the guarded form were a sixth of the kernel's non-MFMA instructions)
-  const uint16_t* b_chunk[NCH];
+  const _Float16* b_src = B2 + (int64_t)tid * 8;  // chunk `tid` of image 0
+  int lds_off[NCH];
 #pragma unroll
   for (int s = 0; s < NCH; ++s) {
     const int c = tid + 512 * s;
-    b_chunk[s] = B2 + (int64_t)(c / CPR) * K3 + (c % CPR) * 8;
+    lds_off[s] = (c / CPR) * LD + (c % CPR) * 8;
   }
-  const bool chunk_tail_live = tid + 512 * (NCH - 1) < BN * CPR;  // the last chunk index may run past the tile
-  auto load_tile = [&](int64_t t) {
-    const int64_t off = t * BN * (int64_t)K3;
-    if (t * BN + BN <= n) {
+  // B2 is padded with zero rows to whole images: no guards
+  static_assert(GCH % 512 == 0, "an image is a whole number of 512-thread rounds");
+  auto load_image = [&](int64_t t) __attribute__((always_inline)) {
+    const _Float16* src = b_src + t * BN * (int64_t)K3;
 #pragma unroll
-      for (int s = 0; s < NCH; ++s)
-        if (s + 1 < NCH || chunk_tail_live) stage[s] = *reinterpret_cast<const u32x4*>(b_chunk[s] + off);
-    } else {
-#pragma unroll
-      for (int s = 0; s < NCH; ++s) {
-        const int c = tid + 512 * s;
-        const int64_t row = t * BN + c / CPR;
-        stage[s] = (c < BN * CPR && row < n) ? *reinterpret_cast<const u32x4*>(b_chunk[s] + off) : u32x4(0u);
-      }
-    }
+    for (int s = 0; s < NCH; ++s) stage[s] = *reinterpret_cast<const u32x4*>(src + (int64_t)512 * 8 * s);
   };
-  auto store_tile = [&](int buf) {
+  auto store_image = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
-    for (int s = 0; s < NCH; ++s) {
-      const int c = tid + 512 * s;
-      if (c < BN * CPR) *reinterpret_cast<u32x4*>(lds + (size_t)buf * BN * LD + (c / CPR) * LD + (c % CPR) * 8) = stage[s];
-    }
+    for (int s = 0; s < NCH; ++s) *reinterpret_cast<u32x4*>(lds_h + (size_t)buf * NT * BN * LD + lds_off[s]) = stage[s];
   };
   f32x16 acc[2][2];
-  // Only lanes with a hit walk their set bits (an in-line "if (pass) append" per pair serialised ~10 returning atomics per
-  // tile and wave: 65 % of all wave cycles were spent waiting).  Both query sub-tiles advance together, so the two
-  // returning LDS atomics of a round are in flight at the same time and the wave waits once per round, not once per hit.
-  auto append = [&](int j, int64_t t, const unsigned int (&h)[2]) __attribute__((always_inline)) {
-#if defined(DH_KNN_ABL) && (DH_KNN_ABL == 1 || DH_KNN_ABL == 2)
+  const unsigned int n1u = (unsigned int)n1;
+  // Only lanes with a hit walk their set bits.  Both query sub-tiles advance together, so the two returning LDS atomics of a
+  // round are in flight at the same time and the wave waits once per round, not once per hit.
+  // (g0, j0): residue class and in-class index of the first row of the candidate tile (row p of B2 = class p / n1, index
+  // p % n1, candidate id = index * G + class); a tile crosses at most one class boundary (n1 >= 128 whenever G > 1)
+  auto append = [&](int j, unsigned int g0, unsigned int j0, const unsigned int (&h)[2]) __attribute__((always_inline)) {
+#if defined(DH_KNN_ABL) && DH_KNN_ABL == 1
     if (h[0] == 0xdeadbeefu && h[1] == 0x12345u) cnt[0] = 1;  // ablation build: keep h alive, never append
     return;
 #endif
-    const int64_t c = t * BN + wc * 64 + j * 32 + lr;
-    const bool live = c < n;  // zero-padded candidate rows pass the folded test
+    unsigned int jj = j0 + (unsigned int)(wc * 64 + j * 32 + lr), gg = g0;
+    if (jj >= n1u) { jj -= n1u; gg += 1u; }
+    const unsigned int id = jj * (unsigned int)G + gg;
+    const bool live = gg < (unsigned int)G && (int64_t)id < n;  // the zero rows behind the last candidate never pass anyway
     unsigned int mk0 = live ? h[0] : 0u, mk1 = live ? h[1] : 0u;
     while (mk0 | mk1) {
       const int b0 = 31 - __clz(mk0 | 1u), b1 = 31 - __clz(mk1 | 1u);  // (| 1: defined for an empty mask, then unused)
       const int r0 = 15 - b0, r1 = 15 - b1;
       const int q0 = (r0 & 3) + 8 * (r0 >> 2), q1 = 32 + (r1 & 3) + 8 * (r1 >> 2);
-      // rows beyond the query range hold zero fragments and pass: skip them
+      // rows beyond the query range hold zero fragments (accumulator +0: no pass), checked all the same
       const bool p0 = mk0 != 0u && row0 + q0 < nq, p1 = mk1 != 0u && row0 + q1 < nq;
       int pos0 = 0, pos1 = 0;
       if (p0) pos0 = atomicAdd(cnt + q0, 1);
       if (p1) pos1 = atomicAdd(cnt + q1, 1);
-      if (p0 && pos0 < seg) surv_base[(int64_t)q0 * cap + pos0] = (int32_t)c;
-      if (p1 && pos1 < seg) surv_base[(int64_t)q1 * cap + pos1] = (int32_t)c;
+      if (p0 && pos0 < seg) surv_base[(int64_t)q0 * cap + pos0] = (int32_t)id;
+      if (p1 && pos1 < seg) surv_base[(int64_t)q1 * cap + pos1] = (int32_t)id;
       mk0 &= ~(1u << b0);
       mk1 &= ~(1u << b1);
     }
   };
-  // One half tile: all K steps of candidate sub-tile JM on the matrix cores (fragments four steps ahead of their MFMAs)
-  // while the vector ALUs take the pass bits of sub-tile JT from the previous half: bit (15 - r) of h[i] =
-  // [acc[i][JT][r] <= 0], one v_cmp + one v_addc (h + h + carry) per pair, a fixed number of pairs behind every MFMA.
-  // The order is written out and pinned (sched_barrier): left to itself the compiler sinks the pass bits into the
-  // (rarely taken) append branch behind the MFMAs and packs them with three VALU ops per pair.
-  auto half_tile = [&](auto jm_tag, const uint16_t* b_frag, unsigned int (&h)[2], int64_t prefetch_tile) __attribute__((always_inline)) {
+  // One half tile: all K steps of candidate sub-tile JM on the matrix cores while the vector ALUs take the pass bits of
+  // sub-tile JT from the previous half: bit (15 - r) of h[i] = sign bit of acc[i][JT][r], one v_alignbit (h = h << 1 | sign)
+  // per pair, a fixed number of pairs behind every MFMA.
+  auto half_tile = [&](auto jm_tag, const _Float16* b_frag, unsigned int (&h)[2], int64_t prefetch_tile) __attribute__((always_inline)) {
     constexpr int JM = decltype(jm_tag)::value, JT = 1 - JM;
     constexpr int PER = (32 + 2 * KS - 1) / (2 * KS);  // pairs behind each MFMA
-    constexpr int AHEAD = 4;  // fragment reads in flight ahead of their MFMAs (an LDS read is ~128 clocks, an MFMA pair 64)
-    bf16x8 b[KS];
+    constexpr int AHEAD = 4;  // fragment reads in flight ahead of their MFMAs
+    f16x8 b[KS];
 #pragma unroll
-    for (int kk = 0; kk < AHEAD && kk < KS; ++kk) b[kk] = *reinterpret_cast<const bf16x8*>(b_frag + JM * 32 * LD + kk * 16);
+    for (int kk = 0; kk < AHEAD && kk < KS; ++kk) b[kk] = *reinterpret_cast<const f16x8*>(b_frag + JM * 32 * LD + kk * 16);
     h[0] = h[1] = 0u;
 #pragma unroll
     for (int m = 0; m < 2 * KS; ++m) {
       const int kk = m >> 1, i = m & 1;
-      if (i == 0 && kk + AHEAD < KS) b[kk + AHEAD] = *reinterpret_cast<const bf16x8*>(b_frag + JM * 32 * LD + (kk + AHEAD) * 16);
+      if (i == 0 && kk + AHEAD < KS) b[kk + AHEAD] = *reinterpret_cast<const f16x8*>(b_frag + JM * 32 * LD + (kk + AHEAD) * 16);
       if (kk == 0) {
         f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[kk], z, 0, 0, 0);
+        acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][kk], b[kk], z, 0, 0, 0);
       } else {
-        acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[kk], acc[i][JM], 0, 0, 0);
+        acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][kk], b[kk], acc[i][JM], 0, 0, 0);
       }
 #pragma unroll
       for (int e = m * PER; e < (m + 1) * PER && e < 32; ++e)
-        asm("v_cmp_ge_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(h[e >> 4]) : "v"(acc[e >> 4][JT][e & 15]) : "vcc");
+        h[e >> 4] = __builtin_amdgcn_alignbit(h[e >> 4], __float_as_uint(acc[e >> 4][JT][e & 15]), 31u);
       __builtin_amdgcn_sched_barrier(0);
-      // the next tile's loads go out behind the FIRST MFMA of the tile: the compiler drains vmcnt (the previous half's append
-      // stores share the counter with loads) in front of this block, so this is the earliest point that keeps them in flight
+      // the next image's loads go out behind the FIRST MFMA of the image: the compiler drains vmcnt (the previous half's
+      // append stores share the counter with loads) in front of this block, so this is the earliest point that keeps them in flight
       if (JM == 0 && m == 0 && prefetch_tile >= 0) {
-        load_tile(prefetch_tile);
+        load_image(prefetch_tile);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
 
-  load_tile(t_lo < t_hi ? t_lo : 0);
-  store_tile(0);
+  load_image(t_lo < t_hi ? t_lo : 0);
+  store_image(0);
   __syncthreads();
   int cur = 0;
   unsigned int h[2];
@@ -327,22 +395,26 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][1][r] = 1.f;  // nothing passes in the first rotated half
-  for (int64_t t = t_lo; t < t_hi; ++t) {
-    const uint16_t* b_frag = lds + (size_t)cur * BN * LD + (wc * 64 + lr) * LD + kh;
-    // half A: matrix cores on sub-tile 0 of tile t, vector ALUs on sub-tile 1 of tile t - 1 (first tile: preset to "no pass")
-    __builtin_amdgcn_sched_barrier(0);
-    half_tile(std::integral_constant<int, 0>{}, b_frag, h, t + 1 < t_hi ? t + 1 : -1);
-    append(1, t - 1, h);
-    // half B: matrix cores on sub-tile 1, vector ALUs on sub-tile 0 of the same tile
-    __builtin_amdgcn_sched_barrier(0);
-    half_tile(std::integral_constant<int, 1>{}, b_frag, h, -1);
-    append(0, t, h);
-    if (t + 1 < t_hi) store_tile(cur ^ 1);
-#if defined(DH_KNN_ABL) && DH_KNN_ABL == 3
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ablation build: no barrier (results are garbage)
-#else
+  unsigned int g_cur = (unsigned int)((t_lo * BN) / n1), j_cur = (unsigned int)((t_lo * BN) % n1), g_prev = 0u, j_prev = 0u;
+  int64_t t = t_lo;
+  for (; t < t_hi; t += NT) {
+#pragma unroll
+    for (int sub = 0; sub < NT; ++sub) {
+      const _Float16* b_frag = lds_h + (size_t)cur * NT * BN * LD + (sub * BN + wc * 64 + lr) * LD + kh;
+      // half A: matrix cores on sub-tile 0 of tile t + sub, vector ALUs on sub-tile 1 of the tile before it
+      __builtin_amdgcn_sched_barrier(0);
+      half_tile(std::integral_constant<int, 0>{}, b_frag, h, (sub == 0 && t + NT < t_hi) ? t + NT : -1);
+      append(1, g_prev, j_prev, h);
+      // half B: matrix cores on sub-tile 1, vector ALUs on sub-tile 0 of the same tile
+      __builtin_amdgcn_sched_barrier(0);
+      half_tile(std::integral_constant<int, 1>{}, b_frag, h, -1);
+      append(0, g_cur, j_cur, h);
+      g_prev = g_cur; j_prev = j_cur;
+      j_cur += BN;
+      if (j_cur >= n1u) { j_cur -= n1u; g_cur += 1u; }
+    }
+    if (t + NT < t_hi) store_image(cur ^ 1);
     __syncthreads();  // everyone is done with `cur` and the next image is complete
-#endif
     cur ^= 1;
   }
   if (t_hi > t_lo) {  // the last half's pass bits
@@ -350,9 +422,9 @@ __global__ __launch_bounds__(512) void knn_filter_small_kernel(int64_t nq, int64
     for (int i = 0; i < 2; ++i) {
       h[i] = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) h[i] = h[i] + h[i] + (unsigned int)(acc[i][1][r] <= 0.f);
+      for (int r = 0; r < 16; ++r) h[i] = h[i] + h[i] + (__float_as_uint(acc[i][1][r]) >> 31);
     }
-    append(1, t_hi - 1, h);
+    append(1, g_prev, j_prev, h);
   }
   __syncthreads();
   if (tid < 256 && (int64_t)blockIdx.x * 256 + tid < nq) counts[(int64_t)blockIdx.y * nq + (int64_t)blockIdx.x * 256 + tid] = cnt_s[tid];
@@ -384,10 +456,15 @@ __device__ __forceinline__ float chain_d2(const float* __restrict__ xq, const fl
   return acc;
 }
 
+// Survivor list of query q: n_seg_a segments of seg_a slots followed by n_seg_b segments of seg_b slots (row stride cap);
+// counts[s * nq + q] entries of segment s are valid.  Segments [sg_lo, sg_hi) are processed; any of them over capacity: the
+// list is incomplete -> every candidate is re-scanned.  carry_in: the k keys (out_idx, raw d2 in out_dist) an earlier pass
+// left take part (equal keys collapse in the selection, so candidates seen twice are harmless).  raw_out: leave raw d2.
 template <bool VEC>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
                                                          int64_t q_begin, int64_t nq, int k, const int32_t* __restrict__ counts,
-                                                         const int32_t* __restrict__ surv, int cap, int n_seg, int seg,
+                                                         const int32_t* __restrict__ surv, int cap, int n_seg_a, int seg_a, int seg_b,
+                                                         int sg_lo, int sg_hi, int carry_in, int raw_out,
                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -397,14 +474,18 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, c
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem) + (size_t)wave * (RR_CHUNK + 64);
   const unsigned long long kInf = ~0ull;
   const float* xq = X + (q_begin + q) * ldx;
-  // the list of query q is n_seg segments of `seg` slots (one per candidate slice of the filter); counts[s * nq + q]
-  // entries of segment s are valid.  Any segment over capacity: the list is incomplete -> every candidate is re-scanned.
   bool overflow = false;
-  for (int sg = 0; sg < n_seg; ++sg) overflow |= counts[(int64_t)sg * nq + q] > seg;
+  for (int sg = sg_lo; sg < sg_hi; ++sg) overflow |= counts[(int64_t)sg * nq + q] > (sg < n_seg_a ? seg_a : seg_b);
   int carried = 0;
-  for (int sg = 0; sg < (overflow ? 1 : n_seg); ++sg) {
+  if (carry_in) {
+    const bool have = lane < k && out_idx[q * k + lane] >= 0;  // a valid prefix (ascending keys, then -1 entries)
+    if (have) keys[RR_CHUNK + lane] = ((unsigned long long)__float_as_uint(out_dist[q * k + lane]) << 32) | (unsigned int)out_idx[q * k + lane];
+    carried = __popcll(__ballot(have));
+    __builtin_amdgcn_wave_barrier();
+  }
+  for (int sg = sg_lo; sg < (overflow ? sg_lo + 1 : sg_hi); ++sg) {
   const int64_t total = overflow ? n : counts[(int64_t)sg * nq + q];
-  const int32_t* mine = surv + q * cap + (int64_t)sg * seg;
+  const int32_t* mine = surv + q * cap + (sg < n_seg_a ? (int64_t)sg * seg_a : (int64_t)n_seg_a * seg_a + (int64_t)(sg - n_seg_a) * seg_b);
   for (int64_t base = 0; base < total; base += RR_CHUNK) {
     const int m = (int)min((int64_t)RR_CHUNK, total - base);
     for (int i = lane; i < m; i += 64) {
@@ -441,7 +522,8 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, c
     if (s < carried) {
       const unsigned long long v = keys[RR_CHUNK + s];
       out_idx[q * k + s] = (int32_t)(unsigned int)v;
-      out_dist[q * k + s] = (float)sqrt((double)__uint_as_float((unsigned int)(v >> 32)));
+      const float d2 = __uint_as_float((unsigned int)(v >> 32));
+      out_dist[q * k + s] = raw_out ? d2 : (float)sqrt((double)d2);
     } else {
       out_idx[q * k + s] = -1;
       out_dist[q * k + s] = __int_as_float(0x7f800000);
@@ -473,56 +555,58 @@ int64_t knn_filter_sample_size(int64_t n) {
   return S < n ? S : n;
 }
 
+static int pow2_at_least(int64_t want, int lo, int hi) {
+  int cap = lo;
+  while (cap < want && cap < hi) cap <<= 1;
+  return cap;
+}
+
 int knn_filter_cap(int64_t n, int k) {
   // expected survivors ~ k n / S (times the eps margin); 4x that, at least 256, a power of two
-  const int64_t want = 4 * (int64_t)k * dh::ceil_div(n, knn_filter_sample_size(n));
-  int cap = 256;
-  while (cap < want && cap < (1 << 16)) cap <<= 1;
-  return cap;  // (split into per-slice segments by knn_filter_launch; an overfull segment only costs that query a re-scan)
+  return pow2_at_least(4 * (int64_t)k * dh::ceil_div(n, knn_filter_sample_size(n)), 256, 1 << 16);
 }
 
-// candidate slices of the query-stationary filter (each gets its own segment of every survivor list and its own
-// counter array): enough blocks for two rounds of the chip
-int knn_filter_slices(int64_t nq) {
-  const int64_t qblocks = ceil_div(nq, 256);
-  return (int)(qblocks >= 512 ? 1 : ceil_div(512, qblocks));
-}
+// bf16 columns of an operand row of the tile kernel (d > 64): three dp-wide parts, whole 16-wide MFMA steps
+int64_t knn_filter_k3(int64_t d) { return (3 * (int64_t)((d + 7) / 8 * 8) + 15) / 16 * 16; }
 
-// bf16 columns of an operand row: three dp-wide parts, for d <= 64 (the query-stationary kernel) plus the six columns that
-// carry the folded thresholds; rounded up to whole 16-wide MFMA steps
-bool knn_filter_folds(int64_t d) { return (d + 7) / 8 * 8 <= 64; }
-int64_t knn_filter_k3(int64_t d) { return (3 * (int64_t)((d + 7) / 8 * 8) + (knn_filter_folds(d) ? 6 : 0) + 15) / 16 * 16; }
-
-// Survivor lists: n_seg segments of `seg` slots per query (row stride n_seg * seg).  One segment for the tile kernel
-// (d > 64); one per candidate slice for the query-stationary kernel, each at least 1024 slots deep so that a query
-// whose neighbours all sit in one slice does not overflow (an overfull segment only costs that query a re-scan).
+// Survivor lists of the tile kernel (d > 64): one segment per query (an overfull list only costs that query a re-scan).
 void knn_filter_geometry(int64_t n, int64_t d, int64_t nq, int k, int* n_seg, int* seg) {
-  const int cap = knn_filter_cap(n, k);
+  (void)d; (void)nq;
   *n_seg = 1;
-  *seg = cap;
-  if (knn_filter_folds(d)) {
-    const int64_t tiles_n = ceil_div(n, BN);
-    int64_t slices = knn_filter_slices(nq);
-    if (slices > tiles_n) slices = tiles_n;
-    const int64_t tps = ceil_div(tiles_n, slices);
-    *n_seg = (int)ceil_div(tiles_n, tps);
-    int sg = cap / *n_seg;
-    if (*n_seg > 1 && sg < 1024) sg = cap < 1024 ? cap : 1024;
-    *seg = sg;
-  }
+  *seg = knn_filter_cap(n, k);
 }
 
 int knn_filter_padded_d(int64_t d) { return (int)((d + 7) / 8 * 8); }
 
-
+void knn_filter_sample_strided(int64_t S, int64_t stride, int64_t d, const float* X, int64_t ldx, int rs, float* Xs, hipStream_t st) {
+  hipLaunchKernelGGL(knn_sample_kernel, dim3((unsigned)ceil_div(S * rs, 256)), dim3(256), 0, st, S, stride, d, X, ldx, rs, Xs);
+}
 void knn_filter_sample(int64_t n, int64_t d, const float* X, int64_t ldx, int rs, float* Xs, hipStream_t st) {
   const int64_t S = knn_filter_sample_size(n);
-  hipLaunchKernelGGL(knn_sample_kernel, dim3((unsigned)ceil_div(S * rs, 256)), dim3(256), 0, st, S, n / S, d, X, ldx, rs, Xs);
+  knn_filter_sample_strided(S, n / S, d, X, ldx, rs, Xs, st);
 }
 
-// Steps 2 and 3 (the sample pass has already left the raw k-th sample distances in sample_d2 [nq][k]).
-// `Xr` (leading dimension ldr, dr >= d columns, extra columns zero) is what the re-rank reads: the zero-padded copy for
-// d <= 64, X itself otherwise.
+static void colmeans(int64_t n, int64_t d, const float* X, int64_t ldx, float* mean_ws, hipStream_t st) {
+  const int n_partial = (int)(n < kMeanBlocks ? n : kMeanBlocks);
+  hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)n_partial), dim3(256), 0, st, n, d, X, ldx, mean_ws + d);
+  hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, n, d, n_partial, mean_ws + d, mean_ws);
+}
+
+static void rerank_launch(int64_t n, const float* Xr, int64_t ldr, int64_t dr, int64_t q_begin, int64_t nq, int k, const int32_t* counts,
+                          const int32_t* surv, int cap, int n_seg_a, int seg_a, int seg_b, int sg_lo, int sg_hi, int carry_in, int raw_out,
+                          int32_t* out_idx, float* out_dist, hipStream_t st) {
+  const size_t lds = 4 * (size_t)(RR_CHUNK + 64) * sizeof(unsigned long long);
+  const bool vec = dr % 4 == 0 && ldr % 4 == 0 && aligned16(Xr);
+  if (vec)
+    hipLaunchKernelGGL(knn_rerank_kernel<true>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
+                       surv, cap, n_seg_a, seg_a, seg_b, sg_lo, sg_hi, carry_in, raw_out, out_idx, out_dist);
+  else
+    hipLaunchKernelGGL(knn_rerank_kernel<false>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
+                       surv, cap, n_seg_a, seg_a, seg_b, sg_lo, sg_hi, carry_in, raw_out, out_idx, out_dist);
+}
+
+// Steps 2 and 3 for d > 64 (the sample pass has already left the raw k-th sample distances in sample_d2 [nq][k]).
+// `Xr` (leading dimension ldr, dr >= d columns, extra columns zero) is what the re-rank reads.
 int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const float* Xr, int64_t ldr, int64_t dr,
                       int64_t q_begin, int64_t nq, int k,
                       const float* sample_d2, float* mean_ws, uint16_t* A2, uint16_t* B2, float* norms, float* Rq, float* Cn,
@@ -530,57 +614,119 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
   const int dp = knn_filter_padded_d(d);
   const int64_t K3 = knn_filter_k3(d);
   const float eps = 1.220703125e-4f + (float)d * 9.5367431640625e-7f;  // 2^-13 + d 2^-20
-  const int n_partial = (int)(n < kMeanBlocks ? n : kMeanBlocks);
-  hipLaunchKernelGGL(knn_colsum_kernel, dim3((unsigned)n_partial), dim3(256), 0, st, n, d, X, ldx, mean_ws + d);
-  hipLaunchKernelGGL(knn_mean_kernel, dim3((unsigned)ceil_div(d, 256)), dim3(256), 0, st, n, d, n_partial, mean_ws + d, mean_ws);
-  const bool fold = knn_filter_folds(d);
-  if (fold)
-    hipLaunchKernelGGL(knn_split_kernel<true>, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, eps, A2, B2, norms);
-  else
-    hipLaunchKernelGGL(knn_split_kernel<false>, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, eps, A2, B2, norms);
+  colmeans(n, d, X, ldx, mean_ws, st);
+  hipLaunchKernelGGL(knn_split_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, A2, B2, norms);
   hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, q_begin, nq, k, eps, norms,
-                     sample_d2, Rq, Cn, counts, fold ? A2 : nullptr, K3, dp);
-  int n_seg, seg;
-  knn_filter_geometry(n, d, nq, k, &n_seg, &seg);
-  const int cap = n_seg * seg;  // slots per query
-  if (fold) {  // query-stationary kernel; candidate tiles sliced over grid.y until >= 2 rounds of blocks exist
-    const int64_t qblocks = ceil_div(nq, 256), tiles_n = ceil_div(n, BN);
-    const int64_t tps = ceil_div(tiles_n, n_seg);
+                     sample_d2, Rq, Cn, counts);
+  const int cap = knn_filter_cap(n, k);
+  const int64_t tiles = ceil_div(nq, BM) * ceil_div(n, BN);
+  if (tiles >= (int64_t)1 << 31) return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: too many filter tiles (%lld)", (long long)tiles);
+  constexpr size_t kTileLds = (size_t)TILE_LDS_ELEMS * sizeof(uint16_t);
+  static const bool tile_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  (int)kTileLds) == hipSuccess;
+  if (!tile_ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");
+  hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)tiles), dim3(256), kTileLds, st, nq, n, K3, A2 + q_begin * K3, B2, Rq, Cn, counts,
+                     surv, cap);
+  rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, cap, 1, cap, 0, 0, 1, 0, 0, out_idx, out_dist, st);
+  return check_launch("dh_knn_bruteforce_f32(filter)");
+}
+
+// ---- d <= 64 ---------------------------------------------------------------------------------------------------------------
+bool knn_fold_applies(int64_t d) { return d <= 64; }
+
+KnnFoldGeom knn_fold_geom(int64_t n, int64_t d, int64_t nq, int k) {
+  KnnFoldGeom g{};
+  g.dp = knn_filter_padded_d(d);
+  g.K3 = (g.dp + 6 + 15) / 16 * 16;
+  g.G = n >= FOLD_TWO_PASS_MIN ? FOLD_G : 1;
+  g.n1 = ceil_div(n, g.G);
+  g.n_pos = ceil_div(g.G * g.n1, (int64_t)FOLD_NT * BN) * FOLD_NT * BN;  // zero rows up to whole LDS images
+  if (g.G > 1) {  // ~4096 sample rows, every one of them in pass 1 (stride a multiple of G)
+    int64_t m = (n + (int64_t)g.G * 2048) / ((int64_t)g.G * 4096);
+    if (m < 1) m = 1;
+    g.stride0 = g.G * m;
+    g.S = ceil_div(n, g.stride0);
+  } else {
+    g.S = knn_filter_sample_size(n);
+    g.stride0 = n / g.S;
+  }
+  g.tiles = ceil_div(g.n_pos, BN);
+  g.t1 = g.G > 1 ? ceil_div(ceil_div(g.n1, BN), FOLD_NT) * FOLD_NT : g.tiles;
+  if (g.t1 > g.tiles) g.t1 = g.tiles;
+  // candidate slices (grid.y) until >= 2 rounds of blocks exist; each slice owns a segment of every survivor list, at least
+  // 1024 slots deep so that a query whose neighbours all sit in one slice does not overflow
+  const int64_t qblocks = ceil_div(nq, 256);
+  const int64_t slices = qblocks >= 512 ? 1 : ceil_div(512, qblocks);
+  auto plan = [&](int64_t T, int64_t want, int64_t* tps, int* n_seg, int* seg) {
+    if (T <= 0) { *tps = FOLD_NT; *n_seg = 0; *seg = 0; return; }
+    int64_t sl = slices;
+    if (sl > ceil_div(T, FOLD_NT)) sl = ceil_div(T, FOLD_NT);
+    *tps = ceil_div(ceil_div(T, sl), FOLD_NT) * FOLD_NT;
+    *n_seg = (int)ceil_div(T, *tps);
+    const int cap = pow2_at_least(want, 256, 1 << 16);
+    int sg = cap / *n_seg;
+    if (*n_seg > 1 && sg < 1024) sg = cap < 1024 ? cap : 1024;
+    *seg = sg;
+  };
+  // pass 1: ~ k (rows of pass 1) / S survivors, 4x that; pass 2: tau1 is the exact k-th of n / G rows -> ~ k G, 8x that (the
+  // coarser fp16 margin inflates this list first)
+  plan(g.t1, 4 * (int64_t)k * ceil_div(g.t1 * BN, g.S), &g.tps1, &g.n_seg1, &g.seg1);
+  plan(g.tiles - g.t1, 8 * (int64_t)k * g.G, &g.tps2, &g.n_seg2, &g.seg2);
+  g.cap = g.n_seg1 * g.seg1 + g.n_seg2 * g.seg2;
+  return g;
+}
+
+int knn_fold_launch(const KnnFoldGeom& g, int64_t n, int64_t d, const float* X, int64_t ldx, const float* Xr, int64_t ldr, int64_t dr,
+                    int64_t q_begin, int64_t nq, int k, float* mean_ws, unsigned int* maxabs, void* A2v, void* B2v, float* norms,
+                    int32_t* counts, int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st) {
+  _Float16* A2 = static_cast<_Float16*>(A2v);
+  _Float16* B2 = static_cast<_Float16*>(B2v);
+  const float eps = 9.765625e-4f + 1.220703125e-4f + (float)g.dp * 9.5367431640625e-7f;  // 2^-10 + 2^-13 + dp 2^-20
+  const float abs_lin = 1.01f * 1.220703125e-4f * sqrtf((float)g.dp);                    // 1.01 * 2^-13 sqrt(dp)
+  colmeans(n, d, X, ldx, mean_ws, st);
+  if (hipMemsetAsync(maxabs, 0, sizeof(unsigned int), st) != hipSuccess) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: memset failed");
+  hipLaunchKernelGGL(knn_maxabs_kernel, dim3((unsigned)(n < 4096 ? ceil_div(n, 4) : 1024)), dim3(256), 0, st, n, d, X, ldx, mean_ws, maxabs);
+  hipLaunchKernelGGL(knn_fold_split_kernel, dim3((unsigned)ceil_div(g.n_pos, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, maxabs, g.dp, g.K3,
+                     eps, abs_lin, g.G, g.n1, g.n_pos, A2, B2, norms);
+  const dim3 tgrid((unsigned)ceil_div(nq, 256));
+  hipLaunchKernelGGL(knn_fold_thresholds_kernel, tgrid, dim3(256), 0, st, q_begin, nq, k, eps, abs_lin, maxabs, norms, out_dist, g.dp, g.K3, A2,
+                     counts, g.n_seg1 + g.n_seg2);
+  const int64_t qblocks = ceil_div(nq, 256);
+  const int ks = g.K3 / 16;
+  const size_t lds = 2 * (size_t)FOLD_NT * BN * (g.K3 + 8) * sizeof(_Float16);
+  auto filter = [&](int n_seg, int seg, int64_t t_begin, int64_t t_end, int64_t tps, int32_t* cnt, int32_t* sv) -> int {
+    if (n_seg <= 0) return DH_OK;
     dim3 grid((unsigned)qblocks, (unsigned)n_seg);
-    const int ks = (int)(K3 / 16);
-    const size_t lds = 2 * (size_t)BN * (K3 + 8) * sizeof(uint16_t);
 #define DH_KNN_FS(KS)                                                                                                          \
   case KS: {                                                                                                                   \
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_small_kernel<KS>),                     \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_fold_filter_kernel<KS, FOLD_NT>),             \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,                                     \
-                                               (int)(2 * BN * (16 * KS + 8) * sizeof(uint16_t))) == hipSuccess;                \
+                                               (int)(2 * FOLD_NT * BN * (16 * KS + 8) * sizeof(_Float16))) == hipSuccess;      \
     if (!ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");                        \
-    hipLaunchKernelGGL(knn_filter_small_kernel<KS>, grid, dim3(512), lds, st, nq, n, A2 + q_begin * K3, B2, counts,            \
-                       surv, cap, seg, tps);                                                                                   \
+    hipLaunchKernelGGL((knn_fold_filter_kernel<KS, FOLD_NT>), grid, dim3(512), lds, st, nq, n, g.G, g.n1,                      \
+                       A2 + q_begin * g.K3, B2, cnt, sv, g.cap, seg, t_begin, t_end, tps);                                     \
   } break
     switch (ks) {
-      DH_KNN_FS(2); DH_KNN_FS(4); DH_KNN_FS(5); DH_KNN_FS(7); DH_KNN_FS(8); DH_KNN_FS(10); DH_KNN_FS(11); DH_KNN_FS(13);
+      DH_KNN_FS(1); DH_KNN_FS(2); DH_KNN_FS(3); DH_KNN_FS(4); DH_KNN_FS(5);
       default: return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: unexpected filter depth %d", ks);
     }
 #undef DH_KNN_FS
+    return DH_OK;
+  };
+  int rc = filter(g.n_seg1, g.seg1, 0, g.t1, g.tps1, counts, surv);
+  if (rc != DH_OK) return rc;
+  if (g.n_seg2 > 0) {
+    // exact k smallest among pass 1's survivors -> tau1 (raw d2 in out_dist) -> thresholds of pass 2
+    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, g.cap, g.n_seg1, g.seg1, g.seg2, 0, g.n_seg1, 0, 1, out_idx, out_dist, st);
+    hipLaunchKernelGGL(knn_fold_thresholds_kernel, tgrid, dim3(256), 0, st, q_begin, nq, k, eps, abs_lin, maxabs, norms, out_dist, g.dp, g.K3,
+                       A2, counts, 0);
+    rc = filter(g.n_seg2, g.seg2, g.t1, g.tiles, g.tps2, counts + (int64_t)g.n_seg1 * nq, surv + (int64_t)g.n_seg1 * g.seg1);
+    if (rc != DH_OK) return rc;
+    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, g.cap, g.n_seg1, g.seg1, g.seg2, g.n_seg1, g.n_seg1 + g.n_seg2, 1, 0, out_idx,
+                  out_dist, st);
   } else {
-    const int64_t tiles = ceil_div(nq, BM) * ceil_div(n, BN);
-    if (tiles >= (int64_t)1 << 31) return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: too many filter tiles (%lld)", (long long)tiles);
-    constexpr size_t kTileLds = (size_t)TILE_LDS_ELEMS * sizeof(uint16_t);
-    static const bool tile_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_filter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)kTileLds) == hipSuccess;
-    if (!tile_ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)tiles), dim3(256), kTileLds, st, nq, n, K3, A2 + q_begin * K3, B2, Rq, Cn, counts,
-                       surv, cap);
+    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, g.cap, g.n_seg1, g.seg1, g.seg2, 0, g.n_seg1, 0, 0, out_idx, out_dist, st);
   }
-  const size_t lds = 4 * (size_t)(RR_CHUNK + 64) * sizeof(unsigned long long);
-  const bool vec = dr % 4 == 0 && ldr % 4 == 0 && aligned16(Xr);
-  if (vec)
-    hipLaunchKernelGGL(knn_rerank_kernel<true>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
-                       surv, cap, n_seg, seg, out_idx, out_dist);
-  else
-    hipLaunchKernelGGL(knn_rerank_kernel<false>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
-                       surv, cap, n_seg, seg, out_idx, out_dist);
   return check_launch("dh_knn_bruteforce_f32(filter)");
 }
 

@@ -122,6 +122,34 @@ def test_knn_filter_equals_scan(cuda_device, n, d, k, kind):
     assert torch.equal(i_s, i_f) and torch.equal(d_s, d_f)
 
 
+@pytest.mark.parametrize("case", ["range", "odd_n", "tiny_scale", "huge_scale", "out_of_range_scale", "centroid_duplicates",
+                                  "one_slice", "spread_clusters", "d64"])
+def test_knn_two_pass_filter_equals_scan(cuda_device, case):
+    """d <= 64, n >= 32768: fp16 filter with thresholds in two passes (rows 0 mod 16 first) — same bits as the scan."""
+    rng = np.random.default_rng(len(case))
+    n, d, k, q = 40_000, 50, 15, None
+    if case == "range":
+        x = rng.standard_normal((n, d)); q = (1000, 3000)
+    elif case == "odd_n":
+        n = 40_013; x = rng.standard_normal((n, 20)) * rng.uniform(0.1, 10, size=(1, 20))
+    elif case == "tiny_scale":
+        x = rng.standard_normal((n, d)) * 1e-10
+    elif case == "huge_scale":
+        x = rng.standard_normal((n, d)) * 1e10
+    elif case == "out_of_range_scale":   # the scale cannot be normalised: every query re-scans (exact all the same)
+        n = 33_000; x = rng.standard_normal((n, 8)) * 1e25
+    elif case == "centroid_duplicates":  # a third of the points sit exactly on the column means' side of things: zero norms, ties
+        x = rng.standard_normal((n, 10)); x[::3] = 0.0
+    elif case == "one_slice":            # >= 512 query blocks: one candidate slice per pass
+        n, k = 140_000, 5; x = rng.standard_normal((n, 8))
+    elif case == "spread_clusters":      # between-cluster spread 30x the within-cluster one: the fp16 margin is relative to the norms
+        x = rng.standard_normal((n, d)) + rng.standard_normal((40, d))[rng.integers(0, 40, size=n)] * 30.0
+    else:
+        n, d = 34_000, 64; x = rng.standard_normal((n, d))
+    (i_s, d_s), (i_f, d_f) = _knn_both(x.astype(np.float32), k, cuda_device, q=q)
+    assert torch.equal(i_s, i_f) and torch.equal(d_s, d_f)
+
+
 def test_knn_filter_small_and_overflow_and_range(cuda_device):
     from dance_amd import kernels
     rng = np.random.default_rng(9)
