@@ -157,10 +157,16 @@ __global__ __launch_bounds__(256) void knn_filter_kernel(int64_t nq, int64_t n, 
 
 // ---- d <= 64: fp16, "query-stationary", thresholds in two passes (design and error budget: head of this file) ----------
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#ifdef DH_KNN_ABL
+#define DH_KNN_ABL_V DH_KNN_ABL
+#else
+#define DH_KNN_ABL_V 0
+#endif
 
 constexpr int FOLD_G = 16;                     // pass 1 = every 16th row
 constexpr int64_t FOLD_TWO_PASS_MIN = 32768;   // below this one pass over everything
-constexpr int FOLD_NT = 2;                     // 128-row candidate tiles per LDS image (one barrier per image)
+constexpr int FOLD_NT = 4;                     // 128-row candidate tiles per LDS image (one barrier per image); tile ranges are aligned to it
+constexpr int fold_nt(int ks) { return ks >= 5 ? 2 : 4; }  // (K3 = 80: four tiles x two stages would not fit the 160 KB)
 constexpr float FOLD_MUL = 4096.f;             // the threshold terms ride as MUL * (t0 + t1 + t2), t_i fp16
 constexpr float FOLD_RQ_MAX = 67108864.f;      // 2^26 > any -2 q.c + Cn of scaled rows (<= 3 d 2^18): "everything passes"
 
@@ -326,10 +332,11 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
   // (g0, j0): residue class and in-class index of the first row of the candidate tile (row p of B2 = class p / n1, index
   // p % n1, candidate id = index * G + class); a tile crosses at most one class boundary (n1 >= 128 whenever G > 1)
   auto append = [&](int j, unsigned int g0, unsigned int j0, const unsigned int (&h)[2]) __attribute__((always_inline)) {
-#if defined(DH_KNN_ABL) && DH_KNN_ABL == 1
+#if defined(DH_KNN_ABL)  // ablation builds (timing only, results are garbage): 1 no appends, 2 + no barrier, 3 + no image traffic
     if (h[0] == 0xdeadbeefu && h[1] == 0x12345u) cnt[0] = 1;  // ablation build: keep h alive, never append
     return;
 #endif
+    if (__builtin_amdgcn_ballot_w64((h[0] | h[1]) != 0u) == 0ull) return;  // nothing in this wave: skip the id arithmetic too
     unsigned int jj = j0 + (unsigned int)(wc * 64 + j * 32 + lr), gg = g0;
     if (jj >= n1u) { jj -= n1u; gg += 1u; }
     const unsigned int id = jj * (unsigned int)G + gg;
@@ -353,18 +360,20 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
   // One half tile: all K steps of candidate sub-tile JM on the matrix cores while the vector ALUs take the pass bits of
   // sub-tile JT from the previous half: bit (15 - r) of h[i] = sign bit of acc[i][JT][r], one v_alignbit (h = h << 1 | sign)
   // per pair, a fixed number of pairs behind every MFMA.
-  auto half_tile = [&](auto jm_tag, const _Float16* b_frag, unsigned int (&h)[2], int64_t prefetch_tile) __attribute__((always_inline)) {
+  // The B fragments of a half tile are read from LDS during the MFMAs of the half before it (two register sets); only the
+  // first half of an image waits for its reads.
+  auto load_frags = [&](f16x8 (&dst)[KS], const _Float16* p) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) dst[kk] = *reinterpret_cast<const f16x8*>(p + kk * 16);
+  };
+  auto half_tile = [&](auto jm_tag, const f16x8 (&b)[KS], f16x8 (&b_next)[KS], const _Float16* next_frag, unsigned int (&h)[2],
+                       int64_t prefetch_tile) __attribute__((always_inline)) {
     constexpr int JM = decltype(jm_tag)::value, JT = 1 - JM;
     constexpr int PER = (32 + 2 * KS - 1) / (2 * KS);  // pairs behind each MFMA
-    constexpr int AHEAD = 4;  // fragment reads in flight ahead of their MFMAs
-    f16x8 b[KS];
-#pragma unroll
-    for (int kk = 0; kk < AHEAD && kk < KS; ++kk) b[kk] = *reinterpret_cast<const f16x8*>(b_frag + JM * 32 * LD + kk * 16);
     h[0] = h[1] = 0u;
 #pragma unroll
     for (int m = 0; m < 2 * KS; ++m) {
       const int kk = m >> 1, i = m & 1;
-      if (i == 0 && kk + AHEAD < KS) b[kk + AHEAD] = *reinterpret_cast<const f16x8*>(b_frag + JM * 32 * LD + (kk + AHEAD) * 16);
       if (kk == 0) {
         f32x16 z;
 #pragma unroll
@@ -373,13 +382,14 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
       } else {
         acc[i][JM] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][kk], b[kk], acc[i][JM], 0, 0, 0);
       }
+      if (m == 0 && next_frag) load_frags(b_next, next_frag);
 #pragma unroll
       for (int e = m * PER; e < (m + 1) * PER && e < 32; ++e)
         h[e >> 4] = __builtin_amdgcn_alignbit(h[e >> 4], __float_as_uint(acc[e >> 4][JT][e & 15]), 31u);
       __builtin_amdgcn_sched_barrier(0);
       // the next image's loads go out behind the FIRST MFMA of the image: the compiler drains vmcnt (the previous half's
       // append stores share the counter with loads) in front of this block, so this is the earliest point that keeps them in flight
-      if (JM == 0 && m == 0 && prefetch_tile >= 0) {
+      if (JM == 0 && m == 0 && prefetch_tile >= 0 && !(DH_KNN_ABL_V >= 3)) {
         load_image(prefetch_tile);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -396,25 +406,35 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][1][r] = 1.f;  // nothing passes in the first rotated half
   unsigned int g_cur = (unsigned int)((t_lo * BN) / n1), j_cur = (unsigned int)((t_lo * BN) % n1), g_prev = 0u, j_prev = 0u;
+  f16x8 bq[2][KS];
   int64_t t = t_lo;
   for (; t < t_hi; t += NT) {
+    const _Float16* img = lds_h + (size_t)cur * NT * BN * LD + (wc * 64 + lr) * LD + kh;  // + (sub * BN + JM * 32) * LD
+    load_frags(bq[0], img);
 #pragma unroll
     for (int sub = 0; sub < NT; ++sub) {
-      const _Float16* b_frag = lds_h + (size_t)cur * NT * BN * LD + (sub * BN + wc * 64 + lr) * LD + kh;
       // half A: matrix cores on sub-tile 0 of tile t + sub, vector ALUs on sub-tile 1 of the tile before it
       __builtin_amdgcn_sched_barrier(0);
-      half_tile(std::integral_constant<int, 0>{}, b_frag, h, (sub == 0 && t + NT < t_hi) ? t + NT : -1);
+      half_tile(std::integral_constant<int, 0>{}, bq[0], bq[1], img + (sub * BN + 32) * LD, h, (sub == 0 && t + NT < t_hi) ? t + NT : -1);
       append(1, g_prev, j_prev, h);
       // half B: matrix cores on sub-tile 1, vector ALUs on sub-tile 0 of the same tile
       __builtin_amdgcn_sched_barrier(0);
-      half_tile(std::integral_constant<int, 1>{}, b_frag, h, -1);
+      half_tile(std::integral_constant<int, 1>{}, bq[1], bq[0], sub + 1 < NT ? img + (sub + 1) * BN * LD : nullptr, h, -1);
       append(0, g_cur, j_cur, h);
       g_prev = g_cur; j_prev = j_cur;
       j_cur += BN;
       if (j_cur >= n1u) { j_cur -= n1u; g_cur += 1u; }
     }
+#if defined(DH_KNN_ABL) && DH_KNN_ABL >= 3
+    if (t_hi == -12345) store_image(cur ^ 1);
+#else
     if (t + NT < t_hi) store_image(cur ^ 1);
+#endif
+#if defined(DH_KNN_ABL) && DH_KNN_ABL >= 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     __syncthreads();  // everyone is done with `cur` and the next image is complete
+#endif
     cur ^= 1;
   }
   if (t_hi > t_lo) {  // the last half's pass bits
@@ -693,17 +713,17 @@ int knn_fold_launch(const KnnFoldGeom& g, int64_t n, int64_t d, const float* X, 
                      counts, g.n_seg1 + g.n_seg2);
   const int64_t qblocks = ceil_div(nq, 256);
   const int ks = g.K3 / 16;
-  const size_t lds = 2 * (size_t)FOLD_NT * BN * (g.K3 + 8) * sizeof(_Float16);
+  const size_t lds = 2 * (size_t)fold_nt(ks) * BN * (g.K3 + 8) * sizeof(_Float16);
   auto filter = [&](int n_seg, int seg, int64_t t_begin, int64_t t_end, int64_t tps, int32_t* cnt, int32_t* sv) -> int {
     if (n_seg <= 0) return DH_OK;
     dim3 grid((unsigned)qblocks, (unsigned)n_seg);
 #define DH_KNN_FS(KS)                                                                                                          \
   case KS: {                                                                                                                   \
-    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_fold_filter_kernel<KS, FOLD_NT>),             \
+    static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(knn_fold_filter_kernel<KS, fold_nt(KS)>),         \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,                                     \
-                                               (int)(2 * FOLD_NT * BN * (16 * KS + 8) * sizeof(_Float16))) == hipSuccess;      \
+                                               (int)(2 * fold_nt(KS) * BN * (16 * KS + 8) * sizeof(_Float16))) == hipSuccess;  \
     if (!ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");                        \
-    hipLaunchKernelGGL((knn_fold_filter_kernel<KS, FOLD_NT>), grid, dim3(512), lds, st, nq, n, g.G, g.n1,                      \
+    hipLaunchKernelGGL((knn_fold_filter_kernel<KS, fold_nt(KS)>), grid, dim3(512), lds, st, nq, n, g.G, g.n1,                  \
                        A2 + q_begin * g.K3, B2, cnt, sv, g.cap, seg, t_begin, t_end, tps);                                     \
   } break
     switch (ks) {
