@@ -321,7 +321,7 @@ Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
       L.scale = take(64);
       L.a2 = take((size_t)n * L.g.K3 * 2);
       L.b2 = take((size_t)L.g.n_pos * L.g.K3 * 2);
-      L.counts = take((size_t)nq * (L.g.n_seg1 + L.g.n_seg2) * sizeof(int32_t));
+      L.counts = take((size_t)nq * L.g.n_seg_total * sizeof(int32_t));
     } else {
       L.S = dh::knn_filter_sample_size(n);
       L.stride = n / L.S;

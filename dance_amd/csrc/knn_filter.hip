@@ -163,8 +163,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define DH_KNN_ABL_V 0
 #endif
 
-constexpr int FOLD_G = 16;                     // pass 1 = every 16th row
 constexpr int64_t FOLD_TWO_PASS_MIN = 32768;   // below this one pass over everything
+constexpr int64_t FOLD_THREE_PASS_MIN = 262144;
 constexpr int FOLD_NT = 4;                     // 128-row candidate tiles per LDS image (one barrier per image); tile ranges are aligned to it
 constexpr int fold_nt(int ks) { return ks >= 5 ? 2 : 4; }  // (K3 = 80: four tiles x two stages would not fit the 160 KB)
 constexpr float FOLD_MUL = 4096.f;             // the threshold terms ride as MUL * (t0 + t1 + t2), t_i fp16
@@ -178,6 +178,14 @@ __device__ __forceinline__ FoldScale fold_scale(unsigned int maxbits) {
   r.ok = e >= 127 - 60 && e <= 127 + 60;
   r.s = r.ok ? __uint_as_float((unsigned int)(127 + 8 - (e - 127)) << 23) : 1.f;
   return r;
+}
+
+// Rows are grouped by residue class c = r % G so that every pass reads contiguous tiles of B2: slot 0 = class 0 (pass 1), slots
+// 1 .. H - 1 = the other multiples of G / H (the middle pass, H > 1 only), then the rest; row p of B2 = slot p / n1, index p % n1,
+// candidate id = index * G + class(slot).  qmagic = ceil(2^16 / (G / H - 1)) divides the small slot numbers exactly (host-checked).
+__device__ __forceinline__ unsigned int fold_class_of_slot(unsigned int slot, unsigned int H, unsigned int GH, unsigned int qmagic) {
+  const unsigned int m = slot - H;
+  return slot < H ? slot * GH : m + ((m * qmagic) >> 16) + 1u;
 }
 
 // w ~ t0 + t1 + t2 in fp16 (|w| <= 2^14); residual <= 2^-33 |w|, or 2^-14 where a term falls below the normal range
@@ -199,19 +207,18 @@ __global__ __launch_bounds__(256) void knn_maxabs_kernel(int64_t n, int64_t d, c
   if (lane == 0) atomicMax(out, __float_as_uint(m));  // non-negative floats order like their bits
 }
 
-// One wavefront per row p < n_pad of B2: p = class * n1 + index holds candidate r = index * G + class (p < G n1, r < n), every
-// other row is zero (never passes).  y = s (x[r] - mu), norms[r] = |y|^2, A2[r] = [-2 yh | 0 0 0 (-Rq: thresholds kernel) |
-// M M M | 0], B2[p] = [yh | M M M | Cn split | 0].
+// One wavefront per row p < n_pad of B2 (slot p / n1, index p % n1; rows without a candidate are zero and never pass).
+// y = s (x[r] - mu), norms[r] = |y|^2, A2[r] = [-2 yh | 0 0 0 (-Rq: thresholds kernel) | M M M | 0], B2[p] = [yh | M M M | Cn split | 0].
 __global__ __launch_bounds__(256) void knn_fold_split_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
                                                              const float* __restrict__ mu, const unsigned int* __restrict__ maxabs,
-                                                             int dp, int K3, float eps, float abs_lin, int G, int64_t n1, int64_t n_pad,
-                                                             _Float16* __restrict__ A2, _Float16* __restrict__ B2,
-                                                             float* __restrict__ norms) {
+                                                             int dp, int K3, float eps, float abs_lin, int G, int H, unsigned int qmagic,
+                                                             int64_t n1, int64_t n_pad, _Float16* __restrict__ A2,
+                                                             _Float16* __restrict__ B2, float* __restrict__ norms) {
   const int lane = threadIdx.x & 63;
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= n_pad) return;
   _Float16* b = B2 + p * K3;
-  const int64_t r = p < (int64_t)G * n1 ? (p % n1) * G + p / n1 : n;
+  const int64_t r = p < (int64_t)G * n1 ? (p % n1) * G + fold_class_of_slot((unsigned int)(p / n1), H, G / H, qmagic) : n;
   if (r >= n) {
     for (int t = lane; t < K3; t += 64) b[t] = (_Float16)0.f;
     return;
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void knn_fold_thresholds_kernel(int64_t q_begi
 // History (profiles/): three-term bf16 form of this kernel, K3 = 176, v_cmp + v_addc per pair: 353 ms at 1M x 50, of which the
 // survivor appends (~960 per query) cost 81 ms; the tile loop sat at ~59 % matrix-pipe utilisation.
 template <int KS, int NT>  // 16-wide k steps: K3 = 16 KS; NT tiles per LDS image
-__global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_t n, int G, int64_t n1,
+__global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_t n, int G, int H, unsigned int qmagic, int64_t n1,
                                                               const _Float16* __restrict__ A2, const _Float16* __restrict__ B2,
                                                               int32_t* __restrict__ counts, int32_t* __restrict__ surv, int cap, int seg,
                                                               int64_t t_begin, int64_t t_end, int64_t tiles_per_slice) {
@@ -329,8 +336,8 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
   const unsigned int n1u = (unsigned int)n1;
   // Only lanes with a hit walk their set bits.  Both query sub-tiles advance together, so the two returning LDS atomics of a
   // round are in flight at the same time and the wave waits once per round, not once per hit.
-  // (g0, j0): residue class and in-class index of the first row of the candidate tile (row p of B2 = class p / n1, index
-  // p % n1, candidate id = index * G + class); a tile crosses at most one class boundary (n1 >= 128 whenever G > 1)
+  // (g0, j0): slot and in-class index of the first row of the candidate tile; a tile crosses at most one slot boundary
+  // (n1 >= 128 whenever G > 1)
   auto append = [&](int j, unsigned int g0, unsigned int j0, const unsigned int (&h)[2]) __attribute__((always_inline)) {
 #if defined(DH_KNN_ABL)  // ablation builds (timing only, results are garbage): 1 no appends, 2 + no barrier, 3 + no image traffic
     if (h[0] == 0xdeadbeefu && h[1] == 0x12345u) cnt[0] = 1;  // ablation build: keep h alive, never append
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
     if (__builtin_amdgcn_ballot_w64((h[0] | h[1]) != 0u) == 0ull) return;  // nothing in this wave: skip the id arithmetic too
     unsigned int jj = j0 + (unsigned int)(wc * 64 + j * 32 + lr), gg = g0;
     if (jj >= n1u) { jj -= n1u; gg += 1u; }
-    const unsigned int id = jj * (unsigned int)G + gg;
+    const unsigned int id = jj * (unsigned int)G + fold_class_of_slot(gg, (unsigned int)H, (unsigned int)(G / H), qmagic);
     const bool live = gg < (unsigned int)G && (int64_t)id < n;  // the zero rows behind the last candidate never pass anyway
     unsigned int mk0 = live ? h[0] : 0u, mk1 = live ? h[1] : 0u;
     while (mk0 | mk1) {
@@ -476,15 +483,15 @@ __device__ __forceinline__ float chain_d2(const float* __restrict__ xq, const fl
   return acc;
 }
 
-// Survivor list of query q: n_seg_a segments of seg_a slots followed by n_seg_b segments of seg_b slots (row stride cap);
-// counts[s * nq + q] entries of segment s are valid.  Segments [sg_lo, sg_hi) are processed; any of them over capacity: the
+// Survivor list of query q in this pass: n_seg segments of seg slots at surv + q * cap (the caller has added the pass's offset);
+// counts[s * nq + q] entries of segment s are valid.  Any segment over capacity: the
 // list is incomplete -> every candidate is re-scanned.  carry_in: the k keys (out_idx, raw d2 in out_dist) an earlier pass
 // left take part (equal keys collapse in the selection, so candidates seen twice are harmless).  raw_out: leave raw d2.
 template <bool VEC>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, const float* __restrict__ X, int64_t ldx,
                                                          int64_t q_begin, int64_t nq, int k, const int32_t* __restrict__ counts,
-                                                         const int32_t* __restrict__ surv, int cap, int n_seg_a, int seg_a, int seg_b,
-                                                         int sg_lo, int sg_hi, int carry_in, int raw_out,
+                                                         const int32_t* __restrict__ surv, int cap, int n_seg, int seg,
+                                                         int carry_in, int raw_out,
                                                          int32_t* __restrict__ out_idx, float* __restrict__ out_dist) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, c
   const unsigned long long kInf = ~0ull;
   const float* xq = X + (q_begin + q) * ldx;
   bool overflow = false;
-  for (int sg = sg_lo; sg < sg_hi; ++sg) overflow |= counts[(int64_t)sg * nq + q] > (sg < n_seg_a ? seg_a : seg_b);
+  for (int sg = 0; sg < n_seg; ++sg) overflow |= counts[(int64_t)sg * nq + q] > seg;
   int carried = 0;
   if (carry_in) {
     const bool have = lane < k && out_idx[q * k + lane] >= 0;  // a valid prefix (ascending keys, then -1 entries)
@@ -503,9 +510,9 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(int64_t n, int64_t d, c
     carried = __popcll(__ballot(have));
     __builtin_amdgcn_wave_barrier();
   }
-  for (int sg = sg_lo; sg < (overflow ? sg_lo + 1 : sg_hi); ++sg) {
+  for (int sg = 0; sg < (overflow ? 1 : n_seg); ++sg) {
   const int64_t total = overflow ? n : counts[(int64_t)sg * nq + q];
-  const int32_t* mine = surv + q * cap + (sg < n_seg_a ? (int64_t)sg * seg_a : (int64_t)n_seg_a * seg_a + (int64_t)(sg - n_seg_a) * seg_b);
+  const int32_t* mine = surv + q * cap + (int64_t)sg * seg;
   for (int64_t base = 0; base < total; base += RR_CHUNK) {
     const int m = (int)min((int64_t)RR_CHUNK, total - base);
     for (int i = lane; i < m; i += 64) {
@@ -613,16 +620,16 @@ static void colmeans(int64_t n, int64_t d, const float* X, int64_t ldx, float* m
 }
 
 static void rerank_launch(int64_t n, const float* Xr, int64_t ldr, int64_t dr, int64_t q_begin, int64_t nq, int k, const int32_t* counts,
-                          const int32_t* surv, int cap, int n_seg_a, int seg_a, int seg_b, int sg_lo, int sg_hi, int carry_in, int raw_out,
+                          const int32_t* surv, int cap, int n_seg, int seg, int carry_in, int raw_out,
                           int32_t* out_idx, float* out_dist, hipStream_t st) {
   const size_t lds = 4 * (size_t)(RR_CHUNK + 64) * sizeof(unsigned long long);
   const bool vec = dr % 4 == 0 && ldr % 4 == 0 && aligned16(Xr);
   if (vec)
     hipLaunchKernelGGL(knn_rerank_kernel<true>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
-                       surv, cap, n_seg_a, seg_a, seg_b, sg_lo, sg_hi, carry_in, raw_out, out_idx, out_dist);
+                       surv, cap, n_seg, seg, carry_in, raw_out, out_idx, out_dist);
   else
     hipLaunchKernelGGL(knn_rerank_kernel<false>, dim3((unsigned)ceil_div(nq, 4)), dim3(256), lds, st, n, dr, Xr, ldr, q_begin, nq, k, counts,
-                       surv, cap, n_seg_a, seg_a, seg_b, sg_lo, sg_hi, carry_in, raw_out, out_idx, out_dist);
+                       surv, cap, n_seg, seg, carry_in, raw_out, out_idx, out_dist);
 }
 
 // Steps 2 and 3 for d > 64 (the sample pass has already left the raw k-th sample distances in sample_d2 [nq][k]).
@@ -647,7 +654,7 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
   if (!tile_ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");
   hipLaunchKernelGGL(knn_filter_kernel, dim3((unsigned)tiles), dim3(256), kTileLds, st, nq, n, K3, A2 + q_begin * K3, B2, Rq, Cn, counts,
                      surv, cap);
-  rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, cap, 1, cap, 0, 0, 1, 0, 0, out_idx, out_dist, st);
+  rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, cap, 1, cap, 0, 0, out_idx, out_dist, st);
   return check_launch("dh_knn_bruteforce_f32(filter)");
 }
 
@@ -658,11 +665,22 @@ KnnFoldGeom knn_fold_geom(int64_t n, int64_t d, int64_t nq, int k) {
   KnnFoldGeom g{};
   g.dp = knn_filter_padded_d(d);
   g.K3 = (g.dp + 6 + 15) / 16 * 16;
-  g.G = n >= FOLD_TWO_PASS_MIN ? FOLD_G : 1;
+  // thresholds in up to three passes: every 64th row, then the other multiples of 8, then the rest (n >= 2^18); every 16th
+  // row, then the rest (n >= 2^15); else one pass
+  int64_t sample_target;
+  if (n >= FOLD_THREE_PASS_MIN) { g.G = 64; g.H = 8; g.n_pass = 3; sample_target = 2048; }
+  else if (n >= FOLD_TWO_PASS_MIN) { g.G = 16; g.H = 1; g.n_pass = 2; sample_target = 4096; }
+  else { g.G = 1; g.H = 1; g.n_pass = 1; sample_target = 0; }
+  {  // exact division of the slot numbers by G / H - 1 through a 16-bit reciprocal (checked here once)
+    const unsigned int q = (unsigned int)(g.G / g.H) > 1u ? (unsigned int)(g.G / g.H) - 1u : 1u;
+    g.qmagic = (65536u + q - 1u) / q;
+    for (unsigned int m = 0; m < (unsigned int)g.G; ++m)
+      if (((m * g.qmagic) >> 16) != m / q) { g.qmagic = 0; break; }  // (never: G <= 64)
+  }
   g.n1 = ceil_div(n, g.G);
   g.n_pos = ceil_div(g.G * g.n1, (int64_t)FOLD_NT * BN) * FOLD_NT * BN;  // zero rows up to whole LDS images
-  if (g.G > 1) {  // ~4096 sample rows, every one of them in pass 1 (stride a multiple of G)
-    int64_t m = (n + (int64_t)g.G * 2048) / ((int64_t)g.G * 4096);
+  if (g.G > 1) {  // every sample row lies in pass 1 (stride a multiple of G)
+    int64_t m = (n + g.G * sample_target / 2) / (g.G * sample_target);
     if (m < 1) m = 1;
     g.stride0 = g.G * m;
     g.S = ceil_div(n, g.stride0);
@@ -671,28 +689,40 @@ KnnFoldGeom knn_fold_geom(int64_t n, int64_t d, int64_t nq, int k) {
     g.stride0 = n / g.S;
   }
   g.tiles = ceil_div(g.n_pos, BN);
-  g.t1 = g.G > 1 ? ceil_div(ceil_div(g.n1, BN), FOLD_NT) * FOLD_NT : g.tiles;
-  if (g.t1 > g.tiles) g.t1 = g.tiles;
+  auto tiles_of = [&](int64_t rows) {
+    int64_t t = ceil_div(ceil_div(rows, BN), FOLD_NT) * FOLD_NT;
+    return t > g.tiles ? g.tiles : t;
+  };
+  int64_t bound[4] = {0, g.tiles, g.tiles, g.tiles};
+  if (g.n_pass >= 2) bound[1] = tiles_of(g.n1);
+  if (g.n_pass == 3) bound[2] = tiles_of(g.H * g.n1);
   // candidate slices (grid.y) until >= 2 rounds of blocks exist; each slice owns a segment of every survivor list, at least
   // 1024 slots deep so that a query whose neighbours all sit in one slice does not overflow
   const int64_t qblocks = ceil_div(nq, 256);
   const int64_t slices = qblocks >= 512 ? 1 : ceil_div(512, qblocks);
-  auto plan = [&](int64_t T, int64_t want, int64_t* tps, int* n_seg, int* seg) {
-    if (T <= 0) { *tps = FOLD_NT; *n_seg = 0; *seg = 0; return; }
+  g.cap = 0;
+  for (int ps = 0; ps < g.n_pass; ++ps) {
+    g.t_begin[ps] = bound[ps];
+    g.t_end[ps] = bound[ps + 1];
+    const int64_t T = g.t_end[ps] - g.t_begin[ps];
+    // expected survivors: pass 1 ~ k (its rows) / S, 4x that; later passes: the threshold is the exact k-th distance among the
+    // fraction f of the rows seen so far -> ~ k / f candidates in all, 8x that (the fp16 margin inflates these lists first)
+    int64_t want;
+    if (ps == 0) want = 4 * (int64_t)k * ceil_div(T * BN, g.S);
+    else if (ps == 1 && g.n_pass == 3) want = 8 * (int64_t)k * g.H;
+    else want = 8 * (int64_t)k * (g.G / g.H);
+    if (T <= 0) { g.tps[ps] = FOLD_NT; g.n_seg[ps] = 0; g.seg[ps] = 0; continue; }
     int64_t sl = slices;
     if (sl > ceil_div(T, FOLD_NT)) sl = ceil_div(T, FOLD_NT);
-    *tps = ceil_div(ceil_div(T, sl), FOLD_NT) * FOLD_NT;
-    *n_seg = (int)ceil_div(T, *tps);
+    g.tps[ps] = ceil_div(ceil_div(T, sl), FOLD_NT) * FOLD_NT;
+    g.n_seg[ps] = (int)ceil_div(T, g.tps[ps]);
     const int cap = pow2_at_least(want, 256, 1 << 16);
-    int sg = cap / *n_seg;
-    if (*n_seg > 1 && sg < 1024) sg = cap < 1024 ? cap : 1024;
-    *seg = sg;
-  };
-  // pass 1: ~ k (rows of pass 1) / S survivors, 4x that; pass 2: tau1 is the exact k-th of n / G rows -> ~ k G, 8x that (the
-  // coarser fp16 margin inflates this list first)
-  plan(g.t1, 4 * (int64_t)k * ceil_div(g.t1 * BN, g.S), &g.tps1, &g.n_seg1, &g.seg1);
-  plan(g.tiles - g.t1, 8 * (int64_t)k * g.G, &g.tps2, &g.n_seg2, &g.seg2);
-  g.cap = g.n_seg1 * g.seg1 + g.n_seg2 * g.seg2;
+    int sg = cap / g.n_seg[ps];
+    if (g.n_seg[ps] > 1 && sg < 1024) sg = cap < 1024 ? cap : 1024;
+    g.seg[ps] = sg;
+    g.cap += g.n_seg[ps] * sg;
+  }
+  g.n_seg_total = g.n_seg[0] + g.n_seg[1] + g.n_seg[2];
   return g;
 }
 
@@ -701,16 +731,15 @@ int knn_fold_launch(const KnnFoldGeom& g, int64_t n, int64_t d, const float* X, 
                     int32_t* counts, int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st) {
   _Float16* A2 = static_cast<_Float16*>(A2v);
   _Float16* B2 = static_cast<_Float16*>(B2v);
+  if (g.qmagic == 0) return fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: slot reciprocal");
   const float eps = 9.765625e-4f + 1.220703125e-4f + (float)g.dp * 9.5367431640625e-7f;  // 2^-10 + 2^-13 + dp 2^-20
   const float abs_lin = 1.01f * 1.220703125e-4f * sqrtf((float)g.dp);                    // 1.01 * 2^-13 sqrt(dp)
   colmeans(n, d, X, ldx, mean_ws, st);
   if (hipMemsetAsync(maxabs, 0, sizeof(unsigned int), st) != hipSuccess) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: memset failed");
   hipLaunchKernelGGL(knn_maxabs_kernel, dim3((unsigned)(n < 4096 ? ceil_div(n, 4) : 1024)), dim3(256), 0, st, n, d, X, ldx, mean_ws, maxabs);
   hipLaunchKernelGGL(knn_fold_split_kernel, dim3((unsigned)ceil_div(g.n_pos, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, maxabs, g.dp, g.K3,
-                     eps, abs_lin, g.G, g.n1, g.n_pos, A2, B2, norms);
+                     eps, abs_lin, g.G, g.H, g.qmagic, g.n1, g.n_pos, A2, B2, norms);
   const dim3 tgrid((unsigned)ceil_div(nq, 256));
-  hipLaunchKernelGGL(knn_fold_thresholds_kernel, tgrid, dim3(256), 0, st, q_begin, nq, k, eps, abs_lin, maxabs, norms, out_dist, g.dp, g.K3, A2,
-                     counts, g.n_seg1 + g.n_seg2);
   const int64_t qblocks = ceil_div(nq, 256);
   const int ks = g.K3 / 16;
   const size_t lds = 2 * (size_t)fold_nt(ks) * BN * (g.K3 + 8) * sizeof(_Float16);
@@ -723,7 +752,7 @@ int knn_fold_launch(const KnnFoldGeom& g, int64_t n, int64_t d, const float* X, 
                                                hipFuncAttributeMaxDynamicSharedMemorySize,                                     \
                                                (int)(2 * fold_nt(KS) * BN * (16 * KS + 8) * sizeof(_Float16))) == hipSuccess;  \
     if (!ok) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: cannot raise the dynamic LDS limit");                        \
-    hipLaunchKernelGGL((knn_fold_filter_kernel<KS, fold_nt(KS)>), grid, dim3(512), lds, st, nq, n, g.G, g.n1,                  \
+    hipLaunchKernelGGL((knn_fold_filter_kernel<KS, fold_nt(KS)>), grid, dim3(512), lds, st, nq, n, g.G, g.H, g.qmagic, g.n1,   \
                        A2 + q_begin * g.K3, B2, cnt, sv, g.cap, seg, t_begin, t_end, tps);                                     \
   } break
     switch (ks) {
@@ -733,19 +762,22 @@ int knn_fold_launch(const KnnFoldGeom& g, int64_t n, int64_t d, const float* X, 
 #undef DH_KNN_FS
     return DH_OK;
   };
-  int rc = filter(g.n_seg1, g.seg1, 0, g.t1, g.tps1, counts, surv);
-  if (rc != DH_OK) return rc;
-  if (g.n_seg2 > 0) {
-    // exact k smallest among pass 1's survivors -> tau1 (raw d2 in out_dist) -> thresholds of pass 2
-    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, g.cap, g.n_seg1, g.seg1, g.seg2, 0, g.n_seg1, 0, 1, out_idx, out_dist, st);
-    hipLaunchKernelGGL(knn_fold_thresholds_kernel, tgrid, dim3(256), 0, st, q_begin, nq, k, eps, abs_lin, maxabs, norms, out_dist, g.dp, g.K3,
-                       A2, counts, 0);
-    rc = filter(g.n_seg2, g.seg2, g.t1, g.tiles, g.tps2, counts + (int64_t)g.n_seg1 * nq, surv + (int64_t)g.n_seg1 * g.seg1);
+  // per pass: thresholds from the k-th distance so far (out_dist, raw d2) -> filter over the pass's tiles -> exact k smallest of
+  // its survivors merged into the keys the passes before left (out_idx / out_dist; raw d2 until the last pass)
+  int64_t seg_base = 0, slot_base = 0;
+  for (int ps = 0; ps < g.n_pass; ++ps) {
+    if (g.n_seg[ps] <= 0) continue;
+    hipLaunchKernelGGL(knn_fold_thresholds_kernel, tgrid, dim3(256), 0, st, q_begin, nq, k, eps, abs_lin, maxabs, norms, out_dist, g.dp, g.K3, A2,
+                       counts, ps == 0 ? g.n_seg_total : 0);
+    int32_t* cnt = counts + seg_base * nq;
+    int32_t* sv = surv + slot_base;
+    const int rc = filter(g.n_seg[ps], g.seg[ps], g.t_begin[ps], g.t_end[ps], g.tps[ps], cnt, sv);
     if (rc != DH_OK) return rc;
-    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, g.cap, g.n_seg1, g.seg1, g.seg2, g.n_seg1, g.n_seg1 + g.n_seg2, 1, 0, out_idx,
-                  out_dist, st);
-  } else {
-    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, counts, surv, g.cap, g.n_seg1, g.seg1, g.seg2, 0, g.n_seg1, 0, 0, out_idx, out_dist, st);
+    bool last = true;
+    for (int nx = ps + 1; nx < g.n_pass; ++nx) last = last && g.n_seg[nx] <= 0;
+    rerank_launch(n, Xr, ldr, dr, q_begin, nq, k, cnt, sv, g.cap, g.n_seg[ps], g.seg[ps], ps > 0 ? 1 : 0, last ? 0 : 1, out_idx, out_dist, st);
+    seg_base += g.n_seg[ps];
+    slot_base += (int64_t)g.n_seg[ps] * g.seg[ps];
   }
   return check_launch("dh_knn_bruteforce_f32(filter)");
 }

@@ -7,13 +7,15 @@ namespace dh {
 struct KnnFoldGeom {
   int dp;              // features padded to a multiple of 8
   int K3;              // fp16 columns of an operand row: dp features + 6 threshold columns, whole 16-wide MFMA steps
-  int G;               // pass 1 covers the rows r with r % G == 0 (G == 1: one pass over everything)
-  int64_t n1, n_pos;   // rows per residue class (ceil(n / G)); operand rows of B (G * n1 rounded up to whole LDS images; rows without a candidate are zero)
+  int G, H;            // rows grouped by r % G; the first H slots hold the classes that are multiples of G / H (knn_filter.hip)
+  unsigned int qmagic; // ceil(2^16 / (G / H - 1))
+  int n_pass;          // 1: everything; 2: every 16th row, the rest; 3: every 64th row, the other multiples of 8, the rest
+  int64_t n1, n_pos;   // rows per residue class (ceil(n / G)); rows of B (G * n1 rounded up to whole LDS images; rows without a candidate are zero)
   int64_t S, stride0;  // the strided sample that gives the first thresholds: rows j * stride0, j < S (a subset of pass 1)
-  int64_t tiles, t1;   // 128-row candidate tiles of B: pass 1 = [0, t1), pass 2 = [t1, tiles)
-  int64_t tps1, tps2;  // tiles per candidate slice (grid.y) of each pass
-  int n_seg1, seg1;    // survivor list of a query: n_seg1 segments of seg1 slots (pass 1, one per slice) ...
-  int n_seg2, seg2;    // ... followed by n_seg2 segments of seg2 slots (pass 2)
+  int64_t tiles;       // 128-row candidate tiles of B
+  int64_t t_begin[3], t_end[3], tps[3];  // tile range of each pass; tiles per candidate slice (grid.y)
+  int n_seg[3], seg[3];                  // survivor list of a query: per pass n_seg segments (one per slice) of seg slots, passes in order
+  int n_seg_total;
   int cap;             // slots per query
 };
 

@@ -123,9 +123,10 @@ def test_knn_filter_equals_scan(cuda_device, n, d, k, kind):
 
 
 @pytest.mark.parametrize("case", ["range", "odd_n", "tiny_scale", "huge_scale", "out_of_range_scale", "centroid_duplicates",
-                                  "one_slice", "spread_clusters", "d64"])
+                                  "one_slice", "spread_clusters", "d64", "three_pass", "three_pass_range", "three_pass_clusters"])
 def test_knn_two_pass_filter_equals_scan(cuda_device, case):
-    """d <= 64, n >= 32768: fp16 filter with thresholds in two passes (rows 0 mod 16 first) — same bits as the scan."""
+    """d <= 64, n >= 32768: fp16 filter with thresholds in two passes (rows 0 mod 16 first), three from n = 262144 (rows
+    0 mod 64, then the other multiples of 8, then the rest) — same bits as the scan."""
     rng = np.random.default_rng(len(case))
     n, d, k, q = 40_000, 50, 15, None
     if case == "range":
@@ -144,8 +145,14 @@ def test_knn_two_pass_filter_equals_scan(cuda_device, case):
         n, k = 140_000, 5; x = rng.standard_normal((n, 8))
     elif case == "spread_clusters":      # between-cluster spread 30x the within-cluster one: the fp16 margin is relative to the norms
         x = rng.standard_normal((n, d)) + rng.standard_normal((40, d))[rng.integers(0, 40, size=n)] * 30.0
-    else:
+    elif case == "d64":
         n, d = 34_000, 64; x = rng.standard_normal((n, d))
+    elif case == "three_pass":
+        n, k = 270_011, 10; x = rng.standard_normal((n, 12))
+    elif case == "three_pass_range":     # few query blocks: every pass sliced over the candidates
+        n, k = 263_000, 7; x = rng.standard_normal((n, 6)); q = (100_000, 101_000)
+    else:                                # ordered by cluster: the strided passes still see every cluster
+        n, k = 300_000, 15; x = rng.standard_normal((n, 16)) + np.repeat(rng.standard_normal((30, 16)) * 8.0, n // 30, axis=0)
     (i_s, d_s), (i_f, d_f) = _knn_both(x.astype(np.float32), k, cuda_device, q=q)
     assert torch.equal(i_s, i_f) and torch.equal(d_s, d_f)
 
