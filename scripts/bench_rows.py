@@ -72,10 +72,11 @@ def main():
         with kernels.KernelTimer() as tm:
             ms_f = gpu_ms(lambda: kernels.knn(x, k, algo=kernels.KNN_FILTER), iters=2, warm=1)
         dp = (d + 7) // 8 * 8
-        k3 = (3 * dp + 15) // 16 * 16
-        flops = 2.0 * n * n * k3  # bf16x3 filter GEMM (hi.hi + hi.lo + lo.hi)
+        # d <= 64: one fp16 term + 6 threshold columns; d > 64: three bf16 terms (hi.hi + hi.lo + lo.hi)
+        k3 = (dp + 6 + 15) // 16 * 16 if d <= 64 else (3 * dp + 15) // 16 * 16
+        flops = 2.0 * n * n * k3
         rows[f"knn_bruteforce_f32 [filter] n={n} d={d} k={k}"] = dict(
-            ms=ms_f, speedup_vs_scan=ms / ms_f, bound="mfma", achieved=flops / ms_f / 1e9, peak=2500.0, unit="TFLOP/s (bf16 filter flops over the whole call)",
+            ms=ms_f, speedup_vs_scan=ms / ms_f, bound="mfma", achieved=flops / ms_f / 1e9, peak=2500.0, unit="TFLOP/s (fp16 / bf16 filter flops over the whole call)",
             frac=flops / ms_f / 1e9 / 2500.0, cells_per_s=n / ms_f * 1e3, gpu_pairs_per_s=n * n / ms_f * 1e3, cpu_baseline=cpu,
             note="sample scan + split + filter + re-rank; identical output to [scan] (tests/test_gpu_graphs.py)")
         if n == 1_000_000 or q:
