@@ -50,6 +50,7 @@ def _declare(lib):
         "dh_rank_rows_f32": (c_int, [i64, i64, P, i64, P, i64, P]),
         "dh_knn_bruteforce_f32_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
         "dh_knn_bruteforce_f32": (c_int, [i64, i64, P, i64, i64, i64, i32, i32, P, P, P, c_size_t, P]),
+        "dh_knn_filter_plan": (c_int, [i64, i64, i64, i32, P, i32]),
         "dh_umap_membership_f32": (c_int, [i64, i32, P, P, P, P, P, P, c_size_t, P]),
         "dh_knn_row_nnz": (c_int, [i64, i32, P, P, P, P]),
         "dh_knn_graph_to_csr": (c_int, [i64, i32, P, P, P, P, P, P]),

@@ -385,6 +385,23 @@ extern "C" size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, in
   return make_layout(n, d, n_queries, k, algo).total;
 }
 
+extern "C" int dh_knn_filter_plan(int64_t n, int64_t d, int64_t n_queries, int k, int64_t* out, int n_out) {
+  constexpr int kFields = 26;
+  if (!out || n_out <= 0 || n <= 0 || n_queries <= 0 || k <= 0) return kFields;
+  int64_t f[kFields] = {0};
+  if (dh::knn_fold_applies(d)) {
+    const dh::KnnFoldGeom g = dh::knn_fold_geom(n, d, n_queries, k);
+    f[0] = g.n_pass; f[1] = g.G; f[2] = g.H; f[3] = g.qmagic; f[4] = g.n1; f[5] = g.n_pos; f[6] = g.S; f[7] = g.stride0;
+    f[8] = g.K3; f[9] = g.cap; f[10] = g.tiles;
+    for (int p = 0; p < 3; ++p) {
+      f[11 + 5 * p] = g.t_begin[p]; f[12 + 5 * p] = g.t_end[p]; f[13 + 5 * p] = g.tps[p];
+      f[14 + 5 * p] = g.n_seg[p]; f[15 + 5 * p] = g.seg[p];
+    }
+  }
+  for (int i = 0; i < kFields && i < n_out; ++i) out[i] = f[i];
+  return kFields;
+}
+
 extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t ldx, int64_t q_begin,
                                      int64_t q_end, int k, int algo, int32_t* out_idx, float* out_dist, void* workspace,
                                      size_t workspace_bytes, dh_stream_t stream) {

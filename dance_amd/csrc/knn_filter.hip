@@ -714,7 +714,8 @@ KnnFoldGeom knn_fold_geom(int64_t n, int64_t d, int64_t nq, int k) {
     if (T <= 0) { g.tps[ps] = FOLD_NT; g.n_seg[ps] = 0; g.seg[ps] = 0; continue; }
     int64_t sl = slices;
     if (sl > ceil_div(T, FOLD_NT)) sl = ceil_div(T, FOLD_NT);
-    g.tps[ps] = ceil_div(ceil_div(T, sl), FOLD_NT) * FOLD_NT;
+    g.tps[ps] = (T / sl) / FOLD_NT * FOLD_NT;  // rounded DOWN to whole images: at least as many slices as asked for
+    if (g.tps[ps] < FOLD_NT) g.tps[ps] = FOLD_NT;
     g.n_seg[ps] = (int)ceil_div(T, g.tps[ps]);
     const int cap = pow2_at_least(want, 256, 1 << 16);
     int sg = cap / g.n_seg[ps];

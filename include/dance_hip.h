@@ -203,9 +203,11 @@ DH_API int dh_rank_rows_f32(int64_t n, int64_t d, const float* X, int64_t ldx, f
  * Two evaluation strategies with IDENTICAL results (the neighbours are defined by the sequential fp32 distance
  * chain and the (d2, index) order; both return exactly those):
  *   DH_KNN_SCAN   — every (query, candidate) pair through the chain on the vector ALUs (knn.hip);
- *   DH_KNN_FILTER — an upper bound of each query's k-th distance from a strided sample, a bf16x3 matrix-core pass
- *                   that discards every pair provably beyond it, and the chain on the survivors only
- *                   (knn_filter.hip; k <= 64, finite inputs);
+ *   DH_KNN_FILTER — an upper bound of each query's k-th distance from a strided sample, a matrix-core pass that
+ *                   discards every pair provably beyond it (d <= 64: one fp16 term on centred, power-of-two scaled
+ *                   rows, the bound tightened in up to three passes over strided subsets of the candidates;
+ *                   d > 64: three bf16 terms), and the chain on the survivors only (knn_filter.hip; k <= 64,
+ *                   finite inputs);
  *   DH_KNN_AUTO   — FILTER for n >= 16384 candidates, >= 1024 queries and k <= 64, SCAN otherwise.
  * Workspace (64-byte aligned) from dh_knn_bruteforce_f32_workspace_bytes with the same algo.                     */
 DH_API size_t dh_knn_bruteforce_f32_workspace_bytes(int64_t n, int64_t d, int64_t n_queries, int k, int algo);
@@ -213,6 +215,12 @@ DH_API int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64_t l
                           int64_t q_begin, int64_t q_end, int k, int algo,
                           int32_t* out_idx, float* out_dist,
                           void* workspace, size_t workspace_bytes, dh_stream_t stream);
+/* Host only (no device): the plan DH_KNN_FILTER follows for d <= 64, for tests and capacity planning — same call site as
+ * above (neighbor_graph.py:52).  out[0..n_out): 0 passes (0: d > 64, the tile kernel), 1 G (rows grouped by r % G), 2 H (the
+ * first H slots hold the classes that are multiples of G / H), 3 slot reciprocal, 4 rows per class, 5 rows of the candidate
+ * operand, 6 sample rows, 7 sample stride, 8 operand columns, 9 survivor slots per query, 10 candidate tiles, then per pass
+ * p < 3 at 11 + 5 p: first tile, end tile, tiles per slice, segments, slots per segment.  Returns the number of fields (26). */
+DH_API int dh_knn_filter_plan(int64_t n, int64_t d, int64_t n_queries, int k, int64_t* out, int n_out);
 
 /* ---- K8: UMAP fuzzy-simplicial-set connectivities on a kNN list ------------------------------
  * What sc.pp.neighbors(method="umap") computes after its kNN search (neighbor_graph.py:52-55;
