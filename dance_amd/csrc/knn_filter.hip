@@ -8,25 +8,30 @@
 //               k-th distance over all candidates can only be smaller, so every true neighbour c has d2(q,c) <= tau_q.
 //   2. filter = for all pairs, d2~(q,c) = |q|^2 + |c|^2 - 2 q.c on v_mfma_f32_32x32x16_bf16, with every fp32 feature
 //               split into two bf16 terms (x = hi + lo + r, |r| <= 2^-16 |x|) and q.c ~ hi.hi + hi.lo + lo.hi (one GEMM
-//               with K = 3 d).  |d2~ - d2| <= eps (|q|^2 + |c|^2) with eps = 2^-13 + d 2^-20 (derivation below), so the
-//               pairs with d2~ <= tau_q + eps (|q|^2 + |c|^2) are a superset of the true neighbours; they are appended
+//               with K = 3 d).  |d2~ - d2| <= eps (|q|^2 + |c|^2) with eps = 2^-14 + d 2^-22 (derivation below), so the
+//               pairs with d2~ <= tau_q (1 + (d + 16) u) + eps (|q|^2 + |c|^2) are a superset of the true neighbours; they are appended
 //               to a per-query survivor list (~ k n / S entries).
 //   3. rerank = the exact chain on the survivors only, k smallest (d2, index) per query — the same keys, hence the same
 //               bits, as the full scan.  A query whose list overflowed re-scans all candidates inside the same kernel.
 //
-// Error budget of step 2 (u = 2^-24; all worst case, no statistics):
-//   representation: dropped lo.lo and r terms            <= 3.1 * 2^-16 sum|q_i c_i|
-//   MFMA accumulation over 3d bf16 products (exact each) <= 3d u (1 + 2^-7) sum|q_i c_i|
-//   fp32 norms, the final subtraction/addition            <= (d + 6) u (|q|^2 + |c|^2)
-//   the chain itself vs the real d2                       <= 2 (d + 2) u (|q|^2 + |c|^2)
-// with sum|q_i c_i| <= (|q|^2 + |c|^2) / 2 and the factor 2 in front of the dot product:
-//   |d2~ - d2_chain| <= (|q|^2 + |c|^2) (3.1 * 2^-16 + (6d + 10) u)  <  (|q|^2 + |c|^2) (2^-13 + d 2^-20) / 2.
+// Error budget of step 2, three-term form (d > 64; u = 2^-24; all worst case, no statistics), N = |q|^2 + |c|^2 of the centred rows:
+//   representation: dropped lo.lo and r terms                     <= 3.1 * 2^-16 sum|q_i c_i|
+//   MFMA accumulation over 3d bf16 products (exact each)          <= 3d u (1 + 2^-7)^2 sum|q_i c_i|
+//   norms (accumulated in double, one rounding), Cn, the final fma <= 8 u N
+//   centring x' = fl(x - mu) moves d2 by                          <= 4 u N
+// with sum|q_i c_i| <= N / 2 and the factor 2 in front of the dot product:
+//   |d2~ - d2'| <= N (3.1 * 2^-16 + (3.06 d + 12) u)  <  N (2^-14 + d 2^-22) = eps N       (d 2^-22 = 4 d u)
+// and the chain itself (the DEFINITION of the distance) differs from the real d2 only relative to d2, not to the norms:
+//   d2 <= chain (1 + (d + 2) u (1 + u)^d),  so a true neighbour (chain <= tau) has  d2' <= tau (1 + (d + 16) u) + 4 u N.
+// Round 4 tightened this: the old form charged the chain and an fp32 norm sum against the NORMS (eps = 2^-13 + d 2^-20, 2e-3
+// at d = 2000) — on clustered 2000-d rows (N = 17x the neighbour distances) that slack alone was two standard deviations of the
+// within-cluster distance distribution and every survivor list overflowed (23 s of re-scans at 100k x 2000 instead of 0.4 s).
 // The margin scales with the NORMS, so the filter works on CENTRED copies x' = fl(x - mu), mu = column means: distances
 // are translation invariant (any mu is admissible — its rounding only costs efficiency), the subtraction's own rounding
 // moves d2 by <= 2 |x-y| u (|x'| + |y'|) <= 4 u (|x'|^2 + |y'|^2), well inside the slack above, and embeddings with a
 // large common offset (or non-negative expression rows) no longer inflate the survivor lists.  Inputs must be finite.
 //
-// d <= 64 (what NeighborGraph feeds: PCA embeddings): ONE fp16 term instead of three bf16 terms, thresholds in two passes.
+// d <= 64 (what NeighborGraph feeds: PCA embeddings): ONE fp16 term instead of three bf16 terms, thresholds in up to three passes.
 //   * The centred data are scaled by a power of two (exact) so that max |y| lies in [2^8, 2^9) and every row becomes ONE
 //     fp16 vector yh (11 significant bits, |yh - y| <= 2^-11 |y|, or <= 2^-14 absolute below fp16's normal range — the
 //     bound does not rely on subnormal support).  With sum |q_i c_i| <= (|q|^2 + |c|^2) / 2 and the factor 2 of the dot product:
@@ -38,12 +43,13 @@
 //   * The whole test rides the matrix cores: A row = [-2 yh | -Rq split in 3 | M M M | 0], B row = [yh | M M M | Cn split in
 //     3 | 0] (M = 2^12), Cn = (1 - eps) |c|^2 - A |c|, Rq = tau - (1 - eps) |q|^2 + A |q| + 1, so the accumulator is
 //     -2 q.c + Cn - Rq and a pair survives iff its SIGN BIT is set: one v_alignbit per pair collects the bits.
-//   * Thresholds in two passes (n >= 32768): tau0 from a strided sample of ~4096 rows (exact scan), then the filter over the
-//     rows r = 0 mod 16 (which contain the sample), an exact re-rank of those survivors -> tau1 = the exact k-th distance
-//     among n / 16 candidates, then the filter over the other 15/16 with tau1: ~16 k survivors per query instead of
-//     k n / S (960 at n = 1M), and a 4x smaller sample scan.  B rows are stored grouped by r mod 16 so that each pass reads
-//     contiguous tiles; the final re-rank merges pass 2's survivors into the k keys pass 1 left (equal keys collapse, so a
-//     query that had to re-scan everything in pass 1 stays exact).
+//   * Thresholds in passes over strided subsets of the candidates.  n >= 32768: tau0 from a strided sample of ~4096 rows (exact
+//     scan), then the filter over the rows r = 0 mod 16 (which contain the sample), an exact re-rank of those survivors ->
+//     tau1 = the exact k-th distance among n / 16 candidates, then the filter over the other 15/16 with tau1: ~16 k survivors
+//     per query instead of k n / S (960 at n = 1M), and a 4x smaller sample scan.  n >= 262144: three passes — r = 0 mod 64
+//     (sample ~2048 rows), the other multiples of 8, the rest: ~281 survivors per query at 1M.  B rows are stored grouped by
+//     residue class so that each pass reads contiguous tiles; each re-rank merges its pass's survivors into the k keys the
+//     passes before left (equal keys collapse, so a query that had to re-scan everything in an early pass stays exact).
 //   * Data whose scale cannot be normalised (max |x - mu| outside [2^-60, 2^60], or all points identical) pass everything:
 //     every query overflows its list and re-scans all candidates — exact, at the scan's speed.
 #include <type_traits>
@@ -90,10 +96,10 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
   uint16_t* a = A2 + r * K3;
   uint16_t* b = B2 + r * K3;
   for (int t = 3 * dp + lane; t < K3; t += 64) a[t] = b[t] = 0;
-  float s = 0.f;
+  double s = 0.0;  // the norms are exact up to their final rounding: no d u term in the budget
   for (int t = lane; t < dp; t += 64) {
     const float v = t < d ? x[t] - mu[t] : 0.f;
-    s = fmaf(v, v, s);
+    s += (double)v * (double)v;
     const unsigned int hi = f32_to_bf16(v);
     const unsigned int lo = f32_to_bf16(v - widen(hi));  // exact subtraction: hi is v rounded to 8 bits
     a[t] = (uint16_t)hi; a[dp + t] = (uint16_t)hi; a[2 * dp + t] = (uint16_t)lo;
@@ -101,19 +107,19 @@ __global__ __launch_bounds__(256) void knn_split_kernel(int64_t n, int64_t d, co
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) norms[r] = s;
+  if (lane == 0) norms[r] = (float)s;
 }
 
-// The filter test  |q|^2 + |c|^2 - 2 dot <= tau + eps (|q|^2 + |c|^2)  rearranged so that the epilogue is one fma and
-// one compare per pair:   fma(-2, dot, Cn[c]) <= Rq[q],   Cn = (1 - eps) |c|^2,   Rq = tau - (1 - eps) |q|^2.
-// (eps carries a factor 2 of slack over the bound above, which also covers these few extra roundings.)
-__global__ __launch_bounds__(256) void knn_thresholds_kernel(int64_t n, int64_t q_begin, int64_t nq, int k, float eps,
+// The filter test  |q|^2 + |c|^2 - 2 dot <= tau (1 + chain_rel) + eps (|q|^2 + |c|^2)  rearranged so that the epilogue is one fma
+// and one compare per pair:   fma(-2, dot, Cn[c]) <= Rq[q],   Cn = (1 - eps) |c|^2,   Rq = tau (1 + chain_rel) - (1 - eps) |q|^2.
+__global__ __launch_bounds__(256) void knn_thresholds_kernel(int64_t n, int64_t q_begin, int64_t nq, int k, float eps, float chain_rel,
                                                              const float* __restrict__ norms, const float* __restrict__ sample_d2,
                                                              float* __restrict__ Rq, float* __restrict__ Cn, int32_t* __restrict__ counts) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) Cn[i] = (1.f - eps) * norms[i];
   if (i < nq) {
-    Rq[i] = sample_d2[i * k + (k - 1)] - (1.f - eps) * norms[q_begin + i];  // +inf when the sample held < k points
+    const float tau = sample_d2[i * k + (k - 1)];  // +inf when the sample held < k points
+    Rq[i] = fmaf(tau, chain_rel, tau) - (1.f - eps) * norms[q_begin + i];
     counts[i] = 0;
   }
 }
@@ -640,10 +646,11 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
                       int32_t* counts, int32_t* surv, int32_t* out_idx, float* out_dist, hipStream_t st) {
   const int dp = knn_filter_padded_d(d);
   const int64_t K3 = knn_filter_k3(d);
-  const float eps = 1.220703125e-4f + (float)d * 9.5367431640625e-7f;  // 2^-13 + d 2^-20
+  const float eps = 6.103515625e-5f + (float)d * 2.384185791015625e-7f;  // 2^-14 + d 2^-22 (budget at the head of the file)
+  const float chain_rel = (float)(d + 16) * 6.3e-8f;                     // (d + 16) u, 5 % over
   colmeans(n, d, X, ldx, mean_ws, st);
   hipLaunchKernelGGL(knn_split_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, dp, K3, A2, B2, norms);
-  hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, q_begin, nq, k, eps, norms,
+  hipLaunchKernelGGL(knn_thresholds_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, st, n, q_begin, nq, k, eps, chain_rel, norms,
                      sample_d2, Rq, Cn, counts);
   const int cap = knn_filter_cap(n, k);
   const int64_t tiles = ceil_div(nq, BM) * ceil_div(n, BN);

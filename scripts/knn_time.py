@@ -16,15 +16,18 @@ for name in ("randn", "clusters20"):
     if name == "clusters20":  # the bench's knn-k15 embedding: 20 cluster centres, spread 4x the within-cluster sigma
         c = torch.randn(20, d, device="cuda", generator=g) * 4.0
         x = x + c[torch.randint(0, 20, (n,), device="cuda", generator=g)]
-    for _ in range(2):
-        idx, dist = kernels.knn(x, k, algo=kernels.KNN_FILTER)
-    torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
-    for _ in range(3):
-        idx, dist = kernels.knn(x, k, algo=kernels.KNN_FILTER)
+    idx, dist = kernels.knn(x, k, algo=kernels.KNN_FILTER)
     t1.record(); torch.cuda.synchronize()
-    ms = t0.elapsed_time(t1) / 3
+    ms = t0.elapsed_time(t1)
+    if ms < 2000.0:  # (a call that fell back to re-scans takes seconds: keep its single timing)
+        idx, dist = kernels.knn(x, k, algo=kernels.KNN_FILTER)
+        t0.record()
+        for _ in range(3):
+            idx, dist = kernels.knn(x, k, algo=kernels.KNN_FILTER)
+        t1.record(); torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / 3
     # exactness on a query range against the scan (the scan over all 1M queries takes 3 s)
     q0, q1 = n // 2, min(n, n // 2 + 20000)
     i_s, d_s = kernels.knn(x, k, q0, q1, algo=kernels.KNN_SCAN)
