@@ -45,6 +45,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--skip-knn", action="store_true", help="skip the (seconds-long) kNN rows")
+    ap.add_argument("--knn-only", action="store_true", help="only the kNN / UMAP rows")
     args = ap.parse_args()
     q = args.quick
     from oracle import graphs as og
@@ -86,6 +87,10 @@ def main():
             rows[f"umap_connectivities n={n} k={k}"] = dict(ms=ms_u, cells_per_s=n / ms_u * 1e3,
                                                             cpu_baseline=dict(sample=f"{ns} cells incl. kNN", cells_per_s=ns / t_u))
         del x
+
+    if args.knn_only:
+        print(json.dumps(rows, indent=1))
+        return
 
     # ---- A14 pairwise distance (SpaGCNGraph) ---------------------------------------------------------------
     n = 4096 if q else 16384
