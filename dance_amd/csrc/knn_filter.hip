@@ -340,8 +340,8 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
   };
   f32x16 acc[2][2];
   const unsigned int n1u = (unsigned int)n1;
-  // Only lanes with a hit walk their set bits.  Both query sub-tiles advance together, so the two returning LDS atomics of a
-  // round are in flight at the same time and the wave waits once per round, not once per hit.
+  const int rows_left = (int)min((int64_t)64, nq - row0);  // queries of this lane's accumulator rows that exist
+  // Only lanes with a hit walk their set bits.
   // (g0, j0): slot and in-class index of the first row of the candidate tile; a tile crosses at most one slot boundary
   // (n1 >= 128 whenever G > 1)
   auto append = [&](int j, unsigned int g0, unsigned int j0, const unsigned int (&h)[2]) __attribute__((always_inline)) {
@@ -354,25 +354,20 @@ __global__ __launch_bounds__(512) void knn_fold_filter_kernel(int64_t nq, int64_
     if (jj >= n1u) { jj -= n1u; gg += 1u; }
     const unsigned int id = jj * (unsigned int)G + fold_class_of_slot(gg, (unsigned int)H, (unsigned int)(G / H), qmagic);
     const bool live = gg < (unsigned int)G && (int64_t)id < n;  // the zero rows behind the last candidate never pass anyway
-    unsigned int mk0 = live ? h[0] : 0u, mk1 = live ? h[1] : 0u;
-    while (mk0 | mk1) {
-      const int b0 = 31 - __clz(mk0 | 1u), b1 = 31 - __clz(mk1 | 1u);  // (| 1: defined for an empty mask, then unused)
-      const int r0 = 15 - b0, r1 = 15 - b1;
-      const int q0 = (r0 & 3) + 8 * (r0 >> 2), q1 = 32 + (r1 & 3) + 8 * (r1 >> 2);
-      // rows beyond the query range hold zero fragments (accumulator +0: no pass), checked all the same
-      const bool p0 = mk0 != 0u && row0 + q0 < nq, p1 = mk1 != 0u && row0 + q1 < nq;
-      int pos0 = 0, pos1 = 0;
-      if (p0) pos0 = atomicAdd(cnt + q0, 1);
-      if (p1) pos1 = atomicAdd(cnt + q1, 1);
-      if (p0 && pos0 < seg) surv_base[(int64_t)q0 * cap + pos0] = (int32_t)id;
-      if (p1 && pos1 < seg) surv_base[(int64_t)q1 * cap + pos1] = (int32_t)id;
-      mk0 &= ~(1u << b0);
-      mk1 &= ~(1u << b1);
+    // one mask for both query sub-tiles: bit 16 i + (15 - r) = accumulator register r of sub-tile i; one hit per round (lanes
+    // rarely hold two), one returning LDS atomic + one 4-byte store each
+    unsigned int mk = live ? (h[0] | (h[1] << 16)) : 0u;
+    while (mk) {
+      const int b = 31 - __clz(mk);
+      mk ^= 1u << b;
+      const int r = 15 - (b & 15);
+      const int q = (b >> 4) * 32 + (r & 3) + 8 * (r >> 2);
+      if (q < rows_left) {  // rows beyond the query range hold zero fragments (accumulator +0: no pass), checked all the same
+        const int pos = atomicAdd(cnt + q, 1);
+        if (pos < seg) surv_base[(unsigned int)(q * cap + pos)] = (int32_t)id;
+      }
     }
   };
-  // One half tile: all K steps of candidate sub-tile JM on the matrix cores while the vector ALUs take the pass bits of
-  // sub-tile JT from the previous half: bit (15 - r) of h[i] = sign bit of acc[i][JT][r], one v_alignbit (h = h << 1 | sign)
-  // per pair, a fixed number of pairs behind every MFMA.
   // The B fragments of a half tile are read from LDS during the MFMAs of the half before it (two register sets); only the
   // first half of an image waits for its reads.
   auto load_frags = [&](f16x8 (&dst)[KS], const _Float16* p) __attribute__((always_inline)) {
