@@ -31,6 +31,7 @@ def _declare(lib):
         "dh_spmm_csr_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, P, P, i64, P, i64, P, i32, i32, P]),
         "dh_spmm_csr_relu_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_spmm_csr_relu_slices_f32": (c_int, [i64, P, i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
+        "dh_spmm_csr_relu_slices_resident_f32": (c_int, [i64, P, i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, i32, P]),
         "dh_relu_mask_apply_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
         "dh_gather_rows_f32": (c_int, [i64, i64, P, P, i64, P, P, i64, P]),
         "dh_csr_transpose_workspace_bytes": (c_size_t, [i64, i64, i64]),

@@ -49,6 +49,10 @@ PIPELINE = os.environ.get("DANCE_AMD_LAYER_PIPELINE", "off")
 PIPELINE_MIN_ROWS = 1 << 17  # below this a layer is a handful of waves of tiles: nothing to overlap
 PIPELINE_TILE = kernels.GEMM_TILE_128
 PIPELINE_SIDE_PRIORITY = 0   # torch stream priority of the aggregation stream (0 = default, -1 = high)
+# (workgroups, shape) of the resident aggregation kernel that runs NEXT TO a GEMM (kernels.spmm_csr_relu); None = the one-shot
+# grid everywhere (round 3's pipeline, which measured serial time: its small workgroups displace the GEMM's, see spmm.hip).
+# The slice that has no GEMM beside it (the last one forward, the first one backward) always runs as the one-shot grid.
+PIPELINE_RESIDENT = None
 _SIDE_STREAMS = {}
 
 
@@ -87,14 +91,15 @@ def _pipelined_forward(x, w, graph, mask, slices):
     support = torch.empty((n, h), dtype=torch.float32, device=x.device)
     out = torch.empty((graph.n_rows, h), dtype=torch.float32, device=x.device)
     side.wait_stream(main)  # the buffers above may recycle blocks whose last use is still queued on the caller's stream
-    for c0, c1 in slices:
+    for i, (c0, c1) in enumerate(slices):
         kernels.gemm(x, w[:, c0:c1], out=support[:, c0:c1], tile=PIPELINE_TILE)
         ready = torch.cuda.Event()
         ready.record(main)
         side.wait_event(ready)
         with torch.cuda.stream(side):
             kernels.spmm_csr_relu(graph.rowptr, graph.col, graph.val, support, n_cols=graph.n_cols, act=kernels.ACT_RELU, out_mask=mask,
-                                  out=out, slices=(c0 // 128, c1 // 128), tag="spmm_csr_f32[fwd]")
+                                  out=out, slices=(c0 // 128, c1 // 128), resident=PIPELINE_RESIDENT if i + 1 < len(slices) else None,
+                                  tag="spmm_csr_f32[fwd]")
     main.wait_stream(side)
     return out
 
@@ -106,10 +111,10 @@ def _pipelined_backward(x, dy, gt, mask, slices):
     ds = torch.empty((gt.n_rows, h), dtype=torch.float32, device=x.device)
     dw = torch.empty((x.shape[1], h), dtype=torch.float32, device=x.device)
     side.wait_stream(main)  # dy (and the recycled blocks of ds / dw) are ready on the caller's stream
-    for c0, c1 in slices:
+    for i, (c0, c1) in enumerate(slices):
         with torch.cuda.stream(side):
             kernels.spmm_csr_relu(gt.rowptr, gt.col, gt.val, dy, n_cols=gt.n_cols, in_mask=mask, out=ds, slices=(c0 // 128, c1 // 128),
-                                  tag="spmm_csr_f32[bwd]")
+                                  resident=PIPELINE_RESIDENT if i > 0 else None, tag="spmm_csr_f32[bwd]")
             ready = torch.cuda.Event()
             ready.record(side)
         main.wait_event(ready)

@@ -575,9 +575,14 @@ def MultiLayerFullNeighborSampler(num_layers: int):
 class DataLoader:
     """Mini-batch iterator yielding ``(input_nodes, output_nodes, blocks)`` like ``dgl.dataloading.DataLoader``."""
 
-    def __init__(self, graph: CellGeneGraph, indices, sampler: NeighborSampler, batch_size: int = 1,
+    def __init__(self, graph: CellGeneGraph, indices, sampler: Optional[NeighborSampler] = None, batch_size: int = 1,
                  shuffle: bool = False, drop_last: bool = False, generator: Optional[torch.Generator] = None, prefetch: bool = True,
-                 block_hook=None, **_ignored):
+                 block_hook=None, graph_sampler: Optional[NeighborSampler] = None, **_ignored):
+        # ``graph_sampler`` is dgl.dataloading.DataLoader's own name for the third argument (scdeepsort.py:233,266,318 pass it by
+        # keyword); ``sampler`` is kept for this package's earlier call sites
+        sampler = graph_sampler if sampler is None else sampler
+        if sampler is None:
+            raise TypeError("DataLoader: a graph_sampler is required")
         self.graph, self.sampler = graph, sampler
         # block_hook(blocks) runs right after a batch's blocks are built, on the stream that built them (the side stream when
         # prefetching): per-batch set-up whose results the host needs (e.g. a count) then never waits for the model's kernels.
@@ -608,6 +613,12 @@ class DataLoader:
         if hit is None:
             hit = cache.put(given, int(given.min()))
         return hit
+
+    def enable_cpu_affinity(self, *args, **kwargs):
+        """dgl.dataloading.DataLoader.enable_cpu_affinity (scdeepsort.py:236 wraps a CPU epoch in it): pins DGL's worker
+        processes to cores.  There are no worker processes here (blocks are built by device kernels), so: a no-op context."""
+        import contextlib
+        return contextlib.nullcontext()
 
     def __len__(self):
         n = self.indices.numel()

@@ -209,6 +209,9 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
   //  * split-K (dW = X^T dS): all tiles of a K-slice run on ONE XCD at the same time (slice = xcd + 8 * round), so the
   //    slice's rows of X and dS are fetched from HBM once and the other tiles of the slice hit that XCD's L2 — the
   //    row tiles re-reading dS (and the column tiles re-reading X) were 2.5x the algorithmic traffic before.
+#ifdef DH_GEMM_SETPRIO  // A/B switch (scripts/overlap_diag.sh): wave priority of the GEMM next to co-resident aggregation waves
+  __builtin_amdgcn_s_setprio(DH_GEMM_SETPRIO);
+#endif
   const int bid = blockIdx.x;
   int logical, slice;
   if (n_slices == 1) {

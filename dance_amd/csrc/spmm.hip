@@ -304,6 +304,128 @@ __global__ __launch_bounds__(256) void spmm_slice128_kernel(
   __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Y + row * ldy + g * 4));
 }
 
+// Resident form of spmm_slice128_kernel for the co-scheduled layer (autograd.py: the GEMM of column panel c + 1 next to the
+// aggregation of panel c).  A GCN layer's GEMM is bound by the matrix cores, its aggregation by HBM; they use disjoint units
+// of a CU, but two ordinary launches do not overlap: the dispatcher hands every register a retiring GEMM workgroup frees to the
+// small aggregation workgroups queued behind it, the next GEMM workgroup (176 registers on each of the 4 SIMDs + 72 KB of LDS at
+// once) never finds room, and the CUs drift from one kernel to the other — the two-stream layer of round 3 measured exactly
+// serial time (profiles/r03b_pipeline_probe.json).  This form takes a FIXED footprint instead: `gridDim.x` workgroups of 512
+// threads (two waves per SIMD, <= 80 registers each = the 160 registers per SIMD the 128 x 128 GEMM configuration leaves free;
+// a second one does not fit beside two GEMM workgroups, so the dispatcher can only place one per CU), each walking the 16-row
+// blocks b, b + gridDim.x, ... of the slice.  Nothing else is ever dispatched into a freed GEMM slot but the next GEMM workgroup.
+// With two waves per SIMD instead of eight, latency is hidden by depth instead of occupancy: the (col, val) chunk of the next
+// row and the row pointers of the one after are fetched while the current row's gathers are in flight, and a row's
+// neighbours are requested 8 at a time.  Accumulation order = CSR order: bit-identical to spmm_slice128_kernel.
+template <bool MIN, bool MOUT, bool IDX32, int NB, int THREADS>
+__global__ __launch_bounds__(THREADS) void spmm_slice128_resident_kernel(
+    int n_rows, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ Z, int64_t ldz, float* __restrict__ Y, int64_t ldy, const float* __restrict__ bias, int act,
+    const int32_t* __restrict__ row_ids, ReluMask mask) {
+  // NB = neighbour rows requested before the first is used; THREADS / 32 rows per block
+  constexpr int RPB = THREADS / 32;
+  const int g = threadIdx.x & 31;
+  const int sub = threadIdx.x >> 5;
+  const float* zc = Z + g * 4;
+  const uint32_t* min_lane = MIN ? mask.in + (int64_t)mask.slice0 * 4 + (g >> 3) : nullptr;
+  const uint32_t bit0 = 4u * (uint32_t)(g & 7);
+  const uint32_t mstride = MIN ? (uint32_t)mask.slices * 4u : 0u;
+  auto zrow = [&](int ck) -> const f32x4* {
+    if constexpr (IDX32) return reinterpret_cast<const f32x4*>(zc + (uint32_t)ck * (uint32_t)ldz);
+    else return reinterpret_cast<const f32x4*>(zc + (int64_t)ck * ldz);
+  };
+  auto mrow = [&](int ck) -> uint32_t {
+    if constexpr (IDX32) return min_lane[(uint32_t)ck * mstride];
+    else return min_lane[(int64_t)ck * mstride];
+  };
+  auto masked = [&](f32x4 z, uint32_t m) -> f32x4 {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      z[i] = __uint_as_float(__float_as_uint(z[i]) & (uint32_t)__builtin_amdgcn_sbfe((int)m, bit0 + i, 1u));
+    return z;
+  };
+  // block walk: with xcd_blocks > 0 the workgroups of XCD x (= blockIdx.x % 8, observed placement) walk XCD x's contiguous
+  // eighth of the blocks, as the one-shot kernel does; otherwise block b, b + gridDim.x, ...
+  const int n_blocks = (n_rows + RPB - 1) / RPB;
+  int blk, blk_end, blk_step;
+  if (mask.xcd_blocks > 0 && (gridDim.x & 7) == 0) {
+    const int per = (n_blocks + 7) / 8;
+    blk = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    blk_end = min((int)((blockIdx.x & 7) + 1) * per, n_blocks);
+    blk_step = (int)(gridDim.x >> 3);
+  } else {
+    blk = (int)blockIdx.x;
+    blk_end = n_blocks;
+    blk_step = (int)gridDim.x;
+  }
+  auto row_of = [&](int b) -> int {  // -1: no row (past the end); b may overflow past blk_end only by 2 steps (host keeps it in range)
+    const int slot = b * RPB + sub;
+    if (b >= blk_end || slot >= n_rows) return -1;
+    return row_ids ? row_ids[slot] : slot;
+  };
+  auto chunk = [&](int base, int t, int& c, float& w) {
+    const int e = base + g;
+    c = 0;
+    w = 0.f;
+    if (e < t) {
+      c = col[e];
+      w = val ? val[e] : 1.f;
+    }
+  };
+  // pipeline registers: current row (row, s, t, c, w), next row (row1, s1, t1), the row after (fetched inside the loop)
+  int row = row_of(blk), row1 = row_of(blk + blk_step);
+  int s = 0, t = 0, s1 = 0, t1 = 0, c, c1;
+  float w, w1;
+  if (row >= 0) { s = rowptr[row]; t = rowptr[row + 1]; }
+  if (row1 >= 0) { s1 = rowptr[row1]; t1 = rowptr[row1 + 1]; }
+  chunk(s, t, c, w);
+  for (; blk < blk_end; blk += blk_step) {
+    // issue the next row's first chunk and the row pointers of the one after before this row's gathers
+    chunk(s1, t1, c1, w1);
+    const int row2 = row_of(blk + 2 * blk_step);
+    int s2 = 0, t2 = 0;
+    if (row2 >= 0) { s2 = rowptr[row2]; t2 = rowptr[row2 + 1]; }
+    if (row >= 0) {
+      f32x4 acc = f32x4(0.f);
+      for (int base = s; base < t; base += 32) {
+        if (base != s) chunk(base, t, c, w);
+        const int cnt = min(32, t - base);
+        for (int k = 0; k < cnt; k += NB) {
+          const int live = min(NB, cnt - k);
+          f32x4 z[NB];
+          uint32_t m[NB];
+          // lanes beyond cnt hold c = 0, w = 0: row 0 of Z is read and multiplied by w = 0 ... which is NOT a no-op for inf / nan
+          // rows, so the loads and the fmas of the dead slots are skipped, not neutralised
+#pragma unroll
+          for (int u = 0; u < NB; ++u)
+            if (u < live) {
+              const int ck = __shfl(c, (k + u) & 31, 32);
+              z[u] = *zrow(ck);
+              if constexpr (MIN) m[u] = mrow(ck);
+            }
+#pragma unroll
+          for (int u = 0; u < NB; ++u)
+            if (u < live) {
+              if constexpr (MIN) z[u] = masked(z[u], m[u]);
+              fma_vec<4>(acc, __shfl(w, (k + u) & 31, 32), z[u]);
+            }
+        }
+      }
+      epilogue<4>(acc, 1.f, bias, (int64_t)g * 4, act);
+      if constexpr (MOUT) {
+        uint32_t nib = (acc[0] > 0.f ? 1u : 0u) | (acc[1] > 0.f ? 2u : 0u) | (acc[2] > 0.f ? 4u : 0u) | (acc[3] > 0.f ? 8u : 0u);
+        nib <<= 4 * (g & 7);
+        nib |= __shfl_xor(nib, 1, 8);
+        nib |= __shfl_xor(nib, 2, 8);
+        nib |= __shfl_xor(nib, 4, 8);
+        if ((g & 7) == 0) mask.out[((int64_t)row * mask.slices + mask.slice0) * 4 + (g >> 3)] = nib;
+      }
+      __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(Y + (int64_t)row * ldy + g * 4));
+    }
+    row = row1; s = s1; t = t1; c = c1; w = w1;
+    row1 = row2; s1 = s2; t1 = t2;
+  }
+}
+
 // launches the slice kernel over every 128-column slice of [0, width)
 template <bool MIN, bool MOUT>
 void launch_slices(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
@@ -325,6 +447,36 @@ void launch_slices(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t*
     else
       hipLaunchKernelGGL((spmm_slice128_kernel<MIN, MOUT, false>), grid, dim3(256), 0, st, n_rows, rowptr, col, val, rowscale, colscale,
                          Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, reduce, row_ids, mask);
+  }
+}
+
+// the resident form over the slices [slice_begin, slice_end): `workgroups` resident blocks per slice.  shape 0: 512 threads, two
+// waves per SIMD at <= 80 registers, 8 neighbours requested at a time; shape 1: 256 threads, one wave per SIMD at <= 160
+// registers, 16 at a time (a whole k = 15 row in one round trip).  Either fits once beside two 128 x 128 GEMM workgroups.
+template <bool MIN, bool MOUT>
+void launch_slices_resident(int64_t n_rows, int64_t n_cols, int64_t width, const int32_t* rowptr, const int32_t* col, const float* val,
+                            const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, const int32_t* row_ids,
+                            const uint32_t* in_mask, uint32_t* out_mask, hipStream_t st, int64_t slice_begin, int64_t slice_end,
+                            int workgroups, int shape) {
+  const int64_t max_stride = MIN ? ((ldz > width / 32) ? ldz : width / 32) : ldz;
+  const bool idx32 = n_cols >= 0 && (double)n_cols * (double)max_stride < 4294967296.0;
+  const int rpb = shape == 1 ? 8 : 16;
+  const int64_t blocks = dh::ceil_div(n_rows, rpb);
+  const int grid = (int)(blocks < workgroups ? blocks : workgroups);
+  const int xcd_blocks = (blocks >= 64 && grid % 8 == 0) ? (int)dh::ceil_div(blocks, 8) : 0;
+  for (int64_t c = slice_begin * 128; c < slice_end * 128; c += 128) {
+    const ReluMask mask{out_mask, in_mask, (int)(width / 128), (int)(c / 128), xcd_blocks};
+#define DH_RES(I32, NB, TH)                                                                                                          \
+  hipLaunchKernelGGL((spmm_slice128_resident_kernel<MIN, MOUT, I32, NB, TH>), dim3(grid), dim3(TH), 0, st, (int)n_rows, rowptr, col, val, \
+                     Z + c, ldz, Y + c, ldy, bias ? bias + c : nullptr, act, row_ids, mask)
+    if (shape == 1) {
+      if (idx32) DH_RES(true, 16, 256);
+      else DH_RES(false, 16, 256);
+    } else {
+      if (idx32) DH_RES(true, (MIN ? 6 : 8), 512);
+      else DH_RES(false, (MIN ? 6 : 8), 512);
+    }
+#undef DH_RES
   }
 }
 
@@ -435,6 +587,18 @@ extern "C" int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_id
                                            int64_t slice_end, const int32_t* rowptr, const int32_t* col, const float* val, const float* Z,
                                            int64_t ldz, float* Y, int64_t ldy, const float* bias, int act, void* out_mask,
                                            const void* in_mask, dh_stream_t stream) {
+  return dh_spmm_csr_relu_slices_resident_f32(n_list, row_ids, n_cols, width, slice_begin, slice_end, rowptr, col, val, Z, ldz, Y, ldy, bias, act,
+                                              out_mask, in_mask, 0, stream);
+}
+
+// resident_workgroups > 0: every slice runs as that many resident 512-thread workgroups walking the rows
+// (spmm_slice128_resident_kernel: the fixed-footprint form that co-schedules with the 128 x 128 GEMM); 0: the one-shot grid.
+// The results are bit-identical either way.
+extern "C" int dh_spmm_csr_relu_slices_resident_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width, int64_t slice_begin,
+                                                    int64_t slice_end, const int32_t* rowptr, const int32_t* col, const float* val,
+                                                    const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
+                                                    void* out_mask, const void* in_mask, int resident_workgroups, dh_stream_t stream) {
+  if (resident_workgroups < 0) return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: negative resident_workgroups");
   if (slice_begin < 0 || slice_end < slice_begin || slice_end * 128 > width)
     return dh::fail(DH_ERR_INVALID, "dh_spmm_csr_relu_f32: slice range [%lld, %lld) outside width %lld", (long long)slice_begin,
                     (long long)slice_end, (long long)width);
@@ -452,8 +616,14 @@ extern "C" int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_id
   const uint32_t* mi = static_cast<const uint32_t*>(in_mask);
   uint32_t* mo = static_cast<uint32_t*>(out_mask);
 #define DH_SLICES(MIN, MOUT)                                                                                                        \
-  launch_slices<MIN, MOUT>(n_list, n_cols, width, rowptr, col, val, nullptr, nullptr, Z, ldz, Y, ldy, bias, act, DH_REDUCE_SUM, row_ids, \
-                           mi, mo, st, slice_begin, slice_end)
+  do {                                                                                                                              \
+    if (resident_workgroups > 0)                                                                                                    \
+      launch_slices_resident<MIN, MOUT>(n_list, n_cols, width, rowptr, col, val, Z, ldz, Y, ldy, bias, act, row_ids, mi, mo, st,     \
+                                        slice_begin, slice_end, resident_workgroups & 0xffff, resident_workgroups >> 16);           \
+    else                                                                                                                            \
+      launch_slices<MIN, MOUT>(n_list, n_cols, width, rowptr, col, val, nullptr, nullptr, Z, ldz, Y, ldy, bias, act, DH_REDUCE_SUM,  \
+                               row_ids, mi, mo, st, slice_begin, slice_end);                                                        \
+  } while (0)
   if (mi && mo) DH_SLICES(true, true);
   else if (mi) DH_SLICES(true, false);
   else if (mo) DH_SLICES(false, true);

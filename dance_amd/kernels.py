@@ -143,17 +143,29 @@ def spmm_csr_relu(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
                   n_cols: Optional[int] = None, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                   out_mask: Optional[torch.Tensor] = None, in_mask: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None,
-                  slices: Optional[Tuple[int, int]] = None, tag: str = "spmm_csr_f32") -> torch.Tensor:
+                  slices: Optional[Tuple[int, int]] = None, resident: Optional[Tuple[int, int]] = None,
+                  tag: str = "spmm_csr_f32") -> torch.Tensor:
     """dh_spmm_csr_relu_f32: forward records the ReLU sign mask (out_mask), backward applies it to the gathered
     rows (in_mask).  Masks are uint8 tensors of ``relu_mask_bytes`` bytes.  ``rows``: as in ``spmm_csr``.
     ``slices`` = (begin, end) in units of 128 columns: only those column slices of the layer are computed
-    (dh_spmm_csr_relu_slices_f32; Z, out and the masks are the whole layer's)."""
+    (dh_spmm_csr_relu_slices_f32; Z, out and the masks are the whole layer's).  ``resident`` = (workgroups, shape) with
+    ``slices``: the fixed-footprint form (dh_spmm_csr_relu_slices_resident_f32) that co-schedules with a 128 x 128 GEMM."""
     lib = _lib_ready()
     n_rows = rowptr.numel() - 1
     width = Z.shape[1]
     n_cols = Z.shape[0] if n_cols is None else n_cols
     if out is None:
         out = torch.empty((n_rows, width), dtype=torch.float32, device=Z.device)
+    if slices is not None and resident is not None:
+        wgs, shape = int(resident[0]), int(resident[1])
+        if not (0 < wgs < 65536 and shape in (0, 1)):
+            raise ValueError(f"spmm_csr_relu: resident=(workgroups, shape) out of range: {resident!r}")
+        _call(tag, lib.dh_spmm_csr_relu_slices_resident_f32, n_rows if rows is None else rows.numel(), _dev(rows, torch.int32, "rows", 1), n_cols,
+              width, int(slices[0]), int(slices[1]), _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),
+              _dev(val, torch.float32, "val", 1), _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(out, torch.float32, "out", 2), _ld(out),
+              _dev(bias, torch.float32, "bias", 1), act, None if out_mask is None else out_mask.data_ptr(),
+              None if in_mask is None else in_mask.data_ptr(), wgs | (shape << 16), _stream())
+        return out
     if slices is not None:
         _call(tag, lib.dh_spmm_csr_relu_slices_f32, n_rows if rows is None else rows.numel(), _dev(rows, torch.int32, "rows", 1), n_cols, width,
               int(slices[0]), int(slices[1]), _dev(rowptr, torch.int32, "rowptr", 1), _dev(col, torch.int32, "col", 1),

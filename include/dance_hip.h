@@ -107,6 +107,15 @@ DH_API int dh_spmm_csr_relu_slices_f32(int64_t n_list, const int32_t* row_ids, i
                          const int32_t* rowptr, const int32_t* col, const float* val,
                          const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
                          void* out_mask, const void* in_mask, dh_stream_t stream);
+/* The same with a FIXED device footprint: resident_workgroups > 0 runs every slice as that many resident 512-thread workgroups
+ * (two waves per SIMD, <= 80 registers) that walk the rows, so that the aggregation co-schedules with the 128 x 128 dh_gemm_f32_ex
+ * of the next column panel instead of displacing its workgroups (the layer of scdsc.py:496-501 as one overlapped pipeline);
+ * 0 = the one-shot grid of dh_spmm_csr_relu_slices_f32.  Bit-identical results.                                           */
+DH_API int dh_spmm_csr_relu_slices_resident_f32(int64_t n_list, const int32_t* row_ids, int64_t n_cols, int64_t width,
+                         int64_t slice_begin, int64_t slice_end,
+                         const int32_t* rowptr, const int32_t* col, const float* val,
+                         const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
+                         void* out_mask, const void* in_mask, int resident_workgroups, dh_stream_t stream);
 DH_API int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx,
                        const void* relu_mask, float* out, int64_t ldo, dh_stream_t stream);
 /* out = X * [Y > 0] from the recorded sign mask of Y (dh_relu_mask_bytes layout; width % 128 == 0): autograd's ReluBackward

@@ -118,6 +118,12 @@ class DGLStubGraph:
     def number_of_dst_nodes(self):
         return self._num_dst
 
+    def num_dst_nodes(self):  # scdeepsort.py:247
+        return self._num_dst
+
+    def num_src_nodes(self):
+        return self._num_src
+
     def update_all(self, message_func, reduce_func):
         import types
 
@@ -182,8 +188,16 @@ def dgl_stub(shuffle_generator=None):
     fn = types.SimpleNamespace(mean=lambda msg, out: ("mean", msg, out), sum=lambda msg, out: ("sum", msg, out))
 
     class _Loader:
-        def __init__(self, g, ids, sampler, batch_size=1, shuffle=False, drop_last=False, num_workers=0):
+        # positional (g, ids, sampler) as graphsc.py:183-187 calls it, or the keywords of scdeepsort.py:233-234,266-267
+        def __init__(self, g=None, ids=None, sampler=None, batch_size=1, shuffle=False, drop_last=False, num_workers=0, *,
+                     graph=None, indices=None, graph_sampler=None):
+            g = graph if g is None else g
+            ids = indices if ids is None else ids
             self.g, self.ids, self.bs, self.shuffle = g, torch.as_tensor(ids).long(), batch_size, shuffle
+
+        def enable_cpu_affinity(self):  # scdeepsort.py:236: a context manager around the epoch
+            import contextlib
+            return contextlib.nullcontext()
 
         def __iter__(self):
             ids = self.ids[torch.randperm(self.ids.numel(), generator=shuffle_generator)] if self.shuffle else self.ids
@@ -194,7 +208,11 @@ def dgl_stub(shuffle_generator=None):
         if n_layers != 1:
             raise NotImplementedError("stub: one-layer blocks only")
         return None
-    dataloading = types.SimpleNamespace(MultiLayerFullNeighborSampler=_sampler, DataLoader=_Loader)
+    def _neighbor_sampler(fanouts, edge_dir="in"):  # scdeepsort.py:183: full fan-out in-neighbour blocks
+        if list(fanouts) != [-1] or edge_dir != "in":
+            raise NotImplementedError("stub: one layer of all in-neighbours only")
+        return None
+    dataloading = types.SimpleNamespace(MultiLayerFullNeighborSampler=_sampler, NeighborSampler=_neighbor_sampler, DataLoader=_Loader)
     return types.SimpleNamespace(graph=lambda pair: DGLStubGraph(pair[0], pair[1]), function=fn, dataloading=dataloading,
                                  DGLGraph=DGLStubGraph)
 

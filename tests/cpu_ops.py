@@ -73,7 +73,7 @@ def _bool_to_mask(b):
 
 
 def spmm_csr_relu(rowptr, col, val, Z, *, n_cols=None, bias=None, act=ACT_NONE, out_mask=None, in_mask=None, out=None, rows=None,
-                  slices=None, tag=None):
+                  slices=None, resident=None, tag=None):  # resident: launch shape only, same arithmetic
     n_rows, width = rowptr.numel() - 1, Z.shape[1]
     if slices is not None:  # column slices [begin, end) x 128 of the layer: every other column (and mask word) is left untouched
         c0, c1 = slices[0] * 128, slices[1] * 128

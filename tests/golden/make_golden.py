@@ -391,6 +391,130 @@ def make_graphsc():
     print("graphsc.npz:", len(out), "arrays")
 
 
+def scdeepsort_reference(dgl, save_dir, log):
+    """The reference's own ScDeepSort (scdeepsort.py:91-349) as a class assembled from its AST-lifted methods (the real class
+    cannot be defined here: its base needs the dance registry), with its GNN (:26-88) and AdaptiveSAGE (gnn.py:8-96) lifted whole.
+    ``log`` receives every value ``cal_loss`` / ``evaluate`` return and the freshly initialised ``state_dict``.  Also used by
+    tests/test_oracle_layers.py to re-derive the golden file."""
+    import logging
+    from contextlib import nullcontext
+    from copy import deepcopy
+    from pathlib import Path
+    from typing import Optional
+
+    import torch.nn as nn
+    sds = "dance/modules/single_modality/cell_type_annotation/scdeepsort.py"
+    SAGE = ref_extract.extract("dance/models/nn/gnn.py", "AdaptiveSAGE", {"dgl": dgl, "logger": logging.getLogger("reference")})
+    GNN = ref_extract.extract(sds, "GNN", {"AdaptiveSAGE": SAGE, "Optional": Optional})
+
+    def recording_gnn(*a, **k):
+        m = GNN(*a, **k)
+        log.setdefault("sd0", {k2: v.detach().clone() for k2, v in m.state_dict().items()})
+        return m
+    ns = {"dgl": dgl, "DataLoader": dgl.dataloading.DataLoader, "NeighborSampler": dgl.dataloading.NeighborSampler, "GNN": recording_gnn,
+          "deepcopy": deepcopy, "nullcontext": nullcontext, "print": lambda *a, **k: None}
+    methods = {m: ref_extract.extract_method(sds, "ScDeepSort", m, ns)
+               for m in ("fit", "cal_loss", "evaluate", "save_model", "predict_proba", "predict")}
+
+    def recorded(name):
+        fn = methods[name]
+
+        def wrapper(self, *a, **k):
+            r = fn(self, *a, **k)
+            log.setdefault(name, []).append(r)
+            return r
+        return wrapper
+    methods["cal_loss"], methods["evaluate"] = recorded("cal_loss"), recorded("evaluate")
+    Ref = type("ReferenceScDeepSort", (), methods)
+
+    def build(dim_in, dim_hid, batch_size):  # the attributes ScDeepSort.__init__ sets (:115-133), without its mkdir in the CWD
+        m = Ref()
+        m.dense_dim, m.hidden_dim, m.n_layers, m.dropout = dim_in, dim_hid, 1, 0
+        m.species, m.tissue, m.batch_size, m.device = "golden", "scds", batch_size, "cpu"
+        m.prj_path, m.save_path = Path(save_dir), Path(save_dir)
+        return m
+    return build
+
+
+def scdeepsort_inputs():
+    """Seeded inputs of scdeepsort.npz: 300 cells of 4 expression programmes over 40 genes, 16-d gene features, cell features =
+    row-normalised expression @ gene features (what WeightedFeaturePCA hands PCACellFeatureGraph, cell_feature.py:66-67)."""
+    rng = np.random.default_rng(21)
+    n_cells, n_genes, d, n_types = 300, 40, 16, 4
+    types = rng.integers(0, n_types, n_cells)
+    rates = rng.gamma(0.5, 1.0, (n_types, n_genes)) * 1.5
+    x = rng.poisson(rates[types]).astype(np.float32)
+    x[np.arange(n_cells), rng.integers(0, n_genes, n_cells)] += 1.0   # every cell expresses something
+    gene_f = rng.standard_normal((n_genes, d)).astype(np.float32)
+    cell_f = ((x / x.sum(1, keepdims=True)) @ gene_f).astype(np.float32)
+    return x, gene_f, cell_f, types.astype(np.int64)
+
+
+def scdeepsort_graph(dgl, x, gene_f, cell_f):
+    """CellFeatureGraph.__call__ of the reference (normalize_edges=True, the scDeepSort pipeline's default) on the stub."""
+    import logging
+    import types as pytypes
+    call = ref_extract.extract_method("dance/transforms/graph/cell_feature_graph.py", "CellFeatureGraph", "__call__", {"dgl": dgl})
+    get_feature = lambda return_type="default", mod=None, channel=None, channel_type=None: (
+        torch.from_numpy(gene_f) if channel_type == "varm" else torch.from_numpy(cell_f) if channel_type == "obsm" else x)
+    data = pytypes.SimpleNamespace(get_feature=get_feature, data=pytypes.SimpleNamespace(uns={}))
+    call(pytypes.SimpleNamespace(mod=None, normalize_edges=True, cell_feature_channel="f", gene_feature_channel="f",
+                                 logger=logging.getLogger("reference"), out="g"), data)
+    return data.data.uns["g"]
+
+
+def scdeepsort_run(batch_size, epochs=3, lr=1e-2, hid=12, seed_model=5, seed_order=77):
+    """One run of the reference's ScDeepSort.fit + predict_proba + predict; returns the arrays of one scdeepsort.npz case.
+    Every random permutation — the train / validation split (scdeepsort.py:157, ``torch.randperm`` on the global RNG) and the
+    stub loader's per-epoch seed orders — is drawn from ONE seeded generator in program order, which is the order the product's
+    ``shuffle_generator`` is consumed in (split, then per epoch: training loader, evaluate(train) loader, evaluate(val) loader)."""
+    import tempfile
+    import unittest.mock as mock
+    x, gene_f, cell_f, labels = scdeepsort_inputs()
+    gen = torch.Generator().manual_seed(seed_order)
+    dgl = ref_extract.dgl_stub(shuffle_generator=gen)
+    g = scdeepsort_graph(dgl, x, gene_f, cell_f)
+    log = {}
+    real_randperm = torch.randperm
+    with tempfile.TemporaryDirectory() as tmp:
+        m = scdeepsort_reference(dgl, tmp, log)(gene_f.shape[1], hid, batch_size)
+        torch.manual_seed(seed_model)
+        with mock.patch.object(torch, "randperm", lambda n, *a, **k: real_randperm(int(n), *a, **({"generator": gen, **k}))):
+            m.fit(g, torch.from_numpy(labels), epochs=epochs, lr=lr, weight_decay=0, val_ratio=0.2)
+            prob = m.predict_proba(g)
+            pred, unsure = m.predict(g, unsure_rate=2.0, return_unsure=True)
+            pred_loose, unsure_loose = m.predict(g, unsure_rate=1.4, return_unsure=True)
+    ev = np.array([[c, u, a] for c, u, a in log["evaluate"]], dtype=np.float64)   # per epoch: evaluate(train), evaluate(val)
+    out = {"losses": np.array(log["cal_loss"], dtype=np.float64), "eval": ev, "prob": prob.astype(np.float32), "pred": pred.astype(np.int64),
+           "unsure": unsure.astype(np.bool_), "pred_loose": pred_loose.astype(np.int64), "unsure_loose": unsure_loose.astype(np.bool_)}
+    for k, v in log["sd0"].items():
+        out[f"sd0::{k}"] = v.numpy().copy()
+    for k, v in m.model.state_dict().items():          # after fit: the best-validation checkpoint (scdeepsort.py:204-206)
+        out[f"sd1::{k}"] = v.numpy().copy()
+    return out
+
+
+def make_scdeepsort():
+    """scdeepsort.npz — the reference's own ScDeepSort.fit / cal_loss / evaluate / predict_proba / predict (scdeepsort.py:142-349)
+    with its GNN and AdaptiveSAGE, AST-lifted and run on torch-CPU over the DGL stub: per-epoch summed-CE loss, (correct, unsure,
+    accuracy) of evaluate on the training and validation cells (the raw-logit "unsure" rule of :280-281), the best-validation
+    state_dict fit ends with, predict_proba and predict(..., return_unsure=True).  Cases: "one" = every epoch is one batch
+    (batch_size >= cells: the seed order only permutes a sum), "mb" = batches of 64 in the seeded loader order, "peak" = the
+    same at lr 0.1, where validation accuracy peaks at the middle epoch (so restoring the best checkpoint is observable)."""
+    x, gene_f, cell_f, labels = scdeepsort_inputs()
+    cases = {"one": {"batch_size": 512, "epochs": 3, "lr": 1e-2}, "mb": {"batch_size": 64, "epochs": 3, "lr": 1e-2},
+             "peak": {"batch_size": 64, "epochs": 3, "lr": 0.1}}
+    out = {"x": x, "gene_feat": gene_f, "cell_feat": cell_f, "labels": labels,
+           "kw": np.array(json.dumps({"hid": 12, "seed_model": 5, "seed_order": 77, "cases": cases}))}
+    for tag, c in cases.items():
+        for k, v in scdeepsort_run(c["batch_size"], epochs=c["epochs"], lr=c["lr"]).items():
+            out[f"{tag}_{k}"] = v
+    val_acc = out["peak_eval"][1::2, 2]
+    assert val_acc.argmax() < len(val_acc) - 1, val_acc   # "peak": the best validation epoch is NOT the last one
+    np.savez_compressed(os.path.join(HERE, "scdeepsort.npz"), **out)
+    print("scdeepsort.npz:", len(out), "arrays;", {t: (out[f"{t}_losses"].round(4).tolist(), out[f"{t}_eval"][:, 2].round(4).tolist()) for t in cases})
+
+
 def make_scheteronet():
     """scheteronet.npz — the reference's own HeteroNet / scHeteroNet classes (scheteronet.py:281-789), AST-lifted and run on
     torch-CPU over stand-ins for torch_sparse / torch_geometric (oracle.ref_extract.pyg_stub): init_adj's two normalised
@@ -1209,3 +1333,4 @@ if __name__ == "__main__":
     make_gene_filters()
     make_feature_feature_graph()
     make_graphsci()
+    make_scdeepsort()

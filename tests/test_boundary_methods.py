@@ -215,3 +215,57 @@ def test_scheteronet_convert_vs_reference_code():
         assert list(ind.splits[ours]) == g[f"ss_ind_split_{key}"].tolist()
     assert list(ood_tr.node_idx) == g["ss_ood_node_idx"].tolist() and list(ood_te.node_idx) == list(ood_tr.node_idx)
     assert ood_tr.num_nodes == n and torch.equal(ood_tr.edge_index, ind.edge_index) and torch.equal(ind.graph["node_feat"], ind.x)
+
+
+@needs_ref
+@pytest.mark.parametrize("tag", ["mb", "peak"])
+def test_reference_scdeepsort_methods_run_on_our_objects(cpu_kernels, tmp_path, monkeypatch, tag):
+    """The reference's own ``cal_loss`` / ``evaluate`` / ``predict_proba`` / ``predict`` bodies (scdeepsort.py:208-349) run LIVE with
+    our ScDeepSort as ``self``, our graph, and our ``DataLoader`` / blocks standing where dgl's are (``graph_sampler=`` keyword,
+    ``enable_cpu_affinity``, ``b.to(device)``, ``num_dst_nodes``): they must return what our own methods return — and what the
+    golden file holds for the trained model."""
+    from contextlib import nullcontext
+
+    import scdeepsort_golden_checks as chk
+    from dance_amd import cellgraph
+    SD = "dance/modules/single_modality/cell_type_annotation/scdeepsort.py"
+    gold, kw = chk.load()
+    m, g, log = chk.fit_case(gold, kw, tag, "cpu", tmp_path, monkeypatch, block_eval=True)
+    ns = {"dgl": types.SimpleNamespace(DGLGraph=object), "DataLoader": cellgraph.DataLoader, "NeighborSampler": cellgraph.NeighborSampler,
+          "nullcontext": nullcontext, "print": lambda *a, **k: None}
+    ref = {name: ref_extract.extract_method(SD, "ScDeepSort", name, ns) for name in ("cal_loss", "evaluate", "predict_proba", "predict")}
+    n_genes, n_cells = gold["x"].shape[1], gold["x"].shape[0]
+    idx = torch.arange(n_genes, n_genes + n_cells)
+    gg = g.to("cpu")
+    gg.ndata["label"] = torch.cat((-torch.ones(n_genes, dtype=torch.long), torch.from_numpy(gold["labels"])))
+    # evaluate: the per-row .item() loop of the reference vs our vectorised form, on the trained model
+    want = ref["evaluate"](m, gg, idx)
+    m.full_graph_eval = False
+    assert tuple(m.evaluate(gg, idx)) == tuple(want)
+    m.full_graph_eval = True
+    assert tuple(m.evaluate(gg, idx)) == tuple(want)
+    # predict_proba / predict
+    prob_ref = ref["predict_proba"](m, gg)
+    assert np.abs(prob_ref - m.predict_proba(gg)).max() < 1e-6 and np.abs(prob_ref - gold[f"{tag}_prob"]).max() < 2e-4
+    m.predict_proba = lambda graph: prob_ref          # the reference's predict calls self.predict_proba
+    for rate, suffix in ((2.0, ""), (1.4, "_loose")):
+        pred, unsure = ref["predict"](m, gg, unsure_rate=rate, return_unsure=True)
+        assert np.array_equal(pred, gold[f"{tag}_pred{suffix}"]) and np.array_equal(unsure, gold[f"{tag}_unsure{suffix}"])
+    del m.predict_proba
+    # cal_loss: one more epoch by the reference's body and by ours from the same state, same loader permutation
+    import copy
+    state = copy.deepcopy(m.model.state_dict())
+    opt_state = copy.deepcopy(m.optimizer.state_dict())
+    train_idx = idx[: n_cells // 2]
+    m.shuffle_generator = torch.Generator().manual_seed(5)
+    ours = m.cal_loss(gg, train_idx)
+    after_ours = copy.deepcopy(m.model.state_dict())
+    m.model.load_state_dict(state)
+    m.optimizer.load_state_dict(opt_state)
+    gen = torch.Generator().manual_seed(5)
+    monkeypatch.setitem(ns, "DataLoader", functools.partial(cellgraph.DataLoader, generator=gen))
+    ref_cal = ref_extract.extract_method(SD, "ScDeepSort", "cal_loss", ns)
+    theirs = ref_cal(m, gg, train_idx)
+    assert abs(ours - theirs) < 1e-5 * abs(theirs)
+    for k, v in m.model.state_dict().items():
+        assert rel_err(v.numpy(), after_ours[k].numpy()) < 1e-5, k

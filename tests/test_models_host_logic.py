@@ -401,3 +401,14 @@ def check_gc_dec(device):
 
 def test_gc_dec_vs_reference_on_cpu(cpu_kernels):
     check_gc_dec("cpu")
+
+
+@pytest.mark.parametrize("tag,block_eval", [("one", True), ("mb", True), ("peak", True), ("one", False)])
+def test_scdeepsort_fit_loop_vs_reference_on_cpu(cpu_kernels, tmp_path, monkeypatch, tag, block_eval):
+    """ScDeepSort.fit / cal_loss / evaluate / predict_proba / predict == the reference's own loop (scdeepsort.py:142-349 run over
+    the DGL stub, tests/golden/scdeepsort.npz): split, per-epoch loss and (correct, unsure, accuracy), best-validation
+    checkpoint, probabilities, unsure flags.  ``block_eval=False`` = the product's default single-pass evaluation; with one
+    batch per epoch ("one") the seed order only permutes a sum, so it must land on the same numbers."""
+    import scdeepsort_golden_checks as chk
+    gold, kw = chk.load()
+    chk.check_case(gold, kw, tag, "cpu", tmp_path, monkeypatch, block_eval=block_eval, rel_err=rel_err)

@@ -272,7 +272,8 @@ def test_graphsc_golden_regenerates_from_reference(tmp_path, monkeypatch):
 @pytest.mark.parametrize("maker,fname", [("make_scheteronet", "scheteronet.npz"), ("make_scdsc_fit", "scdsc_fit.npz"), ("make_sctag", "sctag.npz"), ("make_stagate", "stagate.npz"), ("make_free_riders", "free_riders.npz"),
                                          ("make_gc_dec", "gc_dec.npz"), ("make_wgc_alpha", "wgc_alpha.npz"), ("make_small_transforms", "small_transforms.npz"),
                                          ("make_scheteronet_split", "scheteronet_split.npz"), ("make_gene_filters", "gene_filters.npz"),
-                                         ("make_feature_feature_graph", "feature_feature_graph.npz"), ("make_graphsci", "graphsci.npz")])
+                                         ("make_feature_feature_graph", "feature_feature_graph.npz"), ("make_graphsci", "graphsci.npz"),
+                                         ("make_scdeepsort", "scdeepsort.npz")])
 def test_model_goldens_regenerate_from_reference(tmp_path, monkeypatch, maker, fname):
     """Every model / transform golden is what the reference's own code produces NOW (build container only)."""
     import importlib.util
