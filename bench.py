@@ -171,17 +171,22 @@ def source_hashes():
 
 def cpu_baseline(sample_cells, min_seconds=10.0, max_iters=5):
     """The reference's CPU path for the same layer — oracle.layers.GNNLayer (torch-CPU mm + spmm + autograd,
-    a port of scdsc.py:475-501) — timed on this host's cores on a bounded sample of the workload."""
+    a port of scdsc.py:475-501; the AST-lifted reference class itself cannot travel to the GPU box) — timed on this host's
+    cores on a bounded sample of the workload drawn by the GPU leg's own generators (SURVEY 8(d) expression X with the same
+    seeds, rand-k15 rows, xavier W, fixed dY), down-sampled to ``sample_cells`` cells."""
     import numpy as np
     from oracle import layers as ol
-    torch.manual_seed(0)
     n = sample_cells
-    x = torch.randn(n, N_GENES)
+    cpu = torch.device("cpu")
+    x = synth_features(n, N_GENES, cpu, seed=100)
     layer = ol.GNNLayer(N_GENES, N_HIDDEN)
-    col = torch.randint(0, n, (n, K_NEIGH)).sort(dim=1).values.reshape(-1)
+    bound = (6.0 / (N_GENES + N_HIDDEN))**0.5
+    with torch.no_grad():
+        layer.weight.copy_((torch.rand((N_GENES, N_HIDDEN), generator=torch.Generator().manual_seed(2)) * 2 - 1) * bound)
+    _, col, val = synth_rand_graph(n, K_NEIGH, cpu, seed=1)
     row = torch.arange(n).repeat_interleave(K_NEIGH)
-    adj = torch.sparse_coo_tensor(torch.stack([row, col]), torch.full((n * K_NEIGH,), 1.0 / K_NEIGH), (n, n))
-    dy = torch.randn(n, N_HIDDEN)
+    adj = torch.sparse_coo_tensor(torch.stack([row, col.long()]), val, (n, n))
+    dy = torch.randn((n, N_HIDDEN), generator=torch.Generator().manual_seed(3))
 
     def step():
         layer.weight.grad = None
@@ -201,9 +206,10 @@ def cpu_baseline(sample_cells, min_seconds=10.0, max_iters=5):
         fj = json.load(open(fpath))
         full = {"value": fj["value"], "cores": fj["cores"], "source": "profiles/cpu_baseline_1M.json (bench.py --cpu-sample-cells 1000000 on a GPU box)"}
     return {"value": n / med, "unit": "cells/s", "cores": torch.get_num_threads(), "kind": "port", "full_workload_value": full,
-            "sample": f"{n} cells x {N_GENES} genes -> {N_HIDDEN}, rand k={K_NEIGH} graph, fp32, fwd+bwd, "
-                      f"median of {len(times)} iterations ({med * 1e3:.0f} ms each), torch-CPU "
-                      f"oracle.layers.GNNLayer",
+            "sample": f"{n} cells x {N_GENES} genes -> {N_HIDDEN} drawn by the GPU leg's generators (8(d) expression X, rand-k{K_NEIGH} graph, "
+                      f"same seeds), fp32, fwd+bwd, median of {len(times)} iterations ({med * 1e3:.0f} ms each); kind 'port' = "
+                      f"oracle.layers.GNNLayer on torch-CPU (a restatement of scdsc.py:475-501, not the reference class itself: "
+                      f"/root/reference does not exist on the bench box)",
             "host_cpu_count": os.cpu_count()}
 
 
@@ -271,6 +277,8 @@ def main():
     ap.add_argument("--no-knn-workload", action="store_true", help="skip the second (knn-k15) timed workload at 1 GPU")
     ap.add_argument("--no-x3-row", action="store_true", help="skip the separately labelled split-bf16 GEMM row at 1 GPU")
     ap.add_argument("--no-x-randn", action="store_true", help="skip the A/B leg with standard-normal X at 1 GPU")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the model-level rows of BASELINE configs 2, 3 and 5 (scripts/bench_configs.py; ~1.5 min at 1 GPU)")
     ap.add_argument("--exchange", choices=["auto", "halo", "allgather", "alltoall"], default="auto",
                     help="multi-GPU exchange (dance_amd/sharding.py); auto = time every mode, headline = the fastest")
     ap.add_argument("--emulate-rank", type=int, default=None, metavar="p",
@@ -524,6 +532,17 @@ def main():
             out["knn_k15"] = knn_out
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_cells)
+        if world == 1 and not args.no_configs and n == N_CELLS:
+            # model-level rows of the other BASELINE configs (2: ScDSC epoch at 100k / 1M, 3: ScDeepSort bf16 epoch, 5: SpaGCN iteration at
+            # 500k spots), each with its own roofline and CPU baseline; never the headline, never fatal
+            del x, dy, sg, w
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            try:
+                import bench_configs
+                out["configs"] = bench_configs.run_all(dev)
+            except Exception as e:  # noqa: BLE001
+                out["configs"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

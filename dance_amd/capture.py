@@ -13,7 +13,9 @@ them in place (``optimizer.zero_grad(set_to_none=False)``) instead of replacing 
 epoch's replays died with a GPU memory access fault from 100k cells x batch 128 upwards (toy sizes never showed it; holding extra
 references to the tensors — ``keep_alive`` / ``kept`` below, kept as a second line of defence — was not enough by itself, so the
 mechanism is the allocator's treatment of the graph's pool once eager gradients of the same parameters exist, not a plain
-use-after-free).  Regression test: tests/test_gpu_fullsize.py::test_captured_fits_survive_the_eager_last_batch."""
+use-after-free).  Regression test: tests/test_gpu_fullsize.py::test_captured_fits_survive_the_eager_last_batch.
+``CapturedStep(params=...)`` additionally ENFORCES the invariant: every replay first re-attaches the capture-time gradient tensors to
+parameters whose ``.grad`` was replaced in the meantime (tests/test_gpu_capture_invariant.py)."""
 from typing import Callable, Optional
 
 import torch
@@ -23,7 +25,7 @@ class CapturedStep:
 
     def __init__(self, forward_backward: Callable[[], object], optimiser_step: Callable[[], None], device, *,
                  between: Optional[Callable[[], None]] = None, split: bool = False, warmup: int = 2,
-                 keep_alive: Optional[Callable[[], list]] = None):
+                 keep_alive: Optional[Callable[[], list]] = None, params: Optional[list] = None):
         """``forward_backward()`` -> the step's static outputs (tensors that every replay refreshes); ``optimiser_step()`` applies the
         gradients; ``between()`` (split mode) runs eagerly between the two graphs — the gradient all-reduce.  The callables run
         ``warmup`` times on a side stream first (allocator, lazily created optimiser state), then are recorded.  The caller restores
@@ -53,8 +55,23 @@ class CapturedStep:
                 optimiser_step()
         torch.cuda.synchronize(device)
         self.kept = list(keep_alive()) if keep_alive is not None else []
+        # the invariant of the module docstring, enforced instead of assumed: ``params`` = the parameters whose ``.grad`` the graph
+        # writes.  Any eager code that replaced a gradient tensor since (``zero_grad()`` with its default set_to_none=True, user code,
+        # ``model.zero_grad()``) gets the capture-time tensor put back before the next replay — the eager gradient has been consumed by
+        # then (its optimiser step ran), and in split mode the all-reduce between the two graphs must see the tensors the graph wrote.
+        self._grads = [(p, p.grad) for p in (params or []) if p.grad is not None]
+
+    def restore_gradients(self) -> int:
+        """Re-attach the capture-time gradient tensors where eager code replaced them; returns how many were re-attached."""
+        n = 0
+        for p, g in self._grads:
+            if p.grad is not g:
+                p.grad = g
+                n += 1
+        return n
 
     def replay(self):
+        self.restore_gradients()
         self.graph.replay()
         if self.split:
             if self.between is not None:

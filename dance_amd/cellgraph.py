@@ -533,7 +533,12 @@ def _sampled_in_block(g: CellGeneGraph, seeds: torch.Tensor, fanout: int, genera
     # the kept edges in block order (block rows follow the seeds' order, a row's edges the graph's): their ids in the parent graph
     pos = torch.empty(n, dtype=torch.int64, device=dev)
     pos[seeds] = torch.arange(seeds.numel(), device=dev)
-    blk.edata["_ID"] = ek[torch.argsort(pos[node[srt]], stable=True)]
+    slots = ek[torch.argsort(pos[node[srt]], stable=True)]
+    # "_ID" = the parent graph's EDGE ids, as DGL's blocks carry them (index edata / edge-id-ordered arrays with it); "_SLOT" = the
+    # positions in the parent's CSR arrays (g.col / g.val).  The two coincide only on a graph whose CSR slots are in edge order
+    # (g.eid is None); a CellFeatureGraph's are not (its edge order is the reference's: cell->gene, gene->cell, self loops).
+    blk.edata["_SLOT"] = slots
+    blk.edata["_ID"] = slots if g.eid is None else g.eid[slots].to(torch.int64)
     return blk
 
 

@@ -218,8 +218,9 @@ extern "C" int dh_block_fill(int64_t n_nodes, int64_t n_seeds, const int64_t* se
 //   rows 0 .. B-1 : the seeds' in-edges, column = B + gene id, resp. the row's own index for the self loop
 //   row  B        : a padding row owning the unused tail [nnz, E_max) of the edge arrays (column 0, value 0): the CSR always has
 //                   exactly E_max entries and B + 1 rows, its transpose is well defined, the padding contributes zeros.
-// bad[0] is set when a seed is not a cell of that layout (a non-gene in-neighbour other than the seed itself, no self loop or more
-// than one, or more than E_max edges): the caller checks it once per epoch.
+// bad[0] collects flags, checked by the caller once per epoch: bit 1 = a seed is not a cell of that layout (a non-gene in-neighbour
+// other than the seed itself) or the block needs more than E_max edges; bit 2 = a seed without exactly one self loop (only a caller
+// that relies on the identity among a batch's own cells — graph-sc's decoder target — has to care).
 namespace {
 
 __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds, int64_t n_genes, int64_t e_max, const int64_t* __restrict__ seeds,
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds,
   if (i == n_seeds) {  // the padding row: one wavefront is enough for its bookkeeping, the tail itself is cleared below
     if (lane == 0) {
       brp[n_seeds + 1] = (int32_t)e_max;
-      if (nnz > e_max) bad[0] = 1;
+      if (nnz > e_max) atomicOr(bad, 1);
     }
     return;
   }
@@ -247,15 +248,16 @@ __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds,
     if (c < n_genes) bc = (int)n_seeds + c;
     else {
       bc = (int)i;
-      if (c != v) bad[0] = 1;
+      if (c != v) atomicOr(bad, 1);  // a cell -> cell edge other than the self loop: not a CellFeatureGraph row
     }
     n_self += __popcll(__ballot(c >= n_genes));
     bcol[o + e] = bc;
     bval[o + e] = val ? val[s + e] : 1.f;
   }
-  // the captured training steps take the decoder target among a batch's own cells to be the identity (graphsc.py:208-214 on a
-  // CellFeatureGraph: the only cell -> cell edges are the self loops): a seed row without exactly one self loop breaks that
-  if (lane == 0 && n_self != 1) bad[0] = 1;
+  // graph-sc's captured step takes the decoder target among a batch's own cells to be the identity (graphsc.py:208-214 on a
+  // CellFeatureGraph: the only cell -> cell edges are the self loops): a seed row without exactly one self loop breaks THAT, and only
+  // that — its own bit (2), which ScDeepSort's captured step (no decoder, no identity assumption) does not look at
+  if (lane == 0 && n_self != 1) atomicOr(bad, 2);
 }
 
 __global__ __launch_bounds__(256) void cells_static_pad_kernel(int64_t n_seeds, int64_t e_max, const int32_t* __restrict__ brp,

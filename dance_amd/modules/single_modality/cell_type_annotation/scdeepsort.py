@@ -215,7 +215,7 @@ class ScDeepSort(BaseClassificationMethod):
         block.seeds.copy_(first_seeds)
         g = CapturedStep(lambda: self._captured_forward_backward(block), self._captured_optimiser_step, first_seeds.device,
                          split=getattr(self, "_world", 1) > 1 or self.capture_split, between=lambda: sharding.allreduce_gradients(self.model),
-                         keep_alive=lambda: [p.grad for p in self.model.parameters() if p.grad is not None])
+                         keep_alive=lambda: [p.grad for p in self.model.parameters() if p.grad is not None], params=list(self.model.parameters()))
         loss = g.outputs
         self.model.load_state_dict(saved)       # in place: the graph keeps pointing at these tensors
         for st in self.optimizer.state.values():  # moments and step counters back to zero, in place
@@ -245,8 +245,9 @@ class ScDeepSort(BaseClassificationMethod):
                 block.seeds.copy_(idx[i * self.batch_size:(i + 1) * self.batch_size])
                 cg.replay()
                 loss_all[i].copy_(static_loss)
-            if int(block.bad) != 0:
-                raise RuntimeError("ScDeepSort.fit: a training seed is not a cell of a CellFeatureGraph-layout graph (set DANCE_AMD_HIPGRAPH=0)")
+            if int(block.bad) & 1:  # (bit 2, "no single self loop", only matters to graph-sc's identity decoder target)
+                raise RuntimeError("ScDeepSort.fit: a training seed has a non-gene in-neighbour other than itself, or a batch has more in-edges "
+                                   "than the static block holds — not a CellFeatureGraph-layout graph (set DANCE_AMD_HIPGRAPH=0 for the eager loop)")
             losses, sizes = list(loss_all.unbind(0)), [self.batch_size] * n_full
             tail = idx[n_full * self.batch_size:]
             batches = [self.sampler.sample(graph, tail, True)] if tail.numel() else []

@@ -382,7 +382,7 @@ class _CapturedStep:
         self.block.seeds.copy_(first_seeds)
         self.graph = CapturedStep(self._forward_backward, self._optimiser_step, first_seeds.device, split=split,
                                   between=lambda: sharding.allreduce_gradients(self.model),
-                                  keep_alive=lambda: [p.grad for p in self.model.parameters() if p.grad is not None])
+                                  keep_alive=lambda: [p.grad for p in self.model.parameters() if p.grad is not None], params=list(self.model.parameters()))
         self.emb, self.loss = self.graph.outputs
         self.model.load_state_dict(saved_model)  # copies INTO the captured parameter / buffer tensors
         for st in self.optim.state.values():      # the graph updates these very tensors: reset them in place (moments 0, step 0)

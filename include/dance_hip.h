@@ -427,8 +427,9 @@ DH_API int dh_block_fill(int64_t n_nodes, int64_t n_seeds, const int64_t* seeds,
  * the same layer outputs — and exactly e_max stored entries: rows 0..B-1 the seeds' in-edges (column = B + gene, or the row's own
  * index for the self loop), row B a padding row over the unused tail (column 0, value 0).  block_rowptr has B + 2 entries.  No
  * value is read back by the host, every shape is static: a training step over such a block (scdeepsort.py:183-262,
- * graphsc.py:181-218 at the reference's batch sizes) can be captured as one hipGraph.  bad[0] (int32, device) is set when a seed
- * does not have that layout or the block needs more than e_max entries.                                                      */
+ * graphsc.py:181-218 at the reference's batch sizes) can be captured as one hipGraph.  bad[0] (int32, device) collects flags:
+ * bit 1 = a seed does not have that layout or the block needs more than e_max entries, bit 2 = a seed without exactly one self
+ * loop (graph-sc's identity decoder target needs one; scDeepSort's step does not).                                             */
 DH_API size_t dh_block_cells_static_workspace_bytes(int64_t n_seeds);
 DH_API int dh_block_cells_static(int64_t n_seeds, int64_t n_genes, int64_t e_max, const int64_t* seeds, const int32_t* rowptr,
                           const int32_t* col, const float* val, int32_t* block_rowptr, int32_t* block_col, float* block_val,

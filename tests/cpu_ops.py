@@ -167,12 +167,14 @@ def block_cells_static(rowptr, col, val, seeds, n_genes, brp, bcol, bval, bad, w
     for i, s_ in enumerate(seeds.tolist()):
         cols = c[rp[s_]:rp[s_ + 1]]
         if ((cols >= n_genes) & (cols != s_)).any():
-            bad[0] = 1
+            bad[0] |= 1
+        if int((cols >= n_genes).sum()) != 1:   # bit 2: not exactly one self loop (only graph-sc's identity target needs that)
+            bad[0] |= 2
         oc.extend(np.where(cols < n_genes, b + cols, i).tolist())
         ov.extend((np.ones(len(cols), np.float32) if v is None else v[rp[s_]:rp[s_ + 1]]).tolist())
         out_rp.append(len(oc))
     if len(oc) > e_max:
-        bad[0] = 1
+        bad[0] |= 1
         return
     brp.copy_(torch.tensor(out_rp + [e_max], dtype=torch.int32))
     bcol.zero_()

@@ -65,9 +65,15 @@ def test_fanout_blocks_are_subsets_with_the_graphs_weights(cpu_kernels):
             assert len(set(src[sel])) == sel.sum()                                                  # without replacement
             for u, ww in zip(src[sel], w[sel]):
                 assert a[s, u] == ww                                                                # an edge of the graph, with its weight
-        # the edge ids point at those very entries of the parent CSR
-        eid = blk.edata["_ID"].numpy()
-        assert np.array_equal(g.col.numpy()[eid], src) and np.array_equal(g.val.numpy()[eid], w)
+        # "_SLOT" points at those very entries of the parent CSR; "_ID" holds the parent's EDGE ids of the same entries (DGL's
+        # meaning: on a CellFeatureGraph the CSR slots are not in edge order)
+        slot = blk.edata["_SLOT"].numpy()
+        assert np.array_equal(g.col.numpy()[slot], src) and np.array_equal(g.val.numpy()[slot], w)
+        want = slot if g.eid is None else g.eid.numpy()[slot]
+        assert np.array_equal(blk.edata["_ID"].numpy(), want)
+        if g.eid is not None:   # edge-id-ordered views of the parent give the same edges
+            e_src, e_dst = g.edges()
+            assert np.array_equal(e_src.numpy()[want], src)
     full = NeighborSampler([-1]).sample(g, seeds)[2][0]
     big = NeighborSampler([1000], generator=gen).sample(g, seeds)[2][0]
     assert torch.equal(full.rowptr, big.rowptr) and torch.equal(full.col, big.col) and torch.equal(full.val, big.val)
