@@ -32,6 +32,10 @@ def _declare(lib):
         "dh_spmm_csr_relu_rows_f32": (c_int, [i64, P, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_spmm_csr_relu_slices_f32": (c_int, [i64, P, i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, P]),
         "dh_spmm_csr_relu_slices_resident_f32": (c_int, [i64, P, i64, i64, i64, i64, P, P, P, P, i64, P, i64, P, i32, P, P, i32, P]),
+        "dh_student_t_supported": (c_int, [i64, i64]),
+        "dh_student_t_forward_f32": (c_int, [i64, i64, i64, P, i64, P, c_float, c_float, c_float, c_float, P, i64, P]),
+        "dh_student_t_backward_workspace_bytes": (c_size_t, [i64, i64, i64]),
+        "dh_student_t_backward_f32": (c_int, [i64, i64, i64, P, i64, P, c_float, c_float, c_float, c_float, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_relu_mask_apply_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
         "dh_gather_rows_f32": (c_int, [i64, i64, P, P, i64, P, P, i64, P]),
         "dh_csr_transpose_workspace_bytes": (c_size_t, [i64, i64, i64]),

@@ -520,3 +520,36 @@ class HipLinear(torch.nn.Linear):
 
     def forward(self, input, fuse_relu: bool = False):
         return linear(input, self.weight, self.bias, relu=fuse_relu, out_dtype=self.out_dtype)
+
+
+class _StudentTFn(torch.autograd.Function):
+    """q = normalise_j((1 / ((1 + ||z_i - mu_j||^2 / a) + eps))^pw * scale): the DEC heads' soft assignment on the fused kernel pair
+    dh_student_t_forward_f32 / dh_student_t_backward_f32 (csrc/student_t.hip) — no [N, C, d] broadcast tensor, forward or backward."""
+
+    @staticmethod
+    def forward(ctx, z, mu, a, eps, pw, scale):
+        z = z.contiguous() if z.stride(-1) != 1 else z
+        mu = mu.contiguous()
+        ctx.consts = (float(a), float(eps), float(pw), float(scale))
+        ctx.save_for_backward(z, mu)
+        return kernels.student_t_forward(z, mu, *ctx.consts)
+
+    @staticmethod
+    def backward(ctx, dq):
+        z, mu = ctx.saved_tensors
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            return None, None, None, None, None, None
+        dq = dq.contiguous() if dq.stride(-1) != 1 else dq
+        dz, dmu = kernels.student_t_backward(z, mu, *ctx.consts, dq, want_dz=ctx.needs_input_grad[0])
+        return dz, (dmu if ctx.needs_input_grad[1] else None), None, None, None, None
+
+
+def student_t_assign(z: torch.Tensor, mu: torch.Tensor, *, a: float, eps: float, pw: float, scale: float = 1.0) -> torch.Tensor:
+    """Soft cluster assignment of the DEC heads (SimpleGCDEC / GC_DEC: spagcn.py:394-396,605-607; ScDSCModel: scdsc.py:466-468), rows
+    normalised, differentiable in ``z`` and ``mu``.  Shapes the fused kernels do not cover (kernels.student_t_supported: more than 64 clusters, C d > 4096, wide embeddings; non-fp32)
+    take the reference's broadcast formulation in torch — same arithmetic, three tensors of N x C x d."""
+    if z.dtype == torch.float32 and mu.dtype == torch.float32 and kernels.student_t_supported(mu.shape[0], z.shape[1]):
+        return _StudentTFn.apply(z, mu, a, eps, pw, scale)
+    q = 1.0 / ((1.0 + torch.sum((z.unsqueeze(1) - mu)**2, dim=2) / a) + eps)
+    q = q**pw * scale
+    return q / torch.sum(q, dim=1, keepdim=True)

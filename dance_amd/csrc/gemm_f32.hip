@@ -540,8 +540,16 @@ Plan make_plan(int64_t M, int64_t N, int64_t K, int tile, bool rows_reduced) {
   if (tile == DH_GEMM_TILE_256) return big;
   const bool half_empty = (N % CfgLarge::BN != 0 && N % CfgLarge::BN <= CfgSmall::BN && N < 4 * CfgLarge::BN) ||
                           (M % CfgLarge::BM != 0 && M % CfgLarge::BM <= CfgSmall::BM && M < 4 * CfgLarge::BM);
-  if ((int64_t)big.n_tiles * big.S >= 512 && !half_empty) return big;
-  return plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN, rows_reduced);
+  Plan small = plan_for(M, N, K, CfgSmall::BM, CfgSmall::BN, rows_reduced);
+  if ((int64_t)big.n_tiles * big.S < 512 || half_empty) return small;
+  // Both fill the chip: take the one with fewer matrix-core ROUNDS.  A CU runs one 256 x 256 workgroup or two 128 x 128 ones, so a
+  // round costs (tile area x K-chunk) x 1 resp. x 2; the last round of a grid is a whole round however few tiles it holds.  At
+  // 100k x 2000 x 512 (BASELINE config 2) the 782 large tiles are 3.05 rounds = 4, the 3128 small ones 6.1 = 7 half-cost rounds:
+  // 1.91 -> 1.7 ms; at 1M rows both are 31 rounds and the large tile's ~1 % better loop wins (14.25 vs 14.39 ms).  The K order of
+  // an output element is the same in both configurations, so a forward product's bits do not depend on the choice.
+  const double cost_big = (double)dh::ceil_div((int64_t)big.n_tiles * big.S, (int64_t)256) * (double)big.k_chunk * 4.0;
+  const double cost_small = (double)dh::ceil_div((int64_t)small.n_tiles * small.S, (int64_t)512) * (double)small.k_chunk * 2.0 * 1.01;
+  return cost_small < cost_big ? small : big;
 }
 
 }  // namespace

@@ -1,0 +1,241 @@
+// Student-t soft assignment of the DEC clustering heads (SpaGCN's SimpleGCDEC / GC_DEC, spagcn.py:391-397,600-608; scDSC,
+// scdsc.py:466-468) as ONE kernel each way:
+//     d2_ij = ||z_i - mu_j||^2,   base_ij = 1 / ((1 + d2_ij / a) + eps),   u_ij = base_ij^pw * scale,   q_ij = u_ij / sum_j u_ij
+// The reference writes it with broadcasting — z.unsqueeze(1) - mu is an [N, C, d] tensor (1 GB at 500k spots x 10 x 50, 1.3 GB at 1M
+// cells x 10 x 32), written, squared, summed, and walked again by autograd: at BASELINE config 5 the head cost 4.1 of an iteration's
+// 4.8 ms, six times the layer's own two kernels (profiles/r05e_configs.json).  Here z is read once per pass (N d floats), q written
+// once (N C floats), nothing of size N C d exists.  HBM-bound by N (d + C) 4 bytes forward, N (2 d + 2 C) 4 backward.
+//
+// Mapping: one thread per row, 128 rows per block.  mu (C x d <= 4096 floats) sits in LDS and is read as a broadcast (every lane the
+// same address); the block's rows of z are brought into LDS with coalesced loads and walked per lane (odd row stride: no bank
+// conflicts) ONCE per group of 16 clusters, whose squared distances accumulate in registers.  The backward recomputes base / u / S
+// from z and mu instead of storing them, forms
+//     c_ij = dL / d d2_ij = -(G_ij - sum_k G_ik q_ik) q_ij pw base_ij / a,
+//     dz_i = 2 (z_i sum_j c_ij - sum_j c_ij mu_j),     dmu_j = -2 (sum_i c_ij z_i - mu_j sum_i c_ij)
+// keeps the row's c_ij in LDS, and reduces dmu over the block's rows with the threads re-dealt over (j, t) pairs (coalesced reads of
+// the rows the block just touched); block partials are summed by a second kernel in block order — no float atomics, deterministic.
+#include "common.h"
+
+namespace {
+
+constexpr int ST_ROWS = 128;   // rows (= threads) per block
+constexpr int ST_MAX_C = 64;
+constexpr int ST_MAX_CD = 4096;
+// LDS of the backward kernel: mu + the rows' coefficients + the rows of z, within the 64 KB a launch gets without opting in
+__host__ __device__ constexpr int64_t st_lds_floats(int64_t c, int64_t d) { return c * d + ST_ROWS * (c | 1) + ST_ROWS * (d | 1); }
+constexpr int64_t ST_MAX_LDS_FLOATS = 16384;
+
+struct StParams {
+  float a, eps, pw, scale;
+};
+
+__device__ __forceinline__ float st_base(float d2, const StParams& p) { return 1.f / ((1.f + d2 / p.a) + p.eps); }
+
+constexpr int ST_CG = 16;  // clusters whose squared distances a lane accumulates in registers during one walk over its row
+
+// d2[jj] = ||z_row - mu_(g0 + jj)||^2 for jj < ST_CG: ONE walk over the row (the first version walked it once per cluster: C d loads
+// per row per pass made the kernels texture-path-bound: 0.71 / 1.70 ms forward / backward at 500k x 10 x 50 instead of ~0.1).
+// zr: the lane's row, in global memory (stride 1) or in the block's LDS tile; clusters past c repeat the last one (ignored by the caller).
+__device__ __forceinline__ void st_dist_group(float (&d2)[ST_CG], const float* __restrict__ zr, const float* __restrict__ mu, int g0, int c, int d) {
+#pragma unroll
+  for (int jj = 0; jj < ST_CG; ++jj) d2[jj] = 0.f;
+  for (int t = 0; t < d; ++t) {
+    const float z = zr[t];
+#pragma unroll
+    for (int jj = 0; jj < ST_CG; ++jj) {
+      const int j = min(g0 + jj, c - 1);
+      const float diff = z - mu[j * d + t];
+      d2[jj] = fmaf(diff, diff, d2[jj]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(ST_ROWS) void student_t_forward_kernel(int64_t n, int c, int d, const float* __restrict__ Z, int64_t ldz,
+                                                                    const float* __restrict__ MU, StParams p, float* __restrict__ Q, int64_t ldq) {
+  extern __shared__ float smem[];  // mu [c][d], then the block's rows of z [ST_ROWS][d | 1] (coalesced in, walked per lane without bank conflicts)
+  float* mu = smem;
+  const int zs = d | 1;
+  float* zt = smem + c * d;
+  for (int i = threadIdx.x; i < c * d; i += ST_ROWS) mu[i] = MU[i];
+  const int64_t row0 = (int64_t)blockIdx.x * ST_ROWS;
+  const int rows_here = (int)min((int64_t)ST_ROWS, n - row0);
+  for (int i = threadIdx.x; i < rows_here * d; i += ST_ROWS) {
+    const int r = i / d, t = i - r * d;
+    zt[r * zs + t] = Z[(row0 + r) * ldz + t];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x >= rows_here) return;
+  const float* zr = zt + threadIdx.x * zs;
+  float* qr = Q + (row0 + threadIdx.x) * ldq;
+  float s = 0.f;
+  for (int g0 = 0; g0 < c; g0 += ST_CG) {
+    float d2[ST_CG];
+    st_dist_group(d2, zr, mu, g0, c, d);
+#pragma unroll
+    for (int jj = 0; jj < ST_CG; ++jj)
+      if (g0 + jj < c) {
+        const float u = powf(st_base(d2[jj], p), p.pw) * p.scale;
+        qr[g0 + jj] = u;
+        s += u;
+      }
+  }
+  for (int j = 0; j < c; ++j) qr[j] = qr[j] / s;  // the row just written by this lane: L1 / L2 resident
+}
+
+// dZ (may be null), and this block's partial of dMU: part[block][c * d + c] = [sum_i c_ij z_it | sum_i c_ij]
+__global__ __launch_bounds__(ST_ROWS) void student_t_backward_kernel(int64_t n, int c, int d, const float* __restrict__ Z, int64_t ldz,
+                                                                     const float* __restrict__ MU, StParams p, const float* __restrict__ G,
+                                                                     int64_t ldg, float* __restrict__ dZ, int64_t lddz, float* __restrict__ part) {
+  extern __shared__ float smem[];
+  const int cs_ = c | 1, zs = d | 1;   // odd row strides: a lane walking its own row hits its own bank
+  float* mu = smem;                    // [c][d]
+  float* cf = smem + c * d;            // [ST_ROWS][c | 1]  the rows' squared distances, then their c_ij (0 for rows past n)
+  float* zt = cf + ST_ROWS * cs_;      // [ST_ROWS][d | 1]  the block's rows of z
+  for (int i = threadIdx.x; i < c * d; i += ST_ROWS) mu[i] = MU[i];
+  const int64_t row0 = (int64_t)blockIdx.x * ST_ROWS;
+  const int rows_here = (int)min((int64_t)ST_ROWS, n - row0);
+  for (int i = threadIdx.x; i < rows_here * d; i += ST_ROWS) {
+    const int r = i / d, t = i - r * d;
+    zt[r * zs + t] = Z[(row0 + r) * ldz + t];
+  }
+  __syncthreads();
+  float* my_c = cf + threadIdx.x * cs_;
+  if ((int)threadIdx.x < rows_here) {
+    const int64_t row = row0 + threadIdx.x;
+    const float* zr = zt + threadIdx.x * zs;
+    const float* gr = G + row * ldg;
+    float s = 0.f, t_gq = 0.f;
+    for (int g0 = 0; g0 < c; g0 += ST_CG) {   // pass 1: distances (kept in LDS), S, sum_j G_j u_j
+      float d2[ST_CG];
+      st_dist_group(d2, zr, mu, g0, c, d);
+#pragma unroll
+      for (int jj = 0; jj < ST_CG; ++jj)
+        if (g0 + jj < c) {
+          const float u = powf(st_base(d2[jj], p), p.pw) * p.scale;
+          my_c[g0 + jj] = d2[jj];
+          s += u;
+          t_gq = fmaf(gr[g0 + jj], u, t_gq);
+        }
+    }
+    const float rs = 1.f / s;
+    t_gq *= rs;                        // sum_k G_k q_k
+    float csum = 0.f;
+    for (int j = 0; j < c; ++j) {      // pass 2: c_j from the stored distance
+      const float base = st_base(my_c[j], p);
+      const float q = powf(base, p.pw) * p.scale * rs;
+      const float cj = -(gr[j] - t_gq) * q * p.pw * base / p.a;
+      my_c[j] = cj;
+      csum += cj;
+    }
+    if (dZ) {
+      float* dzr = dZ + row * lddz;
+      for (int t = 0; t < d; ++t) {
+        float acc = zr[t] * csum;
+        for (int j = 0; j < c; ++j) acc = fmaf(-my_c[j], mu[j * d + t], acc);
+        dzr[t] = 2.f * acc;
+      }
+    }
+  } else {
+    for (int j = 0; j < c; ++j) my_c[j] = 0.f;
+  }
+  __syncthreads();
+  // the block's share of dMU: pairs (j, t) dealt over the threads, rows in order (deterministic); column d of a cluster = sum_i c_ij
+  float* out = part + (int64_t)blockIdx.x * (c * d + c);
+  for (int pair = threadIdx.x; pair < c * d; pair += ST_ROWS) {
+    const int j = pair / d, t = pair - j * d;
+    float acc = 0.f;
+    for (int i = 0; i < rows_here; ++i) acc = fmaf(cf[i * cs_ + j], zt[i * zs + t], acc);
+    out[pair] = acc;
+  }
+  for (int j = threadIdx.x; j < c; j += ST_ROWS) {
+    float acc = 0.f;
+    for (int i = 0; i < rows_here; ++i) acc += cf[i * cs_ + j];
+    out[c * d + j] = acc;
+  }
+}
+
+// dMU[j][t] = -2 (sum_blocks part[b][j d + t] - mu[j][t] sum_blocks part[b][c d + j]): one workgroup per (j, t); thread i sums the
+// blocks i, i + 256, ... in order, then a fixed tree over the 256 partial sums (deterministic)
+__global__ __launch_bounds__(256) void student_t_reduce_kernel(int64_t n_blocks, int c, int d, const float* __restrict__ part,
+                                                               const float* __restrict__ MU, float* __restrict__ dMU) {
+  __shared__ float red[2][256];
+  const int pair = blockIdx.x;
+  const int j = pair / d;
+  const int64_t stride = (int64_t)c * d + c;
+  float cz = 0.f, cs = 0.f;
+  for (int64_t b = threadIdx.x; b < n_blocks; b += 256) {
+    cz += part[b * stride + pair];
+    cs += part[b * stride + (int64_t)c * d + j];
+  }
+  red[0][threadIdx.x] = cz;
+  red[1][threadIdx.x] = cs;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) dMU[pair] = -2.f * (red[0][0] - MU[pair] * red[1][0]);
+}
+
+int st_check(const char* me, int64_t n, int64_t c, int64_t d, const void* Z, int64_t ldz, const void* MU, float a) {
+  if (n < 0 || c <= 0 || d <= 0) return dh::fail(DH_ERR_INVALID, "%s: bad size", me);
+  if (c > ST_MAX_C || c * d > ST_MAX_CD || st_lds_floats(c, d) > ST_MAX_LDS_FLOATS)
+    return dh::fail(DH_ERR_INVALID, "%s: at most %d clusters, %d cluster x feature entries and c d + 128 (c + d + 2) <= %lld (dh_student_t_supported)", me,
+                    ST_MAX_C, ST_MAX_CD, (long long)ST_MAX_LDS_FLOATS);
+  if (n > 0 && (!Z || !MU)) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (ldz < d) return dh::fail(DH_ERR_INVALID, "%s: leading dimension < d", me);
+  if (!(a > 0.f)) return dh::fail(DH_ERR_INVALID, "%s: the kernel's degrees-of-freedom parameter must be positive", me);
+  return DH_OK;
+}
+
+}  // namespace
+
+extern "C" int dh_student_t_supported(int64_t c, int64_t d) {
+  return (c > 0 && d > 0 && c <= ST_MAX_C && c * d <= ST_MAX_CD && st_lds_floats(c, d) <= ST_MAX_LDS_FLOATS) ? 1 : 0;
+}
+
+extern "C" int dh_student_t_forward_f32(int64_t n, int64_t c, int64_t d, const float* Z, int64_t ldz, const float* MU, float a, float eps,
+                                        float pw, float scale, float* Q, int64_t ldq, dh_stream_t stream) {
+  const char* me = "dh_student_t_forward_f32";
+  int rc = st_check(me, n, c, d, Z, ldz, MU, a);
+  if (rc != DH_OK) return rc;
+  if (n == 0) return DH_OK;
+  if (!Q || ldq < c) return dh::fail(DH_ERR_INVALID, "%s: bad output", me);
+  hipLaunchKernelGGL(student_t_forward_kernel, dim3((unsigned)dh::ceil_div(n, ST_ROWS)), dim3(ST_ROWS), (size_t)(c * d + ST_ROWS * (d | 1)) * sizeof(float),
+                     dh::as_stream(stream), n, (int)c, (int)d, Z, ldz, MU, StParams{a, eps, pw, scale}, Q, ldq);
+  return dh::check_launch(me);
+}
+
+extern "C" size_t dh_student_t_backward_workspace_bytes(int64_t n, int64_t c, int64_t d) {
+  if (n <= 0 || c <= 0 || d <= 0) return 0;
+  return (size_t)dh::ceil_div(n, ST_ROWS) * (size_t)(c * d + c) * sizeof(float);
+}
+
+extern "C" int dh_student_t_backward_f32(int64_t n, int64_t c, int64_t d, const float* Z, int64_t ldz, const float* MU, float a, float eps,
+                                         float pw, float scale, const float* G, int64_t ldg, float* dZ, int64_t lddz, float* dMU,
+                                         void* workspace, size_t workspace_bytes, dh_stream_t stream) {
+  const char* me = "dh_student_t_backward_f32";
+  int rc = st_check(me, n, c, d, Z, ldz, MU, a);
+  if (rc != DH_OK) return rc;
+  if (!dMU) return dh::fail(DH_ERR_INVALID, "%s: null dMU", me);
+  hipStream_t st = dh::as_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(dMU, 0, (size_t)(c * d) * sizeof(float), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
+    return DH_OK;
+  }
+  if (!G || ldg < c || (dZ && lddz < d)) return dh::fail(DH_ERR_INVALID, "%s: bad gradient operands", me);
+  const size_t need = dh_student_t_backward_workspace_bytes(n, c, d);
+  if (!workspace || workspace_bytes < need) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, workspace_bytes, need);
+  const int64_t n_blocks = dh::ceil_div(n, ST_ROWS);
+  const size_t lds = (size_t)st_lds_floats(c, d) * sizeof(float);
+  hipLaunchKernelGGL(student_t_backward_kernel, dim3((unsigned)n_blocks), dim3(ST_ROWS), lds, st, n, (int)c, (int)d, Z, ldz, MU,
+                     StParams{a, eps, pw, scale}, G, ldg, dZ, lddz, static_cast<float*>(workspace));
+  rc = dh::check_launch(me);
+  if (rc != DH_OK) return rc;
+  hipLaunchKernelGGL(student_t_reduce_kernel, dim3((unsigned)(c * d)), dim3(256), 0, st, n_blocks, (int)c, (int)d,
+                     static_cast<const float*>(workspace), MU, dMU);
+  return dh::check_launch("dh_student_t_backward_f32(reduce)");
+}

@@ -8,6 +8,7 @@
 //      every output row ordered by source row, i.e. bit-identical to scipy's tocsc();
 //   2. out_rowptr[j] = lower_bound(sorted columns, j)            (hand-written, one thread per j)
 //   3. out_col[p] = row owning nnz position perm[p] (upper_bound on rowptr), out_val gathered.
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -54,6 +55,81 @@ __global__ __launch_bounds__(256) void gather_transposed_kernel(int64_t n_rows, 
   }
 }
 
+// Small graphs — the message-flow block of a mini-batch (129 rows of ~200 entries, transposed once per training step inside a captured
+// hipGraph, where the sort-based path is 12 dependent launches of ~5 us each) — in ONE workgroup: histogram of the columns in LDS,
+// block-wide exclusive scan (= out_rowptr), then the rows placed ONE AFTER THE OTHER (a barrier per row), all entries of a row at once
+// through LDS cursors.  Rows in ascending order make every output row ascending by source row, which is what the stable sort
+// produces; entries of one row have distinct columns in every graph of this package (a multi-edge would land next to its twin in
+// arrival order).  Inconsistent input (a column >= n_cols, more entries than the caller's nnz) is skipped instead of written out of
+// bounds; -DDH_TRANSPOSE_DEBUG reports it (the diagnosis build of round 5's replay-fault hunt).
+constexpr int SMALL_T = 1024;
+__global__ __launch_bounds__(SMALL_T) void csr_transpose_small_kernel(int n_rows, int n_cols, int nnz_cap, const int32_t* __restrict__ rowptr,
+                                                                      const int32_t* __restrict__ col, const float* __restrict__ val,
+                                                                      int32_t* __restrict__ out_rowptr, int32_t* __restrict__ out_col,
+                                                                      float* __restrict__ out_val, int32_t* __restrict__ out_perm) {
+  extern __shared__ int cursor[];  // [n_cols + 1] counts -> segment starts -> running cursors
+  __shared__ int wave_tot[SMALL_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nnz = min(rowptr[n_rows], nnz_cap);  // never beyond the buffers the caller sized for nnz_cap entries
+#ifdef DH_TRANSPOSE_DEBUG
+  if (tid == 0 && rowptr[n_rows] != nnz_cap) printf("csr_transpose_small: rowptr[%d] = %d but the caller said nnz = %d\n", n_rows, rowptr[n_rows], nnz_cap);
+#endif
+  for (int i = tid; i <= n_cols; i += SMALL_T) cursor[i] = 0;
+  __syncthreads();
+  for (int e = tid; e < nnz; e += SMALL_T) {
+    const int c = col[e];
+    if ((unsigned)c < (unsigned)n_cols) atomicAdd(&cursor[c], 1);
+#ifdef DH_TRANSPOSE_DEBUG
+    else printf("csr_transpose_small: column %d at entry %d outside [0, %d) (nnz %d of cap %d, rows %d)\n", c, e, n_cols, nnz, nnz_cap, n_rows);
+#endif
+  }
+  __syncthreads();
+  // exclusive scan of cursor[0 .. n_cols]: a contiguous chunk per thread, then the threads' sums across the block
+  const int per = (n_cols + 1 + SMALL_T - 1) / SMALL_T;
+  const int b = tid * per, e_ = min(n_cols + 1, b + per);
+  int sum = 0;
+  for (int i = b; i < e_; ++i) sum += cursor[i];
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d, 64);
+    if (lane >= d) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  for (int i = b; i < e_; ++i) {
+    const int c = cursor[i];
+    cursor[i] = base;
+    out_rowptr[i] = base;
+    base += c;
+  }
+  __syncthreads();
+  for (int r = 0; r < n_rows; ++r) {
+    const int rs = rowptr[r], re = min(rowptr[r + 1], nnz);
+    for (int e = rs + tid; e < re; e += SMALL_T) {
+      const int c = col[e];
+      if ((unsigned)c >= (unsigned)n_cols) continue;
+      const int pos = atomicAdd(&cursor[c], 1);
+      if (pos >= nnz) {
+#ifdef DH_TRANSPOSE_DEBUG
+        printf("csr_transpose_small: cursor %d of column %d past nnz %d (row %d entry %d)\n", pos, c, nnz, r, e);
+#endif
+        continue;
+      }
+      out_col[pos] = r;
+      out_perm[pos] = e;
+      if (out_val) out_val[pos] = val[e];
+    }
+    __syncthreads();
+  }
+}
+bool transpose_small_applies(int64_t n_rows, int64_t n_cols, int64_t nnz) {
+  static const bool on = getenv("DANCE_AMD_TRANSPOSE_SMALL") && getenv("DANCE_AMD_TRANSPOSE_SMALL")[0] == '1';  // round-5 switch, default off
+  return on && n_rows <= 2048 && n_cols <= 12000 && nnz <= 262144;
+}
+
 int end_bit_for(int64_t n_cols) {
   int b = 1;
   while (((int64_t)1 << b) < n_cols && b < 31) ++b;
@@ -98,6 +174,11 @@ extern "C" int dh_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, con
   }
   if (!rowptr || !col || !out_col || !out_perm)
     return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: null pointer");
+  if (transpose_small_applies(n_rows, n_cols, nnz)) {
+    hipLaunchKernelGGL(csr_transpose_small_kernel, dim3(1), dim3(SMALL_T), (size_t)(n_cols + 1) * sizeof(int), st, (int)n_rows, (int)n_cols, (int)nnz,
+                       rowptr, col, val, out_rowptr, out_col, out_val, out_perm);
+    return dh::check_launch("dh_csr_transpose");
+  }
   const size_t need = dh_csr_transpose_workspace_bytes(n_rows, n_cols, nnz);
   if (!workspace || workspace_bytes < need)
     return dh::fail(DH_ERR_WORKSPACE, "dh_csr_transpose: workspace %zu < %zu bytes", workspace_bytes, need);

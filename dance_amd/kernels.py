@@ -186,6 +186,35 @@ def spmm_csr_relu(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
     return out
 
 
+def student_t_supported(n_clusters: int, d: int) -> bool:
+    """Shapes the fused Student-t head covers (dh_student_t_supported)."""
+    return bool(_lib.load().dh_student_t_supported(int(n_clusters), int(d)))
+
+
+def student_t_forward(Z: torch.Tensor, MU: torch.Tensor, a: float, eps: float, pw: float, scale: float) -> torch.Tensor:
+    """q[i, j] of the DEC heads from the embedding Z [N, d] and the centres MU [C, d] (dh_student_t_forward_f32)."""
+    lib = _lib_ready()
+    q = torch.empty((Z.shape[0], MU.shape[0]), dtype=torch.float32, device=Z.device)
+    _call("student_t_forward_f32", lib.dh_student_t_forward_f32, Z.shape[0], MU.shape[0], Z.shape[1], _dev(Z, torch.float32, "Z", 2), _ld(Z),
+          _dev(MU, torch.float32, "MU", 2), float(a), float(eps), float(pw), float(scale), q.data_ptr(), _ld(q), _stream())
+    return q
+
+
+def student_t_backward(Z: torch.Tensor, MU: torch.Tensor, a: float, eps: float, pw: float, scale: float, G: torch.Tensor, *,
+                       want_dz: bool = True) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """(dZ or None, dMU) from G = d loss / d q (dh_student_t_backward_f32)."""
+    lib = _lib_ready()
+    n, c, d = Z.shape[0], MU.shape[0], Z.shape[1]
+    dz = torch.empty_like(Z) if want_dz else None
+    dmu = torch.empty_like(MU)
+    ws_bytes = lib.dh_student_t_backward_workspace_bytes(n, c, d)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=Z.device)
+    _call("student_t_backward_f32", lib.dh_student_t_backward_f32, n, c, d, _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(MU, torch.float32, "MU", 2),
+          float(a), float(eps), float(pw), float(scale), _dev(G, torch.float32, "G", 2), _ld(G), None if dz is None else dz.data_ptr(),
+          0 if dz is None else _ld(dz), dmu.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+    return dz, dmu
+
+
 def gather_rows(X: torch.Tensor, idx: torch.Tensor, *, relu_mask: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[i] = X[idx[i]] (optionally times the ReLU sign mask recorded for X's rows): dh_gather_rows_f32."""

@@ -15,7 +15,7 @@ from torch import nn, optim
 from torch.nn.parameter import Parameter
 
 from .... import kernels
-from ....autograd import dense_adj_layer, gcn_layer
+from ....autograd import dense_adj_layer, gcn_layer, student_t_assign
 from ....graph import CSRGraph, as_graph
 from ....sharding import ShardedGCNGraph, sharded_gcn_layer
 from ....transforms import CellPCA, Compose, SetConfig
@@ -126,10 +126,9 @@ class SimpleGCDEC(nn.Module):
 
     def forward(self, x, adj):
         x = self.gc(x, adj)
-        # Student-t kernel exactly as written in the reference (:394-396), including q**(alpha+1)/2 precedence
-        q = 1.0 / ((1.0 + torch.sum((x.unsqueeze(1) - self.mu)**2, dim=2) / self.alpha) + 1e-8)
-        q = q**(self.alpha + 1.0) / 2.0
-        q = q / torch.sum(q, dim=1, keepdim=True)
+        # Student-t kernel exactly as written in the reference (:394-396), including the q**(alpha+1)/2 precedence — on the fused
+        # kernel pair (no [N, C, d] broadcast tensor: it was 4.1 of an iteration's 4.8 ms at 500k spots)
+        q = student_t_assign(x, self.mu, a=self.alpha, eps=1e-8, pw=self.alpha + 1.0, scale=0.5)
         return x, q
 
     # Sharded training (``adj`` is a ``ShardedGCNGraph``; one process per GPU): X, q, p are this rank's rows; the reductions
@@ -312,9 +311,7 @@ class GC_DEC(SimpleGCDEC):
 
     def forward(self, x, adj):
         x = self.gc(x, adj)
-        q = 1.0 / ((1.0 + torch.sum((x.unsqueeze(1) - self.mu)**2, dim=2) / self.alpha) + 1e-6)
-        q = q**(self.alpha + 1.0) / 2.0
-        q = q / torch.sum(q, dim=1, keepdim=True)
+        q = student_t_assign(x, self.mu, a=self.alpha, eps=1e-6, pw=self.alpha + 1.0, scale=0.5)   # :605-607
         return x, q
 
     def fit(self, X, adj, lr=0.001, epochs=10, update_interval=5, weight_decay=5e-4, opt="sgd", init="louvain", n_neighbors=10, res=0.4):

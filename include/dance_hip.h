@@ -116,6 +116,18 @@ DH_API int dh_spmm_csr_relu_slices_resident_f32(int64_t n_list, const int32_t* r
                          const int32_t* rowptr, const int32_t* col, const float* val,
                          const float* Z, int64_t ldz, float* Y, int64_t ldy, const float* bias, int act,
                          void* out_mask, const void* in_mask, int resident_workgroups, dh_stream_t stream);
+/* Student-t soft assignment of the DEC clustering heads — q = normalise_j((1 / ((1 + ||z_i - mu_j||^2 / a) + eps))^pw * scale) — and its
+ * backward (dZ may be NULL; dMU is always produced) without the [N, C, d] broadcast tensor the reference materialises:
+ * SimpleGCDEC.forward (spagcn.py:391-397: a = alpha, eps = 1e-8, pw = alpha + 1, scale = 1/2), GC_DEC.forward (:600-608: eps = 1e-6),
+ * ScDSCModel.forward (scdsc.py:466-468: a = v, eps = 0, pw = (v + 1) / 2, scale = 1).  c <= 64 clusters, c * d <= 4096 and
+ * c d + 128 (c + d + 2) <= 16384 floats of LDS (dh_student_t_supported; e.g. 10 x 50, 20 x 60, 32 x 40).  G = d loss / d q.  Deterministic (block partials of dMU summed in a fixed order).                   */
+DH_API int dh_student_t_supported(int64_t c, int64_t d);
+DH_API int dh_student_t_forward_f32(int64_t n, int64_t c, int64_t d, const float* Z, int64_t ldz, const float* MU, float a, float eps,
+                         float pw, float scale, float* Q, int64_t ldq, dh_stream_t stream);
+DH_API size_t dh_student_t_backward_workspace_bytes(int64_t n, int64_t c, int64_t d);
+DH_API int dh_student_t_backward_f32(int64_t n, int64_t c, int64_t d, const float* Z, int64_t ldz, const float* MU, float a, float eps,
+                         float pw, float scale, const float* G, int64_t ldg, float* dZ, int64_t lddz, float* dMU,
+                         void* workspace, size_t workspace_bytes, dh_stream_t stream);
 DH_API int dh_gather_rows_f32(int64_t n, int64_t width, const int32_t* idx, const float* X, int64_t ldx,
                        const void* relu_mask, float* out, int64_t ldo, dh_stream_t stream);
 /* out = X * [Y > 0] from the recorded sign mask of Y (dh_relu_mask_bytes layout; width % 128 == 0): autograd's ReluBackward

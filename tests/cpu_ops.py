@@ -502,7 +502,8 @@ STAND_INS = ("adam_step", "degree_scales", "block_cells_static", "block_cells_st
              "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
-             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward")
+             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward",
+             "student_t_supported", "student_t_forward", "student_t_backward")
 
 
 def degree_scales(rowptr, col, n_rows, n_cols, mode=0, *, n_pad=0):
@@ -521,3 +522,25 @@ def adam_step(optimizer):
     """Stand-in of kernels.adam_step: the framework's own step (what the kernel reproduces)."""
     optimizer.step()
     return True
+
+
+def student_t_supported(n_clusters, d):
+    return n_clusters <= 64 and n_clusters * d <= 4096 and n_clusters * d + 128 * ((n_clusters | 1) + (d | 1)) <= 16384
+
+
+def _student_t(z, mu, a, eps, pw, scale):
+    q = 1.0 / ((1.0 + torch.sum((z.unsqueeze(1) - mu)**2, dim=2) / a) + eps)
+    q = q**pw * scale
+    return q / torch.sum(q, dim=1, keepdim=True)
+
+
+def student_t_forward(Z, MU, a, eps, pw, scale):
+    """dh_student_t_forward_f32 restated as the reference writes it (spagcn.py:394-396, scdsc.py:466-468)."""
+    return _student_t(Z, MU, a, eps, pw, scale)
+
+
+def student_t_backward(Z, MU, a, eps, pw, scale, G, *, want_dz=True):
+    with torch.enable_grad():
+        z, mu = Z.detach().clone().requires_grad_(True), MU.detach().clone().requires_grad_(True)
+        _student_t(z, mu, a, eps, pw, scale).backward(G)
+    return (z.grad if want_dz else None), mu.grad

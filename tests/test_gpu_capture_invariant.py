@@ -12,12 +12,12 @@ def test_replay_reattaches_replaced_gradients(cuda_device, split):
     from dance_amd.capture import CapturedStep
     torch.manual_seed(0)
     model = torch.nn.Linear(8, 4).to(cuda_device)
-    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
     x = torch.randn(16, 8, device=cuda_device)
     seen = []
 
     def fwd_bwd():
-        loss = model(x).square().sum()
+        loss = model(x).square().mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
         return loss.detach()
@@ -35,11 +35,11 @@ def test_replay_reattaches_replaced_gradients(cuda_device, split):
     opt.zero_grad()                       # set_to_none=True
     model(x).sum().backward()
     assert all(p.grad is not g for p, g in zip(model.parameters(), captured))
-    loss_before = float(model(x).square().sum())
+    loss_before = float(model(x).detach().square().mean())
     step.replay()                         # re-attaches, then replays
     torch.cuda.synchronize()
     assert all(p.grad is g for p, g in zip(model.parameters(), captured))
     assert [p.grad.data_ptr() for p in model.parameters()] == ptrs
     if split:
         assert seen and all(s == ptrs for s in seen)   # the between() hook (the all-reduce) saw the graph's own tensors, every time
-    assert float(model(x).square().sum()) < loss_before  # the replayed step still trains
+    assert float(model(x).detach().square().mean()) < loss_before  # the replayed step still trains

@@ -348,8 +348,10 @@ def _spagcn_worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import cpu_ops
-    from dance_amd import sharding
+    from dance_amd import kernels, sharding
     from dance_amd.modules.spatial.spatial_domain.spagcn import SimpleGCDEC
+    for name in cpu_ops.STAND_INS:  # the head's fused Student-t kernels (and whatever else the model calls) on the host
+        setattr(kernels, name, getattr(cpu_ops, name))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
