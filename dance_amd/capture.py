@@ -21,6 +21,19 @@ from typing import Callable, Optional
 import torch
 
 
+def kernel_copy_(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """``dst.copy_(src)`` as an elementwise KERNEL.  ``Tensor.copy_`` / ``clone`` of contiguous same-dtype tensors are hipMemcpyAsync
+    calls, which a capture records as memcpy NODES (and ``zero_()`` / hipMemsetAsync as memset nodes).  On ROCm 7.2 / gfx950 such a
+    node was replayed with the wrong extent and fill pattern once eager copies had run between two replays (round 5's fault hunt,
+    profiles/r05_replay_fault.md), so code that runs under capture moves data with kernels only."""
+    return torch.add(src, 0, out=dst)
+
+
+def kernel_clone(x: torch.Tensor) -> torch.Tensor:
+    """``x.clone()`` as an elementwise kernel (see ``kernel_copy_``)."""
+    return torch.add(x, 0)
+
+
 class CapturedStep:
 
     def __init__(self, forward_backward: Callable[[], object], optimiser_step: Callable[[], None], device, *,

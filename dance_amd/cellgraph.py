@@ -458,7 +458,8 @@ class StaticCellBlock(Block):
     def rebuild(self):
         """Refill the buffers for the ids currently in ``self.seeds`` (device only; capturable)."""
         from . import kernels
-        self.src_ids[:self.batch].copy_(self.seeds)
+        from .capture import kernel_copy_
+        kernel_copy_(self.src_ids[:self.batch], self.seeds)  # a kernel, not a memcpy node (capture.py)
         kernels.block_cells_static(self.parent.rowptr, self.parent.col, self.parent.val, self.seeds, self.n_genes, self.rowptr, self.col, self.val,
                                    self.bad, self._ws)
         self.__dict__.pop("_wgc_scales", None)  # per-batch caches of the layers

@@ -168,7 +168,7 @@ extern "C" int dh_block_plan(int64_t n_nodes, int64_t n_seeds, const int64_t* se
   if (!block_rowptr || !totals) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
   hipStream_t st = dh::as_stream(stream);
   if (n_seeds == 0 || n_nodes == 0) {
-    if (hipMemsetAsync(block_rowptr, 0, sizeof(int32_t), st) != hipSuccess || hipMemsetAsync(totals, 0, 2 * sizeof(int32_t), st) != hipSuccess)
+    if (dh::zero_async(block_rowptr, sizeof(int32_t), st) != hipSuccess || dh::zero_async(totals, 2 * sizeof(int32_t), st) != hipSuccess)
       return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
     return DH_OK;
   }
@@ -240,7 +240,10 @@ __global__ __launch_bounds__(256) void cells_static_fill_kernel(int64_t n_seeds,
   }
   const int64_t v = seeds[i];
   const int s = rowptr[v], t = rowptr[v + 1], o = brp[i];
-  if (o + (t - s) > e_max) return;  // flagged by the padding row's wavefront
+  if (o < 0 || o + (t - s) > e_max) {  // too many entries: flagged by the padding row's wavefront; a NEGATIVE offset can only come from
+    if (o < 0 && lane == 0) atomicOr(bad, 1);  // corrupted row pointers (the replayed memset node of round 5's hunt) — never store below the buffer
+    return;
+  }
   int n_self = 0;  // complete in lane 0 (it is active in every trip any lane makes)
   for (int e = lane; e < t - s; e += 64) {
     const int c = col[s + e];
@@ -336,7 +339,7 @@ extern "C" int dh_csr_degree_scales_f32(int64_t n_rows, int64_t n_pad, int64_t n
   const bool cols = mode == DH_DEGREE_BOTH;
   if (cols && n_cols > 0 && (!colscale || !count)) return dh::fail(DH_ERR_INVALID, "%s: mode BOTH needs colscale and the count buffer [n_cols]", me);  // (col may be null for a block without entries)
   hipStream_t st = dh::as_stream(stream);
-  if (cols && n_cols > 0) (void)hipMemsetAsync(count, 0, (size_t)n_cols * sizeof(int32_t), st);
+  if (cols && n_cols > 0) (void)dh::zero_async(count, (size_t)n_cols * sizeof(int32_t), st);
   hipLaunchKernelGGL(degree_count_kernel, dim3(1024), dim3(256), 0, st, n_rows, n_pad, rowptr, col, mode, rowscale, cols && n_cols > 0 ? count : nullptr);
   int rc = dh::check_launch(me);
   if (rc != DH_OK || !cols || n_cols == 0) return rc;

@@ -57,4 +57,12 @@ int sage_bcm_launch(int64_t n_dst, int64_t width, int64_t col_begin, int64_t n_c
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Zero `bytes` bytes at p with a KERNEL launch (lib.hip).  Never hipMemsetAsync in this library: inside a captured hipGraph a memset
+// becomes a memset NODE, and on ROCm 7.2 / gfx950 such a node was replayed with another operation's fill pattern and extent after eager
+// copies had run between two replays (round 5: a 4-byte "out[0] = 0" node filled a block's whole row-pointer array with 0x80 bytes and
+// the next kernel stored 8 GB below its buffer — profiles/r05_replay_fault.md).  Kernel nodes carry their arguments with them.
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
+// rows x width_bytes zeros at p with `pitch` bytes between row starts (hipMemset2DAsync's shape), again as a kernel
+hipError_t zero2d_async(void* p, size_t pitch, size_t width_bytes, size_t rows, hipStream_t st);
+
 }  // namespace dh

@@ -182,8 +182,8 @@ extern "C" int dh_csr_densify_window(int64_t n_rows, int64_t max_row_nnz, const 
   }
   if (n_rows > 65535) return dh::fail(DH_ERR_INVALID, "%s: windows wider than 16384 columns support at most 65535 rows", me);
   const size_t esz = bf16 ? 2 : 4;
-  if (ldo == n_cols) { if (hipMemsetAsync(out, 0, (size_t)n_rows * n_cols * esz, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me); }
-  else if (hipMemset2DAsync(out, (size_t)ldo * esz, 0, (size_t)n_cols * esz, (size_t)n_rows, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
+  if (ldo == n_cols) { if (dh::zero_async(out, (size_t)n_rows * n_cols * esz, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me); }
+  else if (dh::zero2d_async(out, (size_t)ldo * esz, (size_t)n_cols * esz, (size_t)n_rows, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
   const int64_t chunks = dh::ceil_div(max_row_nnz > 0 ? max_row_nnz : 1, 4096);
   dim3 grid((unsigned)dh::ceil_div(chunks, 4), (unsigned)n_rows);
   if (bf16) hipLaunchKernelGGL(densify_scatter_kernel<true>, grid, dim3(256), 0, st, n_rows, rowptr, col, val, rowscale, colscale, mean, col_begin, n_cols, out, ldo);

@@ -112,7 +112,7 @@ extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int6
   if (!out) return dh::fail(DH_ERR_INVALID, "dh_colsum_f32: null out");
   hipStream_t st = dh::as_stream(stream);
   if (n_rows == 0) {
-    if (hipMemsetAsync(out, 0, width * sizeof(float), st) != hipSuccess)
+    if (dh::zero_async(out, width * sizeof(float), st) != hipSuccess)
       return dh::fail(DH_ERR_LAUNCH, "dh_colsum_f32: memset failed");
     return DH_OK;
   }
@@ -385,7 +385,7 @@ extern "C" int dh_col_any_gt_f32(int64_t n_rows, int64_t n_cols, const float* X,
   if (n_cols == 0) return DH_OK;
   if (!flag) return dh::fail(DH_ERR_INVALID, "dh_col_any_gt_f32: null flag");
   hipStream_t st = dh::as_stream(stream);
-  if (hipMemsetAsync(flag, 0, (size_t)n_cols, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_col_any_gt_f32: memset failed");
+  if (dh::zero_async(flag, (size_t)n_cols, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_col_any_gt_f32: memset failed");
   if (n_rows == 0) return DH_OK;
   if (!X || !thresh || ldx < n_cols) return dh::fail(DH_ERR_INVALID, "dh_col_any_gt_f32: bad pointer / leading dimension");
   hipLaunchKernelGGL(col_any_gt_kernel, dim3(flat_grid(n_rows * n_cols)), dim3(256), 0, st, n_rows, n_cols, X, ldx, thresh, flag);

@@ -101,7 +101,7 @@ extern "C" int dh_colsum_bf16(int64_t n_rows, int64_t width, const uint16_t* X, 
   if (!out) return dh::fail(DH_ERR_INVALID, "dh_colsum_bf16: null out");
   hipStream_t st = dh::as_stream(stream);
   if (n_rows == 0) {
-    if (hipMemsetAsync(out, 0, width * sizeof(float), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_colsum_bf16: memset failed");
+    if (dh::zero_async(out, width * sizeof(float), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_colsum_bf16: memset failed");
     return DH_OK;
   }
   if (!X || ldx < width) return dh::fail(DH_ERR_INVALID, "dh_colsum_bf16: bad X/ldx");

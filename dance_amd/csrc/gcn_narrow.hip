@@ -299,8 +299,8 @@ extern "C" int dh_gcn_narrow_backward_f32(int64_t n_rows, int64_t in_features, i
   if (!dW || ldw < out_features) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_backward_f32: bad dW");
   hipStream_t st = dh::as_stream(stream);
   if (n_rows == 0) {
-    (void)hipMemset2DAsync(dW, ldw * sizeof(float), 0, out_features * sizeof(float), in_features, st);
-    if (db) (void)hipMemsetAsync(db, 0, out_features * sizeof(float), st);
+    (void)dh::zero2d_async(dW, ldw * sizeof(float), out_features * sizeof(float), in_features, st);
+    if (db) (void)dh::zero_async(db, out_features * sizeof(float), st);
     return DH_OK;
   }
   if (!agg || !dY || ldd < out_features || (Y_act && ldy < out_features)) return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_backward_f32: bad operand");

@@ -388,8 +388,8 @@ extern "C" int dh_gram_pairwise_rect_f32(int mode, int64_t n_rows, int64_t n, in
   if (!Zr || (n > 0 && !Z) || !O || !rowloss || ldz < d || ldr < d || ldo < d) return dh::fail(DH_ERR_INVALID, "%s: bad pointer / leading dimension", me);
   hipStream_t st = dh::as_stream(stream);
   if (n == 0) {  // no columns: empty sums
-    if (hipMemset2DAsync(O, (size_t)ldo * sizeof(float), 0, (size_t)d * sizeof(float), (size_t)n_rows, st) != hipSuccess ||
-        hipMemsetAsync(rowloss, 0, (size_t)n_rows * sizeof(float), st) != hipSuccess)
+    if (dh::zero2d_async(O, (size_t)ldo * sizeof(float), (size_t)d * sizeof(float), (size_t)n_rows, st) != hipSuccess ||
+        dh::zero_async(rowloss, (size_t)n_rows * sizeof(float), st) != hipSuccess)
       return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
     return DH_OK;
   }

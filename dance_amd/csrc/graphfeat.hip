@@ -90,7 +90,7 @@ extern "C" int dh_sage_alpha_grad_f32(int64_t n_dst, int64_t n_src, int64_t widt
   if (n_dst < 0 || n_src < 0 || width < 0 || n_genes < 0) return dh::fail(DH_ERR_INVALID, "dh_sage_alpha_grad_f32: negative size");
   if (!dalpha) return dh::fail(DH_ERR_INVALID, "dh_sage_alpha_grad_f32: null dalpha");
   hipStream_t st = dh::as_stream(stream);
-  if (hipMemsetAsync(dalpha, 0, (size_t)(n_genes + 2) * sizeof(float), st) != hipSuccess)
+  if (dh::zero_async(dalpha, (size_t)(n_genes + 2) * sizeof(float), st) != hipSuccess)
     return dh::fail(DH_ERR_LAUNCH, "dh_sage_alpha_grad_f32: memset failed");
   if (n_dst == 0 || width == 0) return DH_OK;
   if (!rowptr || !col || !w || !src_cell_id || !dst_cell_id || !H || !dneigh)

@@ -738,7 +738,7 @@ int knn_fold_launch(const KnnFoldGeom& g, int64_t n, int64_t d, const float* X, 
   const float eps = 9.765625e-4f + 1.220703125e-4f + (float)g.dp * 9.5367431640625e-7f;  // 2^-10 + 2^-13 + dp 2^-20
   const float abs_lin = 1.01f * 1.220703125e-4f * sqrtf((float)g.dp);                    // 1.01 * 2^-13 sqrt(dp)
   colmeans(n, d, X, ldx, mean_ws, st);
-  if (hipMemsetAsync(maxabs, 0, sizeof(unsigned int), st) != hipSuccess) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: memset failed");
+  if (dh::zero_async(maxabs, sizeof(unsigned int), st) != hipSuccess) return fail(DH_ERR_LAUNCH, "dh_knn_bruteforce_f32: memset failed");
   hipLaunchKernelGGL(knn_maxabs_kernel, dim3((unsigned)(n < 4096 ? ceil_div(n, 4) : 1024)), dim3(256), 0, st, n, d, X, ldx, mean_ws, maxabs);
   hipLaunchKernelGGL(knn_fold_split_kernel, dim3((unsigned)ceil_div(g.n_pos, 4)), dim3(256), 0, st, n, d, X, ldx, mean_ws, maxabs, g.dp, g.K3,
                      eps, abs_lin, g.G, g.H, g.qmagic, g.n1, g.n_pos, A2, B2, norms);

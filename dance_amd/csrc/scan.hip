@@ -25,7 +25,11 @@ extern "C" int dh_exclusive_scan_i32(int64_t n, const int32_t* in, int32_t* out,
   if (n < 0) return dh::fail(DH_ERR_INVALID, "dh_exclusive_scan_i32: negative size");
   if (!out) return dh::fail(DH_ERR_INVALID, "dh_exclusive_scan_i32: null out");
   hipStream_t st = dh::as_stream(stream);
-  if (hipMemsetAsync(out, 0, sizeof(int32_t), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_exclusive_scan_i32: memset failed");
+  // out[0] = 0 by a KERNEL, not hipMemsetAsync: inside a captured hipGraph the 4-byte memset NODE was replayed (ROCm 7.2, gfx950) as a
+  // fill of the whole row-pointer array with the byte 0x80 on some replays — StaticCellBlock's row pointers then read 0x80808080,
+  // negative offsets slipped past the "fits in e_max" test of the fill kernel, and its stores faulted 8 GB below the buffer
+  // (round 5's hunt: scripts/rebuild_graph_check.py, profiles/r05_replay_fault.md).  A kernel node has no such failure mode.
+  if (dh::zero_async(out, sizeof(int32_t), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_exclusive_scan_i32: zeroing out[0] failed");
   if (n == 0) return DH_OK;
   if (!in) return dh::fail(DH_ERR_INVALID, "dh_exclusive_scan_i32: null in");
   size_t temp = scan_temp_bytes(n);

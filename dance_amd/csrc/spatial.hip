@@ -52,7 +52,7 @@ extern "C" int dh_spatial_gaussian_knn(int64_t n, int64_t d, const float* X, int
   if (n < 0 || d <= 0 || k <= 0) return dh::fail(DH_ERR_INVALID, "%s: bad size", me);
   if (!out_rowptr) return dh::fail(DH_ERR_INVALID, "%s: null out_rowptr", me);
   hipStream_t st = dh::as_stream(stream);
-  if (n == 0) return hipMemsetAsync(out_rowptr, 0, sizeof(int32_t), st) == hipSuccess ? DH_OK : dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
+  if (n == 0) return dh::zero_async(out_rowptr, sizeof(int32_t), st) == hipSuccess ? DH_OK : dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
   if (!X || !out_col || !out_val) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
   if (k > n || k > 64) return dh::fail(DH_ERR_INVALID, "%s: k must be <= min(n, 64)", me);
   if (n * (int64_t)k >= (int64_t)1 << 31) return dh::fail(DH_ERR_INVALID, "%s: n * k >= 2^31", me);

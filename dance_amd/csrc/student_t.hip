@@ -223,7 +223,7 @@ extern "C" int dh_student_t_backward_f32(int64_t n, int64_t c, int64_t d, const 
   if (!dMU) return dh::fail(DH_ERR_INVALID, "%s: null dMU", me);
   hipStream_t st = dh::as_stream(stream);
   if (n == 0) {
-    if (hipMemsetAsync(dMU, 0, (size_t)(c * d) * sizeof(float), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
+    if (dh::zero_async(dMU, (size_t)(c * d) * sizeof(float), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
     return DH_OK;
   }
   if (!G || ldg < c || (dZ && lddz < d)) return dh::fail(DH_ERR_INVALID, "%s: bad gradient operands", me);

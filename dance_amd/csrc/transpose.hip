@@ -56,13 +56,20 @@ __global__ __launch_bounds__(256) void gather_transposed_kernel(int64_t n_rows, 
 }
 
 // Small graphs — the message-flow block of a mini-batch (129 rows of ~200 entries, transposed once per training step inside a captured
-// hipGraph, where the sort-based path is 12 dependent launches of ~5 us each) — in ONE workgroup: histogram of the columns in LDS,
-// block-wide exclusive scan (= out_rowptr), then the rows placed ONE AFTER THE OTHER (a barrier per row), all entries of a row at once
-// through LDS cursors.  Rows in ascending order make every output row ascending by source row, which is what the stable sort
-// produces; entries of one row have distinct columns in every graph of this package (a multi-edge would land next to its twin in
-// arrival order).  Inconsistent input (a column >= n_cols, more entries than the caller's nnz) is skipped instead of written out of
-// bounds; -DDH_TRANSPOSE_DEBUG reports it (the diagnosis build of round 5's replay-fault hunt).
-constexpr int SMALL_T = 1024;
+// hipGraph, where the sort-based path is 12 dependent launches of ~5 us each) — in ONE workgroup, every phase parallel over the
+// entries or the columns:
+//   1. histogram of the columns in LDS, block-wide exclusive scan = out_rowptr;
+//   2. every entry claims a slot of its column's segment through an LDS cursor — in arrival order, i.e. unordered;
+//   3. one thread per column insertion-sorts its segment by source row (segments are a dozen entries; the stable sort's order is
+//      "ascending source row", and entries of one source row never share a column except in a static block's padding row, whose
+//      entries are interchangeable zeros).
+// The first version placed the rows one after the other with a barrier per row: correct, but 129 barriers made it SLOWER than the 12
+// launches it replaced (3.9 vs 3.3 s per 1M-cell graph-sc epoch).  Inconsistent input (a column >= n_cols, more entries than the
+// caller's nnz) is skipped instead of written out of bounds; -DDH_TRANSPOSE_DEBUG reports it.
+#ifndef DH_TRANSPOSE_SMALL_T
+#define DH_TRANSPOSE_SMALL_T 1024
+#endif
+constexpr int SMALL_T = DH_TRANSPOSE_SMALL_T;
 __global__ __launch_bounds__(SMALL_T) void csr_transpose_small_kernel(int n_rows, int n_cols, int nnz_cap, const int32_t* __restrict__ rowptr,
                                                                       const int32_t* __restrict__ col, const float* __restrict__ val,
                                                                       int32_t* __restrict__ out_rowptr, int32_t* __restrict__ out_col,
@@ -106,12 +113,28 @@ __global__ __launch_bounds__(SMALL_T) void csr_transpose_small_kernel(int n_rows
     base += c;
   }
   __syncthreads();
-  for (int r = 0; r < n_rows; ++r) {
+  // unordered placement: a wave owns whole rows (row id = one binary search per entry avoided), lanes stride over the row's entries
+  for (int r = wave; r < n_rows; r += SMALL_T / 64) {
     const int rs = rowptr[r], re = min(rowptr[r + 1], nnz);
-    for (int e = rs + tid; e < re; e += SMALL_T) {
-      const int c = col[e];
-      if ((unsigned)c >= (unsigned)n_cols) continue;
-      const int pos = atomicAdd(&cursor[c], 1);
+    for (int e0 = rs; e0 < re; e0 += 64) {
+      const int e = e0 + lane;
+      const bool live = e < re;
+      const int c = live ? col[e] : -1;
+      if (!live || (unsigned)c >= (unsigned)n_cols) continue;
+      // 64 entries of ONE column (a static block's padding row: thousands of zeros in column 0): one cursor bump for the chunk,
+      // slots in entry order — the run arrives sorted and the insertion sort below passes over it in linear time
+      const int c0 = __builtin_amdgcn_readfirstlane(c);
+      const unsigned long long act = __ballot(true);
+      int pos;
+      if (__ballot(c == c0) == act) {
+        const int lead = __ffsll((long long)act) - 1;
+        int first = 0;
+        if (lane == lead) first = atomicAdd(&cursor[c0], __popcll(act));
+        first = __shfl(first, lead, 64);
+        pos = first + __popcll(act & ((1ull << lane) - 1ull));
+      } else {
+        pos = atomicAdd(&cursor[c], 1);
+      }
       if (pos >= nnz) {
 #ifdef DH_TRANSPOSE_DEBUG
         printf("csr_transpose_small: cursor %d of column %d past nnz %d (row %d entry %d)\n", pos, c, nnz, r, e);
@@ -122,7 +145,25 @@ __global__ __launch_bounds__(SMALL_T) void csr_transpose_small_kernel(int n_rows
       out_perm[pos] = e;
       if (out_val) out_val[pos] = val[e];
     }
-    __syncthreads();
+  }
+  __syncthreads();  // (the block's own global writes are visible to the block after the barrier)
+  // per-column insertion sort by (source row, entry position): the stable sort's order
+  for (int c = tid; c < n_cols; c += SMALL_T) {
+    const int s0 = out_rowptr[c], s1 = min(cursor[c], nnz);  // cursor[c] now = end of the column's segment
+    for (int i = s0 + 1; i < s1; ++i) {
+      const int r = out_col[i], e = out_perm[i];
+      const float v = out_val ? out_val[i] : 0.f;
+      int j = i - 1;
+      while (j >= s0 && (out_col[j] > r || (out_col[j] == r && out_perm[j] > e))) {
+        out_col[j + 1] = out_col[j];
+        out_perm[j + 1] = out_perm[j];
+        if (out_val) out_val[j + 1] = out_val[j];
+        --j;
+      }
+      out_col[j + 1] = r;
+      out_perm[j + 1] = e;
+      if (out_val) out_val[j + 1] = v;
+    }
   }
 }
 bool transpose_small_applies(int64_t n_rows, int64_t n_cols, int64_t nnz) {
@@ -168,14 +209,19 @@ extern "C" int dh_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, con
     return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: val and out_val must both be given or both NULL");
   hipStream_t st = dh::as_stream(stream);
   if (nnz == 0) {
-    if (hipMemsetAsync(out_rowptr, 0, (size_t)(n_cols + 1) * sizeof(int32_t), st) != hipSuccess)
+    if (dh::zero_async(out_rowptr, (size_t)(n_cols + 1) * sizeof(int32_t), st) != hipSuccess)
       return dh::fail(DH_ERR_LAUNCH, "dh_csr_transpose: memset failed");
     return DH_OK;
   }
   if (!rowptr || !col || !out_col || !out_perm)
     return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: null pointer");
   if (transpose_small_applies(n_rows, n_cols, nnz)) {
-    hipLaunchKernelGGL(csr_transpose_small_kernel, dim3(1), dim3(SMALL_T), (size_t)(n_cols + 1) * sizeof(int), st, (int)n_rows, (int)n_cols, (int)nnz,
+#ifdef DH_TRANSPOSE_STATIC_LDS
+    const size_t dyn_lds = 0;
+#else
+    const size_t dyn_lds = (size_t)(n_cols + 1) * sizeof(int);
+#endif
+    hipLaunchKernelGGL(csr_transpose_small_kernel, dim3(1), dim3(SMALL_T), dyn_lds, st, (int)n_rows, (int)n_cols, (int)nnz,
                        rowptr, col, val, out_rowptr, out_col, out_val, out_perm);
     return dh::check_launch("dh_csr_transpose");
   }

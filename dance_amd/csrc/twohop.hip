@@ -122,7 +122,7 @@ extern "C" int dh_csr_two_hop_count(int64_t n, const int32_t* rowptr, const int3
   if (n == 0) return DH_OK;
   if (!rowptr || !col || !rowcnt || !overflow) return dh::fail(DH_ERR_INVALID, "dh_csr_two_hop_count: null pointer");
   hipStream_t st = dh::as_stream(stream);
-  if (hipMemsetAsync(overflow, 0, sizeof(int32_t), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_csr_two_hop_count: memset failed");
+  if (dh::zero_async(overflow, sizeof(int32_t), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "dh_csr_two_hop_count: memset failed");
   hipLaunchKernelGGL(two_hop_count_kernel, dim3((unsigned)dh::ceil_div(n, 256)), dim3(256), 0, st, n, rowptr, col, rowcnt, overflow);
   return dh::check_launch("dh_csr_two_hop_count");
 }
@@ -162,7 +162,7 @@ extern "C" int dh_csr_two_hop_compact(int64_t n, int64_t total, const int32_t* f
   if (!out_rowptr) return dh::fail(DH_ERR_INVALID, "%s: null out_rowptr", me);
   hipStream_t st = dh::as_stream(stream);
   if (total == 0 || n == 0) {
-    if (hipMemsetAsync(out_rowptr, 0, (size_t)(n + 1) * sizeof(int32_t), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
+    if (dh::zero_async(out_rowptr, (size_t)(n + 1) * sizeof(int32_t), st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: memset failed", me);
     return DH_OK;
   }
   if (!flags || !pos || !workspace) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);

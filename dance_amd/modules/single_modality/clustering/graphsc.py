@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import kernels
+from ....capture import kernel_clone
 from ....autograd import HipLinear, gcn_layer, linear
 from ....cellgraph import DataLoader, MultiLayerFullNeighborSampler
 from ....graph import CSRGraph
@@ -352,7 +353,7 @@ class _CapturedStep:
         blk = self.block.rebuild()
         x = blk.srcdata["features"]
         _, emb = self.model.forward([blk], x, decode=False)  # :202
-        emb_out = emb.detach().clone()
+        emb_out = kernel_clone(emb.detach())  # a kernel, not a memcpy node (capture.py)
         _, emb2 = self.model.forward([blk], x, decode=False)  # :215, fresh dropout
         loss = self.norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), self.diag, self.diag, self.pos_weight)
         self.optim.zero_grad(set_to_none=True)

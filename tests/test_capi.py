@@ -93,3 +93,21 @@ def test_bench_and_smoke_fail_loudly_without_a_gpu():
     # a multi-rank request without the launcher is refused before anything is initialised
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def test_library_never_records_memset_nodes():
+    """No hipMemsetAsync / hipMemcpyAsync in the kernels' translation units (comm.hip's host-side staging apart): under a hipGraph
+    capture they become memset / memcpy NODES, which ROCm 7.2 replayed with another operation's extent and pattern (round 5,
+    profiles/r05_replay_fault.md).  dh::zero_async (a kernel) is the library's only way to clear memory."""
+    import glob
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dance_amd", "csrc")
+    bad = []
+    for path in sorted(glob.glob(os.path.join(root, "*.hip"))):
+        if os.path.basename(path) == "comm.hip":
+            continue
+        for i, line in enumerate(open(path), 1):
+            code = line.split("//")[0]
+            if re.search(r"\bhipMemsetAsync\s*\(|\bhipMemset2DAsync\s*\(|\bhipMemcpyAsync\s*\(|\bhipMemset\s*\(", code):
+                bad.append(f"{os.path.basename(path)}:{i}")
+    assert not bad, bad
