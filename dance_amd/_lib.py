@@ -44,6 +44,7 @@ def _declare(lib):
         "dh_gemm_f32": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
         "dh_gemm_f32_ex_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32, i32]),
         "dh_gemm_f32_ex": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, i32, P]),
+        "dh_gemm_f32_bias_act": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, P, i32, P, c_size_t, P]),
         "dh_gemm_f32x3_workspace_bytes": (c_size_t, [i64, i64, i64, i32, i32]),
         "dh_gemm_f32x3": (c_int, [i64, i64, i64, i32, i32, P, i64, P, i64, P, i64, i32, P, c_size_t, P]),
         "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),

@@ -461,7 +461,7 @@ def dense_adj_layer(x, weight, adj, bias=None):
 class _LinearFn(torch.autograd.Function):
     """y = act(x W^T + b) (torch.nn.Linear semantics, optional fused ReLU) on the matrix cores.
 
-    fp32 input: dh_gemm_f32 (exact fp32 MFMA) + dh_bias_act_f32.  bf16 input (config C3): dh_gemm_bf16 with the bias /
+    fp32 input: dh_gemm_f32_bias_act (exact fp32 MFMA, bias / ReLU in the epilogue).  bf16 input (config C3): dh_gemm_bf16 with the bias /
     ReLU epilogue fused; W (an fp32 master parameter) is rounded to bf16 for the products, dW / db come back in fp32."""
 
     @staticmethod
@@ -474,9 +474,7 @@ class _LinearFn(torch.autograd.Function):
                                   out_dtype=out_dtype or torch.bfloat16)
         else:
             w = weight.contiguous()
-            y = kernels.gemm(x, w, trans_b=True)
-            if bias is not None or relu:
-                kernels.bias_act_(y, bias, act)
+            y = kernels.gemm(x, w, trans_b=True, bias=None if bias is None else bias.detach(), act=act)  # bias / ReLU in the tile's store
         ctx.has_bias, ctx.relu = bias is not None, relu
         ctx.save_for_backward(x, w, y if relu else None)
         return y

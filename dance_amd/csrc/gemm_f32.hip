@@ -197,7 +197,8 @@ template <typename C_, bool TA, bool TB, bool ALIGNED>
 __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
     int64_t M, int64_t N, int64_t K, const float* __restrict__ A, int64_t lda,
     const float* __restrict__ B, int64_t ldb, float* __restrict__ C, int64_t ldc,
-    int accumulate, int64_t k_chunk, float* __restrict__ slabs, int tiles_n, int n_tiles, int n_slices) {
+    int accumulate, int64_t k_chunk, float* __restrict__ slabs, int tiles_n, int n_tiles, int n_slices,
+    const float* __restrict__ bias, int act) {
   constexpr int TM = C_::TM, TN = C_::TN, BM = C_::BM, BN = C_::BN, NT = C_::NT;
   constexpr int NLA = C_::NLD_A, NLB = C_::NLD_B;
   __shared__ __attribute__((aligned(16))) float lds[2 * C_::TILE_A + 2 * C_::TILE_B];  // A[0], A[1], B[0], B[1]
@@ -426,13 +427,21 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
   }
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+  // Epilogue: C (+)= acc (+ bias[col], then ReLU): torch.nn.Linear's bias and a following ReLU in the store that writes the tile —
+  // the separate dh_bias_act_f32 pass read and wrote every output once more (19.9 of scDSC's 343 ms epoch at 1M cells were that
+  // pass over the autoencoder's activations).  Same arithmetic, same rounding: acc + b, then max(., 0).  Split-K partial slabs carry
+  // neither; the reduce kernel applies both.
   float* out = C;
   int64_t ldo = ldc;
   bool add = accumulate != 0;
+  const float* eb = bias;
+  bool relu = act == DH_ACT_RELU;
   if (slabs) {
     out = slabs + (int64_t)slice * M * N;
     ldo = N;
     add = false;
+    eb = nullptr;
+    relu = false;
   }
 #pragma unroll
   for (int x = 0; x < TM; ++x)
@@ -445,13 +454,24 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
         static_assert(TN == 2, "float2 epilogue assumes two column tiles");
         const int64_t col = n0 + b_span + 2 * i32;
         float* p = out + row * ldo + col;
+        const float b0 = (eb && col < N) ? eb[col] : 0.f, b1 = (eb && col + 1 < N) ? eb[col + 1] : 0.f;
         if (col + 1 < N && (ldo % 2 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0)) {
           f32x2 v = {acc[x][0][r], acc[x][1][r]};
           if (add) { const f32x2 o = *reinterpret_cast<const f32x2*>(p); v[0] += o[0]; v[1] += o[1]; }
+          if (eb) { v[0] += b0; v[1] += b1; }
+          if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }
           *reinterpret_cast<f32x2*>(p) = v;
         } else {
-          if (col < N) p[0] = add ? p[0] + acc[x][0][r] : acc[x][0][r];
-          if (col + 1 < N) p[1] = add ? p[1] + acc[x][1][r] : acc[x][1][r];
+          if (col < N) {
+            float v = add ? p[0] + acc[x][0][r] : acc[x][0][r];
+            if (eb) v += b0;
+            p[0] = relu ? fmaxf(v, 0.f) : v;
+          }
+          if (col + 1 < N) {
+            float v = add ? p[1] + acc[x][1][r] : acc[x][1][r];
+            if (eb) v += b1;
+            p[1] = relu ? fmaxf(v, 0.f) : v;
+          }
         }
       } else {
 #pragma unroll
@@ -459,7 +479,9 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
           const int64_t col = n0 + b_span + y * 32 + i32;
           if (col >= N) continue;
           float* p = out + row * ldo + col;
-          *p = add ? (*p + acc[x][y][r]) : acc[x][y][r];
+          float v = add ? (*p + acc[x][y][r]) : acc[x][y][r];
+          if (eb) v += eb[col];
+          *p = relu ? fmaxf(v, 0.f) : v;
         }
       }
     }
@@ -469,14 +491,15 @@ __global__ __launch_bounds__(C_::NT, 2) void gemm_f32_kernel(
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N, int S,
                                                             const float* __restrict__ slabs,
                                                             float* __restrict__ C, int64_t ldc,
-                                                            int accumulate) {
+                                                            int accumulate, const float* __restrict__ bias, int act) {
   const int64_t total = M * N;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t row = i / N, col = i % N;
     float* p = C + row * ldc + col;
     float s = accumulate ? *p : 0.f;
     for (int z = 0; z < S; ++z) s += slabs[(int64_t)z * total + i];
-    *p = s;
+    if (bias) s += bias[col];
+    *p = act == DH_ACT_RELU ? fmaxf(s, 0.f) : s;
   }
 }
 
@@ -573,10 +596,30 @@ extern "C" int dh_gemm_f32(int64_t M, int64_t N, int64_t K, int trans_a, int tra
   return dh_gemm_f32_ex(M, N, K, trans_a, trans_b, A, lda, B, ldb, C, ldc, accumulate, workspace, workspace_bytes, DH_GEMM_TILE_AUTO, stream);
 }
 
+namespace {
+int gemm_f32_impl(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                  int64_t ldc, int accumulate, const float* bias, int act, void* workspace, size_t workspace_bytes, int tile, dh_stream_t stream);
+}
+
 extern "C" int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b,
                               const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
                               int64_t ldc, int accumulate, void* workspace, size_t workspace_bytes,
                               int tile, dh_stream_t stream) {
+  return gemm_f32_impl(M, N, K, trans_a, trans_b, A, lda, B, ldb, C, ldc, accumulate, nullptr, DH_ACT_NONE, workspace, workspace_bytes, tile, stream);
+}
+
+// C = act(op(A) op(B) + bias): the product with torch.nn.Linear's bias (one value per column of C) and an optional ReLU applied in the
+// store of the output tile (split-K: in the reduce kernel; narrow layers: dh_bias_act_f32 behind the streaming kernel).
+extern "C" int dh_gemm_f32_bias_act(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda, const float* B,
+                                    int64_t ldb, float* C, int64_t ldc, const float* bias, int act, void* workspace, size_t workspace_bytes,
+                                    dh_stream_t stream) {
+  if (act != DH_ACT_NONE && act != DH_ACT_RELU) return dh::fail(DH_ERR_INVALID, "dh_gemm_f32_bias_act: bad act %d", act);
+  return gemm_f32_impl(M, N, K, trans_a, trans_b, A, lda, B, ldb, C, ldc, 0, bias, act, workspace, workspace_bytes, DH_GEMM_TILE_AUTO, stream);
+}
+
+namespace {
+int gemm_f32_impl(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda, const float* B, int64_t ldb, float* C,
+                  int64_t ldc, int accumulate, const float* bias, int act, void* workspace, size_t workspace_bytes, int tile, dh_stream_t stream) {
   if (tile != DH_GEMM_TILE_AUTO && tile != DH_GEMM_TILE_128 && tile != DH_GEMM_TILE_256)
     return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: bad tile request %d", tile);
   if (M < 0 || N < 0 || K < 0) return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: negative size");
@@ -585,8 +628,11 @@ extern "C" int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int 
   if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldc < N)
     return dh::fail(DH_ERR_INVALID, "dh_gemm_f32: leading dimension too small");
   hipStream_t st = dh::as_stream(stream);
-  if (tile == DH_GEMM_TILE_AUTO && K > 0 && dh::skinny_applies(M, N, K, trans_a))  // narrow layers: HBM-bound streaming kernel (gemm_skinny.hip)
-    return dh::skinny_launch(M, N, K, trans_b, A, lda, B, ldb, C, ldc, accumulate, st);
+  if (tile == DH_GEMM_TILE_AUTO && K > 0 && dh::skinny_applies(M, N, K, trans_a)) {  // narrow layers: HBM-bound streaming kernel (gemm_skinny.hip)
+    const int rc = dh::skinny_launch(M, N, K, trans_b, A, lda, B, ldb, C, ldc, accumulate, st);
+    if (rc != DH_OK || (!bias && act == DH_ACT_NONE)) return rc;
+    return dh_bias_act_f32(M, N, C, ldc, bias, act, stream);
+  }
   Plan p = make_plan(M, N, K, tile, trans_a != 0);
   float* slabs = nullptr;
   if (p.S > 1) {
@@ -609,10 +655,10 @@ extern "C" int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int 
   do {                                                                                                       \
     if (p.large)                                                                                             \
       hipLaunchKernelGGL((gemm_f32_kernel<CfgLarge, TA, TB, AL>), grid, dim3(CfgLarge::NT), 0, st, M, N, K, A, \
-                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles, p.S);       \
+                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles, p.S, bias, act); \
     else                                                                                                     \
       hipLaunchKernelGGL((gemm_f32_kernel<CfgSmall, TA, TB, AL>), grid, dim3(CfgSmall::NT), 0, st, M, N, K, A, \
-                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles, p.S);       \
+                         lda, B, ldb, C, ldc, accumulate, p.k_chunk, slabs, p.tiles_n, p.n_tiles, p.S, bias, act); \
   } while (0)
   const int key = (trans_a ? 4 : 0) | (trans_b ? 2 : 0) | (aligned ? 1 : 0);
   switch (key) {
@@ -631,8 +677,10 @@ extern "C" int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int 
   if (p.S > 1) {
     const int64_t total = M * N;
     const unsigned rgrid = (unsigned)(dh::ceil_div(total, 256) < 4096 ? dh::ceil_div(total, 256) : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, st, M, N, p.S, slabs, C, ldc, accumulate);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, st, M, N, p.S, slabs, C, ldc, accumulate, bias, act);
     rc = dh::check_launch("dh_gemm_f32(split-K reduce)");
   }
   return rc;
 }
+}  // namespace
+

@@ -264,9 +264,10 @@ GEMM_TILE_AUTO, GEMM_TILE_256, GEMM_TILE_128 = 0, 1, 2
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
          out: Optional[torch.Tensor] = None, accumulate: bool = False, tag: Optional[str] = None,
-         mode: Optional[str] = None, tile: int = GEMM_TILE_AUTO) -> torch.Tensor:
+         mode: Optional[str] = None, tile: int = GEMM_TILE_AUTO, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
     """C (+)= op(A) @ op(B), fp32 in / fp32 out, on the matrix cores; see dh_gemm_f32x3 / dh_gemm_f32 and GEMM_MODE.
-    ``tile`` (exact mode): macro-tile request of dh_gemm_f32_ex."""
+    ``tile`` (exact mode): macro-tile request of dh_gemm_f32_ex.  ``bias`` [N] / ``act``: nn.Linear's bias and a ReLU in the output
+    tile's store (dh_gemm_f32_bias_act, exact mode; the x3 mode runs dh_bias_act_f32 behind the product)."""
     lib = _lib_ready()
     mode = mode or GEMM_MODE
     if mode not in ("x3", "exact"):
@@ -282,6 +283,18 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
             raise ValueError("gemm: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
+    if bias is not None or act != ACT_NONE:
+        if accumulate or tile != GEMM_TILE_AUTO:
+            raise ValueError("gemm: bias / act go with a plain product (no accumulate, automatic tile)")
+        if mode == "exact":
+            ws_bytes = lib.dh_gemm_f32_workspace_bytes(M, N, K, int(trans_a), int(trans_b))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None
+            _call(tag, lib.dh_gemm_f32_bias_act, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A),
+                  _dev(B, torch.float32, "B", 2), _ld(B), _dev(out, torch.float32, "out", 2), _ld(out), _dev(bias, torch.float32, "bias", 1), int(act),
+                  None if ws is None else ws.data_ptr(), ws_bytes, _stream())
+            return out
+        gemm(A, B, trans_a=trans_a, trans_b=trans_b, out=out, tag=tag, mode=mode)
+        return bias_act_(out, bias, act)
     if mode == "exact" and tile != GEMM_TILE_AUTO:
         ws_bytes = lib.dh_gemm_f32_ex_workspace_bytes(M, N, K, int(trans_a), int(trans_b), tile)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=A.device) if ws_bytes else None

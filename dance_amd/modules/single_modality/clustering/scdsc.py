@@ -78,8 +78,51 @@ class AE(nn.Module):
             return bn(h)
         return sharded_batch_norm(bn, h, self.rows_total, self.group)
 
+    # A FROZEN autoencoder fed the same full batch in training mode returns the same tensors every time: scDSC's joint loop
+    # (scdsc.py:253-288) does exactly that for hundreds of epochs (``fix_module("model.ae")``, :110; ``model(data, adj)`` on all cells).
+    # The outputs of the first such call are kept and handed back while nothing they depend on has changed (same input tensor object and
+    # version, same parameter versions, training mode, no gradient wanted anywhere); the only state a forward moves — the BatchNorm
+    # running statistics, which the eval-mode passes of every 10th epoch read — is advanced by the same momentum update from the
+    # recorded batch statistics.  5.1 of an epoch's 23 TFLOP, nine BatchNorm passes and 14 GB of activations per epoch at 1M cells
+    # are not recomputed.  ``cache_frozen = False`` switches it off.
+    cache_frozen = True
+    _cache = None
+
+    def _cache_key(self, x):
+        if not (self.cache_frozen and self.training and self.rows_total is None and not x.requires_grad):
+            return None
+        params = list(self.parameters())
+        if any(p.requires_grad for p in params) or any(bn.momentum is None for bn in self._bns()):
+            return None
+        return (id(x), x._version, x.data_ptr(), tuple(x.shape), tuple(p._version for p in params))
+
+    def _bns(self):
+        return [getattr(self, f"BN{i}") for i in range(1, 10)]
+
     def forward(self, x):
-        bn = self._bn
+        key = self._cache_key(x)
+        if key is not None and self._cache is not None and self._cache[0] == key:
+            with torch.no_grad():  # what a training-mode forward does to the BatchNorm buffers (torch.nn.functional.batch_norm)
+                for bn_, (mean, var) in zip(self._bns(), self._cache[2]):
+                    m = bn_.momentum
+                    bn_.running_mean.copy_(m * mean + (1 - m) * bn_.running_mean)
+                    bn_.running_var.copy_(m * var + (1 - m) * bn_.running_var)
+                    bn_.num_batches_tracked += 1
+            return self._cache[1]
+        self._cache = None
+        stats = [] if key is not None else None
+
+        def bn(mod, h):
+            if stats is not None:
+                with torch.no_grad():
+                    stats.append((h.mean(0), h.var(0, unbiased=True) if h.shape[0] > 1 else torch.zeros_like(h[0])))
+            return self._bn(mod, h)
+        out = self._forward(x, bn)
+        if key is not None:
+            self._cache = (key, out, stats, x)  # (x itself is held so that its id cannot be recycled while the cache lives)
+        return out
+
+    def _forward(self, x, bn):
         enc_h1 = F.relu(bn(self.BN1, self.enc_1(x)))
         enc_h2 = F.relu(bn(self.BN2, self.enc_2(enc_h1)))
         enc_h3 = F.relu(bn(self.BN3, self.enc_3(enc_h2)))

@@ -169,6 +169,12 @@ DH_API int dh_gemm_f32_ex(int64_t M, int64_t N, int64_t K, int trans_a, int tran
                 const float* A, int64_t lda, const float* B, int64_t ldb,
                 float* C, int64_t ldc, int accumulate,
                 void* workspace, size_t workspace_bytes, int tile, dh_stream_t stream);
+/* The same product with torch.nn.Linear's bias (one value per column of C; NULL = none) and an optional ReLU applied in the store of
+ * the output tile instead of a second pass over C (dance's Linear layers: scdsc.py:535-555 autoencoder, scdeepsort.py:80 classifier,
+ * gnn.py:54 AdaptiveSAGE update).  Same arithmetic and rounding as dh_gemm_f32 followed by dh_bias_act_f32.                        */
+DH_API int dh_gemm_f32_bias_act(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda,
+                         const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
+                         void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
 /* Same contract as dh_gemm_f32 (operands, result and accumulation in fp32), computed on the bf16 matrix cores: each fp32
  * operand is split exactly into three bf16 terms and six of the nine partial products are accumulated in fp32 (the dropped

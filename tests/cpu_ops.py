@@ -10,8 +10,12 @@ ACT_NONE, ACT_RELU = 0, 1
 REDUCE_SUM, REDUCE_MEAN = 0, 1
 
 
-def gemm(A, B, *, trans_a=False, trans_b=False, out=None, accumulate=False, tag=None, mode=None, tile=0):
+def gemm(A, B, *, trans_a=False, trans_b=False, out=None, accumulate=False, tag=None, mode=None, tile=0, bias=None, act=ACT_NONE):
     r = torch.mm(A.t() if trans_a else A, B.t() if trans_b else B)
+    if bias is not None:
+        r = r + bias
+    if act == ACT_RELU:
+        r = torch.relu(r)
     if out is not None:
         out.copy_(out + r if accumulate else r)
         return out

@@ -103,7 +103,9 @@ def test_static_cell_block_flags_rows_without_exactly_one_self_loop(cuda_device)
         return CellGeneGraph(rowptr, col, torch.ones(col.numel(), device=DEV), None, n_genes + n_cells,
                              {"cell_id": cid, "features": torch.zeros(n_genes + n_cells, 2, device=DEV)})
 
-    for loops, expect in (([1] * 6, 0), ([1, 1, 0, 1, 1, 1], 1), ([1, 2, 1, 1, 1, 1], 1)):
+    # bit 2 = a seed without exactly one self loop (graph-sc's identity target needs it, scDeepSort's step does not: ADVICE r4);
+    # bit 1 (a seed that is not a cell of the layout) stays clear for all three graphs
+    for loops, expect in (([1] * 6, 0), ([1, 1, 0, 1, 1, 1], 2), ([1, 2, 1, 1, 1, 1], 2)):
         sb = StaticCellBlock(build(loops), 4)
         sb.bad.zero_()
         sb.seeds.copy_(torch.tensor([5, 6, 7, 8], device=DEV))  # cells 0 .. 3

@@ -357,3 +357,21 @@ def test_adam_step_kernel_vs_torch(cuda_device):
     before = p.detach().clone()
     assert kernels.adam_step(o) is False and torch.equal(p, before)
     assert kernels.adam_step(torch.optim.SGD([p], lr=0.1)) is False
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(1000, 512, 2000, True), (257, 130, 100, False), (5000, 50, 50, True), (64, 300, 9000, True), (3, 7, 5, False),
+                                      (2000, 512, 70_000, True)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_f32_bias_act_equals_two_passes(cuda_device, M, N, K, tb, act):
+    """dh_gemm_f32_bias_act (bias + ReLU in the output tile's store; split-K: in the reduce kernel; narrow shapes: behind the streaming
+    kernel) is bit for bit dh_gemm_f32 followed by dh_bias_act_f32."""
+    from dance_amd import kernels
+    g = torch.Generator(device=cuda_device).manual_seed(M + N + K)
+    a = torch.randn(M, K, device=cuda_device, generator=g)
+    b = torch.randn((N, K) if tb else (K, N), device=cuda_device, generator=g) / K**0.5
+    bias = torch.randn(N, device=cuda_device, generator=g)
+    two = kernels.bias_act_(kernels.gemm(a, b, trans_b=tb), bias, act)
+    one = kernels.gemm(a, b, trans_b=tb, bias=bias, act=act)
+    assert torch.equal(one, two)
+    if act:
+        assert torch.equal(kernels.gemm(a, b, trans_b=tb, act=act), torch.relu(kernels.gemm(a, b, trans_b=tb)))

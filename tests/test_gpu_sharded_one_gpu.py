@@ -33,10 +33,15 @@ def _problem(n, fin, fout, k, seed):
     return rowptr, col, val, x, w, b, dy
 
 
+def _device_index(rank):
+    """One GPU for every rank (this file), or one GPU per rank (tests/test_gpu_rccl_multi.py sets DANCE_TEST_BACKEND=nccl)."""
+    return rank if os.environ.get("DANCE_TEST_BACKEND", "gloo") == "nccl" else 0
+
+
 def _run_layer(rank, world, mode, n, fin, fout, k, seed, halo_dtype="f32", reorder=None):
     from dance_amd import sharding
     from dance_amd.graph import CSRGraph
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", _device_index(rank) if world > 1 else 0)
     rowptr, col, val, x, w, b, dy = _problem(n, fin, fout, k, seed)
     graph = CSRGraph(rowptr.to(dev), col.to(dev), val.to(dev), n, n)
     sg = sharding.ShardedGCNGraph.from_global_csr(graph, mode=mode, halo_dtype=halo_dtype, reorder=reorder)
@@ -54,15 +59,17 @@ def _run_layer(rank, world, mode, n, fin, fout, k, seed, halo_dtype="f32", reord
 def _worker(rank, world, port, what, args, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DANCE_TEST_BACKEND", "gloo")
+    torch.cuda.set_device(_device_index(rank))
+    dist.init_process_group(backend, rank=rank, world_size=world,
+                            **({"device_id": torch.device("cuda", _device_index(rank))} if backend == "nccl" else {}))
     try:
         if what == "layer":
             out = _run_layer(rank, world, *args)
         else:
             from dance_amd import sharding
             n, d, k, seed = args
-            x = torch.randn((n, d), generator=torch.Generator().manual_seed(seed)).cuda()
+            x = torch.randn((n, d), generator=torch.Generator().manual_seed(seed)).cuda(_device_index(rank))
             idx, dst = sharding.sharded_knn(x, k)
             out = (idx.cpu(), dst.cpu())
         torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
@@ -137,8 +144,10 @@ def _model_worker(rank, world, port, out_dir):
     from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
     from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    backend = os.environ.get("DANCE_TEST_BACKEND", "gloo")
+    torch.cuda.set_device(_device_index(rank))
+    dist.init_process_group(backend, rank=rank, world_size=world,
+                            **({"device_id": torch.device("cuda", _device_index(rank))} if backend == "nccl" else {}))
     try:
         n_cells, n_genes, d = 3000, 200, 50
         cg = _cell_gene_graph(n_cells, n_genes, 20, d, seed=1)

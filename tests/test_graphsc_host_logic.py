@@ -116,7 +116,7 @@ def test_static_cell_block_matches_sampled_block(monkeypatch):
     # a non-cell seed is flagged
     sb.seeds[0] = 0
     sb.rebuild()
-    assert int(sb.bad) == 1
+    assert int(sb.bad) & 1   # bit 1: not a cell of the layout (bit 2, "no single self loop", is set as well)
     # the step body == one eager batch (dropout off): same loss, same updated parameters
     fit = graphsc.GraphSC(**kw, n_clusters=3, device="cpu")
     fit.model.dropout = None

@@ -412,3 +412,42 @@ def test_scdeepsort_fit_loop_vs_reference_on_cpu(cpu_kernels, tmp_path, monkeypa
     import scdeepsort_golden_checks as chk
     gold, kw = chk.load()
     chk.check_case(gold, kw, tag, "cpu", tmp_path, monkeypatch, block_eval=block_eval, rel_err=rel_err)
+
+
+def test_scdsc_frozen_autoencoder_cache(cpu_kernels):
+    """AE.forward hands back the first call's outputs while the autoencoder is frozen, in training mode and fed the same tensor — and
+    moves the BatchNorm running statistics exactly as the recomputation would (the eval-mode passes of scdsc.py:256-263 read them);
+    anything that could change the outputs (a parameter update, another input, eval mode, a trainable autoencoder) recomputes."""
+    from dance_amd.modules.single_modality.clustering.scdsc import AE
+    torch.manual_seed(0)
+    kw = dict(n_enc_1=24, n_enc_2=16, n_enc_3=16, n_dec_1=16, n_dec_2=16, n_dec_3=24, n_input=20, n_z1=16, n_z2=12, n_z3=8)
+    a, b = AE(**kw), AE(**kw)
+    b.load_state_dict(a.state_dict())
+    b.cache_frozen = False
+    for m in (a, b):
+        for p in m.parameters():
+            p.requires_grad_(False)
+        m.train()
+    x = torch.randn(50, 20)
+    for _ in range(4):
+        oa, ob = a(x), b(x)
+    assert a._cache is not None and b._cache is None
+    assert all(torch.equal(u, v) for u, v in zip(oa, ob))                       # the cached tensors ARE the recomputed ones
+    assert oa[0] is a(x)[0]
+    b(x)
+    for i in range(1, 10):
+        ba, bb = getattr(a, f"BN{i}"), getattr(b, f"BN{i}")
+        assert int(ba.num_batches_tracked) == int(bb.num_batches_tracked) == 5
+        assert rel_err(ba.running_mean.numpy(), bb.running_mean.numpy()) < 1e-6 and rel_err(ba.running_var.numpy(), bb.running_var.numpy()) < 1e-6
+    a.eval(), b.eval()
+    assert rel_err(a(x)[0].numpy(), b(x)[0].numpy()) < 1e-5                     # eval mode: running statistics, never the cache
+    a.train(), b.train()
+    with torch.no_grad():
+        a.enc_1.weight.mul_(1.01)
+        b.enc_1.weight.mul_(1.01)
+    assert all(torch.equal(u, v) for u, v in zip(a(x), b(x)))                   # a parameter changed in place: recomputed
+    y = torch.randn(50, 20)
+    assert all(torch.equal(u, v) for u, v in zip(a(y), b(y)))                   # another input: recomputed
+    a.enc_1.weight.requires_grad_(True)
+    a(y)
+    assert a._cache is None                                                      # a trainable autoencoder is never cached
