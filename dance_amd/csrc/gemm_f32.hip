@@ -634,6 +634,9 @@ int gemm_f32_impl(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, con
     return dh_bias_act_f32(M, N, C, ldc, bias, act, stream);
   }
   Plan p = make_plan(M, N, K, tile, trans_a != 0);
+  // (Tried in round 5: handing the rows of the last, partial round of large tiles — 134 of 7814 at the headline shape — to the
+  // 128 x 128 configuration as a second launch: 14.50 instead of 14.26 ms.  The dispatcher already back-fills the last round as
+  // workgroups retire; a second launch adds a drain and a prologue.  profiles/r05l_bench_line.json.)
   float* slabs = nullptr;
   if (p.S > 1) {
     const size_t need = (size_t)p.S * (size_t)M * (size_t)N * sizeof(float);
