@@ -127,11 +127,11 @@ def synth_rand_graph(n, k, device, seed):
     return synth_rand_graph_rows(n, k, 0, n, device, seed)
 
 
-def synth_knn_graph(n, k, device, seed, reorder=True):
+def synth_knn_graph(n, k, device, seed, reorder=True, order="morton"):
     """'knn-k15' (SURVEY.md §8d): cells from 20 Gaussian clusters in a 50-d latent space; exact kNN (self included) and
     UMAP connectivities by the NeighborGraph kernels (dh_knn_bruteforce_f32, dh_umap_membership_f32, ...).  With ``reorder`` the
-    cells are then renumbered by a locality order (reverse Cuthill-McKee, dance_amd.graph.locality_order — graph set-up, like the
-    kNN search itself) and the graph permuted with the edge order inside every row kept, so the layer's outputs are those of
+    cells are then renumbered by a locality order (``order``: Z-order over the embedding's principal components on the device, or
+    reverse Cuthill-McKee on the host; dance_amd.graph.locality_order — graph set-up, like the kNN search itself) and the graph permuted with the edge order inside every row kept, so the layer's outputs are those of
     the unordered graph row for row, bit for bit.  Returns (graph as built, renumbered graph or None, perm, build s, order s)."""
     from dance_amd import kernels
     from dance_amd.graph import CSRGraph, locality_order
@@ -148,10 +148,14 @@ def synth_knn_graph(n, k, device, seed, reorder=True):
     if not reorder:
         return graph, None, None, build_s, 0.0
     t0 = time.perf_counter()
-    perm = locality_order(graph).to(device)
+    # "morton": Z-order over the leading principal components of the embedding the neighbours were searched in, on the device
+    # (dance_amd.graph.morton_order); "rcm": reverse Cuthill-McKee of the pattern on the host (0.5 s at 1M cells)
+    perm = (locality_order(graph, "morton", coords=emb) if order == "morton" else locality_order(graph)).to(device)
+    torch.cuda.synchronize()
+    order_s = time.perf_counter() - t0
     ordered = graph.permute(perm)
     torch.cuda.synchronize()
-    return graph, ordered, perm, build_s, time.perf_counter() - t0
+    return graph, ordered, perm, build_s, order_s
 
 
 def layer_bytes(n, nnz, f=N_GENES, h=N_HIDDEN, s=4):
@@ -277,6 +281,9 @@ def main():
     ap.add_argument("--no-knn-workload", action="store_true", help="skip the second (knn-k15) timed workload at 1 GPU")
     ap.add_argument("--no-x3-row", action="store_true", help="skip the separately labelled split-bf16 GEMM row at 1 GPU")
     ap.add_argument("--no-x-randn", action="store_true", help="skip the A/B leg with standard-normal X at 1 GPU")
+    ap.add_argument("--locality", choices=["morton", "rcm"], default="morton",
+                    help="locality order of the knn-k15 workload: Z-order over the embedding's principal components on the device (default) or "
+                         "reverse Cuthill-McKee on the host")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the model-level rows of BASELINE configs 2, 3 and 5 (scripts/bench_configs.py; ~1.5 min at 1 GPU)")
     ap.add_argument("--exchange", choices=["auto", "halo", "allgather", "alltoall"], default="auto",
@@ -429,7 +436,7 @@ def main():
     knn_out = None
     if world == 1 and not args.no_knn_workload:
         del sg
-        kg, kg_ordered, perm, build_s, order_s = synth_knn_graph(n, K_NEIGH, dev, seed=7)
+        kg, kg_ordered, perm, build_s, order_s = synth_knn_graph(n, K_NEIGH, dev, seed=7, order=args.locality)
         sgk = sharding.ShardedGCNGraph.from_global_csr(kg)
         k_elapsed, _ = time_steps(make_step(sgk), fence, args.steps, args.warmup, world, dev, kernels.KernelTimer)
         k_ms = k_elapsed / args.steps * 1e3
@@ -446,8 +453,10 @@ def main():
         x, dy = x_saved, dy_saved
         del y_ord, y_plain, sgo
         knn_out = {"workload": f"same layer on knn-k15: exact kNN (k={K_NEIGH}, self included) of a 20-cluster 50-d embedding + UMAP "
-                               f"connectivities, built on the device by the NeighborGraph kernels; cells renumbered by reverse "
-                               f"Cuthill-McKee (graph set-up), X permuted once, outputs identical row for row",
+                               f"connectivities, built on the device by the NeighborGraph kernels; cells renumbered by "
+                               f"{'Z-order over the 3 leading principal components of the embedding (device)' if args.locality == 'morton' else 'reverse Cuthill-McKee (host)'}"
+                               f" (graph set-up), X permuted once, outputs identical row for row",
+                   "locality_order": args.locality,
                    "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "locality_order_s": round(order_s, 4),
                    "ms_per_step": o_ms, "value": n / (o_elapsed / args.steps), "unit": "cells/s",
                    "layer_hbm_frac": round(layer_bytes(n, kg.nnz) / (o_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),

@@ -11,9 +11,11 @@ P - 1 links of a GPU usable at once):
     halo       per exchange: max over peers of (rows from that peer x H x 4) / 153 GB/s
     allgather  per exchange: (N / P x H x 4) / 153 GB/s  (every peer sends its shard over its own link)
     all-reduce of dW (4 MB): a latency-bound ~60 us, counted once
+    alltoall   per exchange (4 per step): (N / P x H / P x 4) / 153 GB/s per link; the SpMM then runs over ALL rows at width H / P
 projected step = GEMM + pack + max(exchange, interior SpMM) + boundary SpMM   (forward)
                + mask + pack + max(exchange, interior SpMM) + boundary SpMM + dW GEMM + all-reduce   (backward)
-Graphs: rand-k15 (no locality) and knn-k15 renumbered by reverse Cuthill-McKee.
+alltoall step  = GEMM + mask + dW GEMM + all-reduce + 2 x (pack + unpack) + 4 exchanges + SpMM(A) + SpMM(A^T) over all rows, H / P wide
+Graphs: rand-k15 (no locality) and knn-k15 renumbered by locality (Z-order over the embedding's principal components).
     python scripts/emulate_rank.py [--cells N] [--ranks-of 2,4,8] [--rank -1]   (-1: the middle rank)"""
 import argparse
 import json
@@ -85,8 +87,42 @@ def measure_rank(graph, rank, world, dev, F, H):
             b["pack_ms"] + max(b["exchange_halo_ms_projected"], b["interior_spmm_ms"]) + b["boundary_spmm_ms"] + b["gemm_dw_ms"] + ALLREDUCE_S * 1e3)
     # dense all-gather: nothing to overlap with (every row may be needed): exchange, then one SpMM over all rows (= interior + boundary time)
     ag = compute - f["pack_ms"] - b["pack_ms"] + f["exchange_allgather_ms_projected"] + b["exchange_allgather_ms_projected"] + ALLREDUCE_S * 1e3
-    r.update(fwd=f, bwd=b, measured_compute_ms=compute, projected_step_ms={"halo": halo, "allgather": ag},
-             projected_cells_per_s={"halo": graph.n_rows / halo * 1e3, "allgather": graph.n_rows / ag * 1e3})
+    # feature-sliced all-to-all (sharding.py mode "alltoall"): after the local GEMM every rank receives ALL rows of H / P columns,
+    # aggregates all N rows at that width, and sends the result back; backward the same way round.  Measured here: the two pack /
+    # unpack passes per exchange exactly as sharding.rows_to_columns / columns_to_rows perform them (minus the collective) and the
+    # full-graph SpMM at width H / P on the real graph; projected: the all-to-all, (P - 1) x chunk x H / P x 4 bytes in over P - 1
+    # links at once = chunk x H / P x 4 bytes per link.
+    a2a = None
+    if H % world == 0:
+        hq, n_all = H // world, graph.n_rows
+        gt = graph.transpose()
+        loc = torch.randn((n_loc, H), device=dev)
+        cols_buf = torch.randn((world * sg.chunk, hq), device=dev)
+        ycols = torch.empty((n_all, hq), device=dev)
+
+        def pack_rows_to_columns():
+            send = torch.zeros((world, sg.chunk, hq), dtype=loc.dtype, device=dev)
+            send[:, :n_loc] = loc.reshape(n_loc, world, hq).transpose(0, 1)
+            return send
+
+        def unpack_columns_to_rows():
+            recv = cols_buf.reshape(world, sg.chunk, hq)
+            return recv[:, :n_loc].transpose(0, 1).reshape(n_loc, world * hq).contiguous()
+        a2a = {"slice_width": hq,
+               "pack_ms": t_ms(pack_rows_to_columns), "unpack_ms": t_ms(unpack_columns_to_rows),
+               "spmm_all_rows_fwd_ms": t_ms(lambda: kernels.spmm_csr(graph.rowptr, graph.col, graph.val, cols_buf[:n_all], n_cols=n_all, act=kernels.ACT_RELU, out=ycols)),
+               "spmm_all_rows_bwd_ms": t_ms(lambda: kernels.spmm_csr(gt.rowptr, gt.col, gt.val, cols_buf[:n_all], n_cols=n_all, out=ycols)),
+               "exchange_ms_projected_each": sg.chunk * hq * 4 / (LINK_GBS * 1e9) * 1e3,
+               "bytes_in_per_exchange": (world - 1) * sg.chunk * hq * 4}
+        a2a_step = (f["gemm_ms"] + b["mask_ms"] + b["gemm_dw_ms"] + ALLREDUCE_S * 1e3 + a2a["spmm_all_rows_fwd_ms"] + a2a["spmm_all_rows_bwd_ms"]
+                    + 2 * (a2a["pack_ms"] + a2a["unpack_ms"]) + 4 * a2a["exchange_ms_projected_each"])
+        del loc, cols_buf, ycols
+    steps = {"halo": halo, "allgather": ag}
+    if a2a is not None:
+        steps["alltoall"] = a2a_step
+    best = min(steps, key=steps.get)
+    r.update(fwd=f, bwd=b, alltoall=a2a, measured_compute_ms=compute, projected_step_ms=steps, projected_best_mode=best,
+             projected_cells_per_s={m: graph.n_rows / v * 1e3 for m, v in steps.items()})
     return r
 
 
@@ -107,7 +143,7 @@ def main(argv=None):
         graphs["rand-k15"] = CSRGraph(rp, c, v, n, n)
     if "knn" in args.graphs:
         _, ordered, _, _, _ = bench.synth_knn_graph(n, K, dev, seed=7)
-        graphs["knn-k15 (RCM order)"] = ordered
+        graphs["knn-k15 (Z-order over the embedding's principal components)"] = ordered
     for gname, g in graphs.items():
         g.transpose()
         res[gname] = {"nnz": g.nnz}
@@ -115,7 +151,7 @@ def main(argv=None):
             rank = world // 2 if args.rank < 0 else min(args.rank, world - 1)
             r = measure_rank(g, rank, world, dev, F, H)
             res[gname][f"P={world}"] = r
-            print(gname, f"P={world}", json.dumps({k: r[k] for k in ("measured_compute_ms", "projected_step_ms")}), file=sys.stderr, flush=True)
+            print(gname, f"P={world}", json.dumps({k: r[k] for k in ("measured_compute_ms", "projected_step_ms", "projected_best_mode")}), file=sys.stderr, flush=True)
             torch.cuda.empty_cache()
     print(json.dumps(res))
 
