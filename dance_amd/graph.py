@@ -185,7 +185,7 @@ def morton_order(coords: torch.Tensor, dims: int = 3) -> torch.Tensor:
     cov = (xc.t() @ xc).double() / max(n - 1, 1)                       # d x d: the one reduction over all rows
     # the d x d eigen-decomposition on the host (d = 50: microseconds; the device solver's first call alone costs ~0.15 s)
     evals, evecs = np.linalg.eigh(cov.cpu().numpy())
-    axes = torch.from_numpy(np.ascontiguousarray(evecs[:, ::-1][:, :min(dims, d)])).to(device=x.device, dtype=torch.float32)  # leading components first
+    axes = torch.from_numpy(evecs[:, ::-1][:, :min(dims, d)].copy()).to(device=x.device, dtype=torch.float32)  # leading components first
     proj = xc @ axes                                                   # [N, dims]
     lo, hi = proj.amin(0, keepdim=True), proj.amax(0, keepdim=True)
     q = ((proj - lo) / (hi - lo).clamp_min(1e-30) * (2**21 - 1)).to(torch.int64).clamp_(0, 2**21 - 1)
