@@ -33,7 +33,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .... import kernels
-from ....autograd import HipLinear, spmm, zinb_nll
+from ....autograd import HipLinear, linear, spmm, zinb_nll
 from ....graph import CSRGraph, TensorKeyedCache
 from ....transforms import Compose, SetConfig
 from ....transforms.graph import HeteronetGraph
@@ -73,7 +73,7 @@ class NCDataset:
 def contrastive_loss(z1, z2, temperature=0.5):
     z1 = F.normalize(z1, dim=-1)
     z2 = F.normalize(z2, dim=-1)
-    logits = torch.mm(z1, z2.t()) / temperature
+    logits = linear(z1, z2) / temperature   # z1 z2^T on dh_gemm_f32, gradients to both operands (autograd._LinearFn)
     labels = torch.arange(z1.size(0), device=z1.device)
     return F.cross_entropy(logits, labels)
 

@@ -72,7 +72,9 @@ class NeighborGraph(BaseTransform):
 
     def _gauss_knn(self, idx, dist):
         """knn=True: weights on the kNN entries with sigma_i^2 = median of the point's k - 1 squared neighbour distances, pattern
-        symmetrised by copying W_ij to a missing W_ji (float64 arithmetic on the device, as scanpy's numpy)."""
+        symmetrised by copying W_ij to a missing W_ji (float64 arithmetic on the device, as scanpy's numpy).  Host-grade: torch's
+        sort / isin / bincount on device tensors, not hand-written kernels — ``method="gauss"`` is a non-default option no dance
+        pipeline selects; the default ``method="umap"`` path above runs on dh_knn_bruteforce_f32 / dh_umap_* only."""
         n, k = idx.shape
         d2 = dist[:, 1:].double()**2
         srt = torch.sort(d2, dim=1).values
