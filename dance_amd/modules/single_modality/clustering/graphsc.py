@@ -603,7 +603,8 @@ class GraphSC(BaseClusteringMethod):
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
             self.model.train()
-            emb = self.model.forward_sharded(scg, feats)  # :202 (the embedding that is kept)
+            with torch.no_grad():  # :202 — kept only as z_epoch: no autograd graph over the whole cell set for it (BatchNorm's running
+                emb = self.model.forward_sharded(scg, feats)  # statistics and the dropout draws are those of a grad-mode forward)
             z_epoch = emb.detach()
             emb2 = self.model.forward_sharded(scg, feats)  # second forward, fresh dropout (:215)
             loss = norm * sharding.sharded_selfloop_gram_bce(F.dropout(emb2, self.model.decoder.dropout), has_self, pos_weight, scg)
