@@ -55,40 +55,42 @@ __global__ __launch_bounds__(256) void gather_transposed_kernel(int64_t n_rows, 
   }
 }
 
-// Small graphs — the message-flow block of a mini-batch (129 rows of ~200 entries, transposed once per training step inside a captured
-// hipGraph, where the sort-based path is 12 dependent launches of ~5 us each) — in ONE workgroup, every phase parallel over the
-// entries or the columns:
-//   1. histogram of the columns in LDS, block-wide exclusive scan = out_rowptr;
-//   2. every entry claims a slot of its column's segment through an LDS cursor — in arrival order, i.e. unordered;
-//   3. one thread per column insertion-sorts its segment by source row (segments are a dozen entries; the stable sort's order is
-//      "ascending source row", and entries of one source row never share a column except in a static block's padding row, whose
-//      entries are interchangeable zeros).
-// The first version placed the rows one after the other with a barrier per row: correct, but 129 barriers made it SLOWER than the 12
-// launches it replaced (3.9 vs 3.3 s per 1M-cell graph-sc epoch).  Inconsistent input (a column >= n_cols, more entries than the
-// caller's nnz) is skipped instead of written out of bounds; -DDH_TRANSPOSE_DEBUG reports it.
-#ifndef DH_TRANSPOSE_SMALL_T
-#define DH_TRANSPOSE_SMALL_T 1024
-#endif
-constexpr int SMALL_T = DH_TRANSPOSE_SMALL_T;
+// Small graphs — the message-flow block of a mini-batch (128 rows of ~200 entries, transposed once per training step inside a captured
+// hipGraph, where the sort-based path is 12 dependent launches of ~5 us each) — in TWO launches:
+//   csr_transpose_small_kernel (ONE workgroup of 1024): histogram of the columns in LDS, block-wide exclusive scan = out_rowptr, then
+//       every entry claims a slot of its column's segment through an LDS cursor — in arrival order, i.e. unordered.  Entries are dealt
+//       to the threads 16 at a time with all 16 loads issued before the first use: one workgroup hides memory latency by depth or not
+//       at all (the versions that walked rows paid a round trip per row and chunk: ~100 us);
+//   csr_segment_sort_kernel (one WAVEFRONT per column, the whole chip): the segment's keys (source row, entry position) go into LDS,
+//       every lane ranks its entries by counting the smaller keys (a broadcast LDS read per comparison), and the segment is rewritten
+//       in rank order = the stable sort's order.  Sorted segments are recognised in one pass and left alone.
+// History (profiles/r05_replay_fault.md): v1 placed the rows one after the other with a barrier per row (3.9 s per 1M-cell graph-sc
+// epoch against 3.3 s for the sort path), v2 sorted the segments inside the single workgroup by insertion (4.4 s), v3 split the sort off
+// but still walked rows (3.9 s).  Inconsistent input (a column >= n_cols, more entries than the caller's nnz) is skipped instead of
+// written out of bounds.
+constexpr int SMALL_T = 1024, SMALL_U = 16, SMALL_MAX_ROWS = 2048;
 __global__ __launch_bounds__(SMALL_T) void csr_transpose_small_kernel(int n_rows, int n_cols, int nnz_cap, const int32_t* __restrict__ rowptr,
                                                                       const int32_t* __restrict__ col, const float* __restrict__ val,
                                                                       int32_t* __restrict__ out_rowptr, int32_t* __restrict__ out_col,
                                                                       float* __restrict__ out_val, int32_t* __restrict__ out_perm) {
   extern __shared__ int cursor[];  // [n_cols + 1] counts -> segment starts -> running cursors
+  __shared__ int rp[SMALL_MAX_ROWS + 1];
   __shared__ int wave_tot[SMALL_T / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nnz = min(rowptr[n_rows], nnz_cap);  // never beyond the buffers the caller sized for nnz_cap entries
-#ifdef DH_TRANSPOSE_DEBUG
-  if (tid == 0 && rowptr[n_rows] != nnz_cap) printf("csr_transpose_small: rowptr[%d] = %d but the caller said nnz = %d\n", n_rows, rowptr[n_rows], nnz_cap);
-#endif
+  for (int i = tid; i <= n_rows; i += SMALL_T) rp[i] = rowptr[i];
   for (int i = tid; i <= n_cols; i += SMALL_T) cursor[i] = 0;
   __syncthreads();
-  for (int e = tid; e < nnz; e += SMALL_T) {
-    const int c = col[e];
-    if ((unsigned)c < (unsigned)n_cols) atomicAdd(&cursor[c], 1);
-#ifdef DH_TRANSPOSE_DEBUG
-    else printf("csr_transpose_small: column %d at entry %d outside [0, %d) (nnz %d of cap %d, rows %d)\n", c, e, n_cols, nnz, nnz_cap, n_rows);
-#endif
+  const int nnz = min(rp[n_rows], nnz_cap);  // never beyond the buffers the caller sized for nnz_cap entries
+  for (int base = 0; base < nnz; base += SMALL_T * SMALL_U) {
+    int c[SMALL_U];
+#pragma unroll
+    for (int u = 0; u < SMALL_U; ++u) {
+      const int e = base + u * SMALL_T + tid;
+      c[u] = e < nnz ? col[e] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_U; ++u)
+      if ((unsigned)c[u] < (unsigned)n_cols) atomicAdd(&cursor[c[u]], 1);
   }
   __syncthreads();
   // exclusive scan of cursor[0 .. n_cols]: a contiguous chunk per thread, then the threads' sums across the block
@@ -104,71 +106,98 @@ __global__ __launch_bounds__(SMALL_T) void csr_transpose_small_kernel(int n_rows
   }
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  int base = incl - sum;
-  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  int base0 = incl - sum;
+  for (int w = 0; w < wave; ++w) base0 += wave_tot[w];
   for (int i = b; i < e_; ++i) {
-    const int c = cursor[i];
-    cursor[i] = base;
-    out_rowptr[i] = base;
-    base += c;
+    const int cnt = cursor[i];
+    cursor[i] = base0;
+    out_rowptr[i] = base0;
+    base0 += cnt;
   }
   __syncthreads();
-  // unordered placement: a wave owns whole rows (row id = one binary search per entry avoided), lanes stride over the row's entries
-  for (int r = wave; r < n_rows; r += SMALL_T / 64) {
-    const int rs = rowptr[r], re = min(rowptr[r + 1], nnz);
-    for (int e0 = rs; e0 < re; e0 += 64) {
-      const int e = e0 + lane;
-      const bool live = e < re;
-      const int c = live ? col[e] : -1;
-      if (!live || (unsigned)c >= (unsigned)n_cols) continue;
-      // 64 entries of ONE column (a static block's padding row: thousands of zeros in column 0): one cursor bump for the chunk,
-      // slots in entry order — the run arrives sorted and the insertion sort below passes over it in linear time
-      const int c0 = __builtin_amdgcn_readfirstlane(c);
-      const unsigned long long act = __ballot(true);
-      int pos;
-      if (__ballot(c == c0) == act) {
-        const int lead = __ffsll((long long)act) - 1;
-        int first = 0;
-        if (lane == lead) first = atomicAdd(&cursor[c0], __popcll(act));
-        first = __shfl(first, lead, 64);
-        pos = first + __popcll(act & ((1ull << lane) - 1ull));
-      } else {
-        pos = atomicAdd(&cursor[c], 1);
+  for (int base = 0; base < nnz; base += SMALL_T * SMALL_U) {
+    int c[SMALL_U];
+    float v[SMALL_U];
+#pragma unroll
+    for (int u = 0; u < SMALL_U; ++u) {
+      const int e = base + u * SMALL_T + tid;
+      c[u] = e < nnz ? col[e] : -1;
+      v[u] = (e < nnz && val) ? val[e] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SMALL_U; ++u) {
+      if ((unsigned)c[u] >= (unsigned)n_cols) continue;
+      const int e = base + u * SMALL_T + tid;
+      int lo = 0, hi = n_rows;  // the row r with rp[r] <= e < rp[r + 1] (skips empty rows)
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rp[mid] <= e) lo = mid; else hi = mid;
       }
-      if (pos >= nnz) {
-#ifdef DH_TRANSPOSE_DEBUG
-        printf("csr_transpose_small: cursor %d of column %d past nnz %d (row %d entry %d)\n", pos, c, nnz, r, e);
-#endif
-        continue;
-      }
-      out_col[pos] = r;
+      const int pos = atomicAdd(&cursor[c[u]], 1);
+      if (pos >= nnz) continue;
+      out_col[pos] = lo;
       out_perm[pos] = e;
-      if (out_val) out_val[pos] = val[e];
+      if (out_val) out_val[pos] = v[u];
     }
   }
-  __syncthreads();  // (the block's own global writes are visible to the block after the barrier)
-  // per-column insertion sort by (source row, entry position): the stable sort's order
-  for (int c = tid; c < n_cols; c += SMALL_T) {
-    const int s0 = out_rowptr[c], s1 = min(cursor[c], nnz);  // cursor[c] now = end of the column's segment
-    for (int i = s0 + 1; i < s1; ++i) {
-      const int r = out_col[i], e = out_perm[i];
-      const float v = out_val ? out_val[i] : 0.f;
-      int j = i - 1;
-      while (j >= s0 && (out_col[j] > r || (out_col[j] == r && out_perm[j] > e))) {
-        out_col[j + 1] = out_col[j];
-        out_perm[j + 1] = out_perm[j];
-        if (out_val) out_val[j + 1] = out_val[j];
-        --j;
+}
+
+// One wavefront per column: rank sort of the segment by (source row, entry position).  Segments of up to SEG_LDS entries are
+// ranked and rewritten through LDS; longer ones (a hub column of a general graph, never a mini-batch block of <= 2048 rows) by a
+// serial insertion — correct, slow.
+constexpr int SEG_LDS = 2048;
+__global__ __launch_bounds__(64) void csr_segment_sort_kernel(int n_cols, const int32_t* __restrict__ rowptr_t, int32_t* __restrict__ out_col,
+                                                              float* __restrict__ out_val, int32_t* __restrict__ out_perm) {
+  __shared__ unsigned long long keys[SEG_LDS], sorted[SEG_LDS];
+  __shared__ float sval[SEG_LDS];
+  const int lane = threadIdx.x;
+  const int c = blockIdx.x;
+  if (c >= n_cols) return;
+  const int s0 = rowptr_t[c], s1 = rowptr_t[c + 1], len = s1 - s0;
+  if (len <= 1) return;
+  auto key_at = [&](int i) -> unsigned long long { return ((unsigned long long)(unsigned)out_col[s0 + i] << 32) | (unsigned)out_perm[s0 + i]; };
+  if (len > SEG_LDS) {
+    if (lane == 0) {
+      for (int i = 1; i < len; ++i) {
+        const int r = out_col[s0 + i], e = out_perm[s0 + i];
+        const float vv = out_val ? out_val[s0 + i] : 0.f;
+        int j = i - 1;
+        while (j >= 0 && (out_col[s0 + j] > r || (out_col[s0 + j] == r && out_perm[s0 + j] > e))) {
+          out_col[s0 + j + 1] = out_col[s0 + j];
+          out_perm[s0 + j + 1] = out_perm[s0 + j];
+          if (out_val) out_val[s0 + j + 1] = out_val[s0 + j];
+          --j;
+        }
+        out_col[s0 + j + 1] = r;
+        out_perm[s0 + j + 1] = e;
+        if (out_val) out_val[s0 + j + 1] = vv;
       }
-      out_col[j + 1] = r;
-      out_perm[j + 1] = e;
-      if (out_val) out_val[j + 1] = v;
     }
+    return;
+  }
+  for (int i = lane; i < len; i += 64) keys[i] = key_at(i);
+  __syncthreads();
+  bool ok = true;
+  for (int i = lane; i + 1 < len; i += 64) ok = ok && keys[i] <= keys[i + 1];
+  if (__ballot(!ok) == 0ull) return;   // sorted already
+  for (int i = lane; i < len; i += 64) {
+    const unsigned long long k = keys[i];
+    int rk = 0;
+    for (int j = 0; j < len; ++j) rk += keys[j] < k ? 1 : 0;   // keys are distinct (distinct entry positions)
+    sorted[rk] = k;
+    sval[rk] = out_val ? out_val[s0 + i] : 0.f;
+  }
+  __syncthreads();
+  for (int i = lane; i < len; i += 64) {
+    const unsigned long long k = sorted[i];
+    out_col[s0 + i] = (int)(k >> 32);
+    out_perm[s0 + i] = (int)(unsigned)k;
+    if (out_val) out_val[s0 + i] = sval[i];
   }
 }
 bool transpose_small_applies(int64_t n_rows, int64_t n_cols, int64_t nnz) {
   static const bool on = getenv("DANCE_AMD_TRANSPOSE_SMALL") && getenv("DANCE_AMD_TRANSPOSE_SMALL")[0] == '1';  // round-5 switch, default off
-  return on && n_rows <= 2048 && n_cols <= 12000 && nnz <= 262144;
+  return on && n_rows <= SMALL_MAX_ROWS && n_cols <= 12000 && nnz <= 262144;
 }
 
 int end_bit_for(int64_t n_cols) {
@@ -216,13 +245,9 @@ extern "C" int dh_csr_transpose(int64_t n_rows, int64_t n_cols, int64_t nnz, con
   if (!rowptr || !col || !out_col || !out_perm)
     return dh::fail(DH_ERR_INVALID, "dh_csr_transpose: null pointer");
   if (transpose_small_applies(n_rows, n_cols, nnz)) {
-#ifdef DH_TRANSPOSE_STATIC_LDS
-    const size_t dyn_lds = 0;
-#else
-    const size_t dyn_lds = (size_t)(n_cols + 1) * sizeof(int);
-#endif
-    hipLaunchKernelGGL(csr_transpose_small_kernel, dim3(1), dim3(SMALL_T), dyn_lds, st, (int)n_rows, (int)n_cols, (int)nnz,
+    hipLaunchKernelGGL(csr_transpose_small_kernel, dim3(1), dim3(SMALL_T), (size_t)(n_cols + 1) * sizeof(int), st, (int)n_rows, (int)n_cols, (int)nnz,
                        rowptr, col, val, out_rowptr, out_col, out_val, out_perm);
+    hipLaunchKernelGGL(csr_segment_sort_kernel, dim3((unsigned)n_cols), dim3(64), 0, st, (int)n_cols, out_rowptr, out_col, out_val, out_perm);
     return dh::check_launch("dh_csr_transpose");
   }
   const size_t need = dh_csr_transpose_workspace_bytes(n_rows, n_cols, nnz);

@@ -29,6 +29,9 @@ class CSRGraph:
         self.n_rows, self.n_cols = int(n_rows), int(n_cols)
         self.symmetric = bool(symmetric)  # value-symmetric square matrix: A^T == A, no transpose needed
         self._t: Optional["CSRGraph"] = None
+        # rows whose entries the transpose is built from (None: all).  A StaticCellBlock's CSR ends with a padding row of zeros that
+        # only exists to keep the entry count static: its transpose needs the real rows alone (every consumer goes by the row pointers)
+        self.t_rows: Optional[int] = None
 
     # ---- constructors --------------------------------------------------------------------------------------
     @classmethod
@@ -80,7 +83,7 @@ class CSRGraph:
         if self.symmetric:
             return self
         if self._t is None:
-            rp, c, v, _ = kernels.csr_transpose(self.rowptr, self.col, self.val, self.n_rows, self.n_cols)
+            rp, c, v, _ = kernels.csr_transpose(self.rowptr, self.col, self.val, self.n_rows if self.t_rows is None else self.t_rows, self.n_cols)
             self._t = CSRGraph(rp, c, v, self.n_cols, self.n_rows)
             self._t._t = self
         return self._t

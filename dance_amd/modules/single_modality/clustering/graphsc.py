@@ -59,6 +59,8 @@ class WeightedGraphConv(nn.Module):
         g = graph.__dict__.get("_csr")  # one CSRGraph (hence one transpose for the backward) per block, shared by both forwards of a batch
         if g is None:
             g = graph.__dict__["_csr"] = CSRGraph(graph.rowptr, graph.col, graph.val, n_dst + pad, graph.number_of_src_nodes())
+            if pad:
+                g.t_rows = n_dst  # the transpose (backward gather) is built from the real rows; the padding row holds zeros only
         if self._norm not in cache:
             colscale = rowscale = None
             if self._norm != "none":

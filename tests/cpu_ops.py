@@ -190,13 +190,18 @@ def block_cells_static(rowptr, col, val, seeds, n_genes, brp, bcol, bval, bad, w
 def csr_transpose(rowptr, col, val, n_rows, n_cols):
     """(rowptr_t, col_t, val_t, perm) of A^T, stable by input position (dh_csr_transpose)."""
     nnz = col.numel()
-    rows = torch.repeat_interleave(torch.arange(n_rows), (rowptr[1:] - rowptr[:-1]).to(torch.int64))
-    perm = torch.sort(col.to(torch.int64), stable=True).indices
-    counts = torch.bincount(col.to(torch.int64), minlength=n_cols)
+    rp = rowptr[:n_rows + 1].to(torch.int64)   # n_rows may be fewer than the CSR holds (CSRGraph.t_rows: a static block without its padding row)
+    live = int(rp[-1])
+    rows = torch.repeat_interleave(torch.arange(n_rows), rp[1:] - rp[:-1])
+    c = col[:live].to(torch.int64)
+    perm = torch.sort(c, stable=True).indices
+    counts = torch.bincount(c, minlength=n_cols)
     rowptr_t = torch.zeros(n_cols + 1, dtype=torch.int64)
     rowptr_t[1:] = torch.cumsum(counts, 0)
-    assert perm.numel() == nnz
-    return rowptr_t.to(torch.int32), rows[perm].to(torch.int32), None if val is None else val[perm].contiguous(), perm.to(torch.int32)
+    pad = nnz - live   # the buffers keep their static size; nothing points at the tail
+    col_t = torch.cat((rows[perm], torch.zeros(pad, dtype=torch.int64))).to(torch.int32)
+    val_t = None if val is None else torch.cat((val[:live][perm], torch.zeros(pad, dtype=val.dtype))).contiguous()
+    return rowptr_t.to(torch.int32), col_t, val_t, torch.cat((perm, torch.zeros(pad, dtype=torch.int64))).to(torch.int32)
 
 
 def bias_act_(X, bias, act=ACT_NONE):
