@@ -337,6 +337,7 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
                 self.last_loss = allsum(loss.detach())
         finally:
             model.ae.rows_total, model.ae.group = None, None
+            model.ae._cache = None  # the kept autoencoder outputs (14 GB at 1M cells) are the fit's, not the model's
         self.q = Q[keys[int(np.argmax(aris))]]
 
     def predict_proba(self, x=None) -> np.ndarray:
