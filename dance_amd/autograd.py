@@ -352,11 +352,11 @@ class _ZINBNLL(torch.autograd.Function):
     promote the expression)."""
 
     @staticmethod
-    def forward(ctx, x, mean, disp, pi, scale_factor, ridge_lambda: float):
+    def forward(ctx, x, mean, disp, pi, scale_factor, ridge_lambda: float, logits: bool = False):
         x, mean, disp, pi = (t.contiguous() if t.stride(-1) != 1 else t for t in (x.float(), mean, disp, pi))
         sf = None if scale_factor is None else scale_factor.detach().to(torch.float64).contiguous()
-        rowloss = kernels.zinb_nll_forward(x, mean, disp, pi, sf, ridge_lambda)
-        ctx.ridge = float(ridge_lambda)
+        rowloss = kernels.zinb_nll_forward(x, mean, disp, pi, sf, ridge_lambda, logits=logits)
+        ctx.ridge, ctx.logits = float(ridge_lambda), bool(logits)
         ctx.save_for_backward(x, mean, disp, pi, sf)
         return rowloss.sum() / float(x.shape[0] * x.shape[1])
 
@@ -364,13 +364,20 @@ class _ZINBNLL(torch.autograd.Function):
     def backward(ctx, g):
         x, mean, disp, pi, sf = ctx.saved_tensors
         up = (g.to(torch.float64) / float(x.shape[0] * x.shape[1])).reshape(1).contiguous()
-        dm, dd, dp = kernels.zinb_nll_backward(x, mean, disp, pi, sf, ctx.ridge, up)
-        return None, dm, dd, dp, None, None
+        dm, dd, dp = kernels.zinb_nll_backward(x, mean, disp, pi, sf, ctx.ridge, up, logits=ctx.logits)
+        return None, dm, dd, dp, None, None, None
 
 
 def zinb_nll(x, mean, disp, pi, scale_factor=None, ridge_lambda: float = 0.0) -> torch.Tensor:
     """mean over all (cell, gene) of the ZINB negative log-likelihood; float64 scalar (see _ZINBNLL)."""
-    return _ZINBNLL.apply(x, mean, disp, pi, scale_factor, ridge_lambda)
+    return _ZINBNLL.apply(x, mean, disp, pi, scale_factor, ridge_lambda, False)
+
+
+def zinb_nll_from_logits(x, mean_raw, disp_raw, pi_raw, scale_factor=None, ridge_lambda: float = 0.0) -> torch.Tensor:
+    """``zinb_nll(x, MeanAct(mean_raw), DispAct(disp_raw), sigmoid(pi_raw), ...)`` — the loss on the decoder heads of scdsc.py:409-411 /
+    sctag.py — with the three activations and their backward evaluated inside the two loss kernels instead of as ~17 elementwise
+    torch passes over the cells x genes matrices (dh_zinb_nll_logits_*)."""
+    return _ZINBNLL.apply(x, mean_raw, disp_raw, pi_raw, scale_factor, ridge_lambda, True)
 
 
 class _AdjReconstructionMSE(torch.autograd.Function):

@@ -8,8 +8,8 @@
 // "D = F only if the builder chooses aggregate-first") — which makes the forward ONE gather kernel and the weight gradient ONE
 // streaming kernel:
 //
-//   forward : agg_i = sum_e a_e X[col_e, :]   (16 lanes x float4 per row, 4 rows per wavefront, 4 neighbours in flight per lane)
-//             y_i   = act(agg_i W + b)        (W in LDS; agg values broadcast inside the 16-lane group by ds_bpermute)
+//   forward : agg_i = sum_e a_e X[col_e, :]   (16 lanes x float4 per row, 4 rows per wavefront, 8 neighbours in flight per lane)
+//             y_i   = act(agg_i W + b)        (32-row tiles of agg in LDS times W in LDS on the fp32 matrix cores)
 //             agg is kept ([N, 64] fp32, column 63 = 1) for the backward.
 //   backward: [dW; db] = [agg | 1]^T (dY * [y > 0])   one pass over agg and dY on the fp32 matrix cores (v_mfma_f32_32x32x2_f32,
 //             K = rows: every wavefront owns a contiguous run of rows and a 64 x 64 accumulator), partial tiles reduced in fixed
@@ -29,7 +29,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int NW = 64;        // padded width of agg / W rows
 constexpr int LDW = NW + 4;   // LDS row stride of W (float4-aligned, rows 4 banks apart)
 
-// VEC = 4: 16 lanes per row (X rows 16-byte aligned); VEC = 2: 32 lanes per row (8-byte aligned rows, e.g. ld = 50)
+constexpr int LDT = NW + 4;   // row stride of a wavefront's aggregated tile (float4-aligned, rows 4 banks apart)
+constexpr int TROWS = 32;     // rows per wavefront tile = M of v_mfma_f32_32x32x2_f32
+
+// VEC = 4: 16 lanes per row (X rows 16-byte aligned); VEC = 2: 32 lanes per row (8-byte aligned rows, e.g. ld = 50).
+// Every wavefront owns tiles of 32 consecutive rows.  Phase 1 gathers: a lane group accumulates one row of A X in registers (up to
+// eight neighbour rows in flight per lane; the column indices of the next row are fetched while this one is gathered) and parks it
+// in the wavefront's LDS tile (and in AGG).  Phase 2 multiplies the 32 x 64 tile by W on the fp32 matrix cores: the round-4 kernel
+// did that product with one ds_bpermute + one LDS read of W per (row, feature) — 0.62 ms at 500k rows x 50 -> 50, LDS-issue bound,
+// four times what the gather itself costs.  K is walked as f = h * KS + s (h = lane half, s = k-step), so that a lane reads its A
+// operands as KS consecutive floats of its tile row.  Nothing synchronises the block after W is staged.
 template <int VEC>
 __global__ __launch_bounds__(256) void gcn_narrow_forward_kernel(int64_t n_rows, int F, int H, const int32_t* __restrict__ rowptr,
                                                                  const int32_t* __restrict__ col, const float* __restrict__ val,
@@ -37,105 +46,145 @@ __global__ __launch_bounds__(256) void gcn_narrow_forward_kernel(int64_t n_rows,
                                                                  const float* __restrict__ bias, int act, float* __restrict__ AGG,
                                                                  float* __restrict__ Y, int64_t ldy) {
   constexpr int G = NW / VEC;            // lanes per row
-  constexpr int RPB = 256 / G;           // rows per block
+  constexpr int RW = 64 / G;             // rows per wavefront per gather step
+  constexpr int NB = 8;                  // neighbour rows in flight per lane
   using V = typename std::conditional<VEC == 4, f32x4, f32x2>::type;
   __shared__ __attribute__((aligned(16))) float Ws[NW * LDW];
+  __shared__ __attribute__((aligned(16))) float Ts[4 * TROWS * LDT];
   for (int i = threadIdx.x; i < NW * LDW; i += 256) {
     const int f = i / LDW, j = i - f * LDW;
     Ws[i] = (f < F && j < H) ? W[(int64_t)f * ldw + j] : 0.f;
   }
   __syncthreads();
-  const int g = threadIdx.x % G;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane % G, sub = lane / G;
   const int c0 = g * VEC;
-  // grid-stride over groups of RPB rows: W is staged once per block (the first version staged 17 KB for every 16 rows, which
-  // cost as much as the gather itself); nothing below synchronises the block, whole lane groups skip rows together
-  for (int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G; row < n_rows; row += (int64_t)gridDim.x * RPB) {
-  V acc = V(0.f);
-  const int s = rowptr[row], t = rowptr[row + 1];
-  auto xrow = [&](int ck) -> V {
-    V v = V(0.f);
-    if (c0 < F) {  // lanes beyond the row's width hold zeros; a partial vector at the end is masked below
-      v = *reinterpret_cast<const V*>(X + (int64_t)ck * ldx + c0);
+  const int i32 = lane & 31, h = lane >> 5;
+  const int KS = (((F + 1) >> 1) + 3) & ~3;  // k-steps of the product (2 features each), a multiple of 4: <= 32 since F < 64
+  const bool two = H > 32;                   // the second 32-column half of Y exists
+  float* T = Ts + wave * TROWS * LDT;
+  const float b0 = (bias && i32 < H) ? bias[i32] : 0.f;
+  const float b1 = (bias && i32 + 32 < H) ? bias[i32 + 32] : 0.f;
+  // Branch-free on purpose: with the load inside `if (c0 < F)` / `if (k + u < cnt)` the compiler closed every exec-masked region
+  // with s_waitcnt vmcnt(0), so a row's neighbours were fetched ONE AT A TIME (0.37 ms at 500k rows even with every gather an L1
+  // hit).  Every lane loads from a valid address (column 0 for lanes beyond the row's width, the group's clamped neighbour for
+  // u >= cnt) and what must not count is zeroed by selects afterwards (a select does not propagate the NaN of a padding column).
+  const int cl = c0 < F ? c0 : 0;
+  auto xload = [&](int ck) -> V { return *reinterpret_cast<const V*>(X + (int64_t)ck * ldx + cl); };
+  auto xmask = [&](V v, bool ok) -> V {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i)
-        if (c0 + i >= F) v[i] = 0.f;
-    }
+    for (int i = 0; i < VEC; ++i) v[i] = (ok && c0 + i < F) ? v[i] : 0.f;
     return v;
   };
-  for (int base = s; base < t; base += G) {
-    const int e = base + g;
+  // Workgroup b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own L2.  Each XCD therefore walks ONE contiguous
+  // eighth of the rows, its resident blocks side by side: on graphs whose neighbours are near in row order (spatial kNN in grid
+  // order, a locality-ordered cell graph) the X rows the XCD's resident tiles gather are a sliding window that fits its L2, instead
+  // of eight interleaved copies of the whole of X.
+  const int64_t n_tiles = (n_rows + TROWS - 1) / TROWS;
+  int64_t tile_begin = (int64_t)blockIdx.x * 4 + wave, tile_end = n_tiles, tile_step = (int64_t)gridDim.x * 4;
+  if ((gridDim.x & 7) == 0) {
+    const int64_t per_xcd = (((n_tiles + 7) >> 3) + 3) & ~(int64_t)3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    tile_begin = xcd * per_xcd + slot * 4 + wave;
+    tile_end = min(n_tiles, (xcd + 1) * per_xcd);
+    tile_step = (int64_t)(gridDim.x >> 3) * 4;
+  }
+  for (int64_t tile = tile_begin; tile < tile_end; tile += tile_step) {
+    const int64_t r0 = tile * TROWS;
+    const int rp = rowptr[min(r0 + lane, n_rows)];  // lanes 0..32: the tile's row pointers (rows past the end are empty)
+    int s = __shfl(rp, sub), t = __shfl(rp, sub + 1);
     int c = 0;
     float w = 0.f;
-    if (e < t) {
-      c = col[e];
-      w = val ? val[e] : 1.f;
+    if (s + g < t) {
+      c = col[s + g];
+      w = val ? val[s + g] : 1.f;
     }
-    const int cnt = min(G, t - base);
-    int k = 0;
-    for (; k + 4 <= cnt; k += 4) {
-      int ck[4];
-      float wk[4];
-      V z[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        ck[u] = __shfl(c, k + u, G);
-        wk[u] = __shfl(w, k + u, G);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) z[u] = xrow(ck[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk[u], z[u][i], acc[i]);
-    }
-    const int rem = cnt - k;  // 0..3 neighbours left: their loads go out together as well (one memory round trip, not three)
-    if (rem > 0) {
-      int ck[3];
-      float wk[3];
-      V z[3];
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        ck[u] = __shfl(c, min(k + u, G - 1), G);  // lanes beyond cnt hold c = 0, w = 0
-        wk[u] = __shfl(w, min(k + u, G - 1), G);
-      }
-#pragma unroll
-      for (int u = 0; u < 3; ++u)
-        if (u < rem) z[u] = xrow(ck[u]);
-#pragma unroll
-      for (int u = 0; u < 3; ++u)
-        if (u < rem) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk[u], z[u][i], acc[i]);
+    for (int it = 0; it < TROWS / RW; ++it) {
+      const int ridx = it * RW + sub;
+      int s2 = 0, t2 = 0, c2 = 0;
+      float w2 = 0.f;
+      if (it + 1 < TROWS / RW) {  // uniform
+        s2 = __shfl(rp, ridx + RW);
+        t2 = __shfl(rp, ridx + RW + 1);
+        if (s2 + g < t2) {
+          c2 = col[s2 + g];
+          w2 = val ? val[s2 + g] : 1.f;
         }
+      }
+      V acc = V(0.f);
+      for (int base = s; base < t; base += G) {
+        if (base != s) {  // a row with more edges than the group has lanes
+          const int e = base + g;
+          c = 0;
+          w = 0.f;
+          if (e < t) {
+            c = col[e];
+            w = val ? val[e] : 1.f;
+          }
+        }
+        const int cnt = min(G, t - base);
+        for (int k = 0; k < cnt; k += NB) {
+          int ck[NB];
+          float wk[NB];
+          V z[NB];
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            ck[u] = __shfl(c, min(k + u, G - 1), G);
+            wk[u] = __shfl(w, min(k + u, G - 1), G);
+          }
+#pragma unroll
+          for (int u = 0; u < NB; ++u) z[u] = xload(ck[u]);
+#pragma unroll
+          for (int u = 0; u < NB; ++u) {
+            const V zu = xmask(z[u], k + u < cnt);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) acc[i] = fmaf(wk[u], zu[i], acc[i]);
+          }
+        }
+      }
+      *reinterpret_cast<V*>(T + ridx * LDT + c0) = acc;
+      const int64_t row = r0 + ridx;
+      if (AGG && row < n_rows) {  // [n_rows, 64]: the aggregated row, zero padded, with a 1 in column 63 (the bias row of the backward)
+        V a = acc;
+        if (c0 + VEC == NW) a[VEC - 1] = 1.f;
+        *reinterpret_cast<V*>(AGG + row * NW + c0) = a;
+      }
+      s = s2, t = t2, c = c2, w = w2;
     }
-  }
-  if (AGG) {  // [n_rows, 64]: the aggregated row, zero padded, with a 1 in column 63 (the bias row of the backward product)
-    V a = acc;
-    if (F < NW && c0 + VEC == NW) a[VEC - 1] = 1.f;
-    *reinterpret_cast<V*>(AGG + row * NW + c0) = a;
-  }
-  // y[c0 .. c0 + VEC) = sum_f agg_f W[f][c0 ..] + b: agg_f lives in lane f / VEC of the group, component f % VEC
-  V y = V(0.f);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // Y tile (32 x 64) = T (32 x 2 KS) W (2 KS x 64).  A operand: lane (i32, h) holds T[i32][h KS + s]; B operand: W[h KS + s][i32 (+ 32)]
+    f32x16 y0, y1;
 #pragma unroll
-  for (int fq = 0; fq < NW / VEC; ++fq) {
-    if (fq * VEC >= F) break;  // uniform
+    for (int r = 0; r < 16; ++r) y0[r] = 0.f, y1[r] = 0.f;
+    const float* ta = T + i32 * LDT + h * KS;
+    const float* wb = Ws + h * KS * LDW + i32;
+    for (int s4 = 0; s4 < KS; s4 += 4) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ta + s4);
 #pragma unroll
-    for (int i = 0; i < VEC; ++i) {
-      const float a = __shfl(acc[i], fq, G);
-      const V wv = *reinterpret_cast<const V*>(Ws + (fq * VEC + i) * LDW + c0);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) y[j] = fmaf(a, wv[j], y[j]);
+      for (int e = 0; e < 4; ++e) {
+        y0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], wb[(s4 + e) * LDW], y0, 0, 0, 0);
+        if (two) y1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], wb[(s4 + e) * LDW + 32], y1, 0, 0, 0);
+      }
     }
-  }
+    // C layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
-  for (int j = 0; j < VEC; ++j) {
-    const int cj = c0 + j;
-    if (cj < H) {
-      float v = y[j] + (bias ? bias[cj] : 0.f);
-      if (act == DH_ACT_RELU) v = fmaxf(v, 0.f);
-      Y[row * ldy + cj] = v;
+    for (int r = 0; r < 16; ++r) {
+      const int64_t row = r0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (row < n_rows) {
+        if (i32 < H) {
+          float v = y0[r] + b0;
+          if (act == DH_ACT_RELU) v = fmaxf(v, 0.f);
+          Y[row * ldy + i32] = v;
+        }
+        if (i32 + 32 < H) {
+          float v = y1[r] + b1;
+          if (act == DH_ACT_RELU) v = fmaxf(v, 0.f);
+          Y[row * ldy + i32 + 32] = v;
+        }
+      }
     }
-  }
+    __builtin_amdgcn_wave_barrier();  // the next tile's rows overwrite T
   }
 }
 
@@ -248,6 +297,9 @@ __global__ __launch_bounds__(256) void gcn_narrow_reduce2_kernel(int n_runs, int
   if (is_b) db[j] = acc;
 }
 
+// forward: a block is four wavefront tiles of 32 rows; 52 KB of LDS per block = three blocks per CU, the rest walk by grid stride
+unsigned forward_blocks(int64_t n_rows) { return (unsigned)std::min<int64_t>((dh::ceil_div(n_rows, 4 * TROWS) + 7) & ~(int64_t)7, 3 * 256); }
+
 int plan_blocks(int64_t n_rows) {  // one block per 2048 rows, at most 1024 blocks (16 MB of partial tiles)
   int64_t b = dh::ceil_div(n_rows, 2048);
   return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
@@ -275,10 +327,10 @@ extern "C" int dh_gcn_narrow_forward_f32(int64_t n_rows, int64_t n_cols, int64_t
   const bool v4 = dh::aligned16(X) && ldx % 4 == 0 && ldx >= ((in_features + 3) & ~(int64_t)3);
   const bool v2 = ((uintptr_t)X % 8 == 0) && ldx % 2 == 0 && ldx >= ((in_features + 1) & ~(int64_t)1);
   if (v4)
-    hipLaunchKernelGGL(gcn_narrow_forward_kernel<4>, dim3((unsigned)std::min<int64_t>(dh::ceil_div(n_rows, 16), 4096)), dim3(256), 0, st, n_rows, (int)in_features,
+    hipLaunchKernelGGL(gcn_narrow_forward_kernel<4>, dim3(forward_blocks(n_rows)), dim3(256), 0, st, n_rows, (int)in_features,
                        (int)out_features, rowptr, col, val, X, ldx, W, ldw, bias, act, agg, Y, ldy);
   else if (v2)
-    hipLaunchKernelGGL(gcn_narrow_forward_kernel<2>, dim3((unsigned)std::min<int64_t>(dh::ceil_div(n_rows, 8), 4096)), dim3(256), 0, st, n_rows, (int)in_features,
+    hipLaunchKernelGGL(gcn_narrow_forward_kernel<2>, dim3(forward_blocks(n_rows)), dim3(256), 0, st, n_rows, (int)in_features,
                        (int)out_features, rowptr, col, val, X, ldx, W, ldw, bias, act, agg, Y, ldy);
   else
     return dh::fail(DH_ERR_INVALID, "dh_gcn_narrow_forward_f32: X rows must be 8-byte aligned with an even leading dimension >= round_up(in, 2)");

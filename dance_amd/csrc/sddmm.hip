@@ -44,33 +44,44 @@ __global__ __launch_bounds__(256) void sddmm_csr_kernel(int64_t n_rows, int64_t 
   if (row >= n_rows) return;
   f32x4 u[NACC];
   bool live[NACC];
+  int cl[NACC];  // this lane's column of slice a, or column 0 where the slice lies beyond the width (a valid address whose value is dropped)
 #pragma unroll
   for (int a = 0; a < NACC; ++a) {
     const int64_t c = 4 * g + 4 * G * a;
     live[a] = c < width;
-    u[a] = live[a] ? load4<T>(U + row * ldu + c) : f32x4(0.f);
+    cl[a] = live[a] ? (int)c : 0;
+    const f32x4 x = load4<T>(U + row * ldu + cl[a]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[a][i] = live[a] ? x[i] : 0.f;
   }
   const int s = rowptr[row], t = rowptr[row + 1];
+  // No load below sits behind a divergent guard: guarded, every load is its own exec-masked block that the compiler closes with
+  // s_waitcnt vmcnt(0), and the "4 edges in flight" become 4 (x NACC) dependent round trips (ISA, round 5; the same finding as
+  // gcn_narrow.hip).  Edges past the row's end repeat its last edge and are not stored.
   for (int e0 = s; e0 < t; e0 += 4) {
-    float part[4];
+    int ck[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      part[k] = 0.f;
-      if (e0 + k < t) {
-        const T* v = V + (int64_t)col[e0 + k] * ldv + 4 * g;
+    for (int k = 0; k < 4; ++k) ck[k] = col[min(e0 + k, t - 1)];
+    float sc[4] = {1.f, 1.f, 1.f, 1.f};
+    if (scale) {  // uniform
 #pragma unroll
-        for (int a = 0; a < NACC; ++a) {
-          if (!live[a]) continue;
-          const f32x4 x = load4<T>(v + 4 * G * a);
+      for (int k = 0; k < 4; ++k) sc[k] = scale[min(e0 + k, t - 1)];
+    }
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) part[k] = fmaf(u[a][i], x[i], part[k]);
-        }
-      }
+    for (int a = 0; a < NACC; ++a) {
+      f32x4 x[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) x[k] = load4<T>(V + (int64_t)ck[k] * ldv + cl[a]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) part[k] = fmaf(u[a][i], live[a] ? x[k][i] : 0.f, part[k]);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const float d = group_sum<G>(part[k]);
-      if (g == 0 && e0 + k < t) out[e0 + k] = scale ? scale[e0 + k] * d : d;
+      if (g == 0 && e0 + k < t) out[e0 + k] = sc[k] * d;
     }
   }
 }

@@ -96,6 +96,33 @@ __device__ __forceinline__ float log1p_f(float x) {
   return d == 0.f ? x : __logf(t) * __fdividef(x, d);
 }
 
+// The decoder heads' activations (scdsc.py:601-618, sctag.py:531-548: MeanAct = clamp(exp(a), 1e-5, 1e6), DispAct = clamp(softplus(a),
+// 1e-4, 1e4), pi = sigmoid(a)) applied to the raw head outputs inside the loss kernels (the *_logits entry points): as torch ops they
+// are 5 forward and ~12 backward elementwise passes over N x G matrices (exp, softplus, sigmoid, two clamps; their backward: two
+// compare + where + logical_and per clamp, mul, softplus_backward, sigmoid_backward) — 4.6 of the 27 ms of a scDSC epoch at 100k cells,
+// next to 1.9 for the two loss kernels themselves.  j* = d(activated) / d(raw), torch's own backward formulas (clamp: inclusive bounds;
+// softplus: threshold 20).  exp on the transcendental unit (v_exp_f32): relative error |a| 2^-24 <= 8e-7 inside the clamp range.
+struct HeadActs {
+  float m, d, p, jm, jd, jp;
+};
+template <bool GRAD>
+__device__ __forceinline__ HeadActs head_acts(float am, float ad, float ap) {
+  HeadActs o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float e = __expf(am);
+  o.m = fminf(fmaxf(e, 1e-5f), 1e6f);
+  const float z = __expf(ad);
+  const float sp = ad > 20.f ? ad : log1p_f(z);
+  o.d = fminf(fmaxf(sp, 1e-4f), 1e4f);
+  o.p = __frcp_rn(1.f + __expf(-ap));
+  if (GRAD) {
+    o.jm = (e >= 1e-5f && e <= 1e6f) ? e : 0.f;
+    const float sg = ad > 20.f ? 1.f : z * __frcp_rn(z + 1.f);
+    o.jd = (sp >= 1e-4f && sp <= 1e4f) ? sg : 0.f;
+    o.jp = o.p * (1.f - o.p);
+  }
+  return o;
+}
+
 struct Terms {
   double loss, d_m, d_d, d_p;  // d loss / d (scaled mean, disp, pi)
 };
@@ -216,6 +243,7 @@ __device__ __forceinline__ Terms count_terms(double x, double m, double d, doubl
 // every step (that divergence, not the arithmetic of the zeros, was why round 3's 151 ms did not depend on the density).
 constexpr int ZU = 4;          // 64-gene steps whose loads are issued together: a wave keeps 4 x 4 loads per lane in flight
 
+template <bool LOGITS>
 __global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
                                                            const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
                                                            const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
@@ -244,6 +272,13 @@ __global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g,
       mv[u] = m_row[cc];
       dv[u] = d_row[cc];
       pv[u] = p_row[cc];
+    }
+    if (LOGITS) {
+#pragma unroll
+      for (int u = 0; u < ZU; ++u) {
+        const HeadActs a = head_acts<false>(mv[u], dv[u], pv[u]);
+        mv[u] = a.m, dv[u] = a.d, pv[u] = a.p;
+      }
     }
     int cnt = 0;
     float acc_z = 0.f;  // the window's zeros in fp32 lanes, folded into the float64 sum per window
@@ -279,6 +314,7 @@ __global__ __launch_bounds__(256) void zinb_forward_kernel(int64_t n, int64_t g,
 // stage so that the three outputs are written as whole 256-byte runs.  (With the row-long list of the forward kernel the x = 0 lanes
 // wrote their lines with holes and the counts filled them in much later — after the partly written lines had left L2: the 24 GB of
 // gradient writes turned into read-modify-writes and the kernel took 23 - 26 ms whatever the arithmetic cost.)
+template <bool LOGITS>
 __global__ __launch_bounds__(256) void zinb_backward_kernel(int64_t n, int64_t g, const float* __restrict__ X, int64_t ldx,
                                                             const float* __restrict__ M, int64_t ldm, const float* __restrict__ D, int64_t ldd,
                                                             const float* __restrict__ P, int64_t ldp, const double* __restrict__ sf, double ridge,
@@ -316,10 +352,15 @@ __global__ __launch_bounds__(256) void zinb_backward_kernel(int64_t n, int64_t g
       const bool in = c0 + li < g;
       const bool nz = in && xv[u] > 1e-8f;
       if (in && !nz) {
+        float jm = 1.f, jd = 1.f, jp = 1.f;
+        if (LOGITS) {
+          const HeadActs a = head_acts<true>(mv[u], dv[u], pv[u]);
+          mv[u] = a.m, dv[u] = a.d, pv[u] = a.p, jm = a.jm, jd = a.jd, jp = a.jp;
+        }
         const ZTerms t = zero_terms<true>((float)((double)mv[u] * s), dv[u], pv[u], ridge_f);
-        st[0][li] = upsf * t.d_m;
-        st[1][li] = upf * t.d_d;
-        st[2][li] = upf * t.d_p;
+        st[0][li] = upsf * t.d_m * jm;
+        st[1][li] = upf * t.d_d * jd;
+        st[2][li] = upf * t.d_p * jp;
       }
       const unsigned long long mask = __ballot(nz);
       if (nz) wl[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)li;
@@ -328,10 +369,16 @@ __global__ __launch_bounds__(256) void zinb_backward_kernel(int64_t n, int64_t g
     for (int i = lane; i < cnt; i += 64) {  // the window's counts, every lane busy (a wave reads its own LDS writes: no barrier)
       const int li = wl[i];
       const int64_t c = c0 + li;
-      const Terms t = count_terms<true>((double)x_row[c], (double)m_row[c] * s, (double)d_row[c], (double)p_row[c], ridge);
-      st[0][li] = (float)(up * t.d_m * s);
-      st[1][li] = (float)(up * t.d_d);
-      st[2][li] = (float)(up * t.d_p);
+      float mc = m_row[c], dc = d_row[c], pc = p_row[c];
+      double jm = 1.0, jd = 1.0, jp = 1.0;
+      if (LOGITS) {
+        const HeadActs a = head_acts<true>(mc, dc, pc);
+        mc = a.m, dc = a.d, pc = a.p, jm = (double)a.jm, jd = (double)a.jd, jp = (double)a.jp;
+      }
+      const Terms t = count_terms<true>((double)x_row[c], (double)mc * s, (double)dc, (double)pc, ridge);
+      st[0][li] = (float)(up * t.d_m * s * jm);
+      st[1][li] = (float)(up * t.d_d * jd);
+      st[2][li] = (float)(up * t.d_p * jp);
     }
 #pragma unroll
     for (int u = 0; u < ZU; ++u) {
@@ -355,26 +402,57 @@ int check(const char* me, int64_t n, int64_t g, const void* X, int64_t ldx, cons
   return DH_OK;
 }
 
+template <bool LOGITS>
+int forward_impl(const char* me, int64_t n, int64_t g, const float* X, int64_t ldx, const float* mean, int64_t ldm, const float* disp, int64_t ldd,
+                 const float* pi, int64_t ldp, const double* scale_factor, double ridge_lambda, double* rowloss, dh_stream_t stream) {
+  const int rc = check(me, n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
+  if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
+  if (!rowloss) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  hipLaunchKernelGGL(zinb_forward_kernel<LOGITS>, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm,
+                     disp, ldd, pi, ldp, scale_factor, ridge_lambda, rowloss);
+  return dh::check_launch(me);
+}
+
+template <bool LOGITS>
+int backward_impl(const char* me, int64_t n, int64_t g, const float* X, int64_t ldx, const float* mean, int64_t ldm, const float* disp, int64_t ldd,
+                  const float* pi, int64_t ldp, const double* scale_factor, double ridge_lambda, const double* upstream, float* d_mean,
+                  float* d_disp, float* d_pi, int64_t ldo, dh_stream_t stream) {
+  const int rc = check(me, n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
+  if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
+  if (!upstream || !d_mean || !d_disp || !d_pi || ldo < g) return dh::fail(DH_ERR_INVALID, "%s: bad output / upstream", me);
+  hipLaunchKernelGGL(zinb_backward_kernel<LOGITS>, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm,
+                     disp, ldd, pi, ldp, scale_factor, ridge_lambda, upstream, d_mean, d_disp, d_pi, ldo);
+  return dh::check_launch(me);
+}
+
 }  // namespace
 
 extern "C" int dh_zinb_nll_forward_f32(int64_t n, int64_t g, const float* X, int64_t ldx, const float* mean, int64_t ldm, const float* disp,
                                        int64_t ldd, const float* pi, int64_t ldp, const double* scale_factor, double ridge_lambda,
                                        double* rowloss, dh_stream_t stream) {
-  const int rc = check("dh_zinb_nll_forward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
-  if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
-  if (!rowloss) return dh::fail(DH_ERR_INVALID, "dh_zinb_nll_forward_f32: null output");
-  hipLaunchKernelGGL(zinb_forward_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp, ldd,
-                     pi, ldp, scale_factor, ridge_lambda, rowloss);
-  return dh::check_launch("dh_zinb_nll_forward_f32");
+  return forward_impl<false>("dh_zinb_nll_forward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp, scale_factor, ridge_lambda, rowloss, stream);
 }
 
 extern "C" int dh_zinb_nll_backward_f32(int64_t n, int64_t g, const float* X, int64_t ldx, const float* mean, int64_t ldm, const float* disp,
                                         int64_t ldd, const float* pi, int64_t ldp, const double* scale_factor, double ridge_lambda,
                                         const double* upstream, float* d_mean, float* d_disp, float* d_pi, int64_t ldo, dh_stream_t stream) {
-  const int rc = check("dh_zinb_nll_backward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp);
-  if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
-  if (!upstream || !d_mean || !d_disp || !d_pi || ldo < g) return dh::fail(DH_ERR_INVALID, "dh_zinb_nll_backward_f32: bad output / upstream");
-  hipLaunchKernelGGL(zinb_backward_kernel, dim3((unsigned)dh::ceil_div(n, 4)), dim3(256), 0, dh::as_stream(stream), n, g, X, ldx, mean, ldm, disp,
-                     ldd, pi, ldp, scale_factor, ridge_lambda, upstream, d_mean, d_disp, d_pi, ldo);
-  return dh::check_launch("dh_zinb_nll_backward_f32");
+  return backward_impl<false>("dh_zinb_nll_backward_f32", n, g, X, ldx, mean, ldm, disp, ldd, pi, ldp, scale_factor, ridge_lambda, upstream, d_mean,
+                              d_disp, d_pi, ldo, stream);
+}
+
+// The same loss as a function of the three heads' RAW outputs (the Linear layers' results, before MeanAct / DispAct / Sigmoid):
+// the activations and their Jacobians are applied inside the kernels (head_acts above); d_* are the gradients w.r.t. the raw outputs.
+extern "C" int dh_zinb_nll_logits_forward_f32(int64_t n, int64_t g, const float* X, int64_t ldx, const float* mean_raw, int64_t ldm,
+                                              const float* disp_raw, int64_t ldd, const float* pi_raw, int64_t ldp, const double* scale_factor,
+                                              double ridge_lambda, double* rowloss, dh_stream_t stream) {
+  return forward_impl<true>("dh_zinb_nll_logits_forward_f32", n, g, X, ldx, mean_raw, ldm, disp_raw, ldd, pi_raw, ldp, scale_factor, ridge_lambda,
+                            rowloss, stream);
+}
+
+extern "C" int dh_zinb_nll_logits_backward_f32(int64_t n, int64_t g, const float* X, int64_t ldx, const float* mean_raw, int64_t ldm,
+                                               const float* disp_raw, int64_t ldd, const float* pi_raw, int64_t ldp, const double* scale_factor,
+                                               double ridge_lambda, const double* upstream, float* d_mean_raw, float* d_disp_raw, float* d_pi_raw,
+                                               int64_t ldo, dh_stream_t stream) {
+  return backward_impl<true>("dh_zinb_nll_logits_backward_f32", n, g, X, ldx, mean_raw, ldm, disp_raw, ldd, pi_raw, ldp, scale_factor, ridge_lambda,
+                             upstream, d_mean_raw, d_disp_raw, d_pi_raw, ldo, stream);
 }

@@ -408,23 +408,27 @@ def gcn_narrow_backward(agg, dY, in_features: int, *, y_act: Optional[torch.Tens
     return dw, db
 
 
-def zinb_nll_forward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float = 0.0) -> torch.Tensor:
-    """rowloss [n] float64 of the zero-inflated negative-binomial NLL (dh_zinb_nll_forward_f32); the loss is its sum / (n g)."""
+def zinb_nll_forward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float = 0.0, *, logits: bool = False) -> torch.Tensor:
+    """rowloss [n] float64 of the zero-inflated negative-binomial NLL (dh_zinb_nll_forward_f32); the loss is its sum / (n g).
+    ``logits=True``: mean / disp / pi are the decoder heads' RAW outputs and MeanAct / DispAct / sigmoid are applied inside the kernel
+    (dh_zinb_nll_logits_forward_f32)."""
     lib = _lib_ready()
     n, g = X.shape
     rowloss = torch.empty(n, dtype=torch.float64, device=X.device)
-    _call("zinb_nll_forward_f32", lib.dh_zinb_nll_forward_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean, torch.float32, "mean", 2),
+    _call("zinb_nll_forward_f32", lib.dh_zinb_nll_logits_forward_f32 if logits else lib.dh_zinb_nll_forward_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean, torch.float32, "mean", 2),
           _ld(mean), _dev(disp, torch.float32, "disp", 2), _ld(disp), _dev(pi, torch.float32, "pi", 2), _ld(pi),
           _dev(scale_factor, torch.float64, "scale_factor", 1), float(ridge_lambda), rowloss.data_ptr(), _stream())
     return rowloss
 
 
-def zinb_nll_backward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float, upstream: torch.Tensor):
-    """(d mean, d disp, d pi) fp32 of ``zinb_nll_forward`` times the float64 device scalar ``upstream`` (dh_zinb_nll_backward_f32)."""
+def zinb_nll_backward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], ridge_lambda: float, upstream: torch.Tensor, *,
+                      logits: bool = False):
+    """(d mean, d disp, d pi) fp32 of ``zinb_nll_forward`` times the float64 device scalar ``upstream`` (dh_zinb_nll_backward_f32;
+    ``logits=True``: w.r.t. the heads' raw outputs, dh_zinb_nll_logits_backward_f32)."""
     lib = _lib_ready()
     n, g = X.shape
     dm, dd, dp = (torch.empty((n, g), dtype=torch.float32, device=X.device) for _ in range(3))
-    _call("zinb_nll_backward_f32", lib.dh_zinb_nll_backward_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean, torch.float32, "mean", 2),
+    _call("zinb_nll_backward_f32", lib.dh_zinb_nll_logits_backward_f32 if logits else lib.dh_zinb_nll_backward_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean, torch.float32, "mean", 2),
           _ld(mean), _dev(disp, torch.float32, "disp", 2), _ld(disp), _dev(pi, torch.float32, "pi", 2), _ld(pi),
           _dev(scale_factor, torch.float64, "scale_factor", 1), float(ridge_lambda), _dev(upstream, torch.float64, "upstream"), dm.data_ptr(),
           dd.data_ptr(), dp.data_ptr(), g, _stream())

@@ -7,7 +7,7 @@ init and ``forward(features, adj, active=True)`` signature, so reference checkpo
 import torch
 from torch import nn
 
-from ....autograd import gcn_layer, student_t_assign, zinb_nll
+from ....autograd import gcn_layer, student_t_assign, zinb_nll, zinb_nll_from_logits
 from ....graph import as_graph
 from ....sharding import ShardedGCNGraph, allreduce_sum_gradients, broadcast_parameters, sharded_batch_norm, sharded_gcn_layer
 
@@ -53,6 +53,11 @@ class ZINBLoss(nn.Module):
 
     def forward(self, x, mean, disp, pi, scale_factor, ridge_lambda=0.0):
         return zinb_nll(x, mean, disp, pi, scale_factor, ridge_lambda)
+
+    def from_logits(self, x, mean_raw, disp_raw, pi_raw, scale_factor, ridge_lambda=0.0):
+        """The same loss on the heads' Linear outputs: MeanAct / DispAct / Sigmoid (and their backward) run inside the loss kernels
+        (autograd.zinb_nll_from_logits) — what ``ScDSCModel._forward(x, adj, raw_heads=True)`` hands to the training loop."""
+        return zinb_nll_from_logits(x, mean_raw, disp_raw, pi_raw, scale_factor, ridge_lambda)
 
 
 class AE(nn.Module):
@@ -164,6 +169,12 @@ class ScDSCModel(nn.Module):
         self.to(self.device)
 
     def forward(self, x, adj):
+        return self._forward(x, adj, False)
+
+    def _forward(self, x, adj, raw_heads: bool):
+        """scdsc.py:440-472.  ``raw_heads=True`` (the joint loop's training pass): the three ZINB heads return their Linear outputs and
+        the last element is ``ZINBLoss.from_logits`` — the activations of :409-411 then run inside the loss kernels instead of as 17
+        elementwise passes over cells x genes matrices; the value and the gradients of the loss are the same function."""
         x_bar, tra1, tra2, tra3, z3, z2, z1, dec_h3 = self.ae(x)
         sigma = self.sigma
         if not isinstance(adj, ShardedGCNGraph):
@@ -176,10 +187,13 @@ class ScDSCModel(nn.Module):
         h = self.gnn_6((1 - sigma) * h + sigma * z2, adj)
         h = self.gnn_7((1 - sigma) * h + sigma * z3, adj, active=False)
         predict = F.softmax(h, dim=1)
-        _mean, _disp, _pi = self._dec_mean(dec_h3), self._dec_disp(dec_h3), self._dec_pi(dec_h3)
+        if raw_heads:
+            _mean, _disp, _pi = self._dec_mean[0](dec_h3), self._dec_disp[0](dec_h3), self._dec_pi[0](dec_h3)
+        else:
+            _mean, _disp, _pi = self._dec_mean(dec_h3), self._dec_disp(dec_h3), self._dec_pi(dec_h3)
         # :466-468, on the fused kernel pair (the reference's z3.unsqueeze(1) - cluster_layer is an [N, C, 32] tensor: 1.3 GB at 1M cells)
         q = student_t_assign(z3, self.cluster_layer, a=self.v, eps=0.0, pw=(self.v + 1.0) / 2.0, scale=1.0)
-        return x_bar, q, predict, z3, _mean, _disp, _pi, self.zinb_loss
+        return x_bar, q, predict, z3, _mean, _disp, _pi, (self.zinb_loss.from_logits if raw_heads else self.zinb_loss)
 
 
 # ---- ScDSC: the method wrapper (scdsc.py:33-336) ------------------------------------------------------------------
@@ -304,6 +318,7 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
         others = [p for p in model.parameters() if p.requires_grad and id(p) not in gcn_weights]
         aris, keys, Q = [], [], {}
         p = None
+        recon = None
         try:
             with torch.no_grad():  # :253-254 — its result is unused, but the module is in train mode here: this full-batch pass
                 model.ae(data)     # moves the BatchNorm running statistics that the eval-mode passes below read
@@ -320,15 +335,19 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
                         keys.append(key := f"epoch{epoch}")
                         Q[key] = self.q
                 model.train()
-                x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model(data, adj)
+                x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model._forward(data, adj, True)
                 if sharded:  # this rank's share of the global means: local sum / global count
                     loss = (bcl * F.binary_cross_entropy(q, p, reduction="sum") / (n_all * q.shape[1])
                             + cl * F.kl_div(pred.log(), p, reduction="sum") / n_all
                             + rl * F.mse_loss(x_bar, data, reduction="sum") / (n_all * n_genes)
                             + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf) * (n_loc / n_all))
                 else:
+                    # the autoencoder is frozen and its outputs are kept (AE.cache_frozen): x_bar is then the same tensor every epoch and
+                    # the reconstruction term a constant of the fit — a 2 N G-float pass per epoch when recomputed
+                    if x_bar.requires_grad or recon is None or recon[0] is not x_bar:
+                        recon = (x_bar, F.mse_loss(x_bar, data))
                     loss = (bcl * F.binary_cross_entropy(q, p) + cl * F.kl_div(pred.log(), p, reduction="batchmean")
-                            + rl * F.mse_loss(x_bar, data) + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf))
+                            + rl * recon[1] + zl * zinb_loss(x_raw, meanbatch, dispbatch, pibatch, sf))
                 optimizer.zero_grad()
                 loss.backward()
                 if sharded:

@@ -652,6 +652,18 @@ DH_API int dh_zinb_nll_backward_f32(int64_t n, int64_t n_genes, const float* X, 
                              const float* disp, int64_t ldd, const float* pi, int64_t ldp, const double* scale_factor,
                              double ridge_lambda, const double* upstream, float* d_mean, float* d_disp, float* d_pi, int64_t ldo,
                              dh_stream_t stream);
+/* The same loss as a function of the decoder heads' RAW outputs: the heads are `Sequential(Linear, MeanAct())`, `Sequential(Linear,
+ * DispAct())`, `Sequential(Linear, Sigmoid())` (scdsc.py:409-411 with MeanAct / DispAct at :601-618; sctag.py:531-548), i.e.
+ * mean = clamp(exp(a), 1e-5, 1e6), disp = clamp(softplus(a), 1e-4, 1e4), pi = sigmoid(a) — 5 forward and ~12 backward elementwise
+ * passes over N x G matrices when left to torch.  Here the activations and their Jacobians (torch's backward formulas: inclusive clamp
+ * bounds, softplus threshold 20) are evaluated inside the two loss kernels; d_*_raw are the gradients w.r.t. the raw outputs.        */
+DH_API int dh_zinb_nll_logits_forward_f32(int64_t n, int64_t n_genes, const float* X, int64_t ldx, const float* mean_raw, int64_t ldm,
+                                   const float* disp_raw, int64_t ldd, const float* pi_raw, int64_t ldp, const double* scale_factor,
+                                   double ridge_lambda, double* rowloss, dh_stream_t stream);
+DH_API int dh_zinb_nll_logits_backward_f32(int64_t n, int64_t n_genes, const float* X, int64_t ldx, const float* mean_raw, int64_t ldm,
+                                    const float* disp_raw, int64_t ldd, const float* pi_raw, int64_t ldp, const double* scale_factor,
+                                    double ridge_lambda, const double* upstream, float* d_mean_raw, float* d_disp_raw, float* d_pi_raw,
+                                    int64_t ldo, dh_stream_t stream);
 
 /* ---- multi-GPU: RCCL over xGMI, one process per GPU ------------------------------------------------
  * The reference has no multi-GPU path for these models; the sharded layer replaces the single-process torch.spmm / autograd

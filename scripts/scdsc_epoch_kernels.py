@@ -1,0 +1,56 @@
+"""Which kernels — the library's AND torch's — make up one joint-training epoch of ScDSC.fit (BASELINE config 2's model, 100k cells)?
+Run twice under `rocprofv3 --kernel-trace --stats` with different epoch counts and difference the per-kernel totals:
+
+    python scripts/scdsc_epoch_kernels.py run 1          # one fit of 1 epoch (after a warm-up fit)
+    python scripts/scdsc_epoch_kernels.py run 7
+    python scripts/scdsc_epoch_kernels.py diff a_kernel_stats.csv b_kernel_stats.csv 6
+"""
+import csv
+import os
+import sys
+import tempfile
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(epochs, n=100_000):
+    import torch
+    from bench_configs import _scdsc_inputs
+
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSC
+    dev = torch.device("cuda", 0)
+    x, counts, n_counts, graph, y = _scdsc_inputs(n, dev)
+    graph.transpose()
+    xh, ch, nh = x.cpu().numpy(), counts.cpu().numpy(), n_counts.cpu().numpy().astype("float64")
+    del x, counts
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as tmp:
+        m = ScDSC(pretrain_path=os.path.join(tmp, "ae.pt"), sigma=0.5, n_clusters=10, n_input=xh.shape[1], device="cuda")
+        m.fit((graph, xh, ch, nh), y, lr=1e-3, epochs=1, pt_epochs=0)
+        m.fit((graph, xh, ch, nh), y, lr=1e-3, epochs=epochs, pt_epochs=0)
+        torch.cuda.synchronize()
+
+
+def diff(a, b, units):
+    def load(p):
+        return {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(p))}
+    ka, kb = load(a), load(b)
+    rows = []
+    for name, (cb, tb) in kb.items():
+        ca, ta = ka.get(name, (0, 0.0))
+        if cb != ca:
+            rows.append(((tb - ta) / units / 1e6, (cb - ca) / units, name))
+    rows.sort(reverse=True)
+    total = sum(r[0] for r in rows)
+    print(f"per epoch: {total:.3f} ms of kernel time in {sum(r[1] for r in rows):.0f} launches")
+    print("| ms / epoch | launches / epoch | kernel |\n|---|---|---|")
+    for ms, calls, name in rows[:60]:
+        print(f"| {ms:.4f} | {calls:.1f} | `{name[:150]}` |")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(int(sys.argv[2]))
+    else:
+        diff(sys.argv[2], sys.argv[3], float(sys.argv[4]))

@@ -273,14 +273,26 @@ def _zinb_elements(x, mean, disp, pi, sf, ridge):
     return out + ridge * pi * pi if ridge > 0 else out
 
 
-def zinb_nll_forward(X, mean, disp, pi, scale_factor, ridge_lambda=0.0):
+def _head_acts(mean, disp, pi):
+    """MeanAct / DispAct / Sigmoid of the decoder heads (scdsc.py:601-618), in fp32 as torch evaluates them."""
+    return (torch.clamp(torch.exp(mean), min=1e-5, max=1e6), torch.clamp(torch.nn.functional.softplus(disp), min=1e-4, max=1e4), torch.sigmoid(pi))
+
+
+def zinb_nll_forward(X, mean, disp, pi, scale_factor, ridge_lambda=0.0, *, logits=False):
+    if logits:
+        mean, disp, pi = _head_acts(mean, disp, pi)
     return _zinb_elements(X, mean, disp, pi, scale_factor, ridge_lambda).sum(1)
 
 
-def zinb_nll_backward(X, mean, disp, pi, scale_factor, ridge_lambda, upstream):
-    m, d, p = (t.detach().double().requires_grad_(True) for t in (mean, disp, pi))
-    with torch.enable_grad():
-        total = _zinb_elements(X, m, d, p, scale_factor, ridge_lambda).sum()
+def zinb_nll_backward(X, mean, disp, pi, scale_factor, ridge_lambda, upstream, *, logits=False):
+    if logits:
+        m, d, p = (t.detach().float().requires_grad_(True) for t in (mean, disp, pi))
+        with torch.enable_grad():
+            total = _zinb_elements(X, *_head_acts(m, d, p), scale_factor, ridge_lambda).sum()
+    else:
+        m, d, p = (t.detach().double().requires_grad_(True) for t in (mean, disp, pi))
+        with torch.enable_grad():
+            total = _zinb_elements(X, m, d, p, scale_factor, ridge_lambda).sum()
     gm, gd, gp = torch.autograd.grad(total, (m, d, p))
     up = upstream.reshape(())
     return (gm * up).float(), (gd * up).float(), (gp * up).float()

@@ -79,6 +79,42 @@ def test_zinb_nll_kernels_vs_float64_formula(cuda_device):
         assert torch.equal(again, kernels.zinb_nll_forward(x, mean.detach(), disp.detach(), pi.detach(), sf, ridge))
 
 
+def test_zinb_nll_from_logits_equals_torch_activations_then_loss(cuda_device):
+    """dh_zinb_nll_logits_*: the loss on the heads' RAW outputs == MeanAct / DispAct / sigmoid as torch ops (fp32, scdsc.py:601-618)
+    followed by the float64 formula, value and gradients w.r.t. the raw outputs — including logits beyond every clamp bound (zero
+    gradient there, as torch.clamp's backward gives) and beyond softplus's threshold of 20."""
+    from dance_amd import autograd, kernels
+    torch.manual_seed(2)
+    for n, g, ridge, with_sf in ((64, 50, 0.0, True), (257, 2000, 0.5, True), (1000, 333, 0.0, False)):
+        x = torch.poisson(torch.rand(n, g, device=cuda_device) * 2.5) * (torch.rand(n, g, device=cuda_device) < 0.3)
+        x[:, :5] *= 40
+        am = (torch.randn(n, g, device=cuda_device) * 1.5).requires_grad_(True)
+        ad = (torch.randn(n, g, device=cuda_device) * 2.0).requires_grad_(True)
+        ap = (torch.randn(n, g, device=cuda_device) * 2.0).requires_grad_(True)
+        am.data[:, 9], am.data[:, 10] = -13.0, 14.5      # exp below 1e-5 / above 1e6: clamped, zero gradient
+        ad.data[:, 11], ad.data[:, 12], ad.data[:, 13] = -12.0, 25.0, 1.2e4   # softplus below 1e-4; beyond the threshold; above 1e4
+        ap.data[:, 14], ap.data[:, 15] = -30.0, 30.0
+        sf = (torch.rand(n, device=cuda_device, dtype=torch.float64) + 0.5) if with_sf else None
+        loss = autograd.zinb_nll_from_logits(x, am, ad, ap, sf, ridge)
+        assert loss.dtype == torch.float64
+        gm, gd, gp = torch.autograd.grad(loss * 2.0, (am, ad, ap))
+        rm_, rd_, rp_ = (t.detach().clone().requires_grad_(True) for t in (am, ad, ap))
+        ref = cpu_ops._zinb_elements(x, *cpu_ops._head_acts(rm_, rd_, rp_), sf, ridge).mean()
+        rm, rd, rp = torch.autograd.grad(ref * 2.0, (rm_, rd_, rp_))
+        # tolerance: the kernels' exp is v_exp_f32 (relative error |a| 2^-24 <= 8e-7 inside the clamp range), torch's is a full-precision expf
+        assert abs(float(loss) - float(ref)) < 2e-6 * abs(float(ref)), (float(loss), float(ref))
+        for a, b, nm in ((gm, rm, "mean"), (gd, rd, "disp"), (gp, rp, "pi")):
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-6, (n, g, nm)
+        for a, cols in ((gm, (9, 10)), (gd, (11, 13))):
+            assert bool((a[:, list(cols)] == 0).all())
+        # == the two-step form through the library's own kernels on activated inputs (same element code, different exp): 2e-6
+        m_, d_, p_ = cpu_ops._head_acts(am.detach(), ad.detach(), ap.detach())
+        two = kernels.zinb_nll_forward(x, m_, d_, p_, sf, ridge).sum()
+        one = kernels.zinb_nll_forward(x, am.detach(), ad.detach(), ap.detach(), sf, ridge, logits=True)
+        assert abs(float(one.sum()) - float(two)) < 2e-6 * abs(float(two))
+        assert torch.equal(one, kernels.zinb_nll_forward(x, am.detach(), ad.detach(), ap.detach(), sf, ridge, logits=True))
+
+
 def test_sctag_scalable_fit_on_device(cuda_device):
     """ScTAG(adj_dim=32) on 6000 cells with a sparse kNN-like adjacency: forward loss == dense formula, pretrain + fit run."""
     from dance_amd.modules.single_modality.clustering.sctag import ScTAG
