@@ -180,6 +180,262 @@ __global__ __launch_bounds__(256) void student_t_reduce_kernel(int64_t n_blocks,
   if (threadIdx.x == 0) dMU[pair] = -2.f * (red[0][0] - MU[pair] * red[1][0]);
 }
 
+// ---- round 5, second form: the same two passes for c <= 32 clusters with a fifth of the LDS instructions -------------------------------
+// The kernels above issue one LDS read per (row, cluster, feature) for mu and one per (row, feature) for z, the backward another 2 per
+// (pair, row) for the dMU partial: ~850 + 1000 + 1000 wave-level LDS instructions per 64 rows at 10 x 50, which is what bounded them
+// (0.155 / 0.30 ms at 500k rows; the bytes are worth 0.015 / 0.03).  Here
+//   * mu is kept TRANSPOSED and zero padded, muT[t][CP] (CP = c rounded up to 4): the CP clusters of one feature are CP / 4 broadcast
+//     ds_read_b128; a lane reads its own row of z as b128 too (row stride 4 x odd: the 16 lanes of a quarter wave hit 64 distinct banks);
+//   * the block's share of dMU = C^T Z ([c x 128] x [128 x d], plus the column sums of C as the product with a column of ones) runs on
+//     the matrix cores (v_mfma_f32_16x16x4_f32, both operands straight from the LDS tiles);
+//   * Q, G and dZ move between HBM and LDS as whole tiles (coalesced) instead of one 4-byte store per lane and cluster / feature;
+//   * base^pw is exp2(pw log2 base) on the transcendental unit (relative error ~1e-6 at base = 1e-3; exact for pw = 1) instead of powf;
+//   * no load of the tile loops sits behind a branch (clamped address + select).
+constexpr int STF_ROWS = 128;
+typedef float stf_f32x4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int stf_d4(int d) { return (d + 3) & ~3; }
+__host__ __device__ constexpr int stf_zs(int d) { return 4 * (((d + 3) / 4) | 1); }  // z tile row stride: a multiple of 4 floats, stride / 4 odd
+__host__ __device__ constexpr int stf_cp(int c) { return (c + 3) & ~3; }
+__host__ __device__ constexpr int64_t stf_lds_floats(int c, int d) {
+  return (int64_t)stf_d4(d) * stf_cp(c) + (int64_t)STF_ROWS * stf_zs(d) + (int64_t)STF_ROWS * (stf_cp(c) + 1);
+}
+
+__device__ __forceinline__ float stf_pow(float base, float pw) { return pw == 1.f ? base : __expf(pw * __logf(base)); }
+
+template <int VW>
+__device__ __forceinline__ void stf_stage_z(float* zt, int64_t n, int d, const float* __restrict__ Z, int64_t ldz, int64_t row0) {
+  typedef float VT __attribute__((ext_vector_type(VW)));
+  constexpr int LPR = 64 / VW;  // lanes per row
+  const int d4 = stf_d4(d), zs = stf_zs(d);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int sub = lane / LPR, cl = (lane % LPR) * VW;
+  const int dv = (d + VW - 1) / VW * VW;  // the last vector of a row may reach past d: inside the row's stride (ldz % VW == 0, ldz >= d)
+  for (int t0 = 0; t0 < d4; t0 += 64) {
+    const int t = t0 + cl;
+    if (t < d4) {
+      const int tc = min(t, dv - VW);
+      constexpr int NIT = STF_ROWS / (2 * VW);  // 16 / 32 / 64 row groups per wave
+#pragma unroll 1
+      for (int k0 = 0; k0 < NIT; k0 += 16) {
+        VT v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int r = ((k0 + u) * 2 + wv) * VW + sub;
+          v[u] = *reinterpret_cast<const VT*>(Z + min(row0 + r, n - 1) * ldz + tc);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int r = ((k0 + u) * 2 + wv) * VW + sub;
+          VT o;
+#pragma unroll
+          for (int i = 0; i < VW; ++i) o[i] = (row0 + r < n && t + i < d) ? v[u][i] : 0.f;
+          *reinterpret_cast<VT*>(zt + r * zs + t) = o;
+        }
+      }
+    }
+  }
+}
+
+// muT and the z tile (rows past n and columns past d are zeros: such a row has d2 = |mu|^2, finite, and is never stored)
+template <int CP>
+__device__ __forceinline__ void stf_stage(float* muT, float* zt, int64_t n, int c, int d, const float* __restrict__ Z, int64_t ldz,
+                                          const float* __restrict__ MU, int64_t row0) {
+  const int d4 = stf_d4(d);
+  for (int i = threadIdx.x; i < d4 * CP; i += STF_ROWS) {
+    const int t = i / CP, j = i - t * CP;
+    const float v = MU[min(j, c - 1) * d + min(t, d - 1)];
+    muT[i] = (t < d && j < c) ? v : 0.f;
+  }
+  // A pass covers 64 columns: 64 / VW lanes per row with VW floats each, VW rows per wave instruction, the two waves on alternate row
+  // groups; all 16 loads of a lane are issued before the first is used (no division, no branch between them).  At VW = 1 (the first
+  // version) a wave needed 8 dependent round trips per tile, and with 8 waves per CU (LDS) that latency, not the bytes, was the kernel.
+  const bool v4 = ldz % 4 == 0 && (reinterpret_cast<uintptr_t>(Z) & 15) == 0, v2 = ldz % 2 == 0 && (reinterpret_cast<uintptr_t>(Z) & 7) == 0;
+  if (v4) stf_stage_z<4>(zt, n, d, Z, ldz, row0);
+  else if (v2) stf_stage_z<2>(zt, n, d, Z, ldz, row0);
+  else stf_stage_z<1>(zt, n, d, Z, ldz, row0);
+}
+
+// rows [0, rows_here) x columns [0, d) of an LDS tile -> global memory, the same lane-per-column walk
+__device__ __forceinline__ void stf_store_rows(const float* tile, int ts, int rows_here, int d, float* __restrict__ out, int64_t ld, int64_t row0) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int t = lane; t < d; t += 64)
+    for (int r = wv; r < rows_here; r += STF_ROWS / 64) out[(row0 + r) * ld + t] = tile[r * ts + t];
+}
+
+__device__ __forceinline__ float stf_base(float d2, float inv_a, float eps) { return __frcp_rn((1.f + d2 * inv_a) + eps); }
+
+// d2[j] = ||z_row - mu_j||^2, j < CP (padded clusters: |z|^2, ignored)
+template <int CP>
+__device__ __forceinline__ void stf_dist(float (&d2)[CP], const float* zr, const float* muT, int d4) {
+#pragma unroll
+  for (int j = 0; j < CP; ++j) d2[j] = 0.f;
+  for (int t4 = 0; t4 < d4; t4 += 4) {
+    const stf_f32x4 z4 = *reinterpret_cast<const stf_f32x4*>(zr + t4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int q = 0; q < CP / 4; ++q) {
+        const stf_f32x4 m4 = *reinterpret_cast<const stf_f32x4*>(muT + (t4 + e) * CP + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float diff = z4[e] - m4[i];
+          d2[4 * q + i] = fmaf(diff, diff, d2[4 * q + i]);
+        }
+      }
+  }
+}
+
+template <int CP>
+__global__ __launch_bounds__(STF_ROWS) void student_t_forward_fast_kernel(int64_t n, int c, int d, const float* __restrict__ Z, int64_t ldz,
+                                                                          const float* __restrict__ MU, StParams p, float* __restrict__ Q, int64_t ldq) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d4 = stf_d4(d), zs = stf_zs(d);
+  constexpr int cs = CP + 1;
+  float* muT = smem;
+  float* zt = muT + d4 * CP;
+  float* qt = zt + STF_ROWS * zs;
+  const int64_t row0 = (int64_t)blockIdx.x * STF_ROWS;
+  const int rows_here = (int)min((int64_t)STF_ROWS, n - row0);
+  stf_stage<CP>(muT, zt, n, c, d, Z, ldz, MU, row0);
+  __syncthreads();
+  float d2[CP];
+  stf_dist<CP>(d2, zt + threadIdx.x * zs, muT, d4);
+  const float inv_a = 1.f / p.a;
+  float u[CP], s = 0.f;
+#pragma unroll
+  for (int j = 0; j < CP; ++j) {
+    u[j] = j < c ? stf_pow(stf_base(d2[j], inv_a, p.eps), p.pw) * p.scale : 0.f;
+    s += u[j];
+  }
+  const float rs = __frcp_rn(s);
+#pragma unroll
+  for (int j = 0; j < CP; ++j) qt[threadIdx.x * cs + j] = u[j] * rs;
+  __syncthreads();
+  // the padded index space [128][CP]: consecutive lanes = consecutive clusters of consecutive rows (contiguous in Q when ldq = c)
+  for (int i = threadIdx.x; i < rows_here * CP; i += STF_ROWS) {
+    const int r = i / CP, j = i - r * CP;
+    if (j < c) Q[(row0 + r) * ldq + j] = qt[r * cs + j];
+  }
+}
+
+template <int CP>
+__global__ __launch_bounds__(STF_ROWS) void student_t_backward_fast_kernel(int64_t n, int c, int d, const float* __restrict__ Z, int64_t ldz,
+                                                                           const float* __restrict__ MU, StParams p, const float* __restrict__ G,
+                                                                           int64_t ldg, float* __restrict__ dZ, int64_t lddz, float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int d4 = stf_d4(d), zs = stf_zs(d);
+  constexpr int cs = CP + 1;
+  float* muT = smem;
+  float* zt = muT + d4 * CP;
+  float* gt = zt + STF_ROWS * zs;  // the rows' upstream gradients G, then their coefficients c_ij
+  const int64_t row0 = (int64_t)blockIdx.x * STF_ROWS;
+  const int rows_here = (int)min((int64_t)STF_ROWS, n - row0);
+  stf_stage<CP>(muT, zt, n, c, d, Z, ldz, MU, row0);
+#pragma unroll
+  for (int k = 0; k < CP; ++k) {  // CP loads per lane, all in flight
+    const int i = threadIdx.x + STF_ROWS * k;
+    const int r = i / CP, j = i - r * CP;
+    const float v = G[min(row0 + r, n - 1) * ldg + min(j, c - 1)];
+    gt[r * cs + j] = (row0 + r < n && j < c) ? v : 0.f;
+  }
+  __syncthreads();
+  // per row: the coefficients c_j (registers, and the row's slot of gt) — a row past n has G = 0, hence c_j = 0: no special case
+  float cj[CP], csum = 0.f;
+  {
+    float d2[CP];
+    stf_dist<CP>(d2, zt + threadIdx.x * zs, muT, d4);
+    const float inv_a = 1.f / p.a;
+    float base[CP], s = 0.f, t_gq = 0.f;
+#pragma unroll
+    for (int j = 0; j < CP; ++j) {
+      base[j] = stf_base(d2[j], inv_a, p.eps);
+      cj[j] = j < c ? stf_pow(base[j], p.pw) * p.scale : 0.f;  // u_j
+      s += cj[j];
+      t_gq = fmaf(gt[threadIdx.x * cs + j], cj[j], t_gq);
+    }
+    const float rs = __frcp_rn(s);
+    t_gq *= rs;  // sum_k G_k q_k
+    const float k_pa = p.pw * inv_a;
+#pragma unroll
+    for (int j = 0; j < CP; ++j) {
+      const float q = cj[j] * rs;
+      cj[j] = -(gt[threadIdx.x * cs + j] - t_gq) * q * k_pa * base[j];
+      csum += cj[j];
+    }
+#pragma unroll
+    for (int j = 0; j < CP; ++j) gt[threadIdx.x * cs + j] = cj[j];
+  }
+  __syncthreads();
+  // the block's share of dMU on the matrix cores: P[i][f] = sum_r c_ri z_rf (f < d), P[i][d] = sum_r c_ri.  16 x 16 tiles, K = 4 rows
+  // per step: lane l holds A[i = l % 16][k = l / 16] = c of row 4 s + l / 16, B[k][f = l % 16] = z of the same row; D[4 (l / 16) + r][l % 16]
+  {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int n_tiles = (d + 1 + 15) / 16;
+    float* out = part + (int64_t)blockIdx.x * (c * d + c);
+    for (int nt = wave; nt < n_tiles; nt += STF_ROWS / 64) {
+      const int f = 16 * nt + l16;
+#pragma unroll
+      for (int mt = 0; mt < (CP + 15) / 16; ++mt) {
+        const int ci = 16 * mt + l16;
+        stf_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < STF_ROWS / 4; ++ks) {
+          const int r = 4 * ks + kq;
+          const float a = ci < CP ? gt[r * cs + min(ci, CP - 1)] : 0.f;
+          const float zv = zt[r * zs + min(f, d4 - 1)];
+          const float b = f < d ? zv : (f == d ? 1.f : 0.f);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * mt + 4 * kq + r;
+          if (i < c) {
+            if (f < d) out[i * d + f] = acc[r];
+            else if (f == d) out[c * d + i] = acc[r];
+          }
+        }
+      }
+    }
+  }
+  if (!dZ) return;  // uniform
+  __syncthreads();  // the product above read every row of zt; below each lane replaces its own row by dz
+  {
+    float* zr = zt + threadIdx.x * zs;
+    for (int t4 = 0; t4 < d4; t4 += 4) {
+      const stf_f32x4 z4 = *reinterpret_cast<const stf_f32x4*>(zr + t4);
+      stf_f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = z4[e] * csum;
+#pragma unroll
+        for (int q = 0; q < CP / 4; ++q) {
+          const stf_f32x4 m4 = *reinterpret_cast<const stf_f32x4*>(muT + (t4 + e) * CP + 4 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc = fmaf(-cj[4 * q + i], m4[i], acc);
+        }
+        o[e] = 2.f * acc;
+      }
+      *reinterpret_cast<stf_f32x4*>(zr + t4) = o;
+    }
+  }
+  __syncthreads();
+  stf_store_rows(zt, zs, rows_here, d, dZ, lddz, row0);
+}
+
+bool stf_ok(int64_t c, int64_t d) { return c <= 32 && stf_lds_floats((int)c, (int)d) <= ST_MAX_LDS_FLOATS; }
+
+#define STF_DISPATCH(CPV, ...)                          \
+  switch (CPV) {                                        \
+    case 4: { constexpr int CP = 4; __VA_ARGS__; } break;    \
+    case 8: { constexpr int CP = 8; __VA_ARGS__; } break;    \
+    case 12: { constexpr int CP = 12; __VA_ARGS__; } break;  \
+    case 16: { constexpr int CP = 16; __VA_ARGS__; } break;  \
+    case 20: { constexpr int CP = 20; __VA_ARGS__; } break;  \
+    case 24: { constexpr int CP = 24; __VA_ARGS__; } break;  \
+    case 28: { constexpr int CP = 28; __VA_ARGS__; } break;  \
+    default: { constexpr int CP = 32; __VA_ARGS__; } break;  \
+  }
+
 int st_check(const char* me, int64_t n, int64_t c, int64_t d, const void* Z, int64_t ldz, const void* MU, float a) {
   if (n < 0 || c <= 0 || d <= 0) return dh::fail(DH_ERR_INVALID, "%s: bad size", me);
   if (c > ST_MAX_C || c * d > ST_MAX_CD || st_lds_floats(c, d) > ST_MAX_LDS_FLOATS)
@@ -204,6 +460,12 @@ extern "C" int dh_student_t_forward_f32(int64_t n, int64_t c, int64_t d, const f
   if (rc != DH_OK) return rc;
   if (n == 0) return DH_OK;
   if (!Q || ldq < c) return dh::fail(DH_ERR_INVALID, "%s: bad output", me);
+  if (stf_ok(c, d)) {
+    const size_t lds = (size_t)stf_lds_floats((int)c, (int)d) * sizeof(float);
+    STF_DISPATCH(stf_cp((int)c), hipLaunchKernelGGL(student_t_forward_fast_kernel<CP>, dim3((unsigned)dh::ceil_div(n, STF_ROWS)), dim3(STF_ROWS), lds,
+                                                    dh::as_stream(stream), n, (int)c, (int)d, Z, ldz, MU, StParams{a, eps, pw, scale}, Q, ldq));
+    return dh::check_launch(me);
+  }
   hipLaunchKernelGGL(student_t_forward_kernel, dim3((unsigned)dh::ceil_div(n, ST_ROWS)), dim3(ST_ROWS), (size_t)(c * d + ST_ROWS * (d | 1)) * sizeof(float),
                      dh::as_stream(stream), n, (int)c, (int)d, Z, ldz, MU, StParams{a, eps, pw, scale}, Q, ldq);
   return dh::check_launch(me);
@@ -231,8 +493,13 @@ extern "C" int dh_student_t_backward_f32(int64_t n, int64_t c, int64_t d, const 
   if (!workspace || workspace_bytes < need) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, workspace_bytes, need);
   const int64_t n_blocks = dh::ceil_div(n, ST_ROWS);
   const size_t lds = (size_t)st_lds_floats(c, d) * sizeof(float);
-  hipLaunchKernelGGL(student_t_backward_kernel, dim3((unsigned)n_blocks), dim3(ST_ROWS), lds, st, n, (int)c, (int)d, Z, ldz, MU,
-                     StParams{a, eps, pw, scale}, G, ldg, dZ, lddz, static_cast<float*>(workspace));
+  if (stf_ok(c, d)) {
+    const size_t lds_fast = (size_t)stf_lds_floats((int)c, (int)d) * sizeof(float);
+    STF_DISPATCH(stf_cp((int)c), hipLaunchKernelGGL(student_t_backward_fast_kernel<CP>, dim3((unsigned)n_blocks), dim3(STF_ROWS), lds_fast, st, n, (int)c, (int)d,
+                                                    Z, ldz, MU, StParams{a, eps, pw, scale}, G, ldg, dZ, lddz, static_cast<float*>(workspace)));
+  } else
+    hipLaunchKernelGGL(student_t_backward_kernel, dim3((unsigned)n_blocks), dim3(ST_ROWS), lds, st, n, (int)c, (int)d, Z, ldz, MU,
+                       StParams{a, eps, pw, scale}, G, ldg, dZ, lddz, static_cast<float*>(workspace));
   rc = dh::check_launch(me);
   if (rc != DH_OK) return rc;
   hipLaunchKernelGGL(student_t_reduce_kernel, dim3((unsigned)(c * d)), dim3(256), 0, st, n_blocks, (int)c, (int)d,

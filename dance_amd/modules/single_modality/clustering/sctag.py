@@ -126,7 +126,14 @@ class DecoderX(nn.Module):
         self.dec_pi = nn.Sequential(HipLinear(self.n_dec_3, self.input_dim), nn.Sigmoid())
 
     def forward(self, z):
+        return self._forward(z, False)
+
+    def _forward(self, z, raw_heads: bool):
+        """``raw_heads=True`` (the two training loops): the heads' Linear outputs, for ``ZINBLoss.from_logits`` — MeanAct / DispAct /
+        Sigmoid then run inside the loss kernels (see scdsc.ScDSCModel._forward)."""
         dec_h3 = self.dec_3(self.dec_2(self.dec_1(z, fuse_relu=True), fuse_relu=True), fuse_relu=True)
+        if raw_heads:
+            return self.dec_mean[0](dec_h3), self.dec_disp[0](dec_h3), self.dec_pi[0](dec_h3)
         return self.dec_mean(dec_h3), self.dec_disp(dec_h3), self.dec_pi(dec_h3)
 
 
@@ -218,10 +225,13 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
         )
 
     def forward(self, g, x_input):
+        return self._forward(g, x_input, False)
+
+    def _forward(self, g, x_input, raw_heads: bool):
         enc_h = self.encoder1(g, x_input, edge_weight=g.edata["weight"])
         z = self.encoder2(g, enc_h, edge_weight=g.edata["weight"])
         adj_out = self.decoder_adj(z, factor_only=self.adj_dim is not None)  # scalable mode: the factor z0 [N, adj_dim], not N x N
-        _mean, _disp, _pi = self.decoder_x(z)
+        _mean, _disp, _pi = self.decoder_x._forward(z, raw_heads)
         return adj_out, z, self.soft_assign(z), _mean, _disp, _pi
 
     def adj_loss(self, adj_out, adj_t):
@@ -241,8 +251,8 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
         self.train()
         optimizer = optim.Adam(filter(lambda p: p.requires_grad, self.parameters()), lr=lr, amsgrad=True)
         for _ in range(epochs):
-            adj_out, z, _, mean, disp, pi = self.forward(self.g_n, x)
-            loss = w_a * self.adj_loss(adj_out, adj_t) + w_x * self.zinb_loss(x_raw, mean, disp, pi, scale_factor)
+            adj_out, z, _, mean, disp, pi = self._forward(self.g_n, x, True)  # raw head outputs: the activations run inside the loss kernels
+            loss = w_a * self.adj_loss(adj_out, adj_t) + w_x * self.zinb_loss.from_logits(x_raw, mean, disp, pi, scale_factor)
             if w_d:
                 loss = loss + w_d * torch.mean(dist_loss(z, min_dist, max_dist=max_dist))
             optimizer.zero_grad()
@@ -282,7 +292,7 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
         aris, Q = [], {}
         y_t = torch.as_tensor(np.asarray(y), dtype=torch.float32).to(self.device)
         for epoch in range(epochs):
-            adj_out, _, q, mean, disp, pi = self.forward(self.g_n, x)
+            adj_out, _, q, mean, disp, pi = self._forward(self.g_n, x, True)
             self.q = q
             self.y_pred = self.predict()
             aris.append(self.score(None, y))  # ARI for model selection (:331-333)
@@ -290,7 +300,7 @@ class ScTAG(nn.Module, TorchNNPretrain, BaseClusteringMethod):
             # the "cluster loss" of :343-346 is a KL between two constant label vectors: it carries no gradient, but its value
             # (possibly nan / inf) is added to the loss exactly as the reference does
             cluster_loss = torch.mean(F.kl_div(torch.as_tensor(self.y_pred, dtype=torch.float32).to(self.device), y_t, reduction="batchmean"))
-            loss = w_a * self.adj_loss(adj_out, adj_t) + w_x * self.zinb_loss(x_raw, mean, disp, pi, scale_factor) + w_c * cluster_loss
+            loss = w_a * self.adj_loss(adj_out, adj_t) + w_x * self.zinb_loss.from_logits(x_raw, mean, disp, pi, scale_factor) + w_c * cluster_loss
             optimizer.zero_grad()
             loss.backward()
             optimizer.step()

@@ -281,6 +281,17 @@ def main():
         ms=ms, bound="hbm", achieved=byt / ms / 1e6, peak=HBM, unit="GB/s", frac=byt / ms / 1e6 / HBM, cells_per_s=n / ms * 1e3,
         frac_gather_accounting=byt_gather / ms / 1e6 / HBM)
     del x64
+    for (ns_, c_, d_, consts_, who) in ((n // 2, 10, 50, (0.2, 1e-8, 1.2, 0.5), "SpaGCN"), (n, 10, 32, (1.0, 0.0, 1.0, 1.0), "scDSC")):
+        zz = torch.randn(ns_, d_, device=dev, generator=g)
+        mu_ = torch.randn(c_, d_, device=dev, generator=g) * 0.7
+        gq = torch.randn(ns_, c_, device=dev, generator=g)
+        f_ms = gpu_ms(lambda: kernels.student_t_forward(zz, mu_, *consts_), iters=10, warm=2)
+        b_ms = gpu_ms(lambda: kernels.student_t_backward(zz, mu_, *consts_, gq), iters=10, warm=2)
+        sb = ns_ * (3.0 * d_ + 3.0 * c_) * 4
+        rows[f"Student-t soft assignment fwd+bwd ({who} head) n={ns_} c={c_} d={d_}"] = dict(
+            ms=f_ms + b_ms, forward_ms=f_ms, backward_ms=b_ms, bound="hbm", achieved=sb / (f_ms + b_ms) / 1e6, peak=HBM, unit="GB/s",
+            frac=sb / (f_ms + b_ms) / 1e6 / HBM, note="bytes: forward N (d + c) 4, backward N (2 d + 2 c) 4")
+        del zz, gq
     # ---- (f)2: fused ZINB NLL (fwd + bwd) and the all-pairs adjacency loss of scTAG without the N x N matrix -----------------------
     from dance_amd import autograd
     nz, gz = (50_000 if q else 1_000_000), 2000
@@ -300,6 +311,26 @@ def main():
     zb = nz * gz * (16.0 + 28.0)
     rows[f"ZINB NLL fwd+bwd (dh_zinb_nll_*) cells={nz} genes={gz}"] = dict(ms=ms, kernels_ms=ks, bound="hbm", achieved=zb / ms / 1e6, peak=HBM, unit="GB/s",
                                                                           frac=zb / ms / 1e6 / HBM, note="float64 element arithmetic (3 lgamma, 2 digamma, 5 log, 1 pow): ALU-bound")
+    # the same loss on the heads' raw outputs (MeanAct / DispAct / sigmoid and their backward inside the two kernels), against the
+    # torch activations + their autograd around the loss kernels (what round 4 ran)
+    am = torch.log(mean.detach()).requires_grad_(True)
+    ad = torch.log(torch.expm1(disp.detach())).requires_grad_(True)
+    ap = torch.logit(pi.detach()).requires_grad_(True)
+
+    def zstep_logits():
+        am.grad = ad.grad = ap.grad = None
+        autograd.zinb_nll_from_logits(xr, am, ad, ap, sf).backward()
+
+    def zstep_torch_acts():
+        am.grad = ad.grad = ap.grad = None
+        autograd.zinb_nll(xr, torch.clamp(torch.exp(am), 1e-5, 1e6), torch.clamp(torch.nn.functional.softplus(ad), 1e-4, 1e4), torch.sigmoid(ap), sf).backward()
+
+    ms_l = gpu_ms(zstep_logits, iters=3, warm=1)
+    ms_t = gpu_ms(zstep_torch_acts, iters=3, warm=1)
+    rows[f"ZINB NLL on the heads' raw outputs fwd+bwd (dh_zinb_nll_logits_*) cells={nz} genes={gz}"] = dict(
+        ms=ms_l, bound="hbm", achieved=zb / ms_l / 1e6, peak=HBM, unit="GB/s", frac=zb / ms_l / 1e6 / HBM, torch_activations_around_the_loss_kernels_ms=ms_t,
+        note="same bytes as the row above (16 forward + 28 backward per element); the activations' 17 elementwise passes are gone")
+    del am, ad, ap
     ns = 20_000 if q else 100_000  # the unfused torch formula (float64 temporaries) on a sample
     sl = slice(0, ns)
     import sys as _sys

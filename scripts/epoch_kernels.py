@@ -1,9 +1,10 @@
-"""Which kernels — the library's AND torch's — make up one joint-training epoch of ScDSC.fit (BASELINE config 2's model, 100k cells)?
-Run twice under `rocprofv3 --kernel-trace --stats` with different epoch counts and difference the per-kernel totals:
+"""Which kernels — the library's AND torch's — make up one epoch of a model's fit (ScDSC.fit: BASELINE config 2's model at 100k cells;
+ScDeepSort.fit: config 3 at 1M cells, bf16)?  Run twice under `rocprofv3 --kernel-trace --stats` with different epoch counts and
+difference the per-kernel totals:
 
-    python scripts/scdsc_epoch_kernels.py run 1          # one fit of 1 epoch (after a warm-up fit)
-    python scripts/scdsc_epoch_kernels.py run 7
-    python scripts/scdsc_epoch_kernels.py diff a_kernel_stats.csv b_kernel_stats.csv 6
+    python scripts/epoch_kernels.py run scdsc 1          # one fit of 1 epoch (after a warm-up fit)
+    python scripts/epoch_kernels.py run scdsc 7
+    python scripts/epoch_kernels.py diff a_kernel_stats.csv b_kernel_stats.csv 6
 """
 import csv
 import os
@@ -32,6 +33,22 @@ def run(epochs, n=100_000):
         torch.cuda.synchronize()
 
 
+def run_scdeepsort(epochs, n_cells=1_000_000, batch=65536):
+    import torch
+    from bench_configs import _cellgene_graph
+
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    dev = torch.device("cuda", 0)
+    cg = _cellgene_graph(n_cells, 2000, 200, 400, dev)
+    labels = torch.randint(0, 16, (n_cells, ), generator=torch.Generator().manual_seed(0))
+    with tempfile.TemporaryDirectory() as tmp:
+        m = ScDeepSort(400, 200, 1, "synthetic", "c3", batch_size=batch, device="cuda", save_root=tmp, verbose=False, compute_dtype="bf16")
+        torch.manual_seed(0)
+        m.fit(cg, labels, epochs=1, lr=1e-3, val_ratio=0.2)
+        m.fit(cg, labels, epochs=epochs, lr=1e-3, val_ratio=0.2)
+        torch.cuda.synchronize()
+
+
 def diff(a, b, units):
     def load(p):
         return {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(p))}
@@ -51,6 +68,6 @@ def diff(a, b, units):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        run(int(sys.argv[2]))
+        {"scdsc": run, "scdeepsort": run_scdeepsort}[sys.argv[2]](int(sys.argv[3]))
     else:
         diff(sys.argv[2], sys.argv[3], float(sys.argv[4]))
