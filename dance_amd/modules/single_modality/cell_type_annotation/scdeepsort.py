@@ -54,8 +54,8 @@ class GNN(nn.Module):
 
 
 HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
-HIPGRAPH_MIN_BATCHES = 64   # the capture (two eager steps + instantiation, tens of ms) must be amortised
-HIPGRAPH_MAX_BATCH = 2048    # above this a step is kernel-bound: replaying gains nothing (batch 65536: the capture doubled the epoch)
+HIPGRAPH_MIN_BATCHES = int(os.environ.get("DANCE_AMD_HIPGRAPH_MIN_BATCHES", "64"))  # the capture (two eager steps + instantiation, tens of ms) must be amortised
+HIPGRAPH_MAX_BATCH = int(os.environ.get("DANCE_AMD_HIPGRAPH_MAX_BATCH", "2048"))    # above this a step is kernel-bound: replaying gains little (see fit)
 
 
 class ScDeepSort(BaseClassificationMethod):
@@ -152,7 +152,7 @@ class ScDeepSort(BaseClassificationMethod):
         self._world = sharding.world_info()[1]
         n_full = -(-len(train_idx) // self._world) // self.batch_size
         self._use_graph = (HIPGRAPH and self.n_layers == 1 and graph.gene_prefix() >= 0
-                           and str(self.device).startswith("cuda") and n_full >= HIPGRAPH_MIN_BATCHES and 1 < self.batch_size <= HIPGRAPH_MAX_BATCH
+                           and str(self.device).startswith("cuda") and n_full * max(int(epochs), 1) >= HIPGRAPH_MIN_BATCHES and 1 < self.batch_size <= HIPGRAPH_MAX_BATCH
                            and not any(layer.use_neigh for layer in self.model.layers))
         self._captured = None
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph,

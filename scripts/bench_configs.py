@@ -218,6 +218,16 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
             m = ScDeepSort(dfeat, hid, 1, "synthetic", "c3", batch_size=batch, device="cuda", save_root=tmp, verbose=False, compute_dtype=cd)
             torch.manual_seed(0)
             m.fit(cg, labels, epochs=1, lr=1e-3, val_ratio=0.2)  # warm-up
+            steady = None
+            if cd == "bf16":  # the steady-state epoch, as configs 2 and 5 measure theirs: fit(4) - fit(1) over 3 (a fit call has fixed costs)
+                tt = {}
+                for e in (1, 4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    m.fit(cg, labels, epochs=e, lr=1e-3, val_ratio=0.2)
+                    torch.cuda.synchronize()
+                    tt[e] = time.perf_counter() - t0
+                steady = (tt[4] - tt[1]) / 3
             best = None
             for _ in range(2):  # best of two: a fit call also writes a checkpoint
                 torch.cuda.synchronize()
@@ -229,6 +239,8 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
                 if best is None or dt < best[0]:
                     best = (dt, {k: round(v, 3) for k, v in _kernel_totals(timer).items()})
         out[cd] = best
+        if steady is not None:
+            out["steady"] = steady
     dt, ks = out["bf16"]
     dom = max(ks, key=ks.get)
     # one cell<-gene aggregation over the whole graph = nnz (4 + s) + 4 (N + 1) + G D s + N D s bytes
@@ -254,7 +266,10 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
     med, it = _cpu_time(cpu_batch, min_seconds=6.0, max_iters=12)
     return {"workload": f"ScDeepSort.fit, one epoch = training pass (80 % of the cells, batch {batch}) + the reference's two evaluation passes, "
                         f"{n_cells} cells x {n_genes} genes at 10 % density (nnz {n_cells * per}), D = {dfeat} -> {hid}, bf16 storage + bf16 MFMA dense update",
-            "ms": round(dt * 1e3, 2), "value": n_cells / dt, "unit": "cells/s per epoch", "kernels_ms": ks, "roofline": roof,
+            "ms": round(out["steady"] * 1e3, 2), "value": n_cells / out["steady"], "unit": "cells/s per epoch",
+            "ms_basis": "steady-state epoch = (fit(4 epochs) - fit(1 epoch)) / 3, like configs 2 and 5; fit_call_1_epoch_ms is a whole one-epoch fit call "
+                        "(model construction, split, checkpoint included: the number rounds 3-4 quoted), kernels_ms belongs to that call",
+            "fit_call_1_epoch_ms": round(dt * 1e3, 2), "kernels_ms": ks, "roofline": roof,
             "fp32": {"ms": round(out["fp32"][0] * 1e3, 2), "kernels_ms": out["fp32"][1]},
             "cpu_baseline": {"value": 500 / med, "unit": "training cells/s (one pass; an epoch is ~2.2 passes)", "cores": torch.get_num_threads(), "kind": "port",
                              "sample": f"graph of {cpu_cells} cells from the same generator, batches of 500 (reference default), oracle.models.scdeepsort_batch "
