@@ -380,6 +380,39 @@ def zinb_nll_from_logits(x, mean_raw, disp_raw, pi_raw, scale_factor=None, ridge
     return _ZINBNLL.apply(x, mean_raw, disp_raw, pi_raw, scale_factor, ridge_lambda, True)
 
 
+class _SoftmaxXentSum(torch.autograd.Function):
+    """``F.cross_entropy(logits, labels, reduction="sum")`` as one kernel + a scalar multiply in backward (dh_softmax_xent_sum_f32)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index: int):
+        x = logits if logits.dtype == torch.float32 and logits.stride(-1) == 1 else logits.float().contiguous()
+        need = logits.requires_grad
+        loss, d = kernels.softmax_xent_sum(x, labels, ignore_index, want_grad=need)
+        ctx.in_dtype = logits.dtype
+        if need:
+            ctx.save_for_backward(d)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d, = ctx.saved_tensors
+        return (d * g).to(ctx.in_dtype), None, None
+
+
+class CrossEntropySum(torch.nn.Module):
+    """``nn.CrossEntropyLoss(reduction="sum")`` (scdeepsort.py:185) on dh_softmax_xent_sum_f32 for 2-D logits with int64 class labels on
+    the device; class probabilities as targets or more dimensions are torch's."""
+
+    def __init__(self, ignore_index: int = -100):
+        super().__init__()
+        self.ignore_index = int(ignore_index)
+
+    def forward(self, logits, labels):
+        if logits.dim() == 2 and labels.dim() == 1 and labels.dtype == torch.int64:
+            return _SoftmaxXentSum.apply(logits, labels, self.ignore_index)
+        return torch.nn.functional.cross_entropy(logits, labels, reduction="sum", ignore_index=self.ignore_index)
+
+
 class _AdjReconstructionMSE(torch.autograd.Function):
     """mean_ij (sigmoid(<z_i, z_j>) - a_ij)^2 over ALL n^2 pairs for a sparse target a (CSR, stored entries only), as a function of z
     and without any n x n matrix — scTAG's adjacency-decoder loss ``F.mse_loss(sigmoid(z0 z0^T), adj)`` (sctag.py:470-471, :254):

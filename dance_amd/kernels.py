@@ -435,6 +435,21 @@ def zinb_nll_backward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], r
     return dm, dd, dp
 
 
+def softmax_xent_sum(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100, want_grad: bool = True):
+    """(loss, d) of ``CrossEntropyLoss(reduction="sum")``: loss a 0-dim fp32 tensor, d = softmax(logits) - onehot(labels) or None
+    (dh_softmax_xent_sum_f32)."""
+    lib = _lib_ready()
+    n, c = logits.shape
+    loss = torch.empty((), dtype=torch.float32, device=logits.device)
+    d = torch.empty((n, c), dtype=torch.float32, device=logits.device) if want_grad else None
+    ws_bytes = lib.dh_softmax_xent_sum_workspace_bytes(n, c)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=logits.device)
+    _call("softmax_xent_sum_f32", lib.dh_softmax_xent_sum_f32, n, c, _dev(logits, torch.float32, "logits", 2), _ld(logits),
+          _dev(labels, torch.int64, "labels", 1), int(ignore_index), loss.data_ptr(), None if d is None else d.data_ptr(), c, ws.data_ptr(), ws_bytes,
+          _stream())
+    return loss, d
+
+
 GRAM_SOFTPLUS, GRAM_SIGMOID_SQ = 0, 1
 
 

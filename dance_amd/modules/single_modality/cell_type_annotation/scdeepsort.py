@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from .... import kernels
-from ....autograd import HipLinear
+from ....autograd import CrossEntropySum, HipLinear
 from ....cellgraph import DataLoader, NeighborSampler
 from ....nn import AdaptiveSAGE
 from ....transforms import Compose, SetConfig
@@ -157,7 +157,7 @@ class ScDeepSort(BaseClassificationMethod):
         self._captured = None
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph,
                                           fused=str(self.device).startswith("cuda"))  # one kernel per step instead of ~14
-        self.loss_fn = nn.CrossEntropyLoss(reduction="sum")
+        self.loss_fn = CrossEntropySum()  # nn.CrossEntropyLoss(reduction="sum") of :185 as one kernel (torch's nll_loss reductions are one workgroup)
 
         # more than one process: data parallelism over the training cells (the graph is replicated, the model is small):
         # every rank trains on its share, gradients are averaged with one flat all-reduce per step (dance_amd/sharding.py)

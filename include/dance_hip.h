@@ -195,6 +195,14 @@ DH_API int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* Y, i
  * and of GraphConvolution on a dense adjacency (spagcn.py:360-361).  bias may be NULL.            */
 DH_API int dh_bias_act_f32(int64_t n_rows, int64_t width, float* X, int64_t ldx, const float* bias, int act,
                     dh_stream_t stream);
+/* `nn.CrossEntropyLoss(reduction="sum")` of scDeepSort's training step (scdeepsort.py:185, :242) and its gradient in one pass:
+ * loss[0] = sum_i (logsumexp(x_i) - x_{i, y_i}) over the rows with y_i != ignore_index (torch's default -100),
+ * d_logits (may be NULL) = softmax(x_i) - onehot(y_i) (zero rows where ignored): the autograd backward is d_logits times the upstream
+ * scalar.  labels: int64, as torch holds them.  Deterministic (block partials in the workspace, summed in block order).            */
+DH_API size_t dh_softmax_xent_sum_workspace_bytes(int64_t n, int64_t n_classes);
+DH_API int dh_softmax_xent_sum_f32(int64_t n, int64_t n_classes, const float* logits, int64_t ldx, const int64_t* labels,
+                            int64_t ignore_index, float* loss, float* d_logits, int64_t ldd, void* workspace, size_t workspace_bytes,
+                            dh_stream_t stream);
 /* SpaGCN Gaussian kernel: e = exp(-d^2 / (2 l^2)) (spagcn.py:249-251 calculate_p, :807-809 calc_adj_exp),
  * f32 like numpy.  out (may be NULL) receives e; rowsum (may be NULL) receives sum_j e[i,j], so
  * calculate_p / search_l stream the N x N distance matrix without materialising the kernel.

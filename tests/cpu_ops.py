@@ -524,7 +524,21 @@ STAND_INS = ("adam_step", "degree_scales", "block_cells_static", "block_cells_st
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
              "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward",
-             "student_t_supported", "student_t_forward", "student_t_backward")
+             "student_t_supported", "student_t_forward", "student_t_backward", "softmax_xent_sum")
+
+
+def softmax_xent_sum(logits, labels, ignore_index=-100, want_grad=True):
+    x = logits.detach().float()
+    live = labels != ignore_index
+    lse = torch.logsumexp(x, dim=1)
+    safe = labels.clamp(min=0)
+    loss = ((lse - x.gather(1, safe[:, None])[:, 0]) * live).sum()
+    d = None
+    if want_grad:
+        d = torch.softmax(x, dim=1)
+        d[torch.arange(x.shape[0]), safe] -= 1.0
+        d = d * live[:, None]
+    return loss, d
 
 
 def degree_scales(rowptr, col, n_rows, n_cols, mode=0, *, n_pad=0):

@@ -375,3 +375,33 @@ def test_gemm_f32_bias_act_equals_two_passes(cuda_device, M, N, K, tb, act):
     assert torch.equal(one, two)
     if act:
         assert torch.equal(kernels.gemm(a, b, trans_b=tb, act=act), torch.relu(kernels.gemm(a, b, trans_b=tb)))
+
+
+@pytest.mark.parametrize("n,c", [(1, 1), (1000, 16), (65537, 16), (513, 3), (300, 40), (257, 64), (130, 300), (64, 1000)])
+def test_softmax_xent_sum_matches_torch(cuda_device, n, c):
+    """dh_softmax_xent_sum_f32 == F.cross_entropy(reduction="sum") in float64 and its gradient, ignore_index rows included; the
+    autograd wrapper scales by the upstream scalar; deterministic."""
+    from dance_amd import kernels
+    from dance_amd.autograd import CrossEntropySum
+    g = torch.Generator(device="cpu").manual_seed(n + c)
+    x = (torch.randn(n, c, generator=g) * 3).to(cuda_device).requires_grad_(True)
+    y = torch.randint(0, c, (n, ), generator=g)
+    if n > 10:
+        y[::7] = -100
+    y = y.to(cuda_device)
+    loss = CrossEntropySum()(x, y)
+    gx, = torch.autograd.grad(loss * 0.37, x)
+    x64 = x.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(x64, y, reduction="sum")
+    gref, = torch.autograd.grad(ref * 0.37, x64)
+    assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)) + 1e-6
+    assert rel_err(gx.cpu().numpy(), gref.cpu().numpy()) < 2e-6
+    if n > 10:
+        assert bool((gx[::7] == 0).all())
+    l2, d2 = kernels.softmax_xent_sum(x.detach(), y)
+    l3, d3 = kernels.softmax_xent_sum(x.detach(), y)
+    assert torch.equal(l2, l3) and torch.equal(d2, d3)
+    xs = torch.zeros(n, c + 5, device=cuda_device)   # strided rows
+    xs[:, :c] = x.detach()
+    l4, d4 = kernels.softmax_xent_sum(xs[:, :c], y)
+    assert torch.equal(l4, l2) and torch.equal(d4, d2)
