@@ -207,3 +207,59 @@ def scdeepsort_batch(model, optimizer, rowptr, col, val, features, cell_id, labe
     loss.backward()
     optimizer.step()
     return float(loss.detach())
+
+
+# ---- graph-sc (dance/modules/single_modality/clustering/graphsc.py) ------------------------------------------------------------------
+class GraphSCAE(nn.Module):
+    """``GCNAE`` of graphsc.py:274-384 with one ``WeightedGraphConv`` layer (:428-484, dgl GraphConv norm="both", bias, relu), the hidden
+    Linear stack and the identity-activation ``InnerProductDecoder`` (:387-425; its dropout is a constructor argument here, 0 where a
+    comparison must be deterministic).  State-dict names follow the reference (``layer1.weight / bias``, ``encoder.<i>.weight / bias``)."""
+
+    def __init__(self, in_feats, hidden_dim=200, hidden=(300, ), agg="sum", decoder_dropout=0.1, dropout=0.0):
+        super().__init__()
+        self.agg, self.decoder_dropout, self.dropout = agg, decoder_dropout, dropout
+        self.layer1 = nn.Module()
+        self.layer1.weight = nn.Parameter(torch.empty(in_feats, hidden_dim))
+        self.layer1.bias = nn.Parameter(torch.zeros(hidden_dim))
+        nn.init.xavier_uniform_(self.layer1.weight)
+        dims = (hidden_dim, ) + tuple(hidden)
+        self.encoder = nn.Sequential(*[nn.Linear(dims[i], dims[i + 1]) for i in range(len(hidden))]) if hidden else None
+
+    def forward(self, h_src, n_dst, e_src, e_dst, w):
+        n_src = h_src.shape[0]
+        if self.dropout and self.training:
+            h_src = F.dropout(h_src, self.dropout)                                     # GCNAE.dropout on the block's input (:366-367)
+        out_deg = torch.bincount(e_src, minlength=n_src).float().clamp(min=1)        # degrees INSIDE the block, as DGL computes them
+        in_deg = torch.bincount(e_dst, minlength=n_dst).float().clamp(min=1)
+        feat = (h_src * out_deg.pow(-0.5)[:, None]) @ self.layer1.weight              # :452-467
+        m = feat[e_src] * w[:, None]                                                   # edge_selection_simple (:430-438)
+        h = torch.zeros((n_dst, feat.shape[1]), dtype=feat.dtype).index_add_(0, e_dst, m)
+        if self.agg == "mean":
+            h = h / torch.bincount(e_dst, minlength=n_dst).clamp(min=1)[:, None]
+        h = F.relu(h * in_deg.pow(-0.5)[:, None] + self.layer1.bias)                   # :472-483
+        z = self.encoder(h) if self.encoder is not None else h
+        zd = F.dropout(z, self.decoder_dropout, training=True) if self.decoder_dropout else z   # F.dropout(z, p): always on (:423)
+        return zd @ zd.t(), z
+
+
+def graphsc_batch(model, optimizer, rowptr, col, val, features, seeds):
+    """One batch of ``GraphSC.fit`` (graphsc.py:196-220): full-neighbour block of the seed cells, a first forward (its embedding is what
+    the loop collects), the dense dst x dst adjacency of the block (= the seeds' self loops in a cell-gene graph), the weighted BCE on the
+    logits of a SECOND forward, Adam step.  Returns (loss, embedding of the first forward)."""
+    src_ids, e_src, e_dst, w = scdeepsort_block(rowptr, col, val, seeds)
+    es, ed, wt = torch.from_numpy(e_src), torch.from_numpy(e_dst), torch.from_numpy(w.astype(np.float32))
+    n_dst = len(seeds)
+    with torch.no_grad():
+        _, emb = model(features[src_ids], n_dst, es, ed, wt)
+    adj = torch.zeros((n_dst, n_dst))
+    inner = e_src < n_dst
+    adj[ed[inner], es[inner]] = 1.0
+    tot = float(adj.sum())
+    pos_weight = torch.tensor([(n_dst * n_dst - tot) / tot])
+    factor = (n_dst * n_dst - tot) * 2 or 1
+    logits, _ = model(features[src_ids], n_dst, es, ed, wt)
+    loss = (n_dst * n_dst / factor) * F.binary_cross_entropy_with_logits(logits, adj, pos_weight=pos_weight)
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return float(loss.detach()), emb

@@ -276,6 +276,61 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
                                        f"(restated AdaptiveSAGE block path, fp32; DGL not installable), median of {it} batches ({med * 1e3:.0f} ms each)"}}
 
 
+# ---- config 4 on one GPU: GraphSC.fit epoch on the 1M-cell cell-gene graph ----------------------------------------------------------
+def c4_graphsc_epoch(dev, n_cells=1_000_000, batch=8192, ref_batch=128, cpu_cells=20_000, ref_batch_epochs=True):
+    from dance_amd import kernels
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    from oracle import models as om
+    n_genes, per, dfeat = 2000, 200, 50
+    cg = _cellgene_graph(n_cells, n_genes, per, dfeat, dev)
+
+    def steady(bsz, e2):
+        torch.manual_seed(0)
+        gs = GraphSC(in_feats=dfeat, n_clusters=10, device="cuda")
+        gs.fit(cg, epochs=1, batch_size=bsz)  # warm-up (allocator, capture below batch 2048)
+        res = {}
+        for e in (1, e2):
+            torch.cuda.synchronize()
+            with kernels.KernelTimer() as timer:
+                t0 = time.perf_counter()
+                gs.fit(cg, epochs=e, batch_size=bsz)
+                torch.cuda.synchronize()
+                res[e] = (time.perf_counter() - t0, _kernel_totals(timer))
+        return (res[e2][0] - res[1][0]) / (e2 - 1), _per_unit(res[e2][1], res[1][1], e2 - 1)
+    dt, ks = steady(batch, 3)
+    out = {"workload": f"GraphSC.fit (graph-sc GAE: WeightedGraphConv {dfeat} -> 200, Linear 200 -> 300, inner-product decoder, weighted BCE on the block's "
+                       f"dst x dst adjacency, two forwards per batch as graphsc.py:202,215 writes it), one epoch over {n_cells} cells x {n_genes} genes at 10 % "
+                       f"density, batch {batch}, fp32, ONE GPU (BASELINE's config shards it over 8); steady-state epoch = (fit(3) - fit(1)) / 2",
+           "ms": round(dt * 1e3, 2), "value": n_cells / dt, "unit": "cells/s per epoch", "kernels_ms": ks}
+    dom = max(ks, key=ks.get) if ks else None
+    out["roofline"] = {"kernel": dom, "ms_per_epoch": ks.get(dom) if dom else None, "bound": "launch / latency (mini-batch steps)",
+                       "note": "a batch is ~70 kernels of tens of microseconds; no single kernel's roofline describes the epoch"}
+    if ref_batch_epochs:
+        dt_r, _ = steady(ref_batch, 2)
+        out["reference_batch"] = {"batch": ref_batch, "ms": round(dt_r * 1e3, 1), "value": n_cells / dt_r, "ms_per_step": round(dt_r * 1e3 / -(-n_cells // ref_batch), 4),
+                                  "note": "the reference's default batch size: one captured hipGraph per step (dance_amd/capture.py)"}
+    # CPU: the restated loop at the reference's batch size on a sample graph of the same generator
+    small = _cellgene_graph(cpu_cells, n_genes, per, dfeat, dev, seed=1)
+    rowptr, col, val = small.rowptr.cpu().numpy().astype(np.int64), small.col.cpu().numpy().astype(np.int64), small.val.cpu().numpy()
+    feats = small.ndata["features"].cpu()
+    torch.manual_seed(0)
+    ref = om.GraphSCAE(dfeat, 200, (300, ), decoder_dropout=0.1, dropout=0.1)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-5)
+    seeds_all = np.random.default_rng(0).permutation(cpu_cells) + n_genes
+    state = {"i": 0}
+
+    def cpu_batch():
+        i = state["i"]
+        om.graphsc_batch(ref, opt, rowptr, col, val, feats, seeds_all[i:i + ref_batch])
+        state["i"] = (i + ref_batch) % (cpu_cells - ref_batch)
+    med, it = _cpu_time(cpu_batch, min_seconds=5.0, max_iters=40)
+    out["cpu_baseline"] = {"value": ref_batch / med, "unit": "cells/s per epoch", "cores": torch.get_num_threads(), "kind": "port",
+                           "sample": f"graph of {cpu_cells} cells from the same generator, batches of {ref_batch} (the reference default), oracle.models.graphsc_batch "
+                                     f"(restated block + GCNAE + loss, pinned to every per-batch loss of the reference's own fit: tests/test_oracle_models.py; "
+                                     f"DGL not installable), median of {it} batches ({med * 1e3:.1f} ms each)"}
+    return out
+
+
 # ---- config 5: SpaGCN DEC iteration at 500k spots ---------------------------------------------------------------------------------
 def _spatial_graph(n, k, dev, seed=5):
     from dance_amd import kernels
@@ -370,6 +425,7 @@ def run_all(dev, which=None):
              ("c2_scdsc_epoch_100k", scdsc_100k),
              ("c2_scdsc_epoch_1M", scdsc_1m),
              ("c3_scdeepsort_1M_bf16_epoch", lambda: c3_scdeepsort_epoch(dev)),
+             ("c4_graphsc_1M_epoch_1gpu", lambda: c4_graphsc_epoch(dev)),
              ("c5_spagcn_500k_iter", lambda: c5_spagcn_iter(dev))]
     out = {}
     for name, fn in table:

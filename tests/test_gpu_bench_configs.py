@@ -24,6 +24,7 @@ def test_config_rows_at_toy_sizes(cuda_device, monkeypatch):
     row = bc.c3_scdeepsort_epoch(cuda_device, n_cells=20_000, batch=4096, cpu_cells=2_000)
     _check(row)
     assert row["fp32"]["ms"] > 0
+    _check(bc.c4_graphsc_epoch(cuda_device, n_cells=20_000, batch=4096, cpu_cells=2_000, ref_batch_epochs=False))
     monkeypatch.setattr(bc, "c2_gcn_100k", bc.c2_gcn_100k)  # (the 100k layer row runs at its real size: 4 ms a step)
     _check(bc.c2_gcn_100k(cuda_device, steps=3))
     assert bench.N_CELLS == 1_000_000  # the configs block only rides on the full-size headline run

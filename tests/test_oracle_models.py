@@ -110,3 +110,40 @@ def test_scdeepsort_port_reproduces_the_reference_fit_first_epoch():
         loss = om.scdeepsort_batch(model, opt, rowptr, col, val, feats, cell_id, full_labels, seeds)
         tot, size = tot + loss * len(seeds), size + len(seeds)
     assert abs(tot / size - gold["mb_losses"][0]) < 2e-4 * gold["mb_losses"][0]
+
+
+def test_graphsc_port_reproduces_the_reference_fit_losses():
+    """The graph-sc port (block, WeightedGraphConv + Linear + inner-product decoder, the weighted BCE against the block's dst x dst
+    adjacency, Adam) driven with the golden's loader order reproduces EVERY per-batch loss of the reference's own ``GraphSC.fit``
+    (graphsc.npz, cases "mb": 3 epochs x 3 batches of 16, and "mean") and ends at the same weights."""
+    gold = np.load(os.path.join(GOLDEN, "graphsc.npz"))
+    kw = json.loads(str(gold["gsc_kw"]))
+    x = gold["gsc_x"]
+    n_cells, n_genes = x.shape
+    e = og.cell_feature_graph(x, normalize_edges=False)
+    order = np.argsort(e["dst"], kind="stable")
+    n_nodes = n_genes + n_cells
+    rowptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    rowptr[1:] = np.cumsum(np.bincount(e["dst"], minlength=n_nodes))
+    col, val = e["src"][order], e["weight"][order].astype(np.float32)
+    feats = torch.from_numpy(np.vstack((gold["gsc_gene_feat"], gold["gsc_cell_feat"])).astype(np.float32))
+    for tag, batch, agg in (("mb", 16, "sum"), ("mean", 16, "mean")):
+        model = om.GraphSCAE(kw["in_feats"], kw["hidden_dim"], (kw["hidden_1"], ), agg=agg, decoder_dropout=0.0)
+        model.load_state_dict({k.split("::", 1)[1]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(f"gsc_{tag}_sd0::")})
+        opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+        gen = torch.Generator().manual_seed(123)
+        train_ids = torch.arange(n_genes, n_nodes)
+        losses, z = [], None
+        for _ in range(3):
+            ids = train_ids[torch.randperm(train_ids.numel(), generator=gen)]
+            embs = []
+            for i in range(0, ids.numel(), batch):
+                loss, emb = om.graphsc_batch(model, opt, rowptr, col, val, feats, ids[i:i + batch].numpy())
+                losses.append(loss)
+                embs.append(emb)
+            z = torch.cat(embs)[torch.argsort(ids)]   # graphsc.py:222-228: the epoch's embeddings in node order
+        ref = gold[f"gsc_{tag}_losses"]
+        assert len(losses) == len(ref) and np.allclose(losses, ref, rtol=2e-5, atol=0), (tag, losses, ref)
+        assert np.allclose(z.numpy(), gold[f"gsc_{tag}_z"], rtol=1e-4, atol=1e-5)
+        for k, v in model.state_dict().items():
+            assert np.allclose(v.numpy(), gold[f"gsc_{tag}_sd1::{k}"], rtol=1e-4, atol=1e-6), (tag, k)
