@@ -331,12 +331,20 @@ __global__ __launch_bounds__(STF_ROWS) void student_t_backward_fast_kernel(int64
   const int64_t row0 = (int64_t)blockIdx.x * STF_ROWS;
   const int rows_here = (int)min((int64_t)STF_ROWS, n - row0);
   stf_stage<CP>(muT, zt, n, c, d, Z, ldz, MU, row0);
+  {
+    float gv[CP];  // CP loads per lane, ALL issued before the first LDS store (written as one loop the compiler waited after every load)
 #pragma unroll
-  for (int k = 0; k < CP; ++k) {  // CP loads per lane, all in flight
-    const int i = threadIdx.x + STF_ROWS * k;
-    const int r = i / CP, j = i - r * CP;
-    const float v = G[min(row0 + r, n - 1) * ldg + min(j, c - 1)];
-    gt[r * cs + j] = (row0 + r < n && j < c) ? v : 0.f;
+    for (int k = 0; k < CP; ++k) {
+      const int i = threadIdx.x + STF_ROWS * k;
+      const int r = i / CP, j = i - r * CP;
+      gv[k] = G[min(row0 + r, n - 1) * ldg + min(j, c - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < CP; ++k) {
+      const int i = threadIdx.x + STF_ROWS * k;
+      const int r = i / CP, j = i - r * CP;
+      gt[r * cs + j] = (row0 + r < n && j < c) ? gv[k] : 0.f;
+    }
   }
   __syncthreads();
   // per row: the coefficients c_j (registers, and the row's slot of gt) — a row past n has G = 0, hence c_j = 0: no special case

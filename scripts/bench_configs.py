@@ -221,12 +221,12 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
             steady = None
             if cd == "bf16":  # the steady-state epoch, as configs 2 and 5 measure theirs: fit(4) - fit(1) over 3 (a fit call has fixed costs)
                 tt = {}
-                for e in (1, 4):
+                for e in (1, 4, 1, 4):  # best of two each: a fit call writes a checkpoint whenever validation accuracy improves (~2 ms)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     m.fit(cg, labels, epochs=e, lr=1e-3, val_ratio=0.2)
                     torch.cuda.synchronize()
-                    tt[e] = time.perf_counter() - t0
+                    tt[e] = min(tt.get(e, 1e9), time.perf_counter() - t0)
                 steady = (tt[4] - tt[1]) / 3
             best = None
             for _ in range(2):  # best of two: a fit call also writes a checkpoint
