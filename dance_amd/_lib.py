@@ -127,6 +127,8 @@ def _declare(lib):
         "dh_gcn_narrow_backward_f32": (c_int, [i64, i64, i64, P, P, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_zinb_nll_forward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P]),
         "dh_zinb_nll_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P, P, P, i64, P]),
+        "dh_gemm_f32_small_supported": (c_int, [i64, i64, i64]),
+        "dh_gemm_f32_small": (c_int, [i64, i64, i64, c_int, c_int, P, i64, P, i64, P, i64, P, c_int, P]),
         "dh_softmax_xent_sum_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_softmax_xent_sum_f32": (c_int, [i64, i64, P, i64, P, i64, P, P, i64, P, c_size_t, P]),
         "dh_zinb_nll_logits_forward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P]),

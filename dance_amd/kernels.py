@@ -260,6 +260,7 @@ def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
 # bit-exact k-ordered fmaf chain).  Set with DANCE_AMD_GEMM or per call.
 GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "exact")
 GEMM_TILE_AUTO, GEMM_TILE_256, GEMM_TILE_128 = 0, 1, 2
+GEMM_SMALL = os.environ.get("DANCE_AMD_GEMM_SMALL", "1") != "0"  # small products on dh_gemm_f32_small (A/B switch)
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
@@ -283,6 +284,11 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
             raise ValueError("gemm: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
+    if mode == "exact" and GEMM_SMALL and not accumulate and tile == GEMM_TILE_AUTO and K <= 512 and M * N <= (1 << 20) and M > 0 and N > 0:
+        # the mini-batch steps' launch-bound products: one round trip per 32 x 32 tile instead of a K walk (dh_gemm_f32_small)
+        _call(tag, lib.dh_gemm_f32_small, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A), _dev(B, torch.float32, "B", 2),
+              _ld(B), _dev(out, torch.float32, "out", 2), _ld(out), _dev(bias, torch.float32, "bias", 1), int(act), _stream())
+        return out
     if bias is not None or act != ACT_NONE:
         if accumulate or tile != GEMM_TILE_AUTO:
             raise ValueError("gemm: bias / act go with a plain product (no accumulate, automatic tile)")

@@ -176,6 +176,14 @@ DH_API int dh_gemm_f32_bias_act(int64_t M, int64_t N, int64_t K, int trans_a, in
                          const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act,
                          void* workspace, size_t workspace_bytes, dh_stream_t stream);
 
+/* The same product (no accumulate) for the launch-bound shapes of a mini-batch step — K <= 512 and M N <= 2^20
+ * (dh_gemm_f32_small_supported): graph-sc's WeightedGraphConv / Linear on a block of 128 cells (graphsc.py:452-467, :352-363) and
+ * scDeepSort's classifier on a batch of 500 (scdeepsort.py:80-88).  32 x 32 tiles, the whole K extent fetched in one round trip, no
+ * workspace.  Exact fp32 matrix-core arithmetic like dh_gemm_f32, in another summation order (results agree to rounding).          */
+DH_API int dh_gemm_f32_small_supported(int64_t M, int64_t N, int64_t K);
+DH_API int dh_gemm_f32_small(int64_t M, int64_t N, int64_t K, int trans_a, int trans_b, const float* A, int64_t lda,
+                      const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int act, dh_stream_t stream);
+
 /* Same contract as dh_gemm_f32 (operands, result and accumulation in fp32), computed on the bf16 matrix cores: each fp32
  * operand is split exactly into three bf16 terms and six of the nine partial products are accumulated in fp32 (the dropped
  * ones are <= 2^-23 of a product; csrc/gemm_f32x3.hip) — fp32-level accuracy at 6/16 of the fp32 matrix-pipe time.

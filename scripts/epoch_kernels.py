@@ -49,6 +49,20 @@ def run_scdeepsort(epochs, n_cells=1_000_000, batch=65536):
         torch.cuda.synchronize()
 
 
+def run_graphsc(epochs, n_cells=100_000, batch=128):
+    import torch
+    from bench_configs import _cellgene_graph
+
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    dev = torch.device("cuda", 0)
+    cg = _cellgene_graph(n_cells, 2000, 200, 50, dev)
+    torch.manual_seed(0)
+    gs = GraphSC(in_feats=50, n_clusters=10, device="cuda")
+    gs.fit(cg, epochs=1, batch_size=batch)
+    gs.fit(cg, epochs=epochs, batch_size=batch)
+    torch.cuda.synchronize()
+
+
 def diff(a, b, units):
     def load(p):
         return {r["Name"]: (int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(p))}
@@ -68,6 +82,6 @@ def diff(a, b, units):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        {"scdsc": run, "scdeepsort": run_scdeepsort}[sys.argv[2]](int(sys.argv[3]))
+        {"scdsc": run, "scdeepsort": run_scdeepsort, "graphsc": run_graphsc}[sys.argv[2]](int(sys.argv[3]))
     else:
         diff(sys.argv[2], sys.argv[3], float(sys.argv[4]))

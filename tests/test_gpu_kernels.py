@@ -405,3 +405,32 @@ def test_softmax_xent_sum_matches_torch(cuda_device, n, c):
     xs[:, :c] = x.detach()
     l4, d4 = kernels.softmax_xent_sum(xs[:, :c], y)
     assert torch.equal(l4, l2) and torch.equal(d4, d2)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 300, 200), (2128, 200, 50), (128, 200, 300), (300, 200, 128), (1, 1, 1), (33, 65, 257), (500, 16, 200), (1000, 1000, 512),
+                                   (31, 97, 64), (64, 64, 129)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False), (True, True)])
+def test_gemm_f32_small_vs_float64_and_the_large_kernel(cuda_device, M, N, K, ta, tb):
+    """dh_gemm_f32_small (the mini-batch steps' products: 32 x 32 tiles, whole K in one round trip) against float64 and against
+    dh_gemm_f32 on the same operands, every transposition, ragged edges, strided rows, bias + ReLU in the store."""
+    from dance_amd import kernels
+    assert kernels.GEMM_SMALL
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    abuf = torch.full((a.shape[0], a.shape[1] + 3), float("nan"))
+    abuf[:, :a.shape[1]] = a
+    ad, bd = abuf.to(cuda_device)[:, :a.shape[1]], b.to(cuda_device)
+    bias = torch.randn(N, generator=g).to(cuda_device)
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    out = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)
+    assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6
+    out_b = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb, bias=bias, act=kernels.ACT_RELU)
+    assert rel_err(out_b.cpu().numpy(), torch.relu(ref + bias.cpu().double()).numpy()) < 2e-6
+    assert torch.equal(out, kernels.gemm(ad, bd, trans_a=ta, trans_b=tb))  # deterministic
+    kernels.GEMM_SMALL = False
+    try:
+        big = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)
+    finally:
+        kernels.GEMM_SMALL = True
+    assert rel_err(out.cpu().numpy(), big.cpu().numpy()) < 2e-6
