@@ -121,7 +121,8 @@ extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int6
   if (!workspace || workspace_bytes < need)
     return dh::fail(DH_ERR_WORKSPACE, "dh_colsum_f32: workspace %zu < %zu bytes", workspace_bytes, need);
   const int64_t nb = dh::ceil_div(n_rows, kColsumRows);
-  float* partial = static_cast<float*>(workspace);
+  // one row block (a mini-batch: <= 2048 rows): its "partial" sums are the result — written straight to out, no second launch
+  float* partial = nb == 1 ? out : static_cast<float*>(workspace);
   if (width > 32) {
     dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 64));
     hipLaunchKernelGGL(colsum_partial_kernel<64>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
@@ -132,7 +133,7 @@ extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int6
     dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 16));
     hipLaunchKernelGGL(colsum_partial_kernel<16>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
   }
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
+  if (nb > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
   return dh::check_launch("dh_colsum_f32");
 }
 

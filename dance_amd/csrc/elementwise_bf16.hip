@@ -147,11 +147,11 @@ extern "C" int dh_colsum_bf16(int64_t n_rows, int64_t width, const uint16_t* X, 
   const int64_t nb = dh::ceil_div(n_rows, kColsumRows);
   const size_t need = (size_t)nb * (size_t)width * sizeof(float);  // == dh_colsum_f32_workspace_bytes(n_rows, width)
   if (!workspace || workspace_bytes < need) return dh::fail(DH_ERR_WORKSPACE, "dh_colsum_bf16: workspace %zu < %zu bytes", workspace_bytes, need);
-  float* partial = static_cast<float*>(workspace);
+  float* partial = nb == 1 ? out : static_cast<float*>(workspace);  // one row block: its sums are the result (no second launch)
   if (width % 8 == 0 && ldx % 8 == 0 && dh::aligned16(X))
     hipLaunchKernelGGL(colsum_bf16_partial_vec_kernel, dim3((unsigned)nb, (unsigned)dh::ceil_div(width, 64)), dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
   else if (width > 32) hipLaunchKernelGGL(colsum_bf16_partial_kernel<64>, dim3((unsigned)nb, (unsigned)dh::ceil_div(width, 64)), dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
   else hipLaunchKernelGGL(colsum_bf16_partial_kernel<16>, dim3((unsigned)nb, (unsigned)dh::ceil_div(width, 16)), dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
-  hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
+  if (nb > 1) hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
   return dh::check_launch("dh_colsum_bf16");
 }
