@@ -228,6 +228,8 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
                     torch.cuda.synchronize()
                     tt[e] = min(tt.get(e, 1e9), time.perf_counter() - t0)
                 steady = (tt[4] - tt[1]) / 3
+                if steady <= 0:  # toy sizes: the call's fixed costs (and their jitter) exceed three epochs; an upper bound then
+                    steady = tt[4] / 4
             best = None
             for _ in range(2):  # best of two: a fit call also writes a checkpoint
                 torch.cuda.synchronize()
