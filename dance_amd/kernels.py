@@ -261,6 +261,24 @@ def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
 GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "exact")
 GEMM_TILE_AUTO, GEMM_TILE_256, GEMM_TILE_128 = 0, 1, 2
 GEMM_SMALL = os.environ.get("DANCE_AMD_GEMM_SMALL", "1") != "0"  # small products on dh_gemm_f32_small (A/B switch)
+_mini_batch_depth = 0
+
+
+class mini_batch_products:
+    """``with kernels.mini_batch_products():`` — inside, fp32 products with K <= 512 and M N <= 2^20 run on dh_gemm_f32_small (one round
+    trip per 32 x 32 tile).  Opt-in by the mini-batch training loops (GraphSC.fit, ScDeepSort.fit) and NOT the default: the small kernel
+    sums in another order than dh_gemm_f32, and the full-batch layers promise that a row's result does not depend on how many rows the
+    call holds (a rank's rows of a sharded layer are bit-identical to the single-GPU layer's, tests/test_gpu_sharded_one_gpu.py)."""
+
+    def __enter__(self):
+        global _mini_batch_depth
+        _mini_batch_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _mini_batch_depth
+        _mini_batch_depth -= 1
+        return False
 
 
 def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False,
@@ -284,7 +302,8 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
             raise ValueError("gemm: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
-    if mode == "exact" and GEMM_SMALL and not accumulate and tile == GEMM_TILE_AUTO and K <= 512 and M * N <= (1 << 20) and M > 0 and N > 0:
+    if (mode == "exact" and GEMM_SMALL and _mini_batch_depth > 0 and not accumulate and tile == GEMM_TILE_AUTO and 1 <= K <= 512
+            and M * N <= (1 << 20) and M > 0 and N > 0):
         # the mini-batch steps' launch-bound products: one round trip per 32 x 32 tile instead of a K walk (dh_gemm_f32_small)
         _call(tag, lib.dh_gemm_f32_small, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A), _dev(B, torch.float32, "B", 2),
               _ld(B), _dev(out, torch.float32, "out", 2), _ld(out), _dev(bias, torch.float32, "bias", 1), int(act), _stream())

@@ -117,6 +117,10 @@ class ScDeepSort(BaseClassificationMethod):
 
     def fit(self, graph, labels: torch.Tensor, epochs: int = 300, lr: float = 1e-3, weight_decay: float = 0,
             val_ratio: float = 0.2):
+        with kernels.mini_batch_products():  # the step's small fp32 products on dh_gemm_f32_small (a captured step records them so)
+            return self._fit(graph, labels, epochs, lr, weight_decay, val_ratio)
+
+    def _fit(self, graph, labels, epochs, lr, weight_decay, val_ratio):
         gene_mask = graph.ndata["cell_id"] != -1
         cell_mask = graph.ndata["cell_id"] == -1
         num_genes = int(gene_mask.sum())

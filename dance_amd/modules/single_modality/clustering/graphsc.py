@@ -453,6 +453,10 @@ class GraphSC(BaseClusteringMethod):
 
     def fit(self, g, y: Optional[Any] = None, *, epochs: int = 100, lr: float = 1e-5, batch_size: int = 128,
             show_epoch_ari: bool = False, eval_epoch: bool = False):
+        with kernels.mini_batch_products():  # the step's small fp32 products on dh_gemm_f32_small (a captured step records them so)
+            return self._fit(g, y, epochs=epochs, lr=lr, batch_size=batch_size, show_epoch_ari=show_epoch_ari, eval_epoch=eval_epoch)
+
+    def _fit(self, g, y, *, epochs, lr, batch_size, show_epoch_ari, eval_epoch):
         g = g.to(self.device)
         g.ndata["order"] = g.ndata["label"] = g.ndata["feat_id"]
         train_ids = np.where(g.ndata["label"].cpu().numpy() != -1)[0]

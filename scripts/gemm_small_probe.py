@@ -1,5 +1,5 @@
 """GPU probe: the products of a graph-sc step at the reference's batch size (128 cells + 2000 genes: block of 2128 source rows) and of a
-scDeepSort step at batch 500, through dh_gemm_f32_small and through the large-tile kernel (kernels.GEMM_SMALL toggled)."""
+scDeepSort step at batch 500, through dh_gemm_f32_small (inside kernels.mini_batch_products()) and through the large-tile kernel."""
 import os
 import sys
 
@@ -23,10 +23,9 @@ def main():
         a = torch.randn((K, M) if ta else (M, K), device=dev, generator=gen)
         b = torch.randn((N, K) if tb else (K, N), device=dev, generator=gen)
         res = {}
-        for small in (True, False):
-            kernels.GEMM_SMALL = small
-            res[small] = gpu_ms(lambda: kernels.gemm(a, b, trans_a=ta, trans_b=tb), iters=200, warm=20) * 1e3
-        kernels.GEMM_SMALL = True
+        with kernels.mini_batch_products():
+            res[True] = gpu_ms(lambda: kernels.gemm(a, b, trans_a=ta, trans_b=tb), iters=200, warm=20) * 1e3
+        res[False] = gpu_ms(lambda: kernels.gemm(a, b, trans_a=ta, trans_b=tb), iters=200, warm=20) * 1e3
         print(f"{name:34s} {M:5d} x {N:5d} x {K:4d}: small {res[True]:6.1f} us   large-tile {res[False]:6.1f} us   (back-to-back launches, eager)", flush=True)
 
 

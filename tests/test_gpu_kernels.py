@@ -423,14 +423,13 @@ def test_gemm_f32_small_vs_float64_and_the_large_kernel(cuda_device, M, N, K, ta
     ad, bd = abuf.to(cuda_device)[:, :a.shape[1]], b.to(cuda_device)
     bias = torch.randn(N, generator=g).to(cuda_device)
     ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
-    out = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)
+    with kernels.KernelTimer() as tm, kernels.mini_batch_products():
+        out = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)
+        out_b = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb, bias=bias, act=kernels.ACT_RELU)
+        again = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)
     assert rel_err(out.cpu().numpy(), ref.numpy()) < 2e-6
-    out_b = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb, bias=bias, act=kernels.ACT_RELU)
     assert rel_err(out_b.cpu().numpy(), torch.relu(ref + bias.cpu().double()).numpy()) < 2e-6
-    assert torch.equal(out, kernels.gemm(ad, bd, trans_a=ta, trans_b=tb))  # deterministic
-    kernels.GEMM_SMALL = False
-    try:
-        big = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)
-    finally:
-        kernels.GEMM_SMALL = True
+    assert torch.equal(out, again)  # deterministic
+    big = kernels.gemm(ad, bd, trans_a=ta, trans_b=tb)  # outside the context: the large-tile kernel, whatever the shape
     assert rel_err(out.cpu().numpy(), big.cpu().numpy()) < 2e-6
+    assert len(tm.summary()) == 1
