@@ -111,3 +111,27 @@ def test_library_never_records_memset_nodes():
             if re.search(r"\bhipMemsetAsync\s*\(|\bhipMemset2DAsync\s*\(|\bhipMemcpyAsync\s*\(|\bhipMemset\s*\(", code):
                 bad.append(f"{os.path.basename(path)}:{i}")
     assert not bad, bad
+
+
+def test_small_gemm_is_opt_in_and_scoped():
+    """dh_gemm_f32_small sums in another order than dh_gemm_f32, so ``kernels.gemm`` takes it only inside
+    ``kernels.mini_batch_products()`` (entered by GraphSC.fit / ScDeepSort.fit): the full-batch layers keep row results that do not
+    depend on the row count of the call.  The context nests and always restores."""
+    from dance_amd import kernels
+    assert kernels._mini_batch_depth == 0
+    with kernels.mini_batch_products():
+        assert kernels._mini_batch_depth == 1
+        try:
+            with kernels.mini_batch_products():
+                assert kernels._mini_batch_depth == 2
+                raise RuntimeError("leave by exception")
+        except RuntimeError:
+            pass
+        assert kernels._mini_batch_depth == 1
+    assert kernels._mini_batch_depth == 0
+    import inspect
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSC
+    assert "mini_batch_products" in inspect.getsource(GraphSC.fit) and "mini_batch_products" in inspect.getsource(ScDeepSort.fit)
+    assert "mini_batch_products" not in inspect.getsource(ScDSC.fit)   # full batch, shardable: stays on dh_gemm_f32
