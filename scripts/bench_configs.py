@@ -225,15 +225,15 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
             steady = None
             if cd == "bf16":  # the steady-state epoch, as configs 2 and 5 measure theirs: fit(4) - fit(1) over 3 (a fit call has fixed costs)
                 tt = {}
-                for e in (1, 4, 1, 4):  # best of two each: a fit call writes a checkpoint whenever validation accuracy improves (~2 ms)
+                for e in (1, 7, 1, 7):  # best of two each: a fit call writes a checkpoint whenever validation accuracy improves (~2 ms)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     m.fit(cg, labels, epochs=e, lr=1e-3, val_ratio=0.2)
                     torch.cuda.synchronize()
                     tt[e] = min(tt.get(e, 1e9), time.perf_counter() - t0)
-                steady = (tt[4] - tt[1]) / 3
-                if steady <= 0:  # toy sizes: the call's fixed costs (and their jitter) exceed three epochs; an upper bound then
-                    steady = tt[4] / 4
+                steady = (tt[7] - tt[1]) / 6
+                if steady <= 0:  # toy sizes: the call's fixed costs (and their jitter) exceed six epochs; an upper bound then
+                    steady = tt[7] / 7
             best = None
             for _ in range(2):  # best of two: a fit call also writes a checkpoint
                 torch.cuda.synchronize()
@@ -273,7 +273,7 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000):
     return {"workload": f"ScDeepSort.fit, one epoch = training pass (80 % of the cells, batch {batch}) + the reference's two evaluation passes, "
                         f"{n_cells} cells x {n_genes} genes at 10 % density (nnz {n_cells * per}), D = {dfeat} -> {hid}, bf16 storage + bf16 MFMA dense update",
             "ms": round(out["steady"] * 1e3, 2), "value": n_cells / out["steady"], "unit": "cells/s per epoch",
-            "ms_basis": "steady-state epoch = (fit(4 epochs) - fit(1 epoch)) / 3, like configs 2 and 5; fit_call_1_epoch_ms is a whole one-epoch fit call "
+            "ms_basis": "steady-state epoch = (fit(7 epochs) - fit(1 epoch)) / 6, best of two calls each, like configs 2 and 5; fit_call_1_epoch_ms is a whole one-epoch fit call "
                         "(model construction, split, checkpoint included: the number rounds 3-4 quoted), kernels_ms belongs to that call",
             "fit_call_1_epoch_ms": round(dt * 1e3, 2), "kernels_ms": ks, "roofline": roof,
             "fp32": {"ms": round(out["fp32"][0] * 1e3, 2), "kernels_ms": out["fp32"][1]},
@@ -290,20 +290,22 @@ def c4_graphsc_epoch(dev, n_cells=1_000_000, batch=8192, ref_batch=128, cpu_cell
     n_genes, per, dfeat = 2000, 200, 50
     cg = _cellgene_graph(n_cells, n_genes, per, dfeat, dev)
 
-    def steady(bsz, e2):
+    def steady(bsz, e2, reps=1):
         torch.manual_seed(0)
         gs = GraphSC(in_feats=dfeat, n_clusters=10, device="cuda")
         gs.fit(cg, epochs=1, batch_size=bsz)  # warm-up (allocator, capture below batch 2048)
         res = {}
-        for e in (1, e2):
+        for e in (1, e2) * reps:  # best of `reps` calls each
             torch.cuda.synchronize()
             with kernels.KernelTimer() as timer:
                 t0 = time.perf_counter()
                 gs.fit(cg, epochs=e, batch_size=bsz)
                 torch.cuda.synchronize()
-                res[e] = (time.perf_counter() - t0, _kernel_totals(timer))
+                dt_ = time.perf_counter() - t0
+            if e not in res or dt_ < res[e][0]:
+                res[e] = (dt_, _kernel_totals(timer))
         return (res[e2][0] - res[1][0]) / (e2 - 1), _per_unit(res[e2][1], res[1][1], e2 - 1)
-    dt, ks = steady(batch, 3)
+    dt, ks = steady(batch, 3, reps=2)
     out = {"workload": f"GraphSC.fit (graph-sc GAE: WeightedGraphConv {dfeat} -> 200, Linear 200 -> 300, inner-product decoder, weighted BCE on the block's "
                        f"dst x dst adjacency, two forwards per batch as graphsc.py:202,215 writes it), one epoch over {n_cells} cells x {n_genes} genes at 10 % "
                        f"density, batch {batch}, fp32, ONE GPU (BASELINE's config shards it over 8); steady-state epoch = (fit(3) - fit(1)) / 2",
