@@ -250,7 +250,7 @@ class SimpleGCDEC(nn.Module):
         optimiser is created before ``mu`` receives its values but — unlike ``fit`` — over an existing ``mu`` parameter when
         the model has one, exactly as ``self.parameters()`` yields it there."""
         self.to(self.device)
-        X = _to_device_f32(X, self.device)
+        X = _embed_rows_aligned(_to_device_f32(X, self.device))  # as in fit: whole 256-byte rows for the fused narrow layer's gathers
         adj = self._adj(adj)
         if opt == "sgd":
             optimizer = optim.SGD(self.parameters(), lr=lr, momentum=0.9)
@@ -318,7 +318,7 @@ class GC_DEC(SimpleGCDEC):
         """:622-670: initial clustering of the embedding (k-means with ``n_clusters`` centres, or the community detection), centres =
         group means, then the DEC loop without early stopping, the prediction of every epoch kept in ``trajectory``."""
         self.to(self.device)
-        X, adj = _to_device_f32(X, self.device), self._adj(adj)
+        X, adj = _embed_rows_aligned(_to_device_f32(X, self.device)), self._adj(adj)
         self.trajectory = []
         optimizer = self._optimizer(opt, lr, weight_decay)
         with torch.no_grad():
@@ -361,7 +361,7 @@ class GC_DEC(SimpleGCDEC):
     def fit_with_init(self, X, adj, init_y, lr=0.001, epochs=10, update_interval=1, weight_decay=5e-4, opt="sgd"):
         """:672-697."""
         self.to(self.device)
-        X, adj = _to_device_f32(X, self.device), self._adj(adj)
+        X, adj = _embed_rows_aligned(_to_device_f32(X, self.device)), self._adj(adj)
         optimizer = self._optimizer(opt, lr, weight_decay)
         with torch.no_grad():
             features = self.gc(X, adj)
