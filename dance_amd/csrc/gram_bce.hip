@@ -264,41 +264,64 @@ __global__ __launch_bounds__(256) void gram_listed_forward_kernel(int64_t n_list
 }
 
 // backward: dZ[i, :] = 2 s O[i, :] + s sum_e c_e ([us[e] == i] z[vs[e], :] + [vs[e] == i] z[us[e], :]),  s = scale[0],
-// c_e = p (sigmoid(xe) - 1) - sigmoid(xe).  One workgroup per row i, one column per thread; every wavefront scans the entry list
-// 64 at a time (coalesced), ballots the entries that touch row i and applies them in list order: fixed summation order, no
-// atomics, no sort.
+// c_e = p (sigmoid(xe) - 1) - sigmoid(xe).  One workgroup per row i, one column per thread.  The entry list is walked in segments
+// of 5 x 256 entries: every wavefront scans ITS 256 entries of the segment (four coalesced loads in flight), ballots the entries
+// that touch row i into its own LDS list in lane order, and after a barrier all threads apply the five lists in wave order — list
+// order, as before: fixed summation order, no atomics, no sort, bit-identical to the first form.  (In that form every one of the
+// five wavefronts scanned the WHOLE list with one load in flight: n x n_listed x 5 pair reads — 2.7 GB of L2 traffic and 0.2 ms per
+// call at a batch of 8192 cells, 25 of graph-sc's 250 ms epoch.)
+constexpr int GL_WAVES = 5, GL_U = 4, GL_SEG = GL_WAVES * 64 * GL_U;
 __global__ __launch_bounds__(320) void gram_listed_backward_kernel(int d, int64_t n_listed, const float* __restrict__ Z, int64_t ldz,
                                                                   const float* __restrict__ O, int64_t ldo, const int32_t* __restrict__ us,
                                                                   const int32_t* __restrict__ vs, const float* __restrict__ xe, float p,
                                                                   const float* __restrict__ scale, float* __restrict__ dZ, int64_t ldd) {
+  __shared__ int hu[GL_WAVES][64 * GL_U], hv[GL_WAVES][64 * GL_U];
+  __shared__ float hc[GL_WAVES][64 * GL_U];
+  __shared__ int hn[GL_WAVES];
   const int i = blockIdx.x;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = threadIdx.x;  // column owned by this thread (threads beyond d only help scanning)
   const float s = scale[0];
   float acc = c < d ? 2.f * O[(int64_t)i * ldo + c] : 0.f;
-  for (int64_t base = 0; base < n_listed; base += 64) {
-    const int64_t e = base + lane;
-    int u = -1, v = -1;
-    float x = 0.f;
-    if (e < n_listed) {
-      u = us[e];
-      v = vs[e];
+  for (int64_t seg = 0; seg < n_listed; seg += GL_SEG) {
+    int u[GL_U], v[GL_U];
+#pragma unroll
+    for (int q = 0; q < GL_U; ++q) {  // clamped addresses: the loads are not behind a branch, all four are in flight
+      const int64_t e = seg + (int64_t)wave * (64 * GL_U) + q * 64 + lane;
+      const int64_t ec = e < n_listed ? e : n_listed - 1;
+      u[q] = us[ec];
+      v[q] = vs[ec];
+      if (e >= n_listed) u[q] = v[q] = -1;
     }
-    const bool hit = (u == i) || (v == i);
-    if (hit) x = xe[e];
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      const int l = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int uu = __shfl(u, l, 64), vv = __shfl(v, l, 64);
-      const float xx = __shfl(x, l, 64);
-      const float sg = 1.f / (1.f + expf(-xx));
-      const float ce = p * (sg - 1.f) - sg;
-      if (c < d) {
-        if (uu == i) acc = fmaf(ce, Z[(int64_t)vv * ldz + c], acc);
-        if (vv == i) acc = fmaf(ce, Z[(int64_t)uu * ldz + c], acc);
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < GL_U; ++q) {
+      const bool hit = (u[q] == i) || (v[q] == i);
+      const unsigned long long m = __ballot(hit);
+      if (hit) {
+        const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+        const float xx = xe[seg + (int64_t)wave * (64 * GL_U) + q * 64 + lane];
+        const float sg = 1.f / (1.f + expf(-xx));
+        hu[wave][pos] = u[q];
+        hv[wave][pos] = v[q];
+        hc[wave][pos] = p * (sg - 1.f) - sg;
+      }
+      cnt += __popcll(m);
+    }
+    if (lane == 0) hn[wave] = cnt;
+    __syncthreads();
+    if (c < d) {
+      for (int w = 0; w < GL_WAVES; ++w) {
+        const int nh = hn[w];
+        for (int k = 0; k < nh; ++k) {
+          const int uu = hu[w][k], vv = hv[w][k];
+          const float ce = hc[w][k];
+          if (uu == i) acc = fmaf(ce, Z[(int64_t)vv * ldz + c], acc);
+          if (vv == i) acc = fmaf(ce, Z[(int64_t)uu * ldz + c], acc);
+        }
       }
     }
+    __syncthreads();
   }
   if (c < d) dZ[(int64_t)i * ldd + c] = s * acc;
 }

@@ -332,8 +332,8 @@ if DECODER_MODE not in ("fused", "dense"):
 # host-bound (1.36 ms / batch eager, profiles/r03e_ref_batch_epochs.json).  DANCE_AMD_HIPGRAPH=0 keeps the eager loop; the last,
 # short batch of an epoch always runs eagerly.
 HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
-HIPGRAPH_MIN_BATCHES = 64  # capturing costs two eager steps + the instantiation (tens of ms): it must be amortised
-HIPGRAPH_MAX_BATCH = 2048   # above this a step is kernel-bound and replaying it gains nothing (measured at 8192: 4.2 vs 4.2 ms)
+HIPGRAPH_MIN_BATCHES = int(os.environ.get("DANCE_AMD_HIPGRAPH_MIN_BATCHES", "64"))  # capturing costs two eager steps + the instantiation (tens of ms): it must be amortised
+HIPGRAPH_MAX_BATCH = int(os.environ.get("DANCE_AMD_HIPGRAPH_MAX_BATCH", "2048"))   # above this a step is kernel-bound and replaying it gains little
 
 
 class _CapturedStep:
