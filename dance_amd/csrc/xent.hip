@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void xent_kernel(int64_t n, int c, const float
       for (int j = g; j < c; j += G) d[j] = live ? __expf(x[j] - m) * rs - (j == y ? 1.f : 0.f) : 0.f;
     }
   }
-  // the row's loss: m + log s - x[y]  (a label outside [0, c) that is not ignore_index is the caller's error: flagged by the host wrapper's check)
+  // the row's loss: m + log s - x[y].  A label outside [0, c) that is not ignore_index is the caller's error (torch raises a device
+  // assertion for it); here it is clamped into range rather than read out of bounds, and its row contributes like class 0 / c - 1
   float li = 0.f;
   if (g == 0 && live) li = m + __logf(s) - x[min(max(y, (int64_t)0), (int64_t)c - 1)];
   if (g == 0) red[rl] = li;
