@@ -484,3 +484,26 @@ def test_scdsc_frozen_autoencoder_cache(cpu_kernels):
     a.enc_1.weight.requires_grad_(True)
     a(y)
     assert a._cache is None                                                      # a trainable autoencoder is never cached
+
+
+def test_cross_entropy_sum_module_is_torchs_loss(cpu_kernels):
+    """``autograd.CrossEntropySum`` (what ScDeepSort.fit uses for scdeepsort.py:185) == ``nn.CrossEntropyLoss(reduction="sum")``: value,
+    gradient through an upstream factor, ``ignore_index`` rows, a non-fp32 input; soft targets fall through to torch."""
+    from dance_amd.autograd import CrossEntropySum
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(97, 7, generator=g, requires_grad=True)
+    y = torch.randint(0, 7, (97, ), generator=g)
+    y[::9] = -100
+    ours = CrossEntropySum()(x, y)
+    gx, = torch.autograd.grad(ours * 0.5, x)
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(reduction="sum")(xr, y)
+    gr, = torch.autograd.grad(ref * 0.5, xr)
+    assert torch.allclose(ours, ref, rtol=1e-6) and torch.allclose(gx, gr, rtol=1e-5, atol=1e-7)
+    assert bool((gx[::9] == 0).all())
+    xh = x.detach().to(torch.bfloat16).requires_grad_(True)
+    lh = CrossEntropySum()(xh, y)
+    gh, = torch.autograd.grad(lh, xh)
+    assert gh.dtype == torch.bfloat16 and torch.allclose(lh, torch.nn.functional.cross_entropy(xh.float(), y, reduction="sum"), rtol=1e-5)
+    soft = torch.softmax(torch.randn(97, 7, generator=g), 1)
+    assert torch.allclose(CrossEntropySum()(x, soft), torch.nn.functional.cross_entropy(x, soft, reduction="sum"))

@@ -147,3 +147,24 @@ def test_graphsc_port_reproduces_the_reference_fit_losses():
         assert np.allclose(z.numpy(), gold[f"gsc_{tag}_z"], rtol=1e-4, atol=1e-5)
         for k, v in model.state_dict().items():
             assert np.allclose(v.numpy(), gold[f"gsc_{tag}_sd1::{k}"], rtol=1e-4, atol=1e-6), (tag, k)
+
+
+def test_scdsc_epoch_flop_count_of_the_bench_row():
+    """scripts/bench_configs._scdsc_flops: what an epoch of the joint loop multiplies, per GEMM tag — the three trainable ZINB heads
+    (forward = nt, dW = tn; no dX: their input comes from the frozen decoder), the seven GCN layers (X W = nn, dW = tn, dX of layers
+    2..7 = nt) and NOT the frozen autoencoder (its outputs are computed once per fit).  A wrong count here mis-states the row's
+    matrix-core fraction (it read 0.27 instead of 0.89 for `tn` until the heads were counted)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_configs as bc
+    n = 1000
+    f = bc._scdsc_flops(n)
+    heads = 3 * 512 * 2000
+    gnn = 2000 * 512 + 512 * 256 + 256 * 256 + 256 * 256 + 256 * 128 + 128 * 32 + 32 * 10
+    assert f["gemm_f32_nn"] == 2.0 * n * gnn
+    assert f["gemm_f32_tn"] == 2.0 * n * (gnn + heads)
+    assert f["gemm_f32_nt"] == 2.0 * n * (heads + gnn - 2000 * 512)
+    # the model's own parameter shapes say the same
+    m = om.ScDSCModel(sigma=0.5, n_clusters=10, n_input=2000)
+    w = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert w["_dec_mean.0.weight"] == (2000, 512) and w["gnn_1.weight"] == (2000, 512) and w["gnn_7.weight"] == (32, 10)
