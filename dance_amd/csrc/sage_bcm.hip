@@ -219,6 +219,11 @@ __global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int 
   if (fast) {
     int gq[PACK_ROWS][PACK_IT];
     float wq[PACK_ROWS][PACK_IT];
+    // Every lane loads from a valid index (lanes past a row's end: the group's first entry) and the value is dropped by a select:
+    // written as `ok ? col[e] : -1` each of the 16 pairs sat in its own exec-masked block with a wait behind it (round 5's load
+    // audit) — 16 dependent round trips where "16 pairs at once" was meant.  A group without entries loads nothing.
+    const bool any = misc[2] > 0;  // block-uniform
+    const int e_safe = any ? rowptr[min(c0, n_dst - 1)] : 0;
 #pragma unroll
     for (int rr = 0; rr < PACK_ROWS; ++rr) {
       const int rs = rlo[PACK_ROWS * wv + rr], re = rhi[PACK_ROWS * wv + rr];
@@ -226,8 +231,15 @@ __global__ __launch_bounds__(1024) void sage_bcm_pack_kernel(int64_t n_dst, int 
       for (int it = 0; it < PACK_IT; ++it) {
         const int e = rs + lane + 64 * it;
         const bool ok = e < re;
-        gq[rr][it] = ok ? col[e] - wbeg : -1;
-        wq[rr][it] = ok ? w[e] : 0.f;
+        int cv = 0;
+        float wvv = 0.f;
+        if (any) {
+          const int ec = ok ? e : e_safe;
+          cv = col[ec];
+          wvv = w[ec];
+        }
+        gq[rr][it] = ok ? cv - wbeg : -1;
+        wq[rr][it] = ok ? wvv : 0.f;
       }
     }
 #pragma unroll
