@@ -148,6 +148,13 @@ def _declare(lib):
         "dh_csr_degree_scales_f32": (c_int, [i64, i64, i64, P, P, i32, P, P, P, P]),
         "dh_adam_step_f32": (c_int, [i32, P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
         "dh_sage_alpha_grad_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, P]),
+        "dh_graphsc_step_supported": (c_int, [i64, i64, i64, i64]),
+        "dh_graphsc_step_workspace_bytes": (c_size_t, [i64, i64, i64, i64, i64]),
+        "dh_graphsc_steps": (c_int, [P, i64, i64, P]),            # dh_graphsc_step_t* (dance_amd/ministep.py mirrors the struct)
+        "dh_scdeepsort_step_supported": (c_int, [i64, i64, i64, i64]),
+        "dh_scdeepsort_step_workspace_bytes": (c_size_t, [i64, i64, i64, i64]),
+        "dh_scdeepsort_steps": (c_int, [P, i64, i64, P]),         # dh_scdeepsort_step_t*
+        "dh_ministep_dropout_mask_f32": (c_int, [i64, c_float, ctypes.c_uint64, ctypes.c_uint64, c_int32, P, P]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

@@ -1,0 +1,1025 @@
+// The persistent mini-batch training steps of graph-sc and scDeepSort at the reference's batch sizes (graphsc.py:181-230, batch 128;
+// scdeepsort.py:222-257, batch 500): one C call runs a whole run of steps, FOUR kernel launches per step, nothing else on the stream.
+//
+// Why: with one framework op per reference line a step was 66 launches of ~5 us (block build + degree scalings + a transposed copy
+// of the block through three rocPRIM sorts / scans, seven small GEMMs, dropout, decoder, torch's Adam): 0.29 ms per graph-sc step,
+// 0.24 ms per scDeepSort step, launch-bound at ~0.05 of any roofline (profiles/r05u_graphsc_step_kernels_b128.md).  What the step
+// needs is much less than what it was given:
+//   * no block.  A seed CELL's row of a CellFeatureGraph-layout CSR already IS its block row (its genes ascending, then its self
+//     loop): the kernels walk the parent graph's rows; dgl.to_block's column renumbering exists only to index a gathered feature copy,
+//     and the gene rows of the feature matrix are the same for every batch.
+//   * no transpose.  graph-sc's input features carry no gradient (graphsc.py:200: a leaf), and the layer is linear in them, so with
+//     the aggregation done FIRST — AX = A_norm X at width in_feats = 50, then (AX) W1 — the backward is dW1 = AX^T dPre: a dense
+//     product over the batch rows; A^T never appears.  (The reference multiplies by W first, graphsc.py:452-465; SURVEY 8(d) allows
+//     either order when stated — this is the aggregate-first order; results agree to fp32 rounding, tests pin both to the goldens.)
+//   * weight gradients + bias gradients + Adam are ONE kernel: 32 x 32 tiles of A^T B on the fp32 matrix cores (exact fp32,
+//     v_mfma_f32_32x32x2_f32), each finished tile applying torch.optim.Adam's update to its 1024 parameters in the epilogue.
+//   * dropout is drawn in-kernel: Philox4x32-10 keyed by (seed, step, stream, element), the seed taken from torch's generator by the
+//     host (so torch.manual_seed reproduces a run); masks are never materialised except for the shared gene rows.
+//
+// graph-sc step (B seeds, G genes, F -> H -> E; two forwards per batch as graphsc.py:202,215 writes it):
+//   gsc_prepare : per-gene out-degree of the batch (int atomics), layout checks, dropout of the G x F gene rows for both forwards,
+//                 Adam step counters + bias corrections
+//   gsc_forward : one workgroup per (seed, forward): AX (row gather over the CSR row, D_out^-1/2 per source, D_in^-1/2), ReLU(AX W1 + b1),
+//                 Linear; forward 0 writes the epoch's embedding, forward 1 keeps AX, h and the decoder-dropped embedding
+//   gsc_decoder : one workgroup per seed: its row of z z^T, weighted BCE against the identity target (the only cell -> cell edges of a
+//                 batch are the self loops; checked by gsc_prepare), d/dz, decoder-dropout backward, Linear backward, ReLU mask
+//   ms_grad     : dW1, db1, dW2, db2 tiles + Adam; the step's loss; the gene counters zeroed for the next step
+// scDeepSort step (B seeds, D -> H -> C classes; the layer output ignores the aggregation, as the reference's does: gnn.py:92-96):
+//   sds_neigh   : (optional: AdaptiveSAGE.compute_neigh) the discarded weighted mean over the seed rows, straight off the CSR
+//   sds_hidden  : relu(dropout(feat[seeds]) W1^T + b1), 32 x 32 matrix-core tiles over GATHERED feature rows (fp32 or bf16 storage)
+//   sds_loss    : logits, summed cross entropy, softmax - onehot, its product with W2 masked by the ReLU: one wavefront per seed
+//   ms_grad     : dW1 (over the gathered rows again), db1, dW2, db2 + Adam; the step's loss
+//
+// Deterministic: fixed summation orders everywhere (integer atomics only).  No memset / memcpy nodes (capturable), no host reads.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- Philox4x32-10 (Salmon et al., SC'11; the generator behind torch's CUDA dropout) ------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    if (r) {
+      k.x += 0x9E3779B9u;
+      k.y += 0xBB67AE85u;
+    }
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+  }
+  return c;
+}
+
+// one dropout layer's draw for one step: element e of stream `sid` is kept iff the top 24 bits of word (e & 3) of
+// philox(counter = (e >> 2, sid, step_lo, step_hi), key = seed) are below thr = floor((1 - p) 2^24); kept values are scaled by 1 / (1 - p)
+struct Drop {
+  uint32_t seed_lo, seed_hi, step_lo, step_hi, thr;
+  float scale;
+};
+constexpr uint32_t kKeepAll = 1u << 24;
+
+__device__ __forceinline__ uint4 drop_words(const Drop& d, uint32_t sid, uint64_t quad) {
+  return philox4x32_10(make_uint4((uint32_t)quad, sid | ((uint32_t)(quad >> 32) << 8), d.step_lo, d.step_hi), make_uint2(d.seed_lo, d.seed_hi));
+}
+__device__ __forceinline__ float drop_pick(const Drop& d, const uint4& r, int j) {
+  const uint32_t w = j == 0 ? r.x : j == 1 ? r.y : j == 2 ? r.z : r.w;
+  return (w >> 8) < d.thr ? d.scale : 0.f;
+}
+__device__ __forceinline__ float drop_scale(const Drop& d, uint32_t sid, uint64_t e) {
+  if (d.thr >= kKeepAll) return 1.f;
+  const uint4 r = drop_words(d, sid, e >> 2);
+  return drop_pick(d, r, (int)(e & 3));
+}
+
+// stream ids
+constexpr uint32_t SID_GENE = 0;  // + forward: the G x F gene rows
+constexpr uint32_t SID_SELF = 2;  // + forward: the B x F seed rows
+constexpr uint32_t SID_DEC = 4;   // the decoder's B x E draw
+constexpr uint32_t SID_SDS = 5;   // scDeepSort: the B x D seed rows
+
+__host__ __device__ inline int pow2_at_least(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+  return x;
+}
+
+// ---- Adam: counters and bias corrections (once per step, one thread) ----------------------------------------------------------------
+struct AdamHyper {
+  float lr, beta1, beta2, eps, wd;
+};
+constexpr int MS_MAX_PARAMS = 6;
+struct StepCounters {
+  float* step[MS_MAX_PARAMS];
+  int n;
+};
+// coef[0] = lr / (1 - beta1^t), coef[1] = sqrt(1 - beta2^t) — evaluated in double and rounded once, as adam.hip does
+__device__ void adam_tick(const StepCounters& sc, const AdamHyper& h, float* coef) {
+  float t = 0.f;
+  for (int j = 0; j < sc.n; ++j) {
+    t = *sc.step[j] + 1.f;
+    *sc.step[j] = t;
+  }
+  const double step = (double)t;
+  coef[0] = h.lr / (float)(1.0 - pow((double)h.beta1, step));
+  coef[1] = (float)sqrt(1.0 - pow((double)h.beta2, step));
+}
+// torch/optim/adam.py _single_tensor_adam, every operation rounded separately
+__device__ __forceinline__ float adam_apply(float p, float g, float* m, float* v, const AdamHyper& h, float step_size, float bc2_sqrt) {
+  const float one_minus_b1 = 1.f - h.beta1, one_minus_b2 = 1.f - h.beta2;
+  if (h.wd != 0.f) g = g + h.wd * p;
+  const float mi = *m + one_minus_b1 * (g - *m);
+  const float vi = *v * h.beta2 + one_minus_b2 * g * g;
+  *m = mi;
+  *v = vi;
+  const float denom = sqrtf(vi) / bc2_sqrt + h.eps;
+  return p - step_size * (mi / denom);
+}
+
+// =====================================================================================================================================
+// graph-sc
+// =====================================================================================================================================
+struct GscArgs {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  const float* X;  // node features [n_nodes, F], genes first
+  int64_t ldx, n_nodes;
+  int G, B, F, H, E, FP, mean;
+  const float *W1, *b1, *W2, *b2;  // [F, H], [H], [E, H], [E]
+  const float* w2t;                // [H, E] mirror of W2 (kept by ms_grad)
+  int32_t* count;                  // [G] zero between steps
+  float* coef;                     // [2]
+  float* xdg;                      // [2, G, F] dropped gene rows (dropout > 0 only)
+  float *ax2, *h2, *zd2, *demb, *dpre;  // [B, F], [B, H], [B, E], [B, E], [B, H]
+  double* rowloss;                 // [B]
+  int32_t* bad;
+};
+
+__global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx, StepCounters sc, AdamHyper hy, int nb_count) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < nb_count) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) adam_tick(sc, hy, a.coef);
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= a.B) return;
+    const int64_t v = seeds[i];
+    if (v < a.G || v >= a.n_nodes) {  // not a cell of this layout
+      if (lane == 0) atomicOr(a.bad, 1);
+      return;
+    }
+    const int s = a.rowptr[v], t = a.rowptr[v + 1];
+    int n_self = 0;
+    for (int e = s + lane; e < t; e += 64) {
+      const int c = a.col[e];
+      if (c < a.G) atomicAdd(a.count + c, 1);
+      else if (c != v) atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
+    }
+    for (int e0 = s; e0 < t; e0 += 64) {  // (uniform trip count: ballot over whole wavefronts)
+      const int e = e0 + lane;
+      n_self += __popcll(__ballot(e < t && a.col[min(e, t - 1)] >= a.G));
+    }
+    if (lane == 0 && n_self != 1) atomicOr(a.bad, 2);  // the identity decoder target needs exactly one self loop per seed
+    return;
+  }
+  if (dx.thr >= kKeepAll) return;
+  // dropout of the gene rows, both forwards: one Philox call per 4 consecutive elements of the flat [G * F] index space
+  const int64_t gf = (int64_t)a.G * a.F, nq = (gf + 3) >> 2;
+  const int64_t q = ((int64_t)blockIdx.x - nb_count) * 256 + threadIdx.x;
+  if (q >= 2 * nq) return;
+  const int fwd = q >= nq;
+  const int64_t quad = fwd ? q - nq : q;
+  const uint4 r = drop_words(dx, SID_GENE + fwd, (uint64_t)quad);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t e = quad * 4 + j;
+    if (e < gf) {
+      const int64_t g = e / a.F, f = e - g * a.F;
+      a.xdg[fwd * gf + e] = a.X[g * a.ldx + f] * drop_pick(dx, r, j);
+    }
+  }
+}
+
+// one workgroup per (seed, forward)
+__global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx, Drop dd, float* __restrict__ z_out) {
+  __shared__ float red[512], axs[128], hs[1024];
+  const int i = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+  int64_t v = seeds[i];
+  v = v < a.G ? a.G : v >= a.n_nodes ? a.n_nodes - 1 : v;  // (flagged by gsc_prepare; keep every address valid)
+  const int s = a.rowptr[v], t = a.rowptr[v + 1], deg = t - s;
+  const int FP = a.FP, ngrp = 256 / FP, fl = tid & (FP - 1), grp = tid / FP, F = a.F, G = a.G;
+  const bool drop = dx.thr < kKeepAll;
+  const float* __restrict__ xg = drop ? a.xdg + (int64_t)k * G * F : a.X;
+  const int64_t ldg = drop ? F : a.ldx;
+  const float* __restrict__ xself = a.X + v * a.ldx;
+  const int f0 = min(fl, F - 1), f1 = min(fl + FP, F - 1);
+  float sm0 = 1.f, sm1 = 1.f;  // the seed row's own dropout draw
+  if (drop) {
+    sm0 = drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f0);
+    sm1 = drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f1);
+  }
+  float acc0 = 0.f, acc1 = 0.f;
+  // every load from a clamped, valid address; what must not count is multiplied by a zero weight (no load behind a divergent guard)
+  for (int e0 = s + grp; e0 < t; e0 += 4 * ngrp) {
+    int c[4];
+    float w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = e0 + u * ngrp, ec = min(e, t - 1);
+      c[u] = a.col[ec];
+      w[u] = e < t ? a.val[ec] : 0.f;
+    }
+    int cnt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) cnt[u] = a.count[min(c[u], G - 1)];
+    float x0[4], x1[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* __restrict__ row = c[u] >= G ? xself : xg + (int64_t)c[u] * ldg;
+      x0[u] = row[f0];
+      x1[u] = row[f1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool self = c[u] >= G;
+      // D_out^-1/2 of the source inside the block (graphsc.py:444-449): a gene's count over the batch, 1 for a seed (its self loop)
+      const float cs = self ? 1.f : 1.f / sqrtf(fmaxf((float)cnt[u], 1.f));
+      const float ws = w[u] * cs;
+      acc0 = fmaf(ws * (self ? sm0 : 1.f), x0[u], acc0);
+      acc1 = fmaf(ws * (self ? sm1 : 1.f), x1[u], acc1);
+    }
+  }
+  if (fl < F) red[grp * F + fl] = acc0;
+  if (fl + FP < F) red[grp * F + fl + FP] = acc1;
+  __syncthreads();
+  // D_in^-1/2 of the destination (:467-471); fn.mean divides by the in-degree first (:465)
+  const float dg = fmaxf((float)deg, 1.f);
+  const float rs = (1.f / sqrtf(dg)) * (a.mean ? 1.f / dg : 1.f);
+  for (int f = tid; f < F; f += 256) {
+    float sum = 0.f;
+    for (int g2 = 0; g2 < ngrp; ++g2) sum += red[g2 * F + f];  // group order: deterministic
+    sum *= rs;
+    axs[f] = sum;
+    if (k == 1) a.ax2[(int64_t)i * F + f] = sum;
+  }
+  __syncthreads();
+  const int H = a.H, E = a.E;
+  for (int tt = tid; tt < H; tt += 256) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int f = 0; f < F; ++f) acc = fmaf(axs[f], a.W1[(int64_t)f * H + tt], acc);
+    const float hv = fmaxf(acc + a.b1[tt], 0.f);
+    hs[tt] = hv;
+    if (k == 1) a.h2[(int64_t)i * H + tt] = hv;
+  }
+  __syncthreads();
+  for (int o = tid; o < E; o += 256) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < H; ++kk) acc = fmaf(hs[kk], a.w2t[(int64_t)kk * E + o], acc);
+    const float emb = acc + a.b2[o];
+    if (k == 0) z_out[(int64_t)i * E + o] = emb;                                                  // graphsc.py:202-203
+    else a.zd2[(int64_t)i * E + o] = emb * drop_scale(dd, SID_DEC, (uint64_t)i * E + o);          // :215, :409
+  }
+}
+
+__device__ __forceinline__ float softplusf(float x) { return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))); }
+
+// one workgroup per seed i: row i of the logits z z^T against the identity target, then everything of the backward that is local to row i
+__global__ __launch_bounds__(256) void gsc_decoder_kernel(GscArgs a, Drop dd, float pos_weight, float cscale) {
+  extern __shared__ float sm[];
+  const int B = a.B, E = a.E, H = a.H, i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* zi = sm;          // [E]
+  float* de = sm + E;      // [E]
+  float* gj = sm + 2 * E;  // [B]
+  __shared__ double wl[4];
+  const float* __restrict__ Z = a.zd2;
+  for (int kk = tid; kk < E; kk += 256) zi[kk] = Z[(int64_t)i * E + kk];
+  __syncthreads();
+  double loss = 0.0;
+  for (int j0 = wave; j0 < B; j0 += 16) {  // 4 rows per wavefront in flight
+    float d[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int kk = lane; kk < E; kk += 64) {
+      const float z = zi[kk];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) d[u] = fmaf(z, Z[(int64_t)min(j0 + 4 * u, B - 1) * E + kk], d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float x = wave_sum(d[u]);
+      const int j = j0 + 4 * u;
+      if (lane == 0 && j < B) {
+        const float sg = 1.f / (1.f + expf(-x));
+        if (j == i) {  // target 1, weighted: pos_weight * softplus(-x)
+          loss += (double)(pos_weight * softplusf(-x));
+          gj[j] = pos_weight * (sg - 1.f);
+        } else {
+          loss += (double)softplusf(x);
+          gj[j] = sg;
+        }
+      }
+    }
+  }
+  if (lane == 0) wl[wave] = loss;
+  __syncthreads();
+  if (tid == 0) a.rowloss[i] = ((wl[0] + wl[1]) + wl[2]) + wl[3];
+  // d loss / d zd_i = 2 c sum_j g_ij zd_j (logits and target are symmetric), then the decoder dropout's own mask
+  for (int kk = tid; kk < E; kk += 256) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < B; ++j) acc = fmaf(gj[j], Z[(int64_t)j * E + kk], acc);
+    const float dv = 2.f * cscale * acc * drop_scale(dd, SID_DEC, (uint64_t)i * E + kk);
+    de[kk] = dv;
+    a.demb[(int64_t)i * E + kk] = dv;
+  }
+  __syncthreads();
+  for (int tt = tid; tt < H; tt += 256) {
+    float acc = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < E; ++o) acc = fmaf(de[o], a.W2[(int64_t)o * H + tt], acc);
+    a.dpre[(int64_t)i * H + tt] = a.h2[(int64_t)i * H + tt] > 0.f ? acc : 0.f;
+  }
+}
+
+// =====================================================================================================================================
+// weight gradients + Adam: G = A^T B in 32 x 32 tiles (A [K, M], B [K, N] row-major: the batch rows are the K dimension), exact fp32 MFMA
+// =====================================================================================================================================
+constexpr int MS_T = 32, MS_LD = 33, MS_KC = 128;
+
+struct MsJob {
+  const float* A;  // [K, M]; nullptr = a column of ones (M = 1: column sums, the bias gradients)
+  int64_t lda;
+  const void* Bm;  // [K, N] f32 or bf16
+  int64_t ldb;
+  const int64_t* b_rows;  // row k of B is row b_rows[k] of Bm (gathered feature rows), nullptr = k
+  int b_bf16, b_drop;     // b_drop: B carries the SID_SDS dropout draw (element index k * N + n)
+  int M, N, K;
+  float *p, *m, *v;  // parameter [M, N] and its Adam moments
+  float* pT;         // optional [N, M] mirror of the updated parameter
+  float* g;          // optional gradient output [M, N] (data-parallel form: the update happens after the all-reduce)
+  int tile0, tiles_n;
+};
+struct MsGradArgs {
+  MsJob job[MS_MAX_PARAMS];
+  int n_jobs, total_tiles, adam;
+  AdamHyper hy;
+  const float* coef;
+  Drop bdrop;
+  // extras (the block after the tiles): the step's loss and the counters to clear
+  const double* rowloss_d;
+  const float* rowloss_f;
+  int n_rowloss;
+  double loss_div;
+  float loss_mul;
+  float* loss_out;
+  int32_t* zero_i32;
+  int n_zero;
+};
+
+__global__ __launch_bounds__(256) void ms_grad_kernel(MsGradArgs a) {
+  __shared__ float smem[2 * MS_KC * MS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= a.total_tiles) {
+    // the step's loss: rows summed in index order in double (as the unfused path's .sum(dtype=float64))
+    if (tid == 0 && a.loss_out) {
+      double s = 0.0;
+      for (int i = 0; i < a.n_rowloss; ++i) s += a.rowloss_d ? a.rowloss_d[i] : (double)a.rowloss_f[i];
+      *a.loss_out = a.loss_mul * (float)(s / a.loss_div);
+    }
+    for (int i = tid; i < a.n_zero; i += 256) a.zero_i32[i] = 0;
+    return;
+  }
+  int ji = 0;
+#pragma unroll
+  for (int q = 1; q < MS_MAX_PARAMS; ++q)
+    if (q < a.n_jobs && (int)blockIdx.x >= a.job[q].tile0) ji = q;
+  const MsJob& jb = a.job[ji];
+  const int tile = blockIdx.x - jb.tile0, m0 = (tile / jb.tiles_n) * MS_T, n0 = (tile % jb.tiles_n) * MS_T;
+  const int M = jb.M, N = jb.N, K = jb.K;
+  float* const As = smem;
+  float* const Bs = smem + MS_KC * MS_LD;
+  const int i32 = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool drop = jb.b_drop && a.bdrop.thr < kKeepAll;
+  for (int k0 = 0; k0 < K; k0 += MS_KC) {
+    float ra[MS_KC / 8], rb[MS_KC / 8];
+#pragma unroll
+    for (int q = 0; q < MS_KC / 8; ++q) {
+      const int e = tid + 256 * q, r = e & 31, k = e >> 5;
+      const int kk = min(k0 + k, K - 1);
+      ra[q] = jb.A ? jb.A[(int64_t)kk * jb.lda + min(m0 + r, M - 1)] : 1.f;
+      const int64_t brow = jb.b_rows ? jb.b_rows[kk] : kk;
+      const int nn = min(n0 + r, N - 1);
+      float bv;
+      if (jb.b_bf16) bv = __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(jb.Bm)[brow * jb.ldb + nn] << 16);
+      else bv = reinterpret_cast<const float*>(jb.Bm)[brow * jb.ldb + nn];
+      if (drop) bv *= drop_scale(a.bdrop, SID_SDS, (uint64_t)kk * N + nn);
+      rb[q] = bv;
+    }
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MS_KC / 8; ++q) {
+      const int e = tid + 256 * q, r = e & 31, k = e >> 5;
+      const bool kin = k0 + k < K;
+      As[k * MS_LD + r] = (kin && m0 + r < M) ? ra[q] : 0.f;
+      Bs[k * MS_LD + r] = (kin && n0 + r < N) ? rb[q] : 0.f;
+    }
+    __syncthreads();
+    const int kc = min(MS_KC, K - k0);
+    for (int s = wave; 2 * s < kc; s += 4) {
+      const float av = As[(2 * s + h) * MS_LD + i32];
+      const float bv = Bs[(2 * s + h) * MS_LD + i32];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* const redt = smem + wave * (MS_T * MS_LD);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) redt[((r & 3) + 8 * (r >> 2) + 4 * h) * MS_LD + i32] = acc[r];
+  __syncthreads();
+  const float step_size = a.adam ? a.coef[0] : 0.f, bc2 = a.adam ? a.coef[1] : 1.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, cc = e & 31;
+    float g = smem[row * MS_LD + cc];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) g += smem[w * (MS_T * MS_LD) + row * MS_LD + cc];  // wave order: deterministic
+    if (m0 + row < M && n0 + cc < N) {
+      const int64_t idx = (int64_t)(m0 + row) * N + n0 + cc;
+      if (jb.g) jb.g[idx] = g;
+      if (a.adam) {
+        const float pn = adam_apply(jb.p[idx], g, jb.m + idx, jb.v + idx, a.hy, step_size, bc2);
+        jb.p[idx] = pn;
+        if (jb.pT) jb.pT[(int64_t)(n0 + cc) * M + m0 + row] = pn;
+      }
+    }
+  }
+}
+
+// the update alone, over the same job table (data-parallel form: after the gradient all-reduce)
+__global__ __launch_bounds__(256) void ms_adam_kernel(MsGradArgs a) {
+  const MsJob& jb = a.job[blockIdx.y];
+  const int64_t n = (int64_t)jb.M * jb.N, idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n) return;
+  const float pn = adam_apply(jb.p[idx], jb.g[idx], jb.m + idx, jb.v + idx, a.hy, a.coef[0], a.coef[1]);
+  jb.p[idx] = pn;
+  if (jb.pT) jb.pT[(idx % jb.N) * jb.M + idx / jb.N] = pn;
+}
+
+__global__ __launch_bounds__(256) void ms_transpose_kernel(int M, int N, const float* __restrict__ p, float* __restrict__ pT) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx < (int64_t)M * N) pT[(idx % N) * M + idx / N] = p[idx];
+}
+
+int place_tiles(MsGradArgs& g) {
+  int t = 0;
+  for (int j = 0; j < g.n_jobs; ++j) {
+    g.job[j].tile0 = t;
+    g.job[j].tiles_n = (g.job[j].N + MS_T - 1) / MS_T;
+    t += ((g.job[j].M + MS_T - 1) / MS_T) * g.job[j].tiles_n;
+  }
+  g.total_tiles = t;
+  return t;
+}
+
+Drop make_drop(float p, uint64_t seed, uint64_t step) {
+  Drop d;
+  d.seed_lo = (uint32_t)seed;
+  d.seed_hi = (uint32_t)(seed >> 32);
+  d.step_lo = (uint32_t)step;
+  d.step_hi = (uint32_t)(step >> 32);
+  if (p <= 0.f) {
+    d.thr = kKeepAll;
+    d.scale = 1.f;
+  } else {
+    const double keep = 1.0 - (double)p;
+    d.thr = (uint32_t)(keep * 16777216.0);
+    d.scale = (float)(1.0 / keep);
+  }
+  return d;
+}
+
+// =====================================================================================================================================
+// scDeepSort
+// =====================================================================================================================================
+struct SdsArgs {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  const void* X;  // node features [n_nodes, D], f32 or bf16
+  int64_t ldx, n_nodes;
+  int x_bf16, G, B, D, H, C;
+  const int32_t* cell_id;  // [n_nodes]: gene index for genes, -1 for cells (the graph's ndata["cell_id"])
+  const int64_t* labels;   // [n_nodes]
+  const float* alpha;      // [G + 2]
+  const float *W1, *b1, *W2, *b2;  // [H, D], [H], [C, H], [C]
+  float* coef;
+  float *h1, *dh1, *dlog, *rowloss;  // [B, H], [B, H], [B, C], [B]
+  float* neigh;                      // [B, D] or nullptr
+  int32_t* bad;
+};
+
+__device__ __forceinline__ float load_feat(const void* X, int bf16, int64_t idx) {
+  return bf16 ? __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(X)[idx] << 16) : reinterpret_cast<const float*>(X)[idx];
+}
+
+// neigh[i] = mean over the in-edges e of seed i of alpha[idx(e)] w_e h[src(e)]  (gnn.py:62-90): alpha index = the gene's id for a
+// gene -> cell edge, G + 1 for a cell's self loop (G for gene - gene, the destination gene's id for cell -> gene: not reachable from a seed cell)
+__global__ __launch_bounds__(256) void sds_neigh_kernel(SdsArgs a, const int64_t* __restrict__ seeds) {
+  extern __shared__ float sm[];  // [ngrp][D]
+  const int i = blockIdx.x, tid = threadIdx.x, D = a.D;
+  int64_t v = seeds[i];
+  v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
+  const int s = a.rowptr[v], t = a.rowptr[v + 1];
+  const int DP = min(pow2_at_least(D), 256);
+  const int ngrp = 256 / DP, fl = tid & (DP - 1), grp = tid / DP;
+  const int did = a.cell_id[v];
+  constexpr int NF = 4;  // features per thread (D <= 1024)
+  float acc[NF];
+#pragma unroll
+  for (int q = 0; q < NF; ++q) acc[q] = 0.f;
+  for (int e0 = s + grp; e0 < t; e0 += 2 * ngrp) {
+    int c[2];
+    float w[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = e0 + u * ngrp, ec = min(e, t - 1);
+      c[u] = a.col[ec];
+      w[u] = e < t ? a.val[ec] : 0.f;
+    }
+    int sid[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) sid[u] = a.cell_id[c[u]];
+    float x[2][NF];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int q = 0; q < NF; ++q) x[u][q] = load_feat(a.X, a.x_bf16, (int64_t)c[u] * a.ldx + min(fl + q * DP, D - 1));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ai = (sid[u] >= 0 && did < 0) ? sid[u] : (did >= 0 && sid[u] < 0) ? did : (did >= 0 && sid[u] >= 0) ? a.G : a.G + 1;
+      const float ws = w[u] * a.alpha[ai];
+#pragma unroll
+      for (int q = 0; q < NF; ++q) acc[q] = fmaf(ws, x[u][q], acc[q]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NF; ++q)
+    if (fl + q * DP < D) sm[grp * D + fl + q * DP] = acc[q];
+  __syncthreads();
+  const float inv = 1.f / fmaxf((float)(t - s), 1.f);
+  for (int f = tid; f < D; f += 256) {
+    float sum = 0.f;
+    for (int g2 = 0; g2 < ngrp; ++g2) sum += sm[g2 * D + f];
+    a.neigh[(int64_t)i * D + f] = sum * inv;
+  }
+}
+
+// the same aggregation for 16-byte-aligned rows (D % 4 == 0): one wavefront per entry, four entries per wavefront in flight, lanes across
+// the row in 4-feature vectors (NQ vectors per lane).  The scalar kernel above walks a row's ~200 entries two at a time behind
+// col -> cell_id -> alpha -> feature round trips: 80 us at batch 500 x D 400; this one 16 entries per round.
+template <int NQ, bool BF16>
+__global__ __launch_bounds__(256) void sds_neigh_vec_kernel(SdsArgs a, const int64_t* __restrict__ seeds) {
+  extern __shared__ float sm[];  // [4][D]
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, D = a.D, D4 = D >> 2;
+  int64_t v = seeds[i];
+  v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
+  const int s = a.rowptr[v], t = a.rowptr[v + 1];
+  const int did = a.cell_id[v];
+  float4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int U = 4;
+  for (int e0 = s + wave; e0 < t; e0 += 4 * U) {
+    int c[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + 4 * u, ec = min(e, t - 1);
+      c[u] = a.col[ec];
+      w[u] = e < t ? a.val[ec] : 0.f;
+    }
+    int sid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) sid[u] = a.cell_id[c[u]];
+    float4 x[U][NQ];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int64_t at = (int64_t)c[u] * a.ldx + 4 * min(lane + 64 * q, D4 - 1);
+        if (BF16) {
+          const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(a.X) + at);
+          x[u][q] = make_float4(__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xFFFF0000u), __uint_as_float(r.y << 16), __uint_as_float(r.y & 0xFFFF0000u));
+        } else {
+          x[u][q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.X) + at);
+        }
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ai = (sid[u] >= 0 && did < 0) ? sid[u] : (did >= 0 && sid[u] < 0) ? did : (did >= 0 && sid[u] >= 0) ? a.G : a.G + 1;
+      const float ws = w[u] * a.alpha[ai];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        acc[q].x = fmaf(ws, x[u][q].x, acc[q].x);
+        acc[q].y = fmaf(ws, x[u][q].y, acc[q].y);
+        acc[q].z = fmaf(ws, x[u][q].z, acc[q].z);
+        acc[q].w = fmaf(ws, x[u][q].w, acc[q].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+    if (lane + 64 * q < D4) *reinterpret_cast<float4*>(sm + wave * D + 4 * (lane + 64 * q)) = acc[q];
+  __syncthreads();
+  const float inv = 1.f / fmaxf((float)(t - s), 1.f);
+  for (int f = tid; f < D; f += 256) a.neigh[(int64_t)i * D + f] = (((sm[f] + sm[D + f]) + sm[2 * D + f]) + sm[3 * D + f]) * inv;
+}
+
+// h1 = relu(dropout(X[seeds]) W1^T + b1): 32 x 32 tiles, the feature rows gathered on the way into LDS
+__global__ __launch_bounds__(256) void sds_hidden_kernel(SdsArgs a, const int64_t* __restrict__ seeds, Drop dz, StepCounters sc, AdamHyper hy) {
+  __shared__ float smem[2 * MS_KC * MS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) adam_tick(sc, hy, a.coef);
+  const int m0 = blockIdx.y * MS_T, n0 = blockIdx.x * MS_T, M = a.B, N = a.H, K = a.D;
+  float* const As = smem;
+  float* const Bs = smem + MS_KC * MS_LD;
+  const int i32 = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const bool drop = dz.thr < kKeepAll;
+  for (int k0 = 0; k0 < K; k0 += MS_KC) {
+    float ra[MS_KC / 8], rb[MS_KC / 8];
+#pragma unroll
+    for (int q = 0; q < MS_KC / 8; ++q) {  // both operands K-contiguous: consecutive lanes walk k
+      const int e = tid + 256 * q, r = e / MS_KC, k = e % MS_KC;
+      const int kk = min(k0 + k, K - 1), mm = min(m0 + r, M - 1);
+      int64_t v = seeds[mm];
+      v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
+      float av = load_feat(a.X, a.x_bf16, v * a.ldx + kk);
+      if (drop) av *= drop_scale(dz, SID_SDS, (uint64_t)mm * K + kk);
+      ra[q] = av;
+      rb[q] = a.W1[(int64_t)min(n0 + r, N - 1) * K + kk];
+    }
+    if (k0) __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MS_KC / 8; ++q) {
+      const int e = tid + 256 * q, r = e / MS_KC, k = e % MS_KC;
+      const bool kin = k0 + k < K;
+      As[k * MS_LD + r] = (kin && m0 + r < M) ? ra[q] : 0.f;
+      Bs[k * MS_LD + r] = (kin && n0 + r < N) ? rb[q] : 0.f;
+    }
+    __syncthreads();
+    const int kc = min(MS_KC, K - k0);
+    for (int s = wave; 2 * s < kc; s += 4) {
+      const float av = As[(2 * s + h) * MS_LD + i32];
+      const float bv = Bs[(2 * s + h) * MS_LD + i32];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  float* const redt = smem + wave * (MS_T * MS_LD);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) redt[((r & 3) + 8 * (r >> 2) + 4 * h) * MS_LD + i32] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + 256 * q, row = e >> 5, cc = e & 31;
+    float vv = smem[row * MS_LD + cc];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) vv += smem[w * (MS_T * MS_LD) + row * MS_LD + cc];
+    if (m0 + row < M && n0 + cc < N) a.h1[(int64_t)(m0 + row) * N + n0 + cc] = fmaxf(vv + a.b1[n0 + cc], 0.f);
+  }
+}
+
+// one wavefront per seed: logits = h1 W2^T + b2, loss_i = logsumexp - logit[label], dlog = softmax - onehot (CrossEntropyLoss(reduction="sum"),
+// scdeepsort.py:185), dh1 = (dlog W2) masked by the ReLU.  Lane = (class c, K quarter q): CP classes padded to a power of two, 64 / CP quarters.
+__global__ __launch_bounds__(256) void sds_loss_kernel(SdsArgs a, const int64_t* __restrict__ seeds) {
+  extern __shared__ float sm[];  // W2 [C][H + 1], then per wave: h [H], dl [64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, H = a.H, C = a.C, HL = H + 1;
+  float* w2s = sm;
+  float* hw = sm + C * HL + wave * (H + 64);
+  float* dlw = hw + H;
+  for (int e = tid; e < C * H; e += 256) w2s[(e / H) * HL + e % H] = a.W2[e];
+  const int i = blockIdx.x * 4 + wave;
+  const bool live = i < a.B;
+  const int ii = live ? i : a.B - 1;
+  for (int kk = lane; kk < H; kk += 64) hw[kk] = a.h1[(int64_t)ii * H + kk];
+  __syncthreads();
+  const int CP = pow2_at_least(C), Q = 64 / CP, c = lane & (CP - 1), q = lane / CP;
+  const int hq = (H + Q - 1) / Q, kb = q * hq, ke = min(H, kb + hq);
+  float part = 0.f;
+  const int cc = min(c, C - 1);
+  for (int kk = kb; kk < ke; ++kk) part = fmaf(hw[kk], w2s[cc * HL + kk], part);
+  for (int off = CP; off < 64; off <<= 1) part += __shfl_xor(part, off, 64);  // over the quarters
+  float logit = c < C ? part + a.b2[cc] : -INFINITY;
+  float mx = logit;
+  for (int off = 1; off < CP; off <<= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  const float ex = c < C ? expf(logit - mx) : 0.f;
+  float se = ex;
+  for (int off = 1; off < CP; off <<= 1) se += __shfl_xor(se, off, 64);
+  int64_t v = seeds[ii];
+  v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
+  const int64_t lab = a.labels[v];
+  if (live && lane == 0 && (lab < 0 || lab >= C)) atomicOr(a.bad, 4);
+  const float dl = c < C ? ex / se - (c == lab ? 1.f : 0.f) : 0.f;
+  float lt = (c == lab) ? logit : 0.f;  // the label's logit, broadcast over the wavefront's class lanes
+  for (int off = 1; off < CP; off <<= 1) lt += __shfl_xor(lt, off, 64);
+  if (lane < CP) dlw[lane] = dl;
+  if (live && lane == 0) a.rowloss[i] = (logf(se) + mx) - lt;
+  if (live && q == 0 && c < C) a.dlog[(int64_t)i * C + c] = dl;
+  __syncthreads();
+  for (int kk = lane; kk < H; kk += 64) {
+    float acc = 0.f;
+    for (int c2 = 0; c2 < C; ++c2) acc = fmaf(dlw[c2], w2s[c2 * HL + kk], acc);
+    if (live) a.dh1[(int64_t)i * H + kk] = hw[kk] > 0.f ? acc : 0.f;
+  }
+}
+
+}  // namespace
+
+// =====================================================================================================================================
+// host side
+// =====================================================================================================================================
+namespace {
+
+__global__ __launch_bounds__(256) void ms_dropout_mask_kernel(int64_t n, Drop d, uint32_t sid, float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) out[e] = drop_scale(d, sid, (uint64_t)e);
+}
+
+size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct GscLayout {
+  size_t count, coef, xdg, ax2, h2, zd2, demb, dpre, rowloss, w2t, total;
+};
+GscLayout gsc_layout(int64_t G, int64_t B, int64_t F, int64_t H, int64_t E) {
+  GscLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += a256(bytes);
+    return at;
+  };
+  l.count = take((size_t)G * 4);
+  l.coef = take(16);
+  l.xdg = take((size_t)2 * G * F * 4);
+  l.ax2 = take((size_t)B * F * 4);
+  l.h2 = take((size_t)B * H * 4);
+  l.zd2 = take((size_t)B * E * 4);
+  l.demb = take((size_t)B * E * 4);
+  l.dpre = take((size_t)B * H * 4);
+  l.rowloss = take((size_t)B * 8);
+  l.w2t = take((size_t)H * E * 4);
+  l.total = o;
+  return l;
+}
+
+bool adam_ok(const dh_adam_state_t& s) { return s.param && s.exp_avg && s.exp_avg_sq && s.step; }
+
+void set_job(MsJob& j, const float* A, int64_t lda, const void* Bm, int64_t ldb, int M, int N, int K, const dh_adam_state_t& st, float* pT, float* g) {
+  j = MsJob{};
+  j.A = A;
+  j.lda = lda;
+  j.Bm = Bm;
+  j.ldb = ldb;
+  j.M = M;
+  j.N = N;
+  j.K = K;
+  j.p = st.param;
+  j.m = st.exp_avg;
+  j.v = st.exp_avg_sq;
+  j.pT = pT;
+  j.g = g;
+}
+
+}  // namespace
+
+extern "C" int dh_ministep_dropout_mask_f32(int64_t n, float p, uint64_t seed, uint64_t step, int32_t sid, float* out, dh_stream_t stream) {
+  const char* me = "dh_ministep_dropout_mask_f32";
+  if (n < 0 || p < 0.f || p >= 1.f || sid < 0 || sid > 255) return dh::fail(DH_ERR_INVALID, "%s: bad argument", me);
+  if (n == 0) return DH_OK;
+  if (!out) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  hipLaunchKernelGGL(ms_dropout_mask_kernel, dim3((unsigned)dh::ceil_div(n, 256)), dim3(256), 0, dh::as_stream(stream), n, make_drop(p, seed, step), (uint32_t)sid,
+                     out);
+  return dh::check_launch(me);
+}
+
+extern "C" int dh_graphsc_step_supported(int64_t batch, int64_t in_feats, int64_t hidden, int64_t emb) {
+  return (batch >= 2 && batch <= 4096 && in_feats >= 1 && in_feats <= 128 && hidden >= 1 && hidden <= 1024 && emb >= 1 && emb <= 1024) ? 1 : 0;
+}
+
+extern "C" size_t dh_graphsc_step_workspace_bytes(int64_t n_genes, int64_t batch, int64_t in_feats, int64_t hidden, int64_t emb) {
+  if (n_genes < 1 || !dh_graphsc_step_supported(batch, in_feats, hidden, emb)) return 0;
+  return gsc_layout(n_genes, batch, in_feats, hidden, emb).total;
+}
+
+extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, int64_t n_steps, dh_stream_t stream) {
+  const char* me = "dh_graphsc_steps";
+  if (!c) return dh::fail(DH_ERR_INVALID, "%s: null configuration", me);
+  if (first_step < 0 || n_steps < 0) return dh::fail(DH_ERR_INVALID, "%s: negative step range", me);
+  if (n_steps == 0) return DH_OK;
+  if (!dh_graphsc_step_supported(c->batch, c->in_feats, c->hidden, c->emb))
+    return dh::fail(DH_ERR_INVALID, "%s: batch %lld, %lld -> %lld -> %lld outside dh_graphsc_step_supported", me, (long long)c->batch, (long long)c->in_feats,
+                    (long long)c->hidden, (long long)c->emb);
+  if (c->n_genes < 1 || c->n_nodes <= c->n_genes || c->n_nodes >= ((int64_t)1 << 31)) return dh::fail(DH_ERR_INVALID, "%s: bad node counts", me);
+  if (!c->rowptr || !c->col || !c->val || !c->features || !c->seeds || !c->bad || !c->workspace) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (c->ld_features < c->in_feats) return dh::fail(DH_ERR_INVALID, "%s: ld_features < in_feats", me);
+  if (!adam_ok(c->w1) || !adam_ok(c->b1) || !adam_ok(c->w2) || !adam_ok(c->b2)) return dh::fail(DH_ERR_INVALID, "%s: incomplete Adam state", me);
+  if (c->dropout < 0.f || c->dropout >= 1.f || c->decoder_dropout < 0.f || c->decoder_dropout >= 1.f) return dh::fail(DH_ERR_INVALID, "%s: dropout outside [0, 1)", me);
+  if (c->phase < 0 || c->phase > 2 || (c->phase != 0 && (n_steps != 1 || !c->grads))) return dh::fail(DH_ERR_INVALID, "%s: phases 1 / 2 take one step and a gradient buffer", me);
+  if (c->phase != 2 && (!c->z_out || !c->loss_out)) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  const int B = (int)c->batch, F = (int)c->in_feats, H = (int)c->hidden, E = (int)c->emb, G = (int)c->n_genes;
+  const GscLayout l = gsc_layout(G, B, F, H, E);
+  if (c->workspace_bytes < l.total) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, c->workspace_bytes, l.total);
+  hipStream_t st = dh::as_stream(stream);
+  char* ws = static_cast<char*>(c->workspace);
+  GscArgs a{};
+  a.rowptr = c->rowptr; a.col = c->col; a.val = c->val; a.X = c->features; a.ldx = c->ld_features; a.n_nodes = c->n_nodes;
+  a.G = G; a.B = B; a.F = F; a.H = H; a.E = E; a.FP = std::min(pow2_at_least(F), 64); a.mean = c->agg_mean ? 1 : 0;
+  a.W1 = c->w1.param; a.b1 = c->b1.param; a.W2 = c->w2.param; a.b2 = c->b2.param;
+  float* w2t = reinterpret_cast<float*>(ws + l.w2t);
+  a.w2t = w2t;
+  a.count = reinterpret_cast<int32_t*>(ws + l.count);
+  a.coef = reinterpret_cast<float*>(ws + l.coef);
+  a.xdg = reinterpret_cast<float*>(ws + l.xdg);
+  a.ax2 = reinterpret_cast<float*>(ws + l.ax2);
+  a.h2 = reinterpret_cast<float*>(ws + l.h2);
+  a.zd2 = reinterpret_cast<float*>(ws + l.zd2);
+  a.demb = reinterpret_cast<float*>(ws + l.demb);
+  a.dpre = reinterpret_cast<float*>(ws + l.dpre);
+  a.rowloss = reinterpret_cast<double*>(ws + l.rowloss);
+  a.bad = c->bad;
+  const AdamHyper hy{c->lr, c->beta1, c->beta2, c->eps, c->weight_decay};
+  StepCounters sc{};
+  sc.step[0] = c->w1.step; sc.step[1] = c->b1.step; sc.step[2] = c->w2.step; sc.step[3] = c->b2.step;
+  sc.n = 4;
+  // the job table of the gradient kernel (constant over the steps)
+  MsGradArgs ga{};
+  float* g = c->phase ? c->grads : nullptr;
+  const int64_t o_b1 = (int64_t)F * H, o_w2 = o_b1 + H, o_b2 = o_w2 + (int64_t)E * H;
+  set_job(ga.job[0], a.ax2, F, a.dpre, H, F, H, B, c->w1, nullptr, g);                       // dW1 = AX^T dPre
+  set_job(ga.job[1], nullptr, 0, a.dpre, H, 1, H, B, c->b1, nullptr, g ? g + o_b1 : nullptr); // db1
+  set_job(ga.job[2], a.demb, E, a.h2, H, E, H, B, c->w2, w2t, g ? g + o_w2 : nullptr);        // dW2 = dEmb^T h
+  set_job(ga.job[3], nullptr, 0, a.demb, E, 1, E, B, c->b2, nullptr, g ? g + o_b2 : nullptr); // db2
+  ga.n_jobs = 4;
+  place_tiles(ga);
+  ga.adam = c->phase == 0;
+  ga.hy = hy;
+  ga.coef = a.coef;
+  ga.bdrop = make_drop(0.f, 0, 0);
+  ga.rowloss_d = a.rowloss;
+  ga.n_rowloss = B;
+  const double b = (double)B;
+  const double pos_weight = (b * b - b) / b, norm = b * b / ((b * b - b) * 2.0);  // graphsc.py:210-214 with adj = I
+  ga.loss_div = b * b;
+  ga.loss_mul = (float)norm;
+  ga.zero_i32 = a.count;
+  ga.n_zero = G;
+  if (c->phase == 2) {
+    int64_t longest = 0;
+    for (int j = 0; j < ga.n_jobs; ++j) longest = std::max<int64_t>(longest, (int64_t)ga.job[j].M * ga.job[j].N);
+    hipLaunchKernelGGL(ms_adam_kernel, dim3((unsigned)dh::ceil_div(longest, 256), (unsigned)ga.n_jobs), dim3(256), 0, st, ga);
+    return dh::check_launch(me);
+  }
+  // the mirror of W2 and the gene counters may be stale (an eager step in between, a first call): one launch each per call
+  hipLaunchKernelGGL(ms_transpose_kernel, dim3((unsigned)dh::ceil_div((int64_t)E * H, 256)), dim3(256), 0, st, E, H, c->w2.param, w2t);
+  if (dh::zero_async(a.count, (size_t)G * 4, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: clearing the counters failed", me);
+  const bool drop = c->dropout > 0.f;
+  const int nb_count = (B + 3) / 4;
+  const int nb_drop = drop ? (int)dh::ceil_div(2 * (((int64_t)G * F + 3) / 4), 256) : 0;
+  const size_t dec_lds = (size_t)(2 * E + B) * sizeof(float);
+  for (int64_t s = first_step; s < first_step + n_steps; ++s) {
+    const uint64_t gstep = c->step0 + (uint64_t)s;
+    const Drop dx = make_drop(c->dropout, c->seed, gstep), dd = make_drop(c->decoder_dropout, c->seed, gstep);
+    const int64_t* seeds = c->seeds + s * B;
+    hipLaunchKernelGGL(gsc_prepare_kernel, dim3((unsigned)(nb_count + nb_drop)), dim3(256), 0, st, a, seeds, dx, sc, hy, nb_count);
+    hipLaunchKernelGGL(gsc_forward_kernel, dim3((unsigned)B, 2), dim3(256), 0, st, a, seeds, dx, dd, c->z_out + s * (int64_t)B * E);
+    hipLaunchKernelGGL(gsc_decoder_kernel, dim3((unsigned)B), dim3(256), dec_lds, st, a, dd, (float)pos_weight, (float)(norm / (b * b)));
+    ga.loss_out = c->loss_out + s;
+    hipLaunchKernelGGL(ms_grad_kernel, dim3((unsigned)(ga.total_tiles + 1)), dim3(256), 0, st, ga);
+  }
+  return dh::check_launch(me);
+}
+
+// ---- scDeepSort ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct SdsLayout {
+  size_t coef, h1, dh1, dlog, rowloss, total;
+};
+SdsLayout sds_layout(int64_t B, int64_t D, int64_t H, int64_t C) {
+  SdsLayout l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o += a256(bytes);
+    return at;
+  };
+  l.coef = take(16);
+  l.h1 = take((size_t)B * H * 4);
+  l.dh1 = take((size_t)B * H * 4);
+  l.dlog = take((size_t)B * C * 4);
+  l.rowloss = take((size_t)B * 4);
+  l.total = o;
+  return l;
+}
+}  // namespace
+
+extern "C" int dh_scdeepsort_step_supported(int64_t batch, int64_t dim_in, int64_t hidden, int64_t n_classes) {
+  // sds_loss keeps W2 [C, H + 1] and four rows in LDS; sds_neigh four features per thread
+  return (batch >= 1 && batch <= 65536 && dim_in >= 1 && dim_in <= 1024 && hidden >= 1 && hidden <= 1024 && n_classes >= 1 && n_classes <= 64 &&
+          (n_classes * (hidden + 1) + 4 * (hidden + 64)) * 4 <= 60 * 1024) ? 1 : 0;
+}
+
+extern "C" size_t dh_scdeepsort_step_workspace_bytes(int64_t batch, int64_t dim_in, int64_t hidden, int64_t n_classes) {
+  if (!dh_scdeepsort_step_supported(batch, dim_in, hidden, n_classes)) return 0;
+  return sds_layout(batch, dim_in, hidden, n_classes).total;
+}
+
+extern "C" int dh_scdeepsort_steps(const dh_scdeepsort_step_t* c, int64_t first_step, int64_t n_steps, dh_stream_t stream) {
+  const char* me = "dh_scdeepsort_steps";
+  if (!c) return dh::fail(DH_ERR_INVALID, "%s: null configuration", me);
+  if (first_step < 0 || n_steps < 0) return dh::fail(DH_ERR_INVALID, "%s: negative step range", me);
+  if (n_steps == 0) return DH_OK;
+  if (!dh_scdeepsort_step_supported(c->batch, c->dim_in, c->hidden, c->n_classes))
+    return dh::fail(DH_ERR_INVALID, "%s: batch %lld, %lld -> %lld -> %lld outside dh_scdeepsort_step_supported", me, (long long)c->batch, (long long)c->dim_in,
+                    (long long)c->hidden, (long long)c->n_classes);
+  if (c->n_genes < 0 || c->n_nodes <= 0 || c->n_nodes >= ((int64_t)1 << 31)) return dh::fail(DH_ERR_INVALID, "%s: bad node counts", me);
+  if (!c->features || !c->labels || !c->seeds || !c->bad || !c->workspace) return dh::fail(DH_ERR_INVALID, "%s: null pointer", me);
+  if (c->neigh_out && (!c->rowptr || !c->col || !c->val || !c->cell_id || !c->alpha)) return dh::fail(DH_ERR_INVALID, "%s: the aggregation needs the graph, cell_id and alpha", me);
+  if (c->ld_features < c->dim_in) return dh::fail(DH_ERR_INVALID, "%s: ld_features < dim_in", me);
+  if (!adam_ok(c->w1) || !adam_ok(c->b1) || !adam_ok(c->w2) || !adam_ok(c->b2)) return dh::fail(DH_ERR_INVALID, "%s: incomplete Adam state", me);
+  if (c->dropout < 0.f || c->dropout >= 1.f) return dh::fail(DH_ERR_INVALID, "%s: dropout outside [0, 1)", me);
+  if (c->phase < 0 || c->phase > 2 || (c->phase != 0 && (n_steps != 1 || !c->grads))) return dh::fail(DH_ERR_INVALID, "%s: phases 1 / 2 take one step and a gradient buffer", me);
+  if (c->phase != 2 && !c->loss_out) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  const int B = (int)c->batch, D = (int)c->dim_in, H = (int)c->hidden, C = (int)c->n_classes;
+  const SdsLayout l = sds_layout(B, D, H, C);
+  if (c->workspace_bytes < l.total) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, c->workspace_bytes, l.total);
+  hipStream_t st = dh::as_stream(stream);
+  char* ws = static_cast<char*>(c->workspace);
+  SdsArgs a{};
+  a.rowptr = c->rowptr; a.col = c->col; a.val = c->val; a.X = c->features; a.ldx = c->ld_features; a.n_nodes = c->n_nodes;
+  a.x_bf16 = c->features_bf16 ? 1 : 0; a.G = (int)c->n_genes; a.B = B; a.D = D; a.H = H; a.C = C;
+  a.cell_id = c->cell_id; a.labels = c->labels; a.alpha = c->alpha;
+  a.W1 = c->w1.param; a.b1 = c->b1.param; a.W2 = c->w2.param; a.b2 = c->b2.param;
+  a.coef = reinterpret_cast<float*>(ws + l.coef);
+  a.h1 = reinterpret_cast<float*>(ws + l.h1);
+  a.dh1 = reinterpret_cast<float*>(ws + l.dh1);
+  a.dlog = reinterpret_cast<float*>(ws + l.dlog);
+  a.rowloss = reinterpret_cast<float*>(ws + l.rowloss);
+  a.neigh = c->neigh_out;
+  a.bad = c->bad;
+  const AdamHyper hy{c->lr, c->beta1, c->beta2, c->eps, c->weight_decay};
+  StepCounters sc{};
+  sc.step[0] = c->w1.step; sc.step[1] = c->b1.step; sc.step[2] = c->w2.step; sc.step[3] = c->b2.step;
+  sc.n = 4;
+  MsGradArgs ga{};
+  float* g = c->phase ? c->grads : nullptr;
+  const int64_t o_b1 = (int64_t)H * D, o_w2 = o_b1 + H, o_b2 = o_w2 + (int64_t)C * H;
+  set_job(ga.job[0], a.dh1, H, c->features, c->ld_features, H, D, B, c->w1, nullptr, g);      // dW1 = dH1^T dropout(X[seeds])
+  ga.job[0].b_bf16 = a.x_bf16;
+  ga.job[0].b_drop = 1;
+  set_job(ga.job[1], nullptr, 0, a.dh1, H, 1, H, B, c->b1, nullptr, g ? g + o_b1 : nullptr);   // db1
+  set_job(ga.job[2], a.dlog, C, a.h1, H, C, H, B, c->w2, nullptr, g ? g + o_w2 : nullptr);     // dW2 = dLogits^T h1
+  set_job(ga.job[3], nullptr, 0, a.dlog, C, 1, C, B, c->b2, nullptr, g ? g + o_b2 : nullptr);  // db2
+  ga.n_jobs = 4;
+  place_tiles(ga);
+  ga.adam = c->phase == 0;
+  ga.hy = hy;
+  ga.coef = a.coef;
+  ga.rowloss_f = a.rowloss;
+  ga.n_rowloss = B;
+  ga.loss_div = 1.0;
+  ga.loss_mul = 1.f;
+  if (c->phase == 2) {
+    int64_t longest = 0;
+    for (int j = 0; j < ga.n_jobs; ++j) longest = std::max<int64_t>(longest, (int64_t)ga.job[j].M * ga.job[j].N);
+    hipLaunchKernelGGL(ms_adam_kernel, dim3((unsigned)dh::ceil_div(longest, 256), (unsigned)ga.n_jobs), dim3(256), 0, st, ga);
+    return dh::check_launch(me);
+  }
+  const int DP = std::min(pow2_at_least(D), 256);
+  const size_t neigh_lds = (size_t)(256 / DP) * D * sizeof(float);
+  // rows that start on 16-byte (fp32) / 8-byte (bf16) boundaries take the vector kernel
+  const bool neigh_vec = D % 4 == 0 && c->ld_features % 4 == 0 && (reinterpret_cast<uintptr_t>(c->features) & 15u) == 0;
+  const size_t loss_lds = (size_t)(C * (H + 1) + 4 * (H + 64)) * sizeof(float);
+  for (int64_t s = first_step; s < first_step + n_steps; ++s) {
+    const Drop dz = make_drop(c->dropout, c->seed, c->step0 + (uint64_t)s);
+    const int64_t* seeds = c->seeds + s * B;
+    if (c->neigh_out) {
+      if (neigh_vec) {
+        const size_t lds = (size_t)4 * D * sizeof(float);
+        const int nq = (D / 4 + 63) / 64;
+#define DH_NEIGH(NQ)                                                                                                          \
+  do {                                                                                                                        \
+    if (a.x_bf16) hipLaunchKernelGGL((sds_neigh_vec_kernel<NQ, true>), dim3((unsigned)B), dim3(256), lds, st, a, seeds);   \
+    else hipLaunchKernelGGL((sds_neigh_vec_kernel<NQ, false>), dim3((unsigned)B), dim3(256), lds, st, a, seeds);          \
+  } while (0)
+        if (nq <= 1) DH_NEIGH(1);
+        else if (nq <= 2) DH_NEIGH(2);
+        else DH_NEIGH(4);
+#undef DH_NEIGH
+      } else {
+        hipLaunchKernelGGL(sds_neigh_kernel, dim3((unsigned)B), dim3(256), neigh_lds, st, a, seeds);
+      }
+    }
+    hipLaunchKernelGGL(sds_hidden_kernel, dim3((unsigned)dh::ceil_div(H, MS_T), (unsigned)dh::ceil_div(B, MS_T)), dim3(256), 0, st, a, seeds, dz, sc, hy);
+    hipLaunchKernelGGL(sds_loss_kernel, dim3((unsigned)dh::ceil_div(B, 4)), dim3(256), loss_lds, st, a, seeds);
+    ga.job[0].b_rows = seeds;
+    ga.bdrop = dz;
+    ga.loss_out = c->loss_out + s;
+    hipLaunchKernelGGL(ms_grad_kernel, dim3((unsigned)(ga.total_tiles + 1)), dim3(256), 0, st, ga);
+  }
+  return dh::check_launch(me);
+}

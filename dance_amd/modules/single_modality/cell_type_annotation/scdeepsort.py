@@ -56,6 +56,12 @@ class GNN(nn.Module):
 HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
 HIPGRAPH_MIN_BATCHES = int(os.environ.get("DANCE_AMD_HIPGRAPH_MIN_BATCHES", "64"))  # the capture (two eager steps + instantiation, tens of ms) must be amortised
 HIPGRAPH_MAX_BATCH = int(os.environ.get("DANCE_AMD_HIPGRAPH_MAX_BATCH", "2048"))    # above this a step is kernel-bound: replaying gains little (see fit)
+# The persistent step (dance_amd/ministep.py, csrc/ministep.hip): every full training batch of an epoch behind ONE C call, four launches
+# per step (five with the reference's discarded aggregation), straight off the graph's CSR rows.  The default for the reference's model
+# shape (one AdaptiveSAGE layer whose output ignores the aggregation + ReLU, Linear head) up to MINISTEP_MAX_BATCH cells per batch; above
+# that the Linear layers want the large-tile / bf16 GEMMs of the general loop.  DANCE_AMD_MINISTEP=0: the captured / eager loop.
+MINISTEP = os.environ.get("DANCE_AMD_MINISTEP", "1") != "0"
+MINISTEP_MAX_BATCH = int(os.environ.get("DANCE_AMD_MINISTEP_MAX_BATCH", "4096"))
 
 
 class ScDeepSort(BaseClassificationMethod):
@@ -162,6 +168,12 @@ class ScDeepSort(BaseClassificationMethod):
         self.optimizer = torch.optim.Adam(self.model.parameters(), lr=lr, weight_decay=weight_decay, capturable=self._use_graph,
                                           fused=str(self.device).startswith("cuda"))  # one kernel per step instead of ~14
         self.loss_fn = CrossEntropySum()  # nn.CrossEntropyLoss(reduction="sum") of :185 as one kernel (torch's nll_loss reductions are one workgroup)
+        from ....ministep import ScDeepSortStepper
+        self._stepper = None
+        self._use_mini = (MINISTEP and not self.capture_split and str(self.device).startswith("cuda") and n_full >= 1 and self.batch_size <= MINISTEP_MAX_BATCH
+                          and ScDeepSortStepper.eligible(self.model, graph, self.batch_size, self.optimizer, self.num_labels))
+        if self._use_mini:
+            self._use_graph = False
 
         # more than one process: data parallelism over the training cells (the graph is replicated, the model is small):
         # every rank trains on its share, gradients are averaged with one flat all-reduce per step (dance_amd/sharding.py)
@@ -235,7 +247,22 @@ class ScDeepSort(BaseClassificationMethod):
         from .... import sharding
         if getattr(self, "_world", 1) > 1:
             idx = sharding.shard_seed_ids(idx)
-        if getattr(self, "_use_graph", False) and idx.numel() // self.batch_size >= 1:
+        if getattr(self, "_use_mini", False) and idx.numel() // self.batch_size >= 1:
+            from ....ministep import ScDeepSortStepper
+            idx = idx.to(self.device)
+            perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else
+                    torch.randperm(idx.numel(), generator=self.shuffle_generator).to(idx.device))  # the loader's own order
+            idx = idx[perm].contiguous()
+            n_full = idx.numel() // self.batch_size
+            if self._stepper is None or self._stepper.g is not graph:
+                self._stepper = ScDeepSortStepper(self.model, graph, self.batch_size, self.optimizer, getattr(self, "_world", 1))
+            loss_all = torch.empty(n_full, dtype=torch.float32, device=idx.device)
+            self._stepper.run(idx, n_full, loss_all)  # all full batches of the epoch: one C call
+            self._stepper.check_flags("ScDeepSort.fit", mask=5)  # one read per epoch
+            losses, sizes = list(loss_all.unbind(0)), [self.batch_size] * n_full
+            tail = idx[n_full * self.batch_size:]
+            batches = [self.sampler.sample(graph, tail, True)] if tail.numel() else []
+        elif getattr(self, "_use_graph", False) and idx.numel() // self.batch_size >= 1:
             idx = idx.to(self.device)
             perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else
                     torch.randperm(idx.numel(), generator=self.shuffle_generator).to(idx.device))  # the loader's own order

@@ -335,6 +335,14 @@ HIPGRAPH = os.environ.get("DANCE_AMD_HIPGRAPH", "1") != "0"
 HIPGRAPH_MIN_BATCHES = int(os.environ.get("DANCE_AMD_HIPGRAPH_MIN_BATCHES", "64"))  # capturing costs two eager steps + the instantiation (tens of ms): it must be amortised
 HIPGRAPH_MAX_BATCH = int(os.environ.get("DANCE_AMD_HIPGRAPH_MAX_BATCH", "2048"))   # above this a step is kernel-bound and replaying it gains little
 
+# The persistent step (dance_amd/ministep.py, csrc/ministep.hip): every full batch of an epoch behind ONE C call, four launches per step,
+# straight off the graph's CSR rows (no block, no transposed copy, Adam in the gradient kernel's epilogue).  The default wherever it
+# applies — the reference's own model shape (one WeightedGraphConv norm="both" + ReLU, one Linear, linear decoder) on a CellFeatureGraph-
+# layout graph with cell seeds, batches up to MINISTEP_MAX_BATCH (a seed's row of z z^T is one workgroup's job there: it stops paying
+# once the all-pairs decoder wants the matrix cores).  DANCE_AMD_MINISTEP=0: the captured hipGraph step / the eager loop below.
+MINISTEP = os.environ.get("DANCE_AMD_MINISTEP", "1") != "0"
+MINISTEP_MAX_BATCH = int(os.environ.get("DANCE_AMD_MINISTEP_MAX_BATCH", "512"))
+
 
 class _CapturedStep:
     """The training step of ``GraphSC.fit`` on a ``StaticCellBlock``, captured as one ``torch.cuda.CUDAGraph`` (= hipGraph)."""
@@ -481,11 +489,35 @@ class GraphSC(BaseClusteringMethod):
         # fused: one multi-tensor kernel per step instead of ~14 — inside the captured step of batch 128 that is 0.57 -> 0.47 ms per batch
         optim = torch.optim.Adam(self.model.parameters(), lr=lr, capturable=use_graph, fused=g.device.type == "cuda")
         captured = None
+        from ....ministep import GraphSCStepper
+        use_mini = (MINISTEP and fused and dataloader.cells_only and g.device.type == "cuda" and n_full >= 1 and 1 < batch_size <= MINISTEP_MAX_BATCH
+                    and not self.capture_split and GraphSCStepper.eligible(self.model, g, batch_size, optim))
+        stepper = GraphSCStepper(self.model, g, batch_size, optim, world) if use_mini else None
+        use_graph = use_graph and not use_mini
+        self.step_mode = "ministep" if use_mini else "hipgraph" if use_graph else "eager"
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
             self.model.train()
             z, order, losses = [], [], []
-            if use_graph:
+            if use_mini:
+                # the loader's own seed order (``DataLoader.__iter__``), all full batches of the epoch in one call
+                idx = dataloader.indices
+                perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else
+                        torch.randperm(idx.numel(), generator=self.shuffle_generator).to(idx.device))
+                idx = idx[perm].contiguous()
+                z_all = torch.empty((n_full * batch_size, self.model.embedding_dim), dtype=torch.float32, device=g.device)
+                loss_all = torch.empty(n_full, dtype=torch.float32, device=g.device)
+                stepper.run(idx, n_full, z_all, loss_all)
+                stepper.check_flags("GraphSC.fit")  # one read per epoch
+                z.append(z_all)
+                order.append(g.ndata["order"][idx[:n_full * batch_size]])
+                losses.extend(loss_all.unbind(0))
+                batches = []
+                if n_full * batch_size < idx.numel():  # the short last batch runs eagerly
+                    tail = sampler.sample(g, idx[n_full * batch_size:], True)
+                    tail[2][-1].hook_out = _dst_edge_hook(tail[2])
+                    batches = [tail]
+            elif use_graph:
                 # same seed order as the loader's (``DataLoader.__iter__``): one permutation per epoch from the same generator
                 idx = dataloader.indices
                 perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else

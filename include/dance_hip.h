@@ -732,6 +732,88 @@ DH_API int dh_adam_step_f32(int n, float* const* params, const float* const* gra
                      float* const* step, const int64_t* numel, float lr, float beta1, float beta2, float eps, float weight_decay,
                      dh_stream_t stream);
 
+/* ---- the persistent mini-batch steps (ministep.hip) ---------------------------------------------------------------------------------
+ * One call = a run of consecutive training steps of the reference's mini-batch loops at its default batch sizes, 4 launches per step,
+ * no host read, nothing but kernels on the stream.  The kernels walk the seed cells' rows of the CellFeatureGraph-layout CSR directly
+ * (genes are nodes [0, n_genes), a cell row = its genes ascending + its self loop): no block, no renumbering, no transposed copy.
+ * Adam state is torch.optim.Adam's own (exp_avg, exp_avg_sq, one float32 step counter per tensor, all on the device), updated in place.
+ * Dropout masks are Philox4x32-10 draws keyed by (seed, step0 + step index, layer, element).
+ * bad[0] collects flags (never cleared here): 1 = a seed is not a cell row of that layout, 2 = a seed without exactly one self loop
+ * (graph-sc's identity decoder target), 4 = a label outside [0, n_classes).
+ * phase: 0 = whole steps; 1 = stop after the gradients, written to `grads` (flat: w1 | b1 | w2 | b2) — the data-parallel form, the
+ * caller all-reduces them; 2 = apply `grads` (Adam only).  Phases 1 and 2 take n_steps == 1.                                            */
+typedef struct dh_adam_state { /* one parameter tensor of torch.optim.Adam (amsgrad = False) */
+  float* param;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* step;
+} dh_adam_state_t;
+
+/* graph-sc: dance/modules/single_modality/clustering/graphsc.py:181-230 (the batch loop of GraphSC.fit), :274-383 (GCNAE: one
+ * WeightedGraphConv in_feats -> hidden norm="both" + ReLU, one Linear hidden -> emb), :386-411 (inner-product decoder), :414-484.
+ * Per step s (seeds[s * batch .. + batch)): z_out[s * batch + i] = the embedding of the FIRST forward (:202-203), loss_out[s] = the
+ * loss of the second (:215-216), then Adam (:217-219).  Aggregate-first order (AX, then (AX) W1): see ministep.hip.                      */
+typedef struct dh_graphsc_step {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  const float* features; /* [n_nodes, in_feats] */
+  int64_t ld_features, n_nodes, n_genes;
+  int64_t batch, in_feats, hidden, emb;
+  int32_t agg_mean; /* fn.mean instead of fn.sum (:463-465) */
+  int32_t phase;
+  dh_adam_state_t w1, b1, w2, b2; /* layer1.weight [in_feats, hidden], layer1.bias, encoder.0.weight [emb, hidden], encoder.0.bias */
+  float lr, beta1, beta2, eps, weight_decay;
+  float dropout, decoder_dropout;
+  uint64_t seed, step0;
+  const int64_t* seeds;
+  float* z_out;
+  float* loss_out;
+  int32_t* bad;
+  float* grads;
+  void* workspace;
+  size_t workspace_bytes;
+} dh_graphsc_step_t;
+DH_API int dh_graphsc_step_supported(int64_t batch, int64_t in_feats, int64_t hidden, int64_t emb);
+DH_API size_t dh_graphsc_step_workspace_bytes(int64_t n_genes, int64_t batch, int64_t in_feats, int64_t hidden, int64_t emb);
+DH_API int dh_graphsc_steps(const dh_graphsc_step_t* cfg_host, int64_t first_step, int64_t n_steps, dh_stream_t stream);
+
+/* scDeepSort: dance/modules/single_modality/cell_type_annotation/scdeepsort.py:222-257 (cal_loss), :26-88 (GNN: one AdaptiveSAGE
+ * dim_in -> hidden + ReLU, Linear hidden -> n_classes), dance/models/nn/gnn.py:62-96 (the layer output is Linear(dropout(h_dst)); the
+ * weighted-mean aggregation is computed and dropped: neigh_out != NULL keeps computing it — [batch, dim_in] of the last step —,
+ * NULL skips it), :185 (CrossEntropyLoss(reduction="sum")).  loss_out[s] = the summed loss of step s.                                    */
+typedef struct dh_scdeepsort_step {
+  const int32_t* rowptr;
+  const int32_t* col;
+  const float* val;
+  const void* features; /* [n_nodes, dim_in] f32, or bf16 when features_bf16 */
+  int64_t ld_features, n_nodes, n_genes;
+  const int32_t* cell_id; /* [n_nodes]: gene index, -1 for cells */
+  const int64_t* labels;  /* [n_nodes] */
+  const float* alpha;     /* [n_genes + 2] */
+  int64_t batch, dim_in, hidden, n_classes;
+  int32_t features_bf16;
+  int32_t phase;
+  dh_adam_state_t w1, b1, w2, b2; /* layers.0.layers.1.weight [hidden, dim_in], .bias, linear.weight [n_classes, hidden], .bias */
+  float lr, beta1, beta2, eps, weight_decay;
+  float dropout;
+  uint64_t seed, step0;
+  const int64_t* seeds;
+  float* loss_out;
+  float* neigh_out;
+  int32_t* bad;
+  float* grads;
+  void* workspace;
+  size_t workspace_bytes;
+} dh_scdeepsort_step_t;
+DH_API int dh_scdeepsort_step_supported(int64_t batch, int64_t dim_in, int64_t hidden, int64_t n_classes);
+DH_API size_t dh_scdeepsort_step_workspace_bytes(int64_t batch, int64_t dim_in, int64_t hidden, int64_t n_classes);
+DH_API int dh_scdeepsort_steps(const dh_scdeepsort_step_t* cfg_host, int64_t first_step, int64_t n_steps, dh_stream_t stream);
+
+/* The dropout draw of the two loops as a standalone launch (tests, known-answer checks of the generator): out[e] = 0 or 1 / (1 - p)
+ * for element e of stream `sid` at step `step`.                                                                                          */
+DH_API int dh_ministep_dropout_mask_f32(int64_t n, float p, uint64_t seed, uint64_t step, int32_t sid, float* out, dh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,8 +380,8 @@ def test_bf16_weight_gradient_full_size(cuda_device):
     assert float((small.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
 
 
-def test_captured_fits_survive_the_eager_last_batch(cuda_device):
-    """Regression (round 4): three epochs of GraphSC.fit at batch 128 and of ScDeepSort.fit at batch 500 on 100k cells, every full
+def test_captured_fits_survive_the_eager_last_batch(cuda_device, monkeypatch):
+    """(The hipGraph path — since round 6 the fallback for shapes the persistent step does not cover; forced here.)  Regression (round 4): three epochs of GraphSC.fit at batch 128 and of ScDeepSort.fit at batch 500 on 100k cells, every full
     batch replayed from a captured hipGraph and the short last batch of each epoch run eagerly.  The eager batch's
     ``optimizer.zero_grad()`` used to drop the last reference to the gradient tensors the graph writes; at this size the allocator
     then released their memory and the next epoch's replays died with a GPU memory access fault (toy sizes never released the
@@ -390,10 +390,15 @@ def test_captured_fits_survive_the_eager_last_batch(cuda_device):
 
     from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
     from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    from dance_amd.modules.single_modality.cell_type_annotation import scdeepsort as sds_mod
+    from dance_amd.modules.single_modality.clustering import graphsc as gsc_mod
+    monkeypatch.setattr(gsc_mod, "MINISTEP", False)
+    monkeypatch.setattr(sds_mod, "MINISTEP", False)
     n_cells = 100_000
     cg = _cellgene_graph(n_cells, 2000, 200, 50, seed=6)
     m = GraphSC(in_feats=50, n_clusters=10, device="cuda")
     m.fit(cg, epochs=3, batch_size=128)                                   # 781 captured steps + a batch of 32 per epoch
+    assert m.step_mode == "hipgraph"
     assert len(m.losses) == 3 * 782 and np.isfinite(m.losses).all() and m.get_latent().shape[0] == n_cells
     labels = torch.randint(0, 8, (n_cells, ), generator=torch.Generator().manual_seed(0))
     with tempfile.TemporaryDirectory() as tmp:
@@ -403,6 +408,28 @@ def test_captured_fits_survive_the_eager_last_batch(cuda_device):
         s2 = ScDeepSort(50, 32, 1, "synthetic", "reg2", batch_size=500, device="cuda", save_root=tmp, verbose=False)
         s2.fit(cg, labels, epochs=3, lr=1e-3, val_ratio=0.2037)            # ... and with a short last batch
         assert np.isfinite(s2.predict_proba(cg)).all()
+
+
+def test_ministep_fits_at_the_reference_batch_sizes(cuda_device):
+    """The default path since round 6: three epochs of GraphSC.fit at batch 128 (781 persistent steps + an eager batch of 32 per epoch) and
+    of ScDeepSort.fit at batch 500 on 100k cells x 2000 genes, the eager last batch sharing the optimiser state with the fused update."""
+    import tempfile
+
+    from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
+    from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
+    n_cells = 100_000
+    cg = _cellgene_graph(n_cells, 2000, 200, 50, seed=6)
+    m = GraphSC(in_feats=50, n_clusters=10, device="cuda")
+    m.fit(cg, epochs=3, batch_size=128)
+    assert m.step_mode == "ministep"
+    assert len(m.losses) == 3 * 782 and np.isfinite(m.losses).all() and m.get_latent().shape[0] == n_cells and np.isfinite(m.get_latent()).all()
+    assert np.mean(m.losses[-100:]) < np.mean(m.losses[:100])   # it trains
+    labels = torch.randint(0, 8, (n_cells, ), generator=torch.Generator().manual_seed(0))
+    with tempfile.TemporaryDirectory() as tmp:
+        for ratio in (0.2, 0.2037):  # without and with a short last batch
+            s = ScDeepSort(50, 32, 1, "synthetic", "mini", batch_size=500, device="cuda", save_root=tmp, verbose=False)
+            s.fit(cg, labels, epochs=3, lr=1e-3, val_ratio=ratio)
+            assert s._use_mini and s._stepper is not None and np.isfinite(s.predict_proba(cg)).all()
 
 
 def test_splitk_window_wider_than_one_round_of_sets(cuda_device):

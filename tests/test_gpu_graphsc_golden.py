@@ -209,6 +209,7 @@ def test_graphsc_fit_captured_step_vs_reference(cuda_device, gold, monkeypatch):
     same golden the eager loop is pinned to — and the eager loop's, to fp32 rounding."""
     from dance_amd.modules.single_modality.clustering import graphsc
     monkeypatch.setattr(graphsc, "HIPGRAPH_MIN_BATCHES", 1)
+    monkeypatch.setattr(graphsc, "MINISTEP", False)  # the hipGraph path: the fallback for shapes the persistent step (tests/test_gpu_ministep.py) does not cover
     res = {}
     for on in (True, False, "split"):  # "split": the step as two graphs with the (here: one-rank) gradient all-reduce between them
         monkeypatch.setattr(graphsc, "HIPGRAPH", bool(on))

@@ -203,6 +203,7 @@ def test_scdeepsort_captured_step_equals_eager(cuda_device, tmp_path, monkeypatc
     layer(sb, sb.srcdata["features"])
     assert int(sb.bad) == 0 and rel_err(layer.last_neigh.cpu().numpy(), ref_neigh.cpu().numpy()) < 1e-5
     monkeypatch.setattr(scdeepsort, "HIPGRAPH_MIN_BATCHES", 1)
+    monkeypatch.setattr(scdeepsort, "MINISTEP", False)  # the hipGraph path: the fallback for shapes the persistent step (tests/test_gpu_ministep.py) does not cover
     for cd, tol in (("fp32", 1e-5), ("bf16", 2e-2)):
         out = {}
         for on in (True, False, "split"):  # "split": two graphs per step with the (here: one-rank) gradient all-reduce between them
