@@ -20,7 +20,7 @@
 // graph-sc step (B seeds, G genes, F -> H -> E; two forwards per batch as graphsc.py:202,215 writes it):
 //   gsc_prepare : per-gene out-degree of the batch (int atomics), layout checks, dropout of the G x F gene rows for both forwards,
 //                 Adam step counters + bias corrections
-//   gsc_forward : one workgroup per (seed, forward): AX (row gather over the CSR row, D_out^-1/2 per source, D_in^-1/2), ReLU(AX W1 + b1),
+//   gsc_forward : one workgroup per seed, both forwards: AX (row gather over the CSR row, D_out^-1/2 per source, D_in^-1/2), ReLU(AX W1 + b1),
 //                 Linear; forward 0 writes the epoch's embedding, forward 1 keeps AX, h and the decoder-dropped embedding
 //   gsc_decoder : one workgroup per seed: its row of z z^T, weighted BCE against the identity target (the only cell -> cell edges of a
 //                 batch are the self loops; checked by gsc_prepare), d/dz, decoder-dropout backward, Linear backward, ReLU mask
@@ -33,6 +33,7 @@
 //
 // Deterministic: fixed summation orders everywhere (integer atomics only).  No memset / memcpy nodes (capturable), no host reads.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -94,6 +95,97 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// sum_k v[k] * g[k * stride] for k < n, U global loads in flight per thread (v in LDS / registers-by-broadcast).  A dependent round trip
+// to L2 / MALL costs ~1 us in these one-workgroup-per-CU kernels (every step rewrites weights and activations, so a kernel's first touch
+// of a line is never an L1 / own-L2 hit): the chains are kept SHORT — n / U rounds — rather than the loads few.  Clamped addresses, zero
+// weights past n: no serial remainder loop.
+template <int U>
+__device__ __forceinline__ float dot_strided(const float* v, const float* __restrict__ g, int64_t stride, int n) {
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < n; k0 += U) {
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = g[(int64_t)min(k0 + u, n - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u & 3] = fmaf(v[min(k0 + u, n - 1)], k0 + u < n ? w[u] : 0.f, acc[u & 3]);  // (a select on the VALUE: a guarded LDS read is a branch)
+  }
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// two vectors against the same strided column (both forwards of a seed share the weight loads)
+template <int U>
+__device__ __forceinline__ void dot2_strided(const float* v0, const float* v1, const float* __restrict__ g, int64_t stride, int n, float& r0, float& r1) {
+  float a0[2] = {0.f, 0.f}, a1[2] = {0.f, 0.f};
+  for (int k0 = 0; k0 < n; k0 += U) {
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w[u] = g[(int64_t)min(k0 + u, n - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kc = min(k0 + u, n - 1);
+      const float wu = k0 + u < n ? w[u] : 0.f;
+      a0[u & 1] = fmaf(v0[kc], wu, a0[u & 1]);
+      a1[u & 1] = fmaf(v1[kc], wu, a1[u & 1]);
+    }
+  }
+  r0 = a0[0] + a0[1];
+  r1 = a1[0] + a1[1];
+}
+
+__device__ __forceinline__ float load_feat(const void* X, int bf16, int64_t idx);
+__device__ __forceinline__ uint32_t feat_word(const void* X, int bf16, int64_t idx);
+__device__ __forceinline__ float feat_value(uint32_t w, int bf16, int64_t idx);
+
+// r[c] = sum_k v[k] W[k * ld + c] for c < n (W row-major [K, n], v in LDS; NV = 1 or 2 vectors against the same W) with 16-BYTE loads: a
+// thread owns FOUR consecutive outputs and one of S interleaved K slices (S = 256 / (n / 4), capped), 8 rows in flight; the slices' partial
+// sums meet in `part` ([S][NV][n] floats of LDS) and are added in slice order.  Measured (profiles/r06f): a 4-byte-per-lane load
+// instruction costs these kernels ~24 cycles whatever it fetches, so the 200 x 300 Linear as one output per thread (200 - 400 scalar
+// loads each) took 21 us of the 38 us forward kernel; a quarter of the instructions, each fetching 1 KB per wavefront, is what helps —
+// not more loads in flight (64 instead of 16 made it slower).  Needs n % 4 == 0, ld % 4 == 0, W 16-byte aligned (mv4_ok); call from
+// all 256 threads; results are in part[0 .. NV * n) afterwards (vector 0, then vector 1), valid after the trailing barrier.
+__device__ __forceinline__ bool mv4_ok(const float* W, int64_t ld, int n) { return n % 4 == 0 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15u) == 0; }
+__host__ __device__ inline int mv4_slices(int n) {
+  const int q = n / 4;
+  return q >= 256 ? 1 : (256 / q > 8 ? 8 : 256 / q);
+}
+template <int NV>
+__device__ __forceinline__ void matvec4(const float* v0, const float* v1, const float* __restrict__ W, int64_t ld, int K, int n, float* part) {
+  const int tid = threadIdx.x, Q = n >> 2, S = mv4_slices(n);
+  for (int q0 = 0; q0 < Q; q0 += 256) {  // (n > 1024 would take several column passes; the callers cap n at 1024)
+    const int q = q0 + (S > 1 ? tid % Q : tid), sl = S > 1 ? tid / Q : 0;
+    const bool active = q < Q && sl < S;
+    const int qc = min(q, Q - 1);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    for (int k0 = sl; k0 < K; k0 += 8 * S) {
+      float4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const float4*>(W + (int64_t)min(k0 + u * S, K - 1) * ld + 4 * qc);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kc = min(k0 + u * S, K - 1);
+        float x0 = v0[kc];
+        x0 = k0 + u * S < K ? x0 : 0.f;
+        a0.x = fmaf(x0, w[u].x, a0.x); a0.y = fmaf(x0, w[u].y, a0.y); a0.z = fmaf(x0, w[u].z, a0.z); a0.w = fmaf(x0, w[u].w, a0.w);
+        if (NV == 2) {
+          float x1 = v1[kc];
+          x1 = k0 + u * S < K ? x1 : 0.f;
+          a1.x = fmaf(x1, w[u].x, a1.x); a1.y = fmaf(x1, w[u].y, a1.y); a1.z = fmaf(x1, w[u].z, a1.z); a1.w = fmaf(x1, w[u].w, a1.w);
+        }
+      }
+    }
+    if (active) {
+      *reinterpret_cast<float4*>(part + ((int64_t)sl * NV) * n + 4 * q) = a0;
+      if (NV == 2) *reinterpret_cast<float4*>(part + ((int64_t)sl * NV + 1) * n + 4 * q) = a1;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < NV * n; e += 256) {
+    float r = part[e];
+    for (int sl = 1; sl < S; ++sl) r += part[(int64_t)sl * NV * n + e];  // slice order: deterministic
+    part[e] = r;
+  }
+  __syncthreads();
+}
+
 // ---- Adam: counters and bias corrections (once per step, one thread) ----------------------------------------------------------------
 struct AdamHyper {
   float lr, beta1, beta2, eps, wd;
@@ -142,8 +234,10 @@ struct GscArgs {
   float* coef;                     // [2]
   float* xdg;                      // [2, G, F] dropped gene rows (dropout > 0 only)
   float *ax2, *h2, *zd2, *demb, *dpre;  // [B, F], [B, H], [B, E], [B, E], [B, H]
+  float* zd2t;                          // [E, B]: zd2 transposed (the decoder's row of z z^T as a 16-byte mat-vec)
   double* rowloss;                 // [B]
   int32_t* bad;
+  int dbg_fwd, dbg_dec;            // development: stop the forward / decoder kernel after phase n (DANCE_AMD_MINISTEP_DBG=f,d; 0 = run all)
 };
 
 __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx, StepCounters sc, AdamHyper hy, int nb_count) {
@@ -179,96 +273,188 @@ __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64
   const int fwd = q >= nq;
   const int64_t quad = fwd ? q - nq : q;
   const uint4 r = drop_words(dx, SID_GENE + fwd, (uint64_t)quad);
+  float xv[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int64_t e = quad * 4 + j;
-    if (e < gf) {
-      const int64_t g = e / a.F, f = e - g * a.F;
-      a.xdg[fwd * gf + e] = a.X[g * a.ldx + f] * drop_pick(dx, r, j);
-    }
+    const int64_t e = min(quad * 4 + j, gf - 1), g = e / a.F, f = e - g * a.F;
+    xv[j] = a.X[g * a.ldx + f];
   }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (quad * 4 + j < gf) a.xdg[fwd * gf + quad * 4 + j] = xv[j] * drop_pick(dx, r, j);
 }
 
-// one workgroup per (seed, forward)
+// one workgroup per seed: BOTH forwards of the batch (graphsc.py:202 and :215) — they share every weight load
 __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx, Drop dd, float* __restrict__ z_out) {
-  __shared__ float red[512], axs[128], hs[1024];
-  const int i = blockIdx.x, k = blockIdx.y, tid = threadIdx.x;
+  constexpr int EC = 1024;  // row entries staged per pass
+  __shared__ float red[2][512], axs[2][128], hs[2][1024], ews[EC];
+  __shared__ __attribute__((aligned(16))) float part[2048];  // matvec4: slices x 2 vectors x width <= 2 x 1024
+  __shared__ int ecol[EC];
+  const int i = blockIdx.x, tid = threadIdx.x;
   int64_t v = seeds[i];
   v = v < a.G ? a.G : v >= a.n_nodes ? a.n_nodes - 1 : v;  // (flagged by gsc_prepare; keep every address valid)
   const int s = a.rowptr[v], t = a.rowptr[v + 1], deg = t - s;
   const int FP = a.FP, ngrp = 256 / FP, fl = tid & (FP - 1), grp = tid / FP, F = a.F, G = a.G;
   const bool drop = dx.thr < kKeepAll;
-  const float* __restrict__ xg = drop ? a.xdg + (int64_t)k * G * F : a.X;
+  const float* __restrict__ xg0 = drop ? a.xdg : a.X;
+  const float* __restrict__ xg1 = drop ? a.xdg + (int64_t)G * F : a.X;
   const int64_t ldg = drop ? F : a.ldx;
   const float* __restrict__ xself = a.X + v * a.ldx;
   const int f0 = min(fl, F - 1), f1 = min(fl + FP, F - 1);
-  float sm0 = 1.f, sm1 = 1.f;  // the seed row's own dropout draw
+  float sm[2][2] = {{1.f, 1.f}, {1.f, 1.f}};  // the seed row's own dropout draws [forward][feature slot]
   if (drop) {
-    sm0 = drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f0);
-    sm1 = drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f1);
-  }
-  float acc0 = 0.f, acc1 = 0.f;
-  // every load from a clamped, valid address; what must not count is multiplied by a zero weight (no load behind a divergent guard)
-  for (int e0 = s + grp; e0 < t; e0 += 4 * ngrp) {
-    int c[4];
-    float w[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = e0 + u * ngrp, ec = min(e, t - 1);
-      c[u] = a.col[ec];
-      w[u] = e < t ? a.val[ec] : 0.f;
-    }
-    int cnt[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) cnt[u] = a.count[min(c[u], G - 1)];
-    float x0[4], x1[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* __restrict__ row = c[u] >= G ? xself : xg + (int64_t)c[u] * ldg;
-      x0[u] = row[f0];
-      x1[u] = row[f1];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const bool self = c[u] >= G;
-      // D_out^-1/2 of the source inside the block (graphsc.py:444-449): a gene's count over the batch, 1 for a seed (its self loop)
-      const float cs = self ? 1.f : 1.f / sqrtf(fmaxf((float)cnt[u], 1.f));
-      const float ws = w[u] * cs;
-      acc0 = fmaf(ws * (self ? sm0 : 1.f), x0[u], acc0);
-      acc1 = fmaf(ws * (self ? sm1 : 1.f), x1[u], acc1);
+    for (int k = 0; k < 2; ++k) {
+      sm[k][0] = drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f0);
+      sm[k][1] = drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f1);
     }
   }
-  if (fl < F) red[grp * F + fl] = acc0;
-  if (fl + FP < F) red[grp * F + fl + FP] = acc1;
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  // rows that start on 8-byte boundaries are gathered as float2: one load per (row, forward) and thread instead of two 4-byte ones, and
+  // twice the rows per wavefront instruction (the instruction count is what these latency-bound kernels pay for)
+  const bool v2 = F % 2 == 0 && a.ldx % 2 == 0 && (reinterpret_cast<uintptr_t>(a.X) & 7u) == 0;
+  const int P = F >> 1, PP = v2 ? min(pow2_at_least(P), 64) : FP, ngrp2 = 256 / PP, pl = tid & (PP - 1), grp2 = tid / PP, pc = min(pl, max(P, 1) - 1);
+  float2 sm2[2] = {make_float2(1.f, 1.f), make_float2(1.f, 1.f)};
+  if (v2 && drop) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) sm2[k] = make_float2(drop_scale(dx, SID_SELF + k, (uint64_t)i * F + 2 * pc), drop_scale(dx, SID_SELF + k, (uint64_t)i * F + 2 * pc + 1));
+  }
+  float2 acc2[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  for (int c0 = s; c0 < t; c0 += EC) {
+    const int n = min(EC, t - c0);
+    // stage (source, weight x D_out^-1/2 of the source inside the block: graphsc.py:444-449 — a gene's count over the batch, 1 for the
+    // seed's self loop) of up to EC entries: two round trips for the whole row instead of two per entry
+    if (c0 > s) __syncthreads();
+    for (int j = tid; j < n; j += 256) {
+      const int c = a.col[c0 + j];
+      const float w = a.val[c0 + j];
+      const int cnt = a.count[min(c, G - 1)];
+      ecol[j] = c;
+      ews[j] = c >= G ? w : w * (1.f / sqrtf(fmaxf((float)cnt, 1.f)));
+    }
+    __syncthreads();
+    if (v2) {
+      for (int j0 = grp2; j0 < n; j0 += 16 * ngrp2) {
+        float2 x[16][2];
+        float w[16];
+        bool self[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = j0 + u * ngrp2, jc = min(j, n - 1);
+          const int c = ecol[jc];
+          w[u] = j < n ? ews[jc] : 0.f;
+          self[u] = c >= G;
+          x[u][0] = *reinterpret_cast<const float2*>((self[u] ? xself : xg0 + (int64_t)c * ldg) + 2 * pc);
+          if (drop) x[u][1] = *reinterpret_cast<const float2*>((self[u] ? xself : xg1 + (int64_t)c * ldg) + 2 * pc);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !drop) break;
+            acc2[k].x = fmaf(w[u] * (self[u] ? sm2[k].x : 1.f), x[u][k].x, acc2[k].x);
+            acc2[k].y = fmaf(w[u] * (self[u] ? sm2[k].y : 1.f), x[u][k].y, acc2[k].y);
+          }
+        }
+      }
+      continue;
+    }
+    // gather: 16 rows in flight per thread, every load from a clamped, valid address (what must not count gets a zero weight)
+    for (int j0 = grp; j0 < n; j0 += 16 * ngrp) {
+      float x[16][2][2], w[16];
+      bool self[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int j = j0 + u * ngrp, jc = min(j, n - 1);
+        const int c = ecol[jc];
+        w[u] = j < n ? ews[jc] : 0.f;
+        self[u] = c >= G;
+        const float* __restrict__ r0 = self[u] ? xself : xg0 + (int64_t)c * ldg;
+        x[u][0][0] = r0[f0];
+        x[u][0][1] = r0[f1];
+        if (drop) {
+          const float* __restrict__ r1 = self[u] ? xself : xg1 + (int64_t)c * ldg;
+          x[u][1][0] = r1[f0];
+          x[u][1][1] = r1[f1];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k == 1 && !drop) break;
+          acc[k][0] = fmaf(w[u] * (self[u] ? sm[k][0] : 1.f), x[u][k][0], acc[k][0]);
+          acc[k][1] = fmaf(w[u] * (self[u] ? sm[k][1] : 1.f), x[u][k][1], acc[k][1]);
+        }
+      }
+    }
+  }
+  if (a.dbg_fwd == 1) return;
+  if (!drop) {  // without dropout the two forwards aggregate the same thing
+    acc[1][0] = acc[0][0];
+    acc[1][1] = acc[0][1];
+    acc2[1] = acc2[0];
+  }
+  const int ngrp_r = v2 ? ngrp2 : ngrp;
+  if (v2) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+      if (pl < P) {
+        red[k][grp2 * F + 2 * pl] = acc2[k].x;
+        red[k][grp2 * F + 2 * pl + 1] = acc2[k].y;
+      }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      if (fl < F) red[k][grp * F + fl] = acc[k][0];
+      if (fl + FP < F) red[k][grp * F + fl + FP] = acc[k][1];
+    }
+  }
   __syncthreads();
   // D_in^-1/2 of the destination (:467-471); fn.mean divides by the in-degree first (:465)
   const float dg = fmaxf((float)deg, 1.f);
   const float rs = (1.f / sqrtf(dg)) * (a.mean ? 1.f / dg : 1.f);
-  for (int f = tid; f < F; f += 256) {
+  for (int e = tid; e < 2 * F; e += 256) {
+    const int k = e >= F, f = e - k * F;
     float sum = 0.f;
-    for (int g2 = 0; g2 < ngrp; ++g2) sum += red[g2 * F + f];  // group order: deterministic
+    for (int g2 = 0; g2 < ngrp_r; ++g2) sum += red[k][g2 * F + f];  // group order: deterministic
     sum *= rs;
-    axs[f] = sum;
+    axs[k][f] = sum;
     if (k == 1) a.ax2[(int64_t)i * F + f] = sum;
   }
   __syncthreads();
   const int H = a.H, E = a.E;
+  const bool vb = mv4_ok(a.W1, H, H), vc = mv4_ok(a.w2t, E, E);
+  if (vb) matvec4<2>(axs[0], axs[1], a.W1, H, F, H, part);
   for (int tt = tid; tt < H; tt += 256) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int f = 0; f < F; ++f) acc = fmaf(axs[f], a.W1[(int64_t)f * H + tt], acc);
-    const float hv = fmaxf(acc + a.b1[tt], 0.f);
-    hs[tt] = hv;
-    if (k == 1) a.h2[(int64_t)i * H + tt] = hv;
+    float p0, p1;
+    if (vb) {
+      p0 = part[tt];
+      p1 = part[H + tt];
+    } else {
+      dot2_strided<16>(axs[0], axs[1], a.W1 + tt, H, F, p0, p1);
+    }
+    const float bb = a.b1[tt], h0 = fmaxf(p0 + bb, 0.f), h1 = fmaxf(p1 + bb, 0.f);
+    hs[0][tt] = h0;
+    hs[1][tt] = h1;
+    a.h2[(int64_t)i * H + tt] = h1;
   }
   __syncthreads();
+  if (a.dbg_fwd == 2) return;
+  if (vc) matvec4<2>(hs[0], hs[1], a.w2t, E, H, E, part);
   for (int o = tid; o < E; o += 256) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int kk = 0; kk < H; ++kk) acc = fmaf(hs[kk], a.w2t[(int64_t)kk * E + o], acc);
-    const float emb = acc + a.b2[o];
-    if (k == 0) z_out[(int64_t)i * E + o] = emb;                                                  // graphsc.py:202-203
-    else a.zd2[(int64_t)i * E + o] = emb * drop_scale(dd, SID_DEC, (uint64_t)i * E + o);          // :215, :409
+    float e0, e1;
+    if (vc) {
+      e0 = part[o];
+      e1 = part[E + o];
+    } else {
+      dot2_strided<16>(hs[0], hs[1], a.w2t + o, E, H, e0, e1);
+    }
+    const float bb = a.b2[o];
+    z_out[(int64_t)i * E + o] = e0 + bb;                                                             // graphsc.py:202-203
+    const float zv = (e1 + bb) * drop_scale(dd, SID_DEC, (uint64_t)i * E + o);                    // :215, :409
+    a.zd2[(int64_t)i * E + o] = zv;
+    a.zd2t[(int64_t)o * a.B + i] = zv;
   }
 }
 
@@ -282,58 +468,81 @@ __global__ __launch_bounds__(256) void gsc_decoder_kernel(GscArgs a, Drop dd, fl
   float* de = sm + E;      // [E]
   float* gj = sm + 2 * E;  // [B]
   __shared__ double wl[4];
+  __shared__ __attribute__((aligned(16))) float part[1024];  // matvec4: slices x width <= 1024
   const float* __restrict__ Z = a.zd2;
   for (int kk = tid; kk < E; kk += 256) zi[kk] = Z[(int64_t)i * E + kk];
   __syncthreads();
-  double loss = 0.0;
-  for (int j0 = wave; j0 < B; j0 += 16) {  // 4 rows per wavefront in flight
-    float d[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int kk = lane; kk < E; kk += 64) {
-      const float z = zi[kk];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) d[u] = fmaf(z, Z[(int64_t)min(j0 + 4 * u, B - 1) * E + kk], d[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float x = wave_sum(d[u]);
-      const int j = j0 + 4 * u;
-      if (lane == 0 && j < B) {
-        const float sg = 1.f / (1.f + expf(-x));
-        if (j == i) {  // target 1, weighted: pos_weight * softplus(-x)
-          loss += (double)(pos_weight * softplusf(-x));
-          gj[j] = pos_weight * (sg - 1.f);
-        } else {
-          loss += (double)softplusf(x);
-          gj[j] = sg;
+  const bool v1 = B <= 1024 && mv4_ok(a.zd2t, B, B);
+  if (v1) {  // x_ij = sum_k z_i[k] Z^T[k][j]: the 16-byte mat-vec over the transposed copy the forward kernel wrote
+    matvec4<1>(zi, zi, a.zd2t, B, E, B, part);
+    for (int j = tid; j < B; j += 256) gj[j] = part[j];
+  } else {
+    for (int j0 = wave; j0 < B; j0 += 32) {  // 8 rows per wavefront, 4 x 64 columns each: 32 loads in flight per lane
+      float d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < E; k0 += 256) {
+        float zz[4], zr[8][4];
+  #pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int kk = k0 + lane + 64 * q, kc = min(kk, E - 1);
+          zz[q] = zi[kc];
+          zz[q] = kk < E ? zz[q] : 0.f;
+  #pragma unroll
+          for (int u = 0; u < 8; ++u) zr[u][q] = Z[(int64_t)min(j0 + 4 * u, B - 1) * E + kc];
         }
+  #pragma unroll
+        for (int q = 0; q < 4; ++q)
+  #pragma unroll
+          for (int u = 0; u < 8; ++u) d[u] = fmaf(zz[q], zr[u][q], d[u]);
+      }
+  #pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const float x = wave_sum(d[u]);
+        if (lane == 0 && j0 + 4 * u < B) gj[j0 + 4 * u] = x;  // the logit; its loss term and gradient below, one thread per column
       }
     }
   }
+  __syncthreads();
+  if (a.dbg_dec == 1) return;
+  double loss = 0.0;
+  for (int j = tid; j < B; j += 256) {
+    const float x = gj[j];
+    const float sg = 1.f / (1.f + expf(-x));
+    if (j == i) {  // target 1, weighted: pos_weight * softplus(-x)
+      loss += (double)(pos_weight * softplusf(-x));
+      gj[j] = pos_weight * (sg - 1.f);
+    } else {
+      loss += (double)softplusf(x);
+      gj[j] = sg;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) loss += __shfl_xor(loss, off, 64);
   if (lane == 0) wl[wave] = loss;
   __syncthreads();
   if (tid == 0) a.rowloss[i] = ((wl[0] + wl[1]) + wl[2]) + wl[3];
   // d loss / d zd_i = 2 c sum_j g_ij zd_j (logits and target are symmetric), then the decoder dropout's own mask
+  const bool v2 = mv4_ok(Z, E, E), v3 = mv4_ok(a.W2, H, H);
+  if (v2) matvec4<1>(gj, gj, Z, E, B, E, part);
   for (int kk = tid; kk < E; kk += 256) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int j = 0; j < B; ++j) acc = fmaf(gj[j], Z[(int64_t)j * E + kk], acc);
+    const float acc = v2 ? part[kk] : dot_strided<16>(gj, Z + kk, E, B);
     const float dv = 2.f * cscale * acc * drop_scale(dd, SID_DEC, (uint64_t)i * E + kk);
     de[kk] = dv;
     a.demb[(int64_t)i * E + kk] = dv;
   }
   __syncthreads();
+  if (a.dbg_dec == 2) return;
+  if (v3) matvec4<1>(de, de, a.W2, H, E, H, part);
   for (int tt = tid; tt < H; tt += 256) {
-    float acc = 0.f;
-#pragma unroll 8
-    for (int o = 0; o < E; ++o) acc = fmaf(de[o], a.W2[(int64_t)o * H + tt], acc);
-    a.dpre[(int64_t)i * H + tt] = a.h2[(int64_t)i * H + tt] > 0.f ? acc : 0.f;
+    const float dh = v3 ? part[tt] : dot_strided<16>(de, a.W2 + tt, H, E);
+    a.dpre[(int64_t)i * H + tt] = a.h2[(int64_t)i * H + tt] > 0.f ? dh : 0.f;
   }
 }
 
 // =====================================================================================================================================
 // weight gradients + Adam: G = A^T B in 32 x 32 tiles (A [K, M], B [K, N] row-major: the batch rows are the K dimension), exact fp32 MFMA
 // =====================================================================================================================================
-constexpr int MS_T = 32, MS_LD = 33, MS_KC = 128;
+constexpr int MS_T = 32, MS_LD = 33;  // tile edge, LDS row stride; the K chunk per pass (KC) is a template parameter: 128 / 256 / 512 —
+// the whole K extent in ONE round trip wherever it fits (a pass = two dependent global round trips of ~1 us + a barrier pair)
 
 struct MsJob {
   const float* A;  // [K, M]; nullptr = a column of ones (M = 1: column sums, the bias gradients)
@@ -365,15 +574,24 @@ struct MsGradArgs {
   int n_zero;
 };
 
+template <int MS_KC>
 __global__ __launch_bounds__(256) void ms_grad_kernel(MsGradArgs a) {
   __shared__ float smem[2 * MS_KC * MS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= a.total_tiles) {
-    // the step's loss: rows summed in index order in double (as the unfused path's .sum(dtype=float64))
-    if (tid == 0 && a.loss_out) {
-      double s = 0.0;
-      for (int i = 0; i < a.n_rowloss; ++i) s += a.rowloss_d ? a.rowloss_d[i] : (double)a.rowloss_f[i];
-      *a.loss_out = a.loss_mul * (float)(s / a.loss_div);
+    // the step's loss: the rows' terms summed in double, in a fixed order (per-thread strided partial sums, then a tree over the 256
+    // partials).  NOT one thread walking the rows: that is n dependent ~80 ns loads — 40 us at batch 500, the whole kernel's time.
+    if (a.loss_out) {
+      double* part = reinterpret_cast<double*>(smem);
+      double sacc = 0.0;
+      for (int i = tid; i < a.n_rowloss; i += 256) sacc += a.rowloss_d ? a.rowloss_d[i] : (double)a.rowloss_f[i];
+      part[tid] = sacc;
+      __syncthreads();
+      for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) part[tid] += part[tid + off];
+        __syncthreads();
+      }
+      if (tid == 0) *a.loss_out = a.loss_mul * (float)(part[0] / a.loss_div);
     }
     for (int i = tid; i < a.n_zero; i += 256) a.zero_i32[i] = 0;
     return;
@@ -394,18 +612,39 @@ __global__ __launch_bounds__(256) void ms_grad_kernel(MsGradArgs a) {
   const bool drop = jb.b_drop && a.bdrop.thr < kKeepAll;
   for (int k0 = 0; k0 < K; k0 += MS_KC) {
     float ra[MS_KC / 8], rb[MS_KC / 8];
+    // (uniform branches sit OUTSIDE the unrolled batches: inside, every load shares one basic block and they all go out together)
+    if (jb.A) {
 #pragma unroll
-    for (int q = 0; q < MS_KC / 8; ++q) {
-      const int e = tid + 256 * q, r = e & 31, k = e >> 5;
-      const int kk = min(k0 + k, K - 1);
-      ra[q] = jb.A ? jb.A[(int64_t)kk * jb.lda + min(m0 + r, M - 1)] : 1.f;
-      const int64_t brow = jb.b_rows ? jb.b_rows[kk] : kk;
-      const int nn = min(n0 + r, N - 1);
-      float bv;
-      if (jb.b_bf16) bv = __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(jb.Bm)[brow * jb.ldb + nn] << 16);
-      else bv = reinterpret_cast<const float*>(jb.Bm)[brow * jb.ldb + nn];
-      if (drop) bv *= drop_scale(a.bdrop, SID_SDS, (uint64_t)kk * N + nn);
-      rb[q] = bv;
+      for (int q = 0; q < MS_KC / 8; ++q) {
+        const int e = tid + 256 * q, r = e & 31, k = e >> 5;
+        ra[q] = jb.A[(int64_t)min(k0 + k, K - 1) * jb.lda + min(m0 + r, M - 1)];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) ra[q] = 1.f;
+    }
+    if (jb.b_rows) {
+      int64_t brow[MS_KC / 8];
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) brow[q] = jb.b_rows[min(k0 + ((tid + 256 * q) >> 5), K - 1)];
+      uint32_t wb[MS_KC / 8];
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) wb[q] = feat_word(jb.Bm, jb.b_bf16, brow[q] * jb.ldb + min(n0 + ((tid + 256 * q) & 31), N - 1));
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) rb[q] = feat_value(wb[q], jb.b_bf16, brow[q] * jb.ldb + min(n0 + ((tid + 256 * q) & 31), N - 1));
+    } else {
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) {
+        const int e = tid + 256 * q, r = e & 31, k = e >> 5;
+        rb[q] = reinterpret_cast<const float*>(jb.Bm)[(int64_t)min(k0 + k, K - 1) * jb.ldb + min(n0 + r, N - 1)];
+      }
+    }
+    if (drop) {
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) {
+        const int e = tid + 256 * q, r = e & 31, k = e >> 5;
+        rb[q] *= drop_scale(a.bdrop, SID_SDS, (uint64_t)min(k0 + k, K - 1) * N + min(n0 + r, N - 1));
+      }
     }
     if (k0) __syncthreads();
 #pragma unroll
@@ -473,6 +712,12 @@ int place_tiles(MsGradArgs& g) {
   return t;
 }
 
+void launch_grad(const MsGradArgs& ga, int K, hipStream_t st) {
+  const dim3 grid((unsigned)(ga.total_tiles + 1));
+  if (K <= 128) hipLaunchKernelGGL(ms_grad_kernel<128>, grid, dim3(256), 0, st, ga);
+  else hipLaunchKernelGGL(ms_grad_kernel<256>, grid, dim3(256), 0, st, ga);  // (512 per pass: 128 values in flight per thread spill)
+}
+
 Drop make_drop(float p, uint64_t seed, uint64_t step) {
   Drop d;
   d.seed_lo = (uint32_t)seed;
@@ -510,8 +755,18 @@ struct SdsArgs {
   int32_t* bad;
 };
 
+// one feature value, fp32 or bf16 storage, WITHOUT a branch on the type: a branch — even a uniform one — between the loads of an unrolled batch
+// puts every load into its own basic block behind an s_waitcnt (scripts/isa_load_audit.py found runs of 64 - 128 dependent round trips in the
+// first form of these kernels).  bf16: the aligned 32-bit word that holds the element, then a shift / mask.
 __device__ __forceinline__ float load_feat(const void* X, int bf16, int64_t idx) {
-  return bf16 ? __uint_as_float((uint32_t) reinterpret_cast<const uint16_t*>(X)[idx] << 16) : reinterpret_cast<const float*>(X)[idx];
+  const uint32_t w = reinterpret_cast<const uint32_t*>(X)[bf16 ? (idx >> 1) : idx];
+  return __uint_as_float(bf16 ? ((idx & 1) ? (w & 0xFFFF0000u) : (w << 16)) : w);
+}
+// the two halves of load_feat for batches: all raw words first (nothing touches a loaded value until every load of the batch is out —
+// the compiler does not hoist a load above the select that consumes the previous one), conversion afterwards
+__device__ __forceinline__ uint32_t feat_word(const void* X, int bf16, int64_t idx) { return reinterpret_cast<const uint32_t*>(X)[bf16 ? (idx >> 1) : idx]; }
+__device__ __forceinline__ float feat_value(uint32_t w, int bf16, int64_t idx) {
+  return __uint_as_float(bf16 ? ((idx & 1) ? (w & 0xFFFF0000u) : (w << 16)) : w);
 }
 
 // neigh[i] = mean over the in-edges e of seed i of alpha[idx(e)] w_e h[src(e)]  (gnn.py:62-90): alpha index = the gene's id for a
@@ -628,6 +883,7 @@ __global__ __launch_bounds__(256) void sds_neigh_vec_kernel(SdsArgs a, const int
 }
 
 // h1 = relu(dropout(X[seeds]) W1^T + b1): 32 x 32 tiles, the feature rows gathered on the way into LDS
+template <int MS_KC>
 __global__ __launch_bounds__(256) void sds_hidden_kernel(SdsArgs a, const int64_t* __restrict__ seeds, Drop dz, StepCounters sc, AdamHyper hy) {
   __shared__ float smem[2 * MS_KC * MS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -640,18 +896,35 @@ __global__ __launch_bounds__(256) void sds_hidden_kernel(SdsArgs a, const int64_
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool drop = dz.thr < kKeepAll;
+  // the tile's 32 seeds: ONE load per lane through LDS (read per element they become 32 dependent scalar round trips: the row index is
+  // uniform over the workgroup and the compiler moves it to an SGPR behind a wait)
+  __shared__ int srow[MS_T];
+  if (tid < MS_T) {
+    const int64_t v = seeds[min(m0 + tid, M - 1)];
+    srow[tid] = (int)(v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v);
+  }
+  __syncthreads();
   for (int k0 = 0; k0 < K; k0 += MS_KC) {
     float ra[MS_KC / 8], rb[MS_KC / 8];
+    uint32_t wa[MS_KC / 8];
 #pragma unroll
     for (int q = 0; q < MS_KC / 8; ++q) {  // both operands K-contiguous: consecutive lanes walk k
       const int e = tid + 256 * q, r = e / MS_KC, k = e % MS_KC;
-      const int kk = min(k0 + k, K - 1), mm = min(m0 + r, M - 1);
-      int64_t v = seeds[mm];
-      v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
-      float av = load_feat(a.X, a.x_bf16, v * a.ldx + kk);
-      if (drop) av *= drop_scale(dz, SID_SDS, (uint64_t)mm * K + kk);
-      ra[q] = av;
+      const int kk = min(k0 + k, K - 1);
+      wa[q] = feat_word(a.X, a.x_bf16, (int64_t)srow[r] * a.ldx + kk);
       rb[q] = a.W1[(int64_t)min(n0 + r, N - 1) * K + kk];
+    }
+#pragma unroll
+    for (int q = 0; q < MS_KC / 8; ++q) {
+      const int e = tid + 256 * q, r = e / MS_KC, k = e % MS_KC;
+      ra[q] = feat_value(wa[q], a.x_bf16, (int64_t)srow[r] * a.ldx + min(k0 + k, K - 1));
+    }
+    if (drop) {
+#pragma unroll
+      for (int q = 0; q < MS_KC / 8; ++q) {
+        const int e = tid + 256 * q, r = e / MS_KC, k = e % MS_KC;
+        ra[q] *= drop_scale(dz, SID_SDS, (uint64_t)min(m0 + r, M - 1) * K + min(k0 + k, K - 1));
+      }
     }
     if (k0) __syncthreads();
 #pragma unroll
@@ -743,7 +1016,7 @@ __global__ __launch_bounds__(256) void ms_dropout_mask_kernel(int64_t n, Drop d,
 size_t a256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 struct GscLayout {
-  size_t count, coef, xdg, ax2, h2, zd2, demb, dpre, rowloss, w2t, total;
+  size_t count, coef, xdg, ax2, h2, zd2, zd2t, demb, dpre, rowloss, w2t, total;
 };
 GscLayout gsc_layout(int64_t G, int64_t B, int64_t F, int64_t H, int64_t E) {
   GscLayout l;
@@ -759,6 +1032,7 @@ GscLayout gsc_layout(int64_t G, int64_t B, int64_t F, int64_t H, int64_t E) {
   l.ax2 = take((size_t)B * F * 4);
   l.h2 = take((size_t)B * H * 4);
   l.zd2 = take((size_t)B * E * 4);
+  l.zd2t = take((size_t)B * E * 4);
   l.demb = take((size_t)B * E * 4);
   l.dpre = take((size_t)B * H * 4);
   l.rowloss = take((size_t)B * 8);
@@ -838,10 +1112,12 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
   a.ax2 = reinterpret_cast<float*>(ws + l.ax2);
   a.h2 = reinterpret_cast<float*>(ws + l.h2);
   a.zd2 = reinterpret_cast<float*>(ws + l.zd2);
+  a.zd2t = reinterpret_cast<float*>(ws + l.zd2t);
   a.demb = reinterpret_cast<float*>(ws + l.demb);
   a.dpre = reinterpret_cast<float*>(ws + l.dpre);
   a.rowloss = reinterpret_cast<double*>(ws + l.rowloss);
   a.bad = c->bad;
+  if (const char* dbg = getenv("DANCE_AMD_MINISTEP_DBG")) sscanf(dbg, "%d,%d", &a.dbg_fwd, &a.dbg_dec);
   const AdamHyper hy{c->lr, c->beta1, c->beta2, c->eps, c->weight_decay};
   StepCounters sc{};
   sc.step[0] = c->w1.step; sc.step[1] = c->b1.step; sc.step[2] = c->w2.step; sc.step[3] = c->b2.step;
@@ -886,10 +1162,10 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
     const Drop dx = make_drop(c->dropout, c->seed, gstep), dd = make_drop(c->decoder_dropout, c->seed, gstep);
     const int64_t* seeds = c->seeds + s * B;
     hipLaunchKernelGGL(gsc_prepare_kernel, dim3((unsigned)(nb_count + nb_drop)), dim3(256), 0, st, a, seeds, dx, sc, hy, nb_count);
-    hipLaunchKernelGGL(gsc_forward_kernel, dim3((unsigned)B, 2), dim3(256), 0, st, a, seeds, dx, dd, c->z_out + s * (int64_t)B * E);
+    hipLaunchKernelGGL(gsc_forward_kernel, dim3((unsigned)B), dim3(256), 0, st, a, seeds, dx, dd, c->z_out + s * (int64_t)B * E);
     hipLaunchKernelGGL(gsc_decoder_kernel, dim3((unsigned)B), dim3(256), dec_lds, st, a, dd, (float)pos_weight, (float)(norm / (b * b)));
     ga.loss_out = c->loss_out + s;
-    hipLaunchKernelGGL(ms_grad_kernel, dim3((unsigned)(ga.total_tiles + 1)), dim3(256), 0, st, ga);
+    launch_grad(ga, B, st);
   }
   return dh::check_launch(me);
 }
@@ -1014,12 +1290,16 @@ extern "C" int dh_scdeepsort_steps(const dh_scdeepsort_step_t* c, int64_t first_
         hipLaunchKernelGGL(sds_neigh_kernel, dim3((unsigned)B), dim3(256), neigh_lds, st, a, seeds);
       }
     }
-    hipLaunchKernelGGL(sds_hidden_kernel, dim3((unsigned)dh::ceil_div(H, MS_T), (unsigned)dh::ceil_div(B, MS_T)), dim3(256), 0, st, a, seeds, dz, sc, hy);
+    {
+      const dim3 hg((unsigned)dh::ceil_div(H, MS_T), (unsigned)dh::ceil_div(B, MS_T));
+      if (D <= 128) hipLaunchKernelGGL(sds_hidden_kernel<128>, hg, dim3(256), 0, st, a, seeds, dz, sc, hy);
+      else hipLaunchKernelGGL(sds_hidden_kernel<256>, hg, dim3(256), 0, st, a, seeds, dz, sc, hy);
+    }
     hipLaunchKernelGGL(sds_loss_kernel, dim3((unsigned)dh::ceil_div(B, 4)), dim3(256), loss_lds, st, a, seeds);
     ga.job[0].b_rows = seeds;
     ga.bdrop = dz;
     ga.loss_out = c->loss_out + s;
-    hipLaunchKernelGGL(ms_grad_kernel, dim3((unsigned)(ga.total_tiles + 1)), dim3(256), 0, st, ga);
+    launch_grad(ga, B, st);
   }
   return dh::check_launch(me);
 }

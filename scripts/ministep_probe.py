@@ -19,6 +19,7 @@ from bench_configs import _cellgene_graph  # noqa: E402
 n_cells = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 500
 with_fit = (sys.argv[3] if len(sys.argv) > 3 else "1") != "0"
+batches = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else (128, 256, 512)  # graph-sc batch sizes
 dev = torch.device("cuda")
 out = {"cells": n_cells, "genes": 2000, "edges_per_cell": 200, "steps_per_call": steps}
 
@@ -47,7 +48,7 @@ from dance_amd.modules.single_modality.clustering.graphsc import GraphSC  # noqa
 
 # ---- graph-sc, batch 128 ----------------------------------------------------------------------------------------------------------
 cg = _cellgene_graph(n_cells, 2000, 200, 50, dev)
-for b in (128, 256, 512):
+for b in batches:
     n = min(steps, n_cells // b)
     gs = GraphSC(in_feats=50, n_clusters=10, device="cuda")
     gs.model.train()
@@ -80,7 +81,7 @@ del cg
 cg = _cellgene_graph(n_cells, 2000, 200, 400, dev)
 labels = torch.randint(0, 16, (n_cells, ), generator=torch.Generator().manual_seed(0))
 cg.ndata["label"] = torch.cat((-torch.ones(2000, dtype=torch.long), labels)).to(dev)
-for tag, bf16, neigh in (("fp32", False, True), ("fp32_no_neigh", False, False), ("bf16", True, True)):
+for tag, bf16, neigh in (("fp32", False, True), ("fp32_no_neigh", False, False), ("bf16", True, True))[:3 if len(batches) > 1 else 1]:
     g = cg.with_ndata(features=cg.ndata["features"].to(torch.bfloat16)) if bf16 else cg
     b = 500
     n = min(steps, n_cells // b)
