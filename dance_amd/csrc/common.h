@@ -43,6 +43,13 @@ int knn_filter_launch(int64_t n, int64_t d, const float* X, int64_t ldx, const f
                       hipStream_t st);
 size_t knn_filter_mean_floats(int64_t d);
 
+// knn_grid.hip: exact kNN of points in <= 3 dimensions by a uniform cell grid (DH_KNN_GRID)
+bool knn_grid_supported(int64_t d, int k);
+bool knn_grid_applies(int64_t n, int64_t d, int k);
+size_t knn_grid_workspace_bytes(int64_t n);
+int knn_grid_launch(int64_t n, int d, const float* X, int64_t ldx, int64_t q_begin, int64_t nq, int k, int32_t* out_idx, float* out_dist, void* workspace,
+                    hipStream_t st);
+
 // sage_bcm.hip: the two-waves-per-SIMD kernel pair (block-chunk-major plan of the graph + MFMA) behind the unsplit path of dh_sage_window_mfma
 bool sage_bcm_fits(int64_t n_dst, int64_t n_cols, int64_t width, bool hbf16, const void* H, int64_t ldh, int64_t nnz);
 size_t sage_bcm_plan_bytes(int64_t n_dst, int64_t n_cols, int64_t nnz);

@@ -72,7 +72,15 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int64_t n_blocks, int
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= width) return;
   float s = 0.f;
-  for (int64_t b = 0; b < n_blocks; ++b) s += partial[b * width + c];
+  int64_t b = 0;
+  for (; b + 8 <= n_blocks; b += 8) {  // 8 loads in flight, added in block order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(b + u) * width + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; b < n_blocks; ++b) s += partial[b * width + c];
   out[c] = s;
 }
 
@@ -100,9 +108,21 @@ extern "C" int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* 
   return dh::check_launch("dh_relu_backward_f32");
 }
 
+// Rows per block of pass 1.  2048 for the tall matrices (1M rows: thousands of blocks anyway) and for mini-batch matrices (one block:
+// its partial sums ARE the result, no second launch); in between — 8192 x 300, the bias gradients of graph-sc's large batches — 2048 rows
+// per block meant 20 workgroups each walking 512 rows four at a time, 45 us for 10 MB (round 6: 11 ms of a 229 ms epoch): there the rows
+// are dealt to ~2048 / column-blocks workgroups, at least 64 each.
+static int64_t colsum_rows_per_block(int64_t n_rows, int64_t width) {
+  if (n_rows * width <= 262144) return kColsumRows;
+  const int64_t cb = width > 32 ? dh::ceil_div(width, 64) : width > 16 ? 1 : dh::ceil_div(width, 16);
+  const int64_t nb_target = 2048 / cb > 1 ? 2048 / cb : 1;
+  int64_t rpb = (dh::ceil_div(n_rows, nb_target) + 15) / 16 * 16;
+  return rpb < 64 ? 64 : rpb > kColsumRows ? kColsumRows : rpb;
+}
+
 extern "C" size_t dh_colsum_f32_workspace_bytes(int64_t n_rows, int64_t width) {
   if (n_rows <= 0 || width <= 0) return 0;
-  return (size_t)dh::ceil_div(n_rows, kColsumRows) * (size_t)width * sizeof(float);
+  return (size_t)dh::ceil_div(n_rows, colsum_rows_per_block(n_rows, width)) * (size_t)width * sizeof(float);  // (>= the 2048-row layout dh_colsum_bf16 uses)
 }
 
 extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int64_t ldx, float* out,
@@ -120,18 +140,19 @@ extern "C" int dh_colsum_f32(int64_t n_rows, int64_t width, const float* X, int6
   const size_t need = dh_colsum_f32_workspace_bytes(n_rows, width);
   if (!workspace || workspace_bytes < need)
     return dh::fail(DH_ERR_WORKSPACE, "dh_colsum_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-  const int64_t nb = dh::ceil_div(n_rows, kColsumRows);
+  const int64_t rpb = colsum_rows_per_block(n_rows, width);
+  const int64_t nb = dh::ceil_div(n_rows, rpb);
   // one row block (a mini-batch: <= 2048 rows): its "partial" sums are the result — written straight to out, no second launch
   float* partial = nb == 1 ? out : static_cast<float*>(workspace);
   if (width > 32) {
     dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 64));
-    hipLaunchKernelGGL(colsum_partial_kernel<64>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+    hipLaunchKernelGGL(colsum_partial_kernel<64>, grid, dim3(256), 0, st, n_rows, width, X, ldx, rpb, partial);
   } else if (width > 16) {
     dim3 grid((unsigned)nb, 1);
-    hipLaunchKernelGGL(colsum_partial_kernel<32>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+    hipLaunchKernelGGL(colsum_partial_kernel<32>, grid, dim3(256), 0, st, n_rows, width, X, ldx, rpb, partial);
   } else {
     dim3 grid((unsigned)nb, (unsigned)dh::ceil_div(width, 16));
-    hipLaunchKernelGGL(colsum_partial_kernel<16>, grid, dim3(256), 0, st, n_rows, width, X, ldx, kColsumRows, partial);
+    hipLaunchKernelGGL(colsum_partial_kernel<16>, grid, dim3(256), 0, st, n_rows, width, X, ldx, rpb, partial);
   }
   if (nb > 1) hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)dh::ceil_div(width, 256)), dim3(256), 0, st, nb, width, partial, out);
   return dh::check_launch("dh_colsum_f32");

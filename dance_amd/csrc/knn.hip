@@ -301,8 +301,13 @@ struct Layout {
 Layout make_layout(int64_t n, int64_t d, int64_t nq, int k, int algo) {
   Layout L{};
   // auto: the filter pays off once the n x n pair count dwarfs its fixed passes; it needs k <= 64 (one carried key per lane)
-  if (algo == DH_KNN_AUTO) algo = (n >= 16384 && nq >= 1024 && k <= 64) ? DH_KNN_FILTER : DH_KNN_SCAN;
+  // (spatial coordinates, d <= 3: a cell grid examines ~100 pairs per query instead of n — knn_grid.hip)
+  if (algo == DH_KNN_AUTO) algo = dh::knn_grid_applies(n, d, k) ? DH_KNN_GRID : (n >= 16384 && nq >= 1024 && k <= 64) ? DH_KNN_FILTER : DH_KNN_SCAN;
   L.algo = algo;
+  if (algo == DH_KNN_GRID) {
+    L.total = dh::knn_grid_workspace_bytes(n);
+    return L;
+  }
   L.dch = knn_padded_width(d);
   L.P = knn_slices(nq, k);
   size_t off = 0;
@@ -408,8 +413,9 @@ extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64
   if (n < 0 || d < 0 || k < 0) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: negative size");
   if (q_begin < 0 || q_end > n || q_begin > q_end)
     return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: bad query range [%lld, %lld)", (long long)q_begin, (long long)q_end);
-  if (algo != DH_KNN_AUTO && algo != DH_KNN_SCAN && algo != DH_KNN_FILTER)
+  if (algo != DH_KNN_AUTO && algo != DH_KNN_SCAN && algo != DH_KNN_FILTER && algo != DH_KNN_GRID)
     return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: bad algo %d", algo);
+  if (algo == DH_KNN_GRID && !dh::knn_grid_supported(d, k)) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: the grid path needs d <= 3 and k <= 32");
   if (q_end == q_begin || k == 0) return DH_OK;
   if (!X || !out_idx || !out_dist) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: null pointer");
   if (ldx < d) return dh::fail(DH_ERR_INVALID, "dh_knn_bruteforce_f32: ldx < d");
@@ -420,6 +426,7 @@ extern "C" int dh_knn_bruteforce_f32(int64_t n, int64_t d, const float* X, int64
   const Layout L = make_layout(n, d, nq, k, algo);
   if (L.total && (!workspace || workspace_bytes < L.total || (reinterpret_cast<uintptr_t>(workspace) & 63u)))
     return dh::fail(DH_ERR_WORKSPACE, "dh_knn_bruteforce_f32: workspace %zu < %zu bytes (or not 64-byte aligned)", workspace_bytes, L.total);
+  if (L.algo == DH_KNN_GRID) return dh::knn_grid_launch(n, (int)d, X, ldx, q_begin, nq, k, out_idx, out_dist, workspace, st);
   char* ws = static_cast<char*>(workspace);
   float* Xp = reinterpret_cast<float*>(ws + L.xp);
   if (L.dch)

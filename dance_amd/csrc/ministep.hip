@@ -237,6 +237,7 @@ struct GscArgs {
   float* zd2t;                          // [E, B]: zd2 transposed (the decoder's row of z z^T as a 16-byte mat-vec)
   double* rowloss;                 // [B]
   int32_t* bad;
+  float* ax_out;                   // phase 3: [2, B, F] — the aggregated (and D_in^-1/2-scaled) inputs of both forwards; the kernel stops there
   int dbg_fwd, dbg_dec;            // development: stop the forward / decoder kernel after phase n (DANCE_AMD_MINISTEP_DBG=f,d; 0 = run all)
 };
 
@@ -285,10 +286,15 @@ __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64
 }
 
 // one workgroup per seed: BOTH forwards of the batch (graphsc.py:202 and :215) — they share every weight load
+// AGG_ONLY (dh_graphsc_steps phase 3, large batches: thousands of seeds per launch): the kernel ends with the aggregated inputs, so it is
+// built WITHOUT the dense phases' LDS and with 8 instead of 16 rows in flight — 186 registers and 30 KB of LDS held the whole-step form to
+// two workgroups per CU, and a gather this latency-bound lives on resident wavefronts
+template <bool AGG_ONLY>
 __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx, Drop dd, float* __restrict__ z_out) {
   constexpr int EC = 1024;  // row entries staged per pass
-  __shared__ float red[2][512], axs[2][128], hs[2][1024], ews[EC];
-  __shared__ __attribute__((aligned(16))) float part[2048];  // matvec4: slices x 2 vectors x width <= 2 x 1024
+  constexpr int U = AGG_ONLY ? 8 : 16;
+  __shared__ float red[2][512], axs[2][128], hs[2][AGG_ONLY ? 1 : 1024], ews[EC];
+  __shared__ __attribute__((aligned(16))) float part[AGG_ONLY ? 4 : 2048];  // matvec4: slices x 2 vectors x width <= 2 x 1024
   __shared__ int ecol[EC];
   const int i = blockIdx.x, tid = threadIdx.x;
   int64_t v = seeds[i];
@@ -334,12 +340,12 @@ __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64
     }
     __syncthreads();
     if (v2) {
-      for (int j0 = grp2; j0 < n; j0 += 16 * ngrp2) {
-        float2 x[16][2];
-        float w[16];
-        bool self[16];
+      for (int j0 = grp2; j0 < n; j0 += U * ngrp2) {
+        float2 x[U][2];
+        float w[U];
+        bool self[U];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < U; ++u) {
           const int j = j0 + u * ngrp2, jc = min(j, n - 1);
           const int c = ecol[jc];
           w[u] = j < n ? ews[jc] : 0.f;
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64
           if (drop) x[u][1] = *reinterpret_cast<const float2*>((self[u] ? xself : xg1 + (int64_t)c * ldg) + 2 * pc);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
           for (int k = 0; k < 2; ++k) {
             if (k == 1 && !drop) break;
@@ -360,11 +366,11 @@ __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64
       continue;
     }
     // gather: 16 rows in flight per thread, every load from a clamped, valid address (what must not count gets a zero weight)
-    for (int j0 = grp; j0 < n; j0 += 16 * ngrp) {
-      float x[16][2][2], w[16];
-      bool self[16];
+    for (int j0 = grp; j0 < n; j0 += U * ngrp) {
+      float x[U][2][2], w[U];
+      bool self[U];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int j = j0 + u * ngrp, jc = min(j, n - 1);
         const int c = ecol[jc];
         w[u] = j < n ? ews[jc] : 0.f;
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64
         }
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
+      for (int u = 0; u < U; ++u) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
           if (k == 1 && !drop) break;
@@ -421,7 +427,9 @@ __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64
     sum *= rs;
     axs[k][f] = sum;
     if (k == 1) a.ax2[(int64_t)i * F + f] = sum;
+    if (a.ax_out) a.ax_out[((int64_t)k * a.B + i) * F + f] = sum;
   }
+  if (AGG_ONLY) return;  // (the large-batch loop runs the dense layers on the big-tile GEMMs)
   __syncthreads();
   const int H = a.H, E = a.E;
   const bool vb = mv4_ok(a.W1, H, H), vc = mv4_ok(a.w2t, E, E);
@@ -1072,7 +1080,7 @@ extern "C" int dh_ministep_dropout_mask_f32(int64_t n, float p, uint64_t seed, u
 }
 
 extern "C" int dh_graphsc_step_supported(int64_t batch, int64_t in_feats, int64_t hidden, int64_t emb) {
-  return (batch >= 2 && batch <= 4096 && in_feats >= 1 && in_feats <= 128 && hidden >= 1 && hidden <= 1024 && emb >= 1 && emb <= 1024) ? 1 : 0;
+  return (batch >= 2 && batch <= 65536 && in_feats >= 1 && in_feats <= 128 && hidden >= 1 && hidden <= 1024 && emb >= 1 && emb <= 1024) ? 1 : 0;
 }
 
 extern "C" size_t dh_graphsc_step_workspace_bytes(int64_t n_genes, int64_t batch, int64_t in_feats, int64_t hidden, int64_t emb) {
@@ -1093,8 +1101,11 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
   if (c->ld_features < c->in_feats) return dh::fail(DH_ERR_INVALID, "%s: ld_features < in_feats", me);
   if (!adam_ok(c->w1) || !adam_ok(c->b1) || !adam_ok(c->w2) || !adam_ok(c->b2)) return dh::fail(DH_ERR_INVALID, "%s: incomplete Adam state", me);
   if (c->dropout < 0.f || c->dropout >= 1.f || c->decoder_dropout < 0.f || c->decoder_dropout >= 1.f) return dh::fail(DH_ERR_INVALID, "%s: dropout outside [0, 1)", me);
-  if (c->phase < 0 || c->phase > 2 || (c->phase != 0 && (n_steps != 1 || !c->grads))) return dh::fail(DH_ERR_INVALID, "%s: phases 1 / 2 take one step and a gradient buffer", me);
-  if (c->phase != 2 && (!c->z_out || !c->loss_out)) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  if (c->phase < 0 || c->phase > 3 || ((c->phase == 1 || c->phase == 2) && (n_steps != 1 || !c->grads)))
+    return dh::fail(DH_ERR_INVALID, "%s: phases 1 / 2 take one step and a gradient buffer", me);
+  if (c->phase == 3 && (n_steps != 1 || !c->ax_out)) return dh::fail(DH_ERR_INVALID, "%s: phase 3 (aggregate only) takes one step and ax_out", me);
+  if (c->phase < 2 && (!c->z_out || !c->loss_out)) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  if (c->phase < 2 && (2 * c->emb + c->batch) * 4 > 48 * 1024) return dh::fail(DH_ERR_INVALID, "%s: batch %lld too large for the one-workgroup-per-seed decoder (use phase 3 + the all-pairs kernels)", me, (long long)c->batch);
   const int B = (int)c->batch, F = (int)c->in_feats, H = (int)c->hidden, E = (int)c->emb, G = (int)c->n_genes;
   const GscLayout l = gsc_layout(G, B, F, H, E);
   if (c->workspace_bytes < l.total) return dh::fail(DH_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", me, c->workspace_bytes, l.total);
@@ -1150,6 +1161,18 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
     hipLaunchKernelGGL(ms_adam_kernel, dim3((unsigned)dh::ceil_div(longest, 256), (unsigned)ga.n_jobs), dim3(256), 0, st, ga);
     return dh::check_launch(me);
   }
+  if (c->phase == 3) {  // aggregate only: counters, both forwards' AX (no Adam tick, no dense layer)
+    if (dh::zero_async(a.count, (size_t)G * 4, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: clearing the counters failed", me);
+    const bool drop3 = c->dropout > 0.f;
+    const int nbc = (B + 3) / 4, nbd = drop3 ? (int)dh::ceil_div(2 * (((int64_t)G * F + 3) / 4), 256) : 0;
+    const Drop dx3 = make_drop(c->dropout, c->seed, c->step0 + (uint64_t)first_step);
+    StepCounters none{};
+    a.ax_out = c->ax_out;
+    const int64_t* seeds3 = c->seeds + first_step * B;
+    hipLaunchKernelGGL(gsc_prepare_kernel, dim3((unsigned)(nbc + nbd)), dim3(256), 0, st, a, seeds3, dx3, none, hy, nbc);
+    hipLaunchKernelGGL(gsc_forward_kernel<true>, dim3((unsigned)B), dim3(256), 0, st, a, seeds3, dx3, dx3, (float*)nullptr);
+    return dh::check_launch(me);
+  }
   // the mirror of W2 and the gene counters may be stale (an eager step in between, a first call): one launch each per call
   hipLaunchKernelGGL(ms_transpose_kernel, dim3((unsigned)dh::ceil_div((int64_t)E * H, 256)), dim3(256), 0, st, E, H, c->w2.param, w2t);
   if (dh::zero_async(a.count, (size_t)G * 4, st) != hipSuccess) return dh::fail(DH_ERR_LAUNCH, "%s: clearing the counters failed", me);
@@ -1162,7 +1185,7 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
     const Drop dx = make_drop(c->dropout, c->seed, gstep), dd = make_drop(c->decoder_dropout, c->seed, gstep);
     const int64_t* seeds = c->seeds + s * B;
     hipLaunchKernelGGL(gsc_prepare_kernel, dim3((unsigned)(nb_count + nb_drop)), dim3(256), 0, st, a, seeds, dx, sc, hy, nb_count);
-    hipLaunchKernelGGL(gsc_forward_kernel, dim3((unsigned)B), dim3(256), 0, st, a, seeds, dx, dd, c->z_out + s * (int64_t)B * E);
+    hipLaunchKernelGGL(gsc_forward_kernel<false>, dim3((unsigned)B), dim3(256), 0, st, a, seeds, dx, dd, c->z_out + s * (int64_t)B * E);
     hipLaunchKernelGGL(gsc_decoder_kernel, dim3((unsigned)B), dim3(256), dec_lds, st, a, dd, (float)pos_weight, (float)(norm / (b * b)));
     ga.loss_out = c->loss_out + s;
     launch_grad(ga, B, st);

@@ -661,13 +661,14 @@ def pairwise_distance(X: torch.Tensor, metric: int = METRIC_EUCLIDEAN) -> torch.
     return out
 
 
-KNN_AUTO, KNN_SCAN, KNN_FILTER = 0, 1, 2
+KNN_AUTO, KNN_SCAN, KNN_FILTER, KNN_GRID = 0, 1, 2, 3
 
 
 def knn(X: torch.Tensor, k: int, q_begin: int = 0, q_end: Optional[int] = None, *,
         algo: int = KNN_AUTO) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact kNN (self included), ordered by (distance, index); returns (idx int32 [nq,k], dist f32 [nq,k]).
-    ``algo``: KNN_SCAN (vector-ALU scan), KNN_FILTER (matrix-core filter + exact re-rank) or KNN_AUTO — same result."""
+    ``algo``: KNN_SCAN (vector-ALU scan), KNN_FILTER (matrix-core filter + exact re-rank), KNN_GRID (cell grid; d <= 3, k <= 32: what KNN_AUTO
+    picks for spatial coordinates) or KNN_AUTO — same result, bit for bit."""
     lib = _lib_ready()
     n, d = X.shape
     q_end = n if q_end is None else q_end

@@ -30,7 +30,7 @@ class GraphSCStep(ctypes.Structure):
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
                 ("dropout", c_float), ("decoder_dropout", c_float),
                 ("seed", c_uint64), ("step0", c_uint64),
-                ("seeds", c_void_p), ("z_out", c_void_p), ("loss_out", c_void_p), ("bad", c_void_p), ("grads", c_void_p),
+                ("seeds", c_void_p), ("z_out", c_void_p), ("loss_out", c_void_p), ("bad", c_void_p), ("grads", c_void_p), ("ax_out", c_void_p),
                 ("workspace", c_void_p), ("workspace_bytes", c_size_t)]
 
 
@@ -187,6 +187,22 @@ class GraphSCStepper(_Stepper):
                 c.phase = 2
                 self._run(lib.dh_graphsc_steps, "graphsc_steps", s, 1)
         c.step0 += n_steps
+
+
+    def aggregate(self, seeds: torch.Tensor) -> torch.Tensor:
+        """[2, batch, in_feats]: what ``WeightedGraphConv`` multiplies by its weight for the batch ``seeds`` — sum_e w_e D_out^-1/2 x_src,
+        scaled by D_in^-1/2 (and 1 / in-degree for "mean") — for the two forwards of a batch, each with its own draw of the input dropout
+        (dh_graphsc_steps phase 3: two launches on the graph's CSR rows; no block, no gradient — the input features are a leaf)."""
+        lib = _lib.load()
+        assert seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.numel() == self.batch
+        c = self.cfg
+        out = torch.empty((2, self.batch, int(c.in_feats)), dtype=torch.float32, device=seeds.device)
+        c.dropout = float(self.model.dropout.p) if self.model.dropout is not None and self.model.training else 0.0
+        c.seeds, c.ax_out, c.phase = seeds.data_ptr(), out.data_ptr(), 3
+        self._run(lib.dh_graphsc_steps, "graphsc_aggregate", 0, 1)
+        c.phase, c.ax_out = 0, None
+        c.step0 += 1
+        return out
 
 
 class ScDeepSortStepper(_Stepper):

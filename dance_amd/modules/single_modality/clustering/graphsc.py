@@ -282,6 +282,24 @@ def gram_listed_bce(z, us, vs, pos_weight):
     return _GramListedBCE.apply(z.contiguous(), us.to(torch.int32), vs.to(torch.int32), float(pos_weight))
 
 
+class _AggFirstConv(torch.autograd.Function):
+    """relu((A_norm X) W + b) for an aggregated, gradient-free input ``ax`` = A_norm X (dh_graphsc_steps phase 3): the WeightedGraphConv of a
+    batch in the aggregate-first order — one product on the matrix cores, and a backward that is dW = ax^T (dy o [y > 0]), db = column sums:
+    the transposed block graphsc.py's multiply-first order needs for dX W^T never exists (the input features carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, ax, weight, bias):
+        y = kernels.gemm(ax, weight, bias=bias.detach(), act=kernels.ACT_RELU)
+        ctx.save_for_backward(ax, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ax, y = ctx.saved_tensors
+        g = kernels.relu_backward(y, dy.contiguous())
+        return None, kernels.gemm(ax, g, trans_a=True), kernels.colsum(g)
+
+
 class _PinnedCounts:
     """A small ring of pinned int64 scalars for asynchronous count reads: a slot is handed out again ``slots`` batches later,
     long after its value was read (the loader runs one batch ahead)."""
@@ -493,8 +511,15 @@ class GraphSC(BaseClusteringMethod):
         use_mini = (MINISTEP and fused and dataloader.cells_only and g.device.type == "cuda" and n_full >= 1 and 1 < batch_size <= MINISTEP_MAX_BATCH
                     and not self.capture_split and GraphSCStepper.eligible(self.model, g, batch_size, optim))
         stepper = GraphSCStepper(self.model, g, batch_size, optim, world) if use_mini else None
-        use_graph = use_graph and not use_mini
-        self.step_mode = "ministep" if use_mini else "hipgraph" if use_graph else "eager"
+        # batches past MINISTEP_MAX_BATCH keep the persistent step's FIRST half — the aggregation straight off the CSR rows, both forwards,
+        # no block / degree kernels / transposed copy (dh_graphsc_steps phase 3) — and run the dense layers, the all-pairs decoder and Adam
+        # on the big-tile kernels through autograd ("aggfirst"): ~40 launches per batch instead of ~150 and no host read-back
+        use_agg = (MINISTEP and not use_mini and fused and dataloader.cells_only and g.device.type == "cuda" and n_full >= 1 and batch_size > MINISTEP_MAX_BATCH
+                   and not self.capture_split and GraphSCStepper.eligible(self.model, g, batch_size, optim))
+        if use_agg:
+            stepper = GraphSCStepper(self.model, g, batch_size, optim, 1)
+        use_graph = use_graph and not use_mini and not use_agg
+        self.step_mode = "ministep" if use_mini else "aggfirst" if use_agg else "hipgraph" if use_graph else "eager"
         self.losses, aris, Z = [], [], {}
         for epoch in range(epochs):
             self.model.train()
@@ -514,6 +539,37 @@ class GraphSC(BaseClusteringMethod):
                 losses.extend(loss_all.unbind(0))
                 batches = []
                 if n_full * batch_size < idx.numel():  # the short last batch runs eagerly
+                    tail = sampler.sample(g, idx[n_full * batch_size:], True)
+                    tail[2][-1].hook_out = _dst_edge_hook(tail[2])
+                    batches = [tail]
+            elif use_agg:
+                idx = dataloader.indices
+                perm = (torch.randperm(idx.numel(), device=idx.device) if self.shuffle_generator is None else
+                        torch.randperm(idx.numel(), generator=self.shuffle_generator).to(idx.device))
+                idx = idx[perm].contiguous()
+                z_all = torch.empty((n_full * batch_size, self.model.embedding_dim), dtype=torch.float32, device=g.device)
+                l1, enc = self.model.layer1, self.model.encoder[0]
+                b = float(batch_size)
+                pos_weight, norm = (b * b - b) / b, b * b / ((b * b - b) * 2)  # graphsc.py:210-214 with adj = I (the seeds' self loops; checked per epoch)
+                diag = torch.arange(batch_size, dtype=torch.int32, device=g.device)
+                for i in range(n_full):
+                    ax = stepper.aggregate(idx[i * batch_size:(i + 1) * batch_size])
+                    with torch.no_grad():  # :202-203 — only the embedding is kept
+                        h0 = kernels.gemm(ax[0], l1.weight, bias=l1.bias, act=kernels.ACT_RELU)
+                        kernels.gemm(h0, enc.weight, trans_b=True, bias=enc.bias, out=z_all[i * batch_size:(i + 1) * batch_size])
+                    emb2 = enc(_AggFirstConv.apply(ax[1], l1.weight, l1.bias))  # :215, fresh dropout
+                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), diag, diag, pos_weight)
+                    optim.zero_grad(set_to_none=True)
+                    loss.backward()
+                    sharding.allreduce_gradients(self.model)
+                    if not kernels.adam_step(optim):
+                        optim.step()
+                    losses.append(loss.detach())
+                stepper.check_flags("GraphSC.fit")
+                z.append(z_all)
+                order.append(g.ndata["order"][idx[:n_full * batch_size]])
+                batches = []
+                if n_full * batch_size < idx.numel():  # the short last batch runs through the general loop
                     tail = sampler.sample(g, idx[n_full * batch_size:], True)
                     tail[2][-1].hook_out = _dst_edge_hook(tail[2])
                     batches = [tail]

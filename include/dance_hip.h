@@ -48,7 +48,7 @@ enum dh_status {
 
 enum dh_act { DH_ACT_NONE = 0, DH_ACT_RELU = 1 };
 enum dh_reduce { DH_REDUCE_SUM = 0, DH_REDUCE_MEAN = 1 };
-enum dh_knn_algo { DH_KNN_AUTO = 0, DH_KNN_SCAN = 1, DH_KNN_FILTER = 2 };
+enum dh_knn_algo { DH_KNN_AUTO = 0, DH_KNN_SCAN = 1, DH_KNN_FILTER = 2, DH_KNN_GRID = 3 };
 enum dh_dtype { DH_DTYPE_F32 = 0, DH_DTYPE_BF16 = 1 };
 enum dh_metric { DH_METRIC_EUCLIDEAN = 0, DH_METRIC_PEARSON = 1, DH_METRIC_SPEARMAN = 2 };
 
@@ -741,7 +741,9 @@ DH_API int dh_adam_step_f32(int n, float* const* params, const float* const* gra
  * bad[0] collects flags (never cleared here): 1 = a seed is not a cell row of that layout, 2 = a seed without exactly one self loop
  * (graph-sc's identity decoder target), 4 = a label outside [0, n_classes).
  * phase: 0 = whole steps; 1 = stop after the gradients, written to `grads` (flat: w1 | b1 | w2 | b2) — the data-parallel form, the
- * caller all-reduces them; 2 = apply `grads` (Adam only).  Phases 1 and 2 take n_steps == 1.                                            */
+ * caller all-reduces them; 2 = apply `grads` (Adam only); 3 (graph-sc) = the aggregation alone: ax_out[2, batch, in_feats] = the
+ * D_out^-1/2 / edge-weight / D_in^-1/2 sums of both forwards (each with its own dropout draw) — what the layer multiplies by its weight;
+ * large batches run the dense layers and the all-pairs decoder on the big-tile kernels from there.  Phases 1 - 3 take n_steps == 1.      */
 typedef struct dh_adam_state { /* one parameter tensor of torch.optim.Adam (amsgrad = False) */
   float* param;
   float* exp_avg;
@@ -771,6 +773,7 @@ typedef struct dh_graphsc_step {
   float* loss_out;
   int32_t* bad;
   float* grads;
+  float* ax_out;
   void* workspace;
   size_t workspace_bytes;
 } dh_graphsc_step_t;

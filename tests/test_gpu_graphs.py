@@ -357,3 +357,79 @@ def test_heteronet_graph_other_metrics_vs_sklearn(cuda_device, metric):
     got = edges[:, 1].reshape(800, k + 1)
     same = sum(set(a) == set(b) for a, b in zip(got, ref))
     assert same >= 798, same   # (fp32 vs float64 distances may swap the last neighbour of a row or two)
+
+
+# ---- DH_KNN_GRID: the cell-grid kNN of spatial coordinates (d <= 3) — same bits as the scan ----------------------------------------------
+def _grid_points(kind, n, d, rng):
+    if kind == "uniform":
+        return rng.random((n, d)) * 100.0
+    if kind == "hex":  # BASELINE config 5's jittered hex grid, a thin third dimension
+        side = int(np.ceil(np.sqrt(n)))
+        gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+        xy = np.stack([gx.ravel() + 0.5 * (gy.ravel() % 2), gy.ravel() * 0.866], 1)[:n] + rng.normal(0, 0.05, (n, 2))
+        return np.hstack([xy, rng.normal(0, 0.3, (n, 1))])[:, :d]
+    if kind == "lattice":  # exact ties everywhere: integer coordinates
+        return rng.integers(0, 40, size=(n, d)).astype(np.float64)
+    if kind == "clusters":  # dense blobs + far outliers: queries that need many rings / the whole-array fallback
+        x = rng.standard_normal((n, d)) * 0.01 + rng.integers(0, 5, size=(n, 1)) * 50.0
+        x[:7] = rng.random((7, d)) * 1e4 + 1e3
+        return x
+    if kind == "duplicates":  # more copies of a point than k: ties broken by index
+        x = rng.random((n, d))
+        x[n // 2:] = x[:n - n // 2]
+        return x
+    if kind == "offset":  # coordinates far from the origin: the slack has to cover their rounding
+        return rng.random((n, d)) * 3.0 + 5000.0
+    if kind == "line":  # a degenerate extent (all y equal)
+        x = rng.random((n, d)) * 10.0
+        if d > 1:
+            x[:, 1] = 2.5
+        return x
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind,n,d,k", [("uniform", 5000, 3, 15), ("uniform", 3000, 2, 8), ("uniform", 2500, 1, 5), ("hex", 20000, 3, 15), ("hex", 9000, 2, 32),
+                                        ("lattice", 6000, 3, 15), ("lattice", 4000, 2, 10), ("clusters", 8000, 3, 15), ("duplicates", 4000, 3, 6),
+                                        ("offset", 5000, 3, 15), ("line", 3000, 3, 12), ("uniform", 300, 3, 15), ("uniform", 40, 2, 32)])
+def test_knn_grid_equals_scan(cuda_device, kind, n, d, k):
+    """The grid path returns the scan's indices and distances bit for bit (and the numpy oracle's, at the sizes the oracle finishes):
+    regular and irregular densities, exact ties, duplicates, outliers, degenerate extents, k up to 32, fewer than 2048 points (explicit
+    algo), and it is what KNN_AUTO picks from 2048 points on."""
+    from dance_amd import kernels
+    x = _grid_points(kind, n, d, np.random.default_rng(n + 7 * d + k)).astype(np.float32)
+    xt = _t(x, cuda_device)
+    i_s, d_s = kernels.knn(xt, k, algo=kernels.KNN_SCAN)
+    i_g, d_g = kernels.knn(xt, k, algo=kernels.KNN_GRID)
+    assert torch.equal(i_s, i_g) and torch.equal(d_s, d_g)
+    i_a, d_a = kernels.knn(xt, k)
+    assert torch.equal(i_a, i_s) and torch.equal(d_a, d_s)
+    if n <= 6000:
+        ref_idx, ref_dist = og.knn_exact(x, k)
+        assert np.array_equal(i_g.cpu().numpy(), ref_idx) and np.array_equal(d_g.cpu().numpy(), ref_dist)
+
+
+def test_knn_grid_query_range_and_strided_input(cuda_device):
+    from dance_amd import kernels
+    rng = np.random.default_rng(5)
+    base = torch.from_numpy(rng.random((7000, 8)).astype(np.float32)).to(cuda_device)
+    x = base[:, :3]  # leading dimension 8
+    i_s, d_s = kernels.knn(x.contiguous(), 15, algo=kernels.KNN_SCAN)
+    i_g, d_g = kernels.knn(x, 15, 1234, 4321, algo=kernels.KNN_GRID)
+    assert torch.equal(i_g, i_s[1234:4321]) and torch.equal(d_g, d_s[1234:4321])
+
+
+def test_knn_grid_at_config5_size(cuda_device):
+    """500k spots in 3-d (BASELINE config 5): the grid build against the matrix-core filter + re-rank — same graph, and the time."""
+    import time
+
+    from dance_amd import kernels
+    x = _t(_grid_points("hex", 500_000, 3, np.random.default_rng(5)).astype(np.float32), cuda_device)
+    kernels.knn(x, 15)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    i_g, d_g = kernels.knn(x, 15)
+    torch.cuda.synchronize()
+    t_grid = time.perf_counter() - t0
+    i_f, d_f = kernels.knn(x, 15, algo=kernels.KNN_FILTER)
+    assert torch.equal(i_g, i_f) and torch.equal(d_g, d_f)
+    assert t_grid < 0.1, t_grid

@@ -153,21 +153,23 @@ def _gold_model(gold, tag, agg):
     return m
 
 
-@pytest.mark.parametrize("tag,agg", [("mb", "sum"), ("mean", "mean")])
-def test_graphsc_fit_ministep_vs_reference(cuda_device, gold, monkeypatch, tag, agg):
-    """GraphSC.fit on the persistent step (every full batch of an epoch in one C call, the short last batch eagerly) reproduces the
-    reference's OWN fit: every per-batch loss, the final embedding in cell order and the final weights (graphsc.npz) — and the general
-    loop's numbers to rounding."""
+@pytest.mark.parametrize("tag,agg,mode", [("mb", "sum", "ministep"), ("mean", "mean", "ministep"), ("mb", "sum", "aggfirst"), ("mean", "mean", "aggfirst")])
+def test_graphsc_fit_ministep_vs_reference(cuda_device, gold, monkeypatch, tag, agg, mode):
+    """GraphSC.fit on the persistent step (every full batch of an epoch in one C call, the short last batch eagerly) — and on its
+    large-batch form ("aggfirst": the aggregation of dh_graphsc_steps phase 3, dense layers / all-pairs decoder / Adam on the big-tile
+    kernels; forced at this toy size) — reproduces the reference's OWN fit: every per-batch loss, the final embedding in cell order and
+    the final weights (graphsc.npz) — and the general loop's numbers to rounding."""
     from dance_amd.modules.single_modality.clustering import graphsc
     res = {}
     for on in (True, False):
         monkeypatch.setattr(graphsc, "MINISTEP", on)
         monkeypatch.setattr(graphsc, "HIPGRAPH", False)
+        monkeypatch.setattr(graphsc, "MINISTEP_MAX_BATCH", 512 if mode == "ministep" else 8)
         g = _gold_graph(gold)
         m = _gold_model(gold, tag, agg)
         m.shuffle_generator = torch.Generator().manual_seed(123)
         m.fit(g, epochs=3, lr=1e-2, batch_size=16)
-        assert m.step_mode == ("ministep" if on else "eager")
+        assert m.step_mode == (mode if on else "eager")
         res[on] = (np.asarray(m.losses), m.get_latent().copy(), {k: v.detach().cpu().numpy().copy() for k, v in m.model.state_dict().items()})
     ref = gold[f"gsc_{tag}_losses"]
     assert len(res[True][0]) == len(ref) and np.allclose(res[True][0], ref, rtol=2e-4, atol=0)
@@ -176,6 +178,38 @@ def test_graphsc_fit_ministep_vs_reference(cuda_device, gold, monkeypatch, tag, 
         if k.startswith(f"gsc_{tag}_sd1::"):
             assert rel_err(res[True][2][k.split("::", 1)[1]], gold[k]) < 1e-3, k
     assert np.allclose(res[True][0], res[False][0], rtol=1e-5) and rel_err(res[True][1], res[False][1]) < 1e-5
+
+
+def test_graphsc_aggregate_phase_vs_oracle(cuda_device):
+    """dh_graphsc_steps phase 3: the aggregated layer input of both forwards (own dropout draws) == the oracle's A_norm (X o mask)."""
+    from dance_amd.ministep import GraphSCStepper
+    b, n_genes, f, p = 40, 30, 50, 0.2
+    g = _graph(200, n_genes, f, 4, cuda_device, normalize_edges=False)
+    rowptr, col, val = _host(g)
+    feats = g.ndata["features"].cpu().numpy().astype(np.float64)
+    m = _gsc_model(f, 20, 12, "sum", p, 0.0, cuda_device)
+    optim = torch.optim.Adam(m.model.parameters(), lr=1e-2, fused=True)
+    st = GraphSCStepper(m.model, g, b, optim)
+    seeds = (n_genes + torch.randperm(200, generator=torch.Generator().manual_seed(1))[:b]).to(cuda_device)
+    ax = st.aggregate(seeds).cpu().numpy()
+    st.check_flags("test")
+    sd = seeds.cpu().numpy()
+    cnt = np.zeros(n_genes)
+    for v in sd:
+        for e in range(rowptr[v], rowptr[v + 1]):
+            if col[e] < n_genes:
+                cnt[col[e]] += 1
+    for k in range(2):
+        m_self = oms.dropout_mask(b * f, p, st.cfg.seed, 0, oms.SID_SELF + k).reshape(b, f)
+        m_gene = oms.dropout_mask(n_genes * f, p, st.cfg.seed, 0, oms.SID_GENE + k).reshape(n_genes, f)
+        ref = np.zeros((b, f))
+        for i, v in enumerate(sd):
+            for e in range(rowptr[v], rowptr[v + 1]):
+                c = col[e]
+                ref[i] += val[e] * (feats[c] * m_gene[c] / np.sqrt(max(cnt[c], 1.0)) if c < n_genes else feats[v] * m_self[i])
+            ref[i] /= np.sqrt(max(rowptr[v + 1] - rowptr[v], 1))
+        assert rel_err(ax[k], ref) < 1e-5, k
+    assert st.cfg.step0 == 1
 
 
 def test_graphsc_fit_ministep_dropout_is_keyed_by_torch_seed(cuda_device):
