@@ -148,6 +148,10 @@ def _declare(lib):
         "dh_csr_degree_scales_f32": (c_int, [i64, i64, i64, P, P, i32, P, P, P, P]),
         "dh_adam_step_f32": (c_int, [i32, P, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, P]),
         "dh_sage_alpha_grad_f32": (c_int, [i64, i64, i64, i64, P, P, P, P, P, P, i64, P, i64, P, P]),
+        "dh_dec_target_f32": (c_int, [i64, i64, P, i64, P, P, i64, P]),
+        "dh_dec_kl_workspace_bytes": (c_size_t, []),
+        "dh_dec_kl_forward_f32": (c_int, [i64, i64, P, i64, P, i64, c_float, c_double, P, P, c_size_t, P]),
+        "dh_dec_kl_backward_f32": (c_int, [i64, i64, P, i64, P, i64, c_float, c_double, P, P, i64, P]),
         "dh_graphsc_step_supported": (c_int, [i64, i64, i64, i64]),
         "dh_graphsc_step_workspace_bytes": (c_size_t, [i64, i64, i64, i64, i64]),
         "dh_graphsc_steps": (c_int, [P, i64, i64, P]),            # dh_graphsc_step_t* (dance_amd/ministep.py mirrors the struct)

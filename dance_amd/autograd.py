@@ -582,6 +582,40 @@ class _StudentTFn(torch.autograd.Function):
         return dz, (dmu if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
+class _DecKLFn(torch.autograd.Function):
+    """scale * sum_ij p log(p / (q + eps)), differentiable in q (p is the fixed target): spagcn.py:398-407 on dh_dec_kl_forward / _backward_f32."""
+
+    @staticmethod
+    def forward(ctx, p, q, eps, scale):
+        p = p if p.stride(-1) == 1 else p.contiguous()
+        q = q if q.stride(-1) == 1 else q.contiguous()
+        ctx.save_for_backward(p, q)
+        ctx.consts = (float(eps), float(scale))
+        return kernels.dec_kl_forward(p, q, eps, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q = ctx.saved_tensors
+        return None, kernels.dec_kl_backward(p, q, *ctx.consts, g.contiguous().to(torch.float32)), None, None
+
+
+def dec_kl_loss(p: torch.Tensor, q: torch.Tensor, *, eps: float = 1e-6, scale: float) -> torch.Tensor:
+    """``scale * sum(p * log(p / (q + eps)))`` — the DEC heads' KL loss (``scale`` = 1 / n_spots gives the reference's mean over spots of the
+    row sums).  Fused kernels for fp32 device tensors with at most 4096 clusters; the reference's torch expression otherwise."""
+    if p.is_cuda and q.is_cuda and p.dtype == torch.float32 and q.dtype == torch.float32 and p.dim() == 2 and p.shape == q.shape and q.shape[1] <= 4096:
+        return _DecKLFn.apply(p.detach(), q, eps, scale)
+    return torch.sum(p * torch.log(p / (q + eps))) * scale
+
+
+def dec_target_distribution(q: torch.Tensor, colsum_q=None) -> torch.Tensor:
+    """``p = q**2 / q.sum(0); p / p.sum(1, keepdim=True)`` (spagcn.py:421-425) — one kernel after the column sums for fp32 device tensors."""
+    if q.is_cuda and q.dtype == torch.float32 and q.dim() == 2 and q.shape[1] <= 4096 and not q.requires_grad:
+        return kernels.dec_target(q, colsum_q)
+    f = torch.sum(q, dim=0) if colsum_q is None else colsum_q
+    p = q**2 / f
+    return p / torch.sum(p, dim=1, keepdim=True)
+
+
 def student_t_assign(z: torch.Tensor, mu: torch.Tensor, *, a: float, eps: float, pw: float, scale: float = 1.0) -> torch.Tensor:
     """Soft cluster assignment of the DEC heads (SimpleGCDEC / GC_DEC: spagcn.py:394-396,605-607; ScDSCModel: scdsc.py:466-468), rows
     normalised, differentiable in ``z`` and ``mu``.  Shapes the fused kernels do not cover (kernels.student_t_supported: more than 64 clusters, C d > 4096, wide embeddings; non-fp32)

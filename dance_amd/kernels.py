@@ -974,6 +974,39 @@ def adam_step(optimizer) -> bool:
 _cpu_adam = None  # (tests/cpu_ops.py patches adam_step itself; nothing here runs on CPU tensors)
 
 
+# ---- DEC heads: target distribution and KL loss (dec_loss.hip) -----------------------------------------------------------------------
+def dec_target(q: torch.Tensor, colsum_q: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """p = (q^2 / sum_i q) with rows normalised (spagcn.py:421-425) in one pass; ``colsum_q`` = the (all-reduced) column sums when given."""
+    lib = _lib_ready()
+    q = q if q.stride(-1) == 1 else q.contiguous()
+    if colsum_q is None:
+        colsum_q = colsum(q)
+    p = torch.empty((q.shape[0], q.shape[1]), dtype=torch.float32, device=q.device)
+    _call("dec_target_f32", lib.dh_dec_target_f32, q.shape[0], q.shape[1], _dev(q, torch.float32, "q", 2), _ld(q), _dev(colsum_q, torch.float32, "colsum_q", 1),
+          p.data_ptr(), _ld(p), _stream())
+    return p
+
+
+def dec_kl_forward(p: torch.Tensor, q: torch.Tensor, eps: float, scale: float) -> torch.Tensor:
+    """scale * sum_ij p log(p / (q + eps)) as a 0-d tensor (dh_dec_kl_forward_f32)."""
+    lib = _lib_ready()
+    out = torch.empty((), dtype=torch.float32, device=q.device)
+    nb = int(lib.dh_dec_kl_workspace_bytes())
+    ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
+    _call("dec_kl_forward_f32", lib.dh_dec_kl_forward_f32, q.shape[0], q.shape[1], _dev(p, torch.float32, "p", 2), _ld(p), _dev(q, torch.float32, "q", 2), _ld(q),
+          float(eps), float(scale), out.data_ptr(), ws.data_ptr(), nb, _stream())
+    return out
+
+
+def dec_kl_backward(p: torch.Tensor, q: torch.Tensor, eps: float, scale: float, g: torch.Tensor) -> torch.Tensor:
+    """dq = -g scale p / (q + eps) (dh_dec_kl_backward_f32); ``g``: the 0-d upstream gradient, on the device."""
+    lib = _lib_ready()
+    dq = torch.empty((q.shape[0], q.shape[1]), dtype=torch.float32, device=q.device)
+    _call("dec_kl_backward_f32", lib.dh_dec_kl_backward_f32, q.shape[0], q.shape[1], _dev(p, torch.float32, "p", 2), _ld(p), _dev(q, torch.float32, "q", 2), _ld(q),
+          float(eps), float(scale), g.data_ptr(), dq.data_ptr(), _ld(dq), _stream())
+    return dq
+
+
 # ---- AdaptiveSAGE ------------------------------------------------------------------------------------------
 def sage_aggregate(rowptr, col, w, src_cell_id, dst_cell_id, alpha, H) -> torch.Tensor:
     """neigh[v] = mean_e alpha[idx(e)] * w_e * H[src(e)] (dh_sage_aggregate_f32)."""

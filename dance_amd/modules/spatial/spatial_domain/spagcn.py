@@ -15,7 +15,7 @@ from torch import nn, optim
 from torch.nn.parameter import Parameter
 
 from .... import kernels
-from ....autograd import dense_adj_layer, gcn_layer, student_t_assign
+from ....autograd import dec_kl_loss, dec_target_distribution, dense_adj_layer, gcn_layer, student_t_assign
 from ....graph import CSRGraph, as_graph
 from ....sharding import ShardedGCNGraph, sharded_gcn_layer
 from ....transforms import CellPCA, Compose, SetConfig
@@ -55,6 +55,18 @@ class GraphConvolution(nn.Module):
 
     def __repr__(self):
         return f"{self.__class__.__name__}({self.in_features} -> {self.out_features})"
+
+
+def _on_gpu(device) -> bool:
+    return str(device).startswith("cuda")
+
+
+def _step(optimizer):
+    """``optimizer.step()``; a ``torch.optim.Adam`` with device-side step counters (``capturable=True``: what the fits create on a GPU) takes
+    dh_adam_step_f32 — two launches for gc.weight, gc.bias and mu instead of the ~14 of the framework's multi-tensor implementation — once
+    its state exists (the first step creates it); torch's own arithmetic (adam.hip)."""
+    if not kernels.adam_step(optimizer):
+        optimizer.step()
 
 
 def _to_device_f32(a, device):
@@ -143,19 +155,15 @@ class SimpleGCDEC(nn.Module):
         return t
 
     def loss_function(self, p, q):
-
-        def kld(target, pred):
-            per_spot = torch.sum(target * torch.log(target / (pred + 1e-6)), dim=1)
-            if self._sg is None:
-                return torch.mean(per_spot)
-            # mean over ALL spots: local sum / N (its gradient is the local part of the global mean's; mu's is all-reduced in fit)
-            return per_spot.sum() / self._sg.n_nodes
-
-        return kld(p, q)
+        # kld(p, q) = mean over spots of sum_j p log(p / (q + 1e-6)) (:399-407); sharded: the local sum over N_all (its gradient is the local
+        # part of the global mean's; mu's is all-reduced in fit).  One fused kernel each way instead of ~10 elementwise launches.
+        n_all = q.shape[0] if self._sg is None else self._sg.n_nodes
+        return dec_kl_loss(p, q, eps=1e-6, scale=1.0 / n_all)
 
     def target_distribution(self, q):
-        p = q**2 / self._allsum(torch.sum(q, dim=0))
-        return p / torch.sum(p, dim=1, keepdim=True)
+        if self._sg is not None and self._sg.world > 1:
+            return dec_target_distribution(q.detach(), self._allsum(torch.sum(q.detach(), dim=0)))
+        return dec_target_distribution(q.detach()) if not q.requires_grad or not torch.is_grad_enabled() else dec_target_distribution(q)
 
     def _adj(self, adj):
         if isinstance(adj, (CSRGraph, ShardedGCNGraph)):
@@ -183,7 +191,7 @@ class SimpleGCDEC(nn.Module):
         if opt == "sgd":
             optimizer = optim.SGD(self.parameters(), lr=lr, momentum=0.9)
         elif opt == "admin":
-            optimizer = optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay)
+            optimizer = optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay, capturable=_on_gpu(self.device))
         else:
             raise ValueError(f"Unknown optimizer {opt!r}")
         with torch.no_grad():
@@ -224,16 +232,19 @@ class SimpleGCDEC(nn.Module):
             pass
         self.train()
         for epoch in range(epochs):
+            fwd = None
             if epoch % update_interval == 0:
-                _, q = self.forward(X, adj)
-                p = self.target_distribution(q).data
+                # the reference runs the forward twice here — once for the target (:512-514), once for the loss (:516) — with nothing
+                # changed in between and no randomness in SimpleGCDEC's forward: the second pass is the first, bit for bit, so ONE is run
+                fwd = self(X, adj)
+                p = self.target_distribution(fwd[1].detach()).data
             optimizer.zero_grad()
-            z, q = self(X, adj)
+            z, q = fwd if fwd is not None else self(X, adj)
             loss = self.loss_function(p, q)
             loss.backward()
             if sharded and self.mu.grad is not None:  # gc's gradients are all-reduced inside the sharded layer; mu's here
                 dist.all_reduce(self.mu.grad, group=self._sg.group)
-            optimizer.step()
+            _step(optimizer)
             if epoch % trajectory_interval == 0:
                 self.trajectory.append(torch.argmax(q, dim=1).data.cpu().numpy())
             y_pred = torch.argmax(q, dim=1).data.detach().cpu().numpy()
@@ -255,7 +266,7 @@ class SimpleGCDEC(nn.Module):
         if opt == "sgd":
             optimizer = optim.SGD(self.parameters(), lr=lr, momentum=0.9)
         elif opt == "admin":
-            optimizer = optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay)
+            optimizer = optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay, capturable=_on_gpu(self.device))
         else:
             raise ValueError(f"Unknown optimizer {opt!r}")
         with torch.no_grad():
@@ -270,14 +281,17 @@ class SimpleGCDEC(nn.Module):
         self.mu.data.copy_(centers)
         self.train()
         for epoch in range(epochs):
+            fwd = None
             if epoch % update_interval == 0:
-                _, q = self.forward(X, adj)
-                p = self.target_distribution(q).data
+                # the reference runs the forward twice here — once for the target (:512-514), once for the loss (:516) — with nothing
+                # changed in between and no randomness in SimpleGCDEC's forward: the second pass is the first, bit for bit, so ONE is run
+                fwd = self(X, adj)
+                p = self.target_distribution(fwd[1].detach()).data
             optimizer.zero_grad()
-            z, q = self(X, adj)
+            z, q = fwd if fwd is not None else self(X, adj)
             loss = self.loss_function(p, q)
             loss.backward()
-            optimizer.step()
+            _step(optimizer)
 
     @torch.no_grad()
     def predict(self, X, adj):
@@ -336,20 +350,21 @@ class GC_DEC(SimpleGCDEC):
         self.train()
         for epoch in range(epochs):
             if epoch % update_interval == 0:
-                _, q = self.forward(X, adj)
+                with torch.no_grad():  # (the reference builds and drops an autograd graph here; the values are the same)
+                    _, q = self.forward(X, adj)
                 p = self.target_distribution(q).data
             optimizer.zero_grad()
             z, q = self(X, adj)
             loss = self.loss_function(p, q)
             loss.backward()
-            optimizer.step()
+            _step(optimizer)
             self.trajectory.append(torch.argmax(q, dim=1).data.cpu().numpy())
 
     def _optimizer(self, opt, lr, weight_decay):
         if opt == "sgd":
             return optim.SGD(self.parameters(), lr=lr, momentum=0.9)
         if opt == "admin":
-            return optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay)
+            return optim.Adam(self.parameters(), lr=lr, weight_decay=weight_decay, capturable=_on_gpu(self.device))
         raise ValueError(f"Unknown optimizer {opt!r}")
 
     def _centres_from(self, features, labels):
@@ -369,13 +384,14 @@ class GC_DEC(SimpleGCDEC):
         self.train()
         for epoch in range(epochs):
             if epoch % update_interval == 0:
-                _, q = self.forward(X, adj)
+                with torch.no_grad():  # (the reference builds and drops an autograd graph here; the values are the same)
+                    _, q = self.forward(X, adj)
                 p = self.target_distribution(q).data
             optimizer.zero_grad()
             z, q = self(X, adj)
             loss = self.loss_function(p, q)
             loss.backward()
-            optimizer.step()
+            _step(optimizer)
 
 
 def refine(sample_id, pred, dis, shape="hexagon"):

@@ -817,6 +817,19 @@ DH_API int dh_scdeepsort_steps(const dh_scdeepsort_step_t* cfg_host, int64_t fir
  * for element e of stream `sid` at step `step`.                                                                                          */
 DH_API int dh_ministep_dropout_mask_f32(int64_t n, float p, uint64_t seed, uint64_t step, int32_t sid, float* out, dh_stream_t stream);
 
+/* ---- the DEC heads' target distribution and KL loss (dec_loss.hip) ---------------------------------------------------------------------
+ * dance/modules/spatial/spatial_domain/spagcn.py:398-407 (loss_function: mean over spots of sum_j p log(p / (q + 1e-6))), :421-425
+ * (target_distribution: p = q^2 / sum_i q, rows normalised); GC_DEC :609-620; scDSC's target_distribution scdsc.py:431-441.
+ * colsum_q [c] = the column sums of q (dh_colsum_f32; all-reduced by the caller when the spots are sharded).  kl_forward: *loss =
+ * scale * sum_ij p log(p / (q + eps)) (scale = 1 / n_spots for the mean), double accumulation in a fixed order; kl_backward:
+ * dq = -(g ? *g : 1) * scale * p / (q + eps), g = the upstream gradient of the scalar loss, on the device.                                */
+DH_API int dh_dec_target_f32(int64_t n, int64_t c, const float* q, int64_t ldq, const float* colsum_q, float* p, int64_t ldp, dh_stream_t stream);
+DH_API size_t dh_dec_kl_workspace_bytes(void);
+DH_API int dh_dec_kl_forward_f32(int64_t n, int64_t c, const float* p, int64_t ldp, const float* q, int64_t ldq, float eps, double scale, float* loss,
+                          void* workspace, size_t workspace_bytes, dh_stream_t stream);
+DH_API int dh_dec_kl_backward_f32(int64_t n, int64_t c, const float* p, int64_t ldp, const float* q, int64_t ldq, float eps, double scale, const float* g,
+                           float* dq, int64_t ldd, dh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
