@@ -34,6 +34,8 @@
 // Deterministic: fixed summation orders everywhere (integer atomics only).  No memset / memcpy nodes (capturable), no host reads.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 #include "common.h"
 
@@ -241,29 +243,49 @@ struct GscArgs {
   int dbg_fwd, dbg_dec;            // development: stop the forward / decoder kernel after phase n (DANCE_AMD_MINISTEP_DBG=f,d; 0 = run all)
 };
 
+// LDS_HIST (large batches): the count blocks are few and fat — every block walks B / nb_count seeds and counts into an LDS histogram,
+// flushed with one global atomic per touched gene.  At 8192 seeds x 200 genes the one-atomic-per-entry form was 1.6 M adds onto 2000
+// addresses: 0.2 ms, two thirds of the whole aggregation call (profiles/r06q); the histogram form is ~128 k.
+template <bool LDS_HIST>
 __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx, StepCounters sc, AdamHyper hy, int nb_count) {
+  extern __shared__ int hist[];  // [G] (LDS_HIST only)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < nb_count) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) adam_tick(sc, hy, a.coef);
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= a.B) return;
-    const int64_t v = seeds[i];
-    if (v < a.G || v >= a.n_nodes) {  // not a cell of this layout
-      if (lane == 0) atomicOr(a.bad, 1);
-      return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && sc.n > 0) adam_tick(sc, hy, a.coef);
+    if (LDS_HIST) {
+      for (int g = threadIdx.x; g < a.G; g += 256) hist[g] = 0;
+      __syncthreads();
     }
-    const int s = a.rowptr[v], t = a.rowptr[v + 1];
-    int n_self = 0;
-    for (int e = s + lane; e < t; e += 64) {
-      const int c = a.col[e];
-      if (c < a.G) atomicAdd(a.count + c, 1);
-      else if (c != v) atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
+    for (int i = blockIdx.x * 4 + wave; i < a.B; i += LDS_HIST ? nb_count * 4 : a.B) {
+      const int64_t v = seeds[i];
+      if (v < a.G || v >= a.n_nodes) {  // not a cell of this layout
+        if (lane == 0) atomicOr(a.bad, 1);
+        continue;
+      }
+      const int s = a.rowptr[v], t = a.rowptr[v + 1];
+      int n_self = 0;
+      for (int e0 = s; e0 < t; e0 += 64) {  // (uniform trip count: ballot over whole wavefronts)
+        const int e = e0 + lane;
+        const int c = a.col[min(e, t - 1)];
+        if (e < t) {
+          if (c < a.G) {
+            if (LDS_HIST) atomicAdd(hist + c, 1);
+            else atomicAdd(a.count + c, 1);
+          } else if (c != v) {
+            atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
+          }
+        }
+        n_self += __popcll(__ballot(e < t && c >= a.G));
+      }
+      if (lane == 0 && n_self != 1) atomicOr(a.bad, 2);  // the identity decoder target needs exactly one self loop per seed
     }
-    for (int e0 = s; e0 < t; e0 += 64) {  // (uniform trip count: ballot over whole wavefronts)
-      const int e = e0 + lane;
-      n_self += __popcll(__ballot(e < t && a.col[min(e, t - 1)] >= a.G));
+    if (LDS_HIST) {
+      __syncthreads();
+      for (int g = threadIdx.x; g < a.G; g += 256) {
+        const int h = hist[g];
+        if (h) atomicAdd(a.count + g, h);
+      }
     }
-    if (lane == 0 && n_self != 1) atomicOr(a.bad, 2);  // the identity decoder target needs exactly one self loop per seed
     return;
   }
   if (dx.thr >= kKeepAll) return;
@@ -463,6 +485,184 @@ __global__ __launch_bounds__(256) void gsc_forward_kernel(GscArgs a, const int64
     const float zv = (e1 + bb) * drop_scale(dd, SID_DEC, (uint64_t)i * E + o);                    // :215, :409
     a.zd2[(int64_t)i * E + o] = zv;
     a.zd2t[(int64_t)o * a.B + i] = zv;
+  }
+}
+
+template <typename Fn>
+__device__ __forceinline__ void static_for2(Fn&& f) {
+  f(std::integral_constant<int, 0>{});
+  f(std::integral_constant<int, 1>{});
+}
+
+// ---- the aggregation of a LARGE batch on the matrix cores (phase 3, thousands of seeds) -----------------------------------------------
+// AX = A_norm X_d as a dense product: 32 seed rows x G genes x F features per workgroup, the adjacency tile scattered into LDS chunk by
+// chunk (128 genes) in MFMA operand order, the (dropped) gene rows streamed through LDS once per forward, exact fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: every product w * x rounded once, fp32 accumulation — the gather kernel's arithmetic in another order).  At
+// 10 % density the dense product spends 10x the useful flops and still wins by ~8x: the gather form fetches 201 rows of 200 bytes per
+// seed and forward through L2 (660 MB per batch of 8192, 0.32 ms: profiles/r06k); here a workgroup reads the G x F table once per
+// forward for 32 seeds (256 MB per batch) with 16-byte-class loads, and the 4000 MFMAs of a workgroup are 27 us of matrix-pipe time.
+// The self loop (the seed's own row, its own dropout draw) is added on the vector ALUs in the epilogue.  Needs F <= 64 and at most
+// AG_MAXE gene entries per seed row (the host checks the graph's maximum once); rows may list their entries in any order, each gene at
+// most once (a CSR built from a matrix).
+constexpr int AG_R = 32, AG_KC = 128, AG_MAXE = 256, AG_LDA = 33, AG_LDB = 65;
+
+template <bool V2>
+__global__ __launch_bounds__(256) void gsc_aggregate_mfma_kernel(GscArgs a, const int64_t* __restrict__ seeds, Drop dx) {
+  extern __shared__ __attribute__((aligned(16))) char ag_smem[];
+  float* As = reinterpret_cast<float*>(ag_smem);                  // [AG_KC][33]
+  float* Bs = As + AG_KC * AG_LDA;                                // [AG_KC][65]
+  int* eg = reinterpret_cast<int*>(Bs + AG_KC * AG_LDB);          // [32][AG_MAXE]
+  float* ew = reinterpret_cast<float*>(eg + AG_R * AG_MAXE);      // [32][AG_MAXE]
+  int* ecnt = reinterpret_cast<int*>(ew + AG_R * AG_MAXE);        // [32]
+  float* wself = reinterpret_cast<float*>(ecnt + AG_R);           // [32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r0 = blockIdx.x * AG_R, F = a.F, G = a.G, B = a.B;
+  const bool drop = dx.thr < kKeepAll;
+  const int nf = drop ? 2 : 1;
+  const int64_t ldg = drop ? F : a.ldx;
+  // B tiles travel global -> registers -> LDS, one tile ahead of the products: the L2 round trip of tile (chunk, forward) + 1 runs
+  // under the MFMAs of tile (chunk, forward).  A tile = AG_KC gene rows x F: NB pieces per thread (float2 when rows start on 8 bytes)
+  constexpr int NB = V2 ? 16 : 32;
+  const int P = V2 ? F >> 1 : F;  // pieces per gene row
+  float2 breg[V2 ? NB : 1];
+  float sreg[V2 ? 1 : NB];
+  auto fetch_b = [&](int kchunk, int k) {
+    const float* __restrict__ xg = drop ? a.xdg + (int64_t)k * G * F : a.X;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int e = min(tid + 256 * u, AG_KC * P - 1), kk = e / P, p = e - kk * P;
+      const float* src = xg + (int64_t)min(kchunk + kk, G - 1) * ldg;
+      if (V2) breg[u] = *reinterpret_cast<const float2*>(src + 2 * p);
+      else sreg[u] = src[p];
+    }
+  };
+  auto store_b = [&](int kchunk) {
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int e = tid + 256 * u;
+      if (e < AG_KC * P) {
+        const int kk = e / P, p = e - kk * P;
+        const bool in = kchunk + kk < G;
+        if (V2) {
+          Bs[kk * AG_LDB + 2 * p] = in ? breg[u].x : 0.f;
+          Bs[kk * AG_LDB + 2 * p + 1] = in ? breg[u].y : 0.f;
+        } else {
+          Bs[kk * AG_LDB + p] = in ? sreg[u] : 0.f;
+        }
+      }
+    }
+  };
+  fetch_b(0, 0);  // in flight while the rows are staged
+  if (tid < AG_R) wself[tid] = 0.f;
+  // stage the rows' entries — (gene, weight x D_out^-1/2 of the gene inside the batch), the self loop's weight apart: a wave takes 8 rows,
+  // 64 entries of each per round with all 16 (column, weight) loads in flight, then the 8 counter loads
+  {
+    int sb[8], tb[8], cntr[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = min(r0 + wave * 8 + q, B - 1);
+      int64_t v = seeds[i];
+      v = v < G ? G : v >= a.n_nodes ? a.n_nodes - 1 : v;
+      sb[q] = a.rowptr[v];
+      tb[q] = a.rowptr[v + 1];
+      cntr[q] = 0;
+    }
+    int longest = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) longest = max(longest, tb[q] - sb[q]);
+    for (int e0 = 0; e0 < longest; e0 += 64) {
+      int c[8], cn[8];
+      float w[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int ec = min(sb[q] + e0 + lane, max(tb[q] - 1, sb[q]));
+        c[q] = a.col[ec];
+        w[q] = a.val[ec];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cn[q] = a.count[min(c[q], G - 1)];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int r = wave * 8 + q;
+        const bool in = sb[q] + e0 + lane < tb[q];
+        const bool gene = in && c[q] < G;
+        const unsigned long long m = __ballot(gene);
+        if (gene) {
+          const int pos = cntr[q] + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < AG_MAXE) {
+            eg[r * AG_MAXE + pos] = c[q];
+            ew[r * AG_MAXE + pos] = w[q] * (1.f / sqrtf(fmaxf((float)cn[q], 1.f)));
+          }
+        } else if (in) {
+          wself[r] = w[q];  // (a cell row has exactly one self loop: checked by gsc_prepare)
+        }
+        cntr[q] = min(cntr[q] + (int)__popcll(m), AG_MAXE);
+      }
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) ecnt[wave * 8 + q] = cntr[q];
+    }
+  }
+  __syncthreads();
+  if (a.dbg_fwd == 3) return;
+  const int i32 = lane & 31, h = lane >> 5, ntile = wave & 1, khalf = wave >> 1;
+  f32x16 acc[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  const int srow = tid >> 3, sub = tid & 7;
+  const int ne = ecnt[srow];
+  for (int k0 = 0; k0 < G; k0 += AG_KC) {
+    for (int e = tid; e < AG_KC * AG_LDA; e += 256) As[e] = 0.f;
+    __syncthreads();
+    if (a.dbg_fwd != 5)
+    for (int j = sub; j < ne; j += 8) {
+      const int g = eg[srow * AG_MAXE + j] - k0;
+      if ((unsigned)g < (unsigned)AG_KC) As[g * AG_LDA + srow] = ew[srow * AG_MAXE + j];
+    }
+    // (the forward index is a compile-time constant in each copy of the body: acc[k] with a run-time k makes the compiler move 16
+    // accumulator registers through selects around every MFMA — 800 cycles per step instead of 64, measured)
+    static_for2([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (k < nf) {
+        store_b(k0);
+        __syncthreads();  // Bs (and, before the first forward, the scatter into As) published
+        const bool last = k + 1 == nf;
+        if (!last || k0 + AG_KC < G) fetch_b(last ? k0 + AG_KC : k0, last ? 0 : k + 1);  // the next tile, under this tile's products
+        if (a.dbg_fwd != 4) {
+#pragma unroll 4
+          for (int s = khalf; s < AG_KC / 2; s += 2) {
+            const float av = As[(2 * s + h) * AG_LDA + i32];
+            const float bv = Bs[(2 * s + h) * AG_LDB + 32 * ntile + i32];
+            acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[k], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+      }
+    });
+  }
+  // epilogue: the two K halves meet in LDS; + the self loop; x D_in^-1/2 (and 1 / in-degree for "mean")
+  float* red = As;  // [khalf][fwd][32][64] = 8192 floats <= the As + Bs region (12544)
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((khalf * 2 + k) * AG_R + (r & 3) + 8 * (r >> 2) + 4 * h) * 64 + 32 * ntile + i32] = acc[k][r];
+  __syncthreads();
+  for (int e = tid; e < 2 * AG_R * F; e += 256) {
+    const int k = e / (AG_R * F), rem = e - k * AG_R * F, r = rem / F, f = rem - r * F;
+    const int i = r0 + r;
+    if (i >= B) continue;
+    int64_t v = seeds[i];
+    v = v < G ? G : v >= a.n_nodes ? a.n_nodes - 1 : v;
+    const int ks = drop ? k : 0;
+    float sum = red[((0 * 2 + ks) * AG_R + r) * 64 + f] + red[((1 * 2 + ks) * AG_R + r) * 64 + f];
+    const float sm = drop ? drop_scale(dx, SID_SELF + k, (uint64_t)i * F + f) : 1.f;
+    sum = fmaf(wself[r] * sm, a.X[v * a.ldx + f], sum);
+    const float dg = fmaxf((float)(a.rowptr[v + 1] - a.rowptr[v]), 1.f);
+    sum *= (1.f / sqrtf(dg)) * (a.mean ? 1.f / dg : 1.f);
+    a.ax_out[((int64_t)k * B + i) * F + f] = sum;
+    if (k == 1) a.ax2[(int64_t)i * F + f] = sum;
   }
 }
 
@@ -1169,8 +1369,31 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
     StepCounters none{};
     a.ax_out = c->ax_out;
     const int64_t* seeds3 = c->seeds + first_step * B;
-    hipLaunchKernelGGL(gsc_prepare_kernel, dim3((unsigned)(nbc + nbd)), dim3(256), 0, st, a, seeds3, dx3, none, hy, nbc);
-    hipLaunchKernelGGL(gsc_forward_kernel<true>, dim3((unsigned)B), dim3(256), 0, st, a, seeds3, dx3, dx3, (float*)nullptr);
+    if (G <= 12288 && B >= 1024) {
+      const int nbh = 64;
+      hipLaunchKernelGGL(gsc_prepare_kernel<true>, dim3((unsigned)(nbh + nbd)), dim3(256), (size_t)G * 4, st, a, seeds3, dx3, none, hy, nbh);
+    } else {
+      hipLaunchKernelGGL(gsc_prepare_kernel<false>, dim3((unsigned)(nbc + nbd)), dim3(256), 0, st, a, seeds3, dx3, none, hy, nbc);
+    }
+    // thousands of seeds, narrow features, short rows: the dense product on the matrix cores; otherwise the per-seed gather
+    // (measured at 8192 seeds x 2000 genes x 50, round 6: gather 0.10 ms + counts 0.07; the dense product 0.17 + 0.07 — its tiles wait
+    // for their L2 round trip with one workgroup per CU (116 KB of LDS) — so the gather stays the default; DANCE_AMD_GRAPHSC_AGG=mfma)
+    static const bool agg_mfma = getenv("DANCE_AMD_GRAPHSC_AGG") && !strcmp(getenv("DANCE_AMD_GRAPHSC_AGG"), "mfma");
+    if (agg_mfma && B >= 1024 && F <= 64 && c->max_row_entries > 0 && c->max_row_entries <= AG_MAXE + 1) {
+      const size_t lds = (size_t)(AG_KC * AG_LDA + AG_KC * AG_LDB + 2 * AG_R * AG_MAXE + 2 * AG_R) * 4;
+      const int64_t ldg3 = drop3 ? F : c->ld_features;
+      const bool v2 = F % 2 == 0 && ldg3 % 2 == 0 && (reinterpret_cast<uintptr_t>(c->features) & 7u) == 0;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gsc_aggregate_mfma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gsc_aggregate_mfma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+      }
+      if (v2) hipLaunchKernelGGL(gsc_aggregate_mfma_kernel<true>, dim3((unsigned)dh::ceil_div(B, AG_R)), dim3(256), lds, st, a, seeds3, dx3);
+      else hipLaunchKernelGGL(gsc_aggregate_mfma_kernel<false>, dim3((unsigned)dh::ceil_div(B, AG_R)), dim3(256), lds, st, a, seeds3, dx3);
+    } else {
+      hipLaunchKernelGGL(gsc_forward_kernel<true>, dim3((unsigned)B), dim3(256), 0, st, a, seeds3, dx3, dx3, (float*)nullptr);
+    }
     return dh::check_launch(me);
   }
   // the mirror of W2 and the gene counters may be stale (an eager step in between, a first call): one launch each per call
@@ -1184,7 +1407,7 @@ extern "C" int dh_graphsc_steps(const dh_graphsc_step_t* c, int64_t first_step, 
     const uint64_t gstep = c->step0 + (uint64_t)s;
     const Drop dx = make_drop(c->dropout, c->seed, gstep), dd = make_drop(c->decoder_dropout, c->seed, gstep);
     const int64_t* seeds = c->seeds + s * B;
-    hipLaunchKernelGGL(gsc_prepare_kernel, dim3((unsigned)(nb_count + nb_drop)), dim3(256), 0, st, a, seeds, dx, sc, hy, nb_count);
+    hipLaunchKernelGGL(gsc_prepare_kernel<false>, dim3((unsigned)(nb_count + nb_drop)), dim3(256), 0, st, a, seeds, dx, sc, hy, nb_count);
     hipLaunchKernelGGL(gsc_forward_kernel<false>, dim3((unsigned)B), dim3(256), 0, st, a, seeds, dx, dd, c->z_out + s * (int64_t)B * E);
     hipLaunchKernelGGL(gsc_decoder_kernel, dim3((unsigned)B), dim3(256), dec_lds, st, a, dd, (float)pos_weight, (float)(norm / (b * b)));
     ga.loss_out = c->loss_out + s;

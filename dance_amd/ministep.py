@@ -25,7 +25,7 @@ class GraphSCStep(ctypes.Structure):
     _fields_ = [("rowptr", c_void_p), ("col", c_void_p), ("val", c_void_p), ("features", c_void_p),
                 ("ld_features", c_int64), ("n_nodes", c_int64), ("n_genes", c_int64),
                 ("batch", c_int64), ("in_feats", c_int64), ("hidden", c_int64), ("emb", c_int64),
-                ("agg_mean", c_int32), ("phase", c_int32),
+                ("agg_mean", c_int32), ("phase", c_int32), ("max_row_entries", c_int32), ("reserved", c_int32),
                 ("w1", AdamState), ("b1", AdamState), ("w2", AdamState), ("b2", AdamState),
                 ("lr", c_float), ("beta1", c_float), ("beta2", c_float), ("eps", c_float), ("weight_decay", c_float),
                 ("dropout", c_float), ("decoder_dropout", c_float),
@@ -157,6 +157,8 @@ class GraphSCStepper(_Stepper):
         c.ld_features, c.n_nodes, c.n_genes = feats.stride(0), g.number_of_nodes(), ng
         c.batch, c.in_feats, c.hidden, c.emb = self.batch, f, h, e
         c.agg_mean = 1 if model.agg == "mean" else 0
+        # the longest cell row (one host read per stepper): short rows let the large-batch aggregation run as a dense product (phase 3)
+        c.max_row_entries = int((g.rowptr[ng + 1:] - g.rowptr[ng:-1]).max()) if self.batch >= 1024 and g.number_of_nodes() > ng else 0
         c.w1, c.b1, c.w2, c.b2 = (_adam_struct(optim, p) for p in self.params)
         self._hyper(c, optim)
         c.dropout = float(model.dropout.p) if model.dropout is not None and model.training else 0.0

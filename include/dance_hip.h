@@ -764,6 +764,8 @@ typedef struct dh_graphsc_step {
   int64_t batch, in_feats, hidden, emb;
   int32_t agg_mean; /* fn.mean instead of fn.sum (:463-465) */
   int32_t phase;
+  int32_t max_row_entries; /* the largest in-degree of a cell row of the graph (0 = unknown): short rows let phase 3 run on the matrix cores */
+  int32_t reserved;
   dh_adam_state_t w1, b1, w2, b2; /* layer1.weight [in_feats, hidden], layer1.bias, encoder.0.weight [emb, hidden], encoder.0.bias */
   float lr, beta1, beta2, eps, weight_decay;
   float dropout, decoder_dropout;

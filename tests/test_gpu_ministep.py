@@ -180,36 +180,75 @@ def test_graphsc_fit_ministep_vs_reference(cuda_device, gold, monkeypatch, tag, 
     assert np.allclose(res[True][0], res[False][0], rtol=1e-5) and rel_err(res[True][1], res[False][1]) < 1e-5
 
 
-def test_graphsc_aggregate_phase_vs_oracle(cuda_device):
-    """dh_graphsc_steps phase 3: the aggregated layer input of both forwards (own dropout draws) == the oracle's A_norm (X o mask)."""
+@pytest.mark.parametrize("b,n_cells,n_genes,f,p,agg", [(40, 200, 30, 50, 0.2, "sum"), (1024, 1500, 300, 50, 0.2, "sum"), (1056, 1200, 130, 7, 0.0, "mean"),
+                                                       (1024, 1100, 257, 64, 0.1, "sum")])
+def test_graphsc_aggregate_phase_vs_oracle(cuda_device, monkeypatch, b, n_cells, n_genes, f, p, agg):
+    """dh_graphsc_steps phase 3: the aggregated layer input of both forwards (own dropout draws) == the oracle's A_norm (X o mask) — small
+    and large batches (the LDS-histogram counters from 1024 seeds on), even / odd widths, a ragged last row tile, a gene count that is no
+    multiple of the matrix-core form's K chunk.  tests/test_gpu_ministep.py::test_graphsc_aggregate_mfma_form runs the dense-product form."""
     from dance_amd.ministep import GraphSCStepper
-    b, n_genes, f, p = 40, 30, 50, 0.2
-    g = _graph(200, n_genes, f, 4, cuda_device, normalize_edges=False)
+    g = _graph(n_cells, n_genes, f, 4, cuda_device, density=0.15, normalize_edges=False)
     rowptr, col, val = _host(g)
     feats = g.ndata["features"].cpu().numpy().astype(np.float64)
-    m = _gsc_model(f, 20, 12, "sum", p, 0.0, cuda_device)
+    m = _gsc_model(f, 20, 12, agg, p, 0.0, cuda_device)
     optim = torch.optim.Adam(m.model.parameters(), lr=1e-2, fused=True)
     st = GraphSCStepper(m.model, g, b, optim)
-    seeds = (n_genes + torch.randperm(200, generator=torch.Generator().manual_seed(1))[:b]).to(cuda_device)
+    seeds = (n_genes + torch.randperm(n_cells, generator=torch.Generator().manual_seed(1))[:b]).to(cuda_device)
     ax = st.aggregate(seeds).cpu().numpy()
     st.check_flags("test")
     sd = seeds.cpu().numpy()
     cnt = np.zeros(n_genes)
     for v in sd:
-        for e in range(rowptr[v], rowptr[v + 1]):
-            if col[e] < n_genes:
-                cnt[col[e]] += 1
+        cs_ = col[rowptr[v]:rowptr[v + 1]]
+        np.add.at(cnt, cs_[cs_ < n_genes], 1)
     for k in range(2):
         m_self = oms.dropout_mask(b * f, p, st.cfg.seed, 0, oms.SID_SELF + k).reshape(b, f)
         m_gene = oms.dropout_mask(n_genes * f, p, st.cfg.seed, 0, oms.SID_GENE + k).reshape(n_genes, f)
+        xg = feats[:n_genes] * m_gene / np.sqrt(np.maximum(cnt, 1.0))[:, None]
         ref = np.zeros((b, f))
         for i, v in enumerate(sd):
-            for e in range(rowptr[v], rowptr[v + 1]):
-                c = col[e]
-                ref[i] += val[e] * (feats[c] * m_gene[c] / np.sqrt(max(cnt[c], 1.0)) if c < n_genes else feats[v] * m_self[i])
-            ref[i] /= np.sqrt(max(rowptr[v + 1] - rowptr[v], 1))
+            s_, t_ = rowptr[v], rowptr[v + 1]
+            cs_, ws_ = col[s_:t_], val[s_:t_]
+            gm = cs_ < n_genes
+            ref[i] = ws_[gm] @ xg[cs_[gm]] + ws_[~gm].sum() * feats[v] * m_self[i]
+            deg = max(t_ - s_, 1)
+            ref[i] /= np.sqrt(deg) * (deg if agg == "mean" else 1.0)
         assert rel_err(ax[k], ref) < 1e-5, k
     assert st.cfg.step0 == 1
+    if b >= 1024:
+        assert st.cfg.max_row_entries > 0
+
+
+def test_graphsc_aggregate_mfma_form():
+    """The dense-product form of phase 3 (DANCE_AMD_GRAPHSC_AGG=mfma, read once per process: a subprocess) == the default gather form."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        "sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))\n"
+        "import test_gpu_ministep as t\n"
+        "from dance_amd.ministep import GraphSCStepper\n"
+        "dev = torch.device('cuda')\n"
+        "out = []\n"
+        "for (b, nc, ng, f, p) in ((1024, 1500, 300, 50, 0.2), (1056, 1200, 130, 7, 0.0), (1024, 1100, 257, 64, 0.1)):\n"
+        "    g = t._graph(nc, ng, f, 4, dev, density=0.15, normalize_edges=False)\n"
+        "    m = t._gsc_model(f, 20, 12, 'sum', p, 0.0, dev)\n"
+        "    st = GraphSCStepper(m.model, g, b, torch.optim.Adam(m.model.parameters(), lr=1e-2, fused=True))\n"
+        "    st.cfg.seed = 1234\n"
+        "    seeds = (ng + torch.randperm(nc, generator=torch.Generator().manual_seed(1))[:b]).to(dev)\n"
+        "    out.append(st.aggregate(seeds).cpu().numpy())\n"
+        "np.savez(sys.argv[1], *out)\n")
+    import tempfile
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for mode in ("gather", "mfma"):
+            path = os.path.join(tmp, mode + ".npz")
+            env = dict(os.environ, DANCE_AMD_GRAPHSC_AGG=mode)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            res[mode] = dict(np.load(path))
+    for k in res["gather"]:
+        assert rel_err(res["mfma"][k], res["gather"][k]) < 1e-5, k
+        assert not np.array_equal(res["mfma"][k], np.zeros_like(res["mfma"][k]))
 
 
 def test_graphsc_fit_ministep_dropout_is_keyed_by_torch_seed(cuda_device):
