@@ -146,16 +146,20 @@ def synth_knn_graph(n, k, device, seed, reorder=True, order="morton"):
     build_s = time.perf_counter() - t0
     graph = CSRGraph(rowptr, col, val, n, n, symmetric=True)
     if not reorder:
-        return graph, None, None, build_s, 0.0
+        return graph, None, None, build_s, (0.0, 0.0)
     t0 = time.perf_counter()
     # "morton": Z-order over the leading principal components of the embedding the neighbours were searched in, on the device
     # (dance_amd.graph.morton_order); "rcm": reverse Cuthill-McKee of the pattern on the host (0.5 s at 1M cells)
     perm = (locality_order(graph, "morton", coords=emb) if order == "morton" else locality_order(graph)).to(device)
     torch.cuda.synchronize()
     order_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
     ordered = graph.permute(perm)
     torch.cuda.synchronize()
-    return graph, ordered, perm, build_s, order_s
+    permute_s = time.perf_counter() - t0
+    # (rounds 3-4 reported order + permutation as ONE figure, round 5 the order alone under the same key — both are
+    # reported now: locality_order_s = computing the order, locality_permute_s = renumbering the graph)
+    return graph, ordered, perm, build_s, (order_s, permute_s)
 
 
 def layer_bytes(n, nnz, f=N_GENES, h=N_HIDDEN, s=4):
@@ -401,6 +405,15 @@ def main():
     elapsed, ksum = runs[mode]["elapsed"], runs[mode]["ksum"]
     sg = runs[mode]["sg"] or make_sharded(mode)
     nnz_total = K_NEIGH * n
+    comm_info = None
+    if world > 1:
+        # what the communicator itself saw (not what the launcher was asked for): ranks, backend, every rank's device
+        mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
+                "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        comm_info = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": gathered,
+                     "distinct_devices": len({(g["device"], g["uuid"]) for g in gathered})}
 
     x3_out = None
     if world == 1 and not args.no_x3_row:
@@ -457,7 +470,8 @@ def main():
                                f"{'Z-order over the 3 leading principal components of the embedding (device)' if args.locality == 'morton' else 'reverse Cuthill-McKee (host)'}"
                                f" (graph set-up), X permuted once, outputs identical row for row",
                    "locality_order": args.locality,
-                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "locality_order_s": round(order_s, 4),
+                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "locality_order_s": round(order_s[0], 4), "locality_permute_s": round(order_s[1], 4),
+                   "locality_note": "locality_order_s = computing the order only (as BENCH_r05 reported it); rounds 3-4 quoted order + permutation as one figure",
                    "ms_per_step": o_ms, "value": n / (o_elapsed / args.steps), "unit": "cells/s",
                    "layer_hbm_frac": round(layer_bytes(n, kg.nnz) / (o_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
                    "y_bit_identical_to_unordered": same,
@@ -521,7 +535,10 @@ def main():
                                    f"rand-k{K_NEIGH} graph (nnz={K_NEIGH * n}), fp32; X = SURVEY 8(d) generator (20-cluster latent x "
                                    f"LogNormal gene rates, Poisson counts at 10 % density, normalize_total / log1p / per-gene scale)",
                        "cells": n, "genes": N_GENES, "hidden": N_HIDDEN, "k": K_NEIGH,
-                       "parallelism": f"dst-range x{world}, {mode} exchange" if world > 1 else "single GPU"},
+                       "parallelism": f"dst-range x{world}, {mode} exchange" if world > 1 else "single GPU",
+                       **({"exchange_mode": mode, "exchange_selection": (f"--exchange {args.exchange}: " + ("every mode timed with the same K steps in this run, the fastest is the headline"
+                                                                         if args.exchange == "auto" else "as requested")),
+                           "rccl": comm_info} if world > 1 else {})},
             "roofline": roofline, "kernels": kernels_out,
         }
         if backend != "nccl":

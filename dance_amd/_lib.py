@@ -104,6 +104,7 @@ def _declare(lib):
         "dh_gram_pairwise_rect_f32": (c_int, [i32, i64, i64, i64, P, i64, P, i64, P, i64, P, P, c_size_t, P]),
         "dh_gram_listed_forward_f32": (c_int, [i64, i64, i64, P, i64, P, P, c_float, P, P, P]),
         "dh_gram_listed_backward_f32": (c_int, [i64, i64, i64, P, i64, P, i64, P, P, P, c_float, P, P, i64, P]),
+        "dh_gram_diag_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, c_float, P, P, i64, P]),
         "dh_rowsum_masked_f32": (c_int, [i64, i64, P, i64, P, P, P]),
         "dh_rowscale_log1p_f32": (c_int, [i64, i64, P, i64, P, i32, c_double, P, i64, P]),
         "dh_col_standardize_f32": (c_int, [i64, i64, P, i64, P, P, c_double, P, i64, P]),

@@ -26,12 +26,19 @@ def kernel_copy_(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     calls, which a capture records as memcpy NODES (and ``zero_()`` / hipMemsetAsync as memset nodes).  On ROCm 7.2 / gfx950 such a
     node was replayed with the wrong extent and fill pattern once eager copies had run between two replays (round 5's fault hunt,
     profiles/r05_replay_fault.md), so code that runs under capture moves data with kernels only."""
-    return torch.add(src, 0, out=dst)
+    if dst.dtype != src.dtype:
+        raise TypeError(f"kernel_copy_: dtypes differ ({dst.dtype} <- {src.dtype})")
+    # a BIT copy (ADVICE round 5: ``add(x, 0)`` turns -0.0 into +0.0 and promotes bool): x | 0 for integers / bool, x * 1 for floats
+    if src.dtype.is_floating_point or src.dtype.is_complex:
+        return torch.mul(src, 1, out=dst)
+    return torch.bitwise_or(src, False if src.dtype == torch.bool else 0, out=dst)
 
 
 def kernel_clone(x: torch.Tensor) -> torch.Tensor:
     """``x.clone()`` as an elementwise kernel (see ``kernel_copy_``)."""
-    return torch.add(x, 0)
+    if x.dtype.is_floating_point or x.dtype.is_complex:
+        return torch.mul(x, 1)
+    return torch.bitwise_or(x, False if x.dtype == torch.bool else 0)
 
 
 class CapturedStep:

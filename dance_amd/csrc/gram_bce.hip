@@ -20,6 +20,8 @@
 // 157.3 TFLOP/s fp32 peak; HBM traffic is the 10 MB of z (L2 resident) plus the partial outputs.
 #include <type_traits>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -326,6 +328,27 @@ __global__ __launch_bounds__(320) void gram_listed_backward_kernel(int d, int64_
   if (c < d) dZ[(int64_t)i * ldd + c] = s * acc;
 }
 
+// the listed target is the IDENTITY (every cell's self loop and nothing else: the decoder target of a batch of cells of a cell - gene graph,
+// graphsc.py:208-214): dZ[i, :] = 2 s (O[i, :] + c_i z[i, :]) — an elementwise pass instead of n workgroups each scanning the n-entry list
+__global__ __launch_bounds__(256) void gram_diag_backward_kernel(int64_t n, int d, const float* __restrict__ Z, int64_t ldz, const float* __restrict__ O,
+                                                                int64_t ldo, const float* __restrict__ xe, float p, const float* __restrict__ scale,
+                                                                float* __restrict__ dZ, int64_t ldd) {
+  const float s = scale[0];
+  const int64_t total = n * d;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / d;
+    const int c = (int)(e - i * d);
+    const float sg = 1.f / (1.f + expf(-xe[i]));
+    const float ce = p * (sg - 1.f) - sg;
+    // the generic kernel's order: acc = 2 O; acc = fma(ce, z, acc) twice (u == i and v == i); s * acc
+    float acc = 2.f * O[i * ldo + c];
+    const float z = Z[i * ldz + c];
+    acc = fmaf(ce, z, acc);
+    acc = fmaf(ce, z, acc);
+    dZ[i * ldd + c] = s * acc;
+  }
+}
+
 struct Plan {
   int dp, i_blocks, splits, j_per_split, n_pad;
   size_t opart_bytes, lpart_bytes;
@@ -439,6 +462,16 @@ extern "C" int dh_gram_listed_forward_f32(int64_t n, int64_t d, int64_t n_listed
   hipLaunchKernelGGL(gram_listed_forward_kernel, dim3((unsigned)dh::ceil_div(n_listed, 4)), dim3(256), 0, dh::as_stream(stream), n_listed, (int)d, Z,
                      ldz, us, vs, pos_weight, xe, term);
   return dh::check_launch("dh_gram_listed_forward_f32");
+}
+
+extern "C" int dh_gram_diag_backward_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, const float* O, int64_t ldo, const float* xe, float pos_weight,
+                                         const float* scale, float* dZ, int64_t ldd, dh_stream_t stream) {
+  if (n < 0 || d < 0) return dh::fail(DH_ERR_INVALID, "dh_gram_diag_backward_f32: negative size");
+  if (n == 0 || d == 0) return DH_OK;
+  if (!Z || !O || !xe || !scale || !dZ || ldz < d || ldo < d || ldd < d) return dh::fail(DH_ERR_INVALID, "dh_gram_diag_backward_f32: bad pointer / leading dimension");
+  const unsigned grid = (unsigned)std::min<int64_t>(dh::ceil_div(n * d, 256), 8192);
+  hipLaunchKernelGGL(gram_diag_backward_kernel, dim3(grid), dim3(256), 0, dh::as_stream(stream), n, (int)d, Z, ldz, O, ldo, xe, pos_weight, scale, dZ, ldd);
+  return dh::check_launch("dh_gram_diag_backward_f32");
 }
 
 extern "C" int dh_gram_listed_backward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const float* O, int64_t ldo,

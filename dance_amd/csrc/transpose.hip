@@ -50,8 +50,12 @@ __global__ __launch_bounds__(256) void gather_transposed_kernel(int64_t n_rows, 
       const int64_t mid = (lo + hi) >> 1;
       if (rowptr[mid] <= e) lo = mid; else hi = mid;
     }
-    out_col[p] = (int32_t)lo;
-    if (out_val) out_val[p] = val[e];
+    // entries behind the last of the n_rows rows (a static block's padding tail when the caller transposes its real rows only:
+    // CSRGraph.t_rows) carry no information: they get value 0 AND row n_rows — the block's padding row, whose operand row is zero —
+    // instead of being clamped onto the last real row, where 0 * (a non-finite gradient row) would make a NaN
+    const bool pad = e >= rowptr[n_rows];
+    out_col[p] = pad ? (int32_t)n_rows : (int32_t)lo;
+    if (out_val) out_val[p] = pad ? 0.f : val[e];
   }
 }
 

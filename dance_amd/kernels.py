@@ -261,7 +261,9 @@ def csr_transpose(rowptr: torch.Tensor, col: torch.Tensor, val: Optional[torch.T
 GEMM_MODE = os.environ.get("DANCE_AMD_GEMM", "exact")
 GEMM_TILE_AUTO, GEMM_TILE_256, GEMM_TILE_128 = 0, 1, 2
 GEMM_SMALL = os.environ.get("DANCE_AMD_GEMM_SMALL", "1") != "0"  # small products on dh_gemm_f32_small (A/B switch)
-_mini_batch_depth = 0
+import contextvars  # noqa: E402
+
+_mini_batch_depth = contextvars.ContextVar("dance_amd_mini_batch_products", default=0)  # per thread / task: another thread's gemm() is not switched
 
 
 class mini_batch_products:
@@ -271,13 +273,11 @@ class mini_batch_products:
     call holds (a rank's rows of a sharded layer are bit-identical to the single-GPU layer's, tests/test_gpu_sharded_one_gpu.py)."""
 
     def __enter__(self):
-        global _mini_batch_depth
-        _mini_batch_depth += 1
+        self._token = _mini_batch_depth.set(_mini_batch_depth.get() + 1)
         return self
 
     def __exit__(self, *exc):
-        global _mini_batch_depth
-        _mini_batch_depth -= 1
+        _mini_batch_depth.reset(self._token)
         return False
 
 
@@ -302,7 +302,7 @@ def gemm(A: torch.Tensor, B: torch.Tensor, *, trans_a: bool = False, trans_b: bo
             raise ValueError("gemm: accumulate=True needs an `out` tensor")
         out = torch.empty((M, N), dtype=torch.float32, device=A.device)
     tag = tag or f"gemm_f32_{'t' if trans_a else 'n'}{'t' if trans_b else 'n'}"
-    if (mode == "exact" and GEMM_SMALL and _mini_batch_depth > 0 and not accumulate and tile == GEMM_TILE_AUTO and 1 <= K <= 512
+    if (mode == "exact" and GEMM_SMALL and _mini_batch_depth.get() > 0 and not accumulate and tile == GEMM_TILE_AUTO and 1 <= K <= 512
             and M * N <= (1 << 20) and M > 0 and N > 0):
         # the mini-batch steps' launch-bound products: one round trip per 32 x 32 tile instead of a K walk (dh_gemm_f32_small)
         _call(tag, lib.dh_gemm_f32_small, M, N, K, int(trans_a), int(trans_b), _dev(A, torch.float32, "A", 2), _ld(A), _dev(B, torch.float32, "B", 2),
@@ -538,6 +538,16 @@ def gram_listed_backward(Z: torch.Tensor, O: torch.Tensor, us: torch.Tensor, vs:
     _call("gram_listed_backward_f32", lib.dh_gram_listed_backward_f32, n, d, us.numel(), _dev(Z, torch.float32, "Z", 2), _ld(Z),
           _dev(O, torch.float32, "O", 2), _ld(O), _dev(us, torch.int32, "us", 1), _dev(vs, torch.int32, "vs", 1), _dev(xe, torch.float32, "xe", 1),
           float(pos_weight), _dev(scale.reshape(1), torch.float32, "scale", 1), out.data_ptr(), _ld(out), _stream())
+    return out
+
+
+def gram_diag_backward(Z: torch.Tensor, O: torch.Tensor, xe: torch.Tensor, pos_weight: float, scale: torch.Tensor) -> torch.Tensor:
+    """``gram_listed_backward`` for the identity list (us = vs = arange(n)): one elementwise pass (dh_gram_diag_backward_f32)."""
+    lib = _lib_ready()
+    n, d = Z.shape
+    out = torch.empty((n, d), dtype=torch.float32, device=Z.device)
+    _call("gram_diag_backward_f32", lib.dh_gram_diag_backward_f32, n, d, _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(O, torch.float32, "O", 2), _ld(O),
+          _dev(xe, torch.float32, "xe", 1), float(pos_weight), _dev(scale.reshape(1), torch.float32, "scale", 1), out.data_ptr(), _ld(out), _stream())
     return out
 
 

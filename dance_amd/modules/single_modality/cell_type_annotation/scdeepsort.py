@@ -314,6 +314,10 @@ class ScDeepSort(BaseClassificationMethod):
 
     @torch.no_grad()
     def evaluate(self, graph, idx: torch.Tensor, unsure_rate: float = 2.0, *, _logits=None):
+        with kernels.mini_batch_products():  # the same product kernels inside and outside fit: logits are bit-reproducible
+            return self._evaluate(graph, idx, unsure_rate, _logits)
+
+    def _evaluate(self, graph, idx, unsure_rate, _logits):
         self.model.eval()
         if _logits is None:
             _logits = self._full_graph_logits(graph)
@@ -347,6 +351,10 @@ class ScDeepSort(BaseClassificationMethod):
 
     @torch.no_grad()
     def predict_proba(self, graph):
+        with kernels.mini_batch_products():  # as in fit (see evaluate)
+            return self._predict_proba(graph)
+
+    def _predict_proba(self, graph):
         self.model.eval()
         cell_mask = (graph.ndata["cell_id"] == -1).cpu()
         idx = torch.where(cell_mask)[0]

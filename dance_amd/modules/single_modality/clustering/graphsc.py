@@ -263,23 +263,28 @@ class _GramListedBCE(torch.autograd.Function):
     ``us`` / ``vs`` int32, ``p`` a python float."""
 
     @staticmethod
-    def forward(ctx, z, us, vs, p):
+    def forward(ctx, z, us, vs, p, diag=False):
         n = z.shape[0]
         rowloss, o = kernels.gram_sigmoid(z)
         xe, term = kernels.gram_listed_forward(z, us, vs, p)
         ctx.save_for_backward(z, o, us, vs, xe)
         ctx.p = p
+        ctx.diag = bool(diag) and us.numel() == n  # the caller vouches for us = vs = arange(n): the elementwise backward
         return ((rowloss.sum(dtype=torch.float64) + term.sum(dtype=torch.float64)) / float(n * n)).to(torch.float32)
 
     @staticmethod
     def backward(ctx, g):
         z, o, us, vs, xe = ctx.saved_tensors
         scale = (g / float(z.shape[0]**2)).to(torch.float32)
-        return kernels.gram_listed_backward(z, o, us, vs, xe, ctx.p, scale), None, None, None
+        if ctx.diag:
+            return kernels.gram_diag_backward(z, o, xe, ctx.p, scale), None, None, None, None
+        return kernels.gram_listed_backward(z, o, us, vs, xe, ctx.p, scale), None, None, None, None
 
 
-def gram_listed_bce(z, us, vs, pos_weight):
-    return _GramListedBCE.apply(z.contiguous(), us.to(torch.int32), vs.to(torch.int32), float(pos_weight))
+def gram_listed_bce(z, us, vs, pos_weight, diag: bool = False):
+    """``diag=True``: the listed entries are exactly (i, i) for every row i (us = vs = arange(n)) — same value and gradient, the backward's
+    correction is then an elementwise pass instead of a scan of the list per row."""
+    return _GramListedBCE.apply(z.contiguous(), us.to(torch.int32), vs.to(torch.int32), float(pos_weight), diag)
 
 
 class _AggFirstConv(torch.autograd.Function):
@@ -383,7 +388,7 @@ class _CapturedStep:
         _, emb = self.model.forward([blk], x, decode=False)  # :202
         emb_out = kernel_clone(emb.detach())  # a kernel, not a memcpy node (capture.py)
         _, emb2 = self.model.forward([blk], x, decode=False)  # :215, fresh dropout
-        loss = self.norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), self.diag, self.diag, self.pos_weight)
+        loss = self.norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), self.diag, self.diag, self.pos_weight, diag=True)
         self.optim.zero_grad(set_to_none=True)
         loss.backward()
         return emb_out, loss.detach()
@@ -558,7 +563,7 @@ class GraphSC(BaseClusteringMethod):
                         h0 = kernels.gemm(ax[0], l1.weight, bias=l1.bias, act=kernels.ACT_RELU)
                         kernels.gemm(h0, enc.weight, trans_b=True, bias=enc.bias, out=z_all[i * batch_size:(i + 1) * batch_size])
                     emb2 = enc(_AggFirstConv.apply(ax[1], l1.weight, l1.bias))  # :215, fresh dropout
-                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), diag, diag, pos_weight)
+                    loss = norm * gram_listed_bce(F.dropout(emb2, self.model.decoder.dropout), diag, diag, pos_weight, diag=True)
                     optim.zero_grad(set_to_none=True)
                     loss.backward()
                     sharding.allreduce_gradients(self.model)

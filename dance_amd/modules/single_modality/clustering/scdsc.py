@@ -147,11 +147,11 @@ class AE(nn.Module):
                     bn_.running_var.copy_(m * var + (1 - m) * bn_.running_var)
                     bn_.num_batches_tracked += 1
             return self._cache[1]
-        if key is not None:
-            self._cache = None  # the inputs / parameters changed: the kept outputs are stale
-        # (key None — an eval-mode pass, a sharded or trainable autoencoder — bypasses the cache WITHOUT dropping it: what a training-mode
-        # forward returns does not depend on an evaluation pass in between; the joint loop makes one every 10th epoch, and clearing here
-        # recomputed the frozen outputs and their 18 statistics reductions every 10 epochs — ADVICE round 5)
+        if key is not None or self.training:
+            self._cache = None  # the inputs / parameters changed, or this training-mode call is not cacheable (trainable, sharded): stale
+        # (an EVAL-mode pass bypasses the cache WITHOUT dropping it: what a training-mode forward returns does not depend on an
+        # evaluation pass in between; the joint loop makes one every 10th epoch, and clearing here recomputed the frozen outputs and
+        # their 18 statistics reductions every 10 epochs — ADVICE round 5)
         stats = [] if key is not None else None
 
         def bn(mod, h):

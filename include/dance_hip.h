@@ -436,6 +436,10 @@ DH_API int dh_gram_listed_forward_f32(int64_t n, int64_t d, int64_t n_listed, co
 DH_API int dh_gram_listed_backward_f32(int64_t n, int64_t d, int64_t n_listed, const float* Z, int64_t ldz, const float* O,
                                 int64_t ldo, const int32_t* us, const int32_t* vs, const float* xe, float pos_weight,
                                 const float* scale, float* dZ, int64_t ldd, dh_stream_t stream);
+/* the same backward when the listed entries are exactly (i, i) for i < n (the identity target of a batch of cells of a cell - gene graph:
+ * its only cell -> cell edges are the self loops, graphsc.py:208-214), xe[i] = <z_i, z_i>: one elementwise pass, same arithmetic order. */
+DH_API int dh_gram_diag_backward_f32(int64_t n, int64_t d, const float* Z, int64_t ldz, const float* O, int64_t ldo, const float* xe, float pos_weight,
+                              const float* scale, float* dZ, int64_t ldd, dh_stream_t stream);
 
 /* ---- message-flow blocks of the full-neighbour sampler (block.hip) -------------------------------------------
  * What dgl.dataloading.NeighborSampler([-1]*L, edge_dir="in") / MultiLayerFullNeighborSampler produce for a batch of

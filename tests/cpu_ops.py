@@ -462,6 +462,11 @@ def gram_listed_backward(Z, O, us, vs, xe, pos_weight, scale):
     return (dz * scale.double().reshape(())).float()
 
 
+def gram_diag_backward(Z, O, xe, pos_weight, scale):
+    idx = torch.arange(Z.shape[0])
+    return gram_listed_backward(Z, O, idx, idx, xe, pos_weight, scale)
+
+
 def dense_to_csr(X):
     m = sp.csr_matrix(X.numpy())
     m.eliminate_zeros()
@@ -523,7 +528,7 @@ STAND_INS = ("adam_step", "degree_scales", "block_cells_static", "block_cells_st
              "col_standardize", "gemm", "spmm_csr", "spmm_csr_relu", "relu_mask_bytes", "gather_rows", "relu_backward", "colsum", "knn", "block_build",
              "csr_transpose", "bias_act_", "softplus_rowsum", "sigmoid_scale", "gram_sigmoid", "gram_sigmoid_supported", "edge_softmax",
              "edge_softmax_backward", "sddmm_csr", "csr_two_hop", "gaussian_kernel", "exclusive_scan", "csr_row_normalize",
-             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward",
+             "cellgene_graph_assemble", "sage_mfma_supported", "sage_aggregate", "pairwise_distance", "gram_listed_forward", "gram_listed_backward", "gram_diag_backward",
              "student_t_supported", "student_t_forward", "student_t_backward", "softmax_xent_sum")
 
 

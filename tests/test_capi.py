@@ -118,17 +118,24 @@ def test_small_gemm_is_opt_in_and_scoped():
     ``kernels.mini_batch_products()`` (entered by GraphSC.fit / ScDeepSort.fit): the full-batch layers keep row results that do not
     depend on the row count of the call.  The context nests and always restores."""
     from dance_amd import kernels
-    assert kernels._mini_batch_depth == 0
+    depth = kernels._mini_batch_depth.get  # a context variable: per thread / task (ADVICE round 5)
+    assert depth() == 0
     with kernels.mini_batch_products():
-        assert kernels._mini_batch_depth == 1
+        assert depth() == 1
         try:
             with kernels.mini_batch_products():
-                assert kernels._mini_batch_depth == 2
+                assert depth() == 2
                 raise RuntimeError("leave by exception")
         except RuntimeError:
             pass
-        assert kernels._mini_batch_depth == 1
-    assert kernels._mini_batch_depth == 0
+        assert depth() == 1
+        import threading
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(depth()))  # another thread's gemm() calls are not switched by this fit
+        t.start()
+        t.join()
+        assert seen == [0]
+    assert depth() == 0
     import inspect
     from dance_amd.modules.single_modality.cell_type_annotation.scdeepsort import ScDeepSort
     from dance_amd.modules.single_modality.clustering.graphsc import GraphSC

@@ -151,3 +151,35 @@ def test_fanout_sampled_blocks_on_device(cuda_device):
     y = autograd.gcn_layer(last.srcdata["features"], w, blk_g, None, True)
     y.sum().backward()
     assert y.shape == (3000, 8) and bool(torch.isfinite(w.grad).all())
+
+
+def test_static_block_transpose_ignores_the_padding_tail(cuda_device):
+    """the transposed copy of a StaticCellBlock (built over its real rows only) must apply A^T to a gradient whose last real
+    row is NON-FINITE without leaking NaN through the zero-weight padding entries — they point at the block's padding row, not at the last
+    real row — and equal the transpose of the same block without its padding."""
+    from dance_amd import kernels
+    from dance_amd.cellgraph import StaticCellBlock
+    from dance_amd.graph import CSRGraph
+    from test_gpu_ministep import _graph
+    g = _graph(120, 30, 8, 3, cuda_device)
+    sb = StaticCellBlock(g, 16)
+    sb.seeds.copy_(torch.arange(30, 46, device=cuda_device))
+    sb.rebuild()
+    assert int(sb.bad) == 0
+    nnz = int(sb.rowptr[16])
+    assert nnz < sb.e_max  # there IS a padding tail
+    gr = CSRGraph(sb.rowptr, sb.col, sb.val, 17, sb.number_of_src_nodes())
+    gr.t_rows = 16
+    t = gr.transpose()
+    dy = torch.randn(17, 5, device=cuda_device)
+    dy[16] = 0.0           # the padding row of an upstream gradient is zero ...
+    dy[15] = float("inf")  # ... and the last real row may be anything
+    dx = kernels.spmm_csr(t.rowptr, t.col, t.val, dy, n_cols=17)
+    # reference: the block's real entries only
+    ref = CSRGraph(sb.rowptr[:17].clone(), sb.col[:nnz].clone(), sb.val[:nnz].clone(), 16, sb.number_of_src_nodes()).transpose()
+    dx_ref = kernels.spmm_csr(ref.rowptr, ref.col, ref.val, dy[:16].contiguous(), n_cols=16)
+    touched = torch.isinf(dx_ref).any(1)  # source rows with an edge into row 15
+    assert touched.any() and not torch.isnan(dx).any()
+    assert torch.equal(torch.isinf(dx).any(1), touched)
+    fin = ~touched
+    assert torch.allclose(dx[fin], dx_ref[fin], rtol=1e-6, atol=1e-6)

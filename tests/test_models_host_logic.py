@@ -473,8 +473,12 @@ def test_scdsc_frozen_autoencoder_cache(cpu_kernels):
         assert int(ba.num_batches_tracked) == int(bb.num_batches_tracked) == 5
         assert rel_err(ba.running_mean.numpy(), bb.running_mean.numpy()) < 1e-6 and rel_err(ba.running_var.numpy(), bb.running_var.numpy()) < 1e-6
     a.eval(), b.eval()
+    kept = a._cache
     assert rel_err(a(x)[0].numpy(), b(x)[0].numpy()) < 1e-5                     # eval mode: running statistics, never the cache
+    assert a._cache is kept                                                      # ... and it does not drop the kept outputs
     a.train(), b.train()
+    assert a(x)[0] is oa[0]                                                      # the training pass after an evaluation pass: still the kept tensors
+    b(x)
     with torch.no_grad():
         a.enc_1.weight.mul_(1.01)
         b.enc_1.weight.mul_(1.01)
