@@ -1516,6 +1516,21 @@ extern "C" int dh_scdeepsort_steps(const dh_scdeepsort_step_t* c, int64_t first_
   // rows that start on 16-byte (fp32) / 8-byte (bf16) boundaries take the vector kernel
   const bool neigh_vec = D % 4 == 0 && c->ld_features % 4 == 0 && (reinterpret_cast<uintptr_t>(c->features) & 15u) == 0;
   const size_t loss_lds = (size_t)(C * (H + 1) + 4 * (H + 64)) * sizeof(float);
+  // The discarded aggregation depends on nothing the step computes and nothing depends on it (gnn.py:90-92): it runs on a SIDE stream next to
+  // the step's own chain — forked from the caller's stream at the call's start, joined at its end, so for the caller the call is still one
+  // in-order piece of work on `stream`.  20 of a step's 60 us at batch 500 (profiles/r06h); DANCE_AMD_MINISTEP_SIDE_STREAM=0 keeps one stream.
+  static hipStream_t side = nullptr;
+  static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  static const bool want_side = !(getenv("DANCE_AMD_MINISTEP_SIDE_STREAM") && !strcmp(getenv("DANCE_AMD_MINISTEP_SIDE_STREAM"), "0"));
+  hipStream_t nst = st;
+  if (c->neigh_out && want_side) {
+    if (!side && (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess ||
+                  hipEventCreateWithFlags(&ev_join, hipEventDisableTiming) != hipSuccess)) {
+      side = nullptr;
+      (void)hipGetLastError();
+    }
+    if (side && hipEventRecord(ev_fork, st) == hipSuccess && hipStreamWaitEvent(side, ev_fork, 0) == hipSuccess) nst = side;
+  }
   for (int64_t s = first_step; s < first_step + n_steps; ++s) {
     const Drop dz = make_drop(c->dropout, c->seed, c->step0 + (uint64_t)s);
     const int64_t* seeds = c->seeds + s * B;
@@ -1525,15 +1540,15 @@ extern "C" int dh_scdeepsort_steps(const dh_scdeepsort_step_t* c, int64_t first_
         const int nq = (D / 4 + 63) / 64;
 #define DH_NEIGH(NQ)                                                                                                          \
   do {                                                                                                                        \
-    if (a.x_bf16) hipLaunchKernelGGL((sds_neigh_vec_kernel<NQ, true>), dim3((unsigned)B), dim3(256), lds, st, a, seeds);   \
-    else hipLaunchKernelGGL((sds_neigh_vec_kernel<NQ, false>), dim3((unsigned)B), dim3(256), lds, st, a, seeds);          \
+    if (a.x_bf16) hipLaunchKernelGGL((sds_neigh_vec_kernel<NQ, true>), dim3((unsigned)B), dim3(256), lds, nst, a, seeds);   \
+    else hipLaunchKernelGGL((sds_neigh_vec_kernel<NQ, false>), dim3((unsigned)B), dim3(256), lds, nst, a, seeds);          \
   } while (0)
         if (nq <= 1) DH_NEIGH(1);
         else if (nq <= 2) DH_NEIGH(2);
         else DH_NEIGH(4);
 #undef DH_NEIGH
       } else {
-        hipLaunchKernelGGL(sds_neigh_kernel, dim3((unsigned)B), dim3(256), neigh_lds, st, a, seeds);
+        hipLaunchKernelGGL(sds_neigh_kernel, dim3((unsigned)B), dim3(256), neigh_lds, nst, a, seeds);
       }
     }
     {
@@ -1547,5 +1562,7 @@ extern "C" int dh_scdeepsort_steps(const dh_scdeepsort_step_t* c, int64_t first_
     ga.loss_out = c->loss_out + s;
     launch_grad(ga, B, st);
   }
+  if (nst != st && (hipEventRecord(ev_join, nst) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess))
+    return dh::fail(DH_ERR_LAUNCH, "%s: joining the side stream failed", me);
   return dh::check_launch(me);
 }

@@ -381,3 +381,49 @@ def test_scdeepsort_fit_ministep_equals_general_loop(cuda_device, tmp_path, monk
         for k in out[True][0]:
             assert rel_err(out[True][0][k], out[False][0][k]) < tol, (cd, k)
         assert np.abs(out[True][1] - out[False][1]).max() < tol * 10
+
+
+@pytest.mark.parametrize("which", ["graphsc", "scdeepsort"])
+def test_data_parallel_phases_equal_the_fused_step(cuda_device, which):
+    """The data-parallel form of a step — gradients into a flat buffer (phase 1), [the caller's all-reduce], Adam alone (phase 2) — ends
+    on bit-identical parameters, moments and step counters as the fused step (phase 0): same gradient kernel, same update arithmetic."""
+    from dance_amd import _lib
+    from dance_amd.ministep import GraphSCStepper, ScDeepSortStepper
+    lib = _lib.load()
+    out = []
+    for phases in (False, True):
+        if which == "graphsc":
+            g = _graph(300, 40, 10, 2, cuda_device, normalize_edges=False)
+            m = _gsc_model(10, 12, 8, "sum", 0.1, 0.1, cuda_device).model
+            optim = torch.optim.Adam(m.parameters(), lr=1e-2, fused=True)
+            st = GraphSCStepper(m, g, 32, optim, world=2 if phases else 1)
+            n_genes, fn, extra = 40, lib.dh_graphsc_steps, (torch.empty((64, 8), device=cuda_device), )
+        else:
+            g = _graph(300, 40, 16, 2, cuda_device)
+            g.ndata["label"] = torch.cat((-torch.ones(40, dtype=torch.long), torch.arange(300) % 4)).to(cuda_device)
+            m = _sds_model(16, 12, 4, 40, 0.1, cuda_device)
+            optim = torch.optim.Adam(m.parameters(), lr=1e-2, weight_decay=0.01, fused=True)
+            st = ScDeepSortStepper(m, g, 32, optim, world=2 if phases else 1)
+            n_genes, fn, extra = 40, lib.dh_scdeepsort_steps, ()
+        st.cfg.seed = 777
+        seeds = (n_genes + torch.randperm(300, generator=torch.Generator().manual_seed(5))[:64]).to(cuda_device)
+        loss = torch.empty(2, device=cuda_device)
+        if not phases:
+            st.run(seeds, 2, *extra, loss)
+        else:  # what run() does with world > 1, minus the all-reduce (one process here)
+            c = st.cfg
+            c.seeds, c.loss_out = seeds.data_ptr(), loss.data_ptr()
+            if extra:
+                c.z_out = extra[0].data_ptr()
+            c.dropout = 0.1
+            for s in range(2):
+                c.phase = 1
+                st._run(fn, "steps", s, 1)
+                c.phase = 2
+                st._run(fn, "steps", s, 1)
+        st.check_flags("test")
+        out.append(([p.detach().clone() for p in st.params], [optim.state[p]["exp_avg_sq"].clone() for p in st.params],
+                    [float(optim.state[p]["step"]) for p in st.params], loss.clone()))
+    for a, b in zip(out[0][0] + out[0][1], out[1][0] + out[1][1]):
+        assert torch.equal(a, b)
+    assert out[0][2] == out[1][2] == [2.0] * 4 and torch.equal(out[0][3], out[1][3])

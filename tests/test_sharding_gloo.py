@@ -591,7 +591,7 @@ def test_from_row_shard_builds_the_transposed_shard_by_exchange(world, n):
         assert out == {"allgather": True, "halo": True, "alltoall_rejected": True}
 
 
-def _scdsc_worker(rank, world, port, mode, q):
+def _scdsc_worker(rank, world, port, mode, q, halo_dtype="f32"):
     import json
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -618,7 +618,7 @@ def _scdsc_worker(rank, world, port, mode, q):
             lo, hi = sharding.row_ranges(n, world)[0][rank]
             t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a).astype(dt))
             sl = lambda mm: sharding.slice_rows(t(mm.indptr, np.int32), t(mm.indices, np.int32), t(mm.data, np.float32), lo, hi, n)
-            sg = sharding.ShardedGCNGraph(sl(adj), sl(at), n, mode=mode)
+            sg = sharding.ShardedGCNGraph(sl(adj), sl(at), n, mode=mode, halo_dtype=halo_dtype)
             sg.ops = cpu_ops
             torch.manual_seed(10)
             if rank > 0:  # pre-training is replicated; ranks other than 0 run it from different weights — and are overwritten
@@ -633,16 +633,18 @@ def _scdsc_worker(rank, world, port, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "halo"), (3, "allgather")])
-def test_sharded_scdsc_fit_vs_reference_golden(world, mode):
+@pytest.mark.parametrize("world,mode,halo_dtype", [(2, "halo", "f32"), (3, "allgather", "f32"), (2, "halo", "bf16")])
+def test_sharded_scdsc_fit_vs_reference_golden(world, mode, halo_dtype):
     """ScDSC.fit with the cells sharded by destination range over 2 / 3 ranks (7 chained sharded GCN layers, BatchNorm statistics,
     target distribution and loss means over ALL cells by all-reduce) reproduces the reference's own single-process fit
-    (tests/golden/scdsc_fit.npz) to the tolerance of the single-process test; every rank ends with the same model and the same q."""
+    (tests/golden/scdsc_fit.npz) to the tolerance of the single-process test; every rank ends with the same model and the same q.
+    ``halo_dtype="bf16"``: the rows that cross the wire are rounded to bf16 (2^-9 relative) in every one of the 7 layers and their
+    backward — the fit still lands on the reference's clustering, at a looser tolerance."""
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scdsc_fit.npz"))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_scdsc_worker, args=(r, world, port, mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_scdsc_worker, args=(r, world, port, mode, q, halo_dtype)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
@@ -655,11 +657,12 @@ def test_sharded_scdsc_fit_vs_reference_golden(world, mode):
             assert np.allclose(v, res[0][3][k], rtol=1e-6, atol=1e-7), k
     qq, pred, sd = res[0][1], res[0][2], res[0][3]
     assert qq.shape == g["sf_q"].shape and np.allclose(qq.sum(1), 1, atol=1e-5)
-    assert rel_err(qq, g["sf_q"]) < 5e-3
-    assert (pred == g["sf_pred"]).mean() > 0.98
+    loose = halo_dtype == "bf16"
+    assert rel_err(qq, g["sf_q"]) < (5e-2 if loose else 5e-3)
+    assert (pred == g["sf_pred"]).mean() > (0.95 if loose else 0.98)
     for k in g.files:
         if k.startswith("sf_sd1::") and "num_batches_tracked" not in k:
-            assert np.abs(sd[k.split("::", 1)[1]] - g[k]).max() < 1.5e-2 * max(1.0, np.abs(g[k]).max()), k
+            assert np.abs(sd[k.split("::", 1)[1]] - g[k]).max() < (5e-2 if loose else 1.5e-2) * max(1.0, np.abs(g[k]).max()), k
 
 
 def _graphsc_full_worker(rank, world, port, n_layers, hidden_bn, q):
