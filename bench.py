@@ -410,10 +410,13 @@ def main():
         # what the communicator itself saw (not what the launcher was asked for): ranks, backend, every rank's device
         mine = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "name": torch.cuda.get_device_name(dev),
                 "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", ""))}
-        gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
-        comm_info = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": gathered,
-                     "distinct_devices": len({(g["device"], g["uuid"]) for g in gathered})}
+        comm_info = {"ranks": dist.get_world_size(), "backend": dist.get_backend()}
+        try:  # (a diagnostic: it must never cost the line)
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            comm_info.update(devices=gathered, distinct_devices=len({(g["device"], g["uuid"]) for g in gathered}))
+        except Exception as e:  # noqa: BLE001
+            comm_info["devices_error"] = f"{type(e).__name__}: {e}"
 
     x3_out = None
     if world == 1 and not args.no_x3_row:

@@ -88,6 +88,19 @@ def main():
                                                             cpu_baseline=dict(sample=f"{ns} cells incl. kNN", cells_per_s=ns / t_u))
         del x
 
+    # spatial coordinates (d = 3, BASELINE config 5's 500k spots; a 1M-point 2-d layout): the cell-grid form (DH_KNN_GRID, what KNN_AUTO picks for d <= 3)
+    for n, d, k in ([] if args.skip_knn else [(20_000, 3, 15)] if q else [(500_000, 3, 15), (1_000_000, 2, 15)]):
+        x = torch.rand(n, d, device=dev, generator=g) * (n ** (1.0 / d))
+        ms_g = gpu_ms(lambda: kernels.knn(x, k, algo=kernels.KNN_GRID), iters=3, warm=1)
+        ms_f = gpu_ms(lambda: kernels.knn(x, k, algo=kernels.KNN_FILTER), iters=1, warm=1)
+        i_g, d_g = kernels.knn(x, k, algo=kernels.KNN_GRID)
+        i_f, d_f = kernels.knn(x, k, algo=kernels.KNN_FILTER)
+        rows[f"knn_bruteforce_f32 [grid] n={n} d={d} k={k}"] = dict(
+            ms=ms_g, filter_ms=ms_f, speedup_vs_filter=ms_f / ms_g, cells_per_s=n / ms_g * 1e3, identical_to_filter=bool(torch.equal(i_g, i_f) and torch.equal(d_g, d_f)),
+            bound="latency / L2 (about 100 pair evaluations per query instead of n)",
+            note="bounding box, cell edge by bisection on the device, counting sort into cells, ring search with an exact stop rule: 7 launches, no host read")
+        del x
+
     if args.knn_only:
         print(json.dumps(rows, indent=1))
         return
@@ -229,7 +242,7 @@ def main():
     # ---- config C4 on one GPU: GraphSC.fit, one epoch of the GAE (two forwards per batch as in graphsc.py:202,215), 50 -> 200 -> 300 ----
     from dance_amd.modules.single_modality.clustering.graphsc import GraphSC
     cg50 = cg.with_ndata(features=feats[:, :50].contiguous())
-    for bsz in (8192, 128):  # 128 = the reference's batch size: one captured hipGraph per step (graphsc._CapturedStep)
+    for bsz in (8192, 128):  # 128 = the reference's batch size: the persistent step (dh_graphsc_steps; one C call per epoch)
         gs = GraphSC(in_feats=50, n_clusters=10, device="cuda")
         gs.fit(cg50, epochs=1, batch_size=bsz)  # warm-up
 
@@ -245,8 +258,9 @@ def main():
         rows[f"GraphSC.fit epoch cells={n_cells} batch={bsz} (reference default batch is 128)"] = dict(
             ms=dt * 1e3, cells_per_s=n_cells / dt, ms_per_batch=dt * 1e3 / -(-n_cells // bsz), fit_1_epoch_ms=t1 * 1e3, fit_3_epochs_ms=t3 * 1e3,
             once_per_fit_ms=(t1 - dt) * 1e3,
-            note="epoch = (fit(epochs=3) - fit(epochs=1)) / 2.  Per batch: block, WeightedGraphConv forward x2, Linear, fused decoder loss (no B x B "
-            "logits), backward, Adam — eager above batch 2048, replayed from one captured hipGraph per step below.  once_per_fit = the "
+            step_mode=getattr(gs, "step_mode", None),
+            note="epoch = (fit(epochs=3) - fit(epochs=1)) / 2.  step_mode 'ministep' (batches up to 512): every full batch of the epoch behind one C call, 4 "
+            "launches per step; 'aggfirst' above: the aggregation off the CSR rows + dense layers / all-pairs decoder / Adam on the big-tile kernels.  once_per_fit = the "
             "capture (if any) + the read-out of the embedding to host numpy after the last epoch (1.2 GB at 1M cells, graphsc.py:232-236)")
     del feats, feats16, rowptr, gcol, gval, eid, cg, cg50
 
