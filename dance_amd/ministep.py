@@ -174,6 +174,7 @@ class GraphSCStepper(_Stepper):
         assert z_out.is_contiguous() and z_out.shape == (n_steps * self.batch, self.emb_dim) and loss_out.numel() >= n_steps
         c = self.cfg
         self._hyper(c, self.optim)
+        c.w1, c.b1, c.w2, c.b2 = (_adam_struct(self.optim, p) for p in self.params)  # (re-read every call: ``p.data = ...`` or a re-created state moves them)
         c.dropout = float(self.model.dropout.p) if self.model.dropout is not None and self.model.training else 0.0
         c.seeds, c.z_out, c.loss_out = seeds.data_ptr(), z_out.data_ptr(), loss_out.data_ptr()
         if self.world == 1:
@@ -200,6 +201,7 @@ class GraphSCStepper(_Stepper):
         c = self.cfg
         out = torch.empty((2, self.batch, int(c.in_feats)), dtype=torch.float32, device=seeds.device)
         c.dropout = float(self.model.dropout.p) if self.model.dropout is not None and self.model.training else 0.0
+        c.w1, c.b1, c.w2, c.b2 = (_adam_struct(self.optim, p) for p in self.params)
         c.seeds, c.ax_out, c.phase = seeds.data_ptr(), out.data_ptr(), 3
         self._run(lib.dh_graphsc_steps, "graphsc_aggregate", 0, 1)
         c.phase, c.ax_out = 0, None
@@ -272,6 +274,8 @@ class ScDeepSortStepper(_Stepper):
         assert seeds.dtype == torch.int64 and seeds.is_contiguous() and seeds.numel() >= n_steps * self.batch and loss_out.numel() >= n_steps
         c = self.cfg
         self._hyper(c, self.optim)
+        c.w1, c.b1, c.w2, c.b2 = (_adam_struct(self.optim, p) for p in self.params)  # (re-read every call, as above)
+        c.alpha = self.model.alpha.detach().reshape(-1).data_ptr()
         c.dropout = self._dropout_p()
         c.seeds, c.loss_out = seeds.data_ptr(), loss_out.data_ptr()
         if self.world == 1:

@@ -10,6 +10,10 @@ for path in sys.argv[1:]:
     acc = defaultdict(lambda: [0, 0.0, 0.0])
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"]
+        m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)  # a kernel rocprofv3 left mangled (templates with _Float16 arguments: the kNN filter)
+        if m:
+            k0 = m.end()
+            name = "(anonymous namespace)::" + name[k0:k0 + int(m.group(1))] + "("
         if "at::native" in name or "rocprim" in name or "anonymous namespace)::" not in name:
             continue
         short = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0].replace("void ", "")
