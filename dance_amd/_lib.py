@@ -50,6 +50,7 @@ def _declare(lib):
         "dh_relu_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P]),
         "dh_bias_act_f32": (c_int, [i64, i64, P, i64, P, i32, P]),
         "dh_gaussian_kernel_f32": (c_int, [i64, i64, P, i64, c_double, P, i64, P, P]),
+        "dh_axpby_f32": (c_int, [i64, i64, c_float, P, i64, c_float, P, i64, P, i64, P]),
         "dh_colsum_f32_workspace_bytes": (c_size_t, [i64, i64]),
         "dh_colsum_f32": (c_int, [i64, i64, P, i64, P, P, c_size_t, P]),
         "dh_pairwise_distance_f32": (c_int, [i64, i64, P, i64, P, i64, i32, P]),
@@ -134,6 +135,8 @@ def _declare(lib):
         "dh_softmax_xent_sum_f32": (c_int, [i64, i64, P, i64, P, i64, P, P, i64, P, c_size_t, P]),
         "dh_zinb_nll_logits_forward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P]),
         "dh_zinb_nll_logits_backward_f32": (c_int, [i64, i64, P, i64, P, i64, P, i64, P, i64, P, c_double, P, P, P, P, i64, P]),
+        "dh_zinb_heads_fused_partials": (c_int, [i64, i64, P, P]),
+        "dh_zinb_heads_fused_f32": (c_int, [i64, i64, P, i64, P, P, P, i64, P, c_double, c_double, P, P, P]),
         "dh_comm_unique_id": (c_int, [P]),
         "dh_comm_init": (c_int, [P, i32, i32, P]),
         "dh_comm_destroy": (c_int, [P]),

@@ -86,7 +86,53 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(int64_t n_blocks, int
 
 constexpr int64_t kColsumRows = 2048;
 
+// out = a X + b Y, each product and the sum rounded separately (what the torch expression `a * X + b * Y` computes with three
+// kernels and two temporaries); Y == nullptr: out = a X.
+template <bool VEC>
+__global__ __launch_bounds__(256) void axpby_kernel(int64_t n_rows, int64_t width, float a, const float* __restrict__ X, int64_t ldx, float b,
+                                                    const float* __restrict__ Y, int64_t ldy, float* __restrict__ O, int64_t ldo) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const int64_t per_row = VEC ? width / 4 : width, total = n_rows * per_row;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / per_row, c = (i % per_row) * (VEC ? 4 : 1);
+    if constexpr (VEC) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(X + r * ldx + c);
+      f32x4 o;
+      if (Y) {
+        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + r * ldy + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(a, x[j]), __fmul_rn(b, y[j]));
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a * x[j];
+      }
+      *reinterpret_cast<f32x4*>(O + r * ldo + c) = o;
+    } else {
+      const float x = X[r * ldx + c];
+      O[r * ldo + c] = Y ? __fadd_rn(__fmul_rn(a, x), __fmul_rn(b, Y[r * ldy + c])) : a * x;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int dh_axpby_f32(int64_t n_rows, int64_t width, float a, const float* X, int64_t ldx, float b, const float* Y, int64_t ldy, float* out,
+                            int64_t ldo, dh_stream_t stream) {
+  if (n_rows < 0 || width < 0) return dh::fail(DH_ERR_INVALID, "dh_axpby_f32: negative size");
+  if (n_rows == 0 || width == 0) return DH_OK;
+  if (!X || !out) return dh::fail(DH_ERR_INVALID, "dh_axpby_f32: null pointer");
+  if (ldx < width || ldo < width || (Y && ldy < width)) return dh::fail(DH_ERR_INVALID, "dh_axpby_f32: leading dimension < width");
+  const bool vec = width % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && (!Y || ldy % 4 == 0) && dh::aligned16(X) && dh::aligned16(out) &&
+                   (!Y || dh::aligned16(Y));
+  const int64_t work = vec ? n_rows * (width / 4) : n_rows * width;
+  const unsigned grid = (unsigned)(dh::ceil_div(work, 256) < 16384 ? dh::ceil_div(work, 256) : 16384);
+  hipStream_t st = dh::as_stream(stream);
+  if (vec)
+    hipLaunchKernelGGL(axpby_kernel<true>, dim3(grid), dim3(256), 0, st, n_rows, width, a, X, ldx, b, Y, ldy, out, ldo);
+  else
+    hipLaunchKernelGGL(axpby_kernel<false>, dim3(grid), dim3(256), 0, st, n_rows, width, a, X, ldx, b, Y, ldy, out, ldo);
+  return dh::check_launch("dh_axpby_f32");
+}
 
 extern "C" int dh_relu_backward_f32(int64_t n_rows, int64_t width, const float* Y, int64_t ldy,
                                     const float* dY, int64_t lddy, float* G, int64_t ldg,

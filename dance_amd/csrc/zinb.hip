@@ -34,6 +34,21 @@ namespace {
 
 constexpr double kEps = 1e-10;
 
+// The transcendental unit's own instructions (v_rcp_f32, v_exp_f32, v_log_f32: 1 ulp) without the library's wrappers: __frcp_rn is a
+// correctly rounded division (v_div_scale / v_div_fmas / v_div_fixup and four FMAs: ten instructions), __expf / __logf add a range
+// test, two selects and an ldexp for denormal arguments and results.  None of that is needed here — every argument is a normal number
+// after the activations' clamps and a result below 2^-126 is clamped or added to something O(1e-10) — and these wrappers were 110 of the
+// 215 vector instructions per x = 0 element (ISA count of round 6; the x = 0 path is what the kernels' time is).
+__device__ __forceinline__ float rcp_f(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float exp_f(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float log_f(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+
+// 1 / a for a double inside the fp32 range (every argument here is, after the activations' clamps): the fp32 reciprocal and one Newton
+// step in float64 — ~1e-14 relative for 3 instructions instead of the ~30 of a float64 division
+__device__ __forceinline__ double rcp_d(double a) {
+  const double r = (double)rcp_f((float)a);
+  return r * (2.0 - a * r);
+}
 // log(x) for a positive normal double to ~2e-14 relative: x = 2^e m with m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(t), t = (m - 1) / (m + 1),
 // |t| <= 0.1716: the odd series through t^15 (truncation 2 t^17 / 17 < 2e-14), one division — about a third of the library call,
 // which is what the kernels spend their time in once the gamma functions are gone.
@@ -46,7 +61,7 @@ __device__ __forceinline__ double fast_log(double x) {
     m *= 0.5;
     e += 1;
   }
-  const double t = (m - 1.0) / (m + 1.0);
+  const double t = (m - 1.0) * rcp_d(m + 1.0);  // m + 1 in [1.7, 2.42): the Newton-refined fp32 reciprocal (1e-14) instead of a ~30-instruction division
   const double t2 = t * t;
   double p = 1.0 / 15.0;
   p = p * t2 + 1.0 / 13.0;
@@ -76,24 +91,18 @@ __device__ __forceinline__ double digamma_pos(double x) {
   return r + fast_log(x) - 0.5 / x + t;
 }
 
-// 1 / a for a double inside the fp32 range (every argument here is, after the activations' clamps): the fp32 reciprocal and one Newton
-// step in float64 — ~1e-14 relative for 3 instructions instead of the ~30 of a float64 division
-__device__ __forceinline__ double rcp_d(double a) {
-  const double r = (double)__frcp_rn((float)a);
-  return r * (2.0 - a * r);
-}
 // log of a positive double whose VALUE may lie far outside the fp32 range (products of up to 16 factors): exponent and mantissa apart,
 // the mantissa's logarithm on the fp32 transcendental unit (v_log_f32, ~1 ulp): absolute error ~1e-7, which is what a loss term needs
 __device__ __forceinline__ float log_d(double v) {
   int e;
   const double m = frexp(v, &e);  // m in [0.5, 1)
-  return ((float)e + __log2f((float)m)) * 0.69314718055994531f;
+  return ((float)e + __builtin_amdgcn_logf((float)m)) * 0.69314718055994531f;
 }
 // log(1 + x) in fp32 for x > -1: Kahan's form x log(t) / (t - 1), t = fl(1 + x) — exact in the limit x -> 0 without a series
 __device__ __forceinline__ float log1p_f(float x) {
   const float t = 1.f + x;
   const float d = t - 1.f;
-  return d == 0.f ? x : __logf(t) * __fdividef(x, d);
+  return d == 0.f ? x : log_f(t) * (x * rcp_f(d));  // branch-free: a select on the result
 }
 
 // The decoder heads' activations (scdsc.py:601-618, sctag.py:531-548: MeanAct = clamp(exp(a), 1e-5, 1e6), DispAct = clamp(softplus(a),
@@ -108,15 +117,15 @@ struct HeadActs {
 template <bool GRAD>
 __device__ __forceinline__ HeadActs head_acts(float am, float ad, float ap) {
   HeadActs o{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const float e = __expf(am);
+  const float e = exp_f(am);
   o.m = fminf(fmaxf(e, 1e-5f), 1e6f);
-  const float z = __expf(ad);
+  const float z = exp_f(ad);
   const float sp = ad > 20.f ? ad : log1p_f(z);
   o.d = fminf(fmaxf(sp, 1e-4f), 1e4f);
-  o.p = __frcp_rn(1.f + __expf(-ap));
+  o.p = rcp_f(1.f + exp_f(-ap));
   if (GRAD) {
     o.jm = (e >= 1e-5f && e <= 1e6f) ? e : 0.f;
-    const float sg = ad > 20.f ? 1.f : z * __frcp_rn(z + 1.f);
+    const float sg = ad > 20.f ? 1.f : z * rcp_f(z + 1.f);
     o.jd = (sp >= 1e-4f && sp <= 1e4f) ? sg : 0.f;
     o.jp = o.p * (1.f - o.p);
   }
@@ -159,14 +168,19 @@ template <bool GRAD>
 __device__ __forceinline__ ZTerms zero_terms(float m, float d, float p, float ridge) {
   ZTerms o{0.f, 0.f, 0.f, 0.f};
   const float s = d + m + 1e-10f;
-  const float rs = __frcp_rn(s);
+  const float rs = rcp_f(s);
   const float u = (m + 1e-10f) * rs;
-  const float lr = u < 0.5f ? log1p_f(-u) : __logf(d * rs);  // the transcendental unit's log / exp: ~1 ulp of the result
-  const float zn = __expf(d * lr);
+  // log r = log1p(-u) (Kahan's form) for u < 1/2, log(d / s) otherwise: ONE logarithm of the selected argument and one reciprocal,
+  // no branch (the two-sided form compiled to a divergent branch around two logarithms)
+  const bool small = u < 0.5f;
+  const float t = 1.f - u, dt = t - 1.f;
+  const float lg = log_f(small ? t : d * rs);
+  const float lr = small ? (dt == 0.f ? -u : lg * (-u * rcp_f(dt))) : lg;
+  const float zn = exp_f(d * lr);
   const float w = p + (1.f - p) * zn + 1e-10f;
-  o.loss = -__logf(w);
+  o.loss = -log_f(w);
   if (GRAD) {
-    const float rw = __frcp_rn(w);
+    const float rw = rcp_f(w);
     const float dzc_dzn = -(1.f - p) * rw;
     o.d_p = -(1.f - zn) * rw;
     o.d_m = dzc_dzn * (-zn * d * rs);
@@ -203,7 +217,7 @@ __device__ __forceinline__ Terms count_terms(double x, double m, double d, doubl
         const double f = de + (double)k;
         num *= (double)(k + 1) * de;
         den *= me * f;
-        if (GRAD) ksum += (double)((float)k * __frcp_rn((float)f));
+        if (GRAD) ksum += (double)((float)k * rcp_f((float)f));
       }
       lg += log_d(num) - log_d(den);
     }
@@ -393,6 +407,159 @@ __global__ __launch_bounds__(256) void zinb_backward_kernel(int64_t n, int64_t g
   }
 }
 
+// ---- the three heads' loss, gradients and bias gradients in ONE pass (dh_zinb_heads_fused_f32) -------------------------------------------
+// The training loop of scDSC (scdsc.py:265-283) runs forward and backward of the loss on the same operands back to back: the forward
+// kernel reads the four N x G matrices (32 GB at 1M x 2000) for a scalar, the backward kernel reads them again, and a third pass
+// (dh_colsum_f32, 24 GB) sums the three gradients' columns for the heads' biases: 9.7 + 15.3 + 4.9 ms of a 201 ms epoch.  This kernel
+// evaluates each element once: loss (float64 partial per wavefront), the gradients w.r.t. the raw head outputs for a UNIT upstream
+// gradient times ``unit`` (= 1 / (N G): the caller folds the real upstream scalar into the heads' small dW / db), written OVER the raw
+// outputs (a wavefront owns its elements: read, then write), and the gradients' column sums per block of 64 rows.
+//   * a wavefront owns a window of 256 genes x 64 rows: a lane holds 4 ADJACENT genes (one 16-byte load per matrix and row instead
+//     of four 4-byte ones: a 4-byte-per-lane load instruction costs the same issue time and moves a quarter), the next row's four
+//     loads are in flight while this row is evaluated, the column sums of its 4 genes stay in 12 registers;
+//   * x = 0 arithmetic (fp32) runs for every element, branch-free; the counts of the row's window are listed in LDS (ballot order:
+//     deterministic) and evaluated afterwards 64 at a time in float64 (the split of the two kernels above), their results merged by a
+//     select on the way out;
+//   * no barrier, no atomics: wavefronts are independent.
+constexpr int FW = 256;        // genes per window
+constexpr int FR = 64;         // rows per wavefront
+
+template <bool VEC>
+__device__ __forceinline__ void load_quad(float (&v)[4], const float* __restrict__ row, int64_t c, int64_t g) {
+  if constexpr (VEC) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4 q = *reinterpret_cast<const f32x4*>(row + (c < g ? c : 0));  // g % 4 == 0: a quad is entirely in or out
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = q[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = row[c + j < g ? c + j : g - 1];
+  }
+}
+template <bool VEC>
+__device__ __forceinline__ void store_quad(float* __restrict__ row, int64_t c, int64_t g, const float (&v)[4]) {
+  if constexpr (VEC) {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    if (c < g) *reinterpret_cast<f32x4*>(row + c) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c + j < g) row[c + j] = v[j];
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void zinb_heads_fused_kernel(int64_t n, int64_t g, int nwin, const float* __restrict__ X, int64_t ldx,
+                                                               float* __restrict__ M, float* __restrict__ D, float* __restrict__ P, int64_t ld,
+                                                               const double* __restrict__ sf, double ridge, double unit,
+                                                               double* __restrict__ loss_partials, float* __restrict__ col_partials) {
+  __shared__ __attribute__((aligned(16))) float stage_in[4][4][FW];   // per wave: x, raw mean / disp / pi of the row's window
+  __shared__ __attribute__((aligned(16))) float stage_out[4][3][FW];  // per wave: the counts' gradients
+  __shared__ unsigned short wlist[4][FW];
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t unit_id = (int64_t)blockIdx.x * 4 + wave;  // (row block, window)
+  const int64_t n_rb = (n + FR - 1) / FR;
+  if (unit_id >= n_rb * nwin) return;
+  const int64_t rb = unit_id / nwin;
+  const int win = (int)(unit_id % nwin);
+  const int64_t r0 = rb * FR, r1 = min(n, r0 + FR);
+  const int64_t c = (int64_t)win * FW + 4 * lane;  // this lane's first gene
+  const float ridge_f = (float)ridge;
+  float (*si)[FW] = stage_in[wave];
+  float (*so)[FW] = stage_out[wave];
+  unsigned short* wl = wlist[wave];
+  float colacc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  double acc = 0.0;
+
+  float xn[4], mn[4], dn[4], pn[4];
+  load_quad<VEC>(xn, X + r0 * ldx, c, g);
+  load_quad<VEC>(mn, M + r0 * ld, c, g);
+  load_quad<VEC>(dn, D + r0 * ld, c, g);
+  load_quad<VEC>(pn, P + r0 * ld, c, g);
+  for (int64_t row = r0; row < r1; ++row) {
+    float xv[4], mv[4], dv[4], pv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv[j] = xn[j], mv[j] = mn[j], dv[j] = dn[j], pv[j] = pn[j];
+    {
+      const int64_t nr = row + 1 < r1 ? row + 1 : row;  // the next row's operands: in flight during this row's arithmetic
+      load_quad<VEC>(xn, X + nr * ldx, c, g);
+      load_quad<VEC>(mn, M + nr * ld, c, g);
+      load_quad<VEC>(dn, D + nr * ld, c, g);
+      load_quad<VEC>(pn, P + nr * ld, c, g);
+    }
+    const double s = sf ? sf[row] : 1.0;
+    const float upf = (float)unit, upsf = (float)(unit * s);
+    *reinterpret_cast<f32x4*>(&si[0][4 * lane]) = f32x4{xv[0], xv[1], xv[2], xv[3]};
+    *reinterpret_cast<f32x4*>(&si[1][4 * lane]) = f32x4{mv[0], mv[1], mv[2], mv[3]};
+    *reinterpret_cast<f32x4*>(&si[2][4 * lane]) = f32x4{dv[0], dv[1], dv[2], dv[3]};
+    *reinterpret_cast<f32x4*>(&si[3][4 * lane]) = f32x4{pv[0], pv[1], pv[2], pv[3]};
+    // x = 0 arithmetic for every element, two at a time (NOT unrolled: with the four elements of a lane interleaved the kernel held
+    // 187 registers = 2 resident waves per SIMD; operands come back from the LDS stage so that nothing is indexed by the loop counter
+    // in registers): results to the output stage, counts listed
+    int cnt = 0;
+#pragma nounroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const int l0 = 4 * lane + 2 * jp;
+      const f32x2 x2 = *reinterpret_cast<const f32x2*>(&si[0][l0]);
+      const f32x2 m2 = *reinterpret_cast<const f32x2*>(&si[1][l0]);
+      const f32x2 d2 = *reinterpret_cast<const f32x2*>(&si[2][l0]);
+      const f32x2 p2 = *reinterpret_cast<const f32x2*>(&si[3][l0]);
+      f32x2 om, od, op;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const bool in = c + 2 * jp + e < g;
+        const bool nz = in && x2[e] > 1e-8f;
+        const HeadActs a = head_acts<true>(m2[e], d2[e], p2[e]);
+        const ZTerms t = zero_terms<true>((float)((double)a.m * s), a.d, a.p, ridge_f);
+        om[e] = in ? upsf * t.d_m * a.jm : 0.f;
+        od[e] = in ? upf * t.d_d * a.jd : 0.f;
+        op[e] = in ? upf * t.d_p * a.jp : 0.f;
+        acc += (in && !nz) ? (double)t.loss : 0.0;
+        const unsigned long long mask = __ballot(nz);
+        if (nz) wl[cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(l0 + e);
+        cnt += __popcll(mask);
+      }
+      *reinterpret_cast<f32x2*>(&so[0][l0]) = om;
+      *reinterpret_cast<f32x2*>(&so[1][l0]) = od;
+      *reinterpret_cast<f32x2*>(&so[2][l0]) = op;
+    }
+    for (int i = lane; i < cnt; i += 64) {  // the window's counts, every lane busy (a wave reads its own LDS writes: no barrier)
+      const int li = wl[i];
+      const HeadActs a = head_acts<true>(si[1][li], si[2][li], si[3][li]);
+      const Terms t = count_terms<true>((double)si[0][li], (double)a.m * s, (double)a.d, (double)a.p, ridge);
+      acc += t.loss;
+      so[0][li] = (float)(unit * t.d_m * s * (double)a.jm);
+      so[1][li] = (float)(unit * t.d_d * (double)a.jd);
+      so[2][li] = (float)(unit * t.d_p * (double)a.jp);
+    }
+    const f32x4 cm = *reinterpret_cast<const f32x4*>(&so[0][4 * lane]);
+    const f32x4 cd = *reinterpret_cast<const f32x4*>(&so[1][4 * lane]);
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(&so[2][4 * lane]);
+    float gm[4], gd[4], gp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      gm[j] = cm[j], gd[j] = cd[j], gp[j] = cp[j];
+      colacc[0][j] += gm[j];
+      colacc[1][j] += gd[j];
+      colacc[2][j] += gp[j];
+    }
+    store_quad<VEC>(M + row * ld, c, g, gm);
+    store_quad<VEC>(D + row * ld, c, g, gd);
+    store_quad<VEC>(P + row * ld, c, g, gp);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lane == 0) loss_partials[unit_id] = acc;
+  float* cpart = col_partials + rb * 3 * g;  // [row block][head][gene]
+#pragma unroll
+  for (int hd = 0; hd < 3; ++hd)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (c + j < g) cpart[(int64_t)hd * g + c + j] = colacc[hd][j];
+}
+
 int check(const char* me, int64_t n, int64_t g, const void* X, int64_t ldx, const void* M, int64_t ldm, const void* D, int64_t ldd, const void* P,
           int64_t ldp) {
   if (n < 0 || g < 0) return dh::fail(DH_ERR_INVALID, "%s: negative size", me);
@@ -455,4 +622,39 @@ extern "C" int dh_zinb_nll_logits_backward_f32(int64_t n, int64_t g, const float
                                                int64_t ldo, dh_stream_t stream) {
   return backward_impl<true>("dh_zinb_nll_logits_backward_f32", n, g, X, ldx, mean_raw, ldm, disp_raw, ldd, pi_raw, ldp, scale_factor, ridge_lambda,
                              upstream, d_mean_raw, d_disp_raw, d_pi_raw, ldo, stream);
+}
+
+// Loss, gradients (over the raw outputs, in place) and per-row-block column sums of the three heads in one pass: see
+// zinb_heads_fused_kernel.  loss_partials: dh_zinb_heads_fused_partials(n, g, &n_loss, &n_row_blocks) doubles, summed by the caller in
+// index order; col_partials: [n_row_blocks][3][g] floats, whose column sums (dh_colsum_f32 over the [n_row_blocks, 3 g] matrix) are the
+// three bias gradients for the unit upstream.
+extern "C" int dh_zinb_heads_fused_partials(int64_t n, int64_t g, int64_t* n_loss, int64_t* n_row_blocks) {
+  if (n < 0 || g < 0 || !n_loss || !n_row_blocks) return dh::fail(DH_ERR_INVALID, "dh_zinb_heads_fused_partials: bad argument");
+  const int64_t n_rb = (n + FR - 1) / FR, nwin = (g + FW - 1) / FW;
+  *n_loss = n_rb * nwin;
+  *n_row_blocks = n_rb;
+  return DH_OK;
+}
+
+extern "C" int dh_zinb_heads_fused_f32(int64_t n, int64_t g, const float* X, int64_t ldx, float* mean_raw, float* disp_raw, float* pi_raw,
+                                       int64_t ld, const double* scale_factor, double ridge_lambda, double unit, double* loss_partials,
+                                       float* col_partials, dh_stream_t stream) {
+  const char* me = "dh_zinb_heads_fused_f32";
+  const int rc = check(me, n, g, X, ldx, mean_raw, ld, disp_raw, ld, pi_raw, ld);
+  if (rc != DH_OK) return rc > 0 ? DH_OK : rc;
+  if (!loss_partials || !col_partials) return dh::fail(DH_ERR_INVALID, "%s: null output", me);
+  if (g > 0x7fffffffLL / 2) return dh::fail(DH_ERR_INVALID, "%s: too many genes", me);
+  const int64_t n_rb = (n + FR - 1) / FR, nwin = (g + FW - 1) / FW;
+  const int64_t blocks = dh::ceil_div(n_rb * nwin, 4);
+  if (blocks > 0x7fffffffLL) return dh::fail(DH_ERR_INVALID, "%s: grid too large", me);
+  const bool vec = g % 4 == 0 && ldx % 4 == 0 && ld % 4 == 0 && dh::aligned16(X) && dh::aligned16(mean_raw) && dh::aligned16(disp_raw) &&
+                   dh::aligned16(pi_raw);
+  hipStream_t st = dh::as_stream(stream);
+  if (vec)
+    hipLaunchKernelGGL(zinb_heads_fused_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, n, g, (int)nwin, X, ldx, mean_raw, disp_raw, pi_raw,
+                       ld, scale_factor, ridge_lambda, unit, loss_partials, col_partials);
+  else
+    hipLaunchKernelGGL(zinb_heads_fused_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, n, g, (int)nwin, X, ldx, mean_raw, disp_raw, pi_raw,
+                       ld, scale_factor, ridge_lambda, unit, loss_partials, col_partials);
+  return dh::check_launch(me);
 }

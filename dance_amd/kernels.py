@@ -460,6 +460,27 @@ def zinb_nll_backward(X, mean, disp, pi, scale_factor: Optional[torch.Tensor], r
     return dm, dd, dp
 
 
+def zinb_heads_fused_(X, mean_raw, disp_raw, pi_raw, scale_factor: Optional[torch.Tensor], ridge_lambda: float, unit: float):
+    """One pass over the three heads' raw outputs (dh_zinb_heads_fused_f32): returns (sum of the element losses as a float64 0-dim tensor,
+    d bias [3, G] for a unit upstream) and OVERWRITES ``mean_raw`` / ``disp_raw`` / ``pi_raw`` with ``unit`` x the gradients of that sum
+    w.r.t. them.  The three matrices share one leading dimension (rows of one allocation or three equal ones)."""
+    import ctypes
+    lib = _lib_ready()
+    n, g = X.shape
+    if not (_ld(mean_raw) == _ld(disp_raw) == _ld(pi_raw)):
+        raise ValueError("zinb_heads_fused_: the three head outputs must share one leading dimension")
+    n_loss, n_rb = ctypes.c_int64(0), ctypes.c_int64(0)
+    _lib.check(lib.dh_zinb_heads_fused_partials(n, g, ctypes.byref(n_loss), ctypes.byref(n_rb)), "dh_zinb_heads_fused_partials")
+    loss_p = torch.empty(max(n_loss.value, 1), dtype=torch.float64, device=X.device)
+    col_p = torch.empty((max(n_rb.value, 1), 3 * g), dtype=torch.float32, device=X.device)
+    _call("zinb_heads_fused_f32", lib.dh_zinb_heads_fused_f32, n, g, _dev(X, torch.float32, "X", 2), _ld(X), _dev(mean_raw, torch.float32, "mean_raw", 2),
+          _dev(disp_raw, torch.float32, "disp_raw", 2), _dev(pi_raw, torch.float32, "pi_raw", 2), _ld(mean_raw),
+          _dev(scale_factor, torch.float64, "scale_factor", 1), float(ridge_lambda), float(unit), loss_p.data_ptr(), col_p.data_ptr(), _stream())
+    if n == 0 or g == 0:
+        return torch.zeros((), dtype=torch.float64, device=X.device), torch.zeros((3, g), dtype=torch.float32, device=X.device)
+    return loss_p[:n_loss.value].sum(), colsum(col_p[:n_rb.value]).view(3, g)
+
+
 def softmax_xent_sum(logits: torch.Tensor, labels: torch.Tensor, ignore_index: int = -100, want_grad: bool = True):
     """(loss, d) of ``CrossEntropyLoss(reduction="sum")``: loss a 0-dim fp32 tensor, d = softmax(logits) - onehot(labels) or None
     (dh_softmax_xent_sum_f32)."""
@@ -548,6 +569,15 @@ def gram_diag_backward(Z: torch.Tensor, O: torch.Tensor, xe: torch.Tensor, pos_w
     out = torch.empty((n, d), dtype=torch.float32, device=Z.device)
     _call("gram_diag_backward_f32", lib.dh_gram_diag_backward_f32, n, d, _dev(Z, torch.float32, "Z", 2), _ld(Z), _dev(O, torch.float32, "O", 2), _ld(O),
           _dev(xe, torch.float32, "xe", 1), float(pos_weight), _dev(scale.reshape(1), torch.float32, "scale", 1), out.data_ptr(), _ld(out), _stream())
+    return out
+
+
+def axpby(a: float, X: torch.Tensor, b: float = 0.0, Y: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``a * X + b * Y`` (``Y`` None: ``a * X``) in one pass, rounded like the three torch kernels of the expression (dh_axpby_f32)."""
+    lib = _lib_ready()
+    out = torch.empty(X.shape, dtype=torch.float32, device=X.device)
+    _call("axpby_f32", lib.dh_axpby_f32, X.shape[0], X.shape[1], float(a), _dev(X, torch.float32, "X", 2), _ld(X), float(b),
+          _dev(Y, torch.float32, "Y", 2), 0 if Y is None else _ld(Y), out.data_ptr(), _ld(out), _stream())
     return out
 
 

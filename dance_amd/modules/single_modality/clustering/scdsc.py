@@ -8,7 +8,7 @@ import torch
 from torch import nn
 
 from .... import kernels
-from ....autograd import gcn_layer, student_t_assign, zinb_nll, zinb_nll_from_logits
+from ....autograd import gcn_layer, mix, student_t_assign, zinb_heads_loss, zinb_nll, zinb_nll_from_logits
 from ....graph import as_graph
 from ....sharding import ShardedGCNGraph, allreduce_sum_gradients, broadcast_parameters, sharded_batch_norm, sharded_gcn_layer
 
@@ -217,23 +217,32 @@ class ScDSCModel(nn.Module):
         if not isinstance(adj, ShardedGCNGraph):
             adj = as_graph(adj, x.device)  # CSR (+ transpose) built once, reused by all 7 layers and every epoch
         h = self.gnn_1(x, adj)
-        h = self.gnn_2((1 - sigma) * h + sigma * tra1, adj)
-        h = self.gnn_3((1 - sigma) * h + sigma * tra2, adj)
-        h = self.gnn_4((1 - sigma) * h + sigma * tra3, adj)
-        h = self.gnn_5((1 - sigma) * h + sigma * z1, adj)
-        h = self.gnn_6((1 - sigma) * h + sigma * z2, adj)
-        h = self.gnn_7((1 - sigma) * h + sigma * z3, adj, active=False)
+        h = self.gnn_2(mix(h, tra1, 1 - sigma, sigma), adj)
+        h = self.gnn_3(mix(h, tra2, 1 - sigma, sigma), adj)
+        h = self.gnn_4(mix(h, tra3, 1 - sigma, sigma), adj)
+        h = self.gnn_5(mix(h, z1, 1 - sigma, sigma), adj)
+        h = self.gnn_6(mix(h, z2, 1 - sigma, sigma), adj)
+        h = self.gnn_7(mix(h, z3, 1 - sigma, sigma), adj, active=False)
         predict = F.softmax(h, dim=1)
-        if raw_heads:
+        if raw_heads == "fused":
+            # the joint loop's training pass: heads, loss, gradients and bias gradients in one sweep (autograd.zinb_heads_loss)
+            heads = (self._dec_mean[0], self._dec_disp[0], self._dec_pi[0])
+            _mean = _disp = _pi = None
+            zinb = lambda x_raw, _m, _d, _p, sf, ridge_lambda=0.0: zinb_heads_loss(dec_h3, heads, x_raw, sf, ridge_lambda)  # noqa: E731
+        elif raw_heads:
             _mean, _disp, _pi = self._dec_mean[0](dec_h3), self._dec_disp[0](dec_h3), self._dec_pi[0](dec_h3)
         else:
             _mean, _disp, _pi = self._dec_mean(dec_h3), self._dec_disp(dec_h3), self._dec_pi(dec_h3)
         # :466-468, on the fused kernel pair (the reference's z3.unsqueeze(1) - cluster_layer is an [N, C, 32] tensor: 1.3 GB at 1M cells)
         q = student_t_assign(z3, self.cluster_layer, a=self.v, eps=0.0, pw=(self.v + 1.0) / 2.0, scale=1.0)
+        if raw_heads == "fused":
+            return x_bar, q, predict, z3, _mean, _disp, _pi, zinb
         return x_bar, q, predict, z3, _mean, _disp, _pi, (self.zinb_loss.from_logits if raw_heads else self.zinb_loss)
 
 
 # ---- ScDSC: the method wrapper (scdsc.py:33-336) ------------------------------------------------------------------
+import os  # noqa: E402
+
 import numpy as np  # noqa: E402
 from torch.optim import Adam  # noqa: E402
 from torch.utils.data import DataLoader, TensorDataset  # noqa: E402
@@ -247,6 +256,12 @@ from ...base import BaseClusteringMethod, TorchNNPretrain  # noqa: E402
 class ScDSC(TorchNNPretrain, BaseClusteringMethod):
     # the first GCN layer's aggregation A X is a constant of a fit: computed once and kept (GNNLayer.aggregated).  False: A (X W) every epoch
     cache_first_aggregation = True
+    # the three ZINB heads, their loss, gradients and bias gradients in one sweep over the cells x genes operands (autograd.zinb_heads_loss).
+    # False: three HipLinear + zinb_nll_from_logits (loss kernel, gradient kernel, three column-sum passes)
+    # measurement aid (scripts/bench_configs.py): True -> ``epoch_ms`` holds the device time of every joint-training epoch of the last fit
+    # (events on the current stream at the epoch boundaries; the wall clock of a whole fit also holds 16 GB of host-to-device copies)
+    record_epoch_times = False
+    fuse_zinb_heads = os.environ.get("DANCE_AMD_SCDSC_FUSE_HEADS", "1") != "0"
     """scDSC method wrapper (scdsc.py:33-336): ``fit((adj, x, x_raw, n_counts), y, ...)`` pre-trains the autoencoder, then
     trains the AE + 7-layer GCN jointly (BCE + KL + MSE + ZINB); ``predict`` / ``predict_proba`` return the soft assignment
     of the best-ARI checkpoint, as the reference does.  ``adj`` may be the scipy matrix the NeighborGraph transform leaves in
@@ -363,7 +378,11 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
                 model.gnn_1.cache_aggregated(data, adj)  # A X once per fit (8 GB at 1M cells x 2000 genes; see GNNLayer.aggregated)
             with torch.no_grad():  # :253-254 — its result is unused, but the module is in train mode here: this full-batch pass
                 model.ae(data)     # moves the BatchNorm running statistics that the eval-mode passes below read
+            marks = []
             for epoch in range(epochs):
+                if self.record_epoch_times and torch.cuda.is_available():
+                    marks.append(torch.cuda.Event(enable_timing=True))
+                    marks[-1].record()
                 if epoch % 10 == 0:
                     model.eval()
                     with torch.no_grad():
@@ -376,7 +395,7 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
                         keys.append(key := f"epoch{epoch}")
                         Q[key] = self.q
                 model.train()
-                x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model._forward(data, adj, True)
+                x_bar, q, pred, _, meanbatch, dispbatch, pibatch, zinb_loss = model._forward(data, adj, "fused" if self.fuse_zinb_heads else True)
                 if sharded:  # this rank's share of the global means: local sum / global count
                     loss = (bcl * F.binary_cross_entropy(q, p, reduction="sum") / (n_all * q.shape[1])
                             + cl * F.kl_div(pred.log(), p, reduction="sum") / n_all
@@ -395,6 +414,11 @@ class ScDSC(TorchNNPretrain, BaseClusteringMethod):
                     allreduce_sum_gradients(others, sg.group)
                 optimizer.step()
                 self.last_loss = allsum(loss.detach())
+            if marks:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
+                marks[-1].synchronize()
+                self.epoch_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
         finally:
             model.ae.rows_total, model.ae.group = None, None
             model.ae._cache = None  # the kept autoencoder outputs (14 GB at 1M cells) are the fit's, not the model's

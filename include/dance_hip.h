@@ -193,6 +193,12 @@ DH_API int dh_gemm_f32x3(int64_t M, int64_t N, int64_t K, int trans_a, int trans
                   const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate, void* workspace,
                   size_t workspace_bytes, dh_stream_t stream);
 
+/* out = a X + b Y (Y == NULL: out = a X), fp32, both products and the sum rounded separately: scDSC's mixing of the GCN and autoencoder
+ * streams, `(1 - sigma) * h + sigma * tra` (scdsc.py:454-460), is three torch kernels and two temporaries per layer (28 B per element
+ * instead of 12; 8.7 ms of a 190 ms epoch at 1M cells), its backward `(1 - sigma) * g`.                                              */
+DH_API int dh_axpby_f32(int64_t n_rows, int64_t width, float a, const float* X, int64_t ldx, float b, const float* Y, int64_t ldy, float* out,
+                 int64_t ldo, dh_stream_t stream);
+
 /* ---- elementwise / reductions used by the layers' backward ---------------------------------
  * dh_relu_backward_f32: G = dY where Y > 0 else 0 (autograd of F.relu, scdsc.py:499-500).
  * dh_colsum_f32: out[j] = sum_i X[i,j] (bias gradient of spagcn.py:360-361); deterministic
@@ -684,6 +690,18 @@ DH_API int dh_zinb_nll_logits_backward_f32(int64_t n, int64_t n_genes, const flo
                                     const float* disp_raw, int64_t ldd, const float* pi_raw, int64_t ldp, const double* scale_factor,
                                     double ridge_lambda, const double* upstream, float* d_mean_raw, float* d_disp_raw, float* d_pi_raw,
                                     int64_t ldo, dh_stream_t stream);
+
+/* scDSC's joint loop (scdsc.py:265-283) evaluates this loss and its gradient on the same operands back to back, and the three heads'
+ * bias gradients are the gradients' column sums: ONE pass instead of three (forward 32 GB + backward 56 GB + column sums 24 GB at
+ * 1M x 2000).  On return mean_raw / disp_raw / pi_raw (leading dimension ld) hold unit * d(sum of element losses) / d(raw output) —
+ * `unit` is the caller's constant (1 / (N G) for the mean), the run-time upstream scalar is folded by the caller into the heads' dW / db
+ * — loss_partials[n_loss] the float64 partial sums of the element losses (sum them in index order) and col_partials
+ * [n_row_blocks][3][n_genes] the per-row-block column sums of the three gradients (dh_colsum_f32 over the [n_row_blocks, 3 n_genes]
+ * matrix gives d bias).  dh_zinb_heads_fused_partials returns the two counts (host arithmetic).                                   */
+DH_API int dh_zinb_heads_fused_partials(int64_t n, int64_t n_genes, int64_t* n_loss, int64_t* n_row_blocks);
+DH_API int dh_zinb_heads_fused_f32(int64_t n, int64_t n_genes, const float* X, int64_t ldx, float* mean_raw, float* disp_raw, float* pi_raw,
+                            int64_t ld, const double* scale_factor, double ridge_lambda, double unit, double* loss_partials,
+                            float* col_partials, dh_stream_t stream);
 
 /* ---- multi-GPU: RCCL over xGMI, one process per GPU ------------------------------------------------
  * The reference has no multi-GPU path for these models; the sharded layer replaces the single-process torch.spmm / autograd

@@ -50,5 +50,39 @@ for name, lam_hi, keep in (("poisson(U(0,2)) 57% non-zero", 2.0, 1.0), ("10% non
                      nonzero_frac=round(float((xr[:ns] > 0).float().mean()), 3), loss_rel_err=abs(float(got) - float(ref)) / abs(float(ref)),
                      grad_rel_err=dict(mean=rel(gm, rm), disp=rel(gd, rd), pi=rel(gp, rp)),
                      hbm_frac=round(n * gz * 44.0 / (a.elapsed_time(b) / 3) / 1e6 / 8000, 3))
-    del xr, mean, disp, pi
+    # the heads' one-pass form on RAW outputs (dh_zinb_heads_fused_f32) next to the logits kernels + the three column sums it replaces
+    raws = [torch.randn(n, gz, device=dev, generator=g) for _ in range(3)]
+    up = torch.tensor([1.0 / (n * gz)], dtype=torch.float64, device=dev)
+
+    def three_pass():
+        kernels.zinb_nll_forward(xr, *raws, sf, 0.0, logits=True)
+        for d in kernels.zinb_nll_backward(xr, *raws, sf, 0.0, up, logits=True):
+            kernels.colsum(d)
+
+    def timed(fn, it=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(it):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / it
+
+    t3 = timed(three_pass)
+    scratch = [r.clone() for r in raws]
+
+    def fused():  # in place: from the second call on the operands are gradients — same shapes, same traffic, other values
+        kernels.zinb_heads_fused_(xr, *scratch, sf, 0.0, 1.0 / (n * gz))
+
+    for dst, src in zip(scratch, raws):
+        dst.copy_(src)
+    with kernels.KernelTimer() as tm2:
+        fused()
+        torch.cuda.synchronize()
+    out[name]["logits_three_pass_ms"] = round(t3, 2)
+    out[name]["heads_fused_first_call_kernels_ms"] = {k: round(v[1], 2) for k, v in tm2.summary().items()}
+    out[name]["heads_fused_hbm_frac"] = round(n * gz * 28.0 / tm2.summary()["zinb_heads_fused_f32"][1] / 1e6 / 8000, 3)
+    del xr, mean, disp, pi, raws, scratch
 print(json.dumps(out, indent=1))

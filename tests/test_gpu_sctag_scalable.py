@@ -115,6 +115,115 @@ def test_zinb_nll_from_logits_equals_torch_activations_then_loss(cuda_device):
         assert torch.equal(one, kernels.zinb_nll_forward(x, am.detach(), ad.detach(), ap.detach(), sf, ridge, logits=True))
 
 
+def _heads_case(n, g, h, dev, with_sf=True):
+    x = torch.poisson(torch.rand(n, g, device=dev) * 2.5) * (torch.rand(n, g, device=dev) < 0.3)
+    x[:, :5] *= 40
+    hid = torch.randn(n, h, device=dev)
+    heads = [torch.nn.Linear(h, g).to(dev) for _ in range(3)]
+    with torch.no_grad():
+        for i, L in enumerate(heads):
+            L.weight.mul_(2.0 + i)
+            L.bias.normal_(0, 1.0)
+        heads[0].bias[9], heads[0].bias[10] = -60.0, 60.0   # beyond MeanAct's clamp on most rows
+        heads[1].bias[11], heads[1].bias[12] = -60.0, 60.0
+    sf = (torch.rand(n, device=dev, dtype=torch.float64) + 0.5) if with_sf else None
+    return x, hid, heads, sf
+
+
+@pytest.mark.parametrize("n,g,h,ridge,with_sf", [(64, 256, 16, 0.0, True), (257, 2000, 32, 0.5, True), (1000, 333, 8, 0.0, False), (130, 37, 8, 0.0, True),
+                                                  (63, 1028, 8, 0.0, True)])
+def test_zinb_heads_fused_equals_the_three_pass_form(cuda_device, n, g, h, ridge, with_sf):
+    """dh_zinb_heads_fused_f32 (heads' loss + gradients over the raw outputs + bias column sums in one pass) against three HipLinear +
+    zinb_nll_from_logits (dh_zinb_nll_logits_forward / _backward + dh_colsum_f32): the element arithmetic is the same code, so the
+    raw-output gradients are BIT-identical for the same upstream constant; the loss differs by its summation order (the x = 0 terms: fp32
+    groups of four there, float64 here: 1e-7);
+    dW / db / dh by the order of the upstream scalar (applied to the small results instead of N x G elements: 1e-6).  Shapes: whole
+    and partial 256-gene windows, a row count that is no multiple of 64, gene counts that rule the 16-byte path out (333, 37)."""
+    from dance_amd import autograd, kernels
+    torch.manual_seed(5)
+    x, hid, heads, sf = _heads_case(n, g, h, cuda_device, with_sf)
+    # the kernel alone on raw outputs
+    raws = [kernels.gemm(hid, L.weight.detach(), trans_b=True, bias=L.bias.detach()) for L in heads]
+    unit = 1.0 / (n * g)
+    up = torch.tensor([unit], dtype=torch.float64, device=cuda_device)
+    want_loss = kernels.zinb_nll_forward(x, *raws, sf, ridge, logits=True).sum()
+    want = kernels.zinb_nll_backward(x, *raws, sf, ridge, up, logits=True)
+    got = [r.clone() for r in raws]
+    total, db = kernels.zinb_heads_fused_(x, *got, sf, ridge, unit)
+    assert abs(float(total) - float(want_loss)) <= 1e-7 * abs(float(want_loss))  # the three-pass kernel adds its x = 0 terms in fp32 groups of four
+    for a, b, nm in zip(got, want, ("mean", "disp", "pi")):
+        assert torch.equal(a, b), (nm, float((a - b).abs().max()))
+    want_db = torch.stack([w.double().sum(0) for w in want])
+    assert float((db.double() - want_db).abs().max()) <= 2e-6 * float(want_db.abs().max())
+    again = [r.clone() for r in raws]
+    total2, db2 = kernels.zinb_heads_fused_(x, *again, sf, ridge, unit)
+    assert torch.equal(total, total2) and torch.equal(db, db2) and all(torch.equal(a, b) for a, b in zip(got, again))  # run to run
+    # the autograd function against the three-pass composition, with an upstream factor and a gradient for the hidden matrix
+    hid_a = hid.clone().requires_grad_(True)
+    loss_a = autograd.zinb_heads_loss(hid_a, heads, x, sf, ridge)
+    assert loss_a.dtype == torch.float64
+    params = [p for L in heads for p in (L.weight, L.bias)]
+    ga = torch.autograd.grad(loss_a * 0.7, [hid_a, *params])
+    hid_b = hid.clone().requires_grad_(True)
+    outs = [autograd.linear(hid_b, L.weight, L.bias) for L in heads]
+    loss_b = autograd.zinb_nll_from_logits(x, *outs, sf, ridge)
+    gb = torch.autograd.grad(loss_b * 0.7, [hid_b, *params])
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-7 * abs(float(loss_b))
+    for a, b in zip(ga, gb):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+
+
+def test_mix_equals_the_torch_expression_bit_for_bit(cuda_device):
+    """dh_axpby_f32 behind autograd.mix: (1 - sigma) * h + sigma * t of scdsc.py:454-459 in one pass == the three torch kernels (each
+    product rounded, then the sum), gradients a * g / b * g; 16-byte path and the element path (odd width, a column slice)."""
+    from dance_amd import autograd
+    torch.manual_seed(3)
+    for n, w, sl in ((1000, 256, None), (257, 33, None), (64, 40, slice(4, 37))):
+        for sigma in (0.5, 0.3, 1.0):
+            h = torch.randn(n, w, device=cuda_device)
+            t = torch.randn(n, w, device=cuda_device)
+            if sl is not None:
+                h, t = h[:, sl], t[:, sl]
+            h1, t1 = h.detach().clone().requires_grad_(True), t.detach().clone().requires_grad_(True)
+            h2, t2 = h.detach().clone().requires_grad_(True), t.detach().clone().requires_grad_(True)
+            if sl is not None:
+                got = autograd.mix(h1 * 1.0, t1 * 1.0, 1 - sigma, sigma)
+            else:
+                got = autograd.mix(h1, t1, 1 - sigma, sigma)
+            want = (1 - sigma) * h2 + sigma * t2
+            assert torch.equal(got, want)
+            g = torch.randn_like(want)
+            got.backward(g)
+            want.backward(g)
+            assert torch.equal(h1.grad, h2.grad) and torch.equal(t1.grad, t2.grad)
+
+
+def test_scdsc_fit_fused_heads_equals_unfused(cuda_device, tmp_path):
+    """ScDSC.fit with ``fuse_zinb_heads`` on and off: the same soft assignments and the same last loss within fp32 rounding of the
+    heads' gradients."""
+    import numpy as np
+    from dance_amd.modules.single_modality.clustering.scdsc import ScDSC
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    n, g, k = 600, 96, 6
+    x_raw = rng.poisson(rng.random((n, g)) * 2.0).astype(np.float32)
+    x = np.log1p(x_raw / np.maximum(x_raw.sum(1, keepdims=True), 1) * 1e3).astype(np.float32)
+    nbr = rng.integers(0, n, (n, k))
+    adj = sp.csr_matrix((np.full(n * k, 1.0 / k, np.float32), (np.repeat(np.arange(n), k), nbr.ravel())), shape=(n, n))
+    y = rng.integers(0, 4, n)
+    res = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        m = ScDSC(pretrain_path=str(tmp_path / f"ae{int(fused)}.pt"), n_enc_1=32, n_enc_2=16, n_enc_3=16, n_dec_1=16, n_dec_2=16, n_dec_3=32, n_z1=16, n_z2=8, n_z3=4, n_clusters=4,
+                  n_input=g, device=str(cuda_device))
+        m.fuse_zinb_heads = fused
+        m.fit((adj, x, x_raw, x_raw.sum(1).astype(np.float64) + 1.0), y, lr=1e-3, epochs=4, pt_epochs=2, pt_batch_size=64)
+        res[fused] = (m.predict_proba(), float(m.last_loss))
+    assert np.allclose(res[True][0], res[False][0], rtol=1e-4, atol=1e-6)
+    assert abs(res[True][1] - res[False][1]) <= 1e-5 * abs(res[False][1])
+
+
 def test_sctag_scalable_fit_on_device(cuda_device):
     """ScTAG(adj_dim=32) on 6000 cells with a sparse kNN-like adjacency: forward loss == dense formula, pretrain + fit run."""
     from dance_amd.modules.single_modality.clustering.sctag import ScTAG
