@@ -53,13 +53,16 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 #ifdef DH_SB_PROF  // development build: a cycle-stamped timeline (s_memtime) of every wave of ONE workgroup over a few steps
-constexpr int TL_BLOCK = 3000, TL_J0 = 40, TL_STEPS = 6, TL_PROBES = 8;
+constexpr int TL_BLOCK = 3000, TL_J0 = 40, TL_STEPS = 6, TL_PROBES = 6;
 __device__ unsigned long long dh_sb_timeline[8][TL_STEPS][TL_PROBES];
 #define TLP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); tl[k] = t_; } while (0)
 #else
 #define TLP(k)
 #endif
 #define PROF_T(x)
+#ifndef DH_SB_SETPRIO
+#define DH_SB_SETPRIO 1
+#endif
 #define PROF_ADD(i, a, b)
 
 constexpr int JC = 2;                      // MFMA steps per chunk (32 window genes)
@@ -472,26 +475,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   };
   // this lane's entries of chunk c (in `ent`) -> A buffer c & 1 (cleared one step earlier): a = w * colscale[gene] split into bf16
   // hi + lo (the residual 2^-18 |a|), two 2-byte stores each
-  // round 6: the scatter sat on the step's critical path for ~870 cycles (timeline probes 6 / 7: its entries had arrived, the time was
-  // its own): each of the lane's two entries went through its own exec-masked block — scale look-up in LDS, a full lgkmcnt(0) wait,
-  // two bf16 conversions compiled as branches around their NaN case, two stores — one after the other.  Now both look-ups are issued
-  // together (clamped index: valid for every lane), the arithmetic is branch-free for both entries, and only the stores are predicated.
+  // round 6: each of the lane's two entries went through its own exec-masked block — scale look-up in LDS, a full lgkmcnt(0) wait, two
+  // bf16 conversions compiled as branches around their NaN case, two stores — one after the other.  Now both look-ups are issued
+  // together (clamped index: valid for every lane), the conversions are selects, and only the stores are predicated: 3.66 -> 3.55 ms
+  // bf16, 5.11 -> 5.02 fp32 (A/B on one box).  Two further re-orderings were built and measured and are NOT here: the leading group's
+  // scatter at the START of its step (under the partner's MFMA burst) and the scatter split into a request half in front of the wave's
+  // MFMAs and a store half behind them, entries requested two steps ahead — both 0 % (fp32) / +4 % (bf16) against this form: with the
+  // probes' own lgkmcnt waits removed, the scatter is not what the step waits for.
   auto bf16_rne = [](float x) __attribute__((always_inline)) {  // f32_to_bf16 as a select (same bits)
     const unsigned int u = __float_as_uint(x);
     const unsigned int rounded = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16, quiet = (u >> 16) | 0x40u;
     return (u & 0x7fffffffu) > 0x7f800000u ? quiet : rounded;
   };
-  // The scatter in two halves, so that its LDS round trips (250 - 300 cycles each with eight waves' fragment reads in the queue) overlap
-  // other work instead of following each other: `scatter_issue` requests the chunk's pointer pair and the two column scales (the
-  // addresses depend on the entries only, not on the list length), `scatter_finish` multiplies, splits and stores.
-  float sc_pend[2] = {1.f, 1.f};
-  int sc_first = 0, sc_len = 0;
-  auto scatter_issue = [&](int c) __attribute__((always_inline)) {
-    sc_first = cptr[grp * cptr_stride + ci(c)];
-    sc_len = cptr[grp * cptr_stride + ci(c) + 1] - sc_first;
+  auto put2 = [&](uint16_t* img, int c, const u32x2 (&en)[2], bool ok0, bool ok1) __attribute__((always_inline)) {
+    float a[2] = {__uint_as_float(en[0][1]), __uint_as_float(en[1][1])};
     if (!SPLITK) {
+      float sc[2];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) sc_pend[q] = cs[min(32 * c + (int)(ent[q][0] >> 9) * 8 + (int)(ent[q][0] & 7), wn - 1)];
+      for (int q = 0; q < 2; ++q) sc[q] = cs[min(32 * c + (int)(en[q][0] >> 9) * 8 + (int)(en[q][0] & 7), wn - 1)];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a[q] *= sc[q];
+    }
+    unsigned int ahi[2], alo[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      ahi[q] = bf16_rne(a[q]);
+      alo[q] = bf16_rne(a[q] - widen(ahi[q]));
+    }
+    if (ok0) {
+      img[en[0][0]] = (uint16_t)ahi[0];
+      img[en[0][0] + PLANE] = (uint16_t)alo[0];
+    }
+    if (ok1) {
+      img[en[1][0]] = (uint16_t)ahi[1];
+      img[en[1][0] + PLANE] = (uint16_t)alo[1];
     }
   };
   auto put = [&](uint16_t* img, int c, u32x2 en) __attribute__((always_inline)) {  // the rare rounds beyond 256 entries
@@ -502,32 +519,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     img[en[0]] = (uint16_t)ahi;
     img[en[0] + PLANE] = (uint16_t)alo;
   };
-  auto scatter_finish = [&](int c) __attribute__((always_inline)) {
-    uint16_t* const img = a_img + (size_t)((c & 1) * 2 + grp) * IMG;
-    // (lanes beyond the list hold a neighbour's entry: a valid offset and a finite weight, computed and dropped)
-    unsigned int ahi[2], alo[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      float a = __uint_as_float(ent[q][1]);
-      if (!SPLITK) a *= sc_pend[q];
-      ahi[q] = bf16_rne(a);
-      alo[q] = bf16_rne(a - widen(ahi[q]));
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      if (eli + 128 * q < sc_len) {
-        img[ent[q][0]] = (uint16_t)ahi[q];
-        img[ent[q][0] + PLANE] = (uint16_t)alo[q];
-      }
-    // a group with more than 256 entries in one chunk (mean 205 at 10 % density, ~4 sigma): the rest in rounds, loaded on the spot
-    for (int rnd = 256; __builtin_expect(rnd < sc_len, 0); rnd += 128) {
-      const u32x2 en = pent[min((int64_t)sc_first + rnd + eli, nnz - 1)];
-      if (rnd + eli < sc_len) put(img, c, en);
-    }
-  };
   auto scatter = [&](int c) __attribute__((always_inline)) {
-    scatter_issue(c);
-    scatter_finish(c);
+    uint16_t* const img = a_img + (size_t)((c & 1) * 2 + grp) * IMG;
+    const int first = cptr[grp * cptr_stride + ci(c)];
+    const int len = cptr[grp * cptr_stride + ci(c) + 1] - first;
+    // (lanes beyond the list hold a neighbour's entry: a valid offset and a finite weight, computed and dropped)
+    put2(img, c, ent, eli < len, eli + 128 < len);
+    // a group with more than 256 entries in one chunk (mean 205 at 10 % density, ~4 sigma): the rest in rounds, loaded on the spot
+    for (int rnd = 256; __builtin_expect(rnd < len, 0); rnd += 128) {
+      const u32x2 en = pent[min((int64_t)first + rnd + eli, nnz - 1)];
+      if (rnd + eli < len) put(img, c, en);
+    }
   };
   auto clear = [&](int c) __attribute__((always_inline)) {  // the group's 256 lanes zero the 8 KB of buffer c & 1
     u32x4* const z = reinterpret_cast<u32x4*>(a_img + (size_t)((c & 1) * 2 + grp) * IMG);
@@ -586,6 +588,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the MFMAs of step j; tile 0's fragments (and the A fragments) are already in registers.  `hook(y)` runs after tile y's MFMAs
     // are issued (the leading group's entry waves put their entry request behind tile 0)
     auto mma = [&](int j, auto&& hook) __attribute__((always_inline)) {
+      // the wave inside its MFMA block goes ahead of its SIMD partner's bookkeeping (scatter arithmetic, LDS traffic) at issue:
+      // 4.87 -> 4.76 ms fp32 with priority 1 (3: 4.79; bf16 unchanged), A/B builds on one box, round 6
+      __builtin_amdgcn_s_setprio(DH_SB_SETPRIO);
       static_for<MT>([&](auto y_c) __attribute__((always_inline)) {
         constexpr int y = decltype(y_c)::value;
         if constexpr (y + 1 < MT) read_fb(j, y + 1, (y + 1) & 1);
@@ -595,6 +600,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         hook(y_c);
         __builtin_amdgcn_sched_barrier(0);
       });
+      __builtin_amdgcn_s_setprio(0);
     };
     // One step.  PAR = its parity (selects the bookkeeping role), FULL = steady state: every block / chunk it touches exists, so all
     // of its loads and stores are unconditional.
@@ -611,19 +617,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr bool FULL = decltype(full_c)::value != 0;
       constexpr bool FILL = LAG == (PAR == 1);  // the step that scatters: lagging group odd, leading group even
 #ifdef DH_SB_PROF
-      unsigned long long tl[TL_PROBES] = {0, 0, 0, 0, 0, 0, 0, 0};
+      unsigned long long tl[TL_PROBES] = {0, 0, 0, 0, 0, 0};
 #endif
       const int c = j / JC;
-      // Entries (round 6): a wave requests chunk c + 2 right AFTER it has scattered chunk c + 1 (two steps of flight: they have always
-      // arrived when the next scatter starts — probes 6 / 7 of the timeline), and the scatter no longer trails the step:
-      //   both groups, in their scatter step: pointer pair + column scales requested FIRST THING (an LDS round trip is 350 - 400 cycles
-      //     with eight waves' fragment reads in the queue), the wave's MFMAs next, then the split and the stores next to the fragment
-      //     reads of the next step: one round trip (the stores', shared with those reads) between the MFMAs and the barrier, not three.
-      // (Before: both groups scattered last thing before the barrier, look-up -> wait -> convert -> store per entry, ~870 cycles with
-      // the matrix pipe idle for the last ~500 of them.)
-      constexpr bool SCAT = FILL;
-      const bool scat_live = SCAT && !mover && (FULL || c + 1 < n_chunks);
-      const bool req_live = FULL || c + 2 < n_chunks;
+      // the entry request of the step after a scatter: the lagging group scatters chunk k at the end of step 2k - 1, the leading
+      // group at the end of step 2k - 2; the request for chunk k + 1 follows one step later (step 2k: c + 1, resp. step 2k - 1: c + 2)
+      auto request = [&]() __attribute__((always_inline)) {
+        if (!mover && !FILL) {
+          if (LAG) {
+            if (FULL || c + 1 < n_chunks) ent_load(c + 1);
+          } else if (FULL || c + 2 < n_chunks) ent_load(c + 2);
+        }
+      };
+      auto lead_hook = [&](auto y_c) __attribute__((always_inline)) {
+        if constexpr (decltype(y_c)::value == 0) request();
+      };
       TLP(0);  // after the barrier
       if (!LAG && mover) {
         if (FULL || j + 1 < J) b_store(j + 1);  // loaded at the start of step j - 1 (block 1: in the prologue)
@@ -631,15 +639,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (FULL || j + 2 < J) b_load(j + 2);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (scat_live) {  // pointer pair + scales requested now (the entries arrived a step ago), used behind this wave's MFMAs
-        TLP(6);
-        scatter_issue(c + 1);
-      }
       if (LAG && (FULL || j > 0)) {  // step j - 1: its A fragments and its first tile's B fragments were read before the barrier
         __builtin_amdgcn_sched_barrier(0);
         mma(j - 1, [](auto) {});
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (LAG) request();
       TLP(1);  // lagging group: its MFMAs are issued
       __builtin_amdgcn_sched_barrier(0);
       if (!FILL) {
@@ -653,28 +658,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (LAG) {
           read_a(j);
           read_fb(j, 0, 0);
-          if (scat_live) {
-            scatter_finish(c + 1);
-            TLP(7);
-            if (req_live) ent_load(c + 2);
-          }
         } else {
           read_fb(j, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           TLP(3);  // leading group: first B fragments in registers
-          mma(j, [](auto) {});
+          mma(j, lead_hook);
           TLP(4);  // leading group: its MFMAs are issued
           if (FULL || j + 1 < J) read_a(j + 1);
-          if (scat_live) {
-            scatter_finish(c + 1);
-            TLP(7);
-            if (req_live) ent_load(c + 2);
-          }
         }
-      } else if (scat_live) {
-        scatter_finish(c + 1);
-        if (req_live) ent_load(c + 2);
-      }
+      } else if (!LAG) request();
+      __builtin_amdgcn_sched_barrier(0);
+      if (FILL && !mover && (FULL || c + 1 < n_chunks)) scatter(c + 1);  // requested in the previous step
       __builtin_amdgcn_sched_barrier(0);  // (the scheduler otherwise hoists the loads below above the MFMA block: their registers would be live across it)
       if (LAG && mover) {
         if (FULL || j + 1 < J) b_store(j + 1);  // loaded at the end of step j - 1 (block 1: in the prologue)

@@ -28,7 +28,7 @@ alpha = torch.rand(n_genes + 2, device=dev, generator=g) + 0.5
 lib = _lib.load()
 fn = lib.dh_sage_bcm_prof_read
 fn.argtypes, fn.restype = [ctypes.c_void_p, ctypes.c_int], ctypes.c_int
-STEPS, PROBES = 6, 8
+STEPS, PROBES = 6, 6
 for dt in ("f32", "bf16"):
     h = feats if dt == "f32" else feats.to(torch.bfloat16)
     args = (rowptr, col, w, cid, cid[n_genes:].contiguous(), alpha, h)
