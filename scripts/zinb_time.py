@@ -9,6 +9,9 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import cpu_ops  # noqa: E402
+from dance_amd import _lib  # noqa: E402
+if os.environ.get("VARIANT"):  # A/B builds: dance_amd/libdancehip_<VARIANT>.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libdancehip_{os.environ['VARIANT']}.so")
 from dance_amd import autograd, kernels  # noqa: E402
 
 dev = "cuda"
