@@ -360,7 +360,9 @@ Plan make_plan(int64_t n_r, int64_t n, int64_t d) {  // n_r rows i against n col
   p.i_blocks = (int)dh::ceil_div(n_r, BI);
   p.n_pad = p.i_blocks * BI;
   const int64_t j_tiles = dh::ceil_div(n, BJ);
-  int64_t want = dh::ceil_div(512, p.i_blocks);  // two workgroups per CU
+  // one workgroup per CU (the kernel runs ONE wave per SIMD: two never share a CU); until round 6 this asked for 512 workgroups, i.e. two
+  // rounds of half-length j ranges with twice the prologues, partial outputs and reduce traffic: 0.822 -> 0.80 ms at 8192 x 300
+  int64_t want = dh::ceil_div(256, p.i_blocks);
   if (want > j_tiles) want = j_tiles;
   if (want < 1) want = 1;
   p.j_per_split = (int)(dh::ceil_div(j_tiles, want) * BJ);
