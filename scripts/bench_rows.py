@@ -344,7 +344,34 @@ def main():
     rows[f"ZINB NLL on the heads' raw outputs fwd+bwd (dh_zinb_nll_logits_*) cells={nz} genes={gz}"] = dict(
         ms=ms_l, bound="hbm", achieved=zb / ms_l / 1e6, peak=HBM, unit="GB/s", frac=zb / ms_l / 1e6 / HBM, torch_activations_around_the_loss_kernels_ms=ms_t,
         note="same bytes as the row above (16 forward + 28 backward per element); the activations' 17 elementwise passes are gone")
-    del am, ad, ap
+    # round 6: loss + gradients (in place over the raw outputs) + the three bias column sums in one pass (dh_zinb_heads_fused_f32), against the
+    # two logits kernels + three dh_colsum_f32 passes it replaces in ScDSC.fit
+    raws = [t.detach().clone() for t in (am, ad, ap)]
+    scratch = [r.clone() for r in raws]
+    up = torch.tensor([1.0 / (nz * gz)], dtype=torch.float64, device=dev)
+
+    def heads_three_pass():
+        kernels.zinb_nll_forward(xr, *raws, sf, 0.0, logits=True)
+        for dgrad in kernels.zinb_nll_backward(xr, *raws, sf, 0.0, up, logits=True):
+            kernels.colsum(dgrad)
+
+    def heads_fused():  # in place: restore the operands first (an 8 GB x 3 copy, outside the timed kernel: KernelTimer reads the kernel's own events)
+        for dst, src in zip(scratch, raws):
+            dst.copy_(src)
+        kernels.zinb_heads_fused_(xr, *scratch, sf, 0.0, 1.0 / (nz * gz))
+
+    ms_3 = gpu_ms(heads_three_pass, iters=3, warm=1)
+    heads_fused()
+    with kernels.KernelTimer() as tmf:
+        for _ in range(3):
+            heads_fused()
+        torch.cuda.synchronize()
+    ms_f = tmf.summary()["zinb_heads_fused_f32"][1] / 3
+    hb = nz * gz * 28.0  # 4 x 4 bytes read + 3 x 4 written per element
+    rows[f"ZINB heads: loss + gradients + bias sums in ONE pass (dh_zinb_heads_fused_f32) cells={nz} genes={gz}"] = dict(
+        ms=ms_f, bound="hbm", achieved=hb / ms_f / 1e6, peak=HBM, unit="GB/s", frac=hb / ms_f / 1e6 / HBM, three_pass_ms=ms_3,
+        note="28 bytes per element (x, three raw outputs read; three gradients written over them); three_pass_ms = dh_zinb_nll_logits_forward + _backward + 3 x dh_colsum_f32 on the same operands")
+    del am, ad, ap, raws, scratch
     ns = 20_000 if q else 100_000  # the unfused torch formula (float64 temporaries) on a sample
     sl = slice(0, ns)
     import sys as _sys
