@@ -440,6 +440,9 @@ class GraphSC(BaseClusteringMethod):
     # Captured steps as two graphs with the gradient all-reduce between them (the form used with more than one process); True forces
     # it on one process too (tests)
     capture_split = False
+    # measurement aid (scripts/bench_configs.py): True -> ``epoch_ms`` holds the device time between the epoch boundaries of the last fit
+    # (the last epoch also carries the embedding's gather and copy to the host)
+    record_epoch_times = False
 
     def __init__(self, agg: str = "sum", activation: str = "relu", in_feats: int = 50, n_hidden: int = 1, hidden_dim: int = 200,
                  hidden_1: int = 300, hidden_2: int = 0, dropout: float = 0.1, n_layers: int = 1, hidden_relu: bool = False,
@@ -526,7 +529,11 @@ class GraphSC(BaseClusteringMethod):
         use_graph = use_graph and not use_mini and not use_agg
         self.step_mode = "ministep" if use_mini else "aggfirst" if use_agg else "hipgraph" if use_graph else "eager"
         self.losses, aris, Z = [], [], {}
+        marks = []
         for epoch in range(epochs):
+            if self.record_epoch_times and torch.cuda.is_available():  # measurement aid: see the class attribute
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             self.model.train()
             z, order, losses = [], [], []
             if use_mini:
@@ -657,6 +664,11 @@ class GraphSC(BaseClusteringMethod):
             if eval_epoch and y is not None:
                 aris.append(self.score(None, y))
                 Z[f"epoch{epoch}"] = self.z
+        if marks:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
+            marks[-1].synchronize()
+            self.epoch_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
         if eval_epoch and aris:
             self.z = Z[f"epoch{int(np.argmax(aris))}"]
 
