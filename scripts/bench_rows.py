@@ -366,7 +366,7 @@ def main():
         for _ in range(3):
             heads_fused()
         torch.cuda.synchronize()
-    ms_f = tmf.summary()["zinb_heads_fused_f32"][1] / 3
+    ms_f = tmf.summary()["zinb_heads_fused_f32"][1]  # (launches, mean ms)
     hb = nz * gz * 28.0  # 4 x 4 bytes read + 3 x 4 written per element
     rows[f"ZINB heads: loss + gradients + bias sums in ONE pass (dh_zinb_heads_fused_f32) cells={nz} genes={gz}"] = dict(
         ms=ms_f, bound="hbm", achieved=hb / ms_f / 1e6, peak=HBM, unit="GB/s", frac=hb / ms_f / 1e6 / HBM, three_pass_ms=ms_3,
