@@ -129,6 +129,9 @@ def search_l(p, adj, start=0.01, end=1000, tol=0.01, max_run=100, device="cuda")
 class SimpleGCDEC(nn.Module):
     """Basic model used in SpaGCN training (spagcn.py:369-584): GraphConvolution + DEC clustering head."""
 
+    # measurement aid (scripts/bench_configs.py): True -> ``epoch_ms`` holds the device time of every iteration of the last fit_with_init
+    record_epoch_times = False
+
     def __init__(self, nfeat, nhid, alpha=0.2, device="cuda"):
         super().__init__()
         self.gc = GraphConvolution(nfeat, nhid)
@@ -280,7 +283,11 @@ class SimpleGCDEC(nn.Module):
             self.mu = Parameter(torch.empty(self.n_clusters, self.nhid, device=self.device))
         self.mu.data.copy_(centers)
         self.train()
+        marks = []
         for epoch in range(epochs):
+            if self.record_epoch_times and torch.cuda.is_available():  # measurement aid: see the class attribute
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             fwd = None
             if epoch % update_interval == 0:
                 # the reference runs the forward twice here — once for the target (:512-514), once for the loss (:516) — with nothing
@@ -292,6 +299,11 @@ class SimpleGCDEC(nn.Module):
             loss = self.loss_function(p, q)
             loss.backward()
             _step(optimizer)
+        if marks:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
+            marks[-1].synchronize()
+            self.epoch_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
 
     @torch.no_grad()
     def predict(self, X, adj):
