@@ -173,6 +173,36 @@ def test_zinb_heads_fused_equals_the_three_pass_form(cuda_device, n, g, h, ridge
         assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
 
 
+def test_zinb_heads_fused_edge_cases(cuda_device):
+    """Empty inputs return zeros without a launch; mismatched leading dimensions and CPU tensors are refused; the three-dimensional /
+    non-fp32 fall-back of ``autograd.mix`` is the torch expression."""
+    from dance_amd import _lib, autograd, kernels
+    x = torch.zeros(0, 8, device=cuda_device)
+    r = [torch.zeros(0, 8, device=cuda_device) for _ in range(3)]
+    total, db = kernels.zinb_heads_fused_(x, *r, None, 0.0, 1.0)
+    assert float(total) == 0.0 and db.shape == (3, 8) and float(db.abs().sum()) == 0.0
+    x = torch.ones(4, 8, device=cuda_device)
+    wide = torch.zeros(4, 16, device=cuda_device)
+    with pytest.raises(ValueError):
+        kernels.zinb_heads_fused_(x, wide[:, :8], torch.zeros(4, 8, device=cuda_device), torch.zeros(4, 8, device=cuda_device), None, 0.0, 1.0)
+    with pytest.raises(_lib.DanceHipError):
+        kernels.zinb_heads_fused_(x.cpu(), *(torch.zeros(4, 8) for _ in range(3)), None, 0.0, 1.0)
+    a, b = torch.randn(3, 4, 5, device=cuda_device), torch.randn(3, 4, 5, device=cuda_device)
+    assert torch.equal(autograd.mix(a, b, 0.25, 0.75), 0.25 * a + 0.75 * b)
+    # one row, one gene; a single window with a ragged tail; every count non-zero; every count zero
+    for n, g, dens in ((1, 1, 0.5), (70, 260, 1.0), (70, 260, 0.0)):
+        xx = (torch.poisson(torch.rand(n, g, device=cuda_device) * 3) + 1.0) * (torch.rand(n, g, device=cuda_device) < dens)
+        raws = [torch.randn(n, g, device=cuda_device) for _ in range(3)]
+        unit = 1.0 / (n * g)
+        up = torch.tensor([unit], dtype=torch.float64, device=cuda_device)
+        want = kernels.zinb_nll_backward(xx, *raws, None, 0.0, up, logits=True)
+        want_loss = kernels.zinb_nll_forward(xx, *raws, None, 0.0, logits=True).sum()
+        got = [t.clone() for t in raws]
+        total, db = kernels.zinb_heads_fused_(xx, *got, None, 0.0, unit)
+        assert all(torch.equal(p, q) for p, q in zip(got, want)), (n, g, dens)
+        assert abs(float(total) - float(want_loss)) <= 1e-7 * abs(float(want_loss)) + 1e-12
+
+
 def test_mix_equals_the_torch_expression_bit_for_bit(cuda_device):
     """dh_axpby_f32 behind autograd.mix: (1 - sigma) * h + sigma * t of scdsc.py:454-459 in one pass == the three torch kernels (each
     product rounded, then the sum), gradients a * g / b * g; 16-byte path and the element path (odd width, a column slice)."""
