@@ -256,7 +256,76 @@ __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64
       for (int g = threadIdx.x; g < a.G; g += 256) hist[g] = 0;
       __syncthreads();
     }
-    for (int i = blockIdx.x * 4 + wave; i < a.B; i += LDS_HIST ? nb_count * 4 : a.B) {
+    if (LDS_HIST) {
+      // Thousands of seeds over a few resident workgroups (their LDS histograms are what keeps 1.6 M atomics off the L2): a wave owns the
+      // seeds w, w + W, w + 2 W, ... (W = all waves of the counting blocks).  Walking them one after the other was three DEPENDENT round
+      // trips per seed — seed id -> row bounds -> column ids — 32 times in a row: 87 us per 8192-seed batch, 10.6 ms of graph-sc's 157 ms
+      // large-batch epoch (profiles/r06z_graphsc_epoch_kernels_1M_b8192.md).  Now the lanes fetch the ids and bounds of up to 64 of
+      // the wave's seeds at once (three round trips per WAVE), and a row's column ids are requested 256 at a time, two rows in flight.
+      const int W = nb_count * 4, w0 = blockIdx.x * 4 + wave;
+      for (int base = w0; base < a.B; base += 64 * W) {
+        const int mine = base + lane * W;  // this lane's seed of the group
+        int64_t v = mine < a.B ? seeds[mine] : -1;
+        const bool alien = mine < a.B && (v < a.G || v >= a.n_nodes);
+        if (alien) atomicOr(a.bad, 1);  // not a cell of this layout
+        if (mine >= a.B || alien) v = -1;
+        const int s_l = v >= 0 ? a.rowptr[v] : 0, t_l = v >= 0 ? a.rowptr[v + 1] : 0;
+        const int n_rows = min(64, (a.B - base + W - 1) / W);
+        auto row_of = [&](int k, int& s, int& t, int& vv) __attribute__((always_inline)) {
+          s = __builtin_amdgcn_readlane(s_l, k);
+          t = __builtin_amdgcn_readlane(t_l, k);
+          vv = __builtin_amdgcn_readlane((int)v, k);
+        };
+        auto fetch = [&](int s, int t, int e0, int (&c)[4]) __attribute__((always_inline)) {  // 256 entries from e0 (clamped: always a valid address)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c[j] = t > s ? a.col[min(e0 + 64 * j + lane, t - 1)] : 0;
+        };
+        auto tally = [&](int s, int t, int vv, int e0, const int (&c)[4], int& n_self) __attribute__((always_inline)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int e = e0 + 64 * j + lane;
+            const bool in = e < t;
+            if (in) {
+              if (c[j] < a.G) atomicAdd(hist + c[j], 1);
+              else if (c[j] != vv) atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
+            }
+            n_self += __popcll(__ballot(in && c[j] >= a.G));
+          }
+        };
+        int s0, t0, v0, cur[4];
+        if (n_rows > 0) {
+          row_of(0, s0, t0, v0);
+          fetch(s0, t0, s0, cur);
+        }
+        for (int k = 0; k < n_rows; ++k) {
+          int s1 = 0, t1 = 0, v1 = -1, nxt[4] = {0, 0, 0, 0};
+          if (k + 1 < n_rows) {  // the next row's first 256 ids are in flight while this row is tallied
+            row_of(k + 1, s1, t1, v1);
+            fetch(s1, t1, s1, nxt);
+          }
+          int n_self = 0;
+          if (v0 >= 0) {
+            tally(s0, t0, v0, s0, cur, n_self);
+            for (int e0 = s0 + 256; e0 < t0; e0 += 256) {  // rows beyond 256 entries: the rest on the spot
+              int more[4];
+              fetch(s0, t0, e0, more);
+              tally(s0, t0, v0, e0, more, n_self);
+            }
+            if (lane == 0 && n_self != 1) atomicOr(a.bad, 2);  // the identity decoder target needs exactly one self loop per seed
+          }
+          s0 = s1, t0 = t1, v0 = v1;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
+        }
+      }
+      __syncthreads();
+      for (int g = threadIdx.x; g < a.G; g += 256) {
+        const int h = hist[g];
+        if (h) atomicAdd(a.count + g, h);
+      }
+      return;
+    }
+    for (int i = blockIdx.x * 4 + wave; i < a.B; i += a.B) {
       const int64_t v = seeds[i];
       if (v < a.G || v >= a.n_nodes) {  // not a cell of this layout
         if (lane == 0) atomicOr(a.bad, 1);
@@ -269,8 +338,7 @@ __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64
         const int c = a.col[min(e, t - 1)];
         if (e < t) {
           if (c < a.G) {
-            if (LDS_HIST) atomicAdd(hist + c, 1);
-            else atomicAdd(a.count + c, 1);
+            atomicAdd(a.count + c, 1);
           } else if (c != v) {
             atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
           }
@@ -278,13 +346,6 @@ __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64
         n_self += __popcll(__ballot(e < t && c >= a.G));
       }
       if (lane == 0 && n_self != 1) atomicOr(a.bad, 2);  // the identity decoder target needs exactly one self loop per seed
-    }
-    if (LDS_HIST) {
-      __syncthreads();
-      for (int g = threadIdx.x; g < a.G; g += 256) {
-        const int h = hist[g];
-        if (h) atomicAdd(a.count + g, h);
-      }
     }
     return;
   }

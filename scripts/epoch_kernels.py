@@ -82,6 +82,6 @@ def diff(a, b, units):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run":
-        {"scdsc": run, "scdeepsort": run_scdeepsort, "graphsc": run_graphsc}[sys.argv[2]](int(sys.argv[3]), *(int(a) for a in sys.argv[4:5]))  # optional: cells
+        {"scdsc": run, "scdeepsort": run_scdeepsort, "graphsc": run_graphsc}[sys.argv[2]](int(sys.argv[3]), *(int(a) for a in sys.argv[4:6]))  # optional: cells (graphsc: cells, batch)
     else:
         diff(sys.argv[2], sys.argv[3], float(sys.argv[4]))

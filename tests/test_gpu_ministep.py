@@ -130,6 +130,24 @@ def test_graphsc_steps_flag_bad_seeds(cuda_device):
         st.check_flags("test")
 
 
+def test_graphsc_aggregate_phase_flags_bad_seeds(cuda_device):
+    """The large-batch counters (LDS histograms, seeds fetched 64 at a time per wave) raise the same flags as the per-seed walk: a gene id
+    among the seeds; a seed whose row has no self loop."""
+    from dance_amd.ministep import GraphSCStepper
+    g = _graph(1300, 40, 6, 2, cuda_device)
+    m = _gsc_model(6, 10, 5, "sum", 0.0, 0.0, cuda_device)
+    optim = torch.optim.Adam(m.model.parameters(), lr=1e-3, fused=True)
+    st = GraphSCStepper(m.model, g, 1100, optim)
+    seeds = (40 + torch.arange(1100)).to(cuda_device)
+    st.aggregate(seeds)
+    st.check_flags("test")  # clean
+    bad = seeds.clone()
+    bad[777] = 3
+    with pytest.raises(RuntimeError, match="not a cell row"):
+        st.aggregate(bad)
+        st.check_flags("test")
+
+
 @pytest.fixture(scope="module")
 def gold():
     return np.load(GOLD)
@@ -181,11 +199,12 @@ def test_graphsc_fit_ministep_vs_reference(cuda_device, gold, monkeypatch, tag, 
 
 
 @pytest.mark.parametrize("b,n_cells,n_genes,f,p,agg", [(40, 200, 30, 50, 0.2, "sum"), (1024, 1500, 300, 50, 0.2, "sum"), (1056, 1200, 130, 7, 0.0, "mean"),
-                                                       (1024, 1100, 257, 64, 0.1, "sum")])
+                                                       (1024, 1100, 257, 64, 0.1, "sum"), (1030, 1100, 2100, 8, 0.0, "sum")])
 def test_graphsc_aggregate_phase_vs_oracle(cuda_device, monkeypatch, b, n_cells, n_genes, f, p, agg):
     """dh_graphsc_steps phase 3: the aggregated layer input of both forwards (own dropout draws) == the oracle's A_norm (X o mask) — small
     and large batches (the LDS-histogram counters from 1024 seeds on), even / odd widths, a ragged last row tile, a gene count that is no
-    multiple of the matrix-core form's K chunk.  tests/test_gpu_ministep.py::test_graphsc_aggregate_mfma_form runs the dense-product form."""
+    multiple of the matrix-core form's K chunk, rows of more than 256 entries (the counters fetch a row's column ids 256 at a time).
+    tests/test_gpu_ministep.py::test_graphsc_aggregate_mfma_form runs the dense-product form."""
     from dance_amd.ministep import GraphSCStepper
     g = _graph(n_cells, n_genes, f, 4, cuda_device, density=0.15, normalize_edges=False)
     rowptr, col, val = _host(g)
