@@ -75,7 +75,15 @@ __global__ __launch_bounds__(256) void gemm_bf16_reduce_kernel(int64_t M, int64_
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= M * N) return;
   float v = 0.f;
-  for (int z = 0; z < slices; ++z) v += slabs[(int64_t)z * M * N + i];
+  int z = 0;
+  for (; z + 8 <= slices; z += 8) {  // eight slab values in flight, added in slice order (one loop: `slices` dependent round trips, 30 us per launch)
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = slabs[(int64_t)(z + u) * M * N + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; z < slices; ++z) v += slabs[(int64_t)z * M * N + i];
   store_out(C, ldc, i / N, i % N, v, ep);
 }
 

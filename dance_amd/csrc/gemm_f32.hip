@@ -497,7 +497,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(int64_t M, int64_t N
     const int64_t row = i / N, col = i % N;
     float* p = C + row * ldc + col;
     float s = accumulate ? *p : 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[(int64_t)z * total + i];
+    // eight slab values requested before the first is added (same order of additions): written as one loop this was S dependent round
+    // trips per element — 22 us for the 128 slabs of a 50 x 200 weight gradient (graph-sc's large batches: 5.4 ms of a 157 ms epoch in 246
+    // of these launches, profiles/r06z_graphsc_epoch_kernels_1M_b8192.md)
+    int z = 0;
+    for (; z + 8 <= S; z += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = slabs[(int64_t)(z + u) * total + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < S; ++z) s += slabs[(int64_t)z * total + i];
     if (bias) s += bias[col];
     *p = act == DH_ACT_RELU ? fmaxf(s, 0.f) : s;
   }

@@ -248,7 +248,17 @@ __global__ __launch_bounds__(256) void x3_splitk_reduce_kernel(int64_t M, int64_
     const int64_t row = i / N, col = i % N;
     float* p = C + row * ldc + col;
     float s = accumulate ? *p : 0.f;
-    for (int z = 0; z < S; ++z) s += slabs[(int64_t)z * total + i];
+    {
+      int z = 0;
+      for (; z + 8 <= S; z += 8) {  // eight partial values in flight, added in order (a plain loop is S dependent round trips)
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = slabs[(int64_t)(z + u) * total + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += t8[u];
+      }
+      for (; z < S; ++z) s += slabs[(int64_t)z * total + i];
+    }
     *p = s;
   }
 }

@@ -634,7 +634,17 @@ __global__ __launch_bounds__(256) void sage_mfma_reduce_kernel(int64_t n_dst, in
   const int c = (int)(i - cell * Dp);
   if (c >= width) return;
   float v = 0.f;
-  for (int s = 0; s < S; ++s) v += partial[((int64_t)s * n_dst + cell) * Dp + c];
+  {
+      int s = 0;
+      for (; s + 8 <= S; s += 8) {  // eight partial values in flight, added in order (a plain loop is S dependent round trips)
+        float t8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] = partial[((int64_t)(s + u) * n_dst + cell) * Dp + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v += t8[u];
+      }
+      for (; s < S; ++s) v += partial[((int64_t)s * n_dst + cell) * Dp + c];
+    }
   if (OBF16) {
     uint16_t* o = static_cast<uint16_t*>(neigh) + cell * ldn + c;
     *o = (uint16_t)f32_to_bf16(accumulate ? v + widen(*o) : v);

@@ -67,6 +67,8 @@ MINISTEP_MAX_BATCH = int(os.environ.get("DANCE_AMD_MINISTEP_MAX_BATCH", "4096"))
 class ScDeepSort(BaseClassificationMethod):
 
     shuffle_generator = None  # host torch.Generator for a reproducible train/val split and batch order (see fit)
+    # measurement aid (scripts/bench_configs.py): True -> ``epoch_ms`` holds the device time between the epoch boundaries of the last fit
+    record_epoch_times = False
     # Evaluation / prediction passes (model.eval(), no gradient): per-cell logits do not depend on how the cells are batched,
     # so with one SAGE layer they are computed for ALL cells in one piece straight on the graph's CSR rows — no sampling, no
     # feature gathers — and indexed; the two evaluate() calls of an epoch share one such pass.  False = the reference's
@@ -183,7 +185,11 @@ class ScDeepSort(BaseClassificationMethod):
         max_val_acc, _train_acc, _epoch = 0, 0, 0
         final_val_correct_num = final_val_unsure_num = 0
         best_state_dict = None
+        marks = []
         for epoch in range(epochs):
+            if self.record_epoch_times and torch.cuda.is_available():  # measurement aid: see the class attribute
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             loss = self.cal_loss(graph, train_idx)
             logits = self._full_graph_logits(graph)  # None: block-by-block evaluation
             train_acc = self.evaluate(graph, train_idx, _logits=logits)[-1]
@@ -195,6 +201,11 @@ class ScDeepSort(BaseClassificationMethod):
                 best_state_dict = deepcopy(self.model.state_dict())
             self._print(f">>>>Epoch {epoch:04d}: Train Acc {train_acc:.4f}, Loss {loss / len(train_idx):.4f}, "
                         f"Val correct {val_correct}, Val unsure {val_unsure}, Val Acc {val_acc:.4f}")
+        if marks:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
+            marks[-1].synchronize()
+            self.epoch_ms = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
         if best_state_dict is not None:
             self.model.load_state_dict(best_state_dict)
         self._print(f"---{self.species} {self.tissue} Best val result:---")

@@ -237,9 +237,17 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000, r
                     m.fit(cg, labels, epochs=e, lr=1e-3, val_ratio=0.2)
                     torch.cuda.synchronize()
                     tt[e] = min(tt.get(e, 1e9), time.perf_counter() - t0)
-                steady = (tt[7] - tt[1]) / 6
-                if steady <= 0:  # toy sizes: the call's fixed costs (and their jitter) exceed six epochs; an upper bound then
-                    steady = tt[7] / 7
+                steady_wall = (tt[7] - tt[1]) / 6
+                if steady_wall <= 0:  # toy sizes: the call's fixed costs (and their jitter) exceed six epochs; an upper bound then
+                    steady_wall = tt[7] / 7
+                # device time between the epoch boundaries of one more fit(7), first epoch left out, median: the wall-clock difference of two
+                # fits above gave 15.8 - 25.4 ms for the same kernels (a fit call's fixed costs move by more than six epochs take)
+                m.record_epoch_times = True
+                m.fit(cg, labels, epochs=7, lr=1e-3, val_ratio=0.2)
+                m.record_epoch_times = False
+                ev = sorted(m.epoch_ms[1:])
+                steady = ev[len(ev) // 2] * 1e-3
+                out["steady_wall"] = steady_wall
             best = None
             for _ in range(2):  # best of two: a fit call also writes a checkpoint
                 torch.cuda.synchronize()
@@ -324,7 +332,9 @@ def c3_scdeepsort_epoch(dev, n_cells=1_000_000, batch=65536, cpu_cells=20_000, r
     return {"workload": f"ScDeepSort.fit, one epoch = training pass (80 % of the cells, batch {batch}) + the reference's two evaluation passes, "
                         f"{n_cells} cells x {n_genes} genes at 10 % density (nnz {n_cells * per}), D = {dfeat} -> {hid}, bf16 storage + bf16 MFMA dense update",
             "ms": round(out["steady"] * 1e3, 2), "value": n_cells / out["steady"], "unit": "cells/s per epoch",
-            "ms_basis": "steady-state epoch = (fit(7 epochs) - fit(1 epoch)) / 6, best of two calls each, like configs 2 and 5; fit_call_1_epoch_ms is a whole one-epoch fit call "
+            "wall_clock_difference_ms": round(out.get("steady_wall", 0.0) * 1e3, 2),
+            "ms_basis": "steady-state epoch = median device time between the epoch boundaries of a fit(7), first epoch left out (ScDeepSort.record_epoch_times; "
+                        "wall_clock_difference_ms = (fit(7) - fit(1)) / 6, best of two calls each: what the row quoted before); fit_call_1_epoch_ms is a whole one-epoch fit call "
                         "(model construction, split, checkpoint included: the number rounds 3-4 quoted), kernels_ms belongs to that call",
             "fit_call_1_epoch_ms": round(dt * 1e3, 2), "kernels_ms": ks, "roofline": roof,
             "fp32": {"ms": round(out["fp32"][0] * 1e3, 2), "kernels_ms": out["fp32"][1]},
