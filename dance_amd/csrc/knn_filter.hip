@@ -467,14 +467,31 @@ template <bool VEC>
 __device__ __forceinline__ float chain_d2(const float* __restrict__ xq, const float* __restrict__ xc, int64_t d) {
   float acc = 0.f;
   if constexpr (VEC) {  // 16-byte aligned rows, d % 4 == 0
-    for (int64_t t = 0; t < d; t += 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(xq + t), b = *reinterpret_cast<const f32x4*>(xc + t);
+    // The chain is sequential by definition, its LOADS are not: written as one loop over 16-byte pieces this was a round trip per four
+    // features — 13 in a row for a 50-d survivor (ISA: two loads, s_waitcnt vmcnt(0), eight flops, branch), which is what the re-rank
+    // passes' 8 ms each at 1M x 50 were.  Pieces are requested 8, then 4, then 1 at a time and added in index order (same bits).
+    int64_t t = 0;
+    auto piece = [&](auto n_c) __attribute__((always_inline)) {
+      constexpr int NP = decltype(n_c)::value;
+      for (; t + 4 * NP <= d; t += 4 * NP) {
+        f32x4 a[NP], b[NP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float diff = __fsub_rn(a[u], b[u]);
-        acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+        for (int p = 0; p < NP; ++p) {
+          a[p] = *reinterpret_cast<const f32x4*>(xq + t + 4 * p);
+          b[p] = *reinterpret_cast<const f32x4*>(xc + t + 4 * p);
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float diff = __fsub_rn(a[p][u], b[p][u]);
+            acc = __fadd_rn(acc, __fmul_rn(diff, diff));
+          }
       }
-    }
+    };
+    piece(std::integral_constant<int, 8>{});
+    piece(std::integral_constant<int, 4>{});
+    piece(std::integral_constant<int, 1>{});
   } else {
     for (int64_t t = 0; t < d; ++t) {
       const float diff = __fsub_rn(xq[t], xc[t]);

@@ -3,6 +3,9 @@ python scripts/knn_time.py [n] [d] [k] [out.json]."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from dance_amd import _lib
+if os.environ.get("VARIANT"):  # A/B builds: dance_amd/libdancehip_<VARIANT>.so
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), f"libdancehip_{os.environ['VARIANT']}.so")
 from dance_amd import kernels
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
