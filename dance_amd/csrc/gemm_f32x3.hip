@@ -20,6 +20,8 @@
 // The two k-groups of a plane are 4096 + 128 bytes apart so that the loader's writes (lane pairs alternate k-groups for
 // K-contiguous operands) are conflict-free too.  LDS: 2 stages x 2 operands x 3 planes x 8448 B = 99 KB, one block per CU.
 // The transposed-A form (dW) is split over K into slabs summed in a fixed order by a second kernel (no float atomics).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -164,27 +166,35 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32x3_kernel(int64_t M, int64_t N,
   const int64_t a_kstride = (TA ? lda : 1) * 4, b_kstride = (TB ? 1 : ldb) * 4;  // bytes per unit of k
 
   const int64_t n_steps = (k_end > k_begin) ? (k_end - k_begin + BK - 1) / BK : 0;
-  float sa[8], sb[8];
+  // Round 6 (the kernel stood at 0.46 of the bf16 peak for three rounds): a step used to be  fragment reads -> wait -> 48 MFMAs ->
+  // wait for the next tile's loads -> ~100 vector instructions of splitting -> LDS stores -> barrier, one phase after the other in every
+  // wave.  Now the operand tiles travel TWO steps ahead in registers (s?[parity]): step t requests tile t + 2, and splits and stores tile
+  // t + 1 — loaded a whole step ago, so nothing waits for memory — in the issue slots between its own MFMAs (three vector instructions and
+  // an LDS write behind every MFMA, pinned by sched_group_barrier).  The stage being written (t + 1) was last read in step t - 1, a
+  // barrier ago.
+  float sa[2][8], sb[2][8];
+  auto tile_rsrc_a = [&](int64_t k0) __attribute__((always_inline)) { return make_rsrc(a_origin + k0 * a_kstride, a_end); };
+  auto tile_rsrc_b = [&](int64_t k0) __attribute__((always_inline)) { return make_rsrc(b_origin + k0 * b_kstride, b_end); };
   if (n_steps > 0) {
-    la.load(sa, make_rsrc(a_origin + k_begin * a_kstride, a_end));
-    lb.load(sb, make_rsrc(b_origin + k_begin * b_kstride, b_end));
+    la.load(sa[0], tile_rsrc_a(k_begin));
+    lb.load(sb[0], tile_rsrc_b(k_begin));
     if (k_begin + BK > k_end) {
-      la.mask(sa, k_begin, k_end);
-      lb.mask(sb, k_begin, k_end);
+      la.mask(sa[0], k_begin, k_end);
+      lb.mask(sb[0], k_begin, k_end);
     }
-    la.store(sa, lds);
-    lb.store(sb, lds + OPER);
+    la.store(sa[0], lds);
+    lb.store(sb[0], lds + OPER);
+  }
+  if (n_steps > 1) {  // tile 1 waits in the registers for step 0
+    la.load(sa[1], tile_rsrc_a(k_begin + BK));
+    lb.load(sb[1], tile_rsrc_b(k_begin + BK));
   }
   __syncthreads();
 
-  for (int64_t t = 0; t < n_steps; ++t) {
-    const int cur = t & 1;
-    const bool more = t + 1 < n_steps;
-    const int64_t k_next = k_begin + (t + 1) * BK;
-    if (more) {
-      la.load(sa, make_rsrc(a_origin + k_next * a_kstride, a_end));
-      lb.load(sb, make_rsrc(b_origin + k_next * b_kstride, b_end));
-    }
+  auto step = [&](auto par_c, int64_t t) __attribute__((always_inline)) {
+    constexpr int cur = decltype(par_c)::value, nxt = cur ^ 1;
+    const bool has1 = t + 1 < n_steps, has2 = t + 2 < n_steps;
+    const int64_t k1 = k_begin + (t + 1) * BK, k2 = k1 + BK;
     const uint16_t* a = lds + cur * STAGE + h * KG_STRIDE + (a_span + i32) * 8;
     const uint16_t* b = lds + cur * STAGE + OPER + h * KG_STRIDE + (b_span + i32) * 8;
     bf16x8_t fb[3][TN], fa[TM];
@@ -192,27 +202,52 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32x3_kernel(int64_t M, int64_t N,
     for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int y = 0; y < TN; ++y) fb[p][y] = *reinterpret_cast<const bf16x8_t*>(b + p * PLANE + y * 256);
+    // tile t + 1 (in s?[nxt] since the previous step): masked if it is the partial last one, split and stored below, between the MFMAs
+    if (__builtin_expect(has1 && k1 + BK > k_end, 0)) {  // the partial last tile of a K range whose length is no multiple of 16
+      asm volatile("; partial tile" ::: "memory");         // (keeps this a branch: if-converted, its 16 64-bit compares + selects ran in every step)
+      la.mask(sa[nxt], k1, k_end);
+      lb.mask(sb[nxt], k1, k_end);
+    }
     // A plane h: x {B_h, B_m, B_l};  A plane m: x {B_h, B_m};  A plane l: x {B_h}
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
 #pragma unroll
       for (int x = 0; x < TM; ++x) fa[x] = *reinterpret_cast<const bf16x8_t*>(a + p * PLANE + x * 256);
+      // unconditional (beyond the last tile the registers hold an old tile and the idle stage is never read again): as `if (has1)`
+      // the split sat in a block of its own IN FRONT of the MFMAs instead of between them
+      if (p == 0) la.store(sa[nxt], lds + nxt * STAGE);
+      if (p == 1) lb.store(sb[nxt], lds + nxt * STAGE + OPER);
 #pragma unroll
       for (int pb = 0; pb < 3 - p; ++pb)
 #pragma unroll
         for (int x = 0; x < TM; ++x)
 #pragma unroll
           for (int y = 0; y < TN; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[pb][y], acc[x][y], 0, 0, 0);
-    }
-    if (more) {
-      if (k_next + BK > k_end) {
-        la.mask(sa, k_next, k_end);
-        lb.mask(sb, k_next, k_end);
+      // issue order inside the plane: every MFMA is followed by up to three vector instructions of the split, then LDS traffic
+      constexpr int n_mfma = (3 - 0) * TM * TN;  // at most (plane h)
+#pragma unroll
+      for (int i = 0; i < n_mfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x300, 1, 0);
       }
-      la.store(sa, lds + (cur ^ 1) * STAGE);
-      lb.store(sb, lds + (cur ^ 1) * STAGE + OPER);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
+    // tile t + 2 into the registers tile t just left (its loads fly through the whole next step)
+    if (has2) {
+      la.load(sa[cur], tile_rsrc_a(k2));
+      lb.load(sb[cur], tile_rsrc_b(k2));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // this wave's LDS writes of tile t + 1 are done; no vmcnt(0): tile t + 2 stays in flight
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int64_t t = 0;
+    for (; t + 1 < n_steps; t += 2) {
+      step(std::integral_constant<int, 0>{}, t);
+      step(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < n_steps) step(std::integral_constant<int, 0>{}, t);
   }
 
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
