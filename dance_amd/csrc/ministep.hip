@@ -333,17 +333,19 @@ __global__ __launch_bounds__(256) void gsc_prepare_kernel(GscArgs a, const int64
       }
       const int s = a.rowptr[v], t = a.rowptr[v + 1];
       int n_self = 0;
-      for (int e0 = s; e0 < t; e0 += 64) {  // (uniform trip count: ballot over whole wavefronts)
-        const int e = e0 + lane;
-        const int c = a.col[min(e, t - 1)];
-        if (e < t) {
-          if (c < a.G) {
-            atomicAdd(a.count + c, 1);
-          } else if (c != v) {
-            atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
+      for (int e0 = s; e0 < t; e0 += 256) {  // 256 column ids requested together (one 64-id request per trip was a round trip each: 4 for a 200-gene cell)
+        int c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = a.col[min(e0 + 64 * j + lane, t - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = e0 + 64 * j + lane < t;
+          if (in) {
+            if (c[j] < a.G) atomicAdd(a.count + c[j], 1);
+            else if (c[j] != v) atomicOr(a.bad, 1);  // a cell -> cell edge other than the self loop
           }
+          n_self += __popcll(__ballot(in && c[j] >= a.G));
         }
-        n_self += __popcll(__ballot(e < t && c >= a.G));
       }
       if (lane == 0 && n_self != 1) atomicOr(a.bad, 2);  // the identity decoder target needs exactly one self loop per seed
     }
