@@ -1236,11 +1236,47 @@ __global__ __launch_bounds__(256) void sds_loss_kernel(SdsArgs a, const int64_t*
   float* w2s = sm;
   float* hw = sm + C * HL + wave * (H + 64);
   float* dlw = hw + H;
-  for (int e = tid; e < C * H; e += 256) w2s[(e / H) * HL + e % H] = a.W2[e];
   const int i = blockIdx.x * 4 + wave;
   const bool live = i < a.B;
   const int ii = live ? i : a.B - 1;
-  for (int kk = lane; kk < H; kk += 64) hw[kk] = a.h1[(int64_t)ii * H + kk];
+  // the seed -> label chain (two dependent round trips) starts before the staging loops instead of after them
+  int64_t v = seeds[ii];
+  v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
+  const int64_t lab = a.labels[v];
+  // W2 into LDS, eight elements per thread in flight (one per trip of a plain loop: 13 dependent round trips for 16 x 200 weights —
+  // most of this kernel's 11 us; found by listing loops whose only load sits in front of a wait)
+  {
+    const int n_w = C * H;
+    int e = tid;
+    for (; e + 7 * 256 < n_w; e += 8 * 256) {
+      float w8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w8[u] = a.W2[e + 256 * u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) w2s[((e + 256 * u) / H) * HL + (e + 256 * u) % H] = w8[u];
+    }
+    float w8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w8[u] = a.W2[min(e + 256 * u, n_w - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e + 256 * u < n_w) w2s[((e + 256 * u) / H) * HL + (e + 256 * u) % H] = w8[u];
+  }
+  {
+    float h4[4];  // H <= 256: the row in one batch
+    int kk = lane;
+    for (; kk + 3 * 64 < H; kk += 4 * 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) h4[u] = a.h1[(int64_t)ii * H + kk + 64 * u];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) hw[kk + 64 * u] = h4[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h4[u] = a.h1[(int64_t)ii * H + min(kk + 64 * u, H - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (kk + 64 * u < H) hw[kk + 64 * u] = h4[u];
+  }
   __syncthreads();
   const int CP = pow2_at_least(C), Q = 64 / CP, c = lane & (CP - 1), q = lane / CP;
   const int hq = (H + Q - 1) / Q, kb = q * hq, ke = min(H, kb + hq);
@@ -1254,9 +1290,6 @@ __global__ __launch_bounds__(256) void sds_loss_kernel(SdsArgs a, const int64_t*
   const float ex = c < C ? expf(logit - mx) : 0.f;
   float se = ex;
   for (int off = 1; off < CP; off <<= 1) se += __shfl_xor(se, off, 64);
-  int64_t v = seeds[ii];
-  v = v < 0 ? 0 : v >= a.n_nodes ? a.n_nodes - 1 : v;
-  const int64_t lab = a.labels[v];
   if (live && lane == 0 && (lab < 0 || lab >= C)) atomicOr(a.bad, 4);
   const float dl = c < C ? ex / se - (c == lab ? 1.f : 0.f) : 0.f;
   float lt = (c == lab) ? logit : 0.f;  // the label's logit, broadcast over the wavefront's class lanes
