@@ -1167,6 +1167,7 @@ __global__ __launch_bounds__(256) void sds_hidden_kernel(SdsArgs a, const int64_
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const bool drop = dz.thr < kKeepAll;
+  const float bias_c = a.b1[min(n0 + (tid & 31), N - 1)];  // this thread's output column (the same for its four rows): requested first, used last
   // the tile's 32 seeds: ONE load per lane through LDS (read per element they become 32 dependent scalar round trips: the row index is
   // uniform over the workgroup and the compiler moves it to an SGPR behind a wait)
   __shared__ int srow[MS_T];
@@ -1224,7 +1225,7 @@ __global__ __launch_bounds__(256) void sds_hidden_kernel(SdsArgs a, const int64_
     float vv = smem[row * MS_LD + cc];
 #pragma unroll
     for (int w = 1; w < 4; ++w) vv += smem[w * (MS_T * MS_LD) + row * MS_LD + cc];
-    if (m0 + row < M && n0 + cc < N) a.h1[(int64_t)(m0 + row) * N + n0 + cc] = fmaxf(vv + a.b1[n0 + cc], 0.f);
+    if (m0 + row < M && n0 + cc < N) a.h1[(int64_t)(m0 + row) * N + n0 + cc] = fmaxf(vv + bias_c, 0.f);
   }
 }
 
