@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_f32x3_kernel(int64_t M, int64_t N,
   // t + 1 — loaded a whole step ago, so nothing waits for memory — in the issue slots between its own MFMAs (three vector instructions and
   // an LDS write behind every MFMA, pinned by sched_group_barrier).  The stage being written (t + 1) was last read in step t - 1, a
   // barrier ago.
-  float sa[2][8], sb[2][8];
+  float sa[2][8] = {}, sb[2][8] = {};  // (zeroed: a range of one step splits and stores the never-loaded second set into the idle stage)
   auto tile_rsrc_a = [&](int64_t k0) __attribute__((always_inline)) { return make_rsrc(a_origin + k0 * a_kstride, a_end); };
   auto tile_rsrc_b = [&](int64_t k0) __attribute__((always_inline)) { return make_rsrc(b_origin + k0 * b_kstride, b_end); };
   if (n_steps > 0) {
