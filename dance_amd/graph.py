@@ -185,11 +185,17 @@ def morton_order(coords: torch.Tensor, dims: int = 3) -> torch.Tensor:
     n, d = x.shape
     mean = x.mean(0, keepdim=True)
     xc = x - mean
-    cov = (xc.t() @ xc).double() / max(n - 1, 1)                       # d x d: the one reduction over all rows
+    on_gpu = x.is_cuda
+    if on_gpu:  # the library's own products: torch's `@` brings the vendor BLAS up on its first call (tens of ms of a 90 ms set-up step)
+        from . import kernels
+        xc = xc.contiguous()
+        cov = kernels.gemm(xc, xc, trans_a=True).double() / max(n - 1, 1)
+    else:
+        cov = (xc.t() @ xc).double() / max(n - 1, 1)                   # d x d: the one reduction over all rows
     # the d x d eigen-decomposition on the host (d = 50: microseconds; the device solver's first call alone costs ~0.15 s)
     evals, evecs = np.linalg.eigh(cov.cpu().numpy())
     axes = torch.from_numpy(evecs[:, ::-1][:, :min(dims, d)].copy()).to(device=x.device, dtype=torch.float32)  # leading components first
-    proj = xc @ axes                                                   # [N, dims]
+    proj = kernels.gemm(xc, axes.contiguous()) if on_gpu else xc @ axes   # [N, dims]
     lo, hi = proj.amin(0, keepdim=True), proj.amax(0, keepdim=True)
     q = ((proj - lo) / (hi - lo).clamp_min(1e-30) * (2**21 - 1)).to(torch.int64).clamp_(0, 2**21 - 1)
 

@@ -433,3 +433,26 @@ def test_knn_grid_at_config5_size(cuda_device):
     i_f, d_f = kernels.knn(x, 15, algo=kernels.KNN_FILTER)
     assert torch.equal(i_g, i_f) and torch.equal(d_g, d_f)
     assert t_grid < 0.1, t_grid
+
+
+def test_morton_order_on_the_device(cuda_device):
+    """graph.morton_order on GPU tensors (covariance and projection through dh_gemm_f32, not the vendor BLAS): a permutation,
+    deterministic, local, and the same curve as the host run of the same points up to ties of the 21-bit quantisation."""
+    from dance_amd.graph import morton_order
+    g = torch.Generator().manual_seed(0)
+    centres = torch.randn(8, 12, generator=g) * 6
+    x = centres[torch.randint(0, 8, (6000, ), generator=g)] + torch.randn(6000, 12, generator=g)
+    xd = x.to(cuda_device)
+    p = morton_order(xd)
+    assert p.is_cuda and sorted(p.tolist()) == list(range(6000)) and torch.equal(p, morton_order(xd))
+    step_ord = (xd[p][1:] - xd[p][:-1]).norm(dim=1).mean()
+    step_in = (xd[1:] - xd[:-1]).norm(dim=1).mean()
+    assert float(step_ord) < 0.5 * float(step_in)
+    ph = morton_order(x)
+    inv_d, inv_h = torch.empty(6000, dtype=torch.int64), torch.empty(6000, dtype=torch.int64)
+    inv_d[p.cpu()] = torch.arange(6000)
+    inv_h[ph] = torch.arange(6000)
+    # positions along the curve agree (an eigenvector's sign may flip an axis between the two eigen-solvers' inputs: then the order is mirrored per axis,
+    # which keeps neighbours neighbours): compare the locality, not the positions
+    nb_d = (inv_d[ph[1:]] - inv_d[ph[:-1]]).abs().float().median()
+    assert float(nb_d) <= 8.0
