@@ -138,12 +138,18 @@ def synth_knn_graph(n, k, device, seed, reorder=True, order="morton"):
     g = torch.Generator(device=device).manual_seed(seed)
     centers = torch.randn((20, 50), device=device, generator=g) * 4.0
     emb = centers[torch.randint(0, 20, (n, ), device=device, generator=g)] + torch.randn((n, 50), device=device, generator=g)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    idx, dist_ = kernels.knn(emb, k)
-    (rowptr, col, val), _ = kernels.umap_connectivities(idx, dist_.contiguous())
-    torch.cuda.synchronize()
-    build_s = time.perf_counter() - t0
+    def build():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx, dist_ = kernels.knn(emb, k)
+        out = kernels.umap_connectivities(idx, dist_.contiguous())[0]
+        torch.cuda.synchronize()
+        return out, time.perf_counter() - t0
+    # built twice, the second (steady) time reported: a process's first build also pays the first launches of a dozen kernels and the
+    # first allocation of a multi-GB workspace — 0.18 - 0.41 s over the boxes of round 6 for the same 0.16 s of kernels
+    _, build_cold_s = build()
+    (rowptr, col, val), build_s = build()
+    synth_knn_graph.cold_build_s = build_cold_s
     graph = CSRGraph(rowptr, col, val, n, n, symmetric=True)
     if not reorder:
         return graph, None, None, build_s, (0.0, 0.0)
@@ -492,7 +498,7 @@ def main():
                                f"{'Z-order over the 3 leading principal components of the embedding (device)' if args.locality == 'morton' else 'reverse Cuthill-McKee (host)'}"
                                f" (graph set-up), X permuted once, outputs identical row for row",
                    "locality_order": args.locality,
-                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "locality_order_s": round(order_s[0], 4), "locality_permute_s": round(order_s[1], 4),
+                   "nnz": int(kg.nnz), "graph_build_s": round(build_s, 4), "graph_build_first_call_s": round(getattr(synth_knn_graph, "cold_build_s", 0.0), 4), "locality_order_s": round(order_s[0], 4), "locality_permute_s": round(order_s[1], 4),
                    "locality_note": "locality_order_s = computing the order only (as BENCH_r05 reported it); rounds 3-4 quoted order + permutation as one figure",
                    "ms_per_step": o_ms, "value": n / (o_elapsed / args.steps), "unit": "cells/s",
                    "layer_hbm_frac": round(layer_bytes(n, kg.nnz) / (o_ms * 1e-3) / (PEAK_HBM_GBS * 1e9), 4),
